@@ -1,0 +1,167 @@
+"""Pin the functional StyleGAN2 oracle (oracle/stylegan2.py, oracle/training.py) against
+outputs of the reference's own modules and its own train() loop (tools/make_golden.py)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import t
+from oracle import stylegan2 as S
+from oracle import training as T
+
+TINY = dict(image_size=16, image_channels=3, style_dim=16, channels=4, max_channels=16,
+            block_num_conv=2, map_num_layers=2, map_lr=0.01, mbsd_groups=4)
+
+
+def sub(g, prefix):
+    return {k[len(prefix):]: t(v).clone() for k, v in g.items() if k.startswith(prefix)}
+
+
+def test_state_dict_key_surface(golden):
+    g = golden('sg2_model')
+    cfg = S.Config(**TINY)
+    G, D = sub(g, 'G/'), sub(g, 'D/')
+    gs, ds = S.generator_state_shapes(cfg), S.discriminator_state_shapes(cfg)
+    assert set(gs) == set(G) and set(ds) == set(D)
+    for k in gs:
+        assert tuple(G[k].shape) == tuple(gs[k]), k
+    for k in ds:
+        assert tuple(D[k].shape) == tuple(ds[k]), k
+
+
+def test_param_counts_at_benchmark_configs():
+    # G(256)=19,351,809 D(256)=21,401,537 G(128)=13,842,684 D(128)=16,419,265
+    for size, ng, nd in [(256, 19351809, 21401537), (128, 13842684, 16419265)]:
+        cfg = S.Config(image_size=size)
+        n_g = sum(int(np.prod(s)) for k, s in S.generator_state_shapes(cfg).items() if not k.endswith('.kernel'))
+        n_d = sum(int(np.prod(s)) for s in S.discriminator_state_shapes(cfg).values())
+        assert (n_g, n_d) == (ng, nd)
+
+
+def test_generator_discriminator_forward_and_grads(golden):
+    g = golden('sg2_model')
+    cfg = S.Config(**TINY)
+    G, D = sub(g, 'G/'), sub(g, 'D/')
+    for v in list(G.values()) + list(D.values()):
+        v.requires_grad_(True)
+    noise = S.NoiseSource([t(g[f'noise{i}']) for i in range(int(g['n_noise']))])
+    image, style = S.generator(G, cfg, t(g['z']), noise=noise)
+    torch.testing.assert_close(style, t(g['style']), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(image, t(g['image']), rtol=1e-4, atol=1e-5)
+    logits = S.discriminator(D, cfg, image)
+    torch.testing.assert_close(logits, t(g['logits']), rtol=1e-4, atol=1e-4)
+    loss = torch.nn.functional.softplus(-logits).mean()
+    torch.testing.assert_close(loss, t(g['g_loss']), rtol=1e-5, atol=1e-6)
+    gn = [k[len('gradG/'):] for k in g if k.startswith('gradG/')]
+    dn = [k[len('gradD/'):] for k in g if k.startswith('gradD/')]
+    grads = torch.autograd.grad(loss, [G[k] for k in gn] + [D[k] for k in dn])
+    for k, gr in zip(gn, grads[:len(gn)]):
+        torch.testing.assert_close(gr, t(g['gradG/' + k]), rtol=2e-3, atol=1e-6, msg=lambda m, k=k: f'{k}: {m}')
+    for k, gr in zip(dn, grads[len(gn):]):
+        torch.testing.assert_close(gr, t(g['gradD/' + k]), rtol=2e-3, atol=1e-6, msg=lambda m, k=k: f'{k}: {m}')
+
+
+def test_style_mixing(golden):
+    g = golden('sg2_model')
+    cfg = S.Config(**TINY)
+    G = sub(g, 'G/')
+    noise = S.NoiseSource([t(g[f'mixnoise{i}']) for i in range(int(g['n_noise']))])
+    image, _ = S.generator(G, cfg, (t(g['z']), t(g['z2'])), noise=noise, injection=2)
+    torch.testing.assert_close(image, t(g['image_mix']), rtol=1e-4, atol=1e-5)
+
+
+def test_modulated_conv_and_toimage(golden):
+    g = golden('sg2_model')
+    mc, ti = sub(g, 'mc/'), sub(g, 'ti/')
+    for v in list(mc.values()) + list(ti.values()):
+        v.requires_grad_(True)
+    x = t(g['mc_x']).requires_grad_(True)
+    y = t(g['mc_y']).requires_grad_(True)
+    out = S.modulated_conv2d({'m.' + k: v for k, v in mc.items()}, 'm', x, y)
+    torch.testing.assert_close(out, t(g['mc_out']), rtol=1e-4, atol=1e-5)
+    gx, gy, gw, gb = torch.autograd.grad(out, [x, y, mc['weight'], mc['bias']], t(g['mc_dout']))
+    for a, k in [(gx, 'mc_gx'), (gy, 'mc_gy'), (gw, 'mc_gw'), (gb, 'mc_gb')]:
+        torch.testing.assert_close(a, t(g[k]), rtol=1e-4, atol=1e-4)
+    sd = {'m.' + k: v for k, v in ti.items()}
+    out2 = S.upsample2x(S.modulated_conv2d(sd, 'm.conv', x, y, demod=False) + t(g['ti_pre']))
+    torch.testing.assert_close(out2, t(g['ti_out']), rtol=1e-4, atol=1e-5)
+    gx2, gy2, gw2 = torch.autograd.grad(out2, [x, y, ti['conv.weight']], t(g['ti_dout']))
+    for a, k in [(gx2, 'ti_gx'), (gy2, 'ti_gy'), (gw2, 'ti_gw')]:
+        torch.testing.assert_close(a, t(g[k]), rtol=1e-4, atol=1e-4)
+
+
+def test_losses_r1_pl_ema_diffaugment(golden):
+    g = golden('sg2_train')
+    cfg = S.Config(**TINY)
+    G, D = sub(g, 'G0/'), sub(g, 'D0/')
+    for v in list(G.values()) + list(D.values()):
+        v.requires_grad_(True)
+    torch.testing.assert_close(T.ns_d_loss(t(g['rp']), t(g['fp'])), t(g['ns_d']))
+    torch.testing.assert_close(T.ns_g_loss(t(g['fp'])), t(g['ns_g']))
+    real = t(g['real'])
+    r1 = T.r1_penalty(real, lambda x: S.discriminator(D, cfg, x))
+    torch.testing.assert_close(r1, t(g['r1']), rtol=1e-4, atol=1e-6)
+    names = [k[len('r1grad/'):] for k in g if k.startswith('r1grad/')]
+    grads = torch.autograd.grad(r1, [D[k] for k in names])
+    for k, gr in zip(names, grads):
+        torch.testing.assert_close(gr, t(g['r1grad/' + k]), rtol=2e-3, atol=1e-5, msg=lambda m, k=k: f'{k}: {m}')
+    # path length
+    noise = S.NoiseSource([t(g[f'pl_noise{i}']) for i in range(4)])
+    fake, style = S.generator(G, cfg, t(g['pl_z']), noise=noise)
+    pl = T.pl_penalty(style, fake, 0.3, noise=t(g['pl_noise']))
+    torch.testing.assert_close(pl, t(g['pl']), rtol=1e-4, atol=1e-6)
+    assert abs(T.update_pl_mean(0.3, float(pl)) - float(g['pl_mean_next'])) < 1e-6
+    names = [k[len('plgrad/'):] for k in g if k.startswith('plgrad/')]
+    grads = torch.autograd.grad(pl, [G[k] for k in names])
+    for k, gr in zip(names, grads):
+        torch.testing.assert_close(gr, t(g['plgrad/' + k]), rtol=2e-3, atol=1e-5, msg=lambda m, k=k: f'{k}: {m}')
+    # DiffAugment: same global-RNG consumption order as the reference
+    torch.manual_seed(12)
+    out = T.diffaugment(real, 'color,translation', T.diffaug_draws(real, 'color,translation'))
+    torch.testing.assert_close(out, t(g['aug_out']), rtol=1e-6, atol=1e-6)
+    # EMA
+    G2 = {k: v.detach().clone() for k, v in G.items()}
+    E = {k: v.detach().clone() for k, v in G.items()}
+    pk = {k for k in G2 if not k.endswith('.kernel')}
+    for step in range(3):
+        for k in pk:
+            G2[k] += 0.01 * (step + 1)
+        T.update_ema(G2, E, param_keys=pk)
+    torch.testing.assert_close(E['const'], t(g['ema/const']))
+    torch.testing.assert_close(E['synthesis.input.weight'], t(g['ema/w']))
+
+
+def test_lazy_adam_hparams(golden):
+    g = golden('sg2_train')
+    lr, b0, b1, d_k, g_k, r1l, pll = [float(v) for v in g['train_hparams']]
+    glr, gb = T.lazy_adam_hparams(lr, (b0, b1), g_k, pll)
+    dlr, db = T.lazy_adam_hparams(lr, (b0, b1), d_k, r1l)
+    np.testing.assert_allclose([glr, *gb, dlr, *db], g['train_adam'], rtol=1e-12)
+    assert T.lazy_adam_hparams(0.001, (0., 0.99), 8, 0.) == (0.001, (0., 0.99))     # pl_lambda = 0 default: no rescale
+
+
+def test_train_loop_replay_matches_reference_train(golden):
+    """4 iterations of the reference's own train() (iteration 2 = lazy R1 + PL iteration, loss REPLACED)."""
+    g = golden('sg2_train')
+    cfg = S.Config(**TINY)
+    G, D = sub(g, 'G0/'), sub(g, 'D0/')
+    E = {k: v.clone() for k, v in G.items()}
+    lr, b0, b1, d_k, g_k, r1l, pll = [float(v) for v in g['train_hparams']]
+    st = T.StepState(cfg, G, E, D, lr=lr, betas=(b0, b1), r1_lambda=r1l, pl_lambda=pll, d_k=int(d_k), g_k=int(g_k))
+    torch.manual_seed(13)
+    sampler = lambda size: torch.empty(size).normal_()
+    const_z = sampler((2, cfg.style_dim))
+    losses = []
+    for it in range(4):
+        out = T.train_iteration(st, t(g['train_real'][it]), sampler)
+        losses.append([out['D_loss'], out['G_loss']])
+        if it == 0:
+            # utils.py:119-123: at batches_done % save == 0 the loop evaluates G_ema(const_z), consuming noise draws
+            with torch.no_grad():
+                S.generator(E, cfg, const_z)
+    np.testing.assert_allclose(np.array(losses), g['train_losses'], rtol=2e-4, atol=1e-6)
+    for k, v in sub(g, 'G4/').items():
+        torch.testing.assert_close(G[k].detach(), v, rtol=1e-3, atol=2e-5, msg=lambda m, k=k: f'G {k}: {m}')
+    for k, v in sub(g, 'D4/').items():
+        torch.testing.assert_close(D[k].detach(), v, rtol=1e-3, atol=2e-5, msg=lambda m, k=k: f'D {k}: {m}')
+    for k, v in sub(g, 'Gema4/').items():
+        torch.testing.assert_close(E[k].detach(), v, rtol=1e-3, atol=2e-5, msg=lambda m, k=k: f'Gema {k}: {m}')

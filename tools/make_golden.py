@@ -1,0 +1,492 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by running the REFERENCE itself.
+
+Runs only in the build container (needs /root/reference, CPU only).  The
+reference ships no tests or golden vectors, so parity is pinned to
+outputs of the reference's own code paths executed here:
+
+  * thirdparty/stylegan3_ops/ops/{upfirdn2d,bias_act,filtered_lrelu}.py  (their `_ref` paths,
+    selected automatically for CPU tensors)
+  * implementations/StyleGAN2/model.py (Generator / Discriminator / ModulatedConv2d / ToImage)
+  * nnutils/loss (NonSaturatingLoss, r1_regularizer), implementations/StyleGAN2/utils.py
+    (pl_penalty, update_pl_mean, train), nnutils/training.py (update_ema),
+    thirdparty/diffaugment/DiffAugment.py
+
+Only data (inputs + expected outputs) is written; no reference source travels.
+torch / scipy versions are recorded inside each fixture.
+
+    PYTHONDONTWRITEBYTECODE=1 python tools/make_golden.py
+"""
+import functools
+import io
+import os
+import sys
+import types
+import itertools
+
+import numpy as np
+import torch
+
+REF = '/root/reference'
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden')
+sys.dont_write_bytecode = True
+
+
+def import_reference():
+    sys.path.insert(0, REF)
+    # torchvision / loguru are absent from this image; the reference only needs the names.
+    for name in ['torchvision', 'torchvision.utils', 'torchvision.transforms',
+                 'torchvision.transforms.functional', 'torchvision.models', 'torchvision.datasets', 'loguru']:
+        sys.modules[name] = types.ModuleType(name)
+    tv = sys.modules['torchvision']
+    tv.utils, tv.transforms, tv.models = sys.modules['torchvision.utils'], sys.modules['torchvision.transforms'], sys.modules['torchvision.models']
+    tv.datasets = sys.modules['torchvision.datasets']
+    tv.transforms.functional = sys.modules['torchvision.transforms.functional']
+    tv.utils.save_image = lambda *a, **k: None
+
+    class _Anything:
+        def __getattr__(self, k):
+            return _Anything()
+
+        def __call__(self, *a, **k):
+            return _Anything()
+    sys.modules['loguru'].logger = _Anything()
+    def _stub_attr(k):
+        if k.startswith('__'):
+            raise AttributeError(k)
+        return _Anything()
+    for m in ['torchvision.transforms', 'torchvision.models', 'torchvision.datasets', 'torchvision.transforms.functional']:
+        sys.modules[m].__getattr__ = _stub_attr
+
+
+def meta():
+    import scipy
+    return dict(torch_version=np.array(torch.__version__), scipy_version=np.array(scipy.__version__))
+
+
+def save(name, **arrays):
+    os.makedirs(OUT, exist_ok=True)
+    conv = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        conv[k] = np.asarray(v)
+    conv.update(meta())
+    path = os.path.join(OUT, name + '.npz')
+    np.savez_compressed(path, **conv)
+    print(f'{name}: {os.path.getsize(path) / 1024:.1f} KiB, {len(conv)} arrays')
+
+
+# ------------------------------------------------------------------------------------------------
+
+def gen_upfirdn2d():
+    from thirdparty.stylegan3_ops.ops import upfirdn2d as U
+    g = torch.Generator().manual_seed(0)
+    x = torch.randint(-4, 5, (2, 3, 9, 11), generator=g).float()
+    filters = {
+        'none': None,
+        'box2': torch.tensor([1., 1.]).ger(torch.tensor([1., 1.])),
+        'tri3': torch.tensor([1., 2., 1.]).ger(torch.tensor([1., 2., 1.])),
+        'bil4': torch.tensor([1., 3., 3., 1.]).ger(torch.tensor([1., 3., 3., 1.])),
+        'sep12': torch.tensor([1., -2., 3., 4., -1., 2., 2., 1., -3., 1., 2., 1.]),
+        'ns2x3': torch.tensor([[1., -2., 3.], [2., 1., -1.]]),
+    }
+    arrays = {'x': x}
+    case = 0
+    specs = []
+    for (fname, f), up, down, pad, flip in itertools.product(
+            filters.items(), [1, 2, 3, 4, (2, 1), (1, 2)], [1, 2, 4, (1, 3)],
+            [0, [2, 1, 0, 3], [-1, 2, 3, -2]], [False, True]):
+        # keep the matrix affordable: full cross only for the small filters
+        if fname in ('sep12',) and (up in (3, (2, 1), (1, 2)) or down in ((1, 3),)):
+            continue
+        try:
+            y = U.upfirdn2d(x, f, up=up, down=down, padding=pad, flip_filter=flip, gain=4)  # 4: exact in both the 2-D and the sqrt-split separable ref path
+        except Exception:
+            continue
+        if y.numel() == 0 or min(y.shape) < 1:
+            continue
+        arrays[f'y{case}'] = y
+        upx, upy = (up, up) if isinstance(up, int) else up
+        dnx, dny = (down, down) if isinstance(down, int) else down
+        p = [pad] * 4 if isinstance(pad, int) else pad
+        specs.append([list(filters).index(fname), upx, upy, dnx, dny, *p, int(flip)])
+        case += 1
+    for k, f in filters.items():
+        if f is not None:
+            arrays['f_' + k] = f
+    arrays['specs'] = np.array(specs, dtype=np.int64)
+    arrays['filter_names'] = np.array(list(filters))
+    save('upfirdn2d_int', **arrays)
+
+    # float cases with first- and second-order gradients (wrappers + raw op)
+    g = torch.Generator().manual_seed(1)
+    xf = torch.randn(2, 4, 12, 10, generator=g)
+    arrays = {'x': xf}
+    f4 = U.setup_filter([1, 3, 3, 1])
+    f3 = U.setup_filter([1, 2, 1])
+    f2 = U.setup_filter([1, 1])
+    f12 = U.setup_filter([1., 2., 4., 7., 10., 12., 12., 10., 7., 4., 2., 1.])
+    arrays.update(f4=f4, f3=f3, f2=f2, f12=f12)
+    ops = {
+        'up2_f4': lambda t: U.upsample2d(t, f4, up=2),
+        'down2_f4': lambda t: U.downsample2d(t, f4, down=2),
+        'down2_f2': lambda t: U.downsample2d(t, f2, down=2),
+        'blur_f3': lambda t: U.filter2d(t, f3),
+        'up2_f12': lambda t: U.upsample2d(t, f12, up=2),
+        'down2_f12': lambda t: U.downsample2d(t, f12, down=2),
+        'up4_f12_pad': lambda t: U.upfirdn2d(t, f12, up=4, padding=[3, 2, 1, 4], gain=16),
+    }
+    for name, op in ops.items():
+        t = xf.clone().requires_grad_(True)
+        y = op(t)
+        dy = torch.randn(y.shape, generator=g).requires_grad_(True)
+        dx, = torch.autograd.grad(y, t, dy, create_graph=True)
+        ddx = torch.randn(dx.shape, generator=g)
+        ddy, = torch.autograd.grad(dx, dy, ddx)
+        arrays.update({f'{name}_y': y, f'{name}_dy': dy, f'{name}_dx': dx, f'{name}_ddx': ddx, f'{name}_ddy': ddy})
+    save('upfirdn2d_float', **arrays)
+
+    # setup_filter table
+    arrays = {}
+    for i, (taps, kw) in enumerate([
+            ([1, 3, 3, 1], {}), ([1, 2, 1], dict(gain=4)), ([1, 1], dict(normalize=False)),
+            (list(range(1, 13)), {}), (list(range(1, 13)), dict(flip_filter=True, gain=2)),
+            ([[1, 2], [3, 4]], dict(flip_filter=True)), (None, {}), ([1, 2, 3, 4, 5, 6, 7, 8], dict(separable=False))]):
+        arrays[f'sf{i}'] = U.setup_filter(taps, **kw)
+    save('setup_filter', **arrays)
+
+
+def gen_sg2_equivalences():
+    """The three StyleGAN2 resampling layers the product maps onto upfirdn2d."""
+    sg2 = import_sg2_model()
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 5, 8, 6, generator=g)
+    up = sg2.Upsample2x('bilinear')(x)
+    blur = sg2.Blur2d()(up)
+    pool = sg2.Downsample2x('avg')(blur)
+    save('sg2_resample', x=x, up=up, blur=blur, pool=pool)
+
+
+def gen_bias_act():
+    from thirdparty.stylegan3_ops.ops import bias_act as B
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(3, 5, 4, 6, generator=g) * 2
+    b = torch.randn(5, generator=g)
+    x2 = torch.randn(7, 5, generator=g) * 2
+    arrays = dict(x=x, b=b, x2=x2)
+    for act in B.activation_funcs:
+        for ci, clamp in enumerate([None, 0.5]):
+            for bi, use_b in enumerate([False, True]):
+                tag = f'{act}_c{ci}_b{bi}'
+                xt = x.clone().requires_grad_(True)
+                bt = b.clone().requires_grad_(True)
+                y = B.bias_act(xt, bt if use_b else None, dim=1, act=act, clamp=clamp)
+                dy = torch.randn(y.shape, generator=g).requires_grad_(True)
+                ins = [xt, bt] if use_b else [xt]
+                grads = torch.autograd.grad(y, ins, dy, create_graph=True)
+                arrays[tag + '_y'] = y
+                arrays[tag + '_dy'] = dy
+                arrays[tag + '_dx'] = grads[0]
+                if use_b:
+                    arrays[tag + '_db'] = grads[1]
+                # second order: d/d(dy) and d/dx of <dx, ddx>
+                ddx = torch.randn(x.shape, generator=g)
+                s = (grads[0] * ddx).sum()
+                g2 = torch.autograd.grad(s, [dy, xt], allow_unused=True)
+                arrays[tag + '_ddx'] = ddx
+                arrays[tag + '_ddy'] = g2[0]
+                arrays[tag + '_d2x'] = g2[1] if g2[1] is not None else torch.zeros_like(x)
+        # dim=1 on a rank-2 tensor with non-default alpha/gain
+        y2 = B.bias_act(x2, b, dim=1, act=act, alpha=0.3, gain=1.7)
+        arrays[f'{act}_rank2_y'] = y2
+    save('bias_act', **arrays)
+
+
+def sg3_filter(numtaps, cutoff, width, fs, radial=False):
+    """Call the reference's own low-pass design (implementations/StyleGAN3/model.py:76-93)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('sg3model', os.path.join(REF, 'implementations/StyleGAN3/model.py'))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m.design_filter(numtaps=numtaps, cutoff=cutoff, width=width, fs=fs, radial=radial)
+
+
+def gen_filtered_lrelu():
+    from thirdparty.stylegan3_ops.ops import filtered_lrelu as FL
+    g = torch.Generator().manual_seed(4)
+    fu12 = sg3_filter(12, 2.0, 2.2, 8.0)                  # separable 12-tap (up=2)
+    fu24 = sg3_filter(24, 2.0, 2.2, 16.0)                 # separable 24-tap (up=4)
+    fd12 = sg3_filter(12, 2.0, 2.2, 8.0)                  # separable 12-tap down
+    fd12r = sg3_filter(12, 2.0, 2.2, 8.0, radial=True)    # 12x12 radial down
+    arrays = dict(fu12=fu12, fu24=fu24, fd12=fd12, fd12r=fd12r)
+    # (name, fu, fd, up, down, padding, C, S_in, clamp) -- the SG3-512 kernel configs of SURVEY.md section 8 a14, small spatial size
+    cfgs = [
+        ('u2_fd12r', 'fu12', 'fd12r', 2, 2, [9, 8, 9, 8], 3, 14, 256.0),
+        ('u4_fd12r', 'fu24', 'fd12r', 4, 2, [-6, -9, -6, -9], 3, 16, 256.0),
+        ('u2_fd12s', 'fu12', 'fd12', 2, 2, [9, 8, 9, 8], 3, 14, 256.0),
+        ('u2_fd12s_crop', 'fu12', 'fd12', 2, 2, [-11, -12, -11, -12], 2, 30, 256.0),
+        ('u1_d1', None, None, 1, 1, 0, 3, 12, 256.0),
+        ('u2_fd12s_clamp', 'fu12', 'fd12', 2, 2, [9, 8, 9, 8], 3, 14, 0.4),
+        ('u2_only', 'fu12', None, 2, 1, [5, 6, 5, 6], 2, 10, None),
+        ('d2_only', None, 'fd12', 1, 2, [5, 6, 5, 6], 2, 20, 1.0),
+    ]
+    names = []
+    for name, fu_k, fd_k, up, down, pad, C, S, clamp in cfgs:
+        fu = arrays[fu_k] if fu_k else None
+        fd = arrays[fd_k] if fd_k else None
+        x = (torch.randn(2, C, S, S, generator=g) * 1.5).requires_grad_(True)
+        b = torch.randn(C, generator=g).requires_grad_(True)
+        gain, slope = (np.sqrt(2), 0.2) if name != 'u1_d1' else (1.0, 1.0)
+        y = FL.filtered_lrelu(x, fu=fu, fd=fd, b=b, up=up, down=down, padding=pad, gain=gain, slope=slope, clamp=clamp)
+        dy = torch.randn(y.shape, generator=g).requires_grad_(True)
+        dx, db = torch.autograd.grad(y, [x, b], dy, create_graph=True)
+        ddx = torch.randn(dx.shape, generator=g)
+        ddy, = torch.autograd.grad(dx, dy, ddx)
+        p = [pad] * 4 if isinstance(pad, int) else pad
+        arrays.update({f'{name}_x': x, f'{name}_b': b, f'{name}_y': y, f'{name}_dy': dy, f'{name}_dx': dx,
+                       f'{name}_db': db, f'{name}_ddx': ddx, f'{name}_ddy': ddy,
+                       f'{name}_cfg': np.array([up, down, *p], dtype=np.int64),
+                       f'{name}_gsc': np.array([gain, slope, -1.0 if clamp is None else clamp], dtype=np.float64),
+                       f'{name}_fu': np.array(fu_k or ''), f'{name}_fd': np.array(fd_k or '')})
+        names.append(name)
+    arrays['names'] = np.array(names)
+    save('filtered_lrelu', **arrays)
+
+
+def import_sg2_model():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('ref_sg2_model', os.path.join(REF, 'implementations/StyleGAN2/model.py'))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+TINY = dict(image_size=16, image_channels=3, style_dim=16, channels=4, max_channels=16,
+            block_num_conv=2, map_num_layers=2, map_lr=0.01, mbsd_groups=4)
+
+
+def build_tiny(sg2, seed):
+    torch.manual_seed(seed)
+    G = sg2.Generator(TINY['image_size'], TINY['image_channels'], TINY['style_dim'], TINY['channels'],
+                      TINY['max_channels'], TINY['block_num_conv'], TINY['map_num_layers'], True, TINY['map_lr'])
+    D = sg2.Discriminator(TINY['image_size'], TINY['image_channels'], TINY['channels'], TINY['max_channels'],
+                          TINY['block_num_conv'], TINY['mbsd_groups'])
+    G.init_weight(functools.partial(sg2.init_weight_N01, lr=TINY['map_lr']), sg2.init_weight_N01)
+    D.apply(sg2.init_weight_N01)
+    # non-zero biases so bias handling is actually exercised
+    with torch.no_grad():
+        for p in list(G.parameters()) + list(D.parameters()):
+            if p.ndim in (1, 4) and p.abs().sum() == 0 and p.numel() > 1:
+                p.normal_(0, 0.3)
+    return G, D
+
+
+def capture_noise(G, sg2):
+    draws = []
+    hooks = []
+    for m in G.modules():
+        if isinstance(m, sg2.InjectNoise):
+            hooks.append(m.register_forward_hook(lambda mod, inp, out: draws.append((out - inp[0]).detach()[:, :1].clone())))
+    return draws, hooks
+
+
+def gen_sg2_model():
+    sg2 = import_sg2_model()
+    G, D = build_tiny(sg2, 5)
+    arrays = {}
+    for k, v in G.state_dict().items():
+        arrays['G/' + k] = v
+    for k, v in D.state_dict().items():
+        arrays['D/' + k] = v
+    g = torch.Generator().manual_seed(6)
+    z = torch.randn(4, TINY['style_dim'], generator=g)
+    draws, hooks = capture_noise(G, sg2)
+    image, style = G(z)
+    for h in hooks:
+        h.remove()
+    logits = D(image)
+    arrays.update(z=z, image=image, style=style, logits=logits)
+    for i, d in enumerate(draws):
+        arrays[f'noise{i}'] = d
+    arrays['n_noise'] = np.array(len(draws))
+    # gradients of sum(softplus(-D(G(z)))) w.r.t. a few parameters of G and D (the G-step's backward)
+    loss = torch.nn.functional.softplus(-logits).mean()
+    names_g = ['const', 'synthesis.input.weight', 'synthesis.blocks.1.block.5.weight', 'synthesis.blocks.0.block.2.affine.layer.weight',
+               'synthesis.to_images.1.conv.weight', 'synthesis.blocks.1.block.2.bias', 'map.map.0.linear.layer.weight']
+    names_d = ['from_rgb.0.layer.weight', 'blocks.0.block.2.layer.weight', 'blocks.1.skip.layer.weight', 'blocks.3.layer.bias']
+    pg, pd = dict(G.named_parameters()), dict(D.named_parameters())
+    grads = torch.autograd.grad(loss, [pg[n] for n in names_g] + [pd[n] for n in names_d])
+    arrays['g_loss'] = loss
+    for n, gr in zip(names_g, grads[:len(names_g)]):
+        arrays['gradG/' + n] = gr
+    for n, gr in zip(names_d, grads[len(names_g):]):
+        arrays['gradD/' + n] = gr
+    # style mixing
+    z2 = torch.randn(4, TINY['style_dim'], generator=g)
+    draws2, hooks = capture_noise(G, sg2)
+    image_mix, _ = G((z, z2), injection=2)
+    for h in hooks:
+        h.remove()
+    arrays.update(z2=z2, image_mix=image_mix)
+    for i, d in enumerate(draws2):
+        arrays[f'mixnoise{i}'] = d
+
+    # layer-level: ModulatedConv2d (k=3 demod, k=1 no demod) and ToImage with grads
+    torch.manual_seed(7)
+    mc = sg2.ModulatedConv2d(6, 5, 8, 3)
+    ti = sg2.ToImage(6, 3, 8, upsample=True)
+    for m in (mc, ti):
+        m.apply(sg2.init_weight_N01)
+        with torch.no_grad():
+            for p in m.parameters():
+                if p.abs().sum() == 0:
+                    p.normal_(0, 0.3)
+    x = torch.randn(3, 6, 7, 7, generator=g).requires_grad_(True)
+    y = torch.randn(3, 8, generator=g).requires_grad_(True)
+    pre = torch.randn(3, 3, 7, 7, generator=g)
+    out = mc(x, y)
+    dout = torch.randn(out.shape, generator=g)
+    gx, gy, gw, gb = torch.autograd.grad(out, [x, y, mc.weight, mc.bias], dout)
+    for k, v in mc.state_dict().items():
+        arrays['mc/' + k] = v
+    arrays.update(mc_x=x, mc_y=y, mc_out=out, mc_dout=dout, mc_gx=gx, mc_gy=gy, mc_gw=gw, mc_gb=gb)
+    out2 = ti(x, y, pre)
+    dout2 = torch.randn(out2.shape, generator=g)
+    gx2, gy2, gw2 = torch.autograd.grad(out2, [x, y, ti.conv.weight], dout2)
+    for k, v in ti.state_dict().items():
+        arrays['ti/' + k] = v
+    arrays.update(ti_pre=pre, ti_out=out2, ti_dout=dout2, ti_gx=gx2, ti_gy=gy2, ti_gw=gw2)
+    save('sg2_model', **arrays)
+
+
+def gen_losses_and_train():
+    sg2 = import_sg2_model()
+    from nnutils.loss import NonSaturatingLoss, r1_regularizer
+    from nnutils.training import update_ema
+    import implementations.StyleGAN2.utils as ref_utils
+    from thirdparty.diffaugment import DiffAugment
+
+    arrays = {}
+    G, D = build_tiny(sg2, 8)
+    for k, v in G.state_dict().items():
+        arrays['G0/' + k] = v.clone()
+    for k, v in D.state_dict().items():
+        arrays['D0/' + k] = v.clone()
+    g = torch.Generator().manual_seed(9)
+    real = torch.rand(4, 3, 16, 16, generator=g) * 2 - 1
+    arrays['real'] = real
+
+    # losses on fixed logits
+    rp, fp = torch.randn(4, 1, generator=g), torch.randn(4, 1, generator=g)
+    L = NonSaturatingLoss()
+    arrays.update(rp=rp, fp=fp, ns_d=L.d_loss(rp, fp), ns_g=L.g_loss(fp))
+
+    # R1 on the tiny D: value and resulting parameter gradients
+    D.zero_grad()
+    r1 = r1_regularizer()(real, D, None)
+    r1.backward()
+    arrays['r1'] = r1
+    for n in ['from_rgb.0.layer.weight', 'blocks.0.block.0.layer.weight', 'blocks.0.block.2.layer.bias', 'blocks.1.skip.layer.weight', 'blocks.6.layer.weight']:
+        arrays['r1grad/' + n] = dict(D.named_parameters())[n].grad.clone()
+    D.zero_grad()
+
+    # path length penalty on the tiny G
+    z = torch.randn(4, TINY['style_dim'], generator=g)
+    draws, hooks = capture_noise(G, sg2)
+    fake, style = G(z)
+    for h in hooks:
+        h.remove()
+    torch.manual_seed(11)
+    pl_noise = torch.randn(fake.size())
+    torch.manual_seed(11)
+    pl = ref_utils.pl_penalty(style, fake, 0.3, None)
+    G.zero_grad()
+    pl.backward()
+    arrays.update(pl_z=z, pl=pl, pl_noise=pl_noise, pl_mean_next=np.array(ref_utils.update_pl_mean(0.3, float(pl))))
+    for i, d in enumerate(draws):
+        arrays[f'pl_noise{i}'] = d
+    for n in ['const', 'synthesis.blocks.0.block.2.weight', 'map.map.2.linear.layer.weight']:
+        arrays['plgrad/' + n] = dict(G.named_parameters())[n].grad.clone()
+    G.zero_grad()
+
+    # DiffAugment with the global generator seeded
+    torch.manual_seed(12)
+    arrays['aug_out'] = DiffAugment(real, policy='color,translation')
+
+    # update_ema after 3 fake "steps"
+    G_ema, _ = build_tiny(sg2, 8)
+    update_ema(G, G_ema, decay=0)
+    with torch.no_grad():
+        for t in range(3):
+            for p in G.parameters():
+                p.add_(0.01 * (t + 1))
+            update_ema(G, G_ema)
+    arrays['ema/const'] = G_ema.const.clone()
+    arrays['ema/w'] = dict(G_ema.named_parameters())['synthesis.input.weight'].clone()
+
+    # ---- the reference train() itself, 4 iterations, d_k = g_k = 2 so iteration 2 is an R1 + PL iteration ----
+    G, D = build_tiny(sg2, 8)
+    G_ema, _ = build_tiny(sg2, 8)
+    G_ema.eval()
+    update_ema(G, G_ema, decay=0)
+    lr, betas, d_k, g_k, r1_lambda, pl_lambda = 0.001, (0., 0.99), 2, 2, 10., 2.
+    g_ratio, d_ratio = g_k / (g_k + 1), d_k / (d_k + 1)
+    opt_G = torch.optim.Adam(G.parameters(), lr=lr * g_ratio, betas=(betas[0] ** g_ratio, betas[1] ** g_ratio))
+    opt_D = torch.optim.Adam(D.parameters(), lr=lr * d_ratio, betas=(betas[0] ** d_ratio, betas[1] ** d_ratio))
+    losses = []
+
+    class FakeStatus:
+        def __init__(self, max_iter):
+            self.batches_done = 0
+
+        def update(self, **kw):
+            losses.append([kw['D'], kw['G']])
+            self.batches_done += 1
+
+        def plot_loss(self):
+            pass
+    ref_utils.Status = FakeStatus
+    ref_utils.save_image = lambda *a, **k: None
+    real_batches = [torch.rand(4, 3, 16, 16, generator=g) * 2 - 1 for _ in range(4)]
+    arrays['train_real'] = torch.stack(real_batches)
+    orig_save = torch.save
+    torch.save = lambda *a, **k: None
+    try:
+        torch.manual_seed(13)
+        sampler = functools.partial(ref_utils.sample_nnoise, device='cpu')
+        const_z = ref_utils.sample_nnoise((2, TINY['style_dim']), device='cpu')
+        ref_utils.train(4, real_batches, sampler, const_z, TINY['style_dim'], G, G_ema, D, opt_G, opt_D,
+                        r1_lambda, pl_lambda, d_k, g_k, 'color,translation', torch.device('cpu'), False, save=1000)
+    finally:
+        torch.save = orig_save
+    arrays['train_losses'] = np.array(losses, dtype=np.float64)
+    arrays['train_hparams'] = np.array([lr, betas[0], betas[1], d_k, g_k, r1_lambda, pl_lambda], dtype=np.float64)
+    arrays['train_adam'] = np.array([opt_G.param_groups[0]['lr'], *opt_G.param_groups[0]['betas'],
+                                     opt_D.param_groups[0]['lr'], *opt_D.param_groups[0]['betas']], dtype=np.float64)
+    for k, v in G.state_dict().items():
+        arrays['G4/' + k] = v
+    for k, v in D.state_dict().items():
+        arrays['D4/' + k] = v
+    for k, v in G_ema.state_dict().items():
+        arrays['Gema4/' + k] = v
+    save('sg2_train', **arrays)
+
+
+if __name__ == '__main__':
+    os.environ.setdefault('PYTHONDONTWRITEBYTECODE', '1')
+    torch.set_num_threads(8)
+    import_reference()
+    which = sys.argv[1:] or ['upfirdn2d', 'equiv', 'bias_act', 'filtered_lrelu', 'sg2_model', 'train']
+    if 'upfirdn2d' in which:
+        gen_upfirdn2d()
+    if 'equiv' in which:
+        gen_sg2_equivalences()
+    if 'bias_act' in which:
+        gen_bias_act()
+    if 'filtered_lrelu' in which:
+        gen_filtered_lrelu()
+    if 'sg2_model' in which:
+        gen_sg2_model()
+    if 'train' in which:
+        gen_losses_and_train()
