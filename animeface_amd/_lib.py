@@ -1,0 +1,103 @@
+"""ctypes binding of libagf_ops.so (C ABI: include/agf_ops.h).
+
+PyTorch only supplies device memory and the current HIP stream here: every call
+passes raw ``data_ptr()`` values, sizes, element strides and the stream handle.
+The library is built ahead of time for gfx950 (``animeface_amd/csrc/build.sh``) and
+lives in-tree; a missing library is a hard error -- there is no fallback path.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libagf_ops.so')
+
+AGF_F32, AGF_F16, AGF_BF16, AGF_F64 = 0, 1, 2, 3
+AGF_OK, AGF_EINVAL, AGF_ENOKERNEL, AGF_ELAUNCH = 0, -1, -2, -3
+EDGE_ZERO, EDGE_CLAMP = 0, 1
+
+_DTYPES = {torch.float32: AGF_F32, torch.float16: AGF_F16, torch.bfloat16: AGF_BF16, torch.float64: AGF_F64}
+
+EXPORTS = ['agf_abi_version', 'agf_last_error', 'agf_device_info', 'agf_upfirdn2d', 'agf_bias_act',
+           'agf_filtered_lrelu', 'agf_filtered_lrelu_act', 'agf_conv2d_fwd', 'agf_conv2d_wgrad']
+
+_lib = None
+_i32x4 = ctypes.c_int32 * 4
+_i64x4 = ctypes.c_int64 * 4
+_i32x2 = ctypes.c_int32 * 2
+_i64x2 = ctypes.c_int64 * 2
+_vp = ctypes.c_void_p
+
+
+class AgfError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise AgfError(f'{LIB_PATH} is missing: build it with animeface_amd/csrc/build.sh '
+                           '(python -c "import __graft_entry__ as g; g.build()"); there is no fallback path')
+        L = ctypes.CDLL(LIB_PATH)
+        L.agf_last_error.restype = ctypes.c_char_p
+        L.agf_abi_version.restype = ctypes.c_int
+        L.agf_upfirdn2d.restype = ctypes.c_int
+        L.agf_upfirdn2d.argtypes = [_vp, _vp, _vp, ctypes.c_int, _i32x4, _i64x4, _i32x2, _i64x2, _i32x4, _i64x4,
+                                    ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                    ctypes.c_int, ctypes.c_float, ctypes.c_int, _vp]
+        L.agf_bias_act.restype = ctypes.c_int
+        L.agf_bias_act.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int64, ctypes.c_int32, ctypes.c_int64,
+                                   ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp]
+        L.agf_filtered_lrelu.restype = ctypes.c_int
+        L.agf_filtered_lrelu.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, _i32x4, _i64x4, _i32x4, _i64x4,
+                                         _i32x2, _i64x2, _i32x2, _i64x2, _i32x2, _i32x2, ctypes.c_int,
+                                         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                         ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int, _vp]
+        L.agf_filtered_lrelu_act.restype = ctypes.c_int
+        L.agf_filtered_lrelu_act.argtypes = [_vp, _vp, ctypes.c_int, _i32x4, _i64x4, _i32x2, _i32x2, ctypes.c_int,
+                                             ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp]
+        L.agf_conv2d_fwd.restype = ctypes.c_int
+        L.agf_conv2d_fwd.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp] + [ctypes.c_int32] * 6 + \
+                                    [ctypes.c_int, ctypes.c_float, ctypes.c_float, _vp]
+        L.agf_conv2d_wgrad.restype = ctypes.c_int
+        L.agf_conv2d_wgrad.argtypes = [_vp, _vp, _vp, _vp, _vp] + [ctypes.c_int32] * 6 + [_vp]
+        if L.agf_abi_version() != 1:
+            raise AgfError('libagf_ops.so ABI version mismatch')
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != AGF_OK:
+        msg = lib().agf_last_error().decode('utf-8', 'replace')
+        raise AgfError(f'{what}: {msg} (status {rc})')
+
+
+def dtype_code(t):
+    try:
+        return _DTYPES[t.dtype]
+    except KeyError:
+        raise AgfError(f'unsupported dtype {t.dtype}')
+
+
+def stream_ptr(t):
+    return _vp(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def ptr(t):
+    return _vp(t.data_ptr()) if t is not None else _vp(0)
+
+
+def require_gpu(t, name):
+    if t.device.type != 'cuda':
+        raise AgfError(f'{name}: tensor is on {t.device}; the HIP operators run on the GPU only (no CPU fallback)')
+
+
+def sizes4(t):
+    return _i32x4(*t.shape)
+
+
+def strides4(t):
+    return _i64x4(*t.stride())

@@ -1,0 +1,26 @@
+// Host-side plumbing of libagf_ops.so: error string, ABI version, device query.
+#include "agf_common.h"
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+void agf_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* agf_last_error(void) { return g_err; }
+extern "C" int agf_abi_version(void) { return AGF_ABI_VERSION; }
+
+extern "C" int agf_device_info(int* cu_count, int* lds_bytes_per_block, int* wavefront_size) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { agf_set_error("no HIP device"); return AGF_ELAUNCH; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { agf_set_error("hipGetDeviceProperties failed"); return AGF_ELAUNCH; }
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (lds_bytes_per_block) *lds_bytes_per_block = (int)prop.sharedMemPerBlock;
+    if (wavefront_size) *wavefront_size = prop.warpSize;
+    return AGF_OK;
+}

@@ -1,0 +1,185 @@
+// Fused bias + activation + gain + clamp and its first / second derivatives, gfx950.
+//
+// Semantics: reference bias_act.cu:17-141 (order: +b -> act -> *gain*dy -> clamp; grad 1/2 use the saved
+// yref/gain or xref; clamp grad zeroes where |yref| >= clamp).  Pure streaming op: HBM-bound, so the only
+// design points are 16-byte accesses per lane, a grid-stride loop, and computing the bias index without
+// a division in the common channels-last case (step_b == 1).
+#include "agf_common.h"
+
+struct BiasActParams {
+    const void *x, *b, *xref, *yref, *dy;
+    void* y;
+    int64_t sizeX;
+    int sizeB;
+    int64_t stepB;
+    int grad;
+    float alpha, gain, clamp;
+};
+
+template <class S, int A>
+static __device__ __forceinline__ S act_eval(S x, S xref, S yref, S dy, int G, S alpha, S gain, S clamp) {
+    const S one = 1, two = 2, expRange = 80, halfExpRange = 40;
+    const S seluScale = (S)1.0507009873554804934193349852946, seluAlpha = (S)1.6732632423543772848170429916717;
+    S yy = (gain != 0) ? yref / gain : 0;
+    S y = 0;
+    if (A == 1) { if (G <= 1) y = x; }
+    if (A == 2) { if (G == 0) y = (x > 0) ? x : 0; if (G == 1) y = (yy > 0) ? x : 0; }
+    if (A == 3) { if (G == 0) y = (x > 0) ? x : x * alpha; if (G == 1) y = (yy > 0) ? x : x * alpha; }
+    if (A == 4) {
+        if (G == 0) { S c = exp(x); S d = one / c; y = (x < -expRange) ? -one : (x > expRange) ? one : (c - d) / (c + d); }
+        if (G == 1) y = x * (one - yy * yy);
+        if (G == 2) y = x * (one - yy * yy) * (-two * yy);
+    }
+    if (A == 5) {
+        if (G == 0) y = (x < -expRange) ? 0 : one / (exp(-x) + one);
+        if (G == 1) y = x * yy * (one - yy);
+        if (G == 2) y = x * yy * (one - yy) * (one - two * yy);
+    }
+    if (A == 6) {
+        if (G == 0) y = (x >= 0) ? x : exp(x) - one;
+        if (G == 1) y = (yy >= 0) ? x : x * (yy + one);
+        if (G == 2) y = (yy >= 0) ? 0 : x * (yy + one);
+    }
+    if (A == 7) {
+        if (G == 0) y = (x >= 0) ? seluScale * x : (seluScale * seluAlpha) * (exp(x) - one);
+        if (G == 1) y = (yy >= 0) ? x * seluScale : x * (yy + seluScale * seluAlpha);
+        if (G == 2) y = (yy >= 0) ? 0 : x * (yy + seluScale * seluAlpha);
+    }
+    if (A == 8) {
+        if (G == 0) y = (x > expRange) ? x : log(exp(x) + one);
+        if (G == 1) y = x * (one - exp(-yy));
+        if (G == 2) { S c = exp(-yy); y = x * c * (one - c); }
+    }
+    if (A == 9) {
+        if (G == 0) y = (x < -expRange) ? 0 : x / (exp(-x) + one);
+        else {
+            S c = exp(xref), d = c + one;
+            if (G == 1) y = (xref > halfExpRange) ? x : x * c * (xref + d) / (d * d);
+            else        y = (xref > halfExpRange) ? 0 : x * c * (xref * (two - d) + two * d) / (d * d * d);
+            yref = (xref < -expRange) ? 0 : xref / (exp(-xref) + one) * gain;
+        }
+    }
+    y *= gain * dy;
+    if (clamp >= 0) {
+        if (G == 0) y = (y > -clamp && y < clamp) ? y : (y >= 0) ? clamp : -clamp;
+        else        y = (yref > -clamp && yref < clamp) ? y : 0;
+    }
+    return y;
+}
+
+// scalar kernel (any alignment, fp64, tails)
+template <class T, int A>
+__global__ void __launch_bounds__(256) bias_act_scalar(BiasActParams p, int64_t begin) {
+    typedef typename Elem<T>::acc_t S;
+    for (int64_t i = begin + (int64_t)blockIdx.x * 256 + threadIdx.x; i < p.sizeX; i += (int64_t)gridDim.x * 256) {
+        S x = Elem<T>::load((const T*)p.x + i);
+        S b = p.b ? Elem<T>::load((const T*)p.b + (i / p.stepB) % p.sizeB) : (S)0;
+        S xref = p.xref ? Elem<T>::load((const T*)p.xref + i) : (S)0;
+        S yref = p.yref ? Elem<T>::load((const T*)p.yref + i) : (S)0;
+        S dy = p.dy ? Elem<T>::load((const T*)p.dy + i) : (S)1;
+        if (p.grad == 0) x += b; else xref += b;
+        S y = act_eval<S, A>(x, xref, yref, dy, p.grad, (S)p.alpha, (S)p.gain, (S)p.clamp);
+        Elem<T>::store((T*)p.y + i, y);
+    }
+}
+
+// 16-byte vector kernel: VEC elements per lane per iteration; requires all pointers 16-byte aligned.
+template <class T, int VEC, int A>
+__global__ void __launch_bounds__(256) bias_act_vec(BiasActParams p, int64_t nvec) {
+    for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * 256) {
+        const int64_t i0 = v * VEC;
+        float x[VEC], xr[VEC], yr[VEC], dy[VEC], b[VEC], y[VEC];
+        VecIO<T, VEC>::load((const T*)p.x + i0, x);
+        if (p.xref) VecIO<T, VEC>::load((const T*)p.xref + i0, xr);
+        if (p.yref) VecIO<T, VEC>::load((const T*)p.yref + i0, yr);
+        if (p.dy) VecIO<T, VEC>::load((const T*)p.dy + i0, dy);
+        if (p.b) {
+            if (p.stepB == 1 && p.sizeB % VEC == 0) {                 // channels-last: VEC consecutive channels
+                VecIO<T, VEC>::load((const T*)p.b + (i0 % p.sizeB), b);
+            } else if (p.stepB % VEC == 0) {                          // NCHW with H*W % VEC == 0: one channel per vector
+                float bv = (float)Elem<T>::load((const T*)p.b + (i0 / p.stepB) % p.sizeB);
+#pragma unroll
+                for (int k = 0; k < VEC; k++) b[k] = bv;
+            } else {
+#pragma unroll
+                for (int k = 0; k < VEC; k++) b[k] = (float)Elem<T>::load((const T*)p.b + ((i0 + k) / p.stepB) % p.sizeB);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < VEC; k++) {
+            float xx = x[k], xref = p.xref ? xr[k] : 0.f, yref = p.yref ? yr[k] : 0.f, d = p.dy ? dy[k] : 1.f;
+            float bb = p.b ? b[k] : 0.f;
+            if (p.grad == 0) xx += bb; else xref += bb;
+            y[k] = act_eval<float, A>(xx, xref, yref, d, p.grad, p.alpha, p.gain, p.clamp);
+        }
+        VecIO<T, VEC>::store((T*)p.y + i0, y);
+    }
+}
+
+template <class T, int A>
+static void launch_act(const BiasActParams& p, hipStream_t st) {
+    constexpr int VEC = sizeof(T) == 4 ? 4 : (sizeof(T) == 2 ? 8 : 0);
+    int64_t done = 0;
+    if constexpr (VEC > 0) {
+        auto al = [](const void* q) { return q == nullptr || ((uintptr_t)q % 16) == 0; };
+        if (al(p.x) && al(p.y) && al(p.xref) && al(p.yref) && al(p.dy) && al(p.b)) {
+            int64_t nvec = p.sizeX / VEC;
+            if (nvec > 0) {
+                int64_t blocks = agf_ceil_div(nvec, 256);
+                if (blocks > 256 * 64) blocks = 256 * 64;       // grid-stride beyond 64 blocks per CU
+                hipLaunchKernelGGL((bias_act_vec<T, VEC, A>), dim3((unsigned)blocks), dim3(256), 0, st, p, nvec);
+                done = nvec * VEC;
+            }
+        }
+    }
+    if (done < p.sizeX) {
+        int64_t rest = p.sizeX - done;
+        int64_t blocks = agf_ceil_div(rest, 256);
+        if (blocks > 256 * 64) blocks = 256 * 64;
+        hipLaunchKernelGGL((bias_act_scalar<T, A>), dim3((unsigned)blocks), dim3(256), 0, st, p, done);
+    }
+}
+
+template <class T>
+static int launch_typed(const BiasActParams& p, int act, hipStream_t st) {
+    switch (act) {
+        case 1: launch_act<T, 1>(p, st); break;
+        case 2: launch_act<T, 2>(p, st); break;
+        case 3: launch_act<T, 3>(p, st); break;
+        case 4: launch_act<T, 4>(p, st); break;
+        case 5: launch_act<T, 5>(p, st); break;
+        case 6: launch_act<T, 6>(p, st); break;
+        case 7: launch_act<T, 7>(p, st); break;
+        case 8: launch_act<T, 8>(p, st); break;
+        case 9: launch_act<T, 9>(p, st); break;
+        default: agf_set_error("no kernel found for the specified activation func (%d)", act); return AGF_EINVAL;
+    }
+    return AGF_OK;
+}
+
+extern "C" int agf_bias_act(const void* x, const void* b, const void* xref, const void* yref, const void* dy, void* y,
+                            int dtype, int64_t size_x, int32_t size_b, int64_t step_b,
+                            int grad, int act, float alpha, float gain, float clamp, void* stream) {
+    // validation mirrors bias_act.cpp:29-44
+    AGF_CHECK(x && y, "bias_act: null pointer");
+    AGF_CHECK(dtype >= AGF_F32 && dtype <= AGF_F64, "bias_act: unsupported dtype %d", dtype);
+    AGF_CHECK(size_x >= 0 && size_x <= INT32_MAX, "x is too large");
+    AGF_CHECK(grad >= 0 && grad <= 2, "grad must be 0, 1 or 2");
+    AGF_CHECK(b == nullptr || (size_b >= 1 && step_b >= 1), "b has wrong number of elements");
+    if (size_x == 0) return AGF_OK;
+    BiasActParams p;
+    p.x = x; p.b = b; p.xref = xref; p.yref = yref; p.dy = dy; p.y = y;
+    p.sizeX = size_x; p.sizeB = b ? size_b : 1; p.stepB = b ? step_b : 1;
+    p.grad = grad; p.alpha = alpha; p.gain = gain; p.clamp = clamp;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    switch (dtype) {
+        case AGF_F32:  rc = launch_typed<float>(p, act, st); break;
+        case AGF_F16:  rc = launch_typed<f16_t>(p, act, st); break;
+        case AGF_BF16: rc = launch_typed<bf16_t>(p, act, st); break;
+        default:       rc = launch_typed<double>(p, act, st); break;
+    }
+    if (rc != AGF_OK) return rc;
+    AGF_LAUNCH_CHECK();
+    return AGF_OK;
+}

@@ -1,0 +1,125 @@
+// Shared helpers for the gfx950 kernels of libagf_ops.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/agf_ops.h"
+
+#define AGF_WAVE 64
+
+void agf_set_error(const char* fmt, ...);
+
+#define AGF_CHECK(cond, ...)                 \
+    do {                                     \
+        if (!(cond)) {                       \
+            agf_set_error(__VA_ARGS__);      \
+            return AGF_EINVAL;               \
+        }                                    \
+    } while (0)
+
+#define AGF_LAUNCH_CHECK()                                                        \
+    do {                                                                          \
+        hipError_t e_ = hipGetLastError();                                        \
+        if (e_ != hipSuccess) {                                                   \
+            agf_set_error("%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e_)); \
+            return AGF_ELAUNCH;                                                   \
+        }                                                                         \
+    } while (0)
+
+// ---- element type traits: storage type T, accumulate type acc_t (fp32, or fp64 for double) ----
+typedef uint16_t bf16_raw;   // bf16 handled as raw bits: conversion is a shift / RNE add, no library calls
+
+struct bf16_t { uint16_t v; };
+struct f16_t { _Float16 v; };
+
+template <class T> struct Elem;
+template <> struct Elem<float> {
+    typedef float acc_t;
+    static __device__ __forceinline__ float load(const float* p) { return *p; }
+    static __device__ __forceinline__ void store(float* p, float v) { *p = v; }
+};
+template <> struct Elem<double> {
+    typedef double acc_t;
+    static __device__ __forceinline__ double load(const double* p) { return *p; }
+    static __device__ __forceinline__ void store(double* p, double v) { *p = v; }
+};
+
+static __device__ __forceinline__ float bf16_bits_to_f32(uint32_t bits16) { return __uint_as_float(bits16 << 16); }
+// round-to-nearest-even fp32 -> bf16 (NaN kept quiet), same rule as torch's c10::BFloat16
+static __device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0u;
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+
+template <> struct Elem<bf16_t> {
+    typedef float acc_t;
+    static __device__ __forceinline__ float load(const bf16_t* p) { return bf16_bits_to_f32(p->v); }
+    static __device__ __forceinline__ void store(bf16_t* p, float v) { p->v = (uint16_t)f32_to_bf16_bits(v); }
+};
+template <> struct Elem<f16_t> {
+    typedef float acc_t;
+    static __device__ __forceinline__ float load(const f16_t* p) { return (float)p->v; }
+    static __device__ __forceinline__ void store(f16_t* p, float v) { p->v = (_Float16)v; }
+};
+
+// 16-byte vector of packed 16-bit elements
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <class T> struct Pack16;   // unpack/pack 2 elements in one 32-bit word
+template <> struct Pack16<bf16_t> {
+    static __device__ __forceinline__ void unpack(uint32_t w, float& lo, float& hi) {
+        lo = __uint_as_float(w << 16);
+        hi = __uint_as_float(w & 0xffff0000u);
+    }
+    static __device__ __forceinline__ uint32_t pack(float lo, float hi) {
+        return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16);
+    }
+};
+template <> struct Pack16<f16_t> {
+    static __device__ __forceinline__ void unpack(uint32_t w, float& lo, float& hi) {
+        union { uint32_t u; _Float16 h[2]; } c; c.u = w;
+        lo = (float)c.h[0]; hi = (float)c.h[1];
+    }
+    static __device__ __forceinline__ uint32_t pack(float lo, float hi) {
+        union { uint32_t u; _Float16 h[2]; } c; c.h[0] = (_Float16)lo; c.h[1] = (_Float16)hi;
+        return c.u;
+    }
+};
+
+// 16-byte vector load/store of VEC elements, widened to fp32
+template <class T, int VEC> struct VecIO;
+template <> struct VecIO<float, 4> {
+    static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
+        f32x4 t = *(const f32x4*)p; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+    static __device__ __forceinline__ void store(float* p, const float (&v)[4]) {
+        f32x4 t; t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3]; *(f32x4*)p = t;
+    }
+};
+template <class T> struct VecIO<T, 8> {     // bf16_t / f16_t
+    static __device__ __forceinline__ void load(const T* p, float (&v)[8]) {
+        u32x4 t = *(const u32x4*)p;
+        Pack16<T>::unpack(t.x, v[0], v[1]); Pack16<T>::unpack(t.y, v[2], v[3]);
+        Pack16<T>::unpack(t.z, v[4], v[5]); Pack16<T>::unpack(t.w, v[6], v[7]);
+    }
+    static __device__ __forceinline__ void store(T* p, const float (&v)[8]) {
+        u32x4 t;
+        t.x = Pack16<T>::pack(v[0], v[1]); t.y = Pack16<T>::pack(v[2], v[3]);
+        t.z = Pack16<T>::pack(v[4], v[5]); t.w = Pack16<T>::pack(v[6], v[7]);
+        *(u32x4*)p = t;
+    }
+};
+
+static __host__ __device__ __forceinline__ int agf_floor_div(int a, int b) {   // b > 0; rounds toward -inf
+    int q = a / b;
+    return (a % b != 0 && a < 0) ? q - 1 : q;
+}
+static inline int64_t agf_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline size_t agf_elem_size(int dtype) { return dtype == AGF_F32 ? 4 : dtype == AGF_F64 ? 8 : 2; }

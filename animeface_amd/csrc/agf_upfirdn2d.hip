@@ -1,0 +1,318 @@
+// upfirdn2d for gfx950: pad / zero-insert upsample / 2-D FIR / decimate, one launch per pass.
+//
+// Semantics (reference upfirdn2d.cu:23-86, upfirdn2d.cpp:10-91):
+//   y[n,c,oy,ox] = gain * sum_{ky,kx} U[oy*downy + ky - pady0, ox*downx + kx - padx0] * F[ky,kx]
+//   U[uy,ux]     = x[n,c,uy/upy,ux/upx] on the zero-insertion lattice inside the image, else 0
+//                  (AGF_EDGE_CLAMP: lattice points outside the image take the nearest edge pixel)
+//   F[ky,kx]     = f[fh-1-ky, fw-1-kx]   (true convolution)   or  f[ky,kx] when flip
+// evaluated gather-style: mid = o*down + up-1 - pad0; in0 = floor(mid/up); k0 = (in0+1)*up - mid - 1;
+// taps (in0 + j, k0 + j*up).  fp32 accumulate (fp64 for double), ky-major tap order.
+//
+// Three kernels, all HBM-bound designs (no MFMA: this is byte movement, ~1 FMA per byte):
+//   nhwc_vec : channels-last activations.  A row of W*C elements is contiguous, so a tap shift is a shift by
+//              C elements and every lane issues aligned 16-byte loads (8 x bf16 / 4 x fp32 channels); the few-tap
+//              re-reads are served by L1/L2.  This is the layout the StyleGAN2 path runs in.
+//   nchw_tile: NCHW planes.  A 256-thread workgroup stages a (tile + halo) patch of one plane in LDS as fp32
+//              with coalesced row loads and computes a 64x16 output tile from it (polyphase taps from LDS).
+//   generic  : any strides / sizes; one thread per output, gathers from global memory.
+#include "agf_common.h"
+
+struct UpfirdnParams {
+    const void* x;
+    const float* f;
+    void* y;
+    int N, C, H, W;              // input
+    int OH, OW;                  // output
+    int64_t xs[4], ys[4];        // strides (N, C, H, W) in elements
+    int fh, fw;
+    int64_t fsy, fsx;
+    int upx, upy, downx, downy, padx0, pady0;
+    int flip, clamp_edge;
+    float gain;
+    int tilesX, tilesY;          // nchw_tile only
+    int tileInW, tileInH;
+};
+
+#define MAX_FILTER_TAPS 1024     // up to 32x32 (reference limit: 32x32 in the small kernels)
+
+// Stage the filter in LDS in "F" order (already flipped) as fp32.
+template <int NT>
+static __device__ __forceinline__ void stage_filter(const UpfirdnParams& p, float* sf) {
+    for (int i = threadIdx.x; i < p.fh * p.fw; i += NT) {
+        int ky = i / p.fw, kx = i - ky * p.fw;
+        int fy = p.flip ? ky : p.fh - 1 - ky;
+        int fx = p.flip ? kx : p.fw - 1 - kx;
+        sf[i] = p.f[fy * p.fsy + fx * p.fsx];
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// generic: any strides.  Thread order follows the output's fastest axis for coalescing.
+template <class T>
+__global__ void __launch_bounds__(256) upfirdn2d_generic(UpfirdnParams p) {
+    typedef typename Elem<T>::acc_t acc_t;
+    __shared__ float sf[MAX_FILTER_TAPS];
+    stage_filter<256>(p, sf);
+    __syncthreads();
+    const bool cl = (p.ys[1] == 1 && p.C > 1);     // channels-last style output
+    const int64_t total = (int64_t)p.N * p.C * p.OH * p.OW;
+    for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+        int n, c, oy, ox;
+        int64_t r = id;
+        if (cl) { c = (int)(r % p.C); r /= p.C; ox = (int)(r % p.OW); r /= p.OW; oy = (int)(r % p.OH); n = (int)(r / p.OH); }
+        else    { ox = (int)(r % p.OW); r /= p.OW; oy = (int)(r % p.OH); r /= p.OH; c = (int)(r % p.C); n = (int)(r / p.C); }
+        int midy = oy * p.downy + p.upy - 1 - p.pady0;
+        int midx = ox * p.downx + p.upx - 1 - p.padx0;
+        int iny0 = agf_floor_div(midy, p.upy), inx0 = agf_floor_div(midx, p.upx);
+        int ky0 = (iny0 + 1) * p.upy - midy - 1, kx0 = (inx0 + 1) * p.upx - midx - 1;
+        const T* xb = (const T*)p.x + n * p.xs[0] + c * p.xs[1];
+        acc_t v = 0;
+        for (int ky = ky0, iy = iny0; ky < p.fh; ky += p.upy, iy++) {
+            int iyc = iy;
+            if (p.clamp_edge) iyc = min(max(iy, 0), p.H - 1);
+            else if (iy < 0 || iy >= p.H) continue;
+            for (int kx = kx0, ix = inx0; kx < p.fw; kx += p.upx, ix++) {
+                int ixc = ix;
+                if (p.clamp_edge) ixc = min(max(ix, 0), p.W - 1);
+                else if (ix < 0 || ix >= p.W) continue;
+                v += (acc_t)Elem<T>::load(xb + iyc * p.xs[2] + ixc * p.xs[3]) * (acc_t)sf[ky * p.fw + kx];
+            }
+        }
+        v *= (acc_t)p.gain;
+        Elem<T>::store((T*)p.y + n * p.ys[0] + c * p.ys[1] + oy * p.ys[2] + ox * p.ys[3], v);
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// nhwc_vec: dense channels-last, C % VEC == 0, 16-byte vectors of VEC channels per lane.
+// Compile-time (UPX, UPY, DNX, DNY, FW, FH) when > 0 lets the tap loops unroll fully; 0 = runtime.
+template <class T, int VEC, int UPX, int UPY, int DNX, int DNY, int FW, int FH>
+__global__ void __launch_bounds__(256) upfirdn2d_nhwc_vec(UpfirdnParams p) {
+    __shared__ float sf[MAX_FILTER_TAPS];
+    stage_filter<256>(p, sf);
+    __syncthreads();
+    const int upx = UPX ? UPX : p.upx, upy = UPY ? UPY : p.upy;
+    const int dnx = DNX ? DNX : p.downx, dny = DNY ? DNY : p.downy;
+    const int fw = FW ? FW : p.fw, fh = FH ? FH : p.fh;
+    const int CG = p.C / VEC;
+    const int64_t total = (int64_t)p.N * p.OH * p.OW * CG;
+    const int64_t rowC = (int64_t)p.W * p.C;
+    for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+        int64_t r = id;
+        int cg = (int)(r % CG); r /= CG;
+        int ox = (int)(r % p.OW); r /= p.OW;
+        int oy = (int)(r % p.OH);
+        int n = (int)(r / p.OH);
+        int midy = oy * dny + upy - 1 - p.pady0;
+        int midx = ox * dnx + upx - 1 - p.padx0;
+        int iny0 = agf_floor_div(midy, upy), inx0 = agf_floor_div(midx, upx);
+        int ky0 = (iny0 + 1) * upy - midy - 1, kx0 = (inx0 + 1) * upx - midx - 1;
+        const T* xb = (const T*)p.x + (int64_t)n * p.H * rowC + cg * VEC;
+        float acc[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; i++) acc[i] = 0.f;
+        // compile-time tap counts: ceil(F / UP) taps per axis
+        constexpr int NTY = (FH && UPY) ? (FH + UPY - 1) / UPY : 0;
+        constexpr int NTX = (FW && UPX) ? (FW + UPX - 1) / UPX : 0;
+        if (NTY && NTX) {
+#pragma unroll
+            for (int jy = 0; jy < NTY; jy++) {
+                int ky = ky0 + jy * upy, iy = iny0 + jy;
+                bool oky = ky < fh;
+                if (p.clamp_edge) iy = min(max(iy, 0), p.H - 1); else oky = oky && iy >= 0 && iy < p.H;
+#pragma unroll
+                for (int jx = 0; jx < NTX; jx++) {
+                    int kx = kx0 + jx * upx, ix = inx0 + jx;
+                    bool ok = oky && kx < fw;
+                    if (p.clamp_edge) ix = min(max(ix, 0), p.W - 1); else ok = ok && ix >= 0 && ix < p.W;
+                    if (ok) {
+                        float xv[VEC];
+                        VecIO<T, VEC>::load(xb + iy * rowC + (int64_t)ix * p.C, xv);
+                        float fv = sf[ky * fw + kx];
+#pragma unroll
+                        for (int i = 0; i < VEC; i++) acc[i] += xv[i] * fv;
+                    }
+                }
+            }
+        } else {
+            for (int ky = ky0, iy = iny0; ky < fh; ky += upy, iy++) {
+                int iyc = iy;
+                if (p.clamp_edge) iyc = min(max(iy, 0), p.H - 1); else if (iy < 0 || iy >= p.H) continue;
+                for (int kx = kx0, ix = inx0; kx < fw; kx += upx, ix++) {
+                    int ixc = ix;
+                    if (p.clamp_edge) ixc = min(max(ix, 0), p.W - 1); else if (ix < 0 || ix >= p.W) continue;
+                    float xv[VEC];
+                    VecIO<T, VEC>::load(xb + iyc * rowC + (int64_t)ixc * p.C, xv);
+                    float fv = sf[ky * fw + kx];
+#pragma unroll
+                    for (int i = 0; i < VEC; i++) acc[i] += xv[i] * fv;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < VEC; i++) acc[i] *= p.gain;
+        VecIO<T, VEC>::store((T*)p.y + (((int64_t)n * p.OH + oy) * p.OW + ox) * p.C + cg * VEC, acc);
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// nchw_tile: dense NCHW.  One workgroup = one 64x16 output tile of one (n,c) plane.
+#define TILE_OW 64
+#define TILE_OH 16
+template <class T>
+__global__ void __launch_bounds__(256) upfirdn2d_nchw_tile(UpfirdnParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sf = smem;                               // [fh*fw]
+    float* sx = smem + ((p.fh * p.fw + 3) & ~3);    // [tileInH][tileInW]
+    stage_filter<256>(p, sf);
+    int bid = blockIdx.x;
+    const int tx = bid % p.tilesX; bid /= p.tilesX;
+    const int ty = bid % p.tilesY;
+    const int plane = bid / p.tilesY;               // n*C + c
+    const int oy0 = ty * TILE_OH, ox0 = tx * TILE_OW;
+    const int tmidy = oy0 * p.downy + p.upy - 1 - p.pady0;
+    const int tmidx = ox0 * p.downx + p.upx - 1 - p.padx0;
+    const int tiy0 = agf_floor_div(tmidy, p.upy), tix0 = agf_floor_div(tmidx, p.upx);
+    const T* xb = (const T*)p.x + (int64_t)plane * p.H * p.W;
+    const int nin = p.tileInH * p.tileInW;
+    for (int i = threadIdx.x; i < nin; i += 256) {
+        int ry = i / p.tileInW, rx = i - ry * p.tileInW;
+        int iy = tiy0 + ry, ix = tix0 + rx;
+        float v = 0.f;
+        if (p.clamp_edge) {
+            iy = min(max(iy, 0), p.H - 1); ix = min(max(ix, 0), p.W - 1);
+            v = (float)Elem<T>::load(xb + (int64_t)iy * p.W + ix);
+        } else if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+            v = (float)Elem<T>::load(xb + (int64_t)iy * p.W + ix);
+        }
+        sx[i] = v;
+    }
+    __syncthreads();
+    T* yb = (T*)p.y + (int64_t)plane * p.OH * p.OW;
+#pragma unroll
+    for (int k = 0; k < TILE_OW * TILE_OH / 256; k++) {
+        int idx = k * 256 + threadIdx.x;
+        int ry = idx / TILE_OW, rx = idx - ry * TILE_OW;
+        int oy = oy0 + ry, ox = ox0 + rx;
+        if (oy >= p.OH || ox >= p.OW) continue;
+        int midy = tmidy + ry * p.downy, midx = tmidx + rx * p.downx;
+        int iny0 = agf_floor_div(midy, p.upy), inx0 = agf_floor_div(midx, p.upx);
+        int ky0 = (iny0 + 1) * p.upy - midy - 1, kx0 = (inx0 + 1) * p.upx - midx - 1;
+        const float* sp = sx + (iny0 - tiy0) * p.tileInW + (inx0 - tix0);
+        float v = 0.f;
+        for (int ky = ky0; ky < p.fh; ky += p.upy, sp += p.tileInW) {
+            const float* sq = sp;
+            for (int kx = kx0; kx < p.fw; kx += p.upx, sq++)
+                v += *sq * sf[ky * p.fw + kx];
+        }
+        Elem<T>::store(yb + (int64_t)oy * p.OW + ox, v * p.gain);
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+template <class T, int VEC>
+static bool launch_nhwc(const UpfirdnParams& p, hipStream_t st) {
+    const int64_t total = (int64_t)p.N * p.OH * p.OW * (p.C / VEC);
+    int64_t blocks = agf_ceil_div(total, 256);
+    if (blocks > (1 << 30)) blocks = 1 << 30;
+    dim3 g((unsigned)blocks), b(256);
+#define NHWC_CASE(ux, uy, dx, dy, w, h)                                                                   \
+    if (p.upx == ux && p.upy == uy && p.downx == dx && p.downy == dy && p.fw == w && p.fh == h) {         \
+        hipLaunchKernelGGL((upfirdn2d_nhwc_vec<T, VEC, ux, uy, dx, dy, w, h>), g, b, 0, st, p);           \
+        return true;                                                                                      \
+    }
+    NHWC_CASE(2, 2, 1, 1, 4, 4)   // bilinear-equivalent 2x upsample  (StyleGAN2 Upsample2x, ToImage)
+    NHWC_CASE(1, 1, 1, 1, 3, 3)   // Blur2d
+    NHWC_CASE(1, 1, 2, 2, 2, 2)   // AvgPool2d(2)
+    NHWC_CASE(1, 1, 2, 2, 4, 4)   // adjoint of the 2x upsample; StyleGAN3-D downsample
+    NHWC_CASE(2, 2, 1, 1, 2, 2)   // adjoint of AvgPool2d(2)
+    NHWC_CASE(1, 1, 1, 1, 4, 4)   // StyleGAN3-D filter2d before the strided conv
+#undef NHWC_CASE
+    hipLaunchKernelGGL((upfirdn2d_nhwc_vec<T, VEC, 0, 0, 0, 0, 0, 0>), g, b, 0, st, p);
+    return true;
+}
+
+template <class T>
+static int launch_typed(UpfirdnParams& p, bool dense_nchw, bool dense_nhwc, int vec, hipStream_t st) {
+    const int64_t total = (int64_t)p.N * p.C * p.OH * p.OW;
+    if (dense_nhwc && vec > 0 && p.C % vec == 0 && ((uintptr_t)p.x % 16 == 0) && ((uintptr_t)p.y % 16 == 0)) {
+        if constexpr (sizeof(T) == 4) launch_nhwc<T, 4>(p, st);
+        else if constexpr (sizeof(T) == 2) launch_nhwc<T, 8>(p, st);
+        else goto generic;
+        return AGF_OK;
+    }
+    if (dense_nchw && sizeof(T) <= 4) {      // fp64 keeps full precision through the generic kernel
+        p.tileInW = ((TILE_OW - 1) * p.downx + p.fw - 1) / p.upx + 1;
+        p.tileInH = ((TILE_OH - 1) * p.downy + p.fh - 1) / p.upy + 1;
+        size_t lds = (size_t)(((p.fh * p.fw + 3) & ~3) + p.tileInW * p.tileInH) * sizeof(float);
+        if (lds <= 64 * 1024 && p.OW >= 16) {
+            p.tilesX = (p.OW + TILE_OW - 1) / TILE_OW;
+            p.tilesY = (p.OH + TILE_OH - 1) / TILE_OH;
+            int64_t blocks = (int64_t)p.tilesX * p.tilesY * p.N * p.C;
+            if (blocks < (1ll << 31)) {
+                hipLaunchKernelGGL((upfirdn2d_nchw_tile<T>), dim3((unsigned)blocks), dim3(256), lds, st, p);
+                return AGF_OK;
+            }
+        }
+    }
+generic:
+    {
+        int64_t blocks = agf_ceil_div(total, 256);
+        if (blocks > 65536 * 16) blocks = 65536 * 16;
+        hipLaunchKernelGGL((upfirdn2d_generic<T>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+    }
+    return AGF_OK;
+}
+
+extern "C" int agf_upfirdn2d(const void* x, const float* f, void* y, int dtype,
+                             const int32_t in_size[4], const int64_t in_stride[4],
+                             const int32_t f_size[2], const int64_t f_stride[2],
+                             const int32_t out_size[4], const int64_t out_stride[4],
+                             int upx, int upy, int downx, int downy, int padx0, int pady0,
+                             int flip, float gain, int edge_mode, void* stream) {
+    // validation mirrors upfirdn2d.cpp:13-34
+    AGF_CHECK(x && f && y, "upfirdn2d: null pointer");
+    AGF_CHECK(dtype >= AGF_F32 && dtype <= AGF_F64, "upfirdn2d: unsupported dtype %d", dtype);
+    AGF_CHECK(upx >= 1 && upy >= 1, "upsampling factor must be at least 1");
+    AGF_CHECK(downx >= 1 && downy >= 1, "downsampling factor must be at least 1");
+    AGF_CHECK(f_size[0] >= 1 && f_size[1] >= 1, "f must be at least 1x1");
+    AGF_CHECK((int64_t)f_size[0] * f_size[1] <= MAX_FILTER_TAPS, "f is too large (max %d taps)", MAX_FILTER_TAPS);
+    for (int i = 0; i < 4; i++) AGF_CHECK(in_size[i] >= 1, "x has zero size");
+    AGF_CHECK(out_size[2] >= 1 && out_size[3] >= 1, "output must be at least 1x1");
+    AGF_CHECK(out_size[0] == in_size[0] && out_size[1] == in_size[1], "upfirdn2d: batch/channel mismatch");
+    AGF_CHECK(edge_mode == AGF_EDGE_ZERO || edge_mode == AGF_EDGE_CLAMP, "upfirdn2d: bad edge_mode");
+    int64_t xspan = 0, yspan = 0;
+    for (int i = 0; i < 4; i++) { xspan += (int64_t)(in_size[i] - 1) * in_stride[i]; yspan += (int64_t)(out_size[i] - 1) * out_stride[i]; }
+    AGF_CHECK(xspan <= INT32_MAX, "x memory footprint is too large");
+    AGF_CHECK(yspan <= INT32_MAX, "output memory footprint is too large");
+
+    UpfirdnParams p;
+    p.x = x; p.f = f; p.y = y;
+    p.N = in_size[0]; p.C = in_size[1]; p.H = in_size[2]; p.W = in_size[3];
+    p.OH = out_size[2]; p.OW = out_size[3];
+    for (int i = 0; i < 4; i++) { p.xs[i] = in_stride[i]; p.ys[i] = out_stride[i]; }
+    p.fh = f_size[0]; p.fw = f_size[1]; p.fsy = f_stride[0]; p.fsx = f_stride[1];
+    p.upx = upx; p.upy = upy; p.downx = downx; p.downy = downy; p.padx0 = padx0; p.pady0 = pady0;
+    p.flip = flip ? 1 : 0; p.clamp_edge = edge_mode == AGF_EDGE_CLAMP; p.gain = gain;
+    p.tilesX = p.tilesY = p.tileInW = p.tileInH = 0;
+
+    auto dense = [](const int32_t* sz, const int64_t* st, bool nhwc) {
+        int64_t N = sz[0], C = sz[1], H = sz[2], W = sz[3];
+        (void)N;
+        if (nhwc) return st[1] == 1 && st[3] == C && st[2] == W * C && (N == 1 || st[0] == H * W * C);
+        return st[3] == 1 && st[2] == W && (C == 1 || st[1] == H * W) && (N == 1 || st[0] == C * H * W);
+    };
+    bool nchw = dense(in_size, in_stride, false) && dense(out_size, out_stride, false);
+    bool nhwc = dense(in_size, in_stride, true) && dense(out_size, out_stride, true);
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    switch (dtype) {
+        case AGF_F32:  rc = launch_typed<float>(p, nchw, nhwc, 4, st); break;
+        case AGF_F16:  rc = launch_typed<f16_t>(p, nchw, nhwc, 8, st); break;
+        case AGF_BF16: rc = launch_typed<bf16_t>(p, nchw, nhwc, 8, st); break;
+        default:       rc = launch_typed<double>(p, nchw, nhwc, 0, st); break;
+    }
+    if (rc != AGF_OK) return rc;
+    AGF_LAUNCH_CHECK();
+    return AGF_OK;
+}

@@ -1,0 +1,21 @@
+#!/bin/bash
+# Ahead-of-time build of libagf_ops.so for gfx950 (MI355X).  hipcc cross-compiles without a GPU.
+set -euo pipefail
+cd "$(dirname "$0")"
+OUT=../libagf_ops.so
+SRCS="agf_api.cpp agf_upfirdn2d.hip agf_bias_act.hip agf_filtered_lrelu.hip agf_conv2d.hip"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -Wall -Wno-unused-function"
+mkdir -p build
+objs=""
+pids=()
+for s in $SRCS; do
+  o=build/${s%.*}.o
+  objs="$objs $o"
+  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ agf_common.h -nt "$o" ] || [ ../../include/agf_ops.h -nt "$o" ]; then
+    /opt/rocm/bin/hipcc $FLAGS -x hip -c "$s" -o "$o" &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs -o "$OUT"
+echo "built $(realpath $OUT)"

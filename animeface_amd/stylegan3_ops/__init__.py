@@ -1,0 +1,3 @@
+"""Operator surface of the reference's ``thirdparty/stylegan3_ops/ops`` on MI355X kernels:
+``upfirdn2d``, ``bias_act``, ``filtered_lrelu``, ``conv2d_resample``, ``conv2d_gradfix``."""
+from . import upfirdn2d, bias_act, filtered_lrelu, conv2d_gradfix, conv2d_resample  # noqa: F401

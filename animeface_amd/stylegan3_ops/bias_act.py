@@ -1,0 +1,138 @@
+"""Fused bias + activation on MI355X: same public surface as the reference's
+``thirdparty/stylegan3_ops/ops/bias_act.py`` (``bias_act``, ``activation_funcs``), one
+``agf_bias_act`` launch per evaluation; first and second order gradients are further launches of
+the same kernel with ``grad`` = 1 / 2 (reference bias_act.py:137-198)."""
+import numpy as np
+import torch
+
+from .. import _lib
+
+
+class EasyDict(dict):
+    """Attribute-style dict (the reference's ``utils.EasyDict``, utils/misc.py:10-24)."""
+
+    def __getattr__(self, name):
+        try:
+            return self[name]
+        except KeyError:
+            raise AttributeError(name)
+
+    def __setattr__(self, name, value):
+        self[name] = value
+
+
+# reference bias_act.py:16-26 (cuda_idx is the ``act`` argument of agf_bias_act)
+activation_funcs = {
+    'linear':   EasyDict(def_alpha=0,   def_gain=1,          cuda_idx=1, ref='',  has_2nd_grad=False),
+    'relu':     EasyDict(def_alpha=0,   def_gain=np.sqrt(2), cuda_idx=2, ref='y', has_2nd_grad=False),
+    'lrelu':    EasyDict(def_alpha=0.2, def_gain=np.sqrt(2), cuda_idx=3, ref='y', has_2nd_grad=False),
+    'tanh':     EasyDict(def_alpha=0,   def_gain=1,          cuda_idx=4, ref='y', has_2nd_grad=True),
+    'sigmoid':  EasyDict(def_alpha=0,   def_gain=1,          cuda_idx=5, ref='y', has_2nd_grad=True),
+    'elu':      EasyDict(def_alpha=0,   def_gain=1,          cuda_idx=6, ref='y', has_2nd_grad=True),
+    'selu':     EasyDict(def_alpha=0,   def_gain=1,          cuda_idx=7, ref='y', has_2nd_grad=True),
+    'softplus': EasyDict(def_alpha=0,   def_gain=1,          cuda_idx=8, ref='y', has_2nd_grad=True),
+    'swish':    EasyDict(def_alpha=0,   def_gain=np.sqrt(2), cuda_idx=9, ref='x', has_2nd_grad=True),
+}
+
+
+def _dense_like(t, memory_format):
+    return t.contiguous(memory_format=memory_format)
+
+
+def _native(x, b, xref, yref, dy, grad, dim, act_idx, alpha, gain, clamp):
+    """Counterpart of ``_plugin.bias_act`` (reference bias_act.cpp:26-83); allocates y like ``empty_like(x)``."""
+    _lib.require_gpu(x, 'bias_act')
+    if not x.is_non_overlapping_and_dense():
+        raise RuntimeError('x must be non-overlapping and dense')
+    for name, t in (('xref', xref), ('yref', yref), ('dy', dy)):
+        if t is not None and (t.shape != x.shape or t.dtype != x.dtype or t.stride() != x.stride()):
+            raise RuntimeError(f'{name} must have the same shape, dtype, and layout as x')
+    if b is not None:
+        if b.dtype != x.dtype or b.device != x.device:
+            raise RuntimeError('b must have the same dtype and device as x')
+        if b.dim() != 1:
+            raise RuntimeError('b must have rank 1')
+        if not (0 <= dim < x.dim()):
+            raise RuntimeError('dim is out of bounds')
+        if b.numel() != x.size(dim):
+            raise RuntimeError('b has wrong number of elements')
+        b = b.contiguous()
+    y = torch.empty_like(x)
+    step_b = x.stride(dim) if b is not None else 1
+    rc = _lib.lib().agf_bias_act(_lib.ptr(x), _lib.ptr(b), _lib.ptr(xref), _lib.ptr(yref), _lib.ptr(dy), _lib.ptr(y),
+                                 _lib.dtype_code(x), x.numel(), b.numel() if b is not None else 0, step_b,
+                                 grad, act_idx, alpha, gain, clamp, _lib.stream_ptr(x))
+    _lib.check(rc, 'bias_act')
+    return y
+
+
+_bias_act_hip_cache = dict()
+
+
+def _bias_act_hip(dim=1, act='linear', alpha=None, gain=None, clamp=None):
+    assert clamp is None or clamp >= 0
+    spec = activation_funcs[act]
+    alpha = float(alpha if alpha is not None else spec.def_alpha)
+    gain = float(gain if gain is not None else spec.def_gain)
+    clamp = float(clamp if clamp is not None else -1)
+    key = (dim, act, alpha, gain, clamp)
+    if key in _bias_act_hip_cache:
+        return _bias_act_hip_cache[key]
+
+    class BiasActHip(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, b):
+            ctx.memory_format = torch.channels_last if x.ndim > 2 and x.stride(1) == 1 else torch.contiguous_format
+            x = x.contiguous(memory_format=ctx.memory_format)
+            b = b.contiguous() if b is not None else None
+            y = x
+            if act != 'linear' or gain != 1 or clamp >= 0 or b is not None:
+                y = _native(x, b, None, None, None, 0, dim, spec.cuda_idx, alpha, gain, clamp)
+            need_x = 'x' in spec.ref or spec.has_2nd_grad
+            ctx.has_b = b is not None
+            ctx.save_for_backward(x if need_x else None, b if need_x else None, y if 'y' in spec.ref else None)
+            return y
+
+        @staticmethod
+        def backward(ctx, dy):
+            dy = dy.contiguous(memory_format=ctx.memory_format)
+            x, b, y = ctx.saved_tensors
+            dx = db = None
+            if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+                dx = dy
+                if act != 'linear' or gain != 1 or clamp >= 0:
+                    dx = BiasActHipGrad.apply(dy, x, b, y)
+            if ctx.has_b and ctx.needs_input_grad[1]:
+                db = dx.sum([i for i in range(dx.ndim) if i != dim])
+            return dx, db
+
+    class BiasActHipGrad(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, dy, x, b, y):
+            ctx.memory_format = torch.channels_last if dy.ndim > 2 and dy.stride(1) == 1 else torch.contiguous_format
+            dx = _native(dy, b, x, y, None, 1, dim, spec.cuda_idx, alpha, gain, clamp)
+            ctx.save_for_backward(dy if spec.has_2nd_grad else None, x, b, y)
+            return dx
+
+        @staticmethod
+        def backward(ctx, d_dx):
+            d_dx = d_dx.contiguous(memory_format=ctx.memory_format)
+            dy, x, b, y = ctx.saved_tensors
+            d_dy = d_x = d_b = None
+            if ctx.needs_input_grad[0]:
+                d_dy = BiasActHipGrad.apply(d_dx, x, b, y)
+            if spec.has_2nd_grad and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
+                d_x = _native(d_dx, b, x, y, dy, 2, dim, spec.cuda_idx, alpha, gain, clamp)
+            if spec.has_2nd_grad and b is not None and ctx.needs_input_grad[2]:
+                d_b = d_x.sum([i for i in range(d_x.ndim) if i != dim])
+            return d_dy, d_x, d_b, None
+
+    _bias_act_hip_cache[key] = BiasActHip
+    return BiasActHip
+
+
+def bias_act(x, b=None, dim=1, act='linear', alpha=None, gain=None, clamp=None, impl='hip'):
+    """Fused bias and activation (reference bias_act.py:47-81): ``+b`` -> ``act`` -> ``*gain`` -> clamp."""
+    assert isinstance(x, torch.Tensor)
+    assert impl in ['hip', 'cuda']
+    return _bias_act_hip(dim=dim, act=act, alpha=alpha, gain=gain, clamp=clamp).apply(x, b)

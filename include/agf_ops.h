@@ -1,0 +1,137 @@
+/*
+ * agf_ops.h -- C ABI of libagf_ops.so: the MI355X (gfx950) native operators of the
+ * StyleGAN2/3 training hot path.
+ *
+ * Drop-in boundary.  Each entry point replaces one pybind11
+ * function of the reference's JIT-built torch extensions; the reference interface
+ * it replaces is cited per function (paths relative to the reference root,
+ * thirdparty/stylegan3_ops/ops/).  Differences from the reference interface, all
+ * forced by the C ABI and all documented in INTEGRATION.md:
+ *   - plain pointers + sizes + strides instead of torch::Tensor;
+ *   - the caller allocates every output (shape formulas are cited below);
+ *   - the HIP stream is an explicit argument (hipStream_t passed as void*);
+ *   - errors are an int status + agf_last_error(), not C++ exceptions;
+ *   - no global device state (the reference keeps filters in a __constant__
+ *     singleton, filtered_lrelu.cu:71-72), so calls on different streams are safe.
+ *
+ * Tensor arguments are described by size[4] = {N, C, H, W} and stride[4] in ELEMENTS
+ * in the same order, so both NCHW-contiguous and channels-last tensors are accepted,
+ * like the reference kernels (upfirdn2d.cpp:45-56).
+ */
+#ifndef AGF_OPS_H
+#define AGF_OPS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AGF_ABI_VERSION 1
+
+/* element types of activation tensors */
+enum { AGF_F32 = 0, AGF_F16 = 1, AGF_BF16 = 2, AGF_F64 = 3 };
+
+/* status codes */
+enum {
+    AGF_OK = 0,
+    AGF_EINVAL = -1,     /* argument validation failed (the reference raises via TORCH_CHECK) */
+    AGF_ENOKERNEL = -2,  /* no specialised kernel for this parameter set (reference: return code -1, filtered_lrelu.cpp:45-50) */
+    AGF_ELAUNCH = -3     /* hipLaunch / runtime failure */
+};
+
+/* edge handling of agf_upfirdn2d: 0 = zero fill (the reference op), 1 = clamp to edge
+ * (extension used to express nn.Upsample(bilinear), implementations/StyleGAN2/model.py:56-58) */
+enum { AGF_EDGE_ZERO = 0, AGF_EDGE_CLAMP = 1 };
+
+int         agf_abi_version(void);
+const char* agf_last_error(void);          /* thread-local message of the last failing call */
+int         agf_device_info(int* cu_count, int* lds_bytes_per_block, int* wavefront_size);
+
+/* ---------------------------------------------------------------------------------------------
+ * upfirdn2d  --  replaces  Tensor upfirdn2d(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain)
+ *                upfirdn2d.cpp:10-91 (pybind at :98), kernels upfirdn2d.cu:23-86,91-194.
+ * out_size: outW = (W*upx + padx0 + padx1 - fw + downx) / downx, same for H (upfirdn2d.cpp:29-30);
+ * padx1/pady1 only enter through out_size.  f is fp32, f_size = {fh, fw}, f_stride in elements.
+ * Accumulates in fp32 (fp64 for AGF_F64), tap order ky-major then kx (upfirdn2d.cu:184-187).
+ */
+int agf_upfirdn2d(const void* x, const float* f, void* y, int dtype,
+                  const int32_t in_size[4], const int64_t in_stride[4],
+                  const int32_t f_size[2], const int64_t f_stride[2],
+                  const int32_t out_size[4], const int64_t out_stride[4],
+                  int upx, int upy, int downx, int downy, int padx0, int pady0,
+                  int flip, float gain, int edge_mode, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * bias_act  --  replaces  Tensor bias_act(x, b, xref, yref, dy, grad, dim, act, alpha, gain, clamp)
+ *               bias_act.cpp:26-83 (pybind at :90), kernel bias_act.cu:17-141.
+ * x, xref, yref, dy, y are dense tensors of `size_x` elements with identical layout; b (nullable)
+ * has size_b elements and is indexed (i / step_b) % size_b, step_b = stride of `dim` (bias_act.cpp:69).
+ * act = 1..9 (linear, relu, lrelu, tanh, sigmoid, elu, selu, softplus, swish; bias_act.py:16-26);
+ * grad = 0 forward, 1 first derivative, 2 second derivative.  clamp < 0 disables clamping.
+ */
+int agf_bias_act(const void* x, const void* b, const void* xref, const void* yref, const void* dy, void* y,
+                 int dtype, int64_t size_x, int32_t size_b, int64_t step_b,
+                 int grad, int act, float alpha, float gain, float clamp, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * filtered_lrelu  --  replaces  tuple<Tensor y, Tensor so, int rc> filtered_lrelu(x, fu, fd, b, si, up, down,
+ *                     px0, px1, py0, py1, sx, sy, gain, slope, clamp, flip_filters, writeSigns)
+ *                     filtered_lrelu.cpp:10-203 (pybind at :290), kernels filtered_lrelu.cu:133-1093.
+ * fu / fd: fp32, rank 1 (separable; f*_size = {taps, 0}) or rank 2 ({fh, fw}); strides in elements.
+ * Output size: yw = (xw*up + px0+px1 - (fuw-1) - (fdw-1) + down-1) / down (filtered_lrelu.cpp:57-73).
+ * Sign tensor s: uint8 [N, C, s_size[0], s_size[1]] contiguous, 2 bits per element of the upsampled
+ * image, 4 elements per byte, row width = ceil16(active width) / 4 bytes (filtered_lrelu.cpp:81-88);
+ * sign_mode 0 = none, 1 = write, 2 = read (then s_ofs = {sx, sy} offsets it against the upsampled image).
+ * Returns AGF_ENOKERNEL where the reference returns rc = -1; callers then use the generic path
+ * (agf_upfirdn2d + agf_filtered_lrelu_act), exactly as filtered_lrelu.py:217-223 does.
+ */
+int agf_filtered_lrelu(const void* x, const float* fu, const float* fd, const void* b, uint8_t* s, void* y, int dtype,
+                       const int32_t x_size[4], const int64_t x_stride[4],
+                       const int32_t y_size[4], const int64_t y_stride[4],
+                       const int32_t fu_size[2], const int64_t fu_stride[2],
+                       const int32_t fd_size[2], const int64_t fd_stride[2],
+                       const int32_t s_size[2], const int32_t s_ofs[2], int sign_mode,
+                       int up, int down, int px0, int py0,
+                       float gain, float slope, float clamp, int flip, void* stream);
+
+/* filtered_lrelu_act_  --  replaces  Tensor filtered_lrelu_act_(x, si, sx, sy, gain, slope, clamp, writeSigns)
+ *                          filtered_lrelu.cpp:207-284 (pybind at :291), kernel filtered_lrelu.cu:1099-1210.
+ * In-place gain -> lrelu -> clamp on x with sign write (s_size = {H, ceil16(W)/4}) or sign read. */
+int agf_filtered_lrelu_act(void* x, uint8_t* s, int dtype,
+                           const int32_t x_size[4], const int64_t x_stride[4],
+                           const int32_t s_size[2], const int32_t s_ofs[2], int sign_mode,
+                           float gain, float slope, float clamp, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * conv2d (MFMA implicit-GEMM contraction)  --  replaces the ATen/cuDNN calls under
+ *   F.conv2d(x.reshape(1,B*Cin,H,W), w.reshape(B*Cout,Cin,k,k), padding, groups=B)
+ *   implementations/StyleGAN2/model.py:123-129 (modulated conv, evaluated in the algebraically equal
+ *   "scale activations - shared weights - scale outputs" form) and
+ *   nn.Conv2d inside ELR, implementations/StyleGAN2/model.py:29-37,192-202 (discriminator).
+ * Layout: activations channels-last (NHWC) bf16; weights OHWI bf16 [Cout][kh][kw][Cin]; fp32 accumulate.
+ * Stride 1, "same" zero padding (k-1)/2, k in {1, 3}.
+ *
+ *   y[n,h,w,co] = epilogue( sum_{kh,kw,ci} x[n,h+kh-p,w+kw-p,ci] * in_scale[n,ci] * w[co,kh,kw,ci] )
+ *   epilogue(v) = lrelu_or_id( v * out_scale[n,co] + bias[co] + noise[n,h,w] + residual[n,h,w,co] ) * act_gain
+ * in_scale / out_scale (fp32 [N,Cin] / [N,Cout]), bias (fp32 [Cout]), noise (fp32 or bf16? -> fp32 [N,H,W]) and
+ * residual (bf16 NHWC) are nullable.  act: 1 = linear, 3 = lrelu(alpha).
+ */
+int agf_conv2d_fwd(const void* x, const void* w, void* y,
+                   const float* in_scale, const float* out_scale, const float* bias,
+                   const float* noise, const void* residual,
+                   int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
+                   int act, float alpha, float act_gain, void* stream);
+
+/* weight gradient of the same contraction:
+ *   dw[co,kh,kw,ci] = sum_{n,h,w} dy[n,h,w,co] * out_scale[n,co] * x[n,h+kh-p,w+kw-p,ci] * in_scale[n,ci]
+ * dw is fp32 OHWI.  (dgrad is agf_conv2d_fwd with the spatially flipped, transposed weights.) */
+int agf_conv2d_wgrad(const void* x, const void* dy, float* dw,
+                     const float* in_scale, const float* out_scale,
+                     int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
+                     void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AGF_OPS_H */

@@ -1,0 +1,64 @@
+"""CPU-side checks of the C-ABI boundary: the library loads and exports every symbol that
+include/agf_ops.h declares; the host wrappers refuse CPU tensors loudly (no fallback path)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT
+from animeface_amd import _lib
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, 'include', 'agf_ops.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(agf_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    names = declared_symbols()
+    assert len(names) >= 9
+    for n in names:
+        assert hasattr(L, n), f'{n} declared in include/agf_ops.h but not exported'
+    assert sorted(_lib.EXPORTS) == names
+
+
+def test_abi_version_and_error_string():
+    L = _lib.lib()
+    assert L.agf_abi_version() == 1
+    assert isinstance(L.agf_last_error(), bytes)
+
+
+def test_no_cpu_fallback():
+    from animeface_amd.stylegan3_ops import upfirdn2d, bias_act, filtered_lrelu
+    x = torch.zeros(1, 2, 4, 4)
+    with pytest.raises(_lib.AgfError):
+        upfirdn2d.upfirdn2d(x, upfirdn2d.setup_filter([1, 2, 1]))
+    with pytest.raises(_lib.AgfError):
+        bias_act.bias_act(x, act='lrelu')
+    with pytest.raises(_lib.AgfError):
+        filtered_lrelu.filtered_lrelu(x)
+
+
+def test_product_does_not_import_oracle():
+    """The oracle is test infrastructure: nothing under animeface_amd/ may reference it."""
+    pkg = os.path.join(ROOT, 'animeface_amd')
+    for dirpath, _dirs, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith('.py'):
+                src = open(os.path.join(dirpath, fn)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), os.path.join(dirpath, fn)
+                assert 'from .. import oracle' not in src
+
+
+def test_setup_filter_matches_golden(golden):
+    from animeface_amd.stylegan3_ops.upfirdn2d import setup_filter
+    g = golden('setup_filter')
+    cases = [([1, 3, 3, 1], {}), ([1, 2, 1], dict(gain=4)), ([1, 1], dict(normalize=False)),
+             (list(range(1, 13)), {}), (list(range(1, 13)), dict(flip_filter=True, gain=2)),
+             ([[1, 2], [3, 4]], dict(flip_filter=True)), (None, {}), ([1, 2, 3, 4, 5, 6, 7, 8], dict(separable=False))]
+    for i, (taps, kw) in enumerate(cases):
+        torch.testing.assert_close(setup_filter(taps, **kw), torch.from_numpy(g[f'sf{i}']), rtol=1e-6, atol=1e-7)

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Kernel-level micro-benchmarks: algorithmic GB/s of upfirdn2d / bias_act at the
+256^2 shapes, HIP-event timed on the launch stream.  Prints one JSON line per row."""
+import argparse
+import json
+import sys
+import os
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from animeface_amd.stylegan3_ops import upfirdn2d as U, bias_act as B  # noqa: E402
+
+HBM_PEAK = 8.0e12
+
+
+def timeit(fn, reps=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    s = torch.cuda.Event(enable_timing=True)
+    e = torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / reps * 1e-3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--batch', type=int, default=64)
+    ap.add_argument('--reps', type=int, default=20)
+    a = ap.parse_args()
+    dev = 'cuda'
+    N = a.batch
+    f4 = U.setup_filter([1, 3, 3, 1], device=dev)
+    f3 = U.setup_filter([1, 2, 1], device=dev)
+    f2 = U.setup_filter([1, 1], device=dev)
+    rows = []
+    for dtype in [torch.bfloat16, torch.float32]:
+        es = 2 if dtype == torch.bfloat16 else 4
+        for layout in ['nhwc', 'nchw']:
+            mf = torch.channels_last if layout == 'nhwc' else torch.contiguous_format
+            x128 = torch.randn(N, 64, 128, 128, device=dev).to(dtype).contiguous(memory_format=mf)
+            x256 = torch.randn(N, 64, 256, 256, device=dev).to(dtype).contiguous(memory_format=mf)
+            b = torch.randn(64, device=dev).to(dtype)
+            cases = [
+                ('up2_f4', lambda: U.upsample2d(x128, f4, up=2), x128.numel() * 5 * es),
+                ('up2_f4_clamp', lambda: U.upsample2d(x128, f4, up=2, edge='clamp'), x128.numel() * 5 * es),
+                ('blur_f3', lambda: U.filter2d(x256, f3), x256.numel() * 2 * es),
+                ('down2_f2', lambda: U.downsample2d(x256, f2, down=2), x256.numel() * 1.25 * es),
+                ('down2_f4', lambda: U.downsample2d(x256, f4, down=2), x256.numel() * 1.25 * es),
+                ('bias_lrelu', lambda: B.bias_act(x256, b, act='lrelu'), x256.numel() * 2 * es),
+            ]
+            for name, fn, nbytes in cases:
+                with torch.no_grad():
+                    sec = timeit(fn, a.reps)
+                row = dict(kernel=name, dtype=str(dtype).split('.')[-1], layout=layout, batch=N, ms=round(sec * 1e3, 4),
+                           algorithmic_GBps=round(nbytes / sec / 1e9, 1), frac_of_8TBps=round(nbytes / sec / HBM_PEAK, 4))
+                print(json.dumps(row), flush=True)
+                rows.append(row)
+            del x128, x256
+            torch.cuda.empty_cache()
+
+
+if __name__ == '__main__':
+    main()
