@@ -50,10 +50,9 @@ template <> struct Elem<double> {
 static __device__ __forceinline__ float bf16_bits_to_f32(uint32_t bits16) { return __uint_as_float(bits16 << 16); }
 // round-to-nearest-even fp32 -> bf16 (NaN kept quiet), same rule as torch's c10::BFloat16
 static __device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0u;
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return u >> 16;
+    // native conversion: gfx950 has v_cvt_pk_bf16_f32 (RNE); clang's __bf16 cast selects it
+    __bf16 h = (__bf16)f;
+    return (uint32_t)__builtin_bit_cast(unsigned short, h);
 }
 
 template <> struct Elem<bf16_t> {
@@ -79,7 +78,11 @@ template <> struct Pack16<bf16_t> {
         hi = __uint_as_float(w & 0xffff0000u);
     }
     static __device__ __forceinline__ uint32_t pack(float lo, float hi) {
-        return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16);
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        typedef float f32x2_ __attribute__((ext_vector_type(2)));
+        f32x2_ v; v.x = lo; v.y = hi;
+        bf16x2 h = __builtin_convertvector(v, bf16x2);          // one v_cvt_pk_bf16_f32
+        return __builtin_bit_cast(uint32_t, h);
     }
 };
 template <> struct Pack16<f16_t> {

@@ -1,11 +1,446 @@
-// placeholder (real kernels follow)
+// 3x3 / 1x1 stride-1 "same" convolution for gfx950 as an MFMA implicit GEMM (the im2col contraction of the
+// StyleGAN2 modulated conv and of the discriminator's ELR convs), channels-last bf16, fp32 accumulate.
+//
+// Contraction, per block:  D[co, pixel] = sum_{tap, ci} Wt[co, tap, ci] * X[pixel + tap, ci]
+//   A operand = weights (OHWI: ci contiguous per tap)          rows  = 32 output channels
+//   B operand = activations (NHWC: ci contiguous per pixel)    cols  = 32 output pixels
+//   v_mfma_f32_32x32x16_bf16: lane l feeds A[row = l&31][k = 8*(l>>5) .. +8] and B[k = 8*(l>>5) .. +8][col = l&31],
+//   i.e. one 16-byte LDS read per operand fragment; C/D: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5).
+// No im2col buffer exists anywhere: a (TI x (TH+2) x (TW+2)) pixel patch with halo is staged once per 32-channel
+// chunk in LDS and the nine taps are nine shifted views of it (tap shift = constant LDS offset).
+//
+// Block = 256 threads = 4 waves (2 along co x 2 along pixels); block tile = (64*MT) co x 256 pixels;
+// wave tile = (32*MT) co x 128 pixels = MT x 4 accumulator tiles (MT*64 accumulator VGPRs).
+// LDS rows are padded by 16 bytes (pitch 80 B for a 32-channel chunk) so that the 16-lane groups of a
+// ds_read_b128 fall on 16 distinct 16-byte slots (no bank conflicts; MI355X_MICROARCH.md section LDS).
+// Pixel tiles are (TI images) x (TH rows) x (TW cols) with TI*TH*TW = 256 so that 4x4 ... 16x16 feature maps fill the
+// tile with several images / full maps; block ids are remapped so that the co-tiles sharing one input patch run on
+// the same XCD (its L2 then serves the patch re-reads).
+//
+// Fused on load : per-(n,ci) input scale (the style modulation), fp32 multiply, rounded once to bf16.
+// Fused on store: per-(n,co) output scale (demodulation), bias[co], noise[n,h,w], residual, leaky ReLU, gain.
 #include "agf_common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define KC 32                 // channels per K chunk
+#define PITCH (KC + 8)        // LDS row pitch in elements (80 bytes)
+#define BLOCK_PIX 256
+
+struct ConvParams {
+    const bf16_t* x;          // [N,H,W,Cin]
+    const bf16_t* w;          // [Cout,KS,KS,Cin]
+    bf16_t* y;                // [N,H,W,Cout]
+    const float* in_scale;    // [N,Cin] or null
+    const float* out_scale;   // [N,Cout] or null
+    const float* bias;        // [Cout] or null
+    const float* noise;       // [N,H,W] or null
+    const bf16_t* residual;   // [N,H,W,Cout] or null
+    int N, H, W, Cin, Cout;
+    int TI, TH, TW;           // pixel tile
+    int tilesW, tilesH, tilesN, tilesCo, pixTiles;
+    int act;                  // 1 linear, 3 lrelu
+    float alpha, gain;
+};
+
+template <int KS, int MT, bool IN_SCALE>
+__global__ void __launch_bounds__(256) conv2d_fwd_kernel(ConvParams p) {
+    constexpr int TAPS = KS * KS;
+    constexpr int HALO = KS / 2;
+    constexpr int BM = 64 * MT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* sW = (bf16_t*)smem_raw;                                  // [TAPS][BM][PITCH]
+    bf16_t* sX = sW + TAPS * BM * PITCH;                             // [P][PITCH]
+
+    // ---- block -> (pixel tile, co tile): co tiles of one pixel tile are consecutive slots of one XCD ----
+    const int b = blockIdx.x;
+    const int xcd = b & 7, slot = b >> 3;
+    const int pixTile = (slot / p.tilesCo) * 8 + xcd;
+    const int coTile = slot % p.tilesCo;
+    if (pixTile >= p.pixTiles) return;
+    int tq = pixTile;
+    const int tw = tq % p.tilesW; tq /= p.tilesW;
+    const int th = tq % p.tilesH;
+    const int tn = tq / p.tilesH;
+    const int n0 = tn * p.TI, h0 = th * p.TH, w0 = tw * p.TW;
+    const int co0 = coTile * BM;
+    const int PW = p.TW + 2 * HALO, PH = p.TH + 2 * HALO;
+    const int P = p.TI * PH * PW;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    // per-lane LDS base (in elements) of the B fragment of each of the wave's 4 pixel sub-tiles, tap (0,0), k-step 0
+    int bBase[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int q = wn * 128 + j * 32 + l31;
+        int c = q % p.TW; int r = (q / p.TW) % p.TH; int ti = q / (p.TW * p.TH);
+        bBase[j] = ((ti * PH + r) * PW + c) * PITCH + lhi * 8;
+    }
+    int aBase[MT];
+#pragma unroll
+    for (int i = 0; i < MT; i++) aBase[i] = (wm * 32 * MT + i * 32 + l31) * PITCH + lhi * 8;
+
+    f32x16 acc[MT][4];
+#pragma unroll
+    for (int i = 0; i < MT; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    const int nChunks = (p.Cin + KC - 1) / KC;
+    for (int ch = 0; ch < nChunks; ch++) {
+        const int c0 = ch * KC;
+        __syncthreads();                                  // previous chunk fully consumed
+        // ---- stage weights: TAPS*BM rows of KC channels, 4 x 16-byte vectors per row ----
+        for (int v = tid; v < TAPS * BM * (KC / 8); v += 256) {
+            int cv = v & 3, row = v >> 2;                 // row = tap*BM + co
+            int tap = row / BM, co = row - tap * BM;
+            int gco = co0 + co, gc = c0 + cv * 8;
+            u32x4 val = {0u, 0u, 0u, 0u};
+            if (gco < p.Cout && gc < p.Cin)
+                val = *(const u32x4*)(p.w + ((int64_t)gco * TAPS + tap) * p.Cin + gc);
+            *(u32x4*)(sW + row * PITCH + cv * 8) = val;
+        }
+        // ---- stage the input patch (zero halo outside the image) ----
+        for (int v = tid; v < P * (KC / 8); v += 256) {
+            int cv = v & 3, pix = v >> 2;
+            int pc = pix % PW; int t2 = pix / PW; int pr = t2 % PH; int ti = t2 / PH;
+            int n = n0 + ti, h = h0 + pr - HALO, w = w0 + pc - HALO, gc = c0 + cv * 8;
+            u32x4 val = {0u, 0u, 0u, 0u};
+            if (n < p.N && h >= 0 && h < p.H && w >= 0 && w < p.W && gc < p.Cin) {
+                val = *(const u32x4*)(p.x + (((int64_t)n * p.H + h) * p.W + w) * p.Cin + gc);
+                if (IN_SCALE) {
+                    const float* sc = p.in_scale + (int64_t)n * p.Cin + gc;
+                    f32x4 s0 = *(const f32x4*)sc, s1 = *(const f32x4*)(sc + 4);
+                    float a0, a1;
+                    Pack16<bf16_t>::unpack(val.x, a0, a1); val.x = Pack16<bf16_t>::pack(a0 * s0.x, a1 * s0.y);
+                    Pack16<bf16_t>::unpack(val.y, a0, a1); val.y = Pack16<bf16_t>::pack(a0 * s0.z, a1 * s0.w);
+                    Pack16<bf16_t>::unpack(val.z, a0, a1); val.z = Pack16<bf16_t>::pack(a0 * s1.x, a1 * s1.y);
+                    Pack16<bf16_t>::unpack(val.w, a0, a1); val.w = Pack16<bf16_t>::pack(a0 * s1.z, a1 * s1.w);
+                }
+            }
+            *(u32x4*)(sX + pix * PITCH + cv * 8) = val;
+        }
+        __syncthreads();
+        // ---- contraction over taps and the chunk's two 16-channel k-steps ----
+#pragma unroll
+        for (int kh = 0; kh < KS; kh++) {
+#pragma unroll
+            for (int kw = 0; kw < KS; kw++) {
+                const int tap = kh * KS + kw;
+                const int tapOffB = (kh * PW + kw) * PITCH;
+                const int tapOffA = tap * BM * PITCH;
+#pragma unroll
+                for (int ks = 0; ks < KC / 16; ks++) {
+                    bf16x8 af[MT], bfr[4];
+#pragma unroll
+                    for (int i = 0; i < MT; i++) af[i] = *(const bf16x8*)(sW + tapOffA + aBase[i] + ks * 16);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) bfr[j] = *(const bf16x8*)(sX + tapOffB + bBase[j] + ks * 16);
+#pragma unroll
+                    for (int i = 0; i < MT; i++)
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: lane holds, per accumulator tile, one pixel (col) x 4 groups of 4 consecutive channels ----
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int q = wn * 128 + j * 32 + l31;
+        int c = q % p.TW; int r = (q / p.TW) % p.TH; int ti = q / (p.TW * p.TH);
+        int n = n0 + ti, h = h0 + r, w = w0 + c;
+        if (n >= p.N || h >= p.H || w >= p.W) continue;
+        const int64_t pixIdx = ((int64_t)n * p.H + h) * p.W + w;
+        const float nz = p.noise ? p.noise[pixIdx] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MT; i++) {
+#pragma unroll
+            for (int rg = 0; rg < 4; rg++) {
+                int co = co0 + wm * 32 * MT + i * 32 + rg * 8 + lhi * 4;
+                if (co >= p.Cout) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = acc[i][j][rg * 4 + e];
+                if (p.out_scale) {
+                    f32x4 s = *(const f32x4*)(p.out_scale + (int64_t)n * p.Cout + co);
+                    v[0] *= s.x; v[1] *= s.y; v[2] *= s.z; v[3] *= s.w;
+                }
+                if (p.bias) {
+                    f32x4 bb = *(const f32x4*)(p.bias + co);
+                    v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] += nz;
+                if (p.residual) {
+                    u32x2 rr = *(const u32x2*)(p.residual + pixIdx * p.Cout + co);
+                    float a0, a1;
+                    Pack16<bf16_t>::unpack(rr.x, a0, a1); v[0] += a0; v[1] += a1;
+                    Pack16<bf16_t>::unpack(rr.y, a0, a1); v[2] += a0; v[3] += a1;
+                }
+                if (p.act == 3) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = v[e] > 0.f ? v[e] : v[e] * p.alpha;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] *= p.gain;
+                u32x2 o;
+                o.x = Pack16<bf16_t>::pack(v[0], v[1]);
+                o.y = Pack16<bf16_t>::pack(v[2], v[3]);
+                *(u32x2*)(p.y + pixIdx * p.Cout + co) = o;
+            }
+        }
+    }
+}
+
+static int pow2_ceil(int v) { int r = 1; while (r < v) r <<= 1; return r; }
+
+template <int KS, int MT>
+static int launch_fwd(const ConvParams& p, hipStream_t st) {
+    constexpr int TAPS = KS * KS, HALO = KS / 2, BM = 64 * MT;
+    const int P = p.TI * (p.TH + 2 * HALO) * (p.TW + 2 * HALO);
+    size_t lds = (size_t)(TAPS * BM + P) * PITCH * sizeof(bf16_t);
+    if (lds > 160 * 1024) { agf_set_error("conv2d_fwd: tile needs %zu bytes of LDS", lds); return AGF_ENOKERNEL; }
+    const int slots = ((p.pixTiles + 7) / 8) * p.tilesCo;
+    dim3 grid((unsigned)(slots * 8)), block(256);
+    hipError_t e;
+    if (p.in_scale) {
+        e = hipFuncSetAttribute((const void*)conv2d_fwd_kernel<KS, MT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { agf_set_error("conv2d_fwd: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e)); return AGF_ELAUNCH; }
+        hipLaunchKernelGGL((conv2d_fwd_kernel<KS, MT, true>), grid, block, lds, st, p);
+    } else {
+        e = hipFuncSetAttribute((const void*)conv2d_fwd_kernel<KS, MT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { agf_set_error("conv2d_fwd: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e)); return AGF_ELAUNCH; }
+        hipLaunchKernelGGL((conv2d_fwd_kernel<KS, MT, false>), grid, block, lds, st, p);
+    }
+    return AGF_OK;
+}
+
 extern "C" int agf_conv2d_fwd(const void* x, const void* w, void* y,
-                   const float* in_scale, const float* out_scale, const float* bias,
-                   const float* noise, const void* residual,
-                   int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
-                   int act, float alpha, float act_gain, void* stream) { agf_set_error("conv2d_fwd: not built"); return AGF_ENOKERNEL; }
+                              const float* in_scale, const float* out_scale, const float* bias,
+                              const float* noise, const void* residual,
+                              int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
+                              int act, float alpha, float act_gain, void* stream) {
+    AGF_CHECK(x && w && y, "conv2d_fwd: null pointer");
+    AGF_CHECK(N >= 1 && H >= 1 && W >= 1 && Cin >= 1 && Cout >= 1, "conv2d_fwd: empty tensor");
+    AGF_CHECK(ksize == 1 || ksize == 3, "conv2d_fwd: kernel size must be 1 or 3 (got %d)", ksize);
+    AGF_CHECK(Cin % 8 == 0, "conv2d_fwd: Cin must be a multiple of 8 (pad the channel axis)");
+    AGF_CHECK(Cout % 4 == 0, "conv2d_fwd: Cout must be a multiple of 4 (pad the channel axis)");
+    AGF_CHECK(act == 1 || act == 3, "conv2d_fwd: act must be 1 (linear) or 3 (lrelu)");
+    AGF_CHECK(((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0 && ((uintptr_t)y % 8) == 0, "conv2d_fwd: misaligned pointer");
+    AGF_CHECK((int64_t)N * H * W * (int64_t)(Cin > Cout ? Cin : Cout) < (1ll << 40), "conv2d_fwd: tensor too large");
+    ConvParams p;
+    p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.y = (bf16_t*)y;
+    p.in_scale = in_scale; p.out_scale = out_scale; p.bias = bias; p.noise = noise; p.residual = (const bf16_t*)residual;
+    p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+    p.act = act; p.alpha = alpha; p.gain = act_gain;
+    p.TW = pow2_ceil(W) < 32 ? pow2_ceil(W) : 32;
+    int th = pow2_ceil(H);
+    p.TH = th < BLOCK_PIX / p.TW ? th : BLOCK_PIX / p.TW;
+    p.TI = BLOCK_PIX / (p.TW * p.TH);
+    p.tilesW = (W + p.TW - 1) / p.TW; p.tilesH = (H + p.TH - 1) / p.TH; p.tilesN = (N + p.TI - 1) / p.TI;
+    p.pixTiles = p.tilesW * p.tilesH * p.tilesN;
+    const int MT = Cout > 64 ? 2 : 1;
+    p.tilesCo = (Cout + 64 * MT - 1) / (64 * MT);
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if (ksize == 3) rc = MT == 2 ? launch_fwd<3, 2>(p, st) : launch_fwd<3, 1>(p, st);
+    else            rc = MT == 2 ? launch_fwd<1, 2>(p, st) : launch_fwd<1, 1>(p, st);
+    if (rc != AGF_OK) return rc;
+    AGF_LAUNCH_CHECK();
+    return AGF_OK;
+}
+
+// =================================================================================================
+// Weight gradient:  dw[co, tap, ci] = sum_{n,h,w} dy[n,h,w,co] * os[n,co] * x[n,h+kh-P,w+kw-P,ci] * is[n,ci]
+//
+// GEMM view: M = co, N = ci, K = pixels.  Both operands are channels-last, i.e. K-major ([pixel][channel] rows), which
+// is the WRONG orientation for an MFMA fragment (a lane needs 8 consecutive k for one channel).  gfx950's
+// ds_read_b64_tr_b16 does the transposition in the LDS read path: in every 16-lane group, lane i supplies the address of
+// row i/4, columns 4*(i%4).. of a [4 k][16 ch] block and receives column i (4 consecutive k of ONE channel).  Two such
+// reads build one 32x32x16 operand fragment.  Tiles are kept as [32-channel block][pixel][32 ch] with NO padding:
+// the 4 rows a group touches are 64 B apart = 4 disjoint 16-bank ranges, so the reads are conflict-free, and the staging
+// ds_write_b128s are fully linear.  A tap is a constant row offset into the input patch, as in the forward kernel.
+//
+// Block = 4 waves = (2 co blocks) x (2 ci blocks) of 32; each wave owns one 32x32 (co x ci) tile for all KS*KS taps
+// (9 accumulator tiles = 144 VGPRs).  K (pixels) is split across blocks; partial sums are combined with fp32 atomics
+// (global_atomic_add_f32; dw must be zero-initialised by the caller).
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+struct WgradParams {
+    const bf16_t* x;          // [N,H,W,Cin]
+    const bf16_t* dy;         // [N,H,W,Cout]
+    float* dw;                // [Cout,KS,KS,Cin] fp32, accumulated into
+    const float* in_scale;    // [N,Cin] or null
+    const float* out_scale;   // [N,Cout] or null
+    int N, H, W, Cin, Cout;
+    int TI, TH, TW;
+    int tilesW, tilesH, tilesN, pixTiles;
+    int tilesCo, tilesCi, splitK;
+};
+
+static __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* base) {
+    // base = this lane's address for the first 4 k; the next 4 k are 4 rows (4*32 elements) further
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 4 * 32));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+static __device__ __forceinline__ u32x4 scale_vec8(u32x4 val, const float* sc) {
+    f32x4 s0 = *(const f32x4*)sc, s1 = *(const f32x4*)(sc + 4);
+    float a0, a1;
+    Pack16<bf16_t>::unpack(val.x, a0, a1); val.x = Pack16<bf16_t>::pack(a0 * s0.x, a1 * s0.y);
+    Pack16<bf16_t>::unpack(val.y, a0, a1); val.y = Pack16<bf16_t>::pack(a0 * s0.z, a1 * s0.w);
+    Pack16<bf16_t>::unpack(val.z, a0, a1); val.z = Pack16<bf16_t>::pack(a0 * s1.x, a1 * s1.y);
+    Pack16<bf16_t>::unpack(val.w, a0, a1); val.w = Pack16<bf16_t>::pack(a0 * s1.z, a1 * s1.w);
+    return val;
+}
+
+template <int KS>
+__global__ void __launch_bounds__(256) conv2d_wgrad_kernel(WgradParams p) {
+    constexpr int TAPS = KS * KS;
+    constexpr int HALO = KS / 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    // geometry: both tiles use the padded patch index space q in [0, Ppad); the x tile has MARGIN extra rows at both ends
+    const int PW = p.TW + 2 * HALO, PH = p.TH + 2 * HALO;
+    const int P = p.TI * PH * PW;
+    const int Ppad = (P + 15) & ~15;
+    const int MARGIN = HALO * PW + HALO;                 // largest |tap shift|
+    const int XR = Ppad + 2 * MARGIN;                    // rows of one x block
+    bf16_t* sDy = (bf16_t*)smem_raw;                     // [2][Ppad][32]
+    bf16_t* sX = sDy + 2 * Ppad * 32;                    // [2][XR][32]
+
+    int bid = blockIdx.x;
+    const int ks = bid % p.splitK; bid /= p.splitK;
+    const int tci = bid % p.tilesCi;
+    const int tco = bid / p.tilesCi;
+    const int co0 = tco * 64, ci0 = tci * 64;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wa = wave >> 1, wb = wave & 1;             // co block, ci block
+    const int li = lane & 15, lg = (lane >> 4) & 1, lk = lane >> 5;
+    const int laneOff = (8 * lk + (li >> 2)) * 32 + 16 * lg + 4 * (li & 3);
+    const bf16_t* aPtr = sDy + wa * Ppad * 32 + laneOff;
+    const bf16_t* bPtr = sX + wb * XR * 32 + MARGIN * 32 + laneOff;
+
+    f32x16 acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
+
+    for (int pt = ks; pt < p.pixTiles; pt += p.splitK) {
+        int tq = pt;
+        const int tw = tq % p.tilesW; tq /= p.tilesW;
+        const int th = tq % p.tilesH;
+        const int tn = tq / p.tilesH;
+        const int n0 = tn * p.TI, h0 = th * p.TH, w0 = tw * p.TW;
+        __syncthreads();
+        // ---- stage dy in patch geometry (zero in the halo ring, outside the image and beyond P) ----
+        for (int v = tid; v < Ppad * 8; v += 256) {
+            int cv = v & 7, q = v >> 3;
+            int pc = q % PW; int t2 = q / PW; int pr = t2 % PH; int ti = t2 / PH;
+            int n = n0 + ti, h = h0 + pr - HALO, w = w0 + pc - HALO, gco = co0 + cv * 8;
+            u32x4 val = {0u, 0u, 0u, 0u};
+            bool interior = q < P && pr >= HALO && pr < PH - HALO && pc >= HALO && pc < PW - HALO;
+            if (interior && n < p.N && h < p.H && w < p.W && gco < p.Cout) {
+                val = *(const u32x4*)(p.dy + (((int64_t)n * p.H + h) * p.W + w) * p.Cout + gco);
+                if (p.out_scale) val = scale_vec8(val, p.out_scale + (int64_t)n * p.Cout + gco);
+            }
+            *(u32x4*)(sDy + ((cv >> 2) * Ppad + q) * 32 + (cv & 3) * 8) = val;
+        }
+        // ---- stage x patch (with margins) ----
+        for (int v = tid; v < XR * 8; v += 256) {
+            int cv = v & 7, row = v >> 3;
+            int q = row - MARGIN;
+            u32x4 val = {0u, 0u, 0u, 0u};
+            if (q >= 0 && q < P) {
+                int pc = q % PW; int t2 = q / PW; int pr = t2 % PH; int ti = t2 / PH;
+                int n = n0 + ti, h = h0 + pr - HALO, w = w0 + pc - HALO, gci = ci0 + cv * 8;
+                if (n < p.N && h >= 0 && h < p.H && w >= 0 && w < p.W && gci < p.Cin) {
+                    val = *(const u32x4*)(p.x + (((int64_t)n * p.H + h) * p.W + w) * p.Cin + gci);
+                    if (p.in_scale) val = scale_vec8(val, p.in_scale + (int64_t)n * p.Cin + gci);
+                }
+            }
+            *(u32x4*)(sX + ((cv >> 2) * XR + row) * 32 + (cv & 3) * 8) = val;
+        }
+        __syncthreads();
+        for (int s = 0; s < Ppad / 16; s++) {
+            const bf16x8 af = tr_frag(aPtr + s * 16 * 32);
+#pragma unroll
+            for (int kh = 0; kh < KS; kh++)
+#pragma unroll
+                for (int kw = 0; kw < KS; kw++) {
+                    const int shift = (kh - HALO) * PW + (kw - HALO);
+                    const bf16x8 bfr = tr_frag(bPtr + (s * 16 + shift) * 32);
+                    acc[kh * KS + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[kh * KS + kw], 0, 0, 0);
+                }
+        }
+    }
+    // ---- combine: fp32 atomics into dw[co][tap][ci] ----
+    const int ci = ci0 + wb * 32 + (lane & 31);
+    if (ci < p.Cin) {
+#pragma unroll
+        for (int t = 0; t < TAPS; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                int co = co0 + wa * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (co < p.Cout) unsafeAtomicAdd(p.dw + ((int64_t)co * TAPS + t) * p.Cin + ci, acc[t][r]);
+            }
+    }
+}
+
 extern "C" int agf_conv2d_wgrad(const void* x, const void* dy, float* dw,
-                     const float* in_scale, const float* out_scale,
-                     int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
-                     void* stream) { agf_set_error("conv2d_wgrad: not built"); return AGF_ENOKERNEL; }
+                                const float* in_scale, const float* out_scale,
+                                int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
+                                void* stream) {
+    AGF_CHECK(x && dy && dw, "conv2d_wgrad: null pointer");
+    AGF_CHECK(N >= 1 && H >= 1 && W >= 1 && Cin >= 1 && Cout >= 1, "conv2d_wgrad: empty tensor");
+    AGF_CHECK(ksize == 1 || ksize == 3, "conv2d_wgrad: kernel size must be 1 or 3 (got %d)", ksize);
+    AGF_CHECK(Cin % 8 == 0 && Cout % 8 == 0, "conv2d_wgrad: Cin and Cout must be multiples of 8 (pad the channel axis)");
+    AGF_CHECK(((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0 && ((uintptr_t)dw % 4) == 0, "conv2d_wgrad: misaligned pointer");
+    WgradParams p;
+    p.x = (const bf16_t*)x; p.dy = (const bf16_t*)dy; p.dw = dw; p.in_scale = in_scale; p.out_scale = out_scale;
+    p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+    // pixel tile: up to 4 x 32 interior pixels (128) so that two blocks fit one CU's LDS
+    const int TILE_PIX = 128;
+    p.TW = pow2_ceil(W) < 32 ? pow2_ceil(W) : 32;
+    int th = pow2_ceil(H);
+    p.TH = th < TILE_PIX / p.TW ? th : TILE_PIX / p.TW;
+    p.TI = TILE_PIX / (p.TW * p.TH);
+    p.tilesW = (W + p.TW - 1) / p.TW; p.tilesH = (H + p.TH - 1) / p.TH; p.tilesN = (N + p.TI - 1) / p.TI;
+    p.pixTiles = p.tilesW * p.tilesH * p.tilesN;
+    p.tilesCo = (Cout + 63) / 64; p.tilesCi = (Cin + 63) / 64;
+    int base = p.tilesCo * p.tilesCi;
+    int want = (1024 + base - 1) / base;                 // aim at >= 1024 blocks (4 per CU)
+    p.splitK = want < 1 ? 1 : (want > p.pixTiles ? p.pixTiles : want);
+    const int HALO = ksize / 2;
+    const int PW = p.TW + 2 * HALO, PH = p.TH + 2 * HALO;
+    const int P = p.TI * PH * PW, Ppad = (P + 15) & ~15, MARGIN = HALO * PW + HALO;
+    size_t lds = (size_t)(2 * Ppad + 2 * (Ppad + 2 * MARGIN)) * 32 * sizeof(bf16_t);
+    if (lds > 160 * 1024) { agf_set_error("conv2d_wgrad: tile needs %zu bytes of LDS", lds); return AGF_ENOKERNEL; }
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)(base * p.splitK)), block(256);
+    hipError_t e;
+    if (ksize == 3) {
+        e = hipFuncSetAttribute((const void*)conv2d_wgrad_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { agf_set_error("conv2d_wgrad: cannot reserve LDS: %s", hipGetErrorString(e)); return AGF_ELAUNCH; }
+        hipLaunchKernelGGL((conv2d_wgrad_kernel<3>), grid, block, lds, st, p);
+    } else {
+        e = hipFuncSetAttribute((const void*)conv2d_wgrad_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { agf_set_error("conv2d_wgrad: cannot reserve LDS: %s", hipGetErrorString(e)); return AGF_ELAUNCH; }
+        hipLaunchKernelGGL((conv2d_wgrad_kernel<1>), grid, block, lds, st, p);
+    }
+    AGF_LAUNCH_CHECK();
+    return AGF_OK;
+}

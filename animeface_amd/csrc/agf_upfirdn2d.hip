@@ -31,6 +31,7 @@ struct UpfirdnParams {
     float gain;
     int tilesX, tilesY;          // nchw_tile only
     int tileInW, tileInH;
+    int cg_shift;                // nhwc_vec: log2(C / VEC) or -1
 };
 
 #define MAX_FILTER_TAPS 1024     // up to 32x32 (reference limit: 32x32 in the small kernels)
@@ -88,6 +89,7 @@ __global__ void __launch_bounds__(256) upfirdn2d_generic(UpfirdnParams p) {
 // Compile-time (UPX, UPY, DNX, DNY, FW, FH) when > 0 lets the tap loops unroll fully; 0 = runtime.
 template <class T, int VEC, int UPX, int UPY, int DNX, int DNY, int FW, int FH>
 __global__ void __launch_bounds__(256) upfirdn2d_nhwc_vec(UpfirdnParams p) {
+    // grid: x = tiles of the flattened (ox, channel-group) row, y = oy, z = n  -> no 64-bit index arithmetic
     __shared__ float sf[MAX_FILTER_TAPS];
     stage_filter<256>(p, sf);
     __syncthreads();
@@ -95,64 +97,63 @@ __global__ void __launch_bounds__(256) upfirdn2d_nhwc_vec(UpfirdnParams p) {
     const int dnx = DNX ? DNX : p.downx, dny = DNY ? DNY : p.downy;
     const int fw = FW ? FW : p.fw, fh = FH ? FH : p.fh;
     const int CG = p.C / VEC;
-    const int64_t total = (int64_t)p.N * p.OH * p.OW * CG;
-    const int64_t rowC = (int64_t)p.W * p.C;
-    for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
-        int64_t r = id;
-        int cg = (int)(r % CG); r /= CG;
-        int ox = (int)(r % p.OW); r /= p.OW;
-        int oy = (int)(r % p.OH);
-        int n = (int)(r / p.OH);
-        int midy = oy * dny + upy - 1 - p.pady0;
-        int midx = ox * dnx + upx - 1 - p.padx0;
-        int iny0 = agf_floor_div(midy, upy), inx0 = agf_floor_div(midx, upx);
-        int ky0 = (iny0 + 1) * upy - midy - 1, kx0 = (inx0 + 1) * upx - midx - 1;
-        const T* xb = (const T*)p.x + (int64_t)n * p.H * rowC + cg * VEC;
-        float acc[VEC];
+    const int rowv = p.OW * CG;                       // vectors per output row
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rowv) return;
+    const int ox = (p.cg_shift >= 0) ? (idx >> p.cg_shift) : (idx / CG);
+    const int cg = idx - ox * CG;
+    const int oy = blockIdx.y;
+    const int n = blockIdx.z;
+    const int midy = oy * dny + upy - 1 - p.pady0;
+    const int midx = ox * dnx + upx - 1 - p.padx0;
+    const int iny0 = agf_floor_div(midy, upy), inx0 = agf_floor_div(midx, upx);
+    const int ky0 = (iny0 + 1) * upy - midy - 1, kx0 = (inx0 + 1) * upx - midx - 1;
+    const int rowC = p.W * p.C;                       // < 2^31 guaranteed by the footprint check
+    const T* xb = (const T*)p.x + (int64_t)n * p.H * rowC + cg * VEC;
+    float acc[VEC];
 #pragma unroll
-        for (int i = 0; i < VEC; i++) acc[i] = 0.f;
-        // compile-time tap counts: ceil(F / UP) taps per axis
-        constexpr int NTY = (FH && UPY) ? (FH + UPY - 1) / UPY : 0;
-        constexpr int NTX = (FW && UPX) ? (FW + UPX - 1) / UPX : 0;
-        if (NTY && NTX) {
+    for (int i = 0; i < VEC; i++) acc[i] = 0.f;
+    // compile-time tap counts: ceil(F / UP) taps per axis
+    constexpr int NTY = (FH && UPY) ? (FH + (UPY ? UPY : 1) - 1) / (UPY ? UPY : 1) : 0;
+    constexpr int NTX = (FW && UPX) ? (FW + (UPX ? UPX : 1) - 1) / (UPX ? UPX : 1) : 0;
+    if constexpr (NTY * NTX > 0) {
 #pragma unroll
-            for (int jy = 0; jy < NTY; jy++) {
-                int ky = ky0 + jy * upy, iy = iny0 + jy;
-                bool oky = ky < fh;
-                if (p.clamp_edge) iy = min(max(iy, 0), p.H - 1); else oky = oky && iy >= 0 && iy < p.H;
+        for (int jy = 0; jy < NTY; jy++) {
+            int ky = ky0 + jy * upy, iy = iny0 + jy;
+            bool oky = ky < fh;
+            if (p.clamp_edge) iy = min(max(iy, 0), p.H - 1); else oky = oky && iy >= 0 && iy < p.H;
 #pragma unroll
-                for (int jx = 0; jx < NTX; jx++) {
-                    int kx = kx0 + jx * upx, ix = inx0 + jx;
-                    bool ok = oky && kx < fw;
-                    if (p.clamp_edge) ix = min(max(ix, 0), p.W - 1); else ok = ok && ix >= 0 && ix < p.W;
-                    if (ok) {
-                        float xv[VEC];
-                        VecIO<T, VEC>::load(xb + iy * rowC + (int64_t)ix * p.C, xv);
-                        float fv = sf[ky * fw + kx];
-#pragma unroll
-                        for (int i = 0; i < VEC; i++) acc[i] += xv[i] * fv;
-                    }
-                }
-            }
-        } else {
-            for (int ky = ky0, iy = iny0; ky < fh; ky += upy, iy++) {
-                int iyc = iy;
-                if (p.clamp_edge) iyc = min(max(iy, 0), p.H - 1); else if (iy < 0 || iy >= p.H) continue;
-                for (int kx = kx0, ix = inx0; kx < fw; kx += upx, ix++) {
-                    int ixc = ix;
-                    if (p.clamp_edge) ixc = min(max(ix, 0), p.W - 1); else if (ix < 0 || ix >= p.W) continue;
+            for (int jx = 0; jx < NTX; jx++) {
+                int kx = kx0 + jx * upx, ix = inx0 + jx;
+                bool ok = oky && kx < fw;
+                if (p.clamp_edge) ix = min(max(ix, 0), p.W - 1); else ok = ok && ix >= 0 && ix < p.W;
+                if (ok) {
                     float xv[VEC];
-                    VecIO<T, VEC>::load(xb + iyc * rowC + (int64_t)ixc * p.C, xv);
+                    VecIO<T, VEC>::load(xb + iy * rowC + ix * p.C, xv);
                     float fv = sf[ky * fw + kx];
 #pragma unroll
                     for (int i = 0; i < VEC; i++) acc[i] += xv[i] * fv;
                 }
             }
         }
+    } else {
+        for (int ky = ky0, iy = iny0; ky < fh; ky += upy, iy++) {
+            int iyc = iy;
+            if (p.clamp_edge) iyc = min(max(iy, 0), p.H - 1); else if (iy < 0 || iy >= p.H) continue;
+            for (int kx = kx0, ix = inx0; kx < fw; kx += upx, ix++) {
+                int ixc = ix;
+                if (p.clamp_edge) ixc = min(max(ix, 0), p.W - 1); else if (ix < 0 || ix >= p.W) continue;
+                float xv[VEC];
+                VecIO<T, VEC>::load(xb + iyc * rowC + ixc * p.C, xv);
+                float fv = sf[ky * fw + kx];
 #pragma unroll
-        for (int i = 0; i < VEC; i++) acc[i] *= p.gain;
-        VecIO<T, VEC>::store((T*)p.y + (((int64_t)n * p.OH + oy) * p.OW + ox) * p.C + cg * VEC, acc);
+                for (int i = 0; i < VEC; i++) acc[i] += xv[i] * fv;
+            }
+        }
     }
+#pragma unroll
+    for (int i = 0; i < VEC; i++) acc[i] *= p.gain;
+    VecIO<T, VEC>::store((T*)p.y + ((int64_t)n * p.OH + oy) * ((int64_t)p.OW * p.C) + ox * p.C + cg * VEC, acc);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -212,13 +213,16 @@ __global__ void __launch_bounds__(256) upfirdn2d_nchw_tile(UpfirdnParams p) {
 // -------------------------------------------------------------------------------------------------
 template <class T, int VEC>
 static bool launch_nhwc(const UpfirdnParams& p, hipStream_t st) {
-    const int64_t total = (int64_t)p.N * p.OH * p.OW * (p.C / VEC);
-    int64_t blocks = agf_ceil_div(total, 256);
-    if (blocks > (1 << 30)) blocks = 1 << 30;
-    dim3 g((unsigned)blocks), b(256);
+    const int CG = p.C / VEC;
+    if ((int64_t)p.OW * CG > INT32_MAX || p.OH > 65535 || p.N > 65535) return false;
+    UpfirdnParams q = p;
+    q.cg_shift = -1;
+    for (int sft = 0; sft < 31; sft++) if ((1 << sft) == CG) q.cg_shift = sft;
+    dim3 g((unsigned)agf_ceil_div((int64_t)p.OW * CG, 256), (unsigned)p.OH, (unsigned)p.N), b(256);
+    const UpfirdnParams& pp = q;
 #define NHWC_CASE(ux, uy, dx, dy, w, h)                                                                   \
     if (p.upx == ux && p.upy == uy && p.downx == dx && p.downy == dy && p.fw == w && p.fh == h) {         \
-        hipLaunchKernelGGL((upfirdn2d_nhwc_vec<T, VEC, ux, uy, dx, dy, w, h>), g, b, 0, st, p);           \
+        hipLaunchKernelGGL((upfirdn2d_nhwc_vec<T, VEC, ux, uy, dx, dy, w, h>), g, b, 0, st, pp);          \
         return true;                                                                                      \
     }
     NHWC_CASE(2, 2, 1, 1, 4, 4)   // bilinear-equivalent 2x upsample  (StyleGAN2 Upsample2x, ToImage)
@@ -228,7 +232,7 @@ static bool launch_nhwc(const UpfirdnParams& p, hipStream_t st) {
     NHWC_CASE(2, 2, 1, 1, 2, 2)   // adjoint of AvgPool2d(2)
     NHWC_CASE(1, 1, 1, 1, 4, 4)   // StyleGAN3-D filter2d before the strided conv
 #undef NHWC_CASE
-    hipLaunchKernelGGL((upfirdn2d_nhwc_vec<T, VEC, 0, 0, 0, 0, 0, 0>), g, b, 0, st, p);
+    hipLaunchKernelGGL((upfirdn2d_nhwc_vec<T, VEC, 0, 0, 0, 0, 0, 0>), g, b, 0, st, pp);
     return true;
 }
 
@@ -236,10 +240,10 @@ template <class T>
 static int launch_typed(UpfirdnParams& p, bool dense_nchw, bool dense_nhwc, int vec, hipStream_t st) {
     const int64_t total = (int64_t)p.N * p.C * p.OH * p.OW;
     if (dense_nhwc && vec > 0 && p.C % vec == 0 && ((uintptr_t)p.x % 16 == 0) && ((uintptr_t)p.y % 16 == 0)) {
-        if constexpr (sizeof(T) == 4) launch_nhwc<T, 4>(p, st);
-        else if constexpr (sizeof(T) == 2) launch_nhwc<T, 8>(p, st);
-        else goto generic;
-        return AGF_OK;
+        bool ok = false;
+        if constexpr (sizeof(T) == 4) ok = launch_nhwc<T, 4>(p, st);
+        else if constexpr (sizeof(T) == 2) ok = launch_nhwc<T, 8>(p, st);
+        if (ok) return AGF_OK;
     }
     if (dense_nchw && sizeof(T) <= 4) {      // fp64 keeps full precision through the generic kernel
         p.tileInW = ((TILE_OW - 1) * p.downx + p.fw - 1) / p.upx + 1;
@@ -255,7 +259,6 @@ static int launch_typed(UpfirdnParams& p, bool dense_nchw, bool dense_nhwc, int 
             }
         }
     }
-generic:
     {
         int64_t blocks = agf_ceil_div(total, 256);
         if (blocks > 65536 * 16) blocks = 65536 * 16;
@@ -294,7 +297,7 @@ extern "C" int agf_upfirdn2d(const void* x, const float* f, void* y, int dtype,
     p.fh = f_size[0]; p.fw = f_size[1]; p.fsy = f_stride[0]; p.fsx = f_stride[1];
     p.upx = upx; p.upy = upy; p.downx = downx; p.downy = downy; p.padx0 = padx0; p.pady0 = pady0;
     p.flip = flip ? 1 : 0; p.clamp_edge = edge_mode == AGF_EDGE_CLAMP; p.gain = gain;
-    p.tilesX = p.tilesY = p.tileInW = p.tileInH = 0;
+    p.tilesX = p.tilesY = p.tileInW = p.tileInH = 0; p.cg_shift = -1;
 
     auto dense = [](const int32_t* sz, const int64_t* st, bool nhwc) {
         int64_t N = sz[0], C = sz[1], H = sz[2], W = sz[3];

@@ -35,14 +35,21 @@ activation_funcs = {
 }
 
 
-def _dense_like(t, memory_format):
-    return t.contiguous(memory_format=memory_format)
+def _is_dense(t):
+    """``Tensor::is_non_overlapping_and_dense`` (bias_act.cpp:41): some permutation of the dims is contiguous."""
+    dims = sorted((d for d in range(t.dim()) if t.size(d) > 1), key=lambda d: t.stride(d))
+    expect = 1
+    for d in dims:
+        if t.stride(d) != expect:
+            return False
+        expect *= t.size(d)
+    return True
 
 
 def _native(x, b, xref, yref, dy, grad, dim, act_idx, alpha, gain, clamp):
     """Counterpart of ``_plugin.bias_act`` (reference bias_act.cpp:26-83); allocates y like ``empty_like(x)``."""
     _lib.require_gpu(x, 'bias_act')
-    if not x.is_non_overlapping_and_dense():
+    if not _is_dense(x):
         raise RuntimeError('x must be non-overlapping and dense')
     for name, t in (('xref', xref), ('yref', yref), ('dy', dy)):
         if t is not None and (t.shape != x.shape or t.dtype != x.dtype or t.stride() != x.stride()):
@@ -90,7 +97,9 @@ def _bias_act_hip(dim=1, act='linear', alpha=None, gain=None, clamp=None):
                 y = _native(x, b, None, None, None, 0, dim, spec.cuda_idx, alpha, gain, clamp)
             need_x = 'x' in spec.ref or spec.has_2nd_grad
             ctx.has_b = b is not None
-            ctx.save_for_backward(x if need_x else None, b if need_x else None, y if 'y' in spec.ref else None)
+            # y is also kept when clamping so that the clamp's zero-gradient region is honoured for every activation
+            # (the reference's native path drops it for act='linear', whose ref is ''; its `_ref` path -- the oracle -- does not)
+            ctx.save_for_backward(x if need_x else None, b if need_x else None, y if ('y' in spec.ref or clamp >= 0) else None)
             return y
 
         @staticmethod
