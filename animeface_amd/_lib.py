@@ -59,10 +59,10 @@ def lib():
         L.agf_filtered_lrelu_act.argtypes = [_vp, _vp, ctypes.c_int, _i32x4, _i64x4, _i32x2, _i32x2, ctypes.c_int,
                                              ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp]
         L.agf_conv2d_fwd.restype = ctypes.c_int
-        L.agf_conv2d_fwd.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp] + [ctypes.c_int32] * 6 + \
+        L.agf_conv2d_fwd.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int] + [ctypes.c_int32] * 6 + \
                                     [ctypes.c_int, ctypes.c_float, ctypes.c_float, _vp]
         L.agf_conv2d_wgrad.restype = ctypes.c_int
-        L.agf_conv2d_wgrad.argtypes = [_vp, _vp, _vp, _vp, _vp] + [ctypes.c_int32] * 6 + [_vp]
+        L.agf_conv2d_wgrad.argtypes = [_vp, _vp, _vp, _vp, _vp, ctypes.c_int] + [ctypes.c_int32] * 6 + [_vp]
         if L.agf_abi_version() != 1:
             raise AgfError('libagf_ops.so ABI version mismatch')
         _lib = L

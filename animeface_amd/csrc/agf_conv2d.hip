@@ -201,6 +201,86 @@ __global__ void __launch_bounds__(256) conv2d_fwd_kernel(ConvParams p) {
     }
 }
 
+
+// =================================================================================================
+// fp32 reference-precision path (the reference's --disable-amp configuration and the <= 1e-3 parity tests).
+// Plain VALU FMAs in fp32, same layouts (NHWC activations, OHWI weights), same fused scales / epilogue.
+// Not a throughput path: the bf16 MFMA kernels above are.
+struct ConvF32Params {
+    const float* x; const float* w; float* y;
+    const float* in_scale; const float* out_scale; const float* bias; const float* noise; const float* residual;
+    int N, H, W, Cin, Cout, KS;
+    int act; float alpha, gain;
+};
+
+__global__ void __launch_bounds__(256) conv2d_fwd_f32_kernel(ConvF32Params p) {
+    // thread -> (pixel, co); lanes run along co so x loads broadcast and y stores coalesce
+    const int64_t total = (int64_t)p.N * p.H * p.W * p.Cout;
+    const int HALO = p.KS / 2, TAPS = p.KS * p.KS;
+    for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+        int co = (int)(id % p.Cout);
+        int64_t pix = id / p.Cout;
+        int w = (int)(pix % p.W); int64_t t = pix / p.W; int h = (int)(t % p.H); int n = (int)(t / p.H);
+        float acc = 0.f;
+        for (int kh = 0; kh < p.KS; kh++) {
+            int ih = h + kh - HALO;
+            if (ih < 0 || ih >= p.H) continue;
+            for (int kw = 0; kw < p.KS; kw++) {
+                int iw = w + kw - HALO;
+                if (iw < 0 || iw >= p.W) continue;
+                const float* xp = p.x + (((int64_t)n * p.H + ih) * p.W + iw) * p.Cin;
+                const float* wp = p.w + ((int64_t)co * TAPS + kh * p.KS + kw) * p.Cin;
+                const float* sp = p.in_scale ? p.in_scale + (int64_t)n * p.Cin : nullptr;
+                for (int ci = 0; ci < p.Cin; ci++) {
+                    float xv = xp[ci];
+                    if (sp) xv *= sp[ci];
+                    acc += xv * wp[ci];
+                }
+            }
+        }
+        if (p.out_scale) acc *= p.out_scale[(int64_t)n * p.Cout + co];
+        if (p.bias) acc += p.bias[co];
+        if (p.noise) acc += p.noise[pix];
+        if (p.residual) acc += p.residual[id];
+        if (p.act == 3) acc = acc > 0.f ? acc : acc * p.alpha;
+        p.y[id] = acc * p.gain;
+    }
+}
+
+struct WgradF32Params {
+    const float* x; const float* dy; float* dw;
+    const float* in_scale; const float* out_scale;
+    int N, H, W, Cin, Cout, KS, chunks;
+};
+
+__global__ void __launch_bounds__(256) conv2d_wgrad_f32_kernel(WgradF32Params p) {
+    // thread -> (co, tap, ci); blockIdx.y -> chunk of images; partial sums combined with fp32 atomics
+    const int TAPS = p.KS * p.KS, HALO = p.KS / 2;
+    const int64_t total = (int64_t)p.Cout * TAPS * p.Cin;
+    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= total) return;
+    int ci = (int)(id % p.Cin); int64_t t = id / p.Cin; int tap = (int)(t % TAPS); int co = (int)(t / TAPS);
+    int kh = tap / p.KS, kw = tap % p.KS;
+    float acc = 0.f;
+    for (int n = blockIdx.y; n < p.N; n += p.chunks) {
+        float sc = 1.f;
+        if (p.in_scale) sc *= p.in_scale[(int64_t)n * p.Cin + ci];
+        if (p.out_scale) sc *= p.out_scale[(int64_t)n * p.Cout + co];
+        float a = 0.f;
+        for (int h = 0; h < p.H; h++) {
+            int ih = h + kh - HALO;
+            if (ih < 0 || ih >= p.H) continue;
+            for (int w = 0; w < p.W; w++) {
+                int iw = w + kw - HALO;
+                if (iw < 0 || iw >= p.W) continue;
+                a += p.dy[(((int64_t)n * p.H + h) * p.W + w) * p.Cout + co] * p.x[(((int64_t)n * p.H + ih) * p.W + iw) * p.Cin + ci];
+            }
+        }
+        acc += a * sc;
+    }
+    unsafeAtomicAdd(p.dw + id, acc);
+}
+
 static int pow2_ceil(int v) { int r = 1; while (r < v) r <<= 1; return r; }
 
 template <int KS, int MT>
@@ -227,9 +307,25 @@ static int launch_fwd(const ConvParams& p, hipStream_t st) {
 extern "C" int agf_conv2d_fwd(const void* x, const void* w, void* y,
                               const float* in_scale, const float* out_scale, const float* bias,
                               const float* noise, const void* residual,
-                              int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
+                              int dtype, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
                               int act, float alpha, float act_gain, void* stream) {
     AGF_CHECK(x && w && y, "conv2d_fwd: null pointer");
+    AGF_CHECK(dtype == AGF_BF16 || dtype == AGF_F32, "conv2d_fwd: dtype must be bf16 or f32");
+    if (dtype == AGF_F32) {
+        AGF_CHECK(N >= 1 && H >= 1 && W >= 1 && Cin >= 1 && Cout >= 1, "conv2d_fwd: empty tensor");
+        AGF_CHECK(ksize == 1 || ksize == 3, "conv2d_fwd: kernel size must be 1 or 3 (got %d)", ksize);
+        AGF_CHECK(act == 1 || act == 3, "conv2d_fwd: act must be 1 (linear) or 3 (lrelu)");
+        ConvF32Params q;
+        q.x = (const float*)x; q.w = (const float*)w; q.y = (float*)y;
+        q.in_scale = in_scale; q.out_scale = out_scale; q.bias = bias; q.noise = noise; q.residual = (const float*)residual;
+        q.N = N; q.H = H; q.W = W; q.Cin = Cin; q.Cout = Cout; q.KS = ksize; q.act = act; q.alpha = alpha; q.gain = act_gain;
+        int64_t total = (int64_t)N * H * W * Cout;
+        int64_t blocks = agf_ceil_div(total, 256);
+        if (blocks > (1 << 20)) blocks = 1 << 20;
+        hipLaunchKernelGGL(conv2d_fwd_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, q);
+        AGF_LAUNCH_CHECK();
+        return AGF_OK;
+    }
     AGF_CHECK(N >= 1 && H >= 1 && W >= 1 && Cin >= 1 && Cout >= 1, "conv2d_fwd: empty tensor");
     AGF_CHECK(ksize == 1 || ksize == 3, "conv2d_fwd: kernel size must be 1 or 3 (got %d)", ksize);
     AGF_CHECK(Cin % 8 == 0, "conv2d_fwd: Cin must be a multiple of 8 (pad the channel axis)");
@@ -402,9 +498,22 @@ __global__ void __launch_bounds__(256) conv2d_wgrad_kernel(WgradParams p) {
 
 extern "C" int agf_conv2d_wgrad(const void* x, const void* dy, float* dw,
                                 const float* in_scale, const float* out_scale,
-                                int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
+                                int dtype, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
                                 void* stream) {
     AGF_CHECK(x && dy && dw, "conv2d_wgrad: null pointer");
+    AGF_CHECK(dtype == AGF_BF16 || dtype == AGF_F32, "conv2d_wgrad: dtype must be bf16 or f32");
+    if (dtype == AGF_F32) {
+        AGF_CHECK(N >= 1 && H >= 1 && W >= 1 && Cin >= 1 && Cout >= 1, "conv2d_wgrad: empty tensor");
+        AGF_CHECK(ksize == 1 || ksize == 3, "conv2d_wgrad: kernel size must be 1 or 3 (got %d)", ksize);
+        WgradF32Params q;
+        q.x = (const float*)x; q.dy = (const float*)dy; q.dw = dw; q.in_scale = in_scale; q.out_scale = out_scale;
+        q.N = N; q.H = H; q.W = W; q.Cin = Cin; q.Cout = Cout; q.KS = ksize;
+        q.chunks = N < 64 ? N : 64;
+        int64_t total = (int64_t)Cout * ksize * ksize * Cin;
+        hipLaunchKernelGGL(conv2d_wgrad_f32_kernel, dim3((unsigned)agf_ceil_div(total, 256), (unsigned)q.chunks), dim3(256), 0, (hipStream_t)stream, q);
+        AGF_LAUNCH_CHECK();
+        return AGF_OK;
+    }
     AGF_CHECK(N >= 1 && H >= 1 && W >= 1 && Cin >= 1 && Cout >= 1, "conv2d_wgrad: empty tensor");
     AGF_CHECK(ksize == 1 || ksize == 3, "conv2d_wgrad: kernel size must be 1 or 3 (got %d)", ksize);
     AGF_CHECK(Cin % 8 == 0 && Cout % 8 == 0, "conv2d_wgrad: Cin and Cout must be multiples of 8 (pad the channel axis)");

@@ -21,6 +21,13 @@ def _f32(t):
     return None if t is None else t.contiguous().float()
 
 
+def _ohwi(w):
+    """[Cout,Cin,k,k] -> dense tensor whose memory order is [Cout][kh][kw][Cin]."""
+    if w.shape[2] == 1 and w.shape[3] == 1:
+        return w.contiguous()
+    return w.contiguous(memory_format=torch.channels_last)
+
+
 def conv2d_fwd_raw(x, w, in_scale=None, out_scale=None, bias=None, noise=None, residual=None,
                    act=ACT_LINEAR, alpha=0.2, gain=1.0):
     """One ``agf_conv2d_fwd`` launch.  x: [N,Cin,H,W] bf16 channels_last; w: [Cout,Cin,k,k] (any float dtype).
@@ -30,16 +37,16 @@ def conv2d_fwd_raw(x, w, in_scale=None, out_scale=None, bias=None, noise=None, r
     Cout, Cin_w, k, k2 = w.shape
     if Cin_w != Cin or k != k2:
         raise RuntimeError(f'conv2d: weight {tuple(w.shape)} does not match input {tuple(x.shape)}')
-    if x.dtype != torch.bfloat16:
-        raise RuntimeError('conv2d: activations must be bfloat16')
+    if x.dtype not in (torch.bfloat16, torch.float32):
+        raise RuntimeError('conv2d: activations must be bfloat16 (MFMA path) or float32 (reference-precision path)')
     x = x.contiguous(memory_format=torch.channels_last)
-    wq = w.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)      # OHWI in memory
-    y = torch.empty((N, Cout, H, W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    wq = _ohwi(w.to(x.dtype))
+    y = torch.empty((N, Cout, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
     in_scale, out_scale, bias, noise = _f32(in_scale), _f32(out_scale), _f32(bias), _f32(noise)
     if residual is not None:
-        residual = residual.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        residual = residual.to(x.dtype).contiguous(memory_format=torch.channels_last)
     rc = _lib.lib().agf_conv2d_fwd(_lib.ptr(x), _lib.ptr(wq), _lib.ptr(y), _lib.ptr(in_scale), _lib.ptr(out_scale),
-                                   _lib.ptr(bias), _lib.ptr(noise), _lib.ptr(residual),
+                                   _lib.ptr(bias), _lib.ptr(noise), _lib.ptr(residual), _lib.dtype_code(x),
                                    N, H, W, Cin, Cout, k, act, float(alpha), float(gain), _lib.stream_ptr(x))
     _lib.check(rc, 'conv2d_fwd')
     return y
@@ -53,8 +60,8 @@ def conv2d_wgrad_raw(x, dy, ksize, in_scale=None, out_scale=None):
     Cout = dy.shape[1]
     if dy.shape[0] != N or dy.shape[2] != H or dy.shape[3] != W:
         raise RuntimeError(f'conv2d_wgrad: dy {tuple(dy.shape)} does not match x {tuple(x.shape)}')
-    if x.dtype != torch.bfloat16 or dy.dtype != torch.bfloat16:
-        raise RuntimeError('conv2d_wgrad: activations must be bfloat16')
+    if x.dtype not in (torch.bfloat16, torch.float32) or dy.dtype != x.dtype:
+        raise RuntimeError('conv2d_wgrad: x and dy must both be bfloat16 or both float32')
     x = x.contiguous(memory_format=torch.channels_last)
     dy = dy.contiguous(memory_format=torch.channels_last)
     dw = torch.zeros((Cout, Cin, ksize, ksize), dtype=torch.float32, device=x.device).contiguous(memory_format=torch.channels_last)
@@ -62,7 +69,7 @@ def conv2d_wgrad_raw(x, dy, ksize, in_scale=None, out_scale=None):
         dw = torch.zeros((Cout, Cin, 1, 1), dtype=torch.float32, device=x.device)
     in_scale, out_scale = _f32(in_scale), _f32(out_scale)
     rc = _lib.lib().agf_conv2d_wgrad(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(in_scale), _lib.ptr(out_scale),
-                                     N, H, W, Cin, Cout, ksize, _lib.stream_ptr(x))
+                                     _lib.dtype_code(x), N, H, W, Cin, Cout, ksize, _lib.stream_ptr(x))
     _lib.check(rc, 'conv2d_wgrad')
     return dw
 
@@ -85,7 +92,7 @@ class _ConvFwd(torch.autograd.Function):
     def backward(ctx, dy):
         x, w, s_in, s_out, y = ctx.saved_tensors
         dx = dw = ds_in = ds_out = None
-        dy = dy.to(torch.bfloat16)
+        dy = dy.to(x.dtype)
         if ctx.needs_input_grad[0] or (s_in is not None and ctx.needs_input_grad[2]):
             if s_in is None:
                 dx = _ConvFwd.apply(dy, flip_transpose(w), s_out, None)
@@ -153,7 +160,7 @@ def conv2d(x, w, s_in=None, s_out=None):
     s_in [N,Cin] / s_out [N,Cout]: optional fp32 per-sample channel scales (style modulation / demodulation).
     Channel counts that are not multiples of 8 are zero-padded here (the 513-channel minibatch-stddev conv)."""
     Cout, Cin = w.shape[0], w.shape[1]
-    if Cin % 8 or Cout % 8:
+    if x.dtype == torch.bfloat16 and (Cin % 8 or Cout % 8):
         xp = _pad_channels(x, 8, 1)
         wp = _pad_channels(_pad_channels(w, 8, 1), 8, 0)
         si = _pad_channels(s_in, 8, 1) if s_in is not None else None

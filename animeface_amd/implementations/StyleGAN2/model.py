@@ -1,0 +1,426 @@
+"""StyleGAN2 generator / discriminator on the MI355X operators.
+
+Drop-in for the reference's ``implementations/StyleGAN2/model.py``: same class names, constructor
+arguments and module tree, hence the same ``state_dict`` keys (a ``G_*.pt`` written by the reference
+loads here and vice versa), same forward semantics including its quirks (``InjectNoise`` adds unscaled
+noise and never uses ``scale``; ``PixelNorm`` adds eps after the sqrt).  What differs is how the
+arithmetic is executed:
+
+  reference (stock torch.nn, model.py)                 here (one HIP kernel each, libagf_ops.so)
+  ---------------------------------------------------  ------------------------------------------------------
+  nn.Upsample(bilinear)           :56-58               upfirdn2d  up=2, f=[1,3,3,1], clamp-to-edge
+  Blur2d depthwise conv           :138-149             upfirdn2d  f=[1,2,1]  (bit-identical)
+  nn.AvgPool2d(2)                 :61-63               upfirdn2d  down=2, f=[1,1]
+  grouped F.conv2d on a [B,Cout,Cin,3,3] weight :106-132   shared-weight MFMA conv with per-sample input scale
+                                                       (style) and output scale (demodulation):
+                                                       d * conv(W*coef, x * s),  d = rsqrt(sum (W*coef*s)^2 + 1e-4)
+  ELR: x*coef then nn.Conv2d      :29-37               MFMA conv with coef folded into the weights
+  + bias, LeakyReLU               :132,164,193         bias_act kernel
+Activations run channels-last in ``compute_dtype`` (bf16 for training, fp32 for reference-precision runs);
+parameters stay fp32.  The skip path of ``DBlock`` pools before its 1x1 conv (the two commute exactly).
+"""
+import functools
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ...stylegan3_ops import upfirdn2d, bias_act
+from ... import rng
+from .conv import conv2d
+
+
+class ELR(nn.Module):
+    """equalized learning rate (reference model.py:29-37): ``layer(x * coef)``, coef = gain / sqrt(fan_in)."""
+
+    def __init__(self, layer, gain=1.):
+        super().__init__()
+        self.coef = gain / (layer.weight[0].numel() ** 0.5)
+        self.layer = layer
+
+    def forward(self, x):
+        if isinstance(self.layer, nn.Conv2d):
+            return elr_conv2d(self, x)
+        return F.linear(x.float() * self.coef, self.layer.weight, self.layer.bias)
+
+
+def elr_conv2d(elr, x, act=None):
+    """``ELR(nn.Conv2d)`` on the MFMA conv; coef is folded into the weights; optional fused-order bias + lrelu."""
+    conv = elr.layer
+    k = conv.kernel_size[0]
+    assert conv.stride == (1, 1) and conv.padding == (k // 2, k // 2) and k in (1, 3)
+    y = conv2d(x, conv.weight * elr.coef)
+    b = conv.bias.to(y.dtype) if conv.bias is not None else None
+    if act == 'lrelu':
+        return bias_act.bias_act(y, b, act='lrelu', alpha=0.2, gain=1)
+    return bias_act.bias_act(y, b) if b is not None else y
+
+
+def Linear(name, *args, **kwargs):
+    linear = nn.Linear(*args, **kwargs)
+    if name == 'elr':
+        return ELR(linear)
+    return linear
+
+
+def Conv2d(name, *args, **kwargs):
+    conv = nn.Conv2d(*args, **kwargs)
+    if name == 'elr':
+        return ELR(conv)
+    return conv
+
+
+class _BilinearUp2x(nn.Module):
+    """``nn.Upsample(scale_factor=2, mode='bilinear', align_corners=False)`` as a clamp-edge FIR upsample."""
+
+    def __init__(self):
+        super().__init__()
+        self.register_buffer('f', upfirdn2d.setup_filter([1, 3, 3, 1]), persistent=False)
+
+    def forward(self, x):
+        return upfirdn2d.upsample2d(x, self.f, up=2, edge='clamp')
+
+
+class _AvgPool2x(nn.Module):
+    """``nn.AvgPool2d(2)`` as a FIR downsample with the box filter."""
+
+    def __init__(self):
+        super().__init__()
+        self.register_buffer('f', upfirdn2d.setup_filter([1, 1]), persistent=False)
+
+    def forward(self, x, gain=1):
+        return upfirdn2d.downsample2d(x, self.f, down=2, gain=gain)
+
+
+def Upsample2x(name):
+    if name == 'pixelshuffle':
+        return nn.PixelShuffle(2)
+    assert name == 'bilinear', 'only the bilinear upsample of the reference configuration is mapped onto upfirdn2d'
+    return _BilinearUp2x()
+
+
+def Downsample2x(name):
+    if name == 'max':
+        return nn.MaxPool2d(2)
+    elif name == 'avg':
+        return _AvgPool2x()
+
+
+class Flatten(nn.Module):
+    def forward(self, x):
+        return x.reshape(x.size(0), -1)
+
+
+class MapLinear(nn.Module):
+    """reference model.py:71-78: ``(x*coef @ W^T + b) * lr``."""
+
+    def __init__(self, *args, lr=0.01, **kwargs):
+        super().__init__()
+        self.linear = Linear('elr', *args, **kwargs)
+        self.lr = lr
+
+    def forward(self, x):
+        return self.linear(x) * self.lr
+
+
+class InjectNoise(nn.Module):
+    """reference model.py:81-88: ``x + randn(B,1,H,W)``; ``scale`` exists only for state_dict parity (F10)."""
+
+    def __init__(self):
+        super().__init__()
+        self.scale = nn.Parameter(torch.zeros(1))
+
+    @staticmethod
+    def draw(x):
+        B, _, H, W = x.size()
+        return rng.randn((B, 1, H, W), device=x.device)
+
+    def forward(self, x, noise=None):
+        if noise is None:
+            noise = self.draw(x)
+        return x + noise.to(x.dtype)
+
+
+class ModulatedConv2d(nn.Module):
+    """reference model.py:91-135, evaluated with shared weights and per-sample scales (see module docstring)."""
+
+    def __init__(self, in_channels, out_channels, style_dim, kernel_size, stride=1, demod=True, gain=1.):
+        super().__init__()
+        assert stride == 1, 'the reference only instantiates stride 1'
+        self.out_channels = out_channels
+        self.kernel_size = kernel_size
+        self.stride = stride
+        self.demod = demod
+        self.affine = Linear('elr', style_dim, in_channels)
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, kernel_size, kernel_size))
+        self.bias = nn.Parameter(torch.empty(1, out_channels, 1, 1))
+        self.coef = gain / (self.weight[0].numel() ** 0.5)
+
+    def scales(self, y):
+        """style scale s [B,Cin] and demodulation d [B,Cout] (fp32)."""
+        s = self.affine(y) + 1
+        w = self.weight * self.coef
+        d = None
+        if self.demod:
+            # sum_{ci,kh,kw} (w*s)^2  ==  s^2 @ (sum_{kh,kw} w^2)^T
+            d = torch.rsqrt(s.square() @ w.square().sum((2, 3)).t() + 1e-4)
+        return w, s, d
+
+    def forward(self, x, y):
+        w, s, d = self.scales(y)
+        out = conv2d(x, w, s, d)
+        return bias_act.bias_act(out, self.bias.reshape(-1).to(out.dtype))
+
+
+class Blur2d(nn.Module):
+    """reference model.py:138-149: [1,2,1]x[1,2,1]/16, zero pad 1 (``kernel`` kept as a buffer for state_dict parity)."""
+
+    def __init__(self):
+        super().__init__()
+        kernel = torch.tensor([[[1., 2., 1.], [2., 4., 2.], [1., 2., 1.]]])
+        kernel /= kernel.sum()
+        self.register_buffer('kernel', kernel)
+
+    def forward(self, x):
+        return upfirdn2d.filter2d(x, self.kernel[0])
+
+
+class StyleBlock(nn.Module):
+    """reference model.py:154-180: upsample -> blur -> (modconv, noise, lrelu) * num_conv; same ``block`` indices."""
+
+    def __init__(self, in_channels, out_channels, style_dim, num_conv=2, up_name='bilinear'):
+        super().__init__()
+        self.block = nn.ModuleList([
+            Upsample2x(up_name), Blur2d(),
+            ModulatedConv2d(in_channels, out_channels, style_dim, 3), InjectNoise(), nn.LeakyReLU(0.2, inplace=True)])
+        for _ in range(num_conv - 1):
+            self.block.extend([
+                ModulatedConv2d(out_channels, out_channels, style_dim, 3), InjectNoise(), nn.LeakyReLU(0.2, inplace=True)])
+
+    def forward(self, x, y):
+        mods = list(self.block)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, ModulatedConv2d) and i + 2 < len(mods) + 0 and isinstance(mods[i + 1], InjectNoise) \
+                    and isinstance(mods[i + 2], nn.LeakyReLU):
+                # modconv -> +bias -> +noise -> lrelu, noise drawn exactly where the reference draws it
+                w, s, d = m.scales(y)
+                out = conv2d(x, w, s, d)
+                noise = InjectNoise.draw(out)
+                out = out + noise.to(out.dtype)
+                x = bias_act.bias_act(out, m.bias.reshape(-1).to(out.dtype), act='lrelu', alpha=mods[i + 2].negative_slope, gain=1)
+                i += 3
+            elif isinstance(m, ModulatedConv2d):
+                x = m(x, y)
+                i += 1
+            else:
+                x = m(x)
+                i += 1
+        return x
+
+
+class DBlock(nn.Module):
+    """reference model.py:186-212."""
+
+    def __init__(self, in_channels, out_channels, num_conv=2, down_name='avg'):
+        super().__init__()
+        layers = [Conv2d('elr', in_channels, out_channels, 3, padding=1), nn.LeakyReLU(0.2, inplace=True)]
+        for _ in range(num_conv - 1):
+            layers.extend([Conv2d('elr', out_channels, out_channels, 3, padding=1), nn.LeakyReLU(0.2, inplace=True)])
+        self.block = nn.Sequential(*layers)
+        self.down = Downsample2x(down_name)
+        self.skip = Conv2d('elr', in_channels, out_channels, 1)
+
+    def forward(self, x):
+        t = x
+        mods = list(self.block)
+        for i in range(0, len(mods), 2):
+            x = elr_conv2d(mods[i], x, act='lrelu')
+        c = float(1 / np.sqrt(2))
+        if isinstance(self.down, _AvgPool2x):
+            # avg-pool commutes with the 1x1 skip conv: pool first (4x less work), identical result
+            t = elr_conv2d(self.skip, self.down(t))
+            return self.down(x, gain=c) + t * c
+        t = self.skip(t)
+        return (self.down(x) + self.down(t)) / np.sqrt(2)
+
+
+class MiniBatchStdDev(nn.Module):
+    """reference model.py:215-236 (statistics in fp32; 4x4 maps, negligible cost)."""
+
+    def __init__(self, group_size, eps=1e-4):
+        super().__init__()
+        self.group_size = group_size
+        self.eps = eps
+
+    def forward(self, x):
+        B, C, H, W = x.size()
+        groups = self.group_size if B % self.group_size == 0 else B
+        y = x.float().reshape(groups, -1, C, H, W)
+        y = y - y.mean(0, keepdim=True)
+        y = y.square().mean(0)
+        y = (y + self.eps).sqrt()
+        y = y.mean([1, 2, 3], keepdim=True)
+        y = y.repeat(groups, 1, H, W)
+        return torch.cat([x, y.to(x.dtype)], dim=1)
+
+
+class ToImage(nn.Module):
+    """reference model.py:239-250 ("ToRGB"): 1x1 modulated conv without demodulation, skip sum, bilinear x2."""
+
+    def __init__(self, in_channels, image_channels, style_dim, upsample=True, up_name='bilinear'):
+        super().__init__()
+        self.conv = ModulatedConv2d(in_channels, image_channels, style_dim, 1, demod=False)
+        self.upsample = Upsample2x(up_name) if upsample else None
+
+    def forward(self, x, y, pre=None):
+        x = self.conv(x, y).contiguous()          # RGB maps are kept NCHW (3 channels)
+        if pre is not None:
+            x = x + pre
+        if self.upsample is not None:
+            x = self.upsample(x)
+        return x
+
+
+class PixelNorm(nn.Module):
+    def forward(self, x):
+        return x / x.pow(2).mean(dim=1, keepdim=True).sqrt().add(1e-4)
+
+
+class Mapping(nn.Module):
+    """reference model.py:263-282 (fp32: 8 tiny GEMMs)."""
+
+    def __init__(self, style_dim, num_layers=8, normalize=True, lr=0.01):
+        super().__init__()
+        self.normalize = PixelNorm() if normalize else None
+        layers = []
+        for _ in range(num_layers):
+            layers.extend([MapLinear(style_dim, style_dim, lr=lr), nn.LeakyReLU(0.2, inplace=True)])
+        self.map = nn.Sequential(*layers)
+
+    def forward(self, x):
+        x = x.float()
+        if self.normalize is not None:
+            x = self.normalize(x)
+        return self.map(x)
+
+
+class Synthesis(nn.Module):
+    """reference model.py:285-332."""
+
+    def __init__(self, image_size, image_channels, style_dim, channels=32, max_channels=512, num_conv=2):
+        super().__init__()
+        check_c = functools.partial(min, max_channels)
+        resl = 4
+        channels = channels * (2 ** int(np.log2(image_size) - 2))
+        ochannels = check_c(channels)
+        self.input = ModulatedConv2d(style_dim, ochannels, style_dim, 3)
+        self.input_to_image = ToImage(ochannels, image_channels, style_dim)
+        self.num_layers = 1
+        self.blocks = nn.ModuleList()
+        self.to_images = nn.ModuleList()
+        while resl < image_size:
+            resl *= 2
+            channels = channels // 2
+            ichannels, ochannels = ochannels, check_c(channels)
+            self.blocks.append(StyleBlock(ichannels, ochannels, style_dim, num_conv))
+            self.to_images.append(ToImage(ochannels, image_channels, style_dim, upsample=True if resl < image_size else False))
+            self.num_layers += 1
+        self.tanh = nn.Tanh()
+
+    def forward(self, x, y, injection=None):
+        if isinstance(y, (list, tuple)):          # style mixing
+            assert len(y) == 2
+            if injection is None or injection > self.num_layers:
+                injection = np.random.randint(0, self.num_layers)
+            y = [y[0] for _ in range(injection)] + [y[1] for _ in range(self.num_layers - injection)]
+        else:
+            y = [y for _ in range(self.num_layers)]
+        x = self.input(x, y[0])
+        pre = self.input_to_image(x, y[0])
+        image = pre
+        for block, to_image, yy in zip(self.blocks, self.to_images, y[1:]):
+            x = block(x, yy)
+            image = to_image(x, yy, pre)
+            pre = image
+        return self.tanh(image.float())
+
+
+class Generator(nn.Module):
+    """reference model.py:335-367.  ``compute_dtype``: activation storage type of the synthesis network."""
+
+    def __init__(self, image_size=128, image_channels=3, style_dim=512, channels=32, max_channels=512,
+                 block_num_conv=2, map_num_layers=8, normalize_latent=True, map_lr=0.01, compute_dtype=torch.bfloat16):
+        super().__init__()
+        self.map = Mapping(style_dim, map_num_layers, normalize_latent, map_lr)
+        self.synthesis = Synthesis(image_size, image_channels, style_dim, channels, max_channels, block_num_conv)
+        self.const = nn.Parameter(torch.empty(1, style_dim, 4, 4))
+        self.const.data.normal_(0, 1)
+        self.compute_dtype = compute_dtype
+
+    def forward(self, z, injection=None):
+        if isinstance(z, (list, tuple)):
+            style = [self.map(z[0]), self.map(z[1])]
+            B = z[0].size(0)
+        else:
+            style = self.map(z)
+            B = z.size(0)
+        x = self.const.expand(B, -1, -1, -1).to(self.compute_dtype).contiguous(memory_format=torch.channels_last)
+        image = self.synthesis(x, style, injection)
+        return image, style
+
+    def init_weight(self, map_init_func, syn_init_func):
+        self.map.apply(map_init_func)
+        self.synthesis.apply(syn_init_func)
+
+
+class Discriminator(nn.Module):
+    """reference model.py:370-401."""
+
+    def __init__(self, image_size=128, image_channels=3, channels=32, max_channels=512, block_num_conv=2, mbsd_groups=4,
+                 compute_dtype=torch.bfloat16):
+        super().__init__()
+        check_c = functools.partial(min, max_channels)
+        ochannels = channels
+        self.from_rgb = nn.Sequential(Conv2d('elr', image_channels, ochannels, 1), nn.LeakyReLU(0.2, inplace=True))
+        resl = image_size
+        blocks = []
+        while resl > 4:
+            resl = resl // 2
+            channels *= 2
+            ichannels, ochannels = ochannels, check_c(channels)
+            blocks.append(DBlock(ichannels, ochannels, block_num_conv))
+        blocks.append(MiniBatchStdDev(mbsd_groups))
+        blocks.extend([
+            Conv2d('elr', ochannels + 1, ochannels, 3, padding=1), nn.LeakyReLU(0.2, inplace=True), Flatten(),
+            Linear('elr', ochannels * (resl ** 2), ochannels), nn.LeakyReLU(0.2, inplace=True),
+            Linear('elr', ochannels, 1)])
+        self.blocks = nn.Sequential(*blocks)
+        self.compute_dtype = compute_dtype
+
+    def forward(self, x):
+        x = x.to(self.compute_dtype)
+        x = elr_conv2d(self.from_rgb[0], x, act='lrelu')
+        mods = list(self.blocks)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, ELR) and isinstance(m.layer, nn.Conv2d) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.LeakyReLU):
+                x = elr_conv2d(m, x, act='lrelu')
+                i += 2
+            elif isinstance(m, nn.LeakyReLU):
+                x = F.leaky_relu(x, m.negative_slope)
+                i += 1
+            else:
+                x = m(x)
+                i += 1
+        return x.float()
+
+
+def init_weight_N01(m, lr=1):
+    """init weight with N(0, 1/lr) (reference model.py:404-408)."""
+    if isinstance(m, (nn.Linear, nn.Conv2d, ModulatedConv2d)):
+        m.weight.data.normal_(0., 1 / lr)
+        m.bias.data.fill_(0.)

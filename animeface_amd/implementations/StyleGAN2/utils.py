@@ -1,0 +1,217 @@
+"""StyleGAN2 training loop on MI355X: D-step / G-step / lazy R1 / lazy path-length / EMA.
+
+Mirrors the reference's ``implementations/StyleGAN2/utils.py`` (``pl_penalty`` :18-29, ``update_pl_mean``
+:31-33, ``train`` :35-138, ``main`` :140-231) -- same function names, argument order and semantics, including
+"on a lazy-regularisation iteration the penalty REPLACES the GAN loss" (:71-79, :96-106) and the lazy Adam
+rescale (:208-218).  Differences, all outside the arithmetic of a step:
+  * bf16 activations instead of fp16 autocast + GradScaler (``amp=True`` selects bf16, ``False`` fp32);
+  * the G forward of the D-step runs under ``no_grad`` and D's parameters are frozen during the G-step
+    (the reference computes and discards those gradients: results are identical);
+  * no per-iteration ``save_image`` / ``.item()`` host syncs inside the loop (kept behind ``log_every``);
+  * optional data parallelism: gradients are all-reduced by ``animeface_amd.distributed.GradReducer``.
+"""
+import functools
+
+import numpy as np
+import torch
+import torch.optim as optim
+
+from ...nnutils import get_device, sample_nnoise, update_ema
+from ...nnutils.loss import NonSaturatingLoss, r1_regularizer, calc_grad
+from ...thirdparty.diffaugment import DiffAugment
+from ... import distributed as dp
+from ... import rng
+from .model import Generator, Discriminator, init_weight_N01
+
+
+def pl_penalty(styles, images, pl_mean, scaler=None):
+    """path length regularizer (reference utils.py:18-29)."""
+    num_pixels = images.size()[2:].numel()
+    noise = rng.randn(images.size(), device=images.device) / np.sqrt(num_pixels)
+    outputs = (images * noise).sum()
+    gradients = calc_grad(outputs, styles, scaler)
+    gradients = gradients.pow(2).sum(dim=1).sqrt()
+    return (gradients - pl_mean).pow(2).mean()
+
+
+def update_pl_mean(old, new, decay=0.99):
+    return decay * old + (1 - decay) * new
+
+
+def lazy_adam_hparams(lr, betas, k, lam):
+    """reference utils.py:208-218."""
+    if lam > 0:
+        ratio = k / (k + 1)
+        return lr * ratio, (betas[0] ** ratio, betas[1] ** ratio)
+    return lr, betas
+
+
+class TrainStep:
+    """State and body of one iteration of the reference loop (utils.py:55-116)."""
+
+    def __init__(self, G, G_ema, D, optimizer_G, optimizer_D, r1_lambda, pl_lambda, d_k, g_k, policy,
+                 latent_dim, sampler, reducer_G=None, reducer_D=None):
+        self.G, self.G_ema, self.D = G, G_ema, D
+        self.optimizer_G, self.optimizer_D = optimizer_G, optimizer_D
+        self.r1_lambda, self.pl_lambda, self.d_k, self.g_k = r1_lambda, pl_lambda, d_k, g_k
+        self.augment = functools.partial(DiffAugment, policy=policy)
+        self.latent_dim, self.sampler = latent_dim, sampler
+        self.reducer_G, self.reducer_D = reducer_G, reducer_D
+        self.loss = NonSaturatingLoss()
+        self.r1_loss = r1_regularizer()
+        self.pl_mean = 0.
+        self.batches_done = 0
+
+    def _zero(self, opt, reducer):
+        if reducer is not None:
+            reducer.zero_grad()
+        else:
+            opt.zero_grad(set_to_none=True)
+
+    def __call__(self, real):
+        G, D = self.G, self.D
+        it = self.batches_done
+        self._zero(self.optimizer_G, self.reducer_G)
+        self._zero(self.optimizer_D, self.reducer_D)
+
+        # ---- discriminator (reference utils.py:60-86) ----
+        z = self.sampler((real.size(0), self.latent_dim))
+        real_aug = self.augment(real)
+        real_prob = D(real_aug)
+        with torch.no_grad():
+            fake, _ = G(z)
+        fake_aug = self.augment(fake)
+        fake_prob = D(fake_aug.detach())
+        if it % self.d_k == 0 and self.r1_lambda > 0 and it != 0:
+            r1 = self.r1_loss(real, D, None)
+            D_loss = r1 * self.r1_lambda * self.d_k          # replaces the GAN loss on this iteration
+        else:
+            D_loss = self.loss.d_loss(real_prob, fake_prob)
+        D_loss.backward()
+        if self.reducer_D is not None:
+            self.reducer_D.finish()
+        self.optimizer_D.step()
+
+        # ---- generator (reference utils.py:88-113) ----
+        for p in D.parameters():
+            p.requires_grad_(False)
+        z = self.sampler((real.size(0), self.latent_dim))
+        fake, style = G(z)
+        fake_aug = self.augment(fake)
+        fake_prob = D(fake_aug)
+        if it % self.g_k == 0 and self.pl_lambda > 0 and it != 0:
+            pl = pl_penalty(style, fake, self.pl_mean, None)
+            G_loss = pl * self.pl_lambda * self.g_k
+            self.pl_mean = update_pl_mean(self.pl_mean, float(pl.detach()))
+        else:
+            G_loss = self.loss.g_loss(fake_prob)
+        G_loss.backward()
+        for p in D.parameters():
+            p.requires_grad_(True)
+        if self.reducer_G is not None:
+            self.reducer_G.finish()
+        self.optimizer_G.step()
+
+        if self.G_ema is not None:
+            update_ema(G, self.G_ema)
+        self.batches_done += 1
+        return D_loss.detach(), G_loss.detach(), fake
+
+
+def build_optimizers(G, D, lr, betas, r1_lambda, pl_lambda, d_k, g_k):
+    g_lr, g_betas = lazy_adam_hparams(lr, betas, g_k, pl_lambda)
+    d_lr, d_betas = lazy_adam_hparams(lr, betas, d_k, r1_lambda)
+    fused = all(p.is_cuda for p in G.parameters())
+    optimizer_G = optim.Adam(G.parameters(), lr=g_lr, betas=g_betas, fused=fused)
+    optimizer_D = optim.Adam(D.parameters(), lr=d_lr, betas=d_betas, fused=fused)
+    return optimizer_G, optimizer_D
+
+
+def train(max_iter, dataset, sampler, const_z, latent_dim,
+          G, G_ema, D, optimizer_G, optimizer_D,
+          r1_lambda, pl_lambda, d_k, g_k, policy,
+          device, amp, save=1000, log_every=50, on_save=None, reducer_G=None, reducer_D=None):
+    """Same positional signature as the reference's ``train`` (utils.py:35-41)."""
+    if G_ema is not None:
+        G_ema.eval()
+    step = TrainStep(G, G_ema, D, optimizer_G, optimizer_D, r1_lambda, pl_lambda, d_k, g_k, policy,
+                     latent_dim, sampler, reducer_G, reducer_D)
+    history = []
+    while step.batches_done < max_iter:
+        for real in dataset:
+            real = real.to(device, non_blocking=True)
+            it = step.batches_done
+            D_loss, G_loss, fake = step(real)
+            if it % save == 0 and on_save is not None:
+                with torch.no_grad():
+                    images, _ = G_ema(const_z)
+                on_save(it, images, G_ema)
+            if log_every and it % log_every == 0:
+                d, g = D_loss.item(), G_loss.item()
+                history.append((it, 0 if d != d else d, 0 if g != g else g))
+            if step.batches_done == max_iter:
+                break
+    return history
+
+
+def build_models(args, device, compute_dtype):
+    normalize = not args.disable_map_norm
+    mk_G = lambda: Generator(args.image_size, args.image_channels, args.style_dim, args.channels, args.max_channels,
+                             args.block_num_conv, args.map_num_layers, normalize, args.map_lr, compute_dtype=compute_dtype)
+    G, G_ema = mk_G(), mk_G()
+    D = Discriminator(args.image_size, args.image_channels, args.channels, args.max_channels,
+                      args.block_num_conv, args.mbsd_groups, compute_dtype=compute_dtype)
+    G.init_weight(map_init_func=functools.partial(init_weight_N01, lr=args.map_lr), syn_init_func=init_weight_N01)
+    G_ema.eval()
+    update_ema(G, G_ema, decay=0)
+    D.apply(init_weight_N01)
+    return G.to(device), G_ema.to(device), D.to(device)
+
+
+SG2_ARGS = dict(
+    image_channels=[3, 'number of channels for the generated image'],
+    style_dim=[512, 'style feature dimension'],
+    channels=[32, 'channel width multiplier'],
+    max_channels=[512, 'maximum channels'],
+    block_num_conv=[2, 'number of convolution layers in residual block'],
+    map_num_layers=[8, 'number of layers in mapping network'],
+    map_lr=[0.01, 'learning rate for mapping network'],
+    disable_map_norm=[False, 'disable pixel normalization in mapping network'],
+    mbsd_groups=[4, 'number of groups in mini_batch standard deviation'],
+    lr=[0.001, 'learning rate'],
+    beta1=[0., 'beta1'],
+    beta2=[0.99, 'beta2'],
+    g_k=[8, 'for lazy regularization. calculate perceptual path length loss every g_k iters'],
+    d_k=[16, 'for lazy regularization. calculate gradient penalty each d_k iters'],
+    r1_lambda=[10, 'lambda for r1'],
+    pl_lambda=[0., 'lambda for perceptual path length loss'],
+    policy=['color,translation', 'policy for DiffAugment'])
+
+
+def main(parser, dataset=None):
+    """``implementations.StyleGAN2.main(parser)`` contract of the reference's main.py:17-18.  The dataset
+    is injected (an iterable of image batches in [-1, 1]); without one a synthetic uniform batch is cycled,
+    which is what the benchmark uses -- the reference's file datasets are out of scope."""
+    from ...utils_argument import add_args
+    parser = add_args(parser, SG2_ARGS)
+    args = parser.parse_args()
+    rank, world, _ = dp.init_distributed()
+    amp = not args.disable_amp
+    device = get_device(not args.disable_gpu)
+    compute_dtype = torch.bfloat16 if amp else torch.float32
+    sampler = functools.partial(sample_nnoise, device=device)
+    const_z = sample_nnoise((16, args.style_dim), device=device)
+    G, G_ema, D = build_models(args, device, compute_dtype)
+    dp.broadcast_module(G), dp.broadcast_module(G_ema), dp.broadcast_module(D)
+    optimizer_G, optimizer_D = build_optimizers(G, D, args.lr, (args.beta1, args.beta2), args.r1_lambda, args.pl_lambda, args.d_k, args.g_k)
+    reducer_G = dp.GradReducer(G.parameters()) if world > 1 else None
+    reducer_D = dp.GradReducer(D.parameters()) if world > 1 else None
+    if dataset is None:
+        gen = torch.Generator(device='cpu').manual_seed(rank)
+        batch = (torch.rand(args.batch_size, args.image_channels, args.image_size, args.image_size, generator=gen) * 2 - 1).to(device)
+        dataset = [batch]
+    if args.max_iters < 0:
+        args.max_iters = len(dataset) * args.default_epochs
+    return train(args.max_iters, dataset, sampler, const_z, args.style_dim, G, G_ema, D, optimizer_G, optimizer_D,
+                 args.r1_lambda, args.pl_lambda, args.d_k, args.g_k, args.policy, device, amp, args.save,
+                 reducer_G=reducer_G, reducer_D=reducer_D)

@@ -1,0 +1,35 @@
+"""reference nnutils/training.py:7-40 -- same signatures; ``update_ema`` runs as two multi-tensor
+(foreach) launches instead of ~200 per-parameter kernel pairs."""
+from __future__ import annotations
+
+from typing import Union
+
+import torch
+
+from .. import rng
+
+
+def sample_nnoise(size, device: Union[torch.device, str], mean: float = 0., std: float = 1.) -> torch.Tensor:
+    return rng.normal(size, device, mean, std)
+
+
+def sample_unoise(size, device: Union[torch.device, str], start: float = 0., end: float = 1.) -> torch.Tensor:
+    return rng.uniform(size, device, start, end)
+
+
+@torch.no_grad()
+def update_ema(model: torch.nn.Module, model_ema: torch.nn.Module, decay: float = 0.999, copy_buffers: bool = False) -> None:
+    model.eval()
+    param_ema = dict(model_ema.named_parameters())
+    param = dict(model.named_parameters())
+    keys = list(param_ema.keys())
+    ema_list = [param_ema[k].data for k in keys]
+    src_list = [param[k].data for k in keys]
+    torch._foreach_mul_(ema_list, decay)
+    torch._foreach_add_(ema_list, src_list, alpha=(1 - decay))
+    if copy_buffers:
+        buffer_ema = dict(model_ema.named_buffers())
+        buffer = dict(model.named_buffers())
+        for key in buffer_ema.keys():
+            buffer_ema[key].data.copy_(buffer[key].data)
+    model.train()

@@ -109,26 +109,30 @@ int agf_filtered_lrelu_act(void* x, uint8_t* s, int dtype,
  *   implementations/StyleGAN2/model.py:123-129 (modulated conv, evaluated in the algebraically equal
  *   "scale activations - shared weights - scale outputs" form) and
  *   nn.Conv2d inside ELR, implementations/StyleGAN2/model.py:29-37,192-202 (discriminator).
- * Layout: activations channels-last (NHWC) bf16; weights OHWI bf16 [Cout][kh][kw][Cin]; fp32 accumulate.
+ * Layout: activations channels-last (NHWC); weights OHWI [Cout][kh][kw][Cin]; fp32 accumulate.
+ * dtype AGF_BF16: bf16 activations/weights on the MFMA kernels (the training path; Cin, Cout multiples of 8).
+ * dtype AGF_F32 : fp32 activations/weights on plain fp32 FMAs (the reference's --disable-amp configuration
+ *                 and the <= 1e-3 parity tests; residual is fp32 too).
  * Stride 1, "same" zero padding (k-1)/2, k in {1, 3}.
  *
  *   y[n,h,w,co] = epilogue( sum_{kh,kw,ci} x[n,h+kh-p,w+kw-p,ci] * in_scale[n,ci] * w[co,kh,kw,ci] )
  *   epilogue(v) = lrelu_or_id( v * out_scale[n,co] + bias[co] + noise[n,h,w] + residual[n,h,w,co] ) * act_gain
- * in_scale / out_scale (fp32 [N,Cin] / [N,Cout]), bias (fp32 [Cout]), noise (fp32 or bf16? -> fp32 [N,H,W]) and
- * residual (bf16 NHWC) are nullable.  act: 1 = linear, 3 = lrelu(alpha).
+ * in_scale / out_scale (fp32 [N,Cin] / [N,Cout]), bias (fp32 [Cout]), noise (fp32 [N,H,W]) and
+ * residual (NHWC, activation dtype) are nullable.  act: 1 = linear, 3 = lrelu(alpha).
  */
 int agf_conv2d_fwd(const void* x, const void* w, void* y,
                    const float* in_scale, const float* out_scale, const float* bias,
                    const float* noise, const void* residual,
-                   int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
+                   int dtype, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
                    int act, float alpha, float act_gain, void* stream);
 
 /* weight gradient of the same contraction:
  *   dw[co,kh,kw,ci] = sum_{n,h,w} dy[n,h,w,co] * out_scale[n,co] * x[n,h+kh-p,w+kw-p,ci] * in_scale[n,ci]
- * dw is fp32 OHWI.  (dgrad is agf_conv2d_fwd with the spatially flipped, transposed weights.) */
+ * dw is fp32 OHWI and is ACCUMULATED into (split-K partial sums use fp32 atomics): zero it first.
+ * (dgrad is agf_conv2d_fwd with the spatially flipped, transposed weights.) */
 int agf_conv2d_wgrad(const void* x, const void* dy, float* dw,
                      const float* in_scale, const float* out_scale,
-                     int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
+                     int dtype, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
                      void* stream);
 
 #ifdef __cplusplus

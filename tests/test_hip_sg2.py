@@ -1,0 +1,194 @@
+"""GPU parity of the StyleGAN2 model and training loop on the HIP operators, against golden vectors produced by the
+reference's own modules / train() and against the CPU oracle.
+
+fp32 compute mode: <= 1e-3 relative (north_star tolerance for fp32 activations).
+bf16 compute mode (the training path): compared with the fp32 oracle at bf16-level tolerance."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import t
+from oracle import stylegan2 as S
+from oracle import training as T
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+TINY = dict(image_size=16, image_channels=3, style_dim=16, channels=4, max_channels=16,
+            block_num_conv=2, map_num_layers=2, map_lr=0.01, mbsd_groups=4)
+
+
+def sub(g, prefix):
+    return {k[len(prefix):]: t(v).clone() for k, v in g.items() if k.startswith(prefix)}
+
+
+def build(dtype):
+    from animeface_amd.implementations.StyleGAN2 import model as M
+    G = M.Generator(TINY['image_size'], 3, TINY['style_dim'], TINY['channels'], TINY['max_channels'], 2, TINY['map_num_layers'],
+                    True, TINY['map_lr'], compute_dtype=dtype)
+    D = M.Discriminator(TINY['image_size'], 3, TINY['channels'], TINY['max_channels'], 2, TINY['mbsd_groups'], compute_dtype=dtype)
+    return M, G.to(DEV), D.to(DEV)
+
+
+class ReplayNoise:
+    def __init__(self, M, draws):
+        self.M, self.draws = M, list(draws)
+
+    def __enter__(self):
+        self.orig = self.M.InjectNoise.draw
+        self.M.InjectNoise.draw = staticmethod(lambda x: self.draws.pop(0).to(x.device))
+        return self
+
+    def __exit__(self, *a):
+        self.M.InjectNoise.draw = self.orig
+
+
+def relerr(a, b):
+    return ((a.detach().float().cpu() - b.float()).abs().max() / b.float().abs().max().clamp_min(1e-8)).item()
+
+
+def test_state_dict_is_interchangeable_with_the_reference(golden):
+    g = golden('sg2_model')
+    M, G, D = build(torch.float32)
+    G.load_state_dict(sub(g, 'G/'), strict=True)
+    D.load_state_dict(sub(g, 'D/'), strict=True)
+
+
+@pytest.mark.parametrize('dtype,tol', [(torch.float32, 1e-3), (torch.bfloat16, 6e-2)])
+def test_generator_discriminator_forward_and_grads_vs_reference(golden, dtype, tol):
+    g = golden('sg2_model')
+    M, G, D = build(dtype)
+    G.load_state_dict(sub(g, 'G/'))
+    D.load_state_dict(sub(g, 'D/'))
+    with ReplayNoise(M, [t(g[f'noise{i}']) for i in range(int(g['n_noise']))]):
+        image, style = G(t(g['z']).to(DEV))
+    assert image.dtype == torch.float32 and tuple(image.shape) == (4, 3, 16, 16)
+    assert relerr(style, t(g['style'])) < 1e-4
+    assert relerr(image, t(g['image'])) < tol
+    logits = D(image)
+    assert relerr(logits, t(g['logits'])) < tol
+    loss = torch.nn.functional.softplus(-logits).mean()
+    assert abs(loss.item() - float(g['g_loss'])) < tol * max(1.0, abs(float(g['g_loss'])))
+    pg, pd = dict(G.named_parameters()), dict(D.named_parameters())
+    gn = [k[len('gradG/'):] for k in g if k.startswith('gradG/')]
+    dn = [k[len('gradD/'):] for k in g if k.startswith('gradD/')]
+    grads = torch.autograd.grad(loss, [pg[k] for k in gn] + [pd[k] for k in dn])
+    gtol = tol * (1 if dtype == torch.float32 else 3)
+    for k, gr in zip(gn, grads[:len(gn)]):
+        assert relerr(gr, t(g['gradG/' + k])) < gtol, k
+    for k, gr in zip(dn, grads[len(gn):]):
+        assert relerr(gr, t(g['gradD/' + k])) < gtol, k
+
+
+def test_style_mixing_and_layers_vs_reference(golden):
+    g = golden('sg2_model')
+    M, G, D = build(torch.float32)
+    G.load_state_dict(sub(g, 'G/'))
+    with ReplayNoise(M, [t(g[f'mixnoise{i}']) for i in range(int(g['n_noise']))]):
+        image, _ = G((t(g['z']).to(DEV), t(g['z2']).to(DEV)), injection=2)
+    assert relerr(image, t(g['image_mix'])) < 1e-3
+    # ModulatedConv2d (k=3, demod) and ToImage (k=1, no demod, skip sum, bilinear x2)
+    mc = M.ModulatedConv2d(6, 5, 8, 3).to(DEV)
+    mc.load_state_dict(sub(g, 'mc/'))
+    x = t(g['mc_x']).to(DEV).requires_grad_(True)
+    y = t(g['mc_y']).to(DEV).requires_grad_(True)
+    out = mc(x.contiguous(memory_format=torch.channels_last), y)
+    assert relerr(out, t(g['mc_out'])) < 1e-3
+    gx, gy, gw, gb = torch.autograd.grad(out, [x, y, mc.weight, mc.bias], t(g['mc_dout']).to(DEV))
+    for a, k in [(gx, 'mc_gx'), (gy, 'mc_gy'), (gw, 'mc_gw'), (gb, 'mc_gb')]:
+        assert relerr(a, t(g[k])) < 1e-3, k
+    ti = M.ToImage(6, 3, 8, upsample=True).to(DEV)
+    ti.load_state_dict(sub(g, 'ti/'))
+    out2 = ti(x.contiguous(memory_format=torch.channels_last), y, t(g['ti_pre']).to(DEV))
+    assert relerr(out2, t(g['ti_out'])) < 1e-3
+    gx2, gy2, gw2 = torch.autograd.grad(out2, [x, y, ti.conv.weight], t(g['ti_dout']).to(DEV))
+    for a, k in [(gx2, 'ti_gx'), (gy2, 'ti_gy'), (gw2, 'ti_gw')]:
+        assert relerr(a, t(g[k])) < 1e-3, k
+
+
+@pytest.mark.parametrize('dtype,tol', [(torch.float32, 2e-3), (torch.bfloat16, 0.15)])
+def test_r1_and_path_length_double_backward_vs_reference(golden, dtype, tol):
+    from animeface_amd.nnutils.loss import r1_regularizer
+    from animeface_amd.implementations.StyleGAN2 import utils as U
+    from animeface_amd import rng
+    g = golden('sg2_train')
+    M, G, D = build(dtype)
+    G.load_state_dict(sub(g, 'G0/'))
+    D.load_state_dict(sub(g, 'D0/'))
+    real = t(g['real']).to(DEV)
+    r1 = r1_regularizer()(real, D, None)
+    assert abs(r1.item() - float(g['r1'])) < tol * abs(float(g['r1']))
+    names = [k[len('r1grad/'):] for k in g if k.startswith('r1grad/')]
+    pd = dict(D.named_parameters())
+    grads = torch.autograd.grad(r1, [pd[k] for k in names])
+    for k, gr in zip(names, grads):
+        assert relerr(gr, t(g['r1grad/' + k])) < tol * 2, k
+    if dtype == torch.float32:
+        with ReplayNoise(M, [t(g[f'pl_noise{i}']) for i in range(4)]):
+            fake, style = G(t(g['pl_z']).to(DEV))
+        with rng.cpu_stream():
+            torch.manual_seed(11)
+            pl = U.pl_penalty(style, fake, 0.3, None)
+        assert abs(pl.item() - float(g['pl'])) < 2e-3 * abs(float(g['pl']))
+        names = [k[len('plgrad/'):] for k in g if k.startswith('plgrad/')]
+        pg = dict(G.named_parameters())
+        grads = torch.autograd.grad(pl, [pg[k] for k in names])
+        for k, gr in zip(names, grads):
+            assert relerr(gr, t(g['plgrad/' + k])) < 5e-3, k
+
+
+def test_train_loop_replays_the_references_train(golden):
+    """Four iterations of the reference's own train() (d_k = g_k = 2: iteration 2 replaces both GAN losses by
+    R1 / path-length penalties) replayed through the HIP path in fp32 with the same random stream."""
+    from animeface_amd.implementations.StyleGAN2 import utils as U
+    from animeface_amd.nnutils import sample_nnoise, update_ema
+    from animeface_amd import rng
+    import functools
+    g = golden('sg2_train')
+    M, G, D = build(torch.float32)
+    _, G_ema, _ = build(torch.float32)
+    G.load_state_dict(sub(g, 'G0/'))
+    D.load_state_dict(sub(g, 'D0/'))
+    G_ema.eval()
+    update_ema(G, G_ema, decay=0)
+    lr, b0, b1, d_k, g_k, r1l, pll = [float(v) for v in g['train_hparams']]
+    opt_G, opt_D = U.build_optimizers(G, D, lr, (b0, b1), r1l, pll, int(d_k), int(g_k))
+    np.testing.assert_allclose([opt_G.param_groups[0]['lr'], *opt_G.param_groups[0]['betas'],
+                                opt_D.param_groups[0]['lr'], *opt_D.param_groups[0]['betas']], g['train_adam'], rtol=1e-12)
+    sampler = functools.partial(sample_nnoise, device=DEV)
+    losses = []
+    with rng.cpu_stream():
+        torch.manual_seed(13)
+        const_z = sample_nnoise((2, TINY['style_dim']), device=DEV)
+        step = U.TrainStep(G, G_ema, D, opt_G, opt_D, r1l, pll, int(d_k), int(g_k), 'color,translation', TINY['style_dim'], sampler)
+        for it in range(4):
+            dl, gl, _ = step(t(g['train_real'][it]).to(DEV))
+            losses.append([dl.item(), gl.item()])
+            if it == 0:
+                with torch.no_grad():
+                    G_ema(const_z)          # the reference samples G_ema(const_z) when batches_done % save == 0
+    np.testing.assert_allclose(np.array(losses), g['train_losses'], rtol=5e-3, atol=1e-5)
+    for name, net, prefix in [('G', G, 'G4/'), ('D', D, 'D4/'), ('G_ema', G_ema, 'Gema4/')]:
+        sd = net.state_dict()
+        for k, v in sub(g, prefix).items():
+            torch.testing.assert_close(sd[k].cpu(), v, rtol=5e-3, atol=5e-5, msg=lambda m, k=k, name=name: f'{name} {k}: {m}')
+
+
+def test_bf16_training_step_runs_and_stays_finite():
+    from animeface_amd.implementations.StyleGAN2 import utils as U
+    from animeface_amd.nnutils import sample_nnoise, update_ema
+    from animeface_amd.implementations.StyleGAN2 import model as M
+    import functools
+    torch.manual_seed(0)
+    G = M.Generator(32, 3, 64, 8, 64, 2, 2).to(DEV)
+    G_ema = M.Generator(32, 3, 64, 8, 64, 2, 2).to(DEV)
+    D = M.Discriminator(32, 3, 8, 64, 2, 4).to(DEV)
+    G.init_weight(functools.partial(M.init_weight_N01, lr=0.01), M.init_weight_N01)
+    D.apply(M.init_weight_N01)
+    update_ema(G, G_ema, decay=0)
+    opt_G, opt_D = U.build_optimizers(G, D, 0.001, (0., 0.99), 10., 2., 2, 2)
+    step = U.TrainStep(G, G_ema, D, opt_G, opt_D, 10., 2., 2, 2, 'color,translation', 64, functools.partial(sample_nnoise, device=DEV))
+    real = torch.rand(8, 3, 32, 32, device=DEV) * 2 - 1
+    for _ in range(3):
+        dl, gl, fake = step(real)
+        assert torch.isfinite(dl) and torch.isfinite(gl) and torch.isfinite(fake).all()
+    assert all(torch.isfinite(p).all() for p in list(G.parameters()) + list(D.parameters()))
