@@ -17,6 +17,35 @@ from ... import _lib
 ACT_LINEAR, ACT_LRELU = 1, 3
 
 
+class KernelTimer:
+    """Optional per-launch HIP-event timing of the MFMA kernels on the stream they are launched on
+    (bench.py's roofline numbers).  Disabled unless ``KernelTimer.active`` is set to an instance."""
+    active = None
+
+    def __init__(self):
+        self.records = {}          # kernel name -> list of (start_event, end_event, flops)
+
+    def start(self):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
+    def stop(self, name, ev0, flops):
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev1.record()
+        self.records.setdefault(name, []).append((ev0, ev1, flops))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, recs in self.records.items():
+            ms = sum(a.elapsed_time(b) for a, b, _ in recs)
+            fl = sum(f for _, _, f in recs)
+            out[name] = dict(launches=len(recs), total_ms=ms, avg_ms=ms / max(len(recs), 1), flops=fl,
+                             tflops=fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0)
+        return out
+
+
 def _f32(t):
     return None if t is None else t.contiguous().float()
 
@@ -45,9 +74,13 @@ def conv2d_fwd_raw(x, w, in_scale=None, out_scale=None, bias=None, noise=None, r
     in_scale, out_scale, bias, noise = _f32(in_scale), _f32(out_scale), _f32(bias), _f32(noise)
     if residual is not None:
         residual = residual.to(x.dtype).contiguous(memory_format=torch.channels_last)
+    timer = KernelTimer.active
+    ev0 = timer.start() if timer is not None else None
     rc = _lib.lib().agf_conv2d_fwd(_lib.ptr(x), _lib.ptr(wq), _lib.ptr(y), _lib.ptr(in_scale), _lib.ptr(out_scale),
                                    _lib.ptr(bias), _lib.ptr(noise), _lib.ptr(residual), _lib.dtype_code(x),
                                    N, H, W, Cin, Cout, k, act, float(alpha), float(gain), _lib.stream_ptr(x))
+    if timer is not None:
+        timer.stop('conv2d_fwd_kernel', ev0, 2.0 * N * H * W * Cin * Cout * k * k)
     _lib.check(rc, 'conv2d_fwd')
     return y
 
@@ -68,8 +101,12 @@ def conv2d_wgrad_raw(x, dy, ksize, in_scale=None, out_scale=None):
     if ksize == 1:   # channels_last strides of a [Cout,Cin,1,1] tensor are ambiguous; memory is [Cout][Cin] either way
         dw = torch.zeros((Cout, Cin, 1, 1), dtype=torch.float32, device=x.device)
     in_scale, out_scale = _f32(in_scale), _f32(out_scale)
+    timer = KernelTimer.active
+    ev0 = timer.start() if timer is not None else None
     rc = _lib.lib().agf_conv2d_wgrad(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(in_scale), _lib.ptr(out_scale),
                                      _lib.dtype_code(x), N, H, W, Cin, Cout, ksize, _lib.stream_ptr(x))
+    if timer is not None:
+        timer.stop('conv2d_wgrad_kernel', ev0, 2.0 * N * H * W * Cin * Cout * ksize * ksize)
     _lib.check(rc, 'conv2d_wgrad')
     return dw
 

@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: images/sec of the StyleGAN2 256x256 G+D+R1 training step (bf16) on N MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]            (N > 1: launched by torch.distributed.run)
+
+One "step" = one iteration of the reference loop (implementations/StyleGAN2/utils.py:55-116): D-step (lazy R1 every
+d_k = 16 iterations, replacing the GAN loss) + G-step + EMA, DiffAugment 'color,translation', batch 64 per GPU,
+synthetic uniform [-1,1] images resident in HBM, random-init weights of the exact 256x256 architecture.
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline     -- the dominant kernel (the MFMA conv) timed per launch with HIP events inside the timed region
+  cpu_baseline -- the CPU oracle (a port of the reference's pure-PyTorch path) timed on this box's host cores
+"""
+import argparse
+import functools
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK = 2.5e15      # dense bf16 MFMA peak, MI355X_MICROARCH.md
+HBM_PEAK = 8.0e12
+
+
+def cpu_baseline(image_size, seconds_budget=30.0):
+    """Time the CPU oracle's full training iteration at a small batch (kind = 'port')."""
+    from oracle import stylegan2 as S, training as T
+    torch.manual_seed(0)
+    cfg = S.Config(image_size=image_size)
+    G = S.init_state(S.generator_state_shapes(cfg), cfg, which='G')
+    D = S.init_state(S.discriminator_state_shapes(cfg), cfg, which='D')
+    E = {k: v.clone() for k, v in G.items()}
+    st = T.StepState(cfg, G, E, D)
+    B = 2
+    real = torch.rand(B, 3, image_size, image_size) * 2 - 1
+    sampler = lambda size: torch.empty(size).normal_()
+    t0 = time.time()
+    n = 0
+    while True:
+        T.train_iteration(st, real, sampler)
+        n += 1
+        if time.time() - t0 > seconds_budget * 0.5 or n >= 2:
+            break
+    dt = time.time() - t0
+    return dict(value=round(B * n / dt, 4), unit='img/s', cores=torch.get_num_threads(), kind='port',
+                sample=f'{n} GAN-loss iteration(s) of the same {image_size}x{image_size} step at batch {B} in fp32 '
+                       f'(oracle/training.py, torch {torch.__version__} CPU)')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=16)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--image-size', type=int, default=256)
+    ap.add_argument('--batch', type=int, default=64, help='per-GPU batch')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-timer', action='store_true')
+    args = ap.parse_args()
+
+    from animeface_amd import distributed as dp
+    from animeface_amd.implementations.StyleGAN2 import utils as U, conv as C
+    from animeface_amd.implementations.StyleGAN2 import model as M
+    from animeface_amd.nnutils import sample_nnoise, update_ema
+    import torch.distributed as dist
+
+    rank, world, local_rank = dp.init_distributed()
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    assert torch.cuda.is_available(), 'bench.py needs a GPU (there is no CPU fallback for the product path)'
+    dev = torch.device('cuda', local_rank)
+    torch.cuda.set_device(dev)
+
+    # models: exact reference architecture at 256x256 (19.35 M / 21.40 M parameters), init_weight_N01, seed 0
+    torch.manual_seed(0)
+    S = args.image_size
+    G = M.Generator(S).to(dev)
+    G_ema = M.Generator(S).to(dev)
+    D = M.Discriminator(S).to(dev)
+    G.init_weight(functools.partial(M.init_weight_N01, lr=0.01), M.init_weight_N01)
+    D.apply(M.init_weight_N01)
+    G_ema.eval()
+    update_ema(G, G_ema, decay=0)
+    dp.broadcast_module(G), dp.broadcast_module(G_ema), dp.broadcast_module(D)
+    opt_G, opt_D = U.build_optimizers(G, D, 0.001, (0., 0.99), 10., 0., 16, 8)
+    red_G = dp.GradReducer(G.parameters()) if world > 1 else None
+    red_D = dp.GradReducer(D.parameters()) if world > 1 else None
+    torch.manual_seed(1234 + rank)
+    step = U.TrainStep(G, G_ema, D, opt_G, opt_D, 10., 0., 16, 8, 'color,translation', 512,
+                       functools.partial(sample_nnoise, device=dev), red_G, red_D)
+    gen = torch.Generator(device='cpu').manual_seed(rank)
+    real = (torch.rand(args.batch, 3, S, S, generator=gen) * 2 - 1).to(dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(real)
+    timer = None
+    if not args.no_kernel_timer:
+        timer = C.KernelTimer()
+        C.KernelTimer.active = timer
+    first_timed = step.batches_done
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(real)
+    barrier()
+    dt = time.perf_counter() - t0
+    C.KernelTimer.active = None
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    r1_steps = sum(1 for it in range(first_timed, first_timed + args.steps) if it % 16 == 0 and it != 0)
+
+    if rank == 0:
+        out = {
+            'metric': 'images/sec (G+D+R1 step) StyleGAN2 256x256 bf16',
+            'value': round(args.batch * world * args.steps / dt, 2),
+            'unit': 'img/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(dt / args.steps * 1e3, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': f'StyleGAN2 {S}x{S} G+D+lazy-R1 training step, batch {args.batch}/GPU '
+                                   f'(BASELINE.json configs[2] without ADA: channels 32, max 512, style 512, d_k 16, r1_lambda 10, '
+                                   f'DiffAugment color+translation, Adam, EMA)',
+                       'global_batch': args.batch * world, 'parallelism': f'dp{world}',
+                       'r1_steps_in_window': r1_steps, 'params_G': sum(p.numel() for p in G.parameters()),
+                       'params_D': sum(p.numel() for p in D.parameters())},
+        }
+        if timer is not None:
+            summ = timer.summary()
+            k = summ.get('conv2d_fwd_kernel')
+            if k:
+                out['roofline'] = {'kernel': 'conv2d_fwd_kernel (MFMA implicit-GEMM 3x3/1x1 conv: forward + data-gradient launches)',
+                                   'bound': 'mfma', 'achieved': round(k['tflops'], 2), 'peak': MFMA_BF16_PEAK / 1e12,
+                                   'unit': 'TFLOP/s', 'frac': round(k['tflops'] * 1e12 / MFMA_BF16_PEAK, 4), 'traffic': None,
+                                   'launches': k['launches'], 'avg_launch_ms': round(k['avg_ms'], 4),
+                                   'share_of_step_time': round(k['total_ms'] / (dt * 1e3), 4)}
+            kw = summ.get('conv2d_wgrad_kernel')
+            if kw:
+                out['roofline_wgrad'] = {'kernel': 'conv2d_wgrad_kernel', 'bound': 'mfma', 'achieved': round(kw['tflops'], 2),
+                                         'peak': MFMA_BF16_PEAK / 1e12, 'unit': 'TFLOP/s',
+                                         'frac': round(kw['tflops'] * 1e12 / MFMA_BF16_PEAK, 4), 'launches': kw['launches'],
+                                         'share_of_step_time': round(kw['total_ms'] / (dt * 1e3), 4)}
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(S)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

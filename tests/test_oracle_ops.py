@@ -136,3 +136,32 @@ def test_sign_packing_layout():
     assert p[0, 0, 0, 0].item() == (0 | 1 << 2 | 2 << 4 | 0 << 6)
     assert p[0, 0, 0, 1].item() == (1 | 1 << 2 | 2 << 4 | 2 << 6)
     assert p[0, 0, 0, 4].item() == 1
+
+
+def test_c_oracle_agrees_with_golden_and_python_oracle(golden):
+    """oracle/upfirdn2d_oracle.c (gather form, plain C) against the reference-generated integer matrix."""
+    import ctypes
+    import os
+    from conftest import ROOT
+    so = os.path.join(ROOT, 'oracle', 'libupfirdn2d_oracle.so')
+    if not os.path.exists(so):
+        import subprocess
+        subprocess.check_call(['make', '-C', os.path.join(ROOT, 'oracle')])
+    L = ctypes.CDLL(so)
+    g = golden('upfirdn2d_int')
+    x = np.ascontiguousarray(g['x'], dtype=np.float32)
+    names = [str(n) for n in g['filter_names']]
+    checked = 0
+    for i, spec in enumerate(g['specs']):
+        fi, upx, upy, dnx, dny, px0, px1, py0, py1, flip = [int(v) for v in spec]
+        if names[fi] in ('none', 'sep12'):
+            continue
+        f = np.ascontiguousarray(g['f_' + names[fi]], dtype=np.float32)
+        ref = g[f'y{i}']
+        y = np.zeros(ref.shape, dtype=np.float32)
+        L.upfirdn2d_oracle_f32(x.ctypes.data_as(ctypes.c_void_p), f.ctypes.data_as(ctypes.c_void_p), y.ctypes.data_as(ctypes.c_void_p),
+                               x.shape[0], x.shape[1], x.shape[2], x.shape[3], f.shape[0], f.shape[1], ref.shape[2], ref.shape[3],
+                               upx, upy, dnx, dny, px0, py0, flip, ctypes.c_float(4.0))
+        assert np.array_equal(y, ref), (i, spec.tolist())
+        checked += 1
+    assert checked > 200
