@@ -20,7 +20,8 @@ EDGE_ZERO, EDGE_CLAMP = 0, 1
 _DTYPES = {torch.float32: AGF_F32, torch.float16: AGF_F16, torch.bfloat16: AGF_BF16, torch.float64: AGF_F64}
 
 EXPORTS = ['agf_abi_version', 'agf_last_error', 'agf_device_info', 'agf_upfirdn2d', 'agf_bias_act',
-           'agf_filtered_lrelu', 'agf_filtered_lrelu_act', 'agf_conv2d_fwd', 'agf_conv2d_wgrad']
+           'agf_filtered_lrelu', 'agf_filtered_lrelu_act', 'agf_conv2d_fwd', 'agf_conv2d_wgrad',
+           'agf_act_bwd_reduce', 'agf_scale_dot']
 
 _lib = None
 _i32x4 = ctypes.c_int32 * 4
@@ -63,6 +64,10 @@ def lib():
                                     [ctypes.c_int, ctypes.c_float, ctypes.c_float, _vp]
         L.agf_conv2d_wgrad.restype = ctypes.c_int
         L.agf_conv2d_wgrad.argtypes = [_vp, _vp, _vp, _vp, _vp, ctypes.c_int] + [ctypes.c_int32] * 6 + [_vp]
+        L.agf_act_bwd_reduce.restype = ctypes.c_int
+        L.agf_act_bwd_reduce.argtypes = [_vp] * 7 + [ctypes.c_int] + [ctypes.c_int32] * 4 + [ctypes.c_float, _vp]
+        L.agf_scale_dot.restype = ctypes.c_int
+        L.agf_scale_dot.argtypes = [_vp] * 5 + [ctypes.c_int] + [ctypes.c_int32] * 4 + [_vp]
         if L.agf_abi_version() != 1:
             raise AgfError('libagf_ops.so ABI version mismatch')
         _lib = L

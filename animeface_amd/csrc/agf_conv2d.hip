@@ -92,30 +92,48 @@ __global__ void __launch_bounds__(256) conv2d_fwd_kernel(ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-    const int nChunks = (p.Cin + KC - 1) / KC;
-    for (int ch = 0; ch < nChunks; ch++) {
-        const int c0 = ch * KC;
-        __syncthreads();                                  // previous chunk fully consumed
-        // ---- stage weights: TAPS*BM rows of KC channels, 4 x 16-byte vectors per row ----
-        for (int v = tid; v < TAPS * BM * (KC / 8); v += 256) {
-            int cv = v & 3, row = v >> 2;                 // row = tap*BM + co
+    // ---- software pipeline: the global loads of chunk ch+1 are issued into registers before the MFMAs of chunk ch
+    //      and written to LDS after them, so HBM/L2 latency hides under the matrix work (one LDS buffer) ----
+    constexpr int WV = TAPS * BM * (KC / 8) / 256;        // weight vectors per thread per chunk (18 for 3x3, MT=2)
+    constexpr int XV = KS == 3 ? 9 : 4;                   // patch vectors per thread: P <= 576 (3x3), 256 (1x1)
+    u32x4 wreg[WV], xreg[XV];
+    // per-thread patch geometry is chunk-invariant: precompute global offsets (or -1) once
+    int xoff[XV];                                          // element offset of the vector at channel 0, -1 = zero fill
+    int xn[XV];
+#pragma unroll
+    for (int i = 0; i < XV; i++) {
+        int v = tid + i * 256;
+        int cv = v & 3, pix = v >> 2;
+        xoff[i] = -1; xn[i] = 0;
+        if (pix < P) {
+            int pc = pix % PW; int t2 = pix / PW; int pr = t2 % PH; int ti = t2 / PH;
+            int n = n0 + ti, h = h0 + pr - HALO, w = w0 + pc - HALO;
+            if (n < p.N && h >= 0 && h < p.H && w >= 0 && w < p.W) {
+                xoff[i] = (((n * p.H + h) * p.W + w)) ;    // pixel index; multiplied by Cin at use (fits int for < 2^31 pixels)
+                xn[i] = n;
+            }
+        }
+        (void)cv;
+    }
+    auto load_chunk = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < WV; i++) {
+            int v = tid + i * 256;
+            int cv = v & 3, row = v >> 2;
             int tap = row / BM, co = row - tap * BM;
             int gco = co0 + co, gc = c0 + cv * 8;
             u32x4 val = {0u, 0u, 0u, 0u};
-            if (gco < p.Cout && gc < p.Cin)
-                val = *(const u32x4*)(p.w + ((int64_t)gco * TAPS + tap) * p.Cin + gc);
-            *(u32x4*)(sW + row * PITCH + cv * 8) = val;
+            if (gco < p.Cout && gc < p.Cin) val = *(const u32x4*)(p.w + ((int64_t)gco * TAPS + tap) * p.Cin + gc);
+            wreg[i] = val;
         }
-        // ---- stage the input patch (zero halo outside the image) ----
-        for (int v = tid; v < P * (KC / 8); v += 256) {
-            int cv = v & 3, pix = v >> 2;
-            int pc = pix % PW; int t2 = pix / PW; int pr = t2 % PH; int ti = t2 / PH;
-            int n = n0 + ti, h = h0 + pr - HALO, w = w0 + pc - HALO, gc = c0 + cv * 8;
+#pragma unroll
+        for (int i = 0; i < XV; i++) {
+            int cv = (tid + i * 256) & 3, gc = c0 + cv * 8;
             u32x4 val = {0u, 0u, 0u, 0u};
-            if (n < p.N && h >= 0 && h < p.H && w >= 0 && w < p.W && gc < p.Cin) {
-                val = *(const u32x4*)(p.x + (((int64_t)n * p.H + h) * p.W + w) * p.Cin + gc);
+            if (xoff[i] >= 0 && gc < p.Cin) {
+                val = *(const u32x4*)(p.x + (int64_t)xoff[i] * p.Cin + gc);
                 if (IN_SCALE) {
-                    const float* sc = p.in_scale + (int64_t)n * p.Cin + gc;
+                    const float* sc = p.in_scale + (int64_t)xn[i] * p.Cin + gc;
                     f32x4 s0 = *(const f32x4*)sc, s1 = *(const f32x4*)(sc + 4);
                     float a0, a1;
                     Pack16<bf16_t>::unpack(val.x, a0, a1); val.x = Pack16<bf16_t>::pack(a0 * s0.x, a1 * s0.y);
@@ -124,9 +142,28 @@ __global__ void __launch_bounds__(256) conv2d_fwd_kernel(ConvParams p) {
                     Pack16<bf16_t>::unpack(val.w, a0, a1); val.w = Pack16<bf16_t>::pack(a0 * s1.z, a1 * s1.w);
                 }
             }
-            *(u32x4*)(sX + pix * PITCH + cv * 8) = val;
+            xreg[i] = val;
         }
-        __syncthreads();
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < WV; i++) {
+            int v = tid + i * 256;
+            *(u32x4*)(sW + (v >> 2) * PITCH + (v & 3) * 8) = wreg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < XV; i++) {
+            int v = tid + i * 256;
+            if ((v >> 2) < P) *(u32x4*)(sX + (v >> 2) * PITCH + (v & 3) * 8) = xreg[i];
+        }
+    };
+
+    const int nChunks = (p.Cin + KC - 1) / KC;
+    load_chunk(0);
+    store_chunk();
+    __syncthreads();
+    for (int ch = 0; ch < nChunks; ch++) {
+        if (ch + 1 < nChunks) load_chunk((ch + 1) * KC);
         // ---- contraction over taps and the chunk's two 16-channel k-steps ----
 #pragma unroll
         for (int kh = 0; kh < KS; kh++) {
@@ -149,6 +186,11 @@ __global__ void __launch_bounds__(256) conv2d_fwd_kernel(ConvParams p) {
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
                 }
             }
+        }
+        if (ch + 1 < nChunks) {
+            __syncthreads();                              // every wave is done reading this chunk
+            store_chunk();
+            __syncthreads();
         }
     }
 
@@ -344,7 +386,8 @@ extern "C" int agf_conv2d_fwd(const void* x, const void* w, void* y,
     p.TI = BLOCK_PIX / (p.TW * p.TH);
     p.tilesW = (W + p.TW - 1) / p.TW; p.tilesH = (H + p.TH - 1) / p.TH; p.tilesN = (N + p.TI - 1) / p.TI;
     p.pixTiles = p.tilesW * p.tilesH * p.tilesN;
-    const int MT = Cout > 64 ? 2 : 1;
+    int MT = Cout > 64 ? 2 : 1;
+    if (MT == 2 && (int64_t)p.pixTiles * ((Cout + 127) / 128) < 512) MT = 1;     // small maps: more, smaller blocks
     p.tilesCo = (Cout + 64 * MT - 1) / (64 * MT);
     hipStream_t st = (hipStream_t)stream;
     int rc;
@@ -402,19 +445,22 @@ static __device__ __forceinline__ u32x4 scale_vec8(u32x4 val, const float* sc) {
     return val;
 }
 
-template <int KS>
+template <int KS, bool COMPACT>
 __global__ void __launch_bounds__(256) conv2d_wgrad_kernel(WgradParams p) {
+    // COMPACT (TW in {16, 32}): the dy tile holds only the TH*TW interior pixels and a k-step is a run of 16 pixels of one
+    //   tile row, so no MFMA work is spent on halo positions; the x patch needs no margins.
+    // padded  (small maps): dy is staged in the patch's own (TH+2)x(TW+2) index space (zeros in the halo ring) so that a
+    //   tap is a constant row shift for ANY tile geometry; the x tile gets MARGIN zero rows at both ends.
     constexpr int TAPS = KS * KS;
     constexpr int HALO = KS / 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    // geometry: both tiles use the padded patch index space q in [0, Ppad); the x tile has MARGIN extra rows at both ends
     const int PW = p.TW + 2 * HALO, PH = p.TH + 2 * HALO;
     const int P = p.TI * PH * PW;
-    const int Ppad = (P + 15) & ~15;
-    const int MARGIN = HALO * PW + HALO;                 // largest |tap shift|
-    const int XR = Ppad + 2 * MARGIN;                    // rows of one x block
-    bf16_t* sDy = (bf16_t*)smem_raw;                     // [2][Ppad][32]
-    bf16_t* sX = sDy + 2 * Ppad * 32;                    // [2][XR][32]
+    const int DYR = COMPACT ? p.TI * p.TH * p.TW : ((P + 15) & ~15);     // rows of one dy block (multiple of 16)
+    const int MARGIN = COMPACT ? 0 : HALO * PW + HALO;
+    const int XR = COMPACT ? ((P + 15) & ~15) : DYR + 2 * MARGIN;        // rows of one x block
+    bf16_t* sDy = (bf16_t*)smem_raw;                                     // [2][DYR][32]
+    bf16_t* sX = sDy + 2 * DYR * 32;                                     // [2][XR][32]
 
     int bid = blockIdx.x;
     const int ks = bid % p.splitK; bid /= p.splitK;
@@ -426,8 +472,9 @@ __global__ void __launch_bounds__(256) conv2d_wgrad_kernel(WgradParams p) {
     const int wa = wave >> 1, wb = wave & 1;             // co block, ci block
     const int li = lane & 15, lg = (lane >> 4) & 1, lk = lane >> 5;
     const int laneOff = (8 * lk + (li >> 2)) * 32 + 16 * lg + 4 * (li & 3);
-    const bf16_t* aPtr = sDy + wa * Ppad * 32 + laneOff;
+    const bf16_t* aPtr = sDy + wa * DYR * 32 + laneOff;
     const bf16_t* bPtr = sX + wb * XR * 32 + MARGIN * 32 + laneOff;
+    const int stepsPerRow = COMPACT ? p.TW / 16 : 1;
 
     f32x16 acc[TAPS];
 #pragma unroll
@@ -435,32 +482,45 @@ __global__ void __launch_bounds__(256) conv2d_wgrad_kernel(WgradParams p) {
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
 
-    for (int pt = ks; pt < p.pixTiles; pt += p.splitK) {
+    // register-staged software pipeline (as in the forward kernel): tile pt+splitK is loaded while tile pt is contracted
+    constexpr int DV = 8, XV = 12;                        // vectors per thread: DYR*8/256 <= 8 (DYR <= 256), XR*8/256 <= 12
+    u32x4 dreg[DV], xreg[XV];
+    auto load_tile = [&](int pt) {
         int tq = pt;
         const int tw = tq % p.tilesW; tq /= p.tilesW;
         const int th = tq % p.tilesH;
         const int tn = tq / p.tilesH;
         const int n0 = tn * p.TI, h0 = th * p.TH, w0 = tw * p.TW;
-        __syncthreads();
-        // ---- stage dy in patch geometry (zero in the halo ring, outside the image and beyond P) ----
-        for (int v = tid; v < Ppad * 8; v += 256) {
+#pragma unroll
+        for (int i = 0; i < DV; i++) {
+            int v = tid + i * 256;
             int cv = v & 7, q = v >> 3;
-            int pc = q % PW; int t2 = q / PW; int pr = t2 % PH; int ti = t2 / PH;
-            int n = n0 + ti, h = h0 + pr - HALO, w = w0 + pc - HALO, gco = co0 + cv * 8;
             u32x4 val = {0u, 0u, 0u, 0u};
-            bool interior = q < P && pr >= HALO && pr < PH - HALO && pc >= HALO && pc < PW - HALO;
-            if (interior && n < p.N && h < p.H && w < p.W && gco < p.Cout) {
-                val = *(const u32x4*)(p.dy + (((int64_t)n * p.H + h) * p.W + w) * p.Cout + gco);
-                if (p.out_scale) val = scale_vec8(val, p.out_scale + (int64_t)n * p.Cout + gco);
+            if (q < DYR) {
+                int n, h, w; bool ok;
+                if (COMPACT) {
+                    int c = q % p.TW; int t2 = q / p.TW; int r = t2 % p.TH; int ti = t2 / p.TH;
+                    n = n0 + ti; h = h0 + r; w = w0 + c; ok = true;
+                } else {
+                    int pc = q % PW; int t2 = q / PW; int pr = t2 % PH; int ti = t2 / PH;
+                    n = n0 + ti; h = h0 + pr - HALO; w = w0 + pc - HALO;
+                    ok = q < P && pr >= HALO && pr < PH - HALO && pc >= HALO && pc < PW - HALO;
+                }
+                int gco = co0 + cv * 8;
+                if (ok && n < p.N && h < p.H && w < p.W && gco < p.Cout) {
+                    val = *(const u32x4*)(p.dy + (((int64_t)n * p.H + h) * p.W + w) * p.Cout + gco);
+                    if (p.out_scale) val = scale_vec8(val, p.out_scale + (int64_t)n * p.Cout + gco);
+                }
             }
-            *(u32x4*)(sDy + ((cv >> 2) * Ppad + q) * 32 + (cv & 3) * 8) = val;
+            dreg[i] = val;
         }
-        // ---- stage x patch (with margins) ----
-        for (int v = tid; v < XR * 8; v += 256) {
+#pragma unroll
+        for (int i = 0; i < XV; i++) {
+            int v = tid + i * 256;
             int cv = v & 7, row = v >> 3;
             int q = row - MARGIN;
             u32x4 val = {0u, 0u, 0u, 0u};
-            if (q >= 0 && q < P) {
+            if (row < XR && q >= 0 && q < P) {
                 int pc = q % PW; int t2 = q / PW; int pr = t2 % PH; int ti = t2 / PH;
                 int n = n0 + ti, h = h0 + pr - HALO, w = w0 + pc - HALO, gci = ci0 + cv * 8;
                 if (n < p.N && h >= 0 && h < p.H && w >= 0 && w < p.W && gci < p.Cin) {
@@ -468,19 +528,47 @@ __global__ void __launch_bounds__(256) conv2d_wgrad_kernel(WgradParams p) {
                     if (p.in_scale) val = scale_vec8(val, p.in_scale + (int64_t)n * p.Cin + gci);
                 }
             }
-            *(u32x4*)(sX + ((cv >> 2) * XR + row) * 32 + (cv & 3) * 8) = val;
+            xreg[i] = val;
         }
-        __syncthreads();
-        for (int s = 0; s < Ppad / 16; s++) {
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < DV; i++) {
+            int v = tid + i * 256;
+            int cv = v & 7, q = v >> 3;
+            if (q < DYR) *(u32x4*)(sDy + ((cv >> 2) * DYR + q) * 32 + (cv & 3) * 8) = dreg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < XV; i++) {
+            int v = tid + i * 256;
+            int cv = v & 7, row = v >> 3;
+            if (row < XR) *(u32x4*)(sX + ((cv >> 2) * XR + row) * 32 + (cv & 3) * 8) = xreg[i];
+        }
+    };
+
+    int pt = ks;
+    if (pt < p.pixTiles) { load_tile(pt); store_tile(); }
+    __syncthreads();
+    for (; pt < p.pixTiles; pt += p.splitK) {
+        const bool more = pt + p.splitK < p.pixTiles;
+        if (more) load_tile(pt + p.splitK);
+        for (int s = 0; s < DYR / 16; s++) {
             const bf16x8 af = tr_frag(aPtr + s * 16 * 32);
+            int xrow;
+            if (COMPACT) { int r = s / stepsPerRow; xrow = (r / p.TH * PH + r % p.TH) * PW + (s % stepsPerRow) * 16; }
+            else xrow = s * 16 - (HALO * PW + HALO);
 #pragma unroll
             for (int kh = 0; kh < KS; kh++)
 #pragma unroll
                 for (int kw = 0; kw < KS; kw++) {
-                    const int shift = (kh - HALO) * PW + (kw - HALO);
-                    const bf16x8 bfr = tr_frag(bPtr + (s * 16 + shift) * 32);
+                    const bf16x8 bfr = tr_frag(bPtr + (xrow + kh * PW + kw) * 32);
                     acc[kh * KS + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[kh * KS + kw], 0, 0, 0);
                 }
+        }
+        if (more) {
+            __syncthreads();
+            store_tile();
+            __syncthreads();
         }
     }
     // ---- combine: fp32 atomics into dw[co][tap][ci] ----
@@ -494,6 +582,15 @@ __global__ void __launch_bounds__(256) conv2d_wgrad_kernel(WgradParams p) {
                 if (co < p.Cout) unsafeAtomicAdd(p.dw + ((int64_t)co * TAPS + t) * p.Cin + ci, acc[t][r]);
             }
     }
+}
+
+template <int KS, bool COMPACT>
+static int launch_wgrad(const WgradParams& p, size_t lds, hipStream_t st) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv2d_wgrad_kernel<KS, COMPACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { agf_set_error("conv2d_wgrad: cannot reserve LDS: %s", hipGetErrorString(e)); return AGF_ELAUNCH; }
+    dim3 grid((unsigned)(p.tilesCo * p.tilesCi * p.splitK)), block(256);
+    hipLaunchKernelGGL((conv2d_wgrad_kernel<KS, COMPACT>), grid, block, lds, st, p);
+    return AGF_OK;
 }
 
 extern "C" int agf_conv2d_wgrad(const void* x, const void* dy, float* dw,
@@ -521,35 +618,38 @@ extern "C" int agf_conv2d_wgrad(const void* x, const void* dy, float* dw,
     WgradParams p;
     p.x = (const bf16_t*)x; p.dy = (const bf16_t*)dy; p.dw = dw; p.in_scale = in_scale; p.out_scale = out_scale;
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
-    // pixel tile: up to 4 x 32 interior pixels (128) so that two blocks fit one CU's LDS
-    const int TILE_PIX = 128;
+    // pixel tile: 256 interior pixels (8x32, 16x16) in the compact scheme, 128 in the padded scheme (small maps)
+    const int HALO = ksize / 2;
     p.TW = pow2_ceil(W) < 32 ? pow2_ceil(W) : 32;
+    const bool compact = p.TW >= 16;
+    const int TILE_PIX = compact ? 256 : 128;
     int th = pow2_ceil(H);
     p.TH = th < TILE_PIX / p.TW ? th : TILE_PIX / p.TW;
     p.TI = TILE_PIX / (p.TW * p.TH);
+    // shrink the tile until the per-thread staging registers (8 dy + 12 x vectors) cover it
+    int PW, PH, P, Ppad, MARGIN, DYR, XR;
+    for (;;) {
+        PW = p.TW + 2 * HALO; PH = p.TH + 2 * HALO;
+        P = p.TI * PH * PW; Ppad = (P + 15) & ~15; MARGIN = HALO * PW + HALO;
+        DYR = compact ? p.TI * p.TH * p.TW : Ppad;
+        XR = compact ? Ppad : Ppad + 2 * MARGIN;
+        if (DYR <= 256 && XR * 8 <= 12 * 256) break;
+        if (p.TI > 1) p.TI >>= 1; else if (p.TH > 1) p.TH >>= 1; else break;
+    }
     p.tilesW = (W + p.TW - 1) / p.TW; p.tilesH = (H + p.TH - 1) / p.TH; p.tilesN = (N + p.TI - 1) / p.TI;
     p.pixTiles = p.tilesW * p.tilesH * p.tilesN;
     p.tilesCo = (Cout + 63) / 64; p.tilesCi = (Cin + 63) / 64;
     int base = p.tilesCo * p.tilesCi;
     int want = (1024 + base - 1) / base;                 // aim at >= 1024 blocks (4 per CU)
     p.splitK = want < 1 ? 1 : (want > p.pixTiles ? p.pixTiles : want);
-    const int HALO = ksize / 2;
-    const int PW = p.TW + 2 * HALO, PH = p.TH + 2 * HALO;
-    const int P = p.TI * PH * PW, Ppad = (P + 15) & ~15, MARGIN = HALO * PW + HALO;
-    size_t lds = (size_t)(2 * Ppad + 2 * (Ppad + 2 * MARGIN)) * 32 * sizeof(bf16_t);
+    AGF_CHECK(DYR <= 256 && XR * 8 <= 12 * 256 && DYR % 16 == 0, "conv2d_wgrad: internal tile too large");
+    size_t lds = (size_t)(2 * DYR + 2 * XR) * 32 * sizeof(bf16_t);
     if (lds > 160 * 1024) { agf_set_error("conv2d_wgrad: tile needs %zu bytes of LDS", lds); return AGF_ENOKERNEL; }
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid((unsigned)(base * p.splitK)), block(256);
-    hipError_t e;
-    if (ksize == 3) {
-        e = hipFuncSetAttribute((const void*)conv2d_wgrad_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { agf_set_error("conv2d_wgrad: cannot reserve LDS: %s", hipGetErrorString(e)); return AGF_ELAUNCH; }
-        hipLaunchKernelGGL((conv2d_wgrad_kernel<3>), grid, block, lds, st, p);
-    } else {
-        e = hipFuncSetAttribute((const void*)conv2d_wgrad_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { agf_set_error("conv2d_wgrad: cannot reserve LDS: %s", hipGetErrorString(e)); return AGF_ELAUNCH; }
-        hipLaunchKernelGGL((conv2d_wgrad_kernel<1>), grid, block, lds, st, p);
-    }
+    int rc;
+    if (ksize == 3) rc = compact ? launch_wgrad<3, true>(p, lds, st) : launch_wgrad<3, false>(p, lds, st);
+    else            rc = compact ? launch_wgrad<1, true>(p, lds, st) : launch_wgrad<1, false>(p, lds, st);
+    if (rc != AGF_OK) return rc;
     AGF_LAUNCH_CHECK();
     return AGF_OK;
 }

@@ -1,0 +1,168 @@
+// Backward halves of the fused conv epilogues, channels-last, one streaming pass each (HBM-bound).
+//
+//   agf_act_bwd_reduce:  g = dy * lrelu'(y)                      (mask from the saved post-activation y)
+//                        A[n,c] = sum_p g * y0   (y0 = pre-activation = y > 0 ? y : y / alpha)
+//                        B[n,c] = sum_p g        (-> bias gradient after summing n)
+//                        Cn[n,c] = sum_p g * noise[n,p]
+//     These three sums give the gradient of the demodulation scale d of the modulated conv
+//     y0 = d * conv + bias + noise  without re-running the conv:  dd = (A - bias*B - Cn) / d.
+//   agf_scale_dot:       dx = t * s[n,c],   ds[n,c] = sum_p x * t     (gradient w.r.t. the style scale s of x*s)
+//
+// Thread = one 16-byte channel vector; a 256-thread block covers CG = C/VEC channel groups x (256/CG) pixel lanes,
+// strides over its pixel chunk, reduces the pixel lanes through LDS and issues one fp32 atomic per (n,c) per block.
+// The sum buffers must be zero-initialised by the caller.
+#include "agf_common.h"
+
+struct ActBwdParams {
+    const void* dy; const void* y; const float* noise; void* g;
+    float *sumA, *sumB, *sumC;
+    int N, HW, C, CG, pixLanes, pixPerBlock, chunks;
+    float alpha, inv_alpha;
+};
+
+template <class T, int VEC>
+__global__ void __launch_bounds__(256) act_bwd_reduce_kernel(ActBwdParams p) {
+    __shared__ float red[3][256][VEC + 1];
+    const int tid = threadIdx.x;
+    const int cg = tid % p.CG, pl = tid / p.CG;
+    const int n = blockIdx.y, chunk = blockIdx.x;
+    const int p0 = chunk * p.pixPerBlock;
+    const int p1 = min(p0 + p.pixPerBlock, p.HW);
+    float a[VEC], b[VEC], c[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; i++) a[i] = b[i] = c[i] = 0.f;
+    const bool active = pl < p.pixLanes;
+    if (active) {
+        const int64_t base = (int64_t)n * p.HW * p.C + cg * VEC;
+        for (int px = p0 + pl; px < p1; px += p.pixLanes) {
+            float dy[VEC], y[VEC], g[VEC];
+            VecIO<T, VEC>::load((const T*)p.dy + base + (int64_t)px * p.C, dy);
+            VecIO<T, VEC>::load((const T*)p.y + base + (int64_t)px * p.C, y);
+            const float nz = p.noise ? p.noise[(int64_t)n * p.HW + px] : 0.f;
+#pragma unroll
+            for (int i = 0; i < VEC; i++) {
+                const bool pos = y[i] > 0.f;
+                g[i] = pos ? dy[i] : dy[i] * p.alpha;
+                const float y0 = pos ? y[i] : y[i] * p.inv_alpha;
+                a[i] += g[i] * y0; b[i] += g[i]; c[i] += g[i] * nz;
+            }
+            VecIO<T, VEC>::store((T*)p.g + base + (int64_t)px * p.C, g);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; i++) { red[0][tid][i] = a[i]; red[1][tid][i] = b[i]; red[2][tid][i] = c[i]; }
+    __syncthreads();
+    if (pl == 0) {
+        for (int l = 1; l < p.pixLanes; l++) {
+#pragma unroll
+            for (int i = 0; i < VEC; i++) {
+                a[i] += red[0][l * p.CG + cg][i]; b[i] += red[1][l * p.CG + cg][i]; c[i] += red[2][l * p.CG + cg][i];
+            }
+        }
+        const int64_t o = (int64_t)n * p.C + cg * VEC;
+#pragma unroll
+        for (int i = 0; i < VEC; i++) {
+            if (p.sumA) unsafeAtomicAdd(p.sumA + o + i, a[i]);
+            if (p.sumB) unsafeAtomicAdd(p.sumB + o + i, b[i]);
+            if (p.sumC) unsafeAtomicAdd(p.sumC + o + i, c[i]);
+        }
+    }
+}
+
+struct ScaleDotParams {
+    const void* x; const void* t; const float* s; void* dx; float* ds;
+    int N, HW, C, CG, pixLanes, pixPerBlock;
+};
+
+template <class T, int VEC>
+__global__ void __launch_bounds__(256) scale_dot_kernel(ScaleDotParams p) {
+    __shared__ float red[256][VEC + 1];
+    const int tid = threadIdx.x;
+    const int cg = tid % p.CG, pl = tid / p.CG;
+    const int n = blockIdx.y;
+    const int p0 = blockIdx.x * p.pixPerBlock;
+    const int p1 = min(p0 + p.pixPerBlock, p.HW);
+    float acc[VEC], sc[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; i++) acc[i] = 0.f;
+    const bool active = pl < p.pixLanes;
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < VEC; i++) sc[i] = p.s[(int64_t)n * p.C + cg * VEC + i];
+        const int64_t base = (int64_t)n * p.HW * p.C + cg * VEC;
+        for (int px = p0 + pl; px < p1; px += p.pixLanes) {
+            float x[VEC], t[VEC], o[VEC];
+            VecIO<T, VEC>::load((const T*)p.x + base + (int64_t)px * p.C, x);
+            VecIO<T, VEC>::load((const T*)p.t + base + (int64_t)px * p.C, t);
+#pragma unroll
+            for (int i = 0; i < VEC; i++) { acc[i] += x[i] * t[i]; o[i] = t[i] * sc[i]; }
+            if (p.dx) VecIO<T, VEC>::store((T*)p.dx + base + (int64_t)px * p.C, o);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; i++) red[tid][i] = acc[i];
+    __syncthreads();
+    if (pl == 0) {
+        for (int l = 1; l < p.pixLanes; l++)
+#pragma unroll
+            for (int i = 0; i < VEC; i++) acc[i] += red[l * p.CG + cg][i];
+#pragma unroll
+        for (int i = 0; i < VEC; i++) unsafeAtomicAdd(p.ds + (int64_t)n * p.C + cg * VEC + i, acc[i]);
+    }
+}
+
+static int plan(int C, int vec, int HW, int N, int* CG, int* pixLanes, int* pixPerBlock, int* chunks) {
+    if (C % vec) return 0;
+    *CG = C / vec;
+    if (*CG > 256) return 0;
+    *pixLanes = 256 / *CG;
+    // ~16 pixels per lane per block, but keep >= ~1024 blocks in flight when the tensor is large enough
+    int ppb = *pixLanes * 16;
+    while (ppb > *pixLanes && (int64_t)N * ((HW + ppb - 1) / ppb) < 1024) ppb >>= 1;
+    if (ppb < *pixLanes) ppb = *pixLanes;
+    *pixPerBlock = ppb;
+    *chunks = (HW + ppb - 1) / ppb;
+    return 1;
+}
+
+extern "C" int agf_act_bwd_reduce(const void* dy, const void* y, const float* noise, void* g,
+                                  float* sum_gy0, float* sum_g, float* sum_gnoise,
+                                  int dtype, int32_t N, int32_t H, int32_t W, int32_t C, float alpha, void* stream) {
+    AGF_CHECK(dy && y && g, "act_bwd_reduce: null pointer");
+    AGF_CHECK(dtype == AGF_BF16 || dtype == AGF_F32, "act_bwd_reduce: dtype must be bf16 or f32");
+    AGF_CHECK(alpha > 0.f, "act_bwd_reduce: the leaky slope must be positive");
+    AGF_CHECK(N <= 65535, "act_bwd_reduce: batch too large");
+    ActBwdParams p;
+    p.dy = dy; p.y = y; p.noise = noise; p.g = g; p.sumA = sum_gy0; p.sumB = sum_g; p.sumC = sum_gnoise;
+    p.N = N; p.HW = H * W; p.C = C; p.alpha = alpha; p.inv_alpha = 1.f / alpha;
+    const int vec = dtype == AGF_BF16 ? 8 : 4;
+    if (!plan(C, vec, p.HW, N, &p.CG, &p.pixLanes, &p.pixPerBlock, &p.chunks)) {
+        agf_set_error("act_bwd_reduce: C=%d is not a multiple of %d (or too wide)", C, vec);
+        return AGF_ENOKERNEL;
+    }
+    dim3 grid((unsigned)p.chunks, (unsigned)N), block(256);
+    if (dtype == AGF_BF16) hipLaunchKernelGGL((act_bwd_reduce_kernel<bf16_t, 8>), grid, block, 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((act_bwd_reduce_kernel<float, 4>), grid, block, 0, (hipStream_t)stream, p);
+    AGF_LAUNCH_CHECK();
+    return AGF_OK;
+}
+
+extern "C" int agf_scale_dot(const void* x, const void* t, const float* s, void* dx, float* ds,
+                             int dtype, int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {
+    AGF_CHECK(x && t && s && ds, "scale_dot: null pointer");
+    AGF_CHECK(dtype == AGF_BF16 || dtype == AGF_F32, "scale_dot: dtype must be bf16 or f32");
+    AGF_CHECK(N <= 65535, "scale_dot: batch too large");
+    ScaleDotParams p;
+    p.x = x; p.t = t; p.s = s; p.dx = dx; p.ds = ds; p.N = N; p.HW = H * W; p.C = C;
+    const int vec = dtype == AGF_BF16 ? 8 : 4;
+    int chunks;
+    if (!plan(C, vec, p.HW, N, &p.CG, &p.pixLanes, &p.pixPerBlock, &chunks)) {
+        agf_set_error("scale_dot: C=%d is not a multiple of %d (or too wide)", C, vec);
+        return AGF_ENOKERNEL;
+    }
+    dim3 grid((unsigned)chunks, (unsigned)N), block(256);
+    if (dtype == AGF_BF16) hipLaunchKernelGGL((scale_dot_kernel<bf16_t, 8>), grid, block, 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((scale_dot_kernel<float, 4>), grid, block, 0, (hipStream_t)stream, p);
+    AGF_LAUNCH_CHECK();
+    return AGF_OK;
+}

@@ -204,3 +204,94 @@ def conv2d(x, w, s_in=None, s_out=None):
         so = _pad_channels(s_out, 8, 1) if s_out is not None else None
         return _ConvFwd.apply(xp.contiguous(memory_format=torch.channels_last), wp, si, so)[:, :Cout]
     return _ConvFwd.apply(x, w, s_in, s_out)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# fused epilogue:  y = lrelu( s_out * conv(x * s_in, w) + bias + noise )   in ONE launch, with a fused backward
+
+def act_bwd_reduce_raw(dy, y, noise, alpha, want_sums):
+    """One ``agf_act_bwd_reduce`` launch: g = dy * lrelu'(y) and (optionally) the three per-(n,c) sums."""
+    N, C, H, W = y.shape
+    g = torch.empty_like(y)
+    sums = [torch.zeros((N, C), dtype=torch.float32, device=y.device) if w else None for w in want_sums]
+    rc = _lib.lib().agf_act_bwd_reduce(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(_f32(noise)), _lib.ptr(g),
+                                       _lib.ptr(sums[0]), _lib.ptr(sums[1]), _lib.ptr(sums[2]),
+                                       _lib.dtype_code(y), N, H, W, C, float(alpha), _lib.stream_ptr(y))
+    _lib.check(rc, 'act_bwd_reduce')
+    return g, sums
+
+
+def scale_dot_raw(x, t, s, want_dx=True):
+    """One ``agf_scale_dot`` launch: dx = t * s[n,c], ds[n,c] = sum_hw x * t."""
+    N, C, H, W = x.shape
+    dx = torch.empty_like(t) if want_dx else None
+    ds = torch.zeros((N, C), dtype=torch.float32, device=x.device)
+    rc = _lib.lib().agf_scale_dot(_lib.ptr(x), _lib.ptr(t), _lib.ptr(_f32(s)), _lib.ptr(dx), _lib.ptr(ds),
+                                  _lib.dtype_code(x), N, H, W, C, _lib.stream_ptr(x))
+    _lib.check(rc, 'scale_dot')
+    return dx, ds
+
+
+class _FusedConvAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, s_in, s_out, bias, noise, alpha):
+        y = conv2d_fwd_raw(x, w, in_scale=s_in, out_scale=s_out, bias=bias, noise=noise, act=ACT_LRELU, alpha=alpha)
+        ctx.save_for_backward(x, w, s_in, s_out, bias, noise, y)
+        ctx.alpha = alpha
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, s_in, s_out, bias, noise, y = ctx.saved_tensors
+        alpha = ctx.alpha
+        need_x, need_w, need_si, need_so, need_b = ctx.needs_input_grad[:5]
+        dy = dy.to(y.dtype).contiguous(memory_format=torch.channels_last)
+        k = w.shape[2]
+        dx = dw = dsi = dso = db = None
+        if torch.is_grad_enabled():
+            # a graph is being recorded (R1 differentiates D twice): compose from differentiable ops
+            if s_in is not None or s_out is not None or noise is not None:
+                raise RuntimeError('the fused modulated conv has no double backward; build the generator with '
+                                   'fused_epilogue=False when pl_lambda > 0')
+            from ...stylegan3_ops import bias_act as _ba
+            g = _ba._bias_act_hip(dim=1, act='lrelu', alpha=alpha, gain=1.0).Grad.apply(dy, None, None, y)
+            if need_b:
+                db = g.float().sum((0, 2, 3)).to(bias.dtype)
+            if need_x:
+                dx = _ConvFwd.apply(g, flip_transpose(w), None, None)
+            if need_w:
+                dw = _ConvWgrad.apply(x, g, None, None, k).to(w.dtype)
+            return dx, dw, None, None, db, None, None
+        want_so = s_out is not None and need_so
+        g, (A, B, Cn) = act_bwd_reduce_raw(dy, y, noise, alpha, (want_so, want_so or (need_b and bias is not None), want_so and noise is not None))
+        if need_b and bias is not None:
+            db = B.sum(0).to(bias.dtype)
+        if want_so:
+            num = A - (bias.float()[None, :] * B if bias is not None else 0) - (Cn if Cn is not None else 0)
+            dso = num / s_out
+        if need_x or (s_in is not None and need_si):
+            t = conv2d_fwd_raw(g, flip_transpose(w), in_scale=s_out)
+            if s_in is None:
+                dx = t
+            else:
+                dx, dsi = scale_dot_raw(x, t, s_in, want_dx=need_x)
+        if need_w:
+            dw = conv2d_wgrad_raw(x, g, k, in_scale=s_in, out_scale=s_out).to(w.dtype)
+        return dx, dw, dsi, dso, db, None, None
+
+
+def conv2d_act(x, w, bias=None, s_in=None, s_out=None, noise=None, alpha=0.2, fused=True):
+    """lrelu( s_out * conv(x * s_in, w) + bias + noise ), bias [Cout], noise [N,1,H,W] (no gradient).
+    ``fused=False`` evaluates the same expression with the separately differentiable ops (any-order gradients)."""
+    from ...stylegan3_ops import bias_act as _ba
+    Cout, Cin = w.shape[0], w.shape[1]
+    if fused and Cout % 8 == 0:
+        if x.dtype == torch.bfloat16 and Cin % 8:
+            x = _pad_channels(x, 8, 1).contiguous(memory_format=torch.channels_last)
+            w = _pad_channels(w, 8, 1)
+            s_in = _pad_channels(s_in, 8, 1) if s_in is not None else None
+        return _FusedConvAct.apply(x, w, s_in, s_out, bias, noise, alpha)
+    out = conv2d(x, w, s_in, s_out)
+    if noise is not None:
+        out = out + noise.to(out.dtype)
+    return _ba.bias_act(out, bias.to(out.dtype) if bias is not None else None, act='lrelu', alpha=alpha, gain=1)

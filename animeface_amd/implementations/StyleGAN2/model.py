@@ -28,7 +28,13 @@ import torch.nn.functional as F
 
 from ...stylegan3_ops import upfirdn2d, bias_act
 from ... import rng
-from .conv import conv2d
+from .conv import conv2d, conv2d_act
+
+
+# bias / noise / leaky-ReLU run in the conv kernel's epilogue (with a fused backward).  The fused modulated conv has
+# no double backward, so the generator falls back to the separately differentiable ops when ``fused_epilogue=False``
+# (needed only for the path-length penalty, pl_lambda > 0).
+FUSED_EPILOGUE = True
 
 
 class ELR(nn.Module):
@@ -50,10 +56,10 @@ def elr_conv2d(elr, x, act=None):
     conv = elr.layer
     k = conv.kernel_size[0]
     assert conv.stride == (1, 1) and conv.padding == (k // 2, k // 2) and k in (1, 3)
+    if act == 'lrelu':
+        return conv2d_act(x, conv.weight * elr.coef, conv.bias, alpha=0.2, fused=FUSED_EPILOGUE)
     y = conv2d(x, conv.weight * elr.coef)
     b = conv.bias.to(y.dtype) if conv.bias is not None else None
-    if act == 'lrelu':
-        return bias_act.bias_act(y, b, act='lrelu', alpha=0.2, gain=1)
     return bias_act.bias_act(y, b) if b is not None else y
 
 
@@ -207,10 +213,9 @@ class StyleBlock(nn.Module):
                     and isinstance(mods[i + 2], nn.LeakyReLU):
                 # modconv -> +bias -> +noise -> lrelu, noise drawn exactly where the reference draws it
                 w, s, d = m.scales(y)
-                out = conv2d(x, w, s, d)
-                noise = InjectNoise.draw(out)
-                out = out + noise.to(out.dtype)
-                x = bias_act.bias_act(out, m.bias.reshape(-1).to(out.dtype), act='lrelu', alpha=mods[i + 2].negative_slope, gain=1)
+                noise = InjectNoise.draw(x[:, :1])
+                x = conv2d_act(x, w, m.bias.reshape(-1), s, d, noise, alpha=mods[i + 2].negative_slope,
+                               fused=FUSED_EPILOGUE and getattr(self, 'fused_epilogue', True))
                 i += 3
             elif isinstance(m, ModulatedConv2d):
                 x = m(x, y)
@@ -359,6 +364,13 @@ class Generator(nn.Module):
         self.const = nn.Parameter(torch.empty(1, style_dim, 4, 4))
         self.const.data.normal_(0, 1)
         self.compute_dtype = compute_dtype
+
+    def set_fused_epilogue(self, enabled):
+        """``False`` keeps every op separately differentiable (needed by the path-length penalty's double backward)."""
+        for m in self.modules():
+            if isinstance(m, StyleBlock):
+                m.fused_epilogue = enabled
+        return self
 
     def forward(self, z, injection=None):
         if isinstance(z, (list, tuple)):

@@ -61,6 +61,8 @@ class TrainStep:
         self.r1_loss = r1_regularizer()
         self.pl_mean = 0.
         self.batches_done = 0
+        if hasattr(G, 'set_fused_epilogue'):
+            G.set_fused_epilogue(pl_lambda == 0)     # the fused modulated conv has no double backward (path length needs it)
 
     def _zero(self, opt, reducer):
         if reducer is not None:

@@ -25,8 +25,12 @@ def update_ema(model: torch.nn.Module, model_ema: torch.nn.Module, decay: float 
     keys = list(param_ema.keys())
     ema_list = [param_ema[k].data for k in keys]
     src_list = [param[k].data for k in keys]
-    torch._foreach_mul_(ema_list, decay)
-    torch._foreach_add_(ema_list, src_list, alpha=(1 - decay))
+    if decay == 0:
+        # plain copy: ``mul_(0)`` would keep NaNs of a freshly constructed (torch.empty) model_ema
+        torch._foreach_copy_(ema_list, src_list)
+    else:
+        torch._foreach_mul_(ema_list, decay)
+        torch._foreach_add_(ema_list, src_list, alpha=(1 - decay))
     if copy_buffers:
         buffer_ema = dict(model_ema.named_buffers())
         buffer = dict(model.named_buffers())

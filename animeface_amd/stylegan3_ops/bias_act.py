@@ -136,6 +136,7 @@ def _bias_act_hip(dim=1, act='linear', alpha=None, gain=None, clamp=None):
                 d_b = d_x.sum([i for i in range(d_x.ndim) if i != dim])
             return d_dy, d_x, d_b, None
 
+    BiasActHip.Grad = BiasActHipGrad
     _bias_act_hip_cache[key] = BiasActHip
     return BiasActHip
 

@@ -135,6 +135,21 @@ int agf_conv2d_wgrad(const void* x, const void* dy, float* dw,
                      int dtype, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
                      void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Backward halves of the fused conv epilogues (new: the reference has no counterpart -- it runs these as separate
+ * ATen elementwise + reduction kernels under autograd of model.py:132,164,170 and of the [B,Cout,Cin,k,k] weight ops).
+ * Dense channels-last tensors; sum buffers are fp32 [N,C], ACCUMULATED into (zero them first), nullable.
+ *   g       = dy * (y > 0 ? 1 : alpha)
+ *   sum_gy0 += sum_{h,w} g * (y > 0 ? y : y / alpha)      sum_g += sum_{h,w} g      sum_gnoise += sum_{h,w} g * noise[n,h,w]
+ */
+int agf_act_bwd_reduce(const void* dy, const void* y, const float* noise, void* g,
+                       float* sum_gy0, float* sum_g, float* sum_gnoise,
+                       int dtype, int32_t N, int32_t H, int32_t W, int32_t C, float alpha, void* stream);
+
+/*   dx = t * s[n,c]  (nullable),   ds[n,c] += sum_{h,w} x * t */
+int agf_scale_dot(const void* x, const void* t, const float* s, void* dx, float* ds,
+                  int dtype, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
