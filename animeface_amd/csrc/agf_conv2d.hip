@@ -20,12 +20,11 @@
 // Fused on load : per-(n,ci) input scale (the style modulation), fp32 multiply, rounded once to bf16.
 // Fused on store: per-(n,co) output scale (demodulation), bias[co], noise[n,h,w], residual, leaky ReLU, gain.
 #include "agf_common.h"
+#include <stdlib.h>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#define KC 32                 // channels per K chunk
-#define PITCH (KC + 8)        // LDS row pitch in elements (80 bytes)
 #define BLOCK_PIX 256
 
 struct ConvParams {
@@ -44,8 +43,10 @@ struct ConvParams {
     float alpha, gain;
 };
 
-template <int KS, int MT, bool IN_SCALE>
-__global__ void __launch_bounds__(256) conv2d_fwd_kernel(ConvParams p) {
+template <int KS, int MT, bool IN_SCALE, int KC, int MINW>
+__global__ void __launch_bounds__(256, MINW) conv2d_fwd_kernel(ConvParams p) {
+    // KC = channels per K chunk (16 or 32); LDS row pitch = KC + 8 elements (48 / 80 bytes: conflict-free ds_read_b128)
+    constexpr int PITCH = KC + 8;
     constexpr int TAPS = KS * KS;
     constexpr int HALO = KS / 2;
     constexpr int BM = 64 * MT;
@@ -94,8 +95,9 @@ __global__ void __launch_bounds__(256) conv2d_fwd_kernel(ConvParams p) {
 
     // ---- software pipeline: the global loads of chunk ch+1 are issued into registers before the MFMAs of chunk ch
     //      and written to LDS after them, so HBM/L2 latency hides under the matrix work (one LDS buffer) ----
-    constexpr int WV = TAPS * BM * (KC / 8) / 256;        // weight vectors per thread per chunk (18 for 3x3, MT=2)
-    constexpr int XV = KS == 3 ? 9 : 4;                   // patch vectors per thread: P <= 576 (3x3), 256 (1x1)
+    constexpr int WTOT = TAPS * BM * (KC / 8);
+    constexpr int WV = (WTOT + 255) / 256;                // weight vectors per thread per chunk (18 for 3x3, MT=2, KC=32)
+    constexpr int XV = (KS == 3 ? 576 : 256) * (KC / 8) / 256;   // patch vectors per thread: P <= 576 (3x3), 256 (1x1)
     u32x4 wreg[WV], xreg[XV];
     // per-thread patch geometry is chunk-invariant: precompute global offsets (or -1) once
     int xoff[XV];                                          // element offset of the vector at channel 0, -1 = zero fill
@@ -103,7 +105,7 @@ __global__ void __launch_bounds__(256) conv2d_fwd_kernel(ConvParams p) {
 #pragma unroll
     for (int i = 0; i < XV; i++) {
         int v = tid + i * 256;
-        int cv = v & 3, pix = v >> 2;
+        int cv = v % (KC / 8), pix = v / (KC / 8);
         xoff[i] = -1; xn[i] = 0;
         if (pix < P) {
             int pc = pix % PW; int t2 = pix / PW; int pr = t2 % PH; int ti = t2 / PH;
@@ -119,16 +121,17 @@ __global__ void __launch_bounds__(256) conv2d_fwd_kernel(ConvParams p) {
 #pragma unroll
         for (int i = 0; i < WV; i++) {
             int v = tid + i * 256;
-            int cv = v & 3, row = v >> 2;
+            constexpr int VPR = KC / 8;                   // 16-byte vectors per row
+            int cv = v % VPR, row = v / VPR;
             int tap = row / BM, co = row - tap * BM;
             int gco = co0 + co, gc = c0 + cv * 8;
             u32x4 val = {0u, 0u, 0u, 0u};
-            if (gco < p.Cout && gc < p.Cin) val = *(const u32x4*)(p.w + ((int64_t)gco * TAPS + tap) * p.Cin + gc);
+            if (v < WTOT && gco < p.Cout && gc < p.Cin) val = *(const u32x4*)(p.w + ((int64_t)gco * TAPS + tap) * p.Cin + gc);
             wreg[i] = val;
         }
 #pragma unroll
         for (int i = 0; i < XV; i++) {
-            int cv = (tid + i * 256) & 3, gc = c0 + cv * 8;
+            int cv = (tid + i * 256) % (KC / 8), gc = c0 + cv * 8;
             u32x4 val = {0u, 0u, 0u, 0u};
             if (xoff[i] >= 0 && gc < p.Cin) {
                 val = *(const u32x4*)(p.x + (int64_t)xoff[i] * p.Cin + gc);
@@ -149,12 +152,12 @@ __global__ void __launch_bounds__(256) conv2d_fwd_kernel(ConvParams p) {
 #pragma unroll
         for (int i = 0; i < WV; i++) {
             int v = tid + i * 256;
-            *(u32x4*)(sW + (v >> 2) * PITCH + (v & 3) * 8) = wreg[i];
+            if (WTOT % 256 == 0 || v < WTOT) *(u32x4*)(sW + (v / (KC / 8)) * PITCH + (v % (KC / 8)) * 8) = wreg[i];
         }
 #pragma unroll
         for (int i = 0; i < XV; i++) {
             int v = tid + i * 256;
-            if ((v >> 2) < P) *(u32x4*)(sX + (v >> 2) * PITCH + (v & 3) * 8) = xreg[i];
+            if ((v / (KC / 8)) < P) *(u32x4*)(sX + (v / (KC / 8)) * PITCH + (v % (KC / 8)) * 8) = xreg[i];
         }
     };
 
@@ -325,25 +328,29 @@ __global__ void __launch_bounds__(256) conv2d_wgrad_f32_kernel(WgradF32Params p)
 
 static int pow2_ceil(int v) { int r = 1; while (r < v) r <<= 1; return r; }
 
-template <int KS, int MT>
-static int launch_fwd(const ConvParams& p, hipStream_t st) {
-    constexpr int TAPS = KS * KS, HALO = KS / 2, BM = 64 * MT;
+template <int KS, int MT, bool SC, int KC, int MINW>
+static int launch_fwd_v(const ConvParams& p, hipStream_t st) {
+    constexpr int TAPS = KS * KS, HALO = KS / 2, BM = 64 * MT, PITCH = KC + 8;
     const int P = p.TI * (p.TH + 2 * HALO) * (p.TW + 2 * HALO);
     size_t lds = (size_t)(TAPS * BM + P) * PITCH * sizeof(bf16_t);
     if (lds > 160 * 1024) { agf_set_error("conv2d_fwd: tile needs %zu bytes of LDS", lds); return AGF_ENOKERNEL; }
     const int slots = ((p.pixTiles + 7) / 8) * p.tilesCo;
     dim3 grid((unsigned)(slots * 8)), block(256);
-    hipError_t e;
-    if (p.in_scale) {
-        e = hipFuncSetAttribute((const void*)conv2d_fwd_kernel<KS, MT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { agf_set_error("conv2d_fwd: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e)); return AGF_ELAUNCH; }
-        hipLaunchKernelGGL((conv2d_fwd_kernel<KS, MT, true>), grid, block, lds, st, p);
-    } else {
-        e = hipFuncSetAttribute((const void*)conv2d_fwd_kernel<KS, MT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { agf_set_error("conv2d_fwd: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e)); return AGF_ELAUNCH; }
-        hipLaunchKernelGGL((conv2d_fwd_kernel<KS, MT, false>), grid, block, lds, st, p);
-    }
+    hipError_t e = hipFuncSetAttribute((const void*)conv2d_fwd_kernel<KS, MT, SC, KC, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { agf_set_error("conv2d_fwd: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e)); return AGF_ELAUNCH; }
+    hipLaunchKernelGGL((conv2d_fwd_kernel<KS, MT, SC, KC, MINW>), grid, block, lds, st, p);
     return AGF_OK;
+}
+
+static int g_fwd_variant = -1;     // AGF_CONV_VARIANT: 0 = KC32 (1 block/CU at MT=2), 1 = KC16 + 2 blocks/CU
+
+template <int KS, int MT>
+static int launch_fwd(const ConvParams& p, hipStream_t st) {
+    if (g_fwd_variant < 0) { const char* e = getenv("AGF_CONV_VARIANT"); g_fwd_variant = e ? atoi(e) : 0; }
+    if (g_fwd_variant == 1) {
+        return p.in_scale ? launch_fwd_v<KS, MT, true, 16, 2>(p, st) : launch_fwd_v<KS, MT, false, 16, 2>(p, st);
+    }
+    return p.in_scale ? launch_fwd_v<KS, MT, true, 32, 1>(p, st) : launch_fwd_v<KS, MT, false, 32, 1>(p, st);
 }
 
 extern "C" int agf_conv2d_fwd(const void* x, const void* w, void* y,
@@ -386,7 +393,10 @@ extern "C" int agf_conv2d_fwd(const void* x, const void* w, void* y,
     p.TI = BLOCK_PIX / (p.TW * p.TH);
     p.tilesW = (W + p.TW - 1) / p.TW; p.tilesH = (H + p.TH - 1) / p.TH; p.tilesN = (N + p.TI - 1) / p.TI;
     p.pixTiles = p.tilesW * p.tilesH * p.tilesN;
-    int MT = Cout > 64 ? 2 : 1;
+    // MT = 1 (64-channel co tile, 73 KB of LDS) keeps TWO blocks resident per CU, so one block's staging overlaps the
+    // other's MFMAs; measured faster than MT = 2 (one 119 KB block per CU) on every layer of the 256x256 networks.
+    int MT = 1;
+    { const char* e = getenv("AGF_CONV_MT"); if (e) MT = atoi(e); }
     if (MT == 2 && (int64_t)p.pixTiles * ((Cout + 127) / 128) < 512) MT = 1;     // small maps: more, smaller blocks
     p.tilesCo = (Cout + 64 * MT - 1) / (64 * MT);
     hipStream_t st = (hipStream_t)stream;

@@ -1,0 +1,18 @@
+import sys, os, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from animeface_amd.implementations.StyleGAN2.conv import conv2d_fwd_raw
+N, Cin, Cout, H, W = [int(v) for v in sys.argv[1:6]]
+x = torch.randn(N, Cin, H, W, device='cuda').to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+w = (torch.randn(Cout, Cin, 3, 3, device='cuda') / (Cin * 9) ** 0.5).to(torch.bfloat16)
+for _ in range(3):
+    conv2d_fwd_raw(x, w)
+torch.cuda.synchronize()
+s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+s.record()
+for _ in range(20):
+    conv2d_fwd_raw(x, w)
+e.record(); torch.cuda.synchronize()
+ms = s.elapsed_time(e) / 20
+print(json.dumps(dict(variant=os.environ.get('AGF_CONV_VARIANT'), MT=os.environ.get('AGF_CONV_MT'), shape=[N, Cin, Cout, H, W], ms=round(ms, 4),
+                      TFLOPs=round(2.0 * N * H * W * Cin * Cout * 9 / ms / 1e9, 1))))
