@@ -157,6 +157,122 @@ __global__ void __launch_bounds__(256) upfirdn2d_nhwc_vec(UpfirdnParams p) {
 }
 
 // -------------------------------------------------------------------------------------------------
+// nhwc_rows: the hot specialisations.  One lane = one 16-byte channel vector of one output COLUMN, marching over a strip
+// of ROWS output rows.  The strip is evaluated scatter-style over its input rows: each needed input row is loaded ONCE
+// (NTX vectors per lane) and accumulated into every output row of the strip it contributes to, so the vector-memory
+// instruction count per output drops 2-3x versus one-output-per-lane (which is instruction-issue / wave-launch bound, not
+// HBM bound) and ROWS x fewer waves are launched.  Row validity and tap indices are block-uniform (scalar) work.
+template <class T, int VEC> struct RawUnpack;
+template <> struct RawUnpack<float, 4> {
+    static __device__ __forceinline__ void run(u32x4 r, float (&v)[4]) {
+        v[0] = __uint_as_float(r.x); v[1] = __uint_as_float(r.y); v[2] = __uint_as_float(r.z); v[3] = __uint_as_float(r.w);
+    }
+};
+template <class T> struct RawUnpack<T, 8> {
+    static __device__ __forceinline__ void run(u32x4 r, float (&v)[8]) {
+        Pack16<T>::unpack(r.x, v[0], v[1]); Pack16<T>::unpack(r.y, v[2], v[3]);
+        Pack16<T>::unpack(r.z, v[4], v[5]); Pack16<T>::unpack(r.w, v[6], v[7]);
+    }
+};
+
+template <class T, int VEC, int UP, int DN, int FW, int FH, int ROWS, int K00>
+__global__ void __launch_bounds__(256) upfirdn2d_nhwc_rows(UpfirdnParams p) {
+    // K00 = (floor(mid0/UP)+1)*UP - mid0 - 1 for the strip's first row: identical for every strip because ROWS*DN is a
+    // multiple of UP, so the host passes it as a template argument and every (input row t, output row r) tap index
+    //   ky(t, r) = t*UP + K00 - r*DN        is a compile-time constant: the strip body is branch-free straight-line code.
+    constexpr int NTX = (FW + UP - 1) / UP;
+    constexpr int TMAX = ((ROWS - 1) * DN + FH - 1 - K00) / UP + 1;        // input rows a strip can touch
+    const int CG = p.C / VEC;
+    const int rowv = p.OW * CG;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rowv) return;
+    const int ox = (p.cg_shift >= 0) ? (idx >> p.cg_shift) : (idx / CG);
+    const int cg = idx - ox * CG;
+    const int n = blockIdx.z;
+    const int oy0 = blockIdx.y * ROWS;
+    const int midx = ox * DN + UP - 1 - p.padx0;
+    const int inx0 = agf_floor_div(midx, UP);
+    const int kx0 = (inx0 + 1) * UP - midx - 1;
+    const int rowC = p.W * p.C;
+    const T* xb = (const T*)p.x + (int64_t)n * p.H * rowC + cg * VEC;
+    // per-lane column offsets, validity and filter coefficients (the lane's x phase is fixed): coef[ky][jx] in registers
+    int xo[NTX]; bool xok[NTX];
+    float coef[FH][NTX];
+#pragma unroll
+    for (int jx = 0; jx < NTX; jx++) {
+        int ix = inx0 + jx;
+        const int kx = kx0 + jx * UP;
+        bool ok = kx < FW;
+        if (p.clamp_edge) ix = min(max(ix, 0), p.W - 1); else ok = ok && ix >= 0 && ix < p.W;
+        xok[jx] = ok; xo[jx] = ix * p.C;
+#pragma unroll
+        for (int ky = 0; ky < FH; ky++) {
+            float c = 0.f;
+            if (kx < FW) c = p.f[(p.flip ? ky : FH - 1 - ky) * p.fsy + (p.flip ? kx : FW - 1 - kx) * p.fsx];
+            coef[ky][jx] = c * p.gain;
+        }
+    }
+    float acc[ROWS][VEC];
+#pragma unroll
+    for (int r = 0; r < ROWS; r++)
+#pragma unroll
+        for (int i = 0; i < VEC; i++) acc[r][i] = 0.f;
+    const int mid0 = oy0 * DN + UP - 1 - p.pady0;
+    const int iyA = agf_floor_div(mid0, UP);
+    // two-deep register pipeline over input rows: row t+1 is in flight (packed, 4 VGPRs per vector) while row t is
+    // unpacked and accumulated; the empty asm statements stop the scheduler from hoisting every row's loads to the top
+    // (which costs 256 VGPRs and one wave per SIMD).
+    u32x4 raw[2][NTX];
+    auto load_row = [&](int t, u32x4 (&dst)[NTX]) {
+        int iy = iyA + t;
+        bool rowok = true;
+        if (p.clamp_edge) iy = min(max(iy, 0), p.H - 1); else rowok = iy >= 0 && iy < p.H;      // block-uniform
+#pragma unroll
+        for (int jx = 0; jx < NTX; jx++) {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (rowok && xok[jx]) v = *(const u32x4*)(xb + iy * rowC + xo[jx]);
+            dst[jx] = v;
+        }
+    };
+    load_row(0, raw[0]);
+#pragma unroll
+    for (int t = 0; t < TMAX; t++) {
+        if (t + 1 < TMAX) load_row(t + 1, raw[(t + 1) & 1]);
+        asm volatile("" ::: "memory");
+        float xv[NTX][VEC];
+#pragma unroll
+        for (int jx = 0; jx < NTX; jx++) RawUnpack<T, VEC>::run(raw[t & 1][jx], xv[jx]);
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) {
+            const int ky = t * UP + K00 - r * DN;                          // compile-time after unrolling
+            if (ky >= 0 && ky < FH) {
+#pragma unroll
+                for (int jx = 0; jx < NTX; jx++)
+#pragma unroll
+                    for (int i = 0; i < VEC; i++) acc[r][i] += xv[jx][i] * coef[ky][jx];
+            }
+        }
+        asm volatile("" ::: "memory");
+    }
+    T* yb = (T*)p.y + (int64_t)n * p.OH * ((int64_t)p.OW * p.C) + ox * p.C + cg * VEC;
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) {
+        const int oy = oy0 + r;
+        if (oy < p.OH) VecIO<T, VEC>::store(yb + (int64_t)oy * p.OW * p.C, acc[r]);
+    }
+}
+
+template <class T, int VEC, int UP, int DN, int FW, int FH, int ROWS>
+static void launch_rows(const UpfirdnParams& p, dim3 g, hipStream_t st) {
+    // mid0 mod UP is strip-invariant (ROWS*DN % UP == 0)
+    const int mid0 = UP - 1 - p.pady0;
+    const int k00 = (agf_floor_div(mid0, UP) + 1) * UP - mid0 - 1;
+    static_assert((ROWS * DN) % UP == 0, "strip height must preserve the row phase");
+    if (UP == 1 || k00 == 0) hipLaunchKernelGGL((upfirdn2d_nhwc_rows<T, VEC, UP, DN, FW, FH, ROWS, 0>), g, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((upfirdn2d_nhwc_rows<T, VEC, UP, DN, FW, FH, ROWS, (UP > 1 ? 1 : 0)>), g, dim3(256), 0, st, p);
+}
+
+// -------------------------------------------------------------------------------------------------
 // nchw_tile: dense NCHW.  One workgroup = one 64x16 output tile of one (n,c) plane.
 #define TILE_OW 64
 #define TILE_OH 16
@@ -220,17 +336,19 @@ static bool launch_nhwc(const UpfirdnParams& p, hipStream_t st) {
     for (int sft = 0; sft < 31; sft++) if ((1 << sft) == CG) q.cg_shift = sft;
     dim3 g((unsigned)agf_ceil_div((int64_t)p.OW * CG, 256), (unsigned)p.OH, (unsigned)p.N), b(256);
     const UpfirdnParams& pp = q;
-#define NHWC_CASE(ux, uy, dx, dy, w, h)                                                                   \
-    if (p.upx == ux && p.upy == uy && p.downx == dx && p.downy == dy && p.fw == w && p.fh == h) {         \
-        hipLaunchKernelGGL((upfirdn2d_nhwc_vec<T, VEC, ux, uy, dx, dy, w, h>), g, b, 0, st, pp);          \
+#define NHWC_CASE(ux, uy, dx, dy, w, h, rows)                                                             \
+    if (p.upx == ux && p.upy == uy && p.downx == dx && p.downy == dy && p.fw == w && p.fh == h && ux == uy && dx == dy && w == h) { \
+        constexpr int ROWS = rows;                                                                        \
+        dim3 gr((unsigned)agf_ceil_div((int64_t)p.OW * CG, 256), (unsigned)agf_ceil_div(p.OH, ROWS), (unsigned)p.N);   \
+        launch_rows<T, VEC, ux, dx, w, h, ROWS>(pp, gr, st);                                              \
         return true;                                                                                      \
     }
-    NHWC_CASE(2, 2, 1, 1, 4, 4)   // bilinear-equivalent 2x upsample  (StyleGAN2 Upsample2x, ToImage)
-    NHWC_CASE(1, 1, 1, 1, 3, 3)   // Blur2d
-    NHWC_CASE(1, 1, 2, 2, 2, 2)   // AvgPool2d(2)
-    NHWC_CASE(1, 1, 2, 2, 4, 4)   // adjoint of the 2x upsample; StyleGAN3-D downsample
-    NHWC_CASE(2, 2, 1, 1, 2, 2)   // adjoint of AvgPool2d(2)
-    NHWC_CASE(1, 1, 1, 1, 4, 4)   // StyleGAN3-D filter2d before the strided conv
+    NHWC_CASE(2, 2, 1, 1, 4, 4, 8)   // bilinear-equivalent 2x upsample  (StyleGAN2 Upsample2x, ToImage)
+    NHWC_CASE(1, 1, 1, 1, 3, 3, 8)   // Blur2d
+    NHWC_CASE(1, 1, 2, 2, 2, 2, 4)   // AvgPool2d(2)
+    NHWC_CASE(1, 1, 2, 2, 4, 4, 4)   // adjoint of the 2x upsample; StyleGAN3-D downsample
+    NHWC_CASE(2, 2, 1, 1, 2, 2, 8)   // adjoint of AvgPool2d(2)
+    NHWC_CASE(1, 1, 1, 1, 4, 4, 4)   // StyleGAN3-D filter2d before the strided conv
 #undef NHWC_CASE
     hipLaunchKernelGGL((upfirdn2d_nhwc_vec<T, VEC, 0, 0, 0, 0, 0, 0>), g, b, 0, st, pp);
     return true;
