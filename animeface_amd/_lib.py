@@ -63,7 +63,7 @@ def lib():
         L.agf_conv2d_fwd.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int] + [ctypes.c_int32] * 6 + \
                                     [ctypes.c_int, ctypes.c_float, ctypes.c_float, _vp]
         L.agf_conv2d_wgrad.restype = ctypes.c_int
-        L.agf_conv2d_wgrad.argtypes = [_vp, _vp, _vp, _vp, _vp, ctypes.c_int] + [ctypes.c_int32] * 6 + [_vp]
+        L.agf_conv2d_wgrad.argtypes = [_vp, _vp, _vp, _vp, _vp, ctypes.c_int] + [ctypes.c_int32] * 6 + [ctypes.c_float, _vp]
         L.agf_act_bwd_reduce.restype = ctypes.c_int
         L.agf_act_bwd_reduce.argtypes = [_vp] * 7 + [ctypes.c_int] + [ctypes.c_int32] * 4 + [ctypes.c_float, _vp]
         L.agf_scale_dot.restype = ctypes.c_int

@@ -296,6 +296,7 @@ struct WgradF32Params {
     const float* x; const float* dy; float* dw;
     const float* in_scale; const float* out_scale;
     int N, H, W, Cin, Cout, KS, chunks;
+    float scale;
 };
 
 __global__ void __launch_bounds__(256) conv2d_wgrad_f32_kernel(WgradF32Params p) {
@@ -323,7 +324,7 @@ __global__ void __launch_bounds__(256) conv2d_wgrad_f32_kernel(WgradF32Params p)
         }
         acc += a * sc;
     }
-    unsafeAtomicAdd(p.dw + id, acc);
+    unsafeAtomicAdd(p.dw + id, acc * p.scale);
 }
 
 static int pow2_ceil(int v) { int r = 1; while (r < v) r <<= 1; return r; }
@@ -434,6 +435,7 @@ struct WgradParams {
     int TI, TH, TW;
     int tilesW, tilesH, tilesN, pixTiles;
     int tilesCo, tilesCi, splitK;
+    float scale;              // dw += scale * sum
 };
 
 static __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* base) {
@@ -589,7 +591,7 @@ __global__ void __launch_bounds__(256) conv2d_wgrad_kernel(WgradParams p) {
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 int co = co0 + wa * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (co < p.Cout) unsafeAtomicAdd(p.dw + ((int64_t)co * TAPS + t) * p.Cin + ci, acc[t][r]);
+                if (co < p.Cout) unsafeAtomicAdd(p.dw + ((int64_t)co * TAPS + t) * p.Cin + ci, acc[t][r] * p.scale);
             }
     }
 }
@@ -606,7 +608,7 @@ static int launch_wgrad(const WgradParams& p, size_t lds, hipStream_t st) {
 extern "C" int agf_conv2d_wgrad(const void* x, const void* dy, float* dw,
                                 const float* in_scale, const float* out_scale,
                                 int dtype, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
-                                void* stream) {
+                                float scale, void* stream) {
     AGF_CHECK(x && dy && dw, "conv2d_wgrad: null pointer");
     AGF_CHECK(dtype == AGF_BF16 || dtype == AGF_F32, "conv2d_wgrad: dtype must be bf16 or f32");
     if (dtype == AGF_F32) {
@@ -614,7 +616,7 @@ extern "C" int agf_conv2d_wgrad(const void* x, const void* dy, float* dw,
         AGF_CHECK(ksize == 1 || ksize == 3, "conv2d_wgrad: kernel size must be 1 or 3 (got %d)", ksize);
         WgradF32Params q;
         q.x = (const float*)x; q.dy = (const float*)dy; q.dw = dw; q.in_scale = in_scale; q.out_scale = out_scale;
-        q.N = N; q.H = H; q.W = W; q.Cin = Cin; q.Cout = Cout; q.KS = ksize;
+        q.N = N; q.H = H; q.W = W; q.Cin = Cin; q.Cout = Cout; q.KS = ksize; q.scale = scale;
         q.chunks = N < 64 ? N : 64;
         int64_t total = (int64_t)Cout * ksize * ksize * Cin;
         hipLaunchKernelGGL(conv2d_wgrad_f32_kernel, dim3((unsigned)agf_ceil_div(total, 256), (unsigned)q.chunks), dim3(256), 0, (hipStream_t)stream, q);
@@ -626,7 +628,7 @@ extern "C" int agf_conv2d_wgrad(const void* x, const void* dy, float* dw,
     AGF_CHECK(Cin % 8 == 0 && Cout % 8 == 0, "conv2d_wgrad: Cin and Cout must be multiples of 8 (pad the channel axis)");
     AGF_CHECK(((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0 && ((uintptr_t)dw % 4) == 0, "conv2d_wgrad: misaligned pointer");
     WgradParams p;
-    p.x = (const bf16_t*)x; p.dy = (const bf16_t*)dy; p.dw = dw; p.in_scale = in_scale; p.out_scale = out_scale;
+    p.x = (const bf16_t*)x; p.dy = (const bf16_t*)dy; p.dw = dw; p.in_scale = in_scale; p.out_scale = out_scale; p.scale = scale;
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
     // pixel tile: 256 interior pixels (8x32, 16x16) in the compact scheme, 128 in the padded scheme (small maps)
     const int HALO = ksize / 2;

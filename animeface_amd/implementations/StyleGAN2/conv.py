@@ -58,7 +58,7 @@ def _ohwi(w):
 
 
 def conv2d_fwd_raw(x, w, in_scale=None, out_scale=None, bias=None, noise=None, residual=None,
-                   act=ACT_LINEAR, alpha=0.2, gain=1.0):
+                   act=ACT_LINEAR, alpha=0.2, gain=1.0, prepared=False):
     """One ``agf_conv2d_fwd`` launch.  x: [N,Cin,H,W] bf16 channels_last; w: [Cout,Cin,k,k] (any float dtype).
     in_scale [N,Cin], out_scale [N,Cout], bias [Cout], noise [N,1,H,W] are fp32; residual like y.  Returns y bf16 channels_last."""
     _lib.require_gpu(x, 'conv2d')
@@ -69,7 +69,7 @@ def conv2d_fwd_raw(x, w, in_scale=None, out_scale=None, bias=None, noise=None, r
     if x.dtype not in (torch.bfloat16, torch.float32):
         raise RuntimeError('conv2d: activations must be bfloat16 (MFMA path) or float32 (reference-precision path)')
     x = x.contiguous(memory_format=torch.channels_last)
-    wq = _ohwi(w.to(x.dtype))
+    wq = w if prepared else _ohwi(w.to(x.dtype))       # prepared: already OHWI in the activation dtype
     y = torch.empty((N, Cout, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
     in_scale, out_scale, bias, noise = _f32(in_scale), _f32(out_scale), _f32(bias), _f32(noise)
     if residual is not None:
@@ -85,7 +85,7 @@ def conv2d_fwd_raw(x, w, in_scale=None, out_scale=None, bias=None, noise=None, r
     return y
 
 
-def conv2d_wgrad_raw(x, dy, ksize, in_scale=None, out_scale=None):
+def conv2d_wgrad_raw(x, dy, ksize, in_scale=None, out_scale=None, scale=1.0):
     """One ``agf_conv2d_wgrad`` launch.  x: [N,Cin,H,W], dy: [N,Cout,H,W], both bf16 channels_last.
     Returns dw fp32 in the logical [Cout,Cin,k,k] shape (memory OHWI)."""
     _lib.require_gpu(x, 'conv2d_wgrad')
@@ -104,7 +104,7 @@ def conv2d_wgrad_raw(x, dy, ksize, in_scale=None, out_scale=None):
     timer = KernelTimer.active
     ev0 = timer.start() if timer is not None else None
     rc = _lib.lib().agf_conv2d_wgrad(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(in_scale), _lib.ptr(out_scale),
-                                     _lib.dtype_code(x), N, H, W, Cin, Cout, ksize, _lib.stream_ptr(x))
+                                     _lib.dtype_code(x), N, H, W, Cin, Cout, ksize, float(scale), _lib.stream_ptr(x))
     if timer is not None:
         timer.stop('conv2d_wgrad_kernel', ev0, 2.0 * N * H * W * Cin * Cout * ksize * ksize)
     _lib.check(rc, 'conv2d_wgrad')
@@ -232,66 +232,145 @@ def scale_dot_raw(x, t, s, want_dx=True):
     return dx, ds
 
 
-class _FusedConvAct(torch.autograd.Function):
+class _Prepared:
+    __slots__ = ('ref', 'coef', 'wq', 'wq_ft')
+
+
+_prep_cache = {}
+_prep_cache_on = False
+
+
+class cached_weights:
+    """Context manager: inside it the parameters are promised not to change (one D-step or one G-step between two
+    optimizer steps), so (weight * coef) in bf16 / OHWI -- and its flipped-transposed twin for the data gradient -- is
+    prepared once per layer instead of on each of the 3-5 conv launches that use it.  The cache is dropped on exit;
+    outside the context every call prepares its weights afresh (``Tensor._version`` is NOT a safe key: fused Adam and
+    ``.data`` updates do not bump it)."""
+
+    def __enter__(self):
+        global _prep_cache_on
+        self.prev = _prep_cache_on
+        _prep_cache_on = True
+        return self
+
+    def __exit__(self, *a):
+        global _prep_cache_on
+        _prep_cache_on = self.prev
+        if not _prep_cache_on:
+            _prep_cache.clear()
+
+
+def prepared_weights(weight, coef, dtype, need_ft=False):
+    import weakref
+    cacheable = _prep_cache_on and isinstance(weight, torch.nn.Parameter)
+    ent = None
+    if cacheable:
+        ent = _prep_cache.get((id(weight), dtype))
+        if ent is not None and (ent.ref() is not weight or ent.coef != coef):
+            ent = None
+    if ent is None:
+        ent = _Prepared()
+        ent.coef, ent.wq_ft = coef, None
+        ent.ref = weakref.ref(weight) if cacheable else None
+        with torch.no_grad():
+            ent.wq = _ohwi((weight.detach() * coef).to(dtype))
+        if cacheable:
+            _prep_cache[(id(weight), dtype)] = ent
+    if need_ft and ent.wq_ft is None:
+        with torch.no_grad():
+            ent.wq_ft = _ohwi(flip_transpose(weight.detach() * coef).to(dtype))
+    return ent
+
+
+class _FusedConv(torch.autograd.Function):
+    """y = act( s_out * conv(x * s_in, weight * coef) + bias + noise + residual ) * gain   in one launch.
+    act = lrelu (gain must be 1) or linear.  The backward is fused too unless a graph is being recorded."""
+
     @staticmethod
-    def forward(ctx, x, w, s_in, s_out, bias, noise, alpha):
-        y = conv2d_fwd_raw(x, w, in_scale=s_in, out_scale=s_out, bias=bias, noise=noise, act=ACT_LRELU, alpha=alpha)
-        ctx.save_for_backward(x, w, s_in, s_out, bias, noise, y)
-        ctx.alpha = alpha
+    def forward(ctx, x, weight, coef, s_in, s_out, bias, noise, residual, act, alpha, gain):
+        prep = prepared_weights(weight, coef, x.dtype)
+        y = conv2d_fwd_raw(x, prep.wq, in_scale=s_in, out_scale=s_out, bias=bias, noise=noise, residual=residual,
+                           act=act, alpha=alpha, gain=gain, prepared=True)
+        ctx.save_for_backward(x, weight, s_in, s_out, bias, noise, y if (act == ACT_LRELU or s_out is not None) else None)
+        ctx.coef, ctx.act, ctx.alpha, ctx.gain = coef, act, alpha, gain
+        ctx.has_residual = residual is not None
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w, s_in, s_out, bias, noise, y = ctx.saved_tensors
-        alpha = ctx.alpha
-        need_x, need_w, need_si, need_so, need_b = ctx.needs_input_grad[:5]
-        dy = dy.to(y.dtype).contiguous(memory_format=torch.channels_last)
-        k = w.shape[2]
-        dx = dw = dsi = dso = db = None
+        x, weight, s_in, s_out, bias, noise, y = ctx.saved_tensors
+        coef, act, alpha, gain = ctx.coef, ctx.act, ctx.alpha, ctx.gain
+        need_x, need_w, _, need_si, need_so, need_b, _, need_r = ctx.needs_input_grad[:8]
+        need_r = need_r and ctx.has_residual
+        dy = dy.to(x.dtype).contiguous(memory_format=torch.channels_last)
+        k = weight.shape[2]
+        dx = dw = dsi = dso = db = dres = None
         if torch.is_grad_enabled():
             # a graph is being recorded (R1 differentiates D twice): compose from differentiable ops
             if s_in is not None or s_out is not None or noise is not None:
                 raise RuntimeError('the fused modulated conv has no double backward; build the generator with '
                                    'fused_epilogue=False when pl_lambda > 0')
             from ...stylegan3_ops import bias_act as _ba
-            g = _ba._bias_act_hip(dim=1, act='lrelu', alpha=alpha, gain=1.0).Grad.apply(dy, None, None, y)
-            if need_b:
+            if act == ACT_LRELU:
+                g = _ba._bias_act_hip(dim=1, act='lrelu', alpha=alpha, gain=gain).Grad.apply(dy, None, None, y)
+            else:
+                g = dy * gain if gain != 1 else dy
+            w = weight * coef
+            if need_b and bias is not None:
                 db = g.float().sum((0, 2, 3)).to(bias.dtype)
+            if need_r:
+                dres = g
             if need_x:
                 dx = _ConvFwd.apply(g, flip_transpose(w), None, None)
             if need_w:
-                dw = _ConvWgrad.apply(x, g, None, None, k).to(w.dtype)
-            return dx, dw, None, None, db, None, None
-        want_so = s_out is not None and need_so
-        g, (A, B, Cn) = act_bwd_reduce_raw(dy, y, noise, alpha, (want_so, want_so or (need_b and bias is not None), want_so and noise is not None))
-        if need_b and bias is not None:
-            db = B.sum(0).to(bias.dtype)
-        if want_so:
-            num = A - (bias.float()[None, :] * B if bias is not None else 0) - (Cn if Cn is not None else 0)
-            dso = num / s_out
+                dw = (_ConvWgrad.apply(x, g, None, None, k) * coef).to(weight.dtype)
+            return dx, dw, None, None, None, db, None, dres, None, None, None
+        if act == ACT_LRELU:
+            assert gain == 1.0
+            want_so = s_out is not None and need_so
+            g, (A, B, Cn) = act_bwd_reduce_raw(dy, y, noise, alpha,
+                                               (want_so, want_so or (need_b and bias is not None), want_so and noise is not None))
+            if need_b and bias is not None:
+                db = B.sum(0).to(bias.dtype)
+            if want_so:
+                num = A - (bias.float()[None, :] * B if bias is not None else 0) - (Cn if Cn is not None else 0)
+                dso = num / s_out
+        else:
+            assert s_out is None, 'linear epilogue with a demodulation scale is not used by the networks'
+            g = dy * gain if gain != 1 else dy
+            if need_b and bias is not None:
+                db = g.float().sum((0, 2, 3)).to(bias.dtype)
+        if need_r:
+            dres = g
         if need_x or (s_in is not None and need_si):
-            t = conv2d_fwd_raw(g, flip_transpose(w), in_scale=s_out)
+            prep = prepared_weights(weight, coef, x.dtype, need_ft=True)
+            t = conv2d_fwd_raw(g, prep.wq_ft, in_scale=s_out, prepared=True)
             if s_in is None:
                 dx = t
             else:
                 dx, dsi = scale_dot_raw(x, t, s_in, want_dx=need_x)
         if need_w:
-            dw = conv2d_wgrad_raw(x, g, k, in_scale=s_in, out_scale=s_out).to(w.dtype)
-        return dx, dw, dsi, dso, db, None, None
+            dw = conv2d_wgrad_raw(x, g, k, in_scale=s_in, out_scale=s_out, scale=coef).to(weight.dtype)
+        return dx, dw, None, dsi, dso, db, None, dres, None, None, None
 
 
-def conv2d_act(x, w, bias=None, s_in=None, s_out=None, noise=None, alpha=0.2, fused=True):
-    """lrelu( s_out * conv(x * s_in, w) + bias + noise ), bias [Cout], noise [N,1,H,W] (no gradient).
+def conv2d_act(x, weight, bias=None, s_in=None, s_out=None, noise=None, alpha=0.2, fused=True, coef=1.0,
+               act='lrelu', residual=None, gain=1.0):
+    """act( s_out * conv(x * s_in, weight * coef) + bias + noise + residual ) * gain; act = 'lrelu' | 'linear'.
+    bias [Cout], noise [N,1,H,W] (no gradient), residual like the output.
     ``fused=False`` evaluates the same expression with the separately differentiable ops (any-order gradients)."""
     from ...stylegan3_ops import bias_act as _ba
-    Cout, Cin = w.shape[0], w.shape[1]
-    if fused and Cout % 8 == 0:
+    Cout, Cin = weight.shape[0], weight.shape[1]
+    if fused and Cout % 8 == 0 and (act == 'linear' or gain == 1.0):
         if x.dtype == torch.bfloat16 and Cin % 8:
             x = _pad_channels(x, 8, 1).contiguous(memory_format=torch.channels_last)
-            w = _pad_channels(w, 8, 1)
+            weight = _pad_channels(weight, 8, 1)
             s_in = _pad_channels(s_in, 8, 1) if s_in is not None else None
-        return _FusedConvAct.apply(x, w, s_in, s_out, bias, noise, alpha)
-    out = conv2d(x, w, s_in, s_out)
+        return _FusedConv.apply(x, weight, coef, s_in, s_out, bias, noise, residual,
+                                ACT_LRELU if act == 'lrelu' else ACT_LINEAR, alpha, gain)
+    out = conv2d(x, weight * coef if coef != 1.0 else weight, s_in, s_out)
     if noise is not None:
         out = out + noise.to(out.dtype)
-    return _ba.bias_act(out, bias.to(out.dtype) if bias is not None else None, act='lrelu', alpha=alpha, gain=1)
+    if residual is not None:
+        out = out + residual.to(out.dtype)
+    return _ba.bias_act(out, bias.to(out.dtype) if bias is not None else None, act=act, alpha=alpha if act == 'lrelu' else None, gain=gain)

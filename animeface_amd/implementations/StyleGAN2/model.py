@@ -51,16 +51,13 @@ class ELR(nn.Module):
         return F.linear(x.float() * self.coef, self.layer.weight, self.layer.bias)
 
 
-def elr_conv2d(elr, x, act=None):
+def elr_conv2d(elr, x, act=None, residual=None, gain=1.0):
     """``ELR(nn.Conv2d)`` on the MFMA conv; coef is folded into the weights; optional fused-order bias + lrelu."""
     conv = elr.layer
     k = conv.kernel_size[0]
     assert conv.stride == (1, 1) and conv.padding == (k // 2, k // 2) and k in (1, 3)
-    if act == 'lrelu':
-        return conv2d_act(x, conv.weight * elr.coef, conv.bias, alpha=0.2, fused=FUSED_EPILOGUE)
-    y = conv2d(x, conv.weight * elr.coef)
-    b = conv.bias.to(y.dtype) if conv.bias is not None else None
-    return bias_act.bias_act(y, b) if b is not None else y
+    return conv2d_act(x, conv.weight, conv.bias, alpha=0.2, fused=FUSED_EPILOGUE, coef=elr.coef,
+                      act='lrelu' if act == 'lrelu' else 'linear', residual=residual, gain=gain)
 
 
 def Linear(name, *args, **kwargs):
@@ -212,10 +209,10 @@ class StyleBlock(nn.Module):
             if isinstance(m, ModulatedConv2d) and i + 2 < len(mods) + 0 and isinstance(mods[i + 1], InjectNoise) \
                     and isinstance(mods[i + 2], nn.LeakyReLU):
                 # modconv -> +bias -> +noise -> lrelu, noise drawn exactly where the reference draws it
-                w, s, d = m.scales(y)
+                _w, s, d = m.scales(y)
                 noise = InjectNoise.draw(x[:, :1])
-                x = conv2d_act(x, w, m.bias.reshape(-1), s, d, noise, alpha=mods[i + 2].negative_slope,
-                               fused=FUSED_EPILOGUE and getattr(self, 'fused_epilogue', True))
+                x = conv2d_act(x, m.weight, m.bias.reshape(-1), s, d, noise, alpha=mods[i + 2].negative_slope,
+                               fused=FUSED_EPILOGUE and getattr(self, 'fused_epilogue', True), coef=m.coef)
                 i += 3
             elif isinstance(m, ModulatedConv2d):
                 x = m(x, y)
@@ -246,8 +243,8 @@ class DBlock(nn.Module):
         c = float(1 / np.sqrt(2))
         if isinstance(self.down, _AvgPool2x):
             # avg-pool commutes with the 1x1 skip conv: pool first (4x less work), identical result
-            t = elr_conv2d(self.skip, self.down(t))
-            return self.down(x, gain=c) + t * c
+            # (skip(pool(t)) + pool(x)) / sqrt(2): the residual add and the gain run in the 1x1 conv's epilogue
+            return elr_conv2d(self.skip, self.down(t), residual=self.down(x), gain=c)
         t = self.skip(t)
         return (self.down(x) + self.down(t)) / np.sqrt(2)
 

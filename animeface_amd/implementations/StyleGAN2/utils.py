@@ -22,6 +22,7 @@ from ...thirdparty.diffaugment import DiffAugment
 from ... import distributed as dp
 from ... import rng
 from .model import Generator, Discriminator, init_weight_N01
+from .conv import cached_weights
 
 
 def pl_penalty(styles, images, pl_mean, scaler=None):
@@ -77,6 +78,30 @@ class TrainStep:
         self._zero(self.optimizer_D, self.reducer_D)
 
         # ---- discriminator (reference utils.py:60-86) ----
+        with cached_weights():
+            D_loss = self._d_half(real, it)
+        if self.reducer_D is not None:
+            self.reducer_D.finish()
+        self.optimizer_D.step()
+
+        # ---- generator (reference utils.py:88-113) ----
+        for p in D.parameters():
+            p.requires_grad_(False)
+        with cached_weights():
+            G_loss, fake = self._g_half(real, it)
+        for p in D.parameters():
+            p.requires_grad_(True)
+        if self.reducer_G is not None:
+            self.reducer_G.finish()
+        self.optimizer_G.step()
+
+        if self.G_ema is not None:
+            update_ema(G, self.G_ema)
+        self.batches_done += 1
+        return D_loss.detach(), G_loss.detach(), fake
+
+    def _d_half(self, real, it):
+        G, D = self.G, self.D
         z = self.sampler((real.size(0), self.latent_dim))
         real_aug = self.augment(real)
         real_prob = D(real_aug)
@@ -90,13 +115,10 @@ class TrainStep:
         else:
             D_loss = self.loss.d_loss(real_prob, fake_prob)
         D_loss.backward()
-        if self.reducer_D is not None:
-            self.reducer_D.finish()
-        self.optimizer_D.step()
+        return D_loss
 
-        # ---- generator (reference utils.py:88-113) ----
-        for p in D.parameters():
-            p.requires_grad_(False)
+    def _g_half(self, real, it):
+        G, D = self.G, self.D
         z = self.sampler((real.size(0), self.latent_dim))
         fake, style = G(z)
         fake_aug = self.augment(fake)
@@ -108,16 +130,7 @@ class TrainStep:
         else:
             G_loss = self.loss.g_loss(fake_prob)
         G_loss.backward()
-        for p in D.parameters():
-            p.requires_grad_(True)
-        if self.reducer_G is not None:
-            self.reducer_G.finish()
-        self.optimizer_G.step()
-
-        if self.G_ema is not None:
-            update_ema(G, self.G_ema)
-        self.batches_done += 1
-        return D_loss.detach(), G_loss.detach(), fake
+        return G_loss, fake
 
 
 def build_optimizers(G, D, lr, betas, r1_lambda, pl_lambda, d_k, g_k):

@@ -127,13 +127,13 @@ int agf_conv2d_fwd(const void* x, const void* w, void* y,
                    int act, float alpha, float act_gain, void* stream);
 
 /* weight gradient of the same contraction:
- *   dw[co,kh,kw,ci] = sum_{n,h,w} dy[n,h,w,co] * out_scale[n,co] * x[n,h+kh-p,w+kw-p,ci] * in_scale[n,ci]
+ *   dw[co,kh,kw,ci] += scale * sum_{n,h,w} dy[n,h,w,co] * out_scale[n,co] * x[n,h+kh-p,w+kw-p,ci] * in_scale[n,ci]
  * dw is fp32 OHWI and is ACCUMULATED into (split-K partial sums use fp32 atomics): zero it first.
  * (dgrad is agf_conv2d_fwd with the spatially flipped, transposed weights.) */
 int agf_conv2d_wgrad(const void* x, const void* dy, float* dw,
                      const float* in_scale, const float* out_scale,
                      int dtype, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
-                     void* stream);
+                     float scale, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Backward halves of the fused conv epilogues (new: the reference has no counterpart -- it runs these as separate
