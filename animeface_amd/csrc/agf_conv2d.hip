@@ -458,7 +458,10 @@ static __device__ __forceinline__ u32x4 scale_vec8(u32x4 val, const float* sc) {
 }
 
 template <int KS, bool COMPACT>
-__global__ void __launch_bounds__(256) conv2d_wgrad_kernel(WgradParams p) {
+__global__ void __launch_bounds__(512) conv2d_wgrad_kernel(WgradParams p) {
+    // 8 waves: waves 0-3 and 4-7 own the same four (co32 x ci32) quadrants but alternate k-steps (even / odd); both
+    // halves add their partial sums with the same atomics that already combine the split-K blocks.  Two waves per SIMD
+    // is what hides the LDS latency of the 20 transpose reads per k-step (one wave per SIMD ran the MFMA pipe at 20 %).
     // COMPACT (TW in {16, 32}): the dy tile holds only the TH*TW interior pixels and a k-step is a run of 16 pixels of one
     //   tile row, so no MFMA work is spent on halo positions; the x patch needs no margins.
     // padded  (small maps): dy is staged in the patch's own (TH+2)x(TW+2) index space (zeros in the halo ring) so that a
@@ -481,7 +484,8 @@ __global__ void __launch_bounds__(256) conv2d_wgrad_kernel(WgradParams p) {
     const int co0 = tco * 64, ci0 = tci * 64;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wa = wave >> 1, wb = wave & 1;             // co block, ci block
+    const int khalf = wave >> 2;                         // which k-steps this wave contracts
+    const int wa = (wave >> 1) & 1, wb = wave & 1;       // co block, ci block
     const int li = lane & 15, lg = (lane >> 4) & 1, lk = lane >> 5;
     const int laneOff = (8 * lk + (li >> 2)) * 32 + 16 * lg + 4 * (li & 3);
     const bf16_t* aPtr = sDy + wa * DYR * 32 + laneOff;
@@ -495,31 +499,53 @@ __global__ void __launch_bounds__(256) conv2d_wgrad_kernel(WgradParams p) {
         for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
 
     // register-staged software pipeline (as in the forward kernel): tile pt+splitK is loaded while tile pt is contracted
-    constexpr int DV = 8, XV = 12;                        // vectors per thread: DYR*8/256 <= 8 (DYR <= 256), XR*8/256 <= 12
+    constexpr int NT = 512;
+    constexpr int DV = 4, XV = 6;                         // vectors per thread: DYR*8/512 <= 4 (DYR <= 256), XR*8/512 <= 6
     u32x4 dreg[DV], xreg[XV];
+    // tile-invariant part of the staging index math (no divisions inside the tile loop): per vector the pixel's
+    // (image-in-tile, row, col) relative to the tile origin, packed as ti<<20 | (dh+8)<<10 | (dw+8); -1 = always zero.
+    int drel[DV], xrel[XV];
+#pragma unroll
+    for (int i = 0; i < DV; i++) {
+        int v = tid + i * NT;
+        int q = v >> 3;
+        drel[i] = -1;
+        if (q < DYR) {
+            if (COMPACT) {
+                int c = q % p.TW; int t2 = q / p.TW; int r = t2 % p.TH; int ti = t2 / p.TH;
+                drel[i] = (ti << 20) | ((r + 8) << 10) | (c + 8);
+            } else {
+                int pc = q % PW; int t2 = q / PW; int pr = t2 % PH; int ti = t2 / PH;
+                bool ok = q < P && pr >= HALO && pr < PH - HALO && pc >= HALO && pc < PW - HALO;
+                if (ok) drel[i] = (ti << 20) | ((pr - HALO + 8) << 10) | (pc - HALO + 8);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < XV; i++) {
+        int v = tid + i * NT;
+        int row = v >> 3;
+        int q = row - MARGIN;
+        xrel[i] = -1;
+        if (row < XR && q >= 0 && q < P) {
+            int pc = q % PW; int t2 = q / PW; int pr = t2 % PH; int ti = t2 / PH;
+            xrel[i] = (ti << 20) | ((pr - HALO + 8) << 10) | (pc - HALO + 8);
+        }
+    }
+    const int dcv = (tid & 7) * 8;                        // channel offset of this thread's vectors (v & 7 is i-invariant)
     auto load_tile = [&](int pt) {
         int tq = pt;
         const int tw = tq % p.tilesW; tq /= p.tilesW;
         const int th = tq % p.tilesH;
         const int tn = tq / p.tilesH;
         const int n0 = tn * p.TI, h0 = th * p.TH, w0 = tw * p.TW;
+        const int gco = co0 + dcv, gci = ci0 + dcv;
 #pragma unroll
         for (int i = 0; i < DV; i++) {
-            int v = tid + i * 256;
-            int cv = v & 7, q = v >> 3;
             u32x4 val = {0u, 0u, 0u, 0u};
-            if (q < DYR) {
-                int n, h, w; bool ok;
-                if (COMPACT) {
-                    int c = q % p.TW; int t2 = q / p.TW; int r = t2 % p.TH; int ti = t2 / p.TH;
-                    n = n0 + ti; h = h0 + r; w = w0 + c; ok = true;
-                } else {
-                    int pc = q % PW; int t2 = q / PW; int pr = t2 % PH; int ti = t2 / PH;
-                    n = n0 + ti; h = h0 + pr - HALO; w = w0 + pc - HALO;
-                    ok = q < P && pr >= HALO && pr < PH - HALO && pc >= HALO && pc < PW - HALO;
-                }
-                int gco = co0 + cv * 8;
-                if (ok && n < p.N && h < p.H && w < p.W && gco < p.Cout) {
+            if (drel[i] >= 0) {
+                int n = n0 + (drel[i] >> 20), h = h0 + ((drel[i] >> 10) & 1023) - 8, w = w0 + (drel[i] & 1023) - 8;
+                if (n < p.N && h < p.H && w < p.W && gco < p.Cout) {
                     val = *(const u32x4*)(p.dy + (((int64_t)n * p.H + h) * p.W + w) * p.Cout + gco);
                     if (p.out_scale) val = scale_vec8(val, p.out_scale + (int64_t)n * p.Cout + gco);
                 }
@@ -528,13 +554,9 @@ __global__ void __launch_bounds__(256) conv2d_wgrad_kernel(WgradParams p) {
         }
 #pragma unroll
         for (int i = 0; i < XV; i++) {
-            int v = tid + i * 256;
-            int cv = v & 7, row = v >> 3;
-            int q = row - MARGIN;
             u32x4 val = {0u, 0u, 0u, 0u};
-            if (row < XR && q >= 0 && q < P) {
-                int pc = q % PW; int t2 = q / PW; int pr = t2 % PH; int ti = t2 / PH;
-                int n = n0 + ti, h = h0 + pr - HALO, w = w0 + pc - HALO, gci = ci0 + cv * 8;
+            if (xrel[i] >= 0) {
+                int n = n0 + (xrel[i] >> 20), h = h0 + ((xrel[i] >> 10) & 1023) - 8, w = w0 + (xrel[i] & 1023) - 8;
                 if (n < p.N && h >= 0 && h < p.H && w >= 0 && w < p.W && gci < p.Cin) {
                     val = *(const u32x4*)(p.x + (((int64_t)n * p.H + h) * p.W + w) * p.Cin + gci);
                     if (p.in_scale) val = scale_vec8(val, p.in_scale + (int64_t)n * p.Cin + gci);
@@ -546,13 +568,13 @@ __global__ void __launch_bounds__(256) conv2d_wgrad_kernel(WgradParams p) {
     auto store_tile = [&]() {
 #pragma unroll
         for (int i = 0; i < DV; i++) {
-            int v = tid + i * 256;
+            int v = tid + i * NT;
             int cv = v & 7, q = v >> 3;
             if (q < DYR) *(u32x4*)(sDy + ((cv >> 2) * DYR + q) * 32 + (cv & 3) * 8) = dreg[i];
         }
 #pragma unroll
         for (int i = 0; i < XV; i++) {
-            int v = tid + i * 256;
+            int v = tid + i * NT;
             int cv = v & 7, row = v >> 3;
             if (row < XR) *(u32x4*)(sX + ((cv >> 2) * XR + row) * 32 + (cv & 3) * 8) = xreg[i];
         }
@@ -564,18 +586,24 @@ __global__ void __launch_bounds__(256) conv2d_wgrad_kernel(WgradParams p) {
     for (; pt < p.pixTiles; pt += p.splitK) {
         const bool more = pt + p.splitK < p.pixTiles;
         if (more) load_tile(pt + p.splitK);
-        for (int s = 0; s < DYR / 16; s++) {
-            const bf16x8 af = tr_frag(aPtr + s * 16 * 32);
-            int xrow;
-            if (COMPACT) { int r = s / stepsPerRow; xrow = (r / p.TH * PH + r % p.TH) * PW + (s % stepsPerRow) * 16; }
-            else xrow = s * 16 - (HALO * PW + HALO);
+        // fragment reads are software-pipelined one k-step ahead of the MFMAs (one wave per SIMD: nothing else would
+        // hide the LDS latency of the 20 transpose reads a k-step needs)
+        auto xrow_of = [&](int s) {
+            if (COMPACT) { int r = s / stepsPerRow; return (r / p.TH * PH + r % p.TH) * PW + (s % stepsPerRow) * 16; }
+            return s * 16 - (HALO * PW + HALO);
+        };
+        const int nSteps = DYR / 16;
+        for (int sc = khalf; sc < nSteps; sc += 2) {
+            const int xr = xrow_of(sc);
+            const bf16x8 af = tr_frag(aPtr + sc * 16 * 32);
+            bf16x8 bfr[TAPS];
 #pragma unroll
             for (int kh = 0; kh < KS; kh++)
 #pragma unroll
-                for (int kw = 0; kw < KS; kw++) {
-                    const bf16x8 bfr = tr_frag(bPtr + (xrow + kh * PW + kw) * 32);
-                    acc[kh * KS + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[kh * KS + kw], 0, 0, 0);
-                }
+                for (int kw = 0; kw < KS; kw++) bfr[kh * KS + kw] = tr_frag(bPtr + (xr + kh * PW + kw) * 32);
+#pragma unroll
+            for (int t = 0; t < TAPS; t++)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr[t], acc[t], 0, 0, 0);
         }
         if (more) {
             __syncthreads();
@@ -600,7 +628,7 @@ template <int KS, bool COMPACT>
 static int launch_wgrad(const WgradParams& p, size_t lds, hipStream_t st) {
     hipError_t e = hipFuncSetAttribute((const void*)conv2d_wgrad_kernel<KS, COMPACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { agf_set_error("conv2d_wgrad: cannot reserve LDS: %s", hipGetErrorString(e)); return AGF_ELAUNCH; }
-    dim3 grid((unsigned)(p.tilesCo * p.tilesCi * p.splitK)), block(256);
+    dim3 grid((unsigned)(p.tilesCo * p.tilesCi * p.splitK)), block(512);
     hipLaunchKernelGGL((conv2d_wgrad_kernel<KS, COMPACT>), grid, block, lds, st, p);
     return AGF_OK;
 }
@@ -645,16 +673,19 @@ extern "C" int agf_conv2d_wgrad(const void* x, const void* dy, float* dw,
         P = p.TI * PH * PW; Ppad = (P + 15) & ~15; MARGIN = HALO * PW + HALO;
         DYR = compact ? p.TI * p.TH * p.TW : Ppad;
         XR = compact ? Ppad : Ppad + 2 * MARGIN;
-        if (DYR <= 256 && XR * 8 <= 12 * 256) break;
+        if (DYR <= 256 && XR * 8 <= 6 * 512) break;
         if (p.TI > 1) p.TI >>= 1; else if (p.TH > 1) p.TH >>= 1; else break;
     }
     p.tilesW = (W + p.TW - 1) / p.TW; p.tilesH = (H + p.TH - 1) / p.TH; p.tilesN = (N + p.TI - 1) / p.TI;
     p.pixTiles = p.tilesW * p.tilesH * p.tilesN;
     p.tilesCo = (Cout + 63) / 64; p.tilesCi = (Cin + 63) / 64;
     int base = p.tilesCo * p.tilesCi;
-    int want = (1024 + base - 1) / base;                 // aim at >= 1024 blocks (4 per CU)
-    p.splitK = want < 1 ? 1 : (want > p.pixTiles ? p.pixTiles : want);
-    AGF_CHECK(DYR <= 256 && XR * 8 <= 12 * 256 && DYR % 16 == 0, "conv2d_wgrad: internal tile too large");
+    // split K over blocks: aim at >= 512 blocks, but keep >= 4 pixel tiles per block so that the MFMA work of a block
+    // outweighs its 2 x 64x64x9 fp32 atomics (small maps used to be dominated by the atomic epilogue)
+    int want = (512 + base - 1) / base;
+    int cap = p.pixTiles / 4 < 1 ? 1 : p.pixTiles / 4;
+    p.splitK = want < 1 ? 1 : (want > cap ? cap : want);
+    AGF_CHECK(DYR <= 256 && XR * 8 <= 6 * 512 && DYR % 16 == 0, "conv2d_wgrad: internal tile too large");
     size_t lds = (size_t)(2 * DYR + 2 * XR) * 32 * sizeof(bf16_t);
     if (lds > 160 * 1024) { agf_set_error("conv2d_wgrad: tile needs %zu bytes of LDS", lds); return AGF_ENOKERNEL; }
     hipStream_t st = (hipStream_t)stream;
