@@ -27,6 +27,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define BLOCK_PIX 256
 
+static __device__ __forceinline__ u32x4 scale_vec8(u32x4 val, const float* sc) {
+    f32x4 s0 = *(const f32x4*)sc, s1 = *(const f32x4*)(sc + 4);
+    float a0, a1;
+    Pack16<bf16_t>::unpack(val.x, a0, a1); val.x = Pack16<bf16_t>::pack(a0 * s0.x, a1 * s0.y);
+    Pack16<bf16_t>::unpack(val.y, a0, a1); val.y = Pack16<bf16_t>::pack(a0 * s0.z, a1 * s0.w);
+    Pack16<bf16_t>::unpack(val.z, a0, a1); val.z = Pack16<bf16_t>::pack(a0 * s1.x, a1 * s1.y);
+    Pack16<bf16_t>::unpack(val.w, a0, a1); val.w = Pack16<bf16_t>::pack(a0 * s1.z, a1 * s1.w);
+    return val;
+}
+
 struct ConvParams {
     const bf16_t* x;          // [N,H,W,Cin]
     const bf16_t* w;          // [Cout,KS,KS,Cin]
@@ -248,6 +258,175 @@ __global__ void __launch_bounds__(256, MINW) conv2d_fwd_kernel(ConvParams p) {
 
 
 // =================================================================================================
+// Weight-stationary variant for the high-resolution, few-channel layers (Cin <= 64: the 256x256 and 128x128 layers of
+// both networks and their data gradients).  There the K loop has only 1-2 chunks, so the generic kernel above spends
+// its time in prologue / epilogue and re-stages the (identical) weights for every pixel tile.  Here a block stages the
+// whole [9][64 co][Cin] weight slab ONCE and then streams pixel tiles through it: per tile only the input patch moves
+// (register-prefetched during the previous tile's MFMAs), and the contraction is fully unrolled (9 taps x Cin/16 steps).
+template <int KS, bool IN_SCALE, int CINP, int BM>     // CINP = Cin rounded up to 32 or 64; BM = co tile (64, or 32 for Cout <= 32)
+__global__ void __launch_bounds__(256) conv2d_fwd_ws_kernel(ConvParams p) {
+    constexpr int PITCH = CINP + 8;
+    constexpr int TAPS = KS * KS;
+    constexpr int HALO = KS / 2;
+    constexpr int NJ = BM == 64 ? 4 : 2;                            // 32-pixel accumulator tiles per wave
+    constexpr int VPR = CINP / 8;                                    // 16-byte vectors per row
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* sW = (bf16_t*)smem_raw;                                  // [TAPS][BM][PITCH]
+    bf16_t* sX = sW + TAPS * BM * PITCH;                             // [P][PITCH]
+
+    const int coTile = blockIdx.x % p.tilesCo;
+    const int worker = blockIdx.x / p.tilesCo, workers = gridDim.x / p.tilesCo;
+    const int co0 = coTile * BM;
+    const int PW = p.TW + 2 * HALO, PH = p.TH + 2 * HALO;
+    const int P = p.TI * PH * PW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // BM = 64: waves 2 (co) x 2 (pixel halves), 32 co x 128 px each;  BM = 32: waves 1 x 4, 32 co x 64 px each
+    const int wm = BM == 64 ? (wave >> 1) : 0, wn = BM == 64 ? (wave & 1) : wave;
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    // ---- weights: once per block ----
+    for (int v = tid; v < TAPS * BM * VPR; v += 256) {
+        int cv = v % VPR, row = v / VPR;
+        int tap = row / BM, co = row - tap * BM;
+        int gco = co0 + co, gc = cv * 8;
+        u32x4 val = {0u, 0u, 0u, 0u};
+        if (gco < p.Cout && gc < p.Cin) val = *(const u32x4*)(p.w + ((int64_t)gco * TAPS + tap) * p.Cin + gc);
+        *(u32x4*)(sW + row * PITCH + cv * 8) = val;
+    }
+
+    int bBase[NJ], qc[NJ], qr[NJ], qi[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+        int q = wn * (NJ * 32) + j * 32 + l31;
+        qc[j] = q % p.TW; qr[j] = (q / p.TW) % p.TH; qi[j] = q / (p.TW * p.TH);
+        bBase[j] = ((qi[j] * PH + qr[j]) * PW + qc[j]) * PITCH + lhi * 8;
+    }
+    const int aBase = (wm * 32 + l31) * PITCH + lhi * 8;
+
+    // tile-invariant patch geometry: (image-in-tile, dh, dw) per staged vector, packed; -1 = beyond the patch
+    constexpr int XV = (340 * VPR + 255) / 256;                      // the launcher only uses 8x32 tiles (P = 340)
+    int xrel[XV];
+#pragma unroll
+    for (int i = 0; i < XV; i++) {
+        int v = tid + i * 256;
+        int pix = v / VPR;
+        xrel[i] = -1;
+        if (pix < P) {
+            int pc = pix % PW; int t2 = pix / PW; int pr = t2 % PH; int ti = t2 / PH;
+            xrel[i] = (ti << 20) | ((pr - HALO + 8) << 10) | (pc - HALO + 8);
+        }
+    }
+    u32x4 xreg[XV];
+    auto load_patch = [&](int pt) {
+        int tq = pt;
+        const int tw = tq % p.tilesW; tq /= p.tilesW;
+        const int th = tq % p.tilesH;
+        const int tn = tq / p.tilesH;
+        const int n0 = tn * p.TI, h0 = th * p.TH, w0 = tw * p.TW;
+#pragma unroll
+        for (int i = 0; i < XV; i++) {
+            const int gc = ((tid + i * 256) % VPR) * 8;
+            u32x4 val = {0u, 0u, 0u, 0u};
+            if (xrel[i] >= 0) {
+                int n = n0 + (xrel[i] >> 20), h = h0 + ((xrel[i] >> 10) & 1023) - 8, w = w0 + (xrel[i] & 1023) - 8;
+                if (n < p.N && h >= 0 && h < p.H && w >= 0 && w < p.W && gc < p.Cin) {
+                    val = *(const u32x4*)(p.x + (((int64_t)n * p.H + h) * p.W + w) * p.Cin + gc);
+                    if (IN_SCALE) val = scale_vec8(val, p.in_scale + (int64_t)n * p.Cin + gc);
+                }
+            }
+            xreg[i] = val;
+        }
+    };
+    auto store_patch = [&]() {
+#pragma unroll
+        for (int i = 0; i < XV; i++) {
+            int v = tid + i * 256;
+            if (xrel[i] >= 0) *(u32x4*)(sX + (v / VPR) * PITCH + (v % VPR) * 8) = xreg[i];
+        }
+    };
+
+    int pt = worker;
+    if (pt < p.pixTiles) { load_patch(pt); store_patch(); }
+    __syncthreads();
+    for (; pt < p.pixTiles; pt += workers) {
+        const bool more = pt + workers < p.pixTiles;
+        if (more) load_patch(pt + workers);
+        f32x16 acc[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < KS; kh++)
+#pragma unroll
+            for (int kw = 0; kw < KS; kw++)
+#pragma unroll
+                for (int ks = 0; ks < CINP / 16; ks++) {
+                    const bf16x8 af = *(const bf16x8*)(sW + (kh * KS + kw) * BM * PITCH + aBase + ks * 16);
+#pragma unroll
+                    for (int j = 0; j < NJ; j++) {
+                        const bf16x8 bfr = *(const bf16x8*)(sX + (kh * PW + kw) * PITCH + bBase[j] + ks * 16);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[j], 0, 0, 0);
+                    }
+                }
+        // ---- epilogue of this tile ----
+        {
+            int tq = pt;
+            const int tw = tq % p.tilesW; tq /= p.tilesW;
+            const int th = tq % p.tilesH;
+            const int tn = tq / p.tilesH;
+            const int n0 = tn * p.TI, h0 = th * p.TH, w0 = tw * p.TW;
+#pragma unroll
+            for (int j = 0; j < NJ; j++) {
+                int n = n0 + qi[j], h = h0 + qr[j], w = w0 + qc[j];
+                if (n >= p.N || h >= p.H || w >= p.W) continue;
+                const int64_t pixIdx = ((int64_t)n * p.H + h) * p.W + w;
+                const float nz = p.noise ? p.noise[pixIdx] : 0.f;
+#pragma unroll
+                for (int rg = 0; rg < 4; rg++) {
+                    int co = co0 + wm * 32 + rg * 8 + lhi * 4;
+                    if (co >= p.Cout) continue;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = acc[j][rg * 4 + e];
+                    if (p.out_scale) {
+                        f32x4 sc = *(const f32x4*)(p.out_scale + (int64_t)n * p.Cout + co);
+                        v[0] *= sc.x; v[1] *= sc.y; v[2] *= sc.z; v[3] *= sc.w;
+                    }
+                    if (p.bias) {
+                        f32x4 bb = *(const f32x4*)(p.bias + co);
+                        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] += nz;
+                    if (p.residual) {
+                        u32x2 rr = *(const u32x2*)(p.residual + pixIdx * p.Cout + co);
+                        float a0, a1;
+                        Pack16<bf16_t>::unpack(rr.x, a0, a1); v[0] += a0; v[1] += a1;
+                        Pack16<bf16_t>::unpack(rr.y, a0, a1); v[2] += a0; v[3] += a1;
+                    }
+                    if (p.act == 3) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) v[e] = v[e] > 0.f ? v[e] : v[e] * p.alpha;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] *= p.gain;
+                    u32x2 o;
+                    o.x = Pack16<bf16_t>::pack(v[0], v[1]);
+                    o.y = Pack16<bf16_t>::pack(v[2], v[3]);
+                    *(u32x2*)(p.y + pixIdx * p.Cout + co) = o;
+                }
+            }
+        }
+        if (more) {
+            __syncthreads();
+            store_patch();
+            __syncthreads();
+        }
+    }
+}
+
+// =================================================================================================
 // fp32 reference-precision path (the reference's --disable-amp configuration and the <= 1e-3 parity tests).
 // Plain VALU FMAs in fp32, same layouts (NHWC activations, OHWI weights), same fused scales / epilogue.
 // Not a throughput path: the bf16 MFMA kernels above are.
@@ -345,8 +524,39 @@ static int launch_fwd_v(const ConvParams& p, hipStream_t st) {
 
 static int g_fwd_variant = -1;     // AGF_CONV_VARIANT: 0 = KC32 (1 block/CU at MT=2), 1 = KC16 + 2 blocks/CU
 
+template <int KS, bool SC, int CINP, int BM>
+static int launch_fwd_ws(const ConvParams& p0, hipStream_t st) {
+    constexpr int TAPS = KS * KS, HALO = KS / 2, PITCH = CINP + 8;
+    ConvParams p = p0;
+    p.tilesCo = (p.Cout + BM - 1) / BM;
+    const int P = p.TI * (p.TH + 2 * HALO) * (p.TW + 2 * HALO);
+    size_t lds = (size_t)(TAPS * BM + P) * PITCH * sizeof(bf16_t);
+    if (lds > 160 * 1024) return AGF_ENOKERNEL;
+    const int perCU = lds <= 80 * 1024 ? 2 : 1;
+    int workers = (256 * perCU) / p.tilesCo;
+    if (workers < 1) workers = 1;
+    if (workers > p.pixTiles) workers = p.pixTiles;
+    hipError_t e = hipFuncSetAttribute((const void*)conv2d_fwd_ws_kernel<KS, SC, CINP, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { agf_set_error("conv2d_fwd: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e)); return AGF_ELAUNCH; }
+    hipLaunchKernelGGL((conv2d_fwd_ws_kernel<KS, SC, CINP, BM>), dim3((unsigned)(workers * p.tilesCo)), dim3(256), lds, st, p);
+    return AGF_OK;
+}
+
+static int g_ws_enable = -1;       // AGF_CONV_WS=0 disables the weight-stationary variant (A/B)
+
 template <int KS, int MT>
 static int launch_fwd(const ConvParams& p, hipStream_t st) {
+    if (g_ws_enable < 0) { const char* e = getenv("AGF_CONV_WS"); g_ws_enable = e ? atoi(e) : 1; }
+    // weight-stationary kernel: Cin <= 32 (two blocks per CU), or Cin <= 64 with Cout <= 32 (32-channel co tile: the
+    // generic 64-channel tile would waste half of its MFMAs there); measured per layer in tools/ab_ws.sh
+    if (g_ws_enable && KS == 3 && MT == 1 && p.pixTiles >= 2048 && p.TW == 32 && p.TH == 8 && p.TI == 1 &&
+        (p.Cin <= 32 || (p.Cin <= 64 && p.Cout <= 32))) {
+        int rc;
+        if (p.Cin <= 32 && p.Cout <= 32) rc = p.in_scale ? launch_fwd_ws<3, true, 32, 32>(p, st) : launch_fwd_ws<3, false, 32, 32>(p, st);
+        else if (p.Cin <= 32)            rc = p.in_scale ? launch_fwd_ws<3, true, 32, 64>(p, st) : launch_fwd_ws<3, false, 32, 64>(p, st);
+        else                             rc = p.in_scale ? launch_fwd_ws<3, true, 64, 32>(p, st) : launch_fwd_ws<3, false, 64, 32>(p, st);
+        if (rc != AGF_ENOKERNEL) return rc;
+    }
     if (g_fwd_variant < 0) { const char* e = getenv("AGF_CONV_VARIANT"); g_fwd_variant = e ? atoi(e) : 0; }
     if (g_fwd_variant == 1) {
         return p.in_scale ? launch_fwd_v<KS, MT, true, 16, 2>(p, st) : launch_fwd_v<KS, MT, false, 16, 2>(p, st);
@@ -447,15 +657,6 @@ static __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* base) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
-static __device__ __forceinline__ u32x4 scale_vec8(u32x4 val, const float* sc) {
-    f32x4 s0 = *(const f32x4*)sc, s1 = *(const f32x4*)(sc + 4);
-    float a0, a1;
-    Pack16<bf16_t>::unpack(val.x, a0, a1); val.x = Pack16<bf16_t>::pack(a0 * s0.x, a1 * s0.y);
-    Pack16<bf16_t>::unpack(val.y, a0, a1); val.y = Pack16<bf16_t>::pack(a0 * s0.z, a1 * s0.w);
-    Pack16<bf16_t>::unpack(val.z, a0, a1); val.z = Pack16<bf16_t>::pack(a0 * s1.x, a1 * s1.y);
-    Pack16<bf16_t>::unpack(val.w, a0, a1); val.w = Pack16<bf16_t>::pack(a0 * s1.z, a1 * s1.w);
-    return val;
-}
 
 template <int KS, bool COMPACT>
 __global__ void __launch_bounds__(512) conv2d_wgrad_kernel(WgradParams p) {
