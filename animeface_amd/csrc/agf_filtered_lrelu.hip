@@ -124,8 +124,237 @@ extern "C" int agf_filtered_lrelu_act(void* x, uint8_t* s, int dtype,
     return AGF_OK;
 }
 
-// TODO(fused): single-pass LDS kernel.  Until it lands every parameter set reports "no specialised kernel",
-// which is the reference's own protocol for falling back to the generic 4-pass composition (filtered_lrelu.py:217-223).
+// =================================================================================================
+// Fused filtered_lrelu: bias -> zero-insert upsample + FIR(fu) * up^2 -> * gain -> leaky ReLU -> clamp (sign write / sign
+// read) -> FIR(fd) + decimate, one launch; the up-resolution intermediate lives only in LDS (reference
+// filtered_lrelu.cu:133-1093).  One 256-thread workgroup = one output tile of one (n,c) plane:
+//     sXin [TXH][TXW]   input tile + bias (zero outside the image)           fp32
+//     sH   [TXH][TUW]   after the horizontal up-FIR        (separable fu only)
+//     sU   [TUH][TUW]   upsampled, activated tile  (signs written / applied here)
+//     sD   [TUH][TOW]   after the horizontal down-FIR      (separable fd only)
+// Separable filters run as two 1-D passes (6+6 taps per upsampled sample for the 12-tap up-by-2 SG3 filter), full
+// 2-D (radial) filters as one 2-D pass.  CDNA4's 160 KB of LDS allows 64x32 output tiles (the reference's 48 KB
+// kernels use 56x29 .. 32x16), which cuts the halo recompute of the 12x12 radial down filter to 1.25x.
+// Filters are staged in LDS per workgroup: no __constant__ singleton, so launches on different streams are independent.
+// Sign bytes are written only for a tile's non-overlapping core columns/rows (its width is a multiple of 4 samples, so
+// every byte has exactly one writer); the last tile of a row/column also covers the remainder of the sign plane.
+struct FlrParams {
+    const void* x; const float* fu; const float* fd; const void* b; uint8_t* s; void* y;
+    int N, C, XH, XW, YH, YW;
+    int64_t xs[4], ys[4];
+    int fuw, fuh, fdw, fdh;          // 2-D sizes; separable filters have fuh == 0 / fdh == 0 (then taps = fuw / fdw both ways)
+    int64_t fus0, fus1, fds0, fds1;
+    int up, down, px0, py0;
+    int SH, SWB, sofsx, sofsy, signMode;
+    float gain, slope, clamp;
+    int flip;
+    int TOW, TOH, TUW, TUH, TXW, TXH, tilesX, tilesY;
+    int UW, UH;                      // logical size of the upsampled image
+};
+
+// UP / DOWN / FUW / FDW / SU / SD > 0 fix the configuration at compile time (SU, SD: 1 = separable, 2 = full 2-D) so that
+// the tap loops unroll and their LDS reads issue back to back; 0 = runtime value (generic fallback).
+template <class T, int UP, int DOWN, int FUW, int FDW, int SU, int SD>
+__global__ void __launch_bounds__(256) filtered_lrelu_kernel(FlrParams p0) {
+    extern __shared__ __attribute__((aligned(16))) float flr_smem[];
+    FlrParams p = p0;
+    if (UP) p.up = UP;
+    if (DOWN) p.down = DOWN;
+    if (FUW) { p.fuw = FUW; p.fuh = SU == 1 ? 0 : FUW; }
+    if (FDW) { p.fdw = FDW; p.fdh = SD == 1 ? 0 : FDW; }
+    const bool sepU = SU ? SU == 1 : p.fuh == 0, sepD = SD ? SD == 1 : p.fdh == 0;
+    const int fuH = sepU ? p.fuw : p.fuh, fdH = sepD ? p.fdw : p.fdh;
+    constexpr bool UNR_U = UP > 0 && FUW > 0 && (FUW % (UP ? UP : 1)) == 0;   // every phase has FUW/UP taps
+    constexpr int NTU = UNR_U ? FUW / (UP ? UP : 1) : 1;
+    float* sFu = flr_smem;                                     // fuH*fuw (2-D) or fuw (1-D), stored in "F" order
+    float* sFd = sFu + (sepU ? p.fuw : p.fuh * p.fuw);
+    float* sXin = sFd + (sepD ? p.fdw : p.fdh * p.fdw);
+    float* sH = sXin + p.TXH * p.TXW;
+    float* sU = sH + (sepU ? p.TXH * p.TUW : 0);
+    float* sD = sU + p.TUH * p.TUW;
+    const int tid = threadIdx.x;
+
+    // filters, flipped unless p.flip: F(k) = f[size-1-k]
+    if (sepU) { for (int i = tid; i < p.fuw; i += 256) sFu[i] = p.fu[(p.flip ? i : p.fuw - 1 - i) * p.fus0]; }
+    else { for (int i = tid; i < p.fuh * p.fuw; i += 256) { int ky = i / p.fuw, kx = i - ky * p.fuw;
+            sFu[i] = p.fu[(p.flip ? ky : p.fuh - 1 - ky) * p.fus0 + (p.flip ? kx : p.fuw - 1 - kx) * p.fus1]; } }
+    if (sepD) { for (int i = tid; i < p.fdw; i += 256) sFd[i] = p.fd[(p.flip ? i : p.fdw - 1 - i) * p.fds0]; }
+    else { for (int i = tid; i < p.fdh * p.fdw; i += 256) { int ky = i / p.fdw, kx = i - ky * p.fdw;
+            sFd[i] = p.fd[(p.flip ? ky : p.fdh - 1 - ky) * p.fds0 + (p.flip ? kx : p.fdw - 1 - kx) * p.fds1]; } }
+
+    int bid = blockIdx.x;
+    const int tx = bid % p.tilesX; bid /= p.tilesX;
+    const int ty = bid % p.tilesY;
+    const int plane = bid / p.tilesY;
+    const int n = plane / p.C, c = plane - n * p.C;
+    const int oy0 = ty * p.TOH, ox0 = tx * p.TOW;
+    const int uy0 = oy0 * p.down, ux0 = ox0 * p.down;         // origin of the upsampled tile
+    // input tile origin: first input sample any upsampled sample of the tile can touch
+    const int tix0 = agf_floor_div(ux0 + p.up - 1 - p.px0, p.up);
+    const int tiy0 = agf_floor_div(uy0 + p.up - 1 - p.py0, p.up);
+
+    // ---- 1. input tile + bias ----
+    const T* xb = (const T*)p.x + n * p.xs[0] + c * p.xs[1];
+    const float bias = p.b ? (float)Elem<T>::load((const T*)p.b + c) : 0.f;
+    for (int i = tid; i < p.TXH * p.TXW; i += 256) {
+        int ry = i / p.TXW, rx = i - ry * p.TXW;
+        int iy = tiy0 + ry, ix = tix0 + rx;
+        float v = 0.f;
+        if (iy >= 0 && iy < p.XH && ix >= 0 && ix < p.XW) v = (float)Elem<T>::load(xb + iy * p.xs[2] + ix * p.xs[3]) + bias;
+        sXin[i] = v;
+    }
+    __syncthreads();
+
+    const float upGain = (float)(p.up * p.up) * p.gain;
+    // ---- 2. upsampling FIR ----
+    if (sepU) {
+        // horizontal: sH[ry][ux] = sum_j sXin[ry][inx0 + j] * F(kx0 + j*up)
+        for (int i = tid; i < p.TXH * p.TUW; i += 256) {
+            int ry = i / p.TUW, rux = i - ry * p.TUW;
+            int mid = ux0 + rux + p.up - 1 - p.px0;
+            int in0 = agf_floor_div(mid, p.up), k0 = (in0 + 1) * p.up - mid - 1;
+            const float* src = sXin + ry * p.TXW + (in0 - tix0);
+            float v = 0.f;
+            if (UNR_U) {
+#pragma unroll
+                for (int j = 0; j < NTU; j++) v += src[j] * sFu[k0 + j * UP];
+            } else {
+                for (int k = k0; k < p.fuw; k += p.up, src++) v += *src * sFu[k];
+            }
+            sH[i] = v;
+        }
+        __syncthreads();
+        for (int i = tid; i < p.TUH * p.TUW; i += 256) {
+            int ruy = i / p.TUW, rux = i - ruy * p.TUW;
+            int mid = uy0 + ruy + p.up - 1 - p.py0;
+            int in0 = agf_floor_div(mid, p.up), k0 = (in0 + 1) * p.up - mid - 1;
+            const float* src = sH + (in0 - tiy0) * p.TUW + rux;
+            float v = 0.f;
+            if (UNR_U) {
+#pragma unroll
+                for (int j = 0; j < NTU; j++) v += src[j * p.TUW] * sFu[k0 + j * UP];
+            } else {
+                for (int k = k0; k < fuH; k += p.up, src += p.TUW) v += *src * sFu[k];
+            }
+            sU[i] = v * upGain;
+        }
+    } else {
+        for (int i = tid; i < p.TUH * p.TUW; i += 256) {
+            int ruy = i / p.TUW, rux = i - ruy * p.TUW;
+            int midy = uy0 + ruy + p.up - 1 - p.py0, midx = ux0 + rux + p.up - 1 - p.px0;
+            int iny0 = agf_floor_div(midy, p.up), ky0 = (iny0 + 1) * p.up - midy - 1;
+            int inx0 = agf_floor_div(midx, p.up), kx0 = (inx0 + 1) * p.up - midx - 1;
+            const float* row = sXin + (iny0 - tiy0) * p.TXW + (inx0 - tix0);
+            float v = 0.f;
+            if (UNR_U) {
+#pragma unroll
+                for (int jy = 0; jy < NTU; jy++)
+#pragma unroll
+                    for (int jx = 0; jx < NTU; jx++) v += row[jy * p.TXW + jx] * sFu[(ky0 + jy * UP) * FUW + kx0 + jx * UP];
+            } else {
+                for (int ky = ky0; ky < p.fuh; ky += p.up, row += p.TXW) {
+                    const float* src = row;
+                    for (int kx = kx0; kx < p.fuw; kx += p.up, src++) v += *src * sFu[ky * p.fuw + kx];
+                }
+            }
+            sU[i] = v * upGain;
+        }
+    }
+    __syncthreads();
+
+    // ---- 3. leaky ReLU + clamp with signs, in place on sU; samples beyond the logical upsampled image are zero ----
+    {
+        const int64_t plane64 = (int64_t)plane;
+        const int quadsPerRow = (p.TUW + 3) >> 2;
+        // core region of this tile for sign writes
+        const int coreW = (tx == p.tilesX - 1) ? p.TUW : p.TOW * p.down;
+        const int coreH = (ty == p.tilesY - 1) ? p.TUH : p.TOH * p.down;
+        for (int i = tid; i < p.TUH * quadsPerRow; i += 256) {
+            int ruy = i / quadsPerRow, qx = (i - ruy * quadsPerRow) << 2;
+            int uy = uy0 + ruy;
+            uint32_t byte = 0;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                int rux = qx + e;
+                if (rux >= p.TUW) break;
+                int ux = ux0 + rux;
+                float v = sU[ruy * p.TUW + rux];
+                if (ux >= p.UW || uy >= p.UH) { sU[ruy * p.TUW + rux] = 0.f; continue; }
+                if (p.signMode == 2) {
+                    uint32_t sxx = (uint32_t)(ux + p.sofsx), syy = (uint32_t)(uy + p.sofsy);
+                    if (sxx < (uint32_t)(p.SWB << 2) && syy < (uint32_t)p.SH) {
+                        uint32_t sb = p.s[(sxx >> 2) + (int64_t)p.SWB * (syy + (int64_t)p.SH * plane64)];
+                        sb >>= (sxx & 3) << 1;
+                        if (sb & 1) v *= p.slope;
+                        if (sb & 2) v = 0.f;
+                    }
+                } else {
+                    uint32_t code = 0;
+                    if (v < 0.f) { v *= p.slope; code = 1; }
+                    if (fabsf(v) > p.clamp) { v = clamp_mag(v, p.clamp); code = 2; }
+                    byte |= code << (e << 1);
+                }
+                sU[ruy * p.TUW + rux] = v;
+            }
+            if (p.signMode == 1 && qx < coreW && ruy < coreH) {
+                int sxx = ux0 + qx;                                  // multiple of 4: tile origins are
+                if (uy < p.SH && (sxx >> 2) < p.SWB) p.s[(sxx >> 2) + (int64_t)p.SWB * (uy + (int64_t)p.SH * plane64)] = (uint8_t)byte;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- 4. downsampling FIR + store ----
+    T* yb = (T*)p.y + n * p.ys[0] + c * p.ys[1];
+    if (sepD) {
+        for (int i = tid; i < p.TUH * p.TOW; i += 256) {
+            int ruy = i / p.TOW, rox = i - ruy * p.TOW;
+            const float* src = sU + ruy * p.TUW + rox * p.down;
+            float v = 0.f;
+            if (FDW) {
+#pragma unroll
+                for (int k = 0; k < (FDW ? FDW : 1); k++) v += src[k] * sFd[k];
+            } else {
+                for (int k = 0; k < p.fdw; k++) v += src[k] * sFd[k];
+            }
+            sD[i] = v;
+        }
+        __syncthreads();
+        for (int i = tid; i < p.TOH * p.TOW; i += 256) {
+            int roy = i / p.TOW, rox = i - roy * p.TOW;
+            int oy = oy0 + roy, ox = ox0 + rox;
+            if (oy >= p.YH || ox >= p.YW) continue;
+            const float* src = sD + (roy * p.down) * p.TOW + rox;
+            float v = 0.f;
+            if (FDW) {
+#pragma unroll
+                for (int k = 0; k < (FDW ? FDW : 1); k++) v += src[k * p.TOW] * sFd[k];
+            } else {
+                for (int k = 0; k < fdH; k++, src += p.TOW) v += *src * sFd[k];
+            }
+            Elem<T>::store(yb + oy * p.ys[2] + ox * p.ys[3], v);
+        }
+    } else {
+        for (int i = tid; i < p.TOH * p.TOW; i += 256) {
+            int roy = i / p.TOW, rox = i - roy * p.TOW;
+            int oy = oy0 + roy, ox = ox0 + rox;
+            if (oy >= p.YH || ox >= p.YW) continue;
+            const float* row = sU + (roy * p.down) * p.TUW + rox * p.down;
+            float v = 0.f;
+            if (FDW) {
+#pragma unroll 2
+                for (int ky = 0; ky < (FDW ? FDW : 1); ky++)
+#pragma unroll
+                    for (int kx = 0; kx < (FDW ? FDW : 1); kx++) v += row[ky * p.TUW + kx] * sFd[ky * FDW + kx];
+            } else {
+                for (int ky = 0; ky < p.fdh; ky++, row += p.TUW)
+                    for (int kx = 0; kx < p.fdw; kx++) v += row[kx] * sFd[ky * p.fdw + kx];
+            }
+            Elem<T>::store(yb + oy * p.ys[2] + ox * p.ys[3], v);
+        }
+    }
+}
+
 extern "C" int agf_filtered_lrelu(const void* x, const float* fu, const float* fd, const void* b, uint8_t* s, void* y, int dtype,
                                   const int32_t x_size[4], const int64_t x_stride[4],
                                   const int32_t y_size[4], const int64_t y_stride[4],
@@ -134,9 +363,72 @@ extern "C" int agf_filtered_lrelu(const void* x, const float* fu, const float* f
                                   const int32_t s_size[2], const int32_t s_ofs[2], int sign_mode,
                                   int up, int down, int px0, int py0,
                                   float gain, float slope, float clamp, int flip, void* stream) {
-    (void)x; (void)fu; (void)fd; (void)b; (void)s; (void)y; (void)dtype; (void)x_size; (void)x_stride; (void)y_size; (void)y_stride;
-    (void)fu_size; (void)fu_stride; (void)fd_size; (void)fd_stride; (void)s_size; (void)s_ofs; (void)sign_mode;
-    (void)up; (void)down; (void)px0; (void)py0; (void)gain; (void)slope; (void)clamp; (void)flip; (void)stream;
-    agf_set_error("filtered_lrelu: no specialised kernel for up=%d down=%d", up, down);
-    return AGF_ENOKERNEL;
+    // validation mirrors filtered_lrelu.cpp:15-32
+    AGF_CHECK(x && fu && fd && y, "filtered_lrelu: null pointer");
+    AGF_CHECK(dtype == AGF_F32 || dtype == AGF_F16 || dtype == AGF_BF16, "x and b must be float16, bfloat16 or float32");
+    AGF_CHECK(up >= 1 && down >= 1, "up and down must be at least 1");
+    AGF_CHECK(sign_mode >= 0 && sign_mode <= 2, "bad sign_mode");
+    AGF_CHECK(sign_mode == 0 || s, "signs pointer is null");
+    for (int i = 0; i < 4; i++) AGF_CHECK(x_size[i] >= 1 && y_size[i] >= 1, "x is empty");
+    FlrParams p;
+    p.x = x; p.fu = fu; p.fd = fd; p.b = b; p.s = s; p.y = y;
+    p.N = x_size[0]; p.C = x_size[1]; p.XH = x_size[2]; p.XW = x_size[3]; p.YH = y_size[2]; p.YW = y_size[3];
+    for (int i = 0; i < 4; i++) { p.xs[i] = x_stride[i]; p.ys[i] = y_stride[i]; }
+    // rank-1 filter: size = {taps, 0};  rank-2: {fh, fw}
+    if (fu_size[1] == 0) { p.fuw = fu_size[0]; p.fuh = 0; p.fus0 = fu_stride[0]; p.fus1 = 0; }
+    else { p.fuh = fu_size[0]; p.fuw = fu_size[1]; p.fus0 = fu_stride[0]; p.fus1 = fu_stride[1]; }
+    if (fd_size[1] == 0) { p.fdw = fd_size[0]; p.fdh = 0; p.fds0 = fd_stride[0]; p.fds1 = 0; }
+    else { p.fdh = fd_size[0]; p.fdw = fd_size[1]; p.fds0 = fd_stride[0]; p.fds1 = fd_stride[1]; }
+    const int fuH = p.fuh ? p.fuh : p.fuw, fdH = p.fdh ? p.fdh : p.fdw;
+    p.up = up; p.down = down; p.px0 = px0; p.py0 = py0;
+    p.SH = sign_mode ? s_size[0] : 0; p.SWB = sign_mode ? s_size[1] : 0;
+    p.sofsx = s_ofs ? s_ofs[0] : 0; p.sofsy = s_ofs ? s_ofs[1] : 0; p.signMode = sign_mode;
+    p.gain = gain; p.slope = slope; p.clamp = clamp; p.flip = flip ? 1 : 0;
+    // logical upsampled size implied by the output size (filtered_lrelu.cpp:57-73): yw = (uw - (fdw-1) + down-1)/down
+    p.UW = (p.YW - 1) * down + p.fdw; p.UH = (p.YH - 1) * down + fdH;
+    // tile: start from 64x32 outputs and shrink until everything fits in LDS
+    int TOW = 32, TOH = 16;
+    while (TOW / 2 >= p.YW && TOW > 4) TOW /= 2;
+    while (TOH / 2 >= p.YH && TOH > 1) TOH /= 2;
+    size_t lds = 0;
+    for (;;) {
+        p.TOW = TOW; p.TOH = TOH;
+        p.TUW = (TOW - 1) * down + p.fdw; p.TUH = (TOH - 1) * down + fdH;
+        p.TXW = (p.TUW - 1 + p.fuw - 1) / up + 2; p.TXH = (p.TUH - 1 + fuH - 1) / up + 2;
+        size_t fl = (size_t)(p.fuh ? p.fuh * p.fuw : p.fuw) + (size_t)(p.fdh ? p.fdh * p.fdw : p.fdw) + (size_t)p.TXH * p.TXW
+                  + (p.fuh ? 0 : (size_t)p.TXH * p.TUW) + (size_t)p.TUH * p.TUW + (p.fdh ? 0 : (size_t)p.TUH * p.TOW);
+        lds = fl * sizeof(float);
+        if (lds <= 150 * 1024) break;
+        if (TOH > 4 && TOH >= TOW / 2) TOH /= 2; else if (TOW > 4) TOW /= 2; else if (TOH > 1) TOH /= 2;
+        else { agf_set_error("filtered_lrelu: no specialised kernel (filters of %dx%d / %dx%d taps do not fit LDS)", fuH, p.fuw, fdH, p.fdw); return AGF_ENOKERNEL; }
+    }
+    AGF_CHECK((TOW * down) % 4 == 0 || sign_mode != 1, "filtered_lrelu: internal tile alignment");
+    p.tilesX = (p.YW + TOW - 1) / TOW; p.tilesY = (p.YH + TOH - 1) / TOH;
+    int64_t blocks = (int64_t)p.tilesX * p.tilesY * p.N * p.C;
+    AGF_CHECK(blocks < (1ll << 31), "filtered_lrelu: x is too large");
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e;
+#define FLR_LAUNCH_K(T, UP_, DN_, FU_, FD_, SU_, SD_)                                                                   \
+    {                                                                                                                   \
+        e = hipFuncSetAttribute((const void*)filtered_lrelu_kernel<T, UP_, DN_, FU_, FD_, SU_, SD_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e != hipSuccess) { agf_set_error("filtered_lrelu: cannot reserve LDS: %s", hipGetErrorString(e)); return AGF_ELAUNCH; } \
+        hipLaunchKernelGGL((filtered_lrelu_kernel<T, UP_, DN_, FU_, FD_, SU_, SD_>), dim3((unsigned)blocks), dim3(256), lds, st, p); \
+    }
+    // the StyleGAN3 configurations and their gradients (up<->down, fu<->fd) get unrolled kernels
+#define FLR_LAUNCH(T)                                                                                                   \
+    {                                                                                                                   \
+        const int su = p.fuh ? 2 : 1, sd = p.fdh ? 2 : 1;                                                               \
+        if      (up == 2 && down == 2 && p.fuw == 12 && p.fdw == 12 && su == 1 && sd == 2) FLR_LAUNCH_K(T, 2, 2, 12, 12, 1, 2) \
+        else if (up == 4 && down == 2 && p.fuw == 24 && p.fdw == 12 && su == 1 && sd == 2) FLR_LAUNCH_K(T, 4, 2, 24, 12, 1, 2) \
+        else if (up == 2 && down == 2 && p.fuw == 12 && p.fdw == 12 && su == 1 && sd == 1) FLR_LAUNCH_K(T, 2, 2, 12, 12, 1, 1) \
+        else if (up == 2 && down == 2 && p.fuw == 12 && p.fdw == 12 && su == 2 && sd == 1) FLR_LAUNCH_K(T, 2, 2, 12, 12, 2, 1) \
+        else if (up == 2 && down == 4 && p.fuw == 12 && p.fdw == 24 && su == 2 && sd == 1) FLR_LAUNCH_K(T, 2, 4, 12, 24, 2, 1) \
+        else if (up == 1 && down == 1 && p.fuw == 1 && p.fdw == 1)                         FLR_LAUNCH_K(T, 1, 1, 1, 1, 2, 2)   \
+        else                                                                               FLR_LAUNCH_K(T, 0, 0, 0, 0, 0, 0)   \
+    }
+    if (dtype == AGF_F32) FLR_LAUNCH(float) else if (dtype == AGF_F16) FLR_LAUNCH(f16_t) else FLR_LAUNCH(bf16_t)
+#undef FLR_LAUNCH
+#undef FLR_LAUNCH_K
+    AGF_LAUNCH_CHECK();
+    return AGF_OK;
 }

@@ -49,6 +49,7 @@ def _f_desc(f):
 def _native_fused(x, fu, fd, b, si, up, down, px0, px1, py0, py1, sx, sy, gain, slope, clamp, flip, write_signs):
     """Counterpart of ``_plugin.filtered_lrelu`` (reference filtered_lrelu.cpp:10-203): returns (y, so, rc)."""
     N, C, xh, xw = x.shape
+    b = b.contiguous()
     fut_w, fut_h = int(fu.shape[-1]) - 1, int(fu.shape[0]) - 1
     fdt_w, fdt_h = int(fd.shape[-1]) - 1, int(fd.shape[0]) - 1
     cw = xw * up + (px0 + px1) - fut_w
