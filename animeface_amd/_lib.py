@@ -19,7 +19,7 @@ EDGE_ZERO, EDGE_CLAMP = 0, 1
 
 _DTYPES = {torch.float32: AGF_F32, torch.float16: AGF_F16, torch.bfloat16: AGF_BF16, torch.float64: AGF_F64}
 
-EXPORTS = ['agf_abi_version', 'agf_last_error', 'agf_device_info', 'agf_upfirdn2d', 'agf_bias_act',
+EXPORTS = ['agf_abi_version', 'agf_last_error', 'agf_device_info', 'agf_upfirdn2d', 'agf_upfirdn2d_fold_border', 'agf_bias_act',
            'agf_filtered_lrelu', 'agf_filtered_lrelu_act', 'agf_conv2d_fwd', 'agf_conv2d_wgrad',
            'agf_act_bwd_reduce', 'agf_scale_dot']
 
@@ -48,6 +48,10 @@ def lib():
         L.agf_upfirdn2d.argtypes = [_vp, _vp, _vp, ctypes.c_int, _i32x4, _i64x4, _i32x2, _i64x2, _i32x4, _i64x4,
                                     ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                     ctypes.c_int, ctypes.c_float, ctypes.c_int, _vp]
+        L.agf_upfirdn2d_fold_border.restype = ctypes.c_int
+        L.agf_upfirdn2d_fold_border.argtypes = [_vp, _vp, _vp, ctypes.c_int, _i32x4, _i64x4, _i32x2, _i64x2, _i32x4, _i64x4,
+                                                ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, _vp]
         L.agf_bias_act.restype = ctypes.c_int
         L.agf_bias_act.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int64, ctypes.c_int32, ctypes.c_int64,
                                    ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp]

@@ -385,6 +385,59 @@ static int launch_typed(UpfirdnParams& p, bool dense_nchw, bool dense_nhwc, int 
     return AGF_OK;
 }
 
+// -------------------------------------------------------------------------------------------------
+// fold_border: the adjoint of the clamp-to-edge mode.  forward(clamp) == forward(zero) on the replicate-extended input,
+// so its adjoint is the zero-mode adjoint evaluated on the extended domain with the extension strips folded (summed)
+// onto the edge pixels.  The interior term is what the ordinary (fast) kernel already wrote into `y`; this kernel adds
+// the missing virtual positions, for the border pixels only:  y[oy][ox] += sum over (vy,vx) in S(oy) x S(ox) \ {(oy,ox)}
+// of G(vy,vx), with S(o) = {o} U {-r..-1} if o == 0 U {size..size+r-1} if o == size-1, and G the plain gather formula.
+template <class T>
+__global__ void __launch_bounds__(256) upfirdn2d_fold_border(UpfirdnParams p, int rx, int ry) {
+    typedef typename Elem<T>::acc_t acc_t;
+    __shared__ float sf[MAX_FILTER_TAPS];
+    stage_filter<256>(p, sf);
+    __syncthreads();
+    const int per = 2 * p.OW + 2 * (p.OH > 2 ? p.OH - 2 : 0);           // border pixels of one plane
+    const int64_t total = (int64_t)p.N * p.C * per;
+    const bool cl = (p.ys[1] == 1 && p.C > 1);
+    for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+        int n, c, b;
+        int64_t r = id;
+        if (cl) { c = (int)(r % p.C); r /= p.C; b = (int)(r % per); n = (int)(r / per); }
+        else    { b = (int)(r % per); r /= per; c = (int)(r % p.C); n = (int)(r / p.C); }
+        int oy, ox;
+        if (b < p.OW) { oy = 0; ox = b; }
+        else if (b < 2 * p.OW) { oy = p.OH - 1; ox = b - p.OW; }
+        else { int t = b - 2 * p.OW; oy = 1 + (t >> 1); ox = (t & 1) ? p.OW - 1 : 0; }
+        if (p.OH == 1 && b >= p.OW) continue;                             // single row: listed once
+        const T* xb = (const T*)p.x + n * p.xs[0] + c * p.xs[1];
+        acc_t v = 0;
+        // S(oy) x S(ox): iterate virtual rows / cols; skip the interior term (vy,vx) == (oy,ox)
+        const int y0 = (oy == 0) ? -ry : oy, y1 = (oy == p.OH - 1) ? p.OH - 1 + ry : oy;
+        const int x0 = (ox == 0) ? -rx : ox, x1 = (ox == p.OW - 1) ? p.OW - 1 + rx : ox;
+        for (int vy = y0; vy <= y1; vy++) {
+            if (vy > 0 && vy < p.OH - 1 && vy != oy) continue;
+            if (vy >= 0 && vy <= p.OH - 1 && vy != oy) continue;          // real rows other than oy belong to other pixels
+            for (int vx = x0; vx <= x1; vx++) {
+                if (vx >= 0 && vx <= p.OW - 1 && vx != ox) continue;
+                if (vy == oy && vx == ox) continue;
+                int midy = vy * p.downy + p.upy - 1 - p.pady0, midx = vx * p.downx + p.upx - 1 - p.padx0;
+                int iny0 = agf_floor_div(midy, p.upy), inx0 = agf_floor_div(midx, p.upx);
+                int ky0 = (iny0 + 1) * p.upy - midy - 1, kx0 = (inx0 + 1) * p.upx - midx - 1;
+                for (int ky = ky0, iy = iny0; ky < p.fh; ky += p.upy, iy++) {
+                    if (iy < 0 || iy >= p.H) continue;
+                    for (int kx = kx0, ix = inx0; kx < p.fw; kx += p.upx, ix++) {
+                        if (ix < 0 || ix >= p.W) continue;
+                        v += (acc_t)Elem<T>::load(xb + iy * p.xs[2] + ix * p.xs[3]) * (acc_t)sf[ky * p.fw + kx];
+                    }
+                }
+            }
+        }
+        T* yp = (T*)p.y + n * p.ys[0] + c * p.ys[1] + oy * p.ys[2] + ox * p.ys[3];
+        Elem<T>::store(yp, (acc_t)Elem<T>::load(yp) + v * (acc_t)p.gain);
+    }
+}
+
 extern "C" int agf_upfirdn2d(const void* x, const float* f, void* y, int dtype,
                              const int32_t in_size[4], const int64_t in_stride[4],
                              const int32_t f_size[2], const int64_t f_stride[2],
@@ -434,6 +487,40 @@ extern "C" int agf_upfirdn2d(const void* x, const float* f, void* y, int dtype,
         default:       rc = launch_typed<double>(p, nchw, nhwc, 0, st); break;
     }
     if (rc != AGF_OK) return rc;
+    AGF_LAUNCH_CHECK();
+    return AGF_OK;
+}
+
+extern "C" int agf_upfirdn2d_fold_border(const void* x, const float* f, void* y, int dtype,
+                                         const int32_t in_size[4], const int64_t in_stride[4],
+                                         const int32_t f_size[2], const int64_t f_stride[2],
+                                         const int32_t out_size[4], const int64_t out_stride[4],
+                                         int upx, int upy, int downx, int downy, int padx0, int pady0,
+                                         int flip, float gain, int rx, int ry, void* stream) {
+    AGF_CHECK(x && f && y, "upfirdn2d_fold_border: null pointer");
+    AGF_CHECK(dtype >= AGF_F32 && dtype <= AGF_F64, "upfirdn2d_fold_border: unsupported dtype %d", dtype);
+    AGF_CHECK(rx >= 0 && ry >= 0 && rx <= 64 && ry <= 64, "upfirdn2d_fold_border: bad fold radius");
+    AGF_CHECK((int64_t)f_size[0] * f_size[1] <= MAX_FILTER_TAPS, "f is too large");
+    UpfirdnParams p;
+    p.x = x; p.f = f; p.y = y;
+    p.N = in_size[0]; p.C = in_size[1]; p.H = in_size[2]; p.W = in_size[3];
+    p.OH = out_size[2]; p.OW = out_size[3];
+    for (int i = 0; i < 4; i++) { p.xs[i] = in_stride[i]; p.ys[i] = out_stride[i]; }
+    p.fh = f_size[0]; p.fw = f_size[1]; p.fsy = f_stride[0]; p.fsx = f_stride[1];
+    p.upx = upx; p.upy = upy; p.downx = downx; p.downy = downy; p.padx0 = padx0; p.pady0 = pady0;
+    p.flip = flip ? 1 : 0; p.clamp_edge = 0; p.gain = gain;
+    p.tilesX = p.tilesY = p.tileInW = p.tileInH = 0; p.cg_shift = -1;
+    const int per = 2 * p.OW + 2 * (p.OH > 2 ? p.OH - 2 : 0);
+    int64_t total = (int64_t)p.N * p.C * per;
+    int64_t blocks = agf_ceil_div(total, 256);
+    if (blocks > 65536) blocks = 65536;
+    hipStream_t st = (hipStream_t)stream;
+    switch (dtype) {
+        case AGF_F32:  hipLaunchKernelGGL((upfirdn2d_fold_border<float>), dim3((unsigned)blocks), dim3(256), 0, st, p, rx, ry); break;
+        case AGF_F16:  hipLaunchKernelGGL((upfirdn2d_fold_border<f16_t>), dim3((unsigned)blocks), dim3(256), 0, st, p, rx, ry); break;
+        case AGF_BF16: hipLaunchKernelGGL((upfirdn2d_fold_border<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, st, p, rx, ry); break;
+        default:       hipLaunchKernelGGL((upfirdn2d_fold_border<double>), dim3((unsigned)blocks), dim3(256), 0, st, p, rx, ry); break;
+    }
     AGF_LAUNCH_CHECK();
     return AGF_OK;
 }

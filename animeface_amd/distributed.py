@@ -26,8 +26,10 @@ def init_distributed():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if os.environ.get('AGF_SINGLE_DEVICE') == '1':
+        local_rank = 0                      # test hook: several ranks share GPU 0 (needs the gloo backend)
     if world > 1 and not dist.is_initialized():
-        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        backend = os.environ.get('AGF_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         if torch.cuda.is_available():
             torch.cuda.set_device(local_rank)
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')

@@ -135,10 +135,13 @@ class _ConvFwd(torch.autograd.Function):
                 dx = _ConvFwd.apply(dy, flip_transpose(w), s_out, None)
             else:
                 t = _ConvFwd.apply(dy, flip_transpose(w), s_out, None)           # gradient w.r.t. (x * s_in)
-                if ctx.needs_input_grad[0]:
-                    dx = t * s_in[:, :, None, None].to(t.dtype)
-                if ctx.needs_input_grad[2]:
-                    ds_in = (x.float() * t.float()).sum((2, 3))
+                if not torch.is_grad_enabled() and x.shape[1] % 8 == 0:
+                    dx, ds_in = scale_dot_raw(x, t, s_in, want_dx=ctx.needs_input_grad[0])   # one fused pass
+                else:
+                    if ctx.needs_input_grad[0]:
+                        dx = t * s_in[:, :, None, None].to(t.dtype)
+                    if ctx.needs_input_grad[2]:
+                        ds_in = (x.float() * t.float()).sum((2, 3))
         if ctx.needs_input_grad[1]:
             dw = _ConvWgrad.apply(x, dy, s_in, s_out, w.shape[2]).to(w.dtype)
         if s_out is not None and ctx.needs_input_grad[3]:
@@ -317,7 +320,7 @@ class _FusedConv(torch.autograd.Function):
                 g = dy * gain if gain != 1 else dy
             w = weight * coef
             if need_b and bias is not None:
-                db = g.float().sum((0, 2, 3)).to(bias.dtype)
+                db = g.sum((0, 2, 3), dtype=torch.float32).to(bias.dtype)
             if need_r:
                 dres = g
             if need_x:
@@ -339,7 +342,7 @@ class _FusedConv(torch.autograd.Function):
             assert s_out is None, 'linear epilogue with a demodulation scale is not used by the networks'
             g = dy * gain if gain != 1 else dy
             if need_b and bias is not None:
-                db = g.float().sum((0, 2, 3)).to(bias.dtype)
+                db = g.sum((0, 2, 3), dtype=torch.float32).to(bias.dtype)
         if need_r:
             dres = g
         if need_x or (s_in is not None and need_si):

@@ -162,12 +162,22 @@ def _upfirdn2d_hip(up=1, down=1, padding=0, flip_filter=False, gain=1, edge='zer
                 if edge == 'zero':
                     dx = _upfirdn2d_hip(up=down, down=up, padding=p, flip_filter=(not flip_filter), gain=gain).apply(dy, f)
                 else:
-                    # adjoint on the replicate-extended domain, then fold the extension back onto the edges
                     rx = (max(padx0, padx1, 0) + upx - 1) // upx + 1
                     ry = (max(pady0, pady1, 0) + upy - 1) // upy + 1
-                    pe = [p[0] + rx * upx, p[1] + rx * upx, p[2] + ry * upy, p[3] + ry * upy]
-                    g = _upfirdn2d_hip(up=down, down=up, padding=pe, flip_filter=(not flip_filter), gain=gain).apply(dy, f)
-                    dx = _fold_edges(g, rx, ry)
+                    if torch.is_grad_enabled() or f.ndim != 2:
+                        # differentiable form: adjoint on the replicate-extended domain, then fold the extension onto the edges
+                        pe = [p[0] + rx * upx, p[1] + rx * upx, p[2] + ry * upy, p[3] + ry * upy]
+                        g = _upfirdn2d_hip(up=down, down=up, padding=pe, flip_filter=(not flip_filter), gain=gain).apply(dy, f)
+                        dx = _fold_edges(g, rx, ry)
+                    else:
+                        # fast form: ordinary zero-mode adjoint + a border-only kernel that adds the folded extension terms
+                        dx = _launch(dy, f, downx, downy, upx, upy, p[0], p[1], p[2], p[3], not flip_filter, gain, 'zero')
+                        rc = _lib.lib().agf_upfirdn2d_fold_border(
+                            _lib.ptr(dy), _lib.ptr(f), _lib.ptr(dx), _lib.dtype_code(dy),
+                            _lib.sizes4(dy), _lib.strides4(dy), _lib._i32x2(*f.shape), _lib._i64x2(*f.stride()),
+                            _lib.sizes4(dx), _lib.strides4(dx), downx, downy, upx, upy, p[0], p[2],
+                            int(not flip_filter), float(gain), rx, ry, _lib.stream_ptr(dy))
+                        _lib.check(rc, 'upfirdn2d_fold_border')
             assert not ctx.needs_input_grad[1]
             return dx, None
 

@@ -62,6 +62,16 @@ int agf_upfirdn2d(const void* x, const float* f, void* y, int dtype,
                   int upx, int upy, int downx, int downy, int padx0, int pady0,
                   int flip, float gain, int edge_mode, void* stream);
 
+/* Adjoint helper of AGF_EDGE_CLAMP (no reference counterpart: the reference's bilinear upsample is ATen's
+ * upsample_bilinear2d and its backward).  After agf_upfirdn2d wrote the zero-mode adjoint into y, this adds, for the
+ * border pixels of y only, the terms of the rx / ry replicate-extension columns / rows folded onto the edges. */
+int agf_upfirdn2d_fold_border(const void* x, const float* f, void* y, int dtype,
+                              const int32_t in_size[4], const int64_t in_stride[4],
+                              const int32_t f_size[2], const int64_t f_stride[2],
+                              const int32_t out_size[4], const int64_t out_stride[4],
+                              int upx, int upy, int downx, int downy, int padx0, int pady0,
+                              int flip, float gain, int rx, int ry, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * bias_act  --  replaces  Tensor bias_act(x, b, xref, yref, dy, grad, dim, act, alpha, gain, clamp)
  *               bias_act.cpp:26-83 (pybind at :90), kernel bias_act.cu:17-141.
