@@ -364,7 +364,7 @@ def conv2d_act(x, weight, bias=None, s_in=None, s_out=None, noise=None, alpha=0.
     ``fused=False`` evaluates the same expression with the separately differentiable ops (any-order gradients)."""
     from ...stylegan3_ops import bias_act as _ba
     Cout, Cin = weight.shape[0], weight.shape[1]
-    if fused and Cout % 8 == 0 and (act == 'linear' or gain == 1.0):
+    if fused and Cout % 8 == 0 and (act == 'linear' or gain == 1.0) and not (act == 'linear' and s_out is not None):
         if x.dtype == torch.bfloat16 and Cin % 8:
             x = _pad_channels(x, 8, 1).contiguous(memory_format=torch.channels_last)
             weight = _pad_channels(weight, 8, 1)

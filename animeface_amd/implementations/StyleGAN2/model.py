@@ -161,19 +161,29 @@ class ModulatedConv2d(nn.Module):
         self.coef = gain / (self.weight[0].numel() ** 0.5)
 
     def scales(self, y):
-        """style scale s [B,Cin] and demodulation d [B,Cout] (fp32)."""
+        """style scale s [B,Cin] and demodulation d [B,Cout] (fp32).
+        sum_{ci,kh,kw} (W*coef*s)^2  ==  coef^2 * (s^2 @ (sum_{kh,kw} W^2)^T): no scaled copy of the weights is made."""
         s = self.affine(y) + 1
-        w = self.weight * self.coef
         d = None
         if self.demod:
-            # sum_{ci,kh,kw} (w*s)^2  ==  s^2 @ (sum_{kh,kw} w^2)^T
-            d = torch.rsqrt(s.square() @ w.square().sum((2, 3)).t() + 1e-4)
-        return w, s, d
+            wsq = self.weight.square().sum((2, 3))
+            d = torch.rsqrt((s.square() @ wsq.t()) * (self.coef * self.coef) + 1e-4)
+        return s, d
 
     def forward(self, x, y):
-        w, s, d = self.scales(y)
-        out = conv2d(x, w, s, d)
-        return bias_act.bias_act(out, self.bias.reshape(-1).to(out.dtype))
+        """conv + bias (no activation): the reference's ModulatedConv2d.forward; used by ToImage (k=1, no demodulation)."""
+        s, d = self.scales(y)
+        Cout = self.out_channels
+        w, b = self.weight, self.bias.reshape(-1)
+        pad = (-Cout) % 8
+        if pad and x.dtype == torch.bfloat16:
+            # the MFMA kernel wants Cout % 8 == 0: zero-pad the output channels (RGB: 3 -> 8) and slice them off again
+            w = F.pad(w, [0, 0, 0, 0, 0, 0, 0, pad])
+            b = F.pad(b, [0, pad])
+            if d is not None:
+                d = F.pad(d, [0, pad], value=1.0)
+        out = conv2d_act(x, w, b, s, d, None, fused=FUSED_EPILOGUE and getattr(self, 'fused_epilogue', True), coef=self.coef, act='linear')
+        return out[:, :Cout] if pad and x.dtype == torch.bfloat16 else out
 
 
 class Blur2d(nn.Module):
@@ -209,7 +219,7 @@ class StyleBlock(nn.Module):
             if isinstance(m, ModulatedConv2d) and i + 2 < len(mods) + 0 and isinstance(mods[i + 1], InjectNoise) \
                     and isinstance(mods[i + 2], nn.LeakyReLU):
                 # modconv -> +bias -> +noise -> lrelu, noise drawn exactly where the reference draws it
-                _w, s, d = m.scales(y)
+                s, d = m.scales(y)
                 noise = InjectNoise.draw(x[:, :1])
                 x = conv2d_act(x, m.weight, m.bias.reshape(-1), s, d, noise, alpha=mods[i + 2].negative_slope,
                                fused=FUSED_EPILOGUE and getattr(self, 'fused_epilogue', True), coef=m.coef)
@@ -365,7 +375,7 @@ class Generator(nn.Module):
     def set_fused_epilogue(self, enabled):
         """``False`` keeps every op separately differentiable (needed by the path-length penalty's double backward)."""
         for m in self.modules():
-            if isinstance(m, StyleBlock):
+            if isinstance(m, (StyleBlock, ModulatedConv2d)):
                 m.fused_epilogue = enabled
         return self
 
