@@ -53,8 +53,14 @@ struct ConvParams {
     float alpha, gain;
 };
 
-template <int KS, int MT, bool IN_SCALE, int KC, int MINW>
-__global__ void __launch_bounds__(256, MINW) conv2d_fwd_kernel(ConvParams p) {
+// NWN = waves along the pixel axis (2 or 4): block = 2 x NWN waves, tile = (64*MT) co x (128*NWN) pixels.
+//   <MT=1, NWN=2>: 64 co x 256 px, 4 waves, 73 KB LDS -> two blocks per CU            (default)
+//   <MT=2, NWN=4>: 128 co x 512 px, 8 waves (2 per SIMD), 141 KB LDS, one block per CU: half the staging traffic and
+//                  0.75 instead of 1.25 LDS fragment reads per MFMA (large maps with many channels)
+// PMAX = largest patch (pixels incl. halo) the launcher will use with this instantiation (sizes the staging registers).
+template <int KS, int MT, bool IN_SCALE, int KC, int NWN, int PMAX>
+__global__ void __launch_bounds__(128 * NWN) conv2d_fwd_kernel(ConvParams p) {
+    constexpr int NTHR = 128 * NWN;
     // KC = channels per K chunk (16 or 32); LDS row pitch = KC + 8 elements (48 / 80 bytes: conflict-free ds_read_b128)
     constexpr int PITCH = KC + 8;
     constexpr int TAPS = KS * KS;
@@ -80,7 +86,7 @@ __global__ void __launch_bounds__(256, MINW) conv2d_fwd_kernel(ConvParams p) {
     const int P = p.TI * PH * PW;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / NWN, wn = wave % NWN;
     const int l31 = lane & 31, lhi = lane >> 5;
 
     // per-lane LDS base (in elements) of the B fragment of each of the wave's 4 pixel sub-tiles, tap (0,0), k-step 0
@@ -106,15 +112,15 @@ __global__ void __launch_bounds__(256, MINW) conv2d_fwd_kernel(ConvParams p) {
     // ---- software pipeline: the global loads of chunk ch+1 are issued into registers before the MFMAs of chunk ch
     //      and written to LDS after them, so HBM/L2 latency hides under the matrix work (one LDS buffer) ----
     constexpr int WTOT = TAPS * BM * (KC / 8);
-    constexpr int WV = (WTOT + 255) / 256;                // weight vectors per thread per chunk (18 for 3x3, MT=2, KC=32)
-    constexpr int XV = (KS == 3 ? 576 : 256) * (KC / 8) / 256;   // patch vectors per thread: P <= 576 (3x3), 256 (1x1)
+    constexpr int WV = (WTOT + NTHR - 1) / NTHR;                // weight vectors per thread per chunk (18 for 3x3, MT=2, KC=32)
+    constexpr int XV = (PMAX * (KC / 8) + NTHR - 1) / NTHR;   // patch vectors per thread: P <= 576 (3x3), 256 (1x1)
     u32x4 wreg[WV], xreg[XV];
     // per-thread patch geometry is chunk-invariant: precompute global offsets (or -1) once
     int xoff[XV];                                          // element offset of the vector at channel 0, -1 = zero fill
     int xn[XV];
 #pragma unroll
     for (int i = 0; i < XV; i++) {
-        int v = tid + i * 256;
+        int v = tid + i * NTHR;
         int cv = v % (KC / 8), pix = v / (KC / 8);
         xoff[i] = -1; xn[i] = 0;
         if (pix < P) {
@@ -130,7 +136,7 @@ __global__ void __launch_bounds__(256, MINW) conv2d_fwd_kernel(ConvParams p) {
     auto load_chunk = [&](int c0) {
 #pragma unroll
         for (int i = 0; i < WV; i++) {
-            int v = tid + i * 256;
+            int v = tid + i * NTHR;
             constexpr int VPR = KC / 8;                   // 16-byte vectors per row
             int cv = v % VPR, row = v / VPR;
             int tap = row / BM, co = row - tap * BM;
@@ -141,7 +147,7 @@ __global__ void __launch_bounds__(256, MINW) conv2d_fwd_kernel(ConvParams p) {
         }
 #pragma unroll
         for (int i = 0; i < XV; i++) {
-            int cv = (tid + i * 256) % (KC / 8), gc = c0 + cv * 8;
+            int cv = (tid + i * NTHR) % (KC / 8), gc = c0 + cv * 8;
             u32x4 val = {0u, 0u, 0u, 0u};
             if (xoff[i] >= 0 && gc < p.Cin) {
                 val = *(const u32x4*)(p.x + (int64_t)xoff[i] * p.Cin + gc);
@@ -161,12 +167,12 @@ __global__ void __launch_bounds__(256, MINW) conv2d_fwd_kernel(ConvParams p) {
     auto store_chunk = [&]() {
 #pragma unroll
         for (int i = 0; i < WV; i++) {
-            int v = tid + i * 256;
-            if (WTOT % 256 == 0 || v < WTOT) *(u32x4*)(sW + (v / (KC / 8)) * PITCH + (v % (KC / 8)) * 8) = wreg[i];
+            int v = tid + i * NTHR;
+            if (WTOT % NTHR == 0 || v < WTOT) *(u32x4*)(sW + (v / (KC / 8)) * PITCH + (v % (KC / 8)) * 8) = wreg[i];
         }
 #pragma unroll
         for (int i = 0; i < XV; i++) {
-            int v = tid + i * 256;
+            int v = tid + i * NTHR;
             if ((v / (KC / 8)) < P) *(u32x4*)(sX + (v / (KC / 8)) * PITCH + (v % (KC / 8)) * 8) = xreg[i];
         }
     };
@@ -508,21 +514,20 @@ __global__ void __launch_bounds__(256) conv2d_wgrad_f32_kernel(WgradF32Params p)
 
 static int pow2_ceil(int v) { int r = 1; while (r < v) r <<= 1; return r; }
 
-template <int KS, int MT, bool SC, int KC, int MINW>
+template <int KS, int MT, bool SC, int KC, int NWN, int PMAX>
 static int launch_fwd_v(const ConvParams& p, hipStream_t st) {
     constexpr int TAPS = KS * KS, HALO = KS / 2, BM = 64 * MT, PITCH = KC + 8;
     const int P = p.TI * (p.TH + 2 * HALO) * (p.TW + 2 * HALO);
+    if (P > PMAX) { agf_set_error("conv2d_fwd: internal patch %d exceeds %d", P, PMAX); return AGF_ENOKERNEL; }
     size_t lds = (size_t)(TAPS * BM + P) * PITCH * sizeof(bf16_t);
     if (lds > 160 * 1024) { agf_set_error("conv2d_fwd: tile needs %zu bytes of LDS", lds); return AGF_ENOKERNEL; }
     const int slots = ((p.pixTiles + 7) / 8) * p.tilesCo;
-    dim3 grid((unsigned)(slots * 8)), block(256);
-    hipError_t e = hipFuncSetAttribute((const void*)conv2d_fwd_kernel<KS, MT, SC, KC, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    dim3 grid((unsigned)(slots * 8)), block(128 * NWN);
+    hipError_t e = hipFuncSetAttribute((const void*)conv2d_fwd_kernel<KS, MT, SC, KC, NWN, PMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { agf_set_error("conv2d_fwd: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e)); return AGF_ELAUNCH; }
-    hipLaunchKernelGGL((conv2d_fwd_kernel<KS, MT, SC, KC, MINW>), grid, block, lds, st, p);
+    hipLaunchKernelGGL((conv2d_fwd_kernel<KS, MT, SC, KC, NWN, PMAX>), grid, block, lds, st, p);
     return AGF_OK;
 }
-
-static int g_fwd_variant = -1;     // AGF_CONV_VARIANT: 0 = KC32 (1 block/CU at MT=2), 1 = KC16 + 2 blocks/CU
 
 template <int KS, bool SC, int CINP, int BM>
 static int launch_fwd_ws(const ConvParams& p0, hipStream_t st) {
@@ -557,11 +562,8 @@ static int launch_fwd(const ConvParams& p, hipStream_t st) {
         else                             rc = p.in_scale ? launch_fwd_ws<3, true, 64, 32>(p, st) : launch_fwd_ws<3, false, 64, 32>(p, st);
         if (rc != AGF_ENOKERNEL) return rc;
     }
-    if (g_fwd_variant < 0) { const char* e = getenv("AGF_CONV_VARIANT"); g_fwd_variant = e ? atoi(e) : 0; }
-    if (g_fwd_variant == 1) {
-        return p.in_scale ? launch_fwd_v<KS, MT, true, 16, 2>(p, st) : launch_fwd_v<KS, MT, false, 16, 2>(p, st);
-    }
-    return p.in_scale ? launch_fwd_v<KS, MT, true, 32, 1>(p, st) : launch_fwd_v<KS, MT, false, 32, 1>(p, st);
+    if (MT == 2) return p.in_scale ? launch_fwd_v<KS, 2, true, 16, 4, 612>(p, st) : launch_fwd_v<KS, 2, false, 16, 4, 612>(p, st);
+    return p.in_scale ? launch_fwd_v<KS, 1, true, 32, 2, (KS == 3 ? 576 : 256)>(p, st) : launch_fwd_v<KS, 1, false, 32, 2, (KS == 3 ? 576 : 256)>(p, st);
 }
 
 extern "C" int agf_conv2d_fwd(const void* x, const void* w, void* y,
@@ -598,17 +600,23 @@ extern "C" int agf_conv2d_fwd(const void* x, const void* w, void* y,
     p.in_scale = in_scale; p.out_scale = out_scale; p.bias = bias; p.noise = noise; p.residual = (const bf16_t*)residual;
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
     p.act = act; p.alpha = alpha; p.gain = act_gain;
+    // Two tilings.  Large: 128 co x 512 px (16x32 pixel tile), 8 waves -- when the map is at least 16x32, there are at
+    // least 128 output channels and the grid still fills the chip (>= 384 blocks).  Default: 64 co x 256 px, 4 waves.
+    int MT = 1;
+    {
+        const char* e = getenv("AGF_CONV_MT");
+        int forced = e ? atoi(e) : 0;
+        int64_t bigBlocks = (int64_t)N * ((H + 15) / 16) * ((W + 31) / 32) * ((Cout + 127) / 128);
+        if (forced == 2 || (forced != 1 && ksize == 3 && W >= 32 && H >= 16 && Cout >= 128 && Cin >= 64 && bigBlocks >= 384)) MT = 2;
+        if (MT == 2 && !(W >= 32 && H >= 16)) MT = 1;
+    }
+    const int blockPix = MT == 2 ? 512 : BLOCK_PIX;
     p.TW = pow2_ceil(W) < 32 ? pow2_ceil(W) : 32;
     int th = pow2_ceil(H);
-    p.TH = th < BLOCK_PIX / p.TW ? th : BLOCK_PIX / p.TW;
-    p.TI = BLOCK_PIX / (p.TW * p.TH);
+    p.TH = th < blockPix / p.TW ? th : blockPix / p.TW;
+    p.TI = blockPix / (p.TW * p.TH);
     p.tilesW = (W + p.TW - 1) / p.TW; p.tilesH = (H + p.TH - 1) / p.TH; p.tilesN = (N + p.TI - 1) / p.TI;
     p.pixTiles = p.tilesW * p.tilesH * p.tilesN;
-    // MT = 1 (64-channel co tile, 73 KB of LDS) keeps TWO blocks resident per CU, so one block's staging overlaps the
-    // other's MFMAs; measured faster than MT = 2 (one 119 KB block per CU) on every layer of the 256x256 networks.
-    int MT = 1;
-    { const char* e = getenv("AGF_CONV_MT"); if (e) MT = atoi(e); }
-    if (MT == 2 && (int64_t)p.pixTiles * ((Cout + 127) / 128) < 512) MT = 1;     // small maps: more, smaller blocks
     p.tilesCo = (Cout + 64 * MT - 1) / (64 * MT);
     hipStream_t st = (hipStream_t)stream;
     int rc;
