@@ -27,6 +27,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define BLOCK_PIX 256
 
+static __device__ __forceinline__ u32x4 scale_vec8_reg(u32x4 val, f32x4 s0, f32x4 s1) {
+    float a0, a1;
+    Pack16<bf16_t>::unpack(val.x, a0, a1); val.x = Pack16<bf16_t>::pack(a0 * s0.x, a1 * s0.y);
+    Pack16<bf16_t>::unpack(val.y, a0, a1); val.y = Pack16<bf16_t>::pack(a0 * s0.z, a1 * s0.w);
+    Pack16<bf16_t>::unpack(val.z, a0, a1); val.z = Pack16<bf16_t>::pack(a0 * s1.x, a1 * s1.y);
+    Pack16<bf16_t>::unpack(val.w, a0, a1); val.w = Pack16<bf16_t>::pack(a0 * s1.z, a1 * s1.w);
+    return val;
+}
+
 static __device__ __forceinline__ u32x4 scale_vec8(u32x4 val, const float* sc) {
     f32x4 s0 = *(const f32x4*)sc, s1 = *(const f32x4*)(sc + 4);
     float a0, a1;
@@ -51,6 +60,7 @@ struct ConvParams {
     int tilesW, tilesH, tilesN, tilesCo, pixTiles;
     int act;                  // 1 linear, 3 lrelu
     float alpha, gain;
+    int hoist;                // A/B switch: hoist the style-scale loads out of the per-vector staging loop
 };
 
 // NWN = waves along the pixel axis (2 or 4): block = 2 x NWN waves, tile = (64*MT) co x (128*NWN) pixels.
@@ -59,7 +69,7 @@ struct ConvParams {
 //                  0.75 instead of 1.25 LDS fragment reads per MFMA (large maps with many channels)
 // PMAX = largest patch (pixels incl. halo) the launcher will use with this instantiation (sizes the staging registers).
 template <int KS, int MT, bool IN_SCALE, int KC, int NWN, int PMAX>
-__global__ void __launch_bounds__(128 * NWN) conv2d_fwd_kernel(ConvParams p) {
+__global__ void __launch_bounds__(128 * NWN, 2) conv2d_fwd_kernel(ConvParams p) {   // 2 waves per SIMD: two 4-wave blocks or one 8-wave block per CU
     constexpr int NTHR = 128 * NWN;
     // KC = channels per K chunk (16 or 32); LDS row pitch = KC + 8 elements (48 / 80 bytes: conflict-free ds_read_b128)
     constexpr int PITCH = KC + 8;
@@ -145,6 +155,17 @@ __global__ void __launch_bounds__(128 * NWN) conv2d_fwd_kernel(ConvParams p) {
             if (v < WTOT && gco < p.Cout && gc < p.Cin) val = *(const u32x4*)(p.w + ((int64_t)gco * TAPS + tap) * p.Cin + gc);
             wreg[i] = val;
         }
+        // style scale: when the tile lies in ONE image (TI == 1) every vector of this thread shares (n, channel group),
+        // so the 8 scale values are loaded once per chunk instead of once per vector
+        f32x4 sc0 = {1.f, 1.f, 1.f, 1.f}, sc1 = sc0;
+        const bool oneImage = p.hoist && p.TI == 1 && (NTHR % (KC / 8)) == 0;
+        if (IN_SCALE && oneImage) {
+            const int gcs = c0 + (tid % (KC / 8)) * 8;
+            if (n0 < p.N && gcs < p.Cin) {
+                const float* sc = p.in_scale + (int64_t)n0 * p.Cin + gcs;
+                sc0 = *(const f32x4*)sc; sc1 = *(const f32x4*)(sc + 4);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < XV; i++) {
             int cv = (tid + i * NTHR) % (KC / 8), gc = c0 + cv * 8;
@@ -152,13 +173,8 @@ __global__ void __launch_bounds__(128 * NWN) conv2d_fwd_kernel(ConvParams p) {
             if (xoff[i] >= 0 && gc < p.Cin) {
                 val = *(const u32x4*)(p.x + (int64_t)xoff[i] * p.Cin + gc);
                 if (IN_SCALE) {
-                    const float* sc = p.in_scale + (int64_t)xn[i] * p.Cin + gc;
-                    f32x4 s0 = *(const f32x4*)sc, s1 = *(const f32x4*)(sc + 4);
-                    float a0, a1;
-                    Pack16<bf16_t>::unpack(val.x, a0, a1); val.x = Pack16<bf16_t>::pack(a0 * s0.x, a1 * s0.y);
-                    Pack16<bf16_t>::unpack(val.y, a0, a1); val.y = Pack16<bf16_t>::pack(a0 * s0.z, a1 * s0.w);
-                    Pack16<bf16_t>::unpack(val.z, a0, a1); val.z = Pack16<bf16_t>::pack(a0 * s1.x, a1 * s1.y);
-                    Pack16<bf16_t>::unpack(val.w, a0, a1); val.w = Pack16<bf16_t>::pack(a0 * s1.z, a1 * s1.w);
+                    if (oneImage) val = scale_vec8_reg(val, sc0, sc1);
+                    else val = scale_vec8(val, p.in_scale + (int64_t)xn[i] * p.Cin + gc);
                 }
             }
             xreg[i] = val;
@@ -329,6 +345,14 @@ __global__ void __launch_bounds__(256) conv2d_fwd_ws_kernel(ConvParams p) {
         const int th = tq % p.tilesH;
         const int tn = tq / p.tilesH;
         const int n0 = tn * p.TI, h0 = th * p.TH, w0 = tw * p.TW;
+        f32x4 sc0 = {1.f, 1.f, 1.f, 1.f}, sc1 = sc0;            // TI == 1 here: one (n, channel group) per thread per tile
+        if (IN_SCALE) {
+            const int gcs = (tid % VPR) * 8;
+            if (n0 < p.N && gcs < p.Cin) {
+                const float* sc = p.in_scale + (int64_t)n0 * p.Cin + gcs;
+                sc0 = *(const f32x4*)sc; sc1 = *(const f32x4*)(sc + 4);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < XV; i++) {
             const int gc = ((tid + i * 256) % VPR) * 8;
@@ -337,7 +361,7 @@ __global__ void __launch_bounds__(256) conv2d_fwd_ws_kernel(ConvParams p) {
                 int n = n0 + (xrel[i] >> 20), h = h0 + ((xrel[i] >> 10) & 1023) - 8, w = w0 + (xrel[i] & 1023) - 8;
                 if (n < p.N && h >= 0 && h < p.H && w >= 0 && w < p.W && gc < p.Cin) {
                     val = *(const u32x4*)(p.x + (((int64_t)n * p.H + h) * p.W + w) * p.Cin + gc);
-                    if (IN_SCALE) val = scale_vec8(val, p.in_scale + (int64_t)n * p.Cin + gc);
+                    if (IN_SCALE) val = scale_vec8_reg(val, sc0, sc1);
                 }
             }
             xreg[i] = val;
@@ -351,12 +375,44 @@ __global__ void __launch_bounds__(256) conv2d_fwd_ws_kernel(ConvParams p) {
         }
     };
 
+    f32x4 ebias[4];
+#pragma unroll
+    for (int rg = 0; rg < 4; rg++) {
+        int co = co0 + wm * 32 + rg * 8 + lhi * 4;
+        f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        ebias[rg] = (p.bias && co < p.Cout) ? *(const f32x4*)(p.bias + co) : zero;
+    }
     int pt = worker;
     if (pt < p.pixTiles) { load_patch(pt); store_patch(); }
     __syncthreads();
     for (; pt < p.pixTiles; pt += workers) {
         const bool more = pt + workers < p.pixTiles;
         if (more) load_patch(pt + workers);
+        // epilogue operands of THIS tile are fetched now so that their latency hides under the MFMAs (a persistent block
+        // has no sibling to cover a dependent load at the end of every tile)
+        int en[NJ]; int64_t epix[NJ]; float enz[NJ]; bool eok[NJ];
+        f32x4 esc[NJ][4];
+        {
+            int tq = pt;
+            const int tw = tq % p.tilesW; tq /= p.tilesW;
+            const int th = tq % p.tilesH;
+            const int tn = tq / p.tilesH;
+            const int n0 = tn * p.TI, h0 = th * p.TH, w0 = tw * p.TW;
+#pragma unroll
+            for (int j = 0; j < NJ; j++) {
+                int n = n0 + qi[j], h = h0 + qr[j], w = w0 + qc[j];
+                eok[j] = n < p.N && h < p.H && w < p.W;
+                en[j] = n;
+                epix[j] = ((int64_t)n * p.H + h) * p.W + w;
+                enz[j] = (eok[j] && p.noise) ? p.noise[epix[j]] : 0.f;
+#pragma unroll
+                for (int rg = 0; rg < 4; rg++) {
+                    int co = co0 + wm * 32 + rg * 8 + lhi * 4;
+                    f32x4 one = {1.f, 1.f, 1.f, 1.f};
+                    esc[j][rg] = (eok[j] && p.out_scale && co < p.Cout) ? *(const f32x4*)(p.out_scale + (int64_t)n * p.Cout + co) : one;
+                }
+            }
+        }
         f32x16 acc[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; j++)
@@ -376,52 +432,36 @@ __global__ void __launch_bounds__(256) conv2d_fwd_ws_kernel(ConvParams p) {
                     }
                 }
         // ---- epilogue of this tile ----
-        {
-            int tq = pt;
-            const int tw = tq % p.tilesW; tq /= p.tilesW;
-            const int th = tq % p.tilesH;
-            const int tn = tq / p.tilesH;
-            const int n0 = tn * p.TI, h0 = th * p.TH, w0 = tw * p.TW;
 #pragma unroll
-            for (int j = 0; j < NJ; j++) {
-                int n = n0 + qi[j], h = h0 + qr[j], w = w0 + qc[j];
-                if (n >= p.N || h >= p.H || w >= p.W) continue;
-                const int64_t pixIdx = ((int64_t)n * p.H + h) * p.W + w;
-                const float nz = p.noise ? p.noise[pixIdx] : 0.f;
+        for (int j = 0; j < NJ; j++) {
+            if (!eok[j]) continue;
+            const int64_t pixIdx = epix[j];
+            const float nz = enz[j];
 #pragma unroll
-                for (int rg = 0; rg < 4; rg++) {
-                    int co = co0 + wm * 32 + rg * 8 + lhi * 4;
-                    if (co >= p.Cout) continue;
-                    float v[4];
+            for (int rg = 0; rg < 4; rg++) {
+                int co = co0 + wm * 32 + rg * 8 + lhi * 4;
+                if (co >= p.Cout) continue;
+                float v[4];
 #pragma unroll
-                    for (int e = 0; e < 4; e++) v[e] = acc[j][rg * 4 + e];
-                    if (p.out_scale) {
-                        f32x4 sc = *(const f32x4*)(p.out_scale + (int64_t)n * p.Cout + co);
-                        v[0] *= sc.x; v[1] *= sc.y; v[2] *= sc.z; v[3] *= sc.w;
-                    }
-                    if (p.bias) {
-                        f32x4 bb = *(const f32x4*)(p.bias + co);
-                        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; e++) v[e] += nz;
-                    if (p.residual) {
-                        u32x2 rr = *(const u32x2*)(p.residual + pixIdx * p.Cout + co);
-                        float a0, a1;
-                        Pack16<bf16_t>::unpack(rr.x, a0, a1); v[0] += a0; v[1] += a1;
-                        Pack16<bf16_t>::unpack(rr.y, a0, a1); v[2] += a0; v[3] += a1;
-                    }
-                    if (p.act == 3) {
-#pragma unroll
-                        for (int e = 0; e < 4; e++) v[e] = v[e] > 0.f ? v[e] : v[e] * p.alpha;
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; e++) v[e] *= p.gain;
-                    u32x2 o;
-                    o.x = Pack16<bf16_t>::pack(v[0], v[1]);
-                    o.y = Pack16<bf16_t>::pack(v[2], v[3]);
-                    *(u32x2*)(p.y + pixIdx * p.Cout + co) = o;
+                for (int e = 0; e < 4; e++) v[e] = acc[j][rg * 4 + e];
+                v[0] *= esc[j][rg].x; v[1] *= esc[j][rg].y; v[2] *= esc[j][rg].z; v[3] *= esc[j][rg].w;
+                v[0] += ebias[rg].x + nz; v[1] += ebias[rg].y + nz; v[2] += ebias[rg].z + nz; v[3] += ebias[rg].w + nz;
+                if (p.residual) {
+                    u32x2 rr = *(const u32x2*)(p.residual + pixIdx * p.Cout + co);
+                    float a0, a1;
+                    Pack16<bf16_t>::unpack(rr.x, a0, a1); v[0] += a0; v[1] += a1;
+                    Pack16<bf16_t>::unpack(rr.y, a0, a1); v[2] += a0; v[3] += a1;
                 }
+                if (p.act == 3) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = v[e] > 0.f ? v[e] : v[e] * p.alpha;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] *= p.gain;
+                u32x2 o;
+                o.x = Pack16<bf16_t>::pack(v[0], v[1]);
+                o.y = Pack16<bf16_t>::pack(v[2], v[3]);
+                *(u32x2*)(p.y + pixIdx * p.Cout + co) = o;
             }
         }
         if (more) {
@@ -600,6 +640,7 @@ extern "C" int agf_conv2d_fwd(const void* x, const void* w, void* y,
     p.in_scale = in_scale; p.out_scale = out_scale; p.bias = bias; p.noise = noise; p.residual = (const bf16_t*)residual;
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
     p.act = act; p.alpha = alpha; p.gain = act_gain;
+    { static int h = -1; if (h < 0) { const char* e = getenv("AGF_CONV_HOIST"); h = e ? atoi(e) : 1; } p.hoist = h; }
     // Two tilings.  Large: 128 co x 512 px (16x32 pixel tile), 8 waves -- when the map is at least 16x32, there are at
     // least 128 output channels and the grid still fills the chip (>= 384 blocks).  Default: 64 co x 256 px, 4 waves.
     int MT = 1;

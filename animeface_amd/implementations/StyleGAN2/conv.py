@@ -24,16 +24,19 @@ class KernelTimer:
 
     def __init__(self):
         self.records = {}          # kernel name -> list of (start_event, end_event, flops)
+        self.by_shape = {}
 
     def start(self):
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
         return ev
 
-    def stop(self, name, ev0, flops):
+    def stop(self, name, ev0, flops, tag=None):
         ev1 = torch.cuda.Event(enable_timing=True)
         ev1.record()
         self.records.setdefault(name, []).append((ev0, ev1, flops))
+        if tag is not None:
+            self.by_shape.setdefault((name,) + tuple(tag), []).append((ev0, ev1, flops))
 
     def summary(self):
         torch.cuda.synchronize()
@@ -80,7 +83,7 @@ def conv2d_fwd_raw(x, w, in_scale=None, out_scale=None, bias=None, noise=None, r
                                    _lib.ptr(bias), _lib.ptr(noise), _lib.ptr(residual), _lib.dtype_code(x),
                                    N, H, W, Cin, Cout, k, act, float(alpha), float(gain), _lib.stream_ptr(x))
     if timer is not None:
-        timer.stop('conv2d_fwd_kernel', ev0, 2.0 * N * H * W * Cin * Cout * k * k)
+        timer.stop('conv2d_fwd_kernel', ev0, 2.0 * N * H * W * Cin * Cout * k * k, (N, Cin, Cout, H, W, k, in_scale is not None))
     _lib.check(rc, 'conv2d_fwd')
     return y
 
@@ -106,7 +109,7 @@ def conv2d_wgrad_raw(x, dy, ksize, in_scale=None, out_scale=None, scale=1.0):
     rc = _lib.lib().agf_conv2d_wgrad(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(in_scale), _lib.ptr(out_scale),
                                      _lib.dtype_code(x), N, H, W, Cin, Cout, ksize, float(scale), _lib.stream_ptr(x))
     if timer is not None:
-        timer.stop('conv2d_wgrad_kernel', ev0, 2.0 * N * H * W * Cin * Cout * ksize * ksize)
+        timer.stop('conv2d_wgrad_kernel', ev0, 2.0 * N * H * W * Cin * Cout * ksize * ksize, (N, Cin, Cout, H, W, ksize, in_scale is not None))
     _lib.check(rc, 'conv2d_wgrad')
     return dw
 

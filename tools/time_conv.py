@@ -5,13 +5,14 @@ from animeface_amd.implementations.StyleGAN2.conv import conv2d_fwd_raw
 N, Cin, Cout, H, W = [int(v) for v in sys.argv[1:6]]
 x = torch.randn(N, Cin, H, W, device='cuda').to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
 w = (torch.randn(Cout, Cin, 3, 3, device='cuda') / (Cin * 9) ** 0.5).to(torch.bfloat16)
+sc = (torch.rand(N, Cin, device='cuda') + 0.5) if os.environ.get('SCALED') == '1' else None
 for _ in range(3):
-    conv2d_fwd_raw(x, w)
+    conv2d_fwd_raw(x, w, in_scale=sc)
 torch.cuda.synchronize()
 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 s.record()
 for _ in range(20):
-    conv2d_fwd_raw(x, w)
+    conv2d_fwd_raw(x, w, in_scale=sc)
 e.record(); torch.cuda.synchronize()
 ms = s.elapsed_time(e) / 20
 print(json.dumps(dict(variant=os.environ.get('AGF_CONV_VARIANT'), MT=os.environ.get('AGF_CONV_MT'), shape=[N, Cin, Cout, H, W], ms=round(ms, 4),
