@@ -1,0 +1,180 @@
+"""StyleGAN3 training loop on MI355X.
+
+Mirrors the reference's ``implementations/StyleGAN3/utils.py`` (``train`` :15-100, ``main`` :102-198): one ``G(z)`` per
+iteration shared by the D-step (detached) and the G-step, R1 ADDED to the adversarial loss every ``gp_every`` iterations
+(iteration 0 included, :50-53), the G-step through the already-updated D (:63-67), ``update_ema(copy_buffers=True)``
+(:77), Adam with the mapping network at ``lr * map_lr_scale`` (:176-181), and the warm-up ``D(G(const_input))`` that
+advances the ``ema`` / ``w_avg`` buffers once before training (:173-174).  Differences, none in a step's arithmetic:
+  * bf16 activations instead of fp16 autocast + GradScaler (``amp`` selects bf16, otherwise fp32);
+  * D's parameters are frozen during the G-step (the reference accumulates and then zeroes those gradients);
+  * no per-iteration ``save_image`` / ``.item()`` host syncs (kept behind ``log_every`` / ``on_save``);
+  * optional data parallelism through ``animeface_amd.distributed.GradReducer``.
+"""
+import functools
+
+import torch
+import torch.optim as optim
+
+from ...nnutils import get_device, sample_nnoise, update_ema, freeze
+from ...nnutils.loss import NonSaturatingLoss, r1_regularizer
+from ...thirdparty.diffaugment import DiffAugment
+from ... import distributed as dp
+from .model import Generator, Discriminator
+
+
+class TrainStep:
+    """One iteration of the reference loop (utils.py:30-77)."""
+
+    def __init__(self, G, G_ema, D, optimizer_G, optimizer_D, gp_lambda, gp_every, augment, latent_dim,
+                 reducer_G=None, reducer_D=None):
+        self.G, self.G_ema, self.D = G, G_ema, D
+        self.optimizer_G, self.optimizer_D = optimizer_G, optimizer_D
+        self.gp_lambda, self.gp_every, self.augment, self.latent_dim = gp_lambda, gp_every, augment, latent_dim
+        self.reducer_G, self.reducer_D = reducer_G, reducer_D
+        self.adv_fn = NonSaturatingLoss()
+        self.gp_fn = r1_regularizer()
+        self.batches_done = 0
+
+    @staticmethod
+    def _zero(opt, reducer):
+        if reducer is not None:
+            reducer.zero_grad()
+        else:
+            opt.zero_grad(set_to_none=True)
+
+    def __call__(self, real):
+        G, D = self.G, self.D
+        self._zero(self.optimizer_D, self.reducer_D)
+        self._zero(self.optimizer_G, self.reducer_G)
+        z = sample_nnoise((real.size(0), self.latent_dim), real.device)
+
+        fake = G(z)
+        real_aug = self.augment(real)
+        fake_aug = self.augment(fake)
+        real_prob = D(real_aug)
+        fake_prob = D(fake_aug.detach())
+        D_loss = self.adv_fn.d_loss(real_prob, fake_prob)
+        if self.gp_lambda > 0 and self.batches_done % self.gp_every == 0:
+            D_loss = D_loss + self.gp_fn(real, D, None) * self.gp_lambda
+        D_loss.backward()
+        if self.reducer_D is not None:
+            self.reducer_D.finish()
+        self.optimizer_D.step()
+
+        for p in D.parameters():
+            p.requires_grad_(False)
+        G_loss = self.adv_fn.g_loss(D(fake_aug))
+        G_loss.backward()
+        for p in D.parameters():
+            p.requires_grad_(True)
+        if self.reducer_G is not None:
+            self.reducer_G.finish()
+        self.optimizer_G.step()
+
+        update_ema(G, self.G_ema, copy_buffers=True)
+        self.batches_done += 1
+        return D_loss.detach(), G_loss.detach(), fake
+
+
+def train(max_iters, dataset, latent_dim, const_input,
+          G, G_ema, D, optimizer_G, optimizer_D,
+          gp_lambda, gp_every, augment,
+          device, amp, save=1000, log_file=None, log_every=50, on_save=None, reducer_G=None, reducer_D=None):
+    """Same positional signature as the reference's ``train`` (utils.py:15-20)."""
+    step = TrainStep(G, G_ema, D, optimizer_G, optimizer_D, gp_lambda, gp_every, augment, latent_dim, reducer_G, reducer_D)
+    history = []
+    while step.batches_done < max_iters:
+        for real in dataset:
+            real = real.to(device, non_blocking=True)
+            it = step.batches_done
+            D_loss, G_loss, fake = step(real)
+            if it % save == 0 and on_save is not None:
+                with torch.no_grad():
+                    on_save(it, G_ema(const_input), G_ema)
+            if log_every and it % log_every == 0:
+                history.append((it, D_loss.item(), G_loss.item()))
+            if step.batches_done == max_iters:
+                break
+    return history
+
+
+def build_optimizers(G, D, lr, map_lr_scale, betas):
+    """reference utils.py:176-181."""
+    fused = all(p.is_cuda for p in G.parameters())
+    optimizer_G = optim.Adam([{'params': G.synthesis.parameters()},
+                              {'params': G.map.parameters(), 'lr': lr * map_lr_scale}], lr=lr, betas=betas, fused=fused)
+    optimizer_D = optim.Adam(D.parameters(), lr=lr, betas=betas, fused=fused)
+    return optimizer_G, optimizer_D
+
+
+def build_models(args, device, compute_dtype):
+    mk_G = lambda: Generator(args.image_size, args.latent_dim, args.num_layers, args.map_num_layers, args.channels,
+                             args.max_channels, args.style_dim, not args.no_pixel_norm, args.image_channels,
+                             args.output_scale, args.margin_size, args.first_cutoff, args.first_stopband,
+                             args.last_stopband_rel, args.kernel_size, compute_dtype=compute_dtype)
+    G, G_ema = mk_G(), mk_G()
+    freeze(G_ema)
+    update_ema(G, G_ema, 0., copy_buffers=True)
+    D = Discriminator(args.image_size, args.image_channels, args.d_channels, args.d_max_channels, 3, args.mbsd_group_size,
+                      args.mbsd_channels, args.bottom, args.gaus_filter_size, 'lrelu', 1, compute_dtype=compute_dtype)
+    return G.to(device), G_ema.to(device), D.to(device)
+
+
+SG3_ARGS = dict(
+    num_test=[16, 'number of images for eval'],
+    image_channels=[3, 'number of image channels'],
+    latent_dim=[512, 'latent dimension'],
+    num_layers=[14, 'number of layers in G'],
+    map_num_layers=[2, 'number of layers in mapping network'],
+    channels=[32, 'channel base'],
+    max_channels=[512, 'maximum channel width'],
+    style_dim=[512, 'style code dimension'],
+    kernel_size=[3, 'kernel size. 3'],
+    no_pixel_norm=[False, 'no pixel normalization'],
+    output_scale=[0.25, 'scale output tensor with'],
+    margin_size=[10, 'bigger size to work on'],
+    first_cutoff=[2., 'first cutoff'],
+    first_stopband=[2 ** 2.1, 'first stopband'],
+    last_stopband_rel=[2 ** 0.3, 'last relative stopband'],
+    d_channels=[32, 'channel base for D'],
+    d_max_channels=[512, 'maximum channels in D'],
+    mbsd_group_size=[4, 'mini-batch stddev group size'],
+    mbsd_channels=[1, 'mini-batch stddev channels'],
+    bottom=[4, 'bottom width in D'],
+    gaus_filter_size=[4, 'filter size in D'],
+    lr=[0.0025, 'learning rate'],
+    map_lr_scale=[0.01, 'scale learning rate for mapping network with'],
+    betas=[[0., 0.99], 'betas'],
+    gp_lambda=[3., 'lambda for r1'],
+    gp_every=[16, 'calc penalty every'],
+    policy=['color,translation', 'policy for DiffAugment'],
+    logfile=[str, 'log file'])
+
+
+def main(parser, dataset=None):
+    """``implementations.StyleGAN3.main(parser)`` contract of the reference's main.py.  The dataset is injected (an
+    iterable of image batches in [-1, 1]); without one a synthetic uniform batch is cycled."""
+    from ...utils_argument import add_args
+    parser = add_args(parser, SG3_ARGS)
+    args = parser.parse_args()
+    rank, world, _ = dp.init_distributed()
+    device = get_device(not args.disable_gpu)
+    amp = not args.disable_amp and not args.disable_gpu
+    compute_dtype = torch.bfloat16 if amp else torch.float32
+    const_input = sample_nnoise((args.num_test, args.latent_dim), device)
+    G, G_ema, D = build_models(args, device, compute_dtype)
+    dp.broadcast_module(G), dp.broadcast_module(G_ema), dp.broadcast_module(D)
+    D(G(const_input))                                             # the reference's warm-up call; it moves ema / w_avg
+    optimizer_G, optimizer_D = build_optimizers(G, D, args.lr, args.map_lr_scale, tuple(args.betas))
+    reducer_G = dp.GradReducer(G.parameters()) if world > 1 else None
+    reducer_D = dp.GradReducer(D.parameters()) if world > 1 else None
+    if dataset is None:
+        gen = torch.Generator(device='cpu').manual_seed(rank)
+        batch = (torch.rand(args.batch_size, args.image_channels, args.image_size, args.image_size, generator=gen) * 2 - 1).to(device)
+        dataset = [batch]
+    if args.max_iters < 0:
+        args.max_iters = len(dataset) * args.default_epochs
+    augment = functools.partial(DiffAugment, policy=args.policy)
+    return train(args.max_iters, dataset, args.latent_dim, const_input, G, G_ema, D, optimizer_G, optimizer_D,
+                 args.gp_lambda, args.gp_every, augment, device, amp, args.save, args.logfile,
+                 reducer_G=reducer_G, reducer_D=reducer_D)

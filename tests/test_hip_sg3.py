@@ -1,0 +1,185 @@
+"""GPU parity of the StyleGAN3 model and training loop on the HIP operators, against golden vectors produced by the
+reference's own modules / train() on CPU (tools/make_golden.py, fixtures sg3_model / sg3_train).
+
+fp32 compute mode: <= 1e-3 relative (north_star tolerance for fp32 activations).
+bf16 compute mode (the training path): compared with the fp32 reference at bf16-level tolerance."""
+import functools
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import t
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+CFG = dict(image_size=32, latent_dim=16, num_layers=6, map_num_layers=2, channels=32, max_channels=16, style_dim=16,
+           margin_size=4, d_channels=8, d_max_channels=16)
+
+
+def sub(g, prefix):
+    return {k[len(prefix):]: t(v).clone() for k, v in g.items() if k.startswith(prefix)}
+
+
+def build(dtype):
+    from animeface_amd.implementations.StyleGAN3 import model as M
+    c = CFG
+    G = M.Generator(c['image_size'], c['latent_dim'], c['num_layers'], c['map_num_layers'], c['channels'], c['max_channels'],
+                    c['style_dim'], margin_size=c['margin_size'], compute_dtype=dtype)
+    D = M.Discriminator(c['image_size'], 3, c['d_channels'], c['d_max_channels'], compute_dtype=dtype)
+    return M, G.to(DEV), D.to(DEV)
+
+
+def relerr(a, b):
+    return ((a.detach().float().cpu() - b.float()).abs().max() / b.float().abs().max().clamp_min(1e-8)).item()
+
+
+def test_layer_params_and_filters_match_the_reference(golden):
+    from animeface_amd.implementations.StyleGAN3 import model as M
+    g = golden('sg3_model')
+    for tag, args in [('lp', (32, 6, 2 ** 11 * 0.5, 16, 3, 4)), ('lp256', (256, 14, 2 ** 14 * 0.5, 512, 3, 10))]:
+        for name, val in zip(['channels', 'sizes', 'rates', 'cutoffs', 'half_widths'], M.get_layer_params(*args)):
+            np.testing.assert_allclose(val, g[f'{tag}_{name}'], rtol=1e-12)
+    # the design filters are buffers: a freshly built model must carry the reference's values
+    _, G, D = build(torch.float32)
+    ref = sub(g, 'G/')
+    sd = G.state_dict()
+    assert set(sd) == set(ref)
+    for k in sd:
+        if k.endswith('up_filter') or k.endswith('down_filter'):
+            torch.testing.assert_close(sd[k].cpu(), ref[k], rtol=1e-6, atol=1e-8)
+    refd = sub(g, 'D/')
+    assert set(D.state_dict()) == set(refd)
+    for k, v in D.state_dict().items():
+        assert tuple(v.shape) == tuple(refd[k].shape), k
+        if k.endswith('down_filter'):
+            torch.testing.assert_close(v.cpu(), refd[k])
+
+
+@pytest.mark.parametrize('dtype,tol', [(torch.float32, 1e-3), (torch.bfloat16, 8e-2)])
+def test_generator_discriminator_forward_and_grads_vs_reference(golden, dtype, tol):
+    g = golden('sg3_model')
+    M, G, D = build(dtype)
+    G.load_state_dict(sub(g, 'G/'), strict=True)
+    D.load_state_dict(sub(g, 'D/'), strict=True)
+    z = t(g['z']).to(DEV)
+    G.train()
+    image = G(z)
+    assert image.dtype == torch.float32 and tuple(image.shape) == (4, 3, 32, 32)
+    assert relerr(image, t(g['image'])) < tol
+    sd = G.state_dict()
+    for k, v in sub(g, 'G1/').items():                      # ema / w_avg buffers moved exactly like the reference's
+        torch.testing.assert_close(sd[k].cpu(), v, rtol=tol, atol=tol * 1e-2, msg=lambda m, k=k: f'{k}: {m}')
+    if dtype == torch.float32:
+        logits = D(image)
+    else:
+        logits = D(t(g['image']).to(DEV))                    # isolate D from G's bf16 rounding
+    assert relerr(logits, t(g['logits'])) < tol
+    if dtype != torch.float32:
+        return
+    loss = torch.nn.functional.softplus(-logits).mean()
+    assert abs(loss.item() - float(g['g_loss'])) < tol * max(1.0, abs(float(g['g_loss'])))
+    pg, pd = dict(G.named_parameters()), dict(D.named_parameters())
+    gn = [k[len('gradG/'):] for k in g if k.startswith('gradG/')]
+    dn = [k[len('gradD/'):] for k in g if k.startswith('gradD/')]
+    grads = torch.autograd.grad(loss, [pg[k] for k in gn] + [pd[k] for k in dn])
+    for k, gr in zip(gn, grads[:len(gn)]):
+        assert relerr(gr, t(g['gradG/' + k])) < tol, k
+    for k, gr in zip(dn, grads[len(gn):]):
+        assert relerr(gr, t(g['gradD/' + k])) < tol, k
+    G.eval()
+    with torch.no_grad():
+        assert relerr(G(z, truncation_psi=0.7), t(g['image_eval_psi07'])) < tol
+
+
+def test_bf16_backward_tracks_the_fp32_reference(golden):
+    g = golden('sg3_model')
+    M, G, D = build(torch.bfloat16)
+    G.load_state_dict(sub(g, 'G/'))
+    D.load_state_dict(sub(g, 'D/'))
+    G.train()
+    logits = D(G(t(g['z']).to(DEV)))
+    loss = torch.nn.functional.softplus(-logits).mean()
+    assert abs(loss.item() - float(g['g_loss'])) < 5e-2
+    pg, pd = dict(G.named_parameters()), dict(D.named_parameters())
+    gn = [k[len('gradG/'):] for k in g if k.startswith('gradG/')]
+    dn = [k[len('gradD/'):] for k in g if k.startswith('gradD/')]
+    grads = torch.autograd.grad(loss, [pg[k] for k in gn] + [pd[k] for k in dn])
+    for k, gr in zip(gn + dn, grads):
+        ref = t(g[('gradG/' if k in gn else 'gradD/') + k]).float()
+        cos = torch.nn.functional.cosine_similarity(gr.float().cpu().flatten(), ref.flatten(), dim=0).item()
+        assert cos > 0.97, (k, cos)
+
+
+def test_r1_double_backward_vs_reference(golden):
+    from animeface_amd.nnutils.loss import r1_regularizer
+    g = golden('sg3_model')
+    M, G, D = build(torch.float32)
+    D.load_state_dict(sub(g, 'D/'))
+    r1 = r1_regularizer()(t(g['real']).to(DEV), D, None)
+    assert abs(r1.item() - float(g['r1'])) < 1e-3 * abs(float(g['r1']))
+    r1.backward()
+    pd = dict(D.named_parameters())
+    for k in g:
+        if k.startswith('r1grad/'):
+            assert relerr(pd[k[len('r1grad/'):]].grad, t(g[k])) < 1e-3, k
+
+
+def test_train_loop_replays_the_references_train(golden):
+    """Three iterations of the reference's own StyleGAN3 train() (gp_every = 2: iterations 0 and 2 add R1) replayed
+    through the HIP path in fp32 with the same random stream."""
+    from animeface_amd.implementations.StyleGAN3 import utils as U
+    from animeface_amd.nnutils import sample_nnoise, update_ema, freeze
+    from animeface_amd.thirdparty.diffaugment import DiffAugment
+    from animeface_amd import rng
+    g = golden('sg3_train')
+    M, G, D = build(torch.float32)
+    _, G_ema, _ = build(torch.float32)
+    G.load_state_dict(sub(g, 'G0/'))
+    D.load_state_dict(sub(g, 'D0/'))
+    freeze(G_ema)
+    update_ema(G, G_ema, 0., copy_buffers=True)
+    lr, map_lr_scale, b0, b1, gp_lambda, gp_every = [float(v) for v in g['train_hparams']]
+    opt_G, opt_D = U.build_optimizers(G, D, lr, map_lr_scale, (b0, b1))
+    assert opt_G.param_groups[1]['lr'] == lr * map_lr_scale and opt_G.param_groups[0]['lr'] == lr
+    losses = []
+    with rng.cpu_stream():
+        torch.manual_seed(26)
+        const_input = sample_nnoise((2, CFG['latent_dim']), DEV)
+        step = U.TrainStep(G, G_ema, D, opt_G, opt_D, gp_lambda, int(gp_every),
+                           functools.partial(DiffAugment, policy='color,translation'), CFG['latent_dim'])
+        for it in range(3):
+            dl, gl, _ = step(t(g['train_real'][it]).to(DEV))
+            losses.append([dl.item(), gl.item()])
+    np.testing.assert_allclose(np.array(losses), g['train_losses'], rtol=5e-3, atol=1e-5)
+    for name, net, prefix in [('G', G, 'G3/'), ('D', D, 'D3/'), ('G_ema', G_ema, 'Gema3/')]:
+        sd = net.state_dict()
+        ref = sub(g, prefix)
+        assert set(sd) == set(ref)
+        bad = 0
+        total = 0
+        for k, v in ref.items():
+            d = (sd[k].cpu().float() - v.float()).abs()
+            # Adam with beta1 = 0 moves every weight by ~lr * sign(grad): an element whose gradient is at rounding level
+            # may legitimately take the other sign, so count outliers instead of demanding every element
+            bad += int((d > 5e-5 + 5e-3 * v.float().abs()).sum())
+            total += d.numel()
+        assert bad <= 0.002 * total, (name, bad, total)
+
+
+def test_bf16_training_steps_run_and_stay_finite():
+    from animeface_amd.implementations.StyleGAN3 import utils as U
+    from animeface_amd.nnutils import update_ema, freeze
+    from animeface_amd.thirdparty.diffaugment import DiffAugment
+    torch.manual_seed(0)
+    M, G, D = build(torch.bfloat16)
+    _, G_ema, _ = build(torch.bfloat16)
+    freeze(G_ema)
+    update_ema(G, G_ema, 0., copy_buffers=True)
+    opt_G, opt_D = U.build_optimizers(G, D, 0.0025, 0.01, (0., 0.99))
+    real = torch.rand(8, 3, 32, 32, device=DEV) * 2 - 1
+    hist = U.train(3, [real], CFG['latent_dim'], torch.randn(2, CFG['latent_dim'], device=DEV), G, G_ema, D, opt_G, opt_D,
+                   3., 2, functools.partial(DiffAugment, policy='color,translation'), torch.device(DEV), True, log_every=1)
+    assert len(hist) == 3 and all(np.isfinite(h[1]) and np.isfinite(h[2]) for h in hist)
+    for p in list(G.parameters()) + list(D.parameters()) + list(G_ema.parameters()):
+        assert torch.isfinite(p).all()

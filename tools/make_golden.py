@@ -473,11 +473,140 @@ def gen_losses_and_train():
     save('sg2_train', **arrays)
 
 
+# ------------------------------------------------------------------------------------------------
+# StyleGAN3 (reference implementations/StyleGAN3/{model,utils}.py) on a tiny configuration that still covers
+# up 2 / up 4 / down 2, separable and radial filters, the critically sampled tail and the 1x1 toRGB layer.
+
+SG3_TINY = dict(image_size=32, latent_dim=16, num_layers=6, map_num_layers=2, channels=32, max_channels=16, style_dim=16,
+                margin_size=4, d_channels=8, d_max_channels=16)
+
+
+def build_sg3_tiny(seed):
+    import implementations.StyleGAN3.model as sg3
+    c = SG3_TINY
+    torch.manual_seed(seed)
+    G = sg3.Generator(c['image_size'], c['latent_dim'], c['num_layers'], c['map_num_layers'], c['channels'],
+                      c['max_channels'], c['style_dim'], margin_size=c['margin_size'])
+    D = sg3.Discriminator(c['image_size'], 3, c['d_channels'], c['d_max_channels'])
+    with torch.no_grad():
+        for n, p in list(G.named_parameters()) + list(D.named_parameters()):
+            if n.endswith('bias') and 'affine' not in n:
+                p.normal_(0, 0.2)
+    return sg3, G, D
+
+
+def gen_sg3_model():
+    sg3, G, D = build_sg3_tiny(21)
+    arrays = {}
+    for k, v in G.state_dict().items():
+        arrays['G/' + k] = v.clone()
+    for k, v in D.state_dict().items():
+        arrays['D/' + k] = v.clone()
+    g = torch.Generator().manual_seed(22)
+    z = torch.randn(4, SG3_TINY['latent_dim'], generator=g)
+    G.train()
+    image = G(z)                       # training mode: moves every layer's ema and the mapping's w_avg
+    logits = D(image)
+    arrays.update(z=z, image=image, logits=logits)
+    for k, v in G.state_dict().items():
+        if k.endswith('ema') or k.endswith('w_avg'):
+            arrays['G1/' + k] = v.clone()
+    loss = torch.nn.functional.softplus(-logits).mean()
+    names_g = ['synthesis.input.weight', 'synthesis.input.affine.weight', 'synthesis.net.0.conv.weight', 'synthesis.net.0.bias',
+               'synthesis.net.2.affine.weight', 'synthesis.net.2.conv.weight', 'synthesis.net.4.conv.weight',
+               'synthesis.net.5.bias', 'synthesis.net.6.conv.weight', 'synthesis.net.6.affine.bias', 'map.net.0.weight', 'map.net.1.bias']
+    names_d = ['from_rgb.weight', 'resblocks.0.conv1.weight', 'resblocks.0.conv2.weight', 'resblocks.1.skip.weight',
+               'resblocks.2.conv2.bias', 'epilogue.epilogue.1.weight', 'epilogue.epilogue.3.weight', 'epilogue.epilogue.4.bias']
+    pg, pd = dict(G.named_parameters()), dict(D.named_parameters())
+    grads = torch.autograd.grad(loss, [pg[n] for n in names_g] + [pd[n] for n in names_d])
+    arrays['g_loss'] = loss
+    for n, gr in zip(names_g, grads[:len(names_g)]):
+        arrays['gradG/' + n] = gr
+    for n, gr in zip(names_d, grads[len(names_g):]):
+        arrays['gradD/' + n] = gr
+    G.eval()
+    arrays['image_eval_psi07'] = G(z, truncation_psi=0.7)
+    # R1 on D
+    from nnutils.loss import r1_regularizer
+    real = torch.rand(4, 3, 32, 32, generator=g) * 2 - 1
+    D.zero_grad()
+    r1 = r1_regularizer()(real, D, None)
+    r1.backward()
+    arrays.update(real=real, r1=r1)
+    for n in names_d:
+        if pd[n].grad is not None:
+            arrays['r1grad/' + n] = pd[n].grad.clone()
+    # layer parameters derived from the filter design
+    ch, sizes, rates, cutoffs, hw = sg3.get_layer_params(32, 6, 2 ** 11 * 0.5, 16, 3, 4)
+    arrays.update(lp_channels=ch, lp_sizes=sizes, lp_rates=rates, lp_cutoffs=cutoffs, lp_half_widths=hw)
+    ch, sizes, rates, cutoffs, hw = sg3.get_layer_params(256, 14, 2 ** 14 * 0.5, 512, 3, 10)
+    arrays.update(lp256_channels=ch, lp256_sizes=sizes, lp256_rates=rates, lp256_cutoffs=cutoffs, lp256_half_widths=hw)
+    save('sg3_model', **arrays)
+
+
+def gen_sg3_train():
+    import implementations.StyleGAN3.utils as ref_utils
+    from nnutils import update_ema, freeze
+    from thirdparty.diffaugment import DiffAugment
+    sg3, G, D = build_sg3_tiny(23)
+    _, G_ema, _ = build_sg3_tiny(24)
+    freeze(G_ema)
+    update_ema(G, G_ema, 0., copy_buffers=True)
+    arrays = {}
+    for k, v in G.state_dict().items():
+        arrays['G0/' + k] = v.clone()
+    for k, v in D.state_dict().items():
+        arrays['D0/' + k] = v.clone()
+    g = torch.Generator().manual_seed(25)
+    real_batches = [torch.rand(4, 3, 32, 32, generator=g) * 2 - 1 for _ in range(3)]
+    arrays['train_real'] = torch.stack(real_batches)
+    lr, map_lr_scale, betas, gp_lambda, gp_every = 0.0025, 0.01, (0., 0.99), 3., 2
+    opt_G = torch.optim.Adam([{'params': G.synthesis.parameters()}, {'params': G.map.parameters(), 'lr': lr * map_lr_scale}],
+                             lr=lr, betas=betas)
+    opt_D = torch.optim.Adam(D.parameters(), lr=lr, betas=betas)
+    losses = []
+
+    class FakeStatus:
+        def __init__(self, max_iter, *a):
+            self.batches_done, self.max_iter = 0, max_iter
+
+        def is_end(self):
+            return self.batches_done >= self.max_iter
+
+        def update(self, **kw):
+            losses.append([kw['d'], kw['g']])
+            self.batches_done += 1
+
+        def plot_loss(self):
+            pass
+    ref_utils.Status = FakeStatus
+    ref_utils.save_image = lambda *a, **k: None
+    orig_save = torch.save
+    torch.save = lambda *a, **k: None
+    try:
+        torch.manual_seed(26)
+        const_input = ref_utils.sample_nnoise((2, SG3_TINY['latent_dim']), 'cpu')
+        ref_utils.train(3, real_batches, SG3_TINY['latent_dim'], const_input, G, G_ema, D, opt_G, opt_D,
+                        gp_lambda, gp_every, functools.partial(DiffAugment, policy='color,translation'),
+                        torch.device('cpu'), False, 1000, None)
+    finally:
+        torch.save = orig_save
+    arrays['train_losses'] = np.array(losses, dtype=np.float64)
+    arrays['train_hparams'] = np.array([lr, map_lr_scale, betas[0], betas[1], gp_lambda, gp_every], dtype=np.float64)
+    for k, v in G.state_dict().items():
+        arrays['G3/' + k] = v
+    for k, v in D.state_dict().items():
+        arrays['D3/' + k] = v
+    for k, v in G_ema.state_dict().items():
+        arrays['Gema3/' + k] = v
+    save('sg3_train', **arrays)
+
+
 if __name__ == '__main__':
     os.environ.setdefault('PYTHONDONTWRITEBYTECODE', '1')
     torch.set_num_threads(8)
     import_reference()
-    which = sys.argv[1:] or ['upfirdn2d', 'equiv', 'bias_act', 'filtered_lrelu', 'sg2_model', 'train']
+    which = sys.argv[1:] or ['upfirdn2d', 'equiv', 'bias_act', 'filtered_lrelu', 'sg2_model', 'train', 'sg3_model', 'sg3_train']
     if 'upfirdn2d' in which:
         gen_upfirdn2d()
     if 'equiv' in which:
@@ -490,3 +619,7 @@ if __name__ == '__main__':
         gen_sg2_model()
     if 'train' in which:
         gen_losses_and_train()
+    if 'sg3_model' in which:
+        gen_sg3_model()
+    if 'sg3_train' in which:
+        gen_sg3_train()
