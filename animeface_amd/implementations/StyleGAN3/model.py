@@ -9,9 +9,9 @@ reference's ``implementations/StyleGAN3/model.py``; the arithmetic runs on this 
     (model.py:46-74), padding k-1                               s * ema^-1/2 and output scale d = rsqrt(sum (W*scale*s)^2 + 1e-8);
                                                                 "full" padding = zero-pad the input by (k-1) - k//2, then "same" conv
   filtered_lrelu (model.py:186-189)                            fused HIP kernel (agf_filtered_lrelu)
-  ConvAct: conv2d_resample + bias_act (model.py:410-417)       stride-1 convs on the MFMA conv, the stride-2 path = HIP upfirdn2d
-                                                                + ATen strided conv (the reference's own conv2d_gradfix falls through
-                                                                to F.conv2d, conv2d_gradfix.py:15,29-37), HIP bias_act
+  ConvAct: conv2d_resample + bias_act (model.py:410-417)       stride-1 convs on the MFMA conv; 1x1+down = HIP upfirdn2d(down) then
+                                                                MFMA conv; 3x3+down = MFMA conv at stride 1 then HIP upfirdn2d(down)
+                                                                (FIR and conv commute, see ConvAct.forward); HIP bias_act
 Filter design (``design_filter``, ``get_layer_params``) is scipy / numpy arithmetic exactly as in model.py:76-115.
 """
 import math
@@ -23,12 +23,46 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ...stylegan3_ops import bias_act, filtered_lrelu, conv2d_resample
+from ...stylegan3_ops import bias_act, filtered_lrelu, conv2d_resample, upfirdn2d
 from ..StyleGAN2.conv import conv2d
 
 
 def _native(x):
     return x.is_cuda
+
+
+class _PadToChannelsLast(torch.autograd.Function):
+    """NCHW (any layout) -> zero-padded dense channels-last in one copy; the gradient comes back cropped and NCHW-dense,
+    which is the layout the plane-wise filtered_lrelu kernels read at full bandwidth."""
+
+    @staticmethod
+    def forward(ctx, x, pad):
+        ctx.pad = pad
+        N, C, H, W = x.shape
+        if pad == 0:
+            return x.contiguous(memory_format=torch.channels_last)
+        y = torch.empty((N, C, H + 2 * pad, W + 2 * pad), dtype=x.dtype, device=x.device, memory_format=torch.channels_last).zero_()
+        y[:, :, pad:-pad, pad:-pad].copy_(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return _CropToPlanar.apply(g, ctx.pad), None
+
+
+class _CropToPlanar(torch.autograd.Function):
+    """Adjoint of ``_PadToChannelsLast``: crop the border, NCHW-dense result."""
+
+    @staticmethod
+    def forward(ctx, g, pad):
+        ctx.pad = pad
+        if pad:
+            g = g[:, :, pad:-pad, pad:-pad]
+        return g.contiguous()
+
+    @staticmethod
+    def backward(ctx, gg):
+        return _PadToChannelsLast.apply(gg, ctx.pad), None
 
 
 class Linear(nn.Module):
@@ -68,10 +102,9 @@ class ModulatedConv(nn.Module):
         s_in = s * input_gain if input_gain is not None else s
         extra = self.padding - k // 2                      # reference pads k-1; the kernel pads k//2
         assert extra >= 0
-        if extra:
-            x = F.pad(x, [extra] * 4)
-        x = x.contiguous(memory_format=torch.channels_last)
-        return conv2d(x, self.weight * self.scale, s_in, d)
+        x = _PadToChannelsLast.apply(x, extra)
+        y = conv2d(x, self.weight * self.scale, s_in, d)
+        return _CropToPlanar.apply(y, 0)                   # planar for filtered_lrelu; its gradient returns channels-last
 
 
 def design_filter(numtaps, cutoff, width, fs, radial=False):
@@ -319,10 +352,25 @@ class ConvAct(nn.Module):
 
     def forward(self, x):
         weight = self.weight * self.scale
-        if self.down == 1 and x.dtype in (torch.bfloat16, torch.float32) and _native(x):
-            x = conv2d(x.contiguous(memory_format=torch.channels_last), weight)             # MFMA conv, "same" padding
-        else:
+        k = self.weight.shape[2]
+        if not _native(x):
             x = conv2d_resample.conv2d_resample(x, weight.to(x.dtype), self.down_filter, 1, self.down, self.padding)
+        elif self.down == 1:
+            x = conv2d(x.contiguous(memory_format=torch.channels_last), weight)             # MFMA conv, "same" padding
+        elif k == 1:
+            # conv2d_resample's "1x1 + down" order (conv2d_resample.py:88-91): FIR-downsample first, then the 1x1 conv on MFMA
+            f = self.down_filter
+            p0, p1 = (f.shape[-1] - self.down + 1) // 2, (f.shape[-1] - self.down) // 2
+            x = upfirdn2d.upfirdn2d(x, f, down=self.down, padding=[p0, p1, p0, p1])
+            x = conv2d(x.contiguous(memory_format=torch.channels_last), weight)
+        else:
+            # FIR + stride-2 conv of conv2d_resample.py:100-103.  The FIR and the (channel-mixing) conv commute, so the conv
+            # runs first, at stride 1 on the MFMA kernel over the input zero-padded by one more pixel, and ONE upfirdn2d then
+            # filters and decimates: same linear map, every piece double-differentiable on this package's kernels (MIOpen's
+            # double backward of a strided conv lands on its "naive" kernels: 12 s per R1 iteration at 256x256).
+            assert self.down == 2 and k == 3 and self.padding == 1
+            x = conv2d(_PadToChannelsLast.apply(x, 1), weight)
+            x = upfirdn2d.upfirdn2d(x, self.down_filter, down=self.down, padding=0)
         b = self.bias.to(x.dtype) if self.bias is not None else None
         return bias_act.bias_act(x, b, act=self.act_name, gain=self.act_gain)
 

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Time StyleGAN3 (reference defaults: 14 layers, channels 32, 256x256) training iterations on one GPU.
+    python tools/bench_sg3.py --batch 32 --steps 8"""
+import argparse
+import functools
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from animeface_amd.implementations.StyleGAN3 import utils as U          # noqa: E402
+from animeface_amd.implementations.StyleGAN3 import model as M          # noqa: E402
+from animeface_amd.nnutils import update_ema, freeze                    # noqa: E402
+from animeface_amd.thirdparty.diffaugment import DiffAugment            # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--batch', type=int, default=32)
+ap.add_argument('--image-size', type=int, default=256)
+ap.add_argument('--steps', type=int, default=8)
+ap.add_argument('--warmup', type=int, default=2)
+ap.add_argument('--fp32', action='store_true')
+a = ap.parse_args()
+dev = torch.device('cuda')
+dt = torch.float32 if a.fp32 else torch.bfloat16
+torch.manual_seed(0)
+G = M.Generator(a.image_size, 512, compute_dtype=dt).to(dev)
+G_ema = M.Generator(a.image_size, 512, compute_dtype=dt).to(dev)
+freeze(G_ema)
+update_ema(G, G_ema, 0., copy_buffers=True)
+D = M.Discriminator(a.image_size, 3, 32, 512, compute_dtype=dt).to(dev)
+print('params G %d D %d' % (sum(p.numel() for p in G.parameters()), sum(p.numel() for p in D.parameters())))
+opt_G, opt_D = U.build_optimizers(G, D, 0.0025, 0.01, (0., 0.99))
+step = U.TrainStep(G, G_ema, D, opt_G, opt_D, 3., 16, functools.partial(DiffAugment, policy='color,translation'), 512)
+real = torch.rand(a.batch, 3, a.image_size, a.image_size, device=dev) * 2 - 1
+for _ in range(a.warmup):
+    step(real)
+torch.cuda.synchronize()
+t0 = time.time()
+for _ in range(a.steps):
+    step(real)
+torch.cuda.synchronize()
+dtm = (time.time() - t0) / a.steps
+print('sg3 %s batch %d: %.1f ms/iter, %.1f img/s' % ('fp32' if a.fp32 else 'bf16', a.batch, dtm * 1e3, a.batch / dtm))
