@@ -355,6 +355,494 @@ __global__ void __launch_bounds__(256) filtered_lrelu_kernel(FlrParams p0) {
     }
 }
 
+
+// =================================================================================================
+// Register-blocked variant for the StyleGAN3 configurations (12 taps per factor of 2: FU = 6*UP, FD = 6*DOWN).
+//
+// The kernel above spends two LDS reads (one sample, one tap) per FMA and is bound by LDS issue at ~5 % of the fp32 VALU
+// peak.  Here every phase keeps a window of samples in registers and loads a row of taps once for many FMAs:
+//   2  horizontal up-FIR   : one lane = 8 consecutive up-resolution columns of one input row (12 / 8 inputs as b128 / b64
+//                            reads, 48 FMAs, taps in registers)
+//   3  vertical up-FIR     : one lane = one column, a run of 8 rows (9 / 7 b32 reads, 48 FMAs)
+//   3' 2-D (radial) up-FIR : one lane = one input column (two output columns), a run of RN input rows; a (RN+5) x 6
+//                            input window in registers; the 12 taps of one (row phase, tap row) serve 12*RN FMAs
+//   act                    : gain / leaky ReLU / clamp with sign write or sign read, in place on the LDS tile (float4)
+//   4  2-D (radial) down   : one lane = one output column, a strip of R4 output rows; sliding window of R4 rows x 12
+//                            samples (conflict-free b64 reads), the 12 taps of one tap row serve 12*R4 FMAs
+//   4' separable down      : vertical pass (lane = column, strip of R rows, taps in registers), then horizontal pass
+// Up-resolution samples are computed on the lattice aligned to the input samples ("v" coordinates: v = tile coordinate +
+// d, d = phase of the tile origin), which makes every polyphase tap index a compile-time constant; results are stored
+// in tile coordinates so that the decimating reads stay 8-byte aligned.
+struct FlrRbParams {
+    FlrParams b;
+    int XP, HP, UPC;                 // pitches (floats) of sX, sH, sU / sV
+    int TVWa;                        // v-lattice width handled by the horizontal pass (multiple of 8)
+    int runsV;                       // 8-row runs of the vertical up pass
+    int MW, NR;                      // 2-D up: input columns / runs of RN input rows
+    int ofsU, ofsX, ofsH, ofsV;      // LDS offsets (floats) after the filters
+    uint32_t mG, mTUW, mMW, mQ4, mTOW, mXP;   // magic numbers for division by nG, TUW, MW, UPC/4, TOW, XP
+};
+
+// Scheduling fence: the value must be materialised here, and no memory access moves across.  Without tying the accumulators
+// to the fence the compiler sinks every FMA below all the loads of an unrolled phase (everything live at once -> spills).
+#define FLR_PIN(v) asm volatile("" : "+v"(v) :: "memory")
+typedef float v2f __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ uint32_t flr_div(uint32_t a, uint32_t magic) { return __umulhi(a, magic); }
+static inline uint32_t flr_magic(uint32_t d) { return d <= 1 ? 0u : (uint32_t)(0xFFFFFFFFull / d) + 1u; }
+#define FLR_DIV(a, d, magic) ((d) <= 1 ? (uint32_t)(a) : flr_div((uint32_t)(a), (magic)))
+
+// 2-bit codes of the four samples sx .. sx+3 of sign row sy (0 where the sign tensor does not cover them)
+static __device__ __forceinline__ uint32_t flr_load_signs(const FlrParams& p, int64_t plane64, int sx, int sy) {
+    if ((uint32_t)sy >= (uint32_t)p.SH) return 0;
+    const uint8_t* row = p.s + (int64_t)p.SWB * (sy + (int64_t)p.SH * plane64);
+    if (sx >= 0) {
+        const uint32_t b0 = (uint32_t)sx >> 2, b1 = b0 + 1;
+        uint32_t lo = b0 < (uint32_t)p.SWB ? row[b0] : 0u;
+        uint32_t hi = ((sx & 3) && b1 < (uint32_t)p.SWB) ? row[b1] : 0u;
+        return ((lo | (hi << 8)) >> ((sx & 3) << 1)) & 0xffu;
+    }
+    uint32_t sb = 0;                                             // left border: sample by sample
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const int sx1 = sx + e;
+        if (sx1 >= 0 && (uint32_t)(sx1 >> 2) < (uint32_t)p.SWB) sb |= ((uint32_t)(row[sx1 >> 2] >> ((sx1 & 3) << 1)) & 3u) << (e << 1);
+    }
+    return sb;
+}
+
+template <class T, int UP, int DOWN, int SU, int SD, int RN, int R4>
+__global__ void __launch_bounds__(256, 2) flr_rb_kernel(FlrRbParams P) {
+    constexpr int FU = 6 * UP, FD = 6 * DOWN;
+    static_assert(SU == 1 || UP == 2, "2-D up filter: factor 2 only");
+    static_assert(SD == 1 || DOWN == 2, "2-D down filter: factor 2 only");
+    extern __shared__ __attribute__((aligned(16))) float flr_smem[];
+    const FlrParams& p = P.b;
+    constexpr int NFU = SU == 1 ? FU : FU * FU, NFD = SD == 1 ? FD : FD * FD;
+    float* sFu = flr_smem;
+    float* sFd = sFu + NFU;
+    float* base = sFd + NFD;
+    float* sU = base + P.ofsU;
+    float* sX = base + P.ofsX;
+    float* sH = base + P.ofsH;
+    float* sV = base + P.ofsV;
+    const int tid = threadIdx.x;
+
+    // ---- filters.  F(k) = f[size-1-k] unless flip.  2-D up taps are stored in the order the polyphase loop consumes them:
+    //      sFu[((a*6 + jy)*6 + jx)*2 + b] = F(1-a+2jy, 1-b+2jx) ----
+    if (SU == 1) { for (int i = tid; i < FU; i += 256) sFu[i] = p.fu[(p.flip ? i : FU - 1 - i) * p.fus0]; }
+    else {
+        for (int i = tid; i < FU * FU; i += 256) {
+            int b = i & 1, jx = (i >> 1) % 6, jy = (i / 12) % 6, a = i / 72;
+            int ky = 1 - a + 2 * jy, kx = 1 - b + 2 * jx;
+            sFu[i] = p.fu[(p.flip ? ky : FU - 1 - ky) * p.fus0 + (p.flip ? kx : FU - 1 - kx) * p.fus1];
+        }
+    }
+    if (SD == 1) { for (int i = tid; i < FD; i += 256) sFd[i] = p.fd[(p.flip ? i : FD - 1 - i) * p.fds0]; }
+    else { for (int i = tid; i < FD * FD; i += 256) { int ky = i / FD, kx = i - ky * FD;
+            sFd[i] = p.fd[(p.flip ? ky : FD - 1 - ky) * p.fds0 + (p.flip ? kx : FD - 1 - kx) * p.fds1]; } }
+
+    int bid = blockIdx.x;
+    const int tx = bid % p.tilesX; bid /= p.tilesX;
+    const int ty = bid % p.tilesY;
+    const int plane = bid / p.tilesY;
+    const int n = plane / p.C, c = plane - n * p.C;
+    const int oy0 = ty * p.TOH, ox0 = tx * p.TOW;
+    const int uy0 = oy0 * DOWN, ux0 = ox0 * DOWN;
+    const int midx0 = ux0 + UP - 1 - p.px0, midy0 = uy0 + UP - 1 - p.py0;
+    const int tix0 = agf_floor_div(midx0, UP), tiy0 = agf_floor_div(midy0, UP);
+    const int dx = midx0 - tix0 * UP, dy = midy0 - tiy0 * UP;          // 0 .. UP-1
+
+    // ---- 1. input tile + bias (zero outside the image).  Eight independent loads in flight per lane: with two
+    //      workgroups per CU a load -> wait -> store loop would leave the phase bound by one HBM latency per row ----
+    {
+        const T* xb = (const T*)p.x + n * p.xs[0] + c * p.xs[1];
+        const float bias = p.b ? (float)Elem<T>::load((const T*)p.b + c) : 0.f;
+        const int total = p.TXH * P.XP;
+        for (int i0 = tid; i0 < total; i0 += 256 * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int i = i0 + u * 256;
+                const int ry = (int)FLR_DIV(i, P.XP, P.mXP), rx = i - ry * P.XP;
+                const int iy = tiy0 + ry, ix = tix0 + rx;
+                v[u] = 0.f;
+                if (i < total && iy >= 0 && iy < p.XH && ix >= 0 && ix < p.XW) v[u] = (float)Elem<T>::load(xb + iy * p.xs[2] + ix * p.xs[3]) + bias;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const int i = i0 + u * 256; if (i < total) sX[i] = v[u]; }
+        }
+    }
+    __syncthreads();
+
+    const float upGain = (float)(UP * UP) * p.gain;
+    if (SU == 1) {
+        float fu[FU];
+#pragma unroll
+        for (int k = 0; k < FU; k++) fu[k] = sFu[k];
+        // ---- 2. horizontal up-FIR: sH[ry][v], v = 8g .. 8g+7 ----
+        {
+            const int nG = P.TVWa >> 3;
+            const int items = p.TXH * nG;
+            for (int it = tid; it < items; it += 256) {
+                const int ry = (int)FLR_DIV(it, nG, P.mG), g = it - ry * nG;
+                constexpr int NIN = UP == 2 ? 12 : 8;
+                float xin[NIN];
+                const float* src = sX + ry * P.XP + (UP == 2 ? 4 * g : 2 * g);
+                if (UP == 2) {
+#pragma unroll
+                    for (int q = 0; q < 3; q++) { float4 t = *(const float4*)(src + 4 * q); xin[4*q] = t.x; xin[4*q+1] = t.y; xin[4*q+2] = t.z; xin[4*q+3] = t.w; }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) { float2 t = *(const float2*)(src + 2 * q); xin[2*q] = t.x; xin[2*q+1] = t.y; }
+                }
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int k0 = UP - 1 - (e % UP), b0 = e / UP;
+                    float a = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 6; j++) a = fmaf(xin[b0 + j], fu[k0 + j * UP], a);
+                    o[e] = a;
+                }
+                float* dst = sH + ry * P.HP + 8 * g;
+                *(float4*)dst = make_float4(o[0], o[1], o[2], o[3]);
+                *(float4*)(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
+            }
+        }
+        __syncthreads();
+        // ---- 3. vertical up-FIR: column rux (v = rux + dx), rows vy = 8s .. 8s+7 -> sU[vy - dy][rux] ----
+        {
+            const int items = P.runsV * p.TUW;
+            for (int it = tid; it < items; it += 256) {
+                const int sr = (int)FLR_DIV(it, p.TUW, P.mTUW), rux = it - sr * p.TUW;
+                constexpr int NROW = UP == 2 ? 9 : 7;
+                const float* src = sH + (UP == 2 ? 4 * sr : 2 * sr) * P.HP + rux + dx;
+                float h[NROW];
+#pragma unroll
+                for (int j = 0; j < NROW; j++) h[j] = src[j * P.HP];
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const int k0 = UP - 1 - (e % UP), b0 = e / UP;
+                    float a = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 6; j++) a = fmaf(h[b0 + j], fu[k0 + j * UP], a);
+                    const int ruy = 8 * sr + e - dy;
+                    if (ruy >= 0 && ruy < p.TUH) sU[ruy * P.UPC + rux] = a * upGain;
+                }
+            }
+        }
+    } else {
+        // ---- 3'. 2-D up-FIR (UP == 2, 12x12): input column m -> output columns v = 2m, 2m+1; RN input rows per run.
+        //      acc[i][a] = (column phase 0, column phase 1) of output row 2(n0+i)+a, updated with packed fp32 FMAs:
+        //      (acc.x, acc.y) += (w, w) * (tap of phase 0, tap of phase 1); the taps of step s+1 are fetched during step s ----
+        const int items = P.NR * P.MW;
+        for (int it = tid; it < items; it += 256) {
+            const int run = (int)FLR_DIV(it, P.MW, P.mMW), m = it - run * P.MW;
+            const int n0 = run * RN;
+            const float* src = sX + n0 * P.XP + m;
+            float w[RN + 5][6];
+#pragma unroll
+            for (int r = 0; r < RN + 5; r++)
+#pragma unroll
+                for (int q = 0; q < 6; q++) w[r][q] = src[r * P.XP + q];
+            v2f acc[RN][2];
+#pragma unroll
+            for (int i = 0; i < RN; i++) { acc[i][0] = (v2f)(0.f); acc[i][1] = (v2f)(0.f); }
+            v2f t[13][6];
+            {
+                const float4* tp = (const float4*)sFu;
+#pragma unroll
+                for (int q = 0; q < 3; q++) { float4 v4 = tp[q]; t[0][2*q] = (v2f){v4.x, v4.y}; t[0][2*q+1] = (v2f){v4.z, v4.w}; }
+            }
+#pragma unroll
+            for (int st = 0; st < 12; st++) {
+                const int a = st / 6, jy = st % 6;
+#pragma unroll
+                for (int i = 0; i < RN; i++) FLR_PIN(acc[i][a]);
+                if (st < 11) {
+                    const float4* tp = (const float4*)(sFu + (st + 1) * 12);
+#pragma unroll
+                    for (int q = 0; q < 3; q++) { float4 v4 = tp[q]; t[st + 1][2*q] = (v2f){v4.x, v4.y}; t[st + 1][2*q+1] = (v2f){v4.z, v4.w}; }
+                }
+#pragma unroll
+                for (int i = 0; i < RN; i++)
+#pragma unroll
+                    for (int jx = 0; jx < 6; jx++) acc[i][a] = __builtin_elementwise_fma((v2f)(w[i + jy][jx]), t[st][jx], acc[i][a]);
+            }
+#pragma unroll
+            for (int i = 0; i < RN; i++)
+#pragma unroll
+                for (int a = 0; a < 2; a++) {
+                    const int ruy = 2 * (n0 + i) + a - dy;
+                    if (ruy < 0 || ruy >= p.TUH) continue;
+                    const int rux0 = 2 * m - dx;
+                    if (rux0 >= 0 && rux0 < p.TUW) sU[ruy * P.UPC + rux0] = acc[i][a].x * upGain;
+                    if (rux0 + 1 >= 0 && rux0 + 1 < p.TUW) sU[ruy * P.UPC + rux0 + 1] = acc[i][a].y * upGain;
+                }
+        }
+    }
+    __syncthreads();
+
+    // ---- act: leaky ReLU + clamp with signs, in place on sU (float4 quads); samples beyond the logical image are zero.
+    //      Four quads per lane and iteration so that the sign-byte loads of the gradient pass overlap ----
+    {
+        const int64_t plane64 = (int64_t)plane;
+        const int q4 = P.UPC >> 2;
+        const int coreW = (tx == p.tilesX - 1) ? p.TUW : p.TOW * DOWN;
+        const int coreH = (ty == p.tilesY - 1) ? p.TUH : p.TOH * DOWN;
+        const int items = p.TUH * q4;
+        for (int it0 = tid; it0 < items; it0 += 256 * 4) {
+            uint32_t sbv[4];
+            int ruyv[4], qxv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int it = it0 + u * 256;
+                const int ruy = (int)FLR_DIV(it, q4, P.mQ4), qx = (it - ruy * q4) << 2;
+                ruyv[u] = ruy; qxv[u] = (it < items && qx < p.TUW) ? qx : -1;
+                sbv[u] = 0;
+                if (p.signMode == 2 && qxv[u] >= 0) sbv[u] = flr_load_signs(p, plane64, ux0 + qx + p.sofsx, uy0 + ruy + p.sofsy);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int ruy = ruyv[u], qx = qxv[u];
+                if (qx < 0) continue;
+                const int uy = uy0 + ruy;
+                float4 v4 = *(float4*)(sU + ruy * P.UPC + qx);
+                float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+                uint32_t byte = 0;
+                const uint32_t sb = sbv[u];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int rux = qx + e;
+                    const int ux = ux0 + rux;
+                    float v = vv[e];
+                    if (rux >= p.TUW || ux >= p.UW || uy >= p.UH) { vv[e] = 0.f; continue; }
+                    if (p.signMode == 2) {
+                        uint32_t cde = (sb >> (e << 1)) & 3u;
+                        if (cde & 1) v *= p.slope;
+                        if (cde & 2) v = 0.f;
+                    } else {
+                        uint32_t code = 0;
+                        if (v < 0.f) { v *= p.slope; code = 1; }
+                        if (fabsf(v) > p.clamp) { v = clamp_mag(v, p.clamp); code = 2; }
+                        byte |= code << (e << 1);
+                    }
+                    vv[e] = v;
+                }
+                *(float4*)(sU + ruy * P.UPC + qx) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+                if (p.signMode == 1 && qx < coreW && ruy < coreH) {
+                    int sxx = ux0 + qx;
+                    if (uy < p.SH && (sxx >> 2) < p.SWB) p.s[(sxx >> 2) + (int64_t)p.SWB * (uy + (int64_t)p.SH * plane64)] = (uint8_t)byte;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    T* yb = (T*)p.y + n * p.ys[0] + c * p.ys[1];
+    if (SD == 2) {
+        // ---- 4. 2-D down-FIR (DOWN == 2, 12x12): output column rox, strip of R4 rows, sliding window over tap rows ----
+        const int strips = p.TOH / R4;
+        const int items = strips * p.TOW;
+        for (int it = tid; it < items; it += 256) {
+            const int strip = (int)FLR_DIV(it, p.TOW, P.mTOW), rox = it - strip * p.TOW;
+            const float* ubase = sU + (strip * R4 * 2) * P.UPC + 2 * rox;
+            // acc2[o] = (sum over even kx, sum over odd kx): packed fp32 FMAs on the b64 pairs exactly as they come from LDS
+            v2f acc2[R4];
+#pragma unroll
+            for (int o = 0; o < R4; o++) acc2[o] = (v2f)(0.f);
+#pragma unroll
+            for (int par = 0; par < 2; par++) {
+                // rows of parity `par`; at step j (tap row par + 2j) output o reads row o + j of this list
+#pragma unroll
+                for (int o = 0; o < R4; o++) FLR_PIN(acc2[o]);
+                v2f rows[R4 + 5][6];
+                v2f t[7][6];
+                const float* hb = ubase + par * P.UPC;
+#pragma unroll
+                for (int mrow = 0; mrow < R4; mrow++) {
+                    const v2f* rp = (const v2f*)(hb + (2 * mrow) * P.UPC);
+#pragma unroll
+                    for (int q = 0; q < 6; q++) rows[mrow][q] = rp[q];
+                }
+                {
+                    const v2f* tp = (const v2f*)(sFd + par * 12);
+#pragma unroll
+                    for (int q = 0; q < 6; q++) t[0][q] = tp[q];
+                }
+#pragma unroll
+                for (int j = 0; j < 6; j++) {
+#pragma unroll
+                    for (int o = 0; o < R4; o++) FLR_PIN(acc2[o]);
+                    if (j < 5) {                                   // fetch the next step's row and taps under this step's FMAs
+                        const v2f* rp = (const v2f*)(hb + (2 * (R4 + j)) * P.UPC);
+#pragma unroll
+                        for (int q = 0; q < 6; q++) rows[R4 + j][q] = rp[q];
+                        const v2f* tp = (const v2f*)(sFd + (par + 2 * (j + 1)) * 12);
+#pragma unroll
+                        for (int q = 0; q < 6; q++) t[j + 1][q] = tp[q];
+                    }
+#pragma unroll
+                    for (int o = 0; o < R4; o++)
+#pragma unroll
+                        for (int q = 0; q < 6; q++) acc2[o] = __builtin_elementwise_fma(rows[o + j][q], t[j][q], acc2[o]);
+                }
+            }
+            float acc[R4];
+#pragma unroll
+            for (int o = 0; o < R4; o++) acc[o] = acc2[o].x + acc2[o].y;
+            const int ox = ox0 + rox;
+            if (ox < p.YW) {
+#pragma unroll
+                for (int o = 0; o < R4; o++) {
+                    const int oy = oy0 + strip * R4 + o;
+                    if (oy < p.YH) Elem<T>::store(yb + oy * p.ys[2] + ox * p.ys[3], acc[o]);
+                }
+            }
+        }
+    } else {
+        // ---- 4'. separable down-FIR: vertical (lane = column, strip of RD rows), then horizontal ----
+        constexpr int RD = DOWN == 2 ? 8 : 4;
+        float fd[FD];
+#pragma unroll
+        for (int k = 0; k < FD; k++) fd[k] = sFd[k];
+        {
+            const int strips = p.TOH / RD;
+            const int items = strips * p.TUW;
+            for (int it = tid; it < items; it += 256) {
+                const int strip = (int)FLR_DIV(it, p.TUW, P.mTUW), rux = it - strip * p.TUW;
+                const float* src = sU + (strip * RD * DOWN) * P.UPC + rux;
+                float acc[RD];
+#pragma unroll
+                for (int o = 0; o < RD; o++) acc[o] = 0.f;
+                constexpr int NROWS = DOWN * (RD - 1) + FD;
+#pragma unroll
+                for (int r = 0; r < NROWS; r++) {
+                    const float u = src[r * P.UPC];
+#pragma unroll
+                    for (int o = 0; o < RD; o++) {
+                        const int k = r - DOWN * o;
+                        if (k >= 0 && k < FD) acc[o] = fmaf(u, fd[k], acc[o]);
+                    }
+                }
+#pragma unroll
+                for (int o = 0; o < RD; o++) sV[(strip * RD + o) * P.UPC + rux] = acc[o];
+            }
+        }
+        __syncthreads();
+        {
+            const int items = p.TOH * p.TOW;
+            for (int it = tid; it < items; it += 256) {
+                const int roy = (int)FLR_DIV(it, p.TOW, P.mTOW), rox = it - roy * p.TOW;
+                const int oy = oy0 + roy, ox = ox0 + rox;
+                if (oy >= p.YH || ox >= p.YW) continue;
+                const float* src = sV + roy * P.UPC + DOWN * rox;
+                float a = 0.f;
+                if (DOWN == 2) {
+#pragma unroll
+                    for (int q = 0; q < 6; q++) { float2 t = *(const float2*)(src + 2 * q); a = fmaf(t.x, fd[2*q], a); a = fmaf(t.y, fd[2*q+1], a); }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 6; q++) { float4 t = *(const float4*)(src + 4 * q);
+                        a = fmaf(t.x, fd[4*q], a); a = fmaf(t.y, fd[4*q+1], a); a = fmaf(t.z, fd[4*q+2], a); a = fmaf(t.w, fd[4*q+3], a); }
+                }
+                Elem<T>::store(yb + oy * p.ys[2] + ox * p.ys[3], a);
+            }
+        }
+    }
+}
+
+// host side: tile geometry + launch of the register-blocked kernel; returns false when the configuration is not one of its
+// instantiations (the caller then uses filtered_lrelu_kernel).
+template <class T, int UP, int DOWN, int SU, int SD>
+static bool flr_rb_launch(FlrParams p, hipStream_t st, int* status) {
+    constexpr int FU = 6 * UP, FD = 6 * DOWN, RN = 4, R4 = 8;
+    constexpr int RD = DOWN == 2 ? 8 : 4;
+    constexpr int ROUT = SD == 2 ? R4 : RD;                   // TOH is a multiple of this
+    const int maxW = (SD == 2) ? 64 : (DOWN == 2 ? 64 : 32);
+    int nTx = (p.YW + maxW - 1) / maxW;
+    int TOW = (p.YW + nTx - 1) / nTx;
+    TOW = (TOW + 1) & ~1;
+    if (DOWN == 2 && (TOW & 1)) TOW++;
+    int strips = SD == 2 ? 256 / TOW : 4;
+    if (strips < 1) strips = 1;
+    int needStrips = (p.YH + ROUT - 1) / ROUT;
+    if (strips > needStrips) strips = needStrips;
+    FlrRbParams P;
+    size_t lds = 0;
+    for (;; strips--) {
+        if (strips < 1) return false;
+        const int TOH = strips * ROUT;
+        p.TOW = TOW; p.TOH = TOH;
+        p.TUW = (TOW - 1) * DOWN + FD; p.TUH = (TOH - 1) * DOWN + FD;
+        P.UPC = (p.TUW + 3) & ~3;
+        int szX, szH = 0;
+        if (SU == 1) {
+            P.TVWa = (p.TUW + UP - 1 + 7) & ~7;
+            P.XP = ((UP == 2 ? P.TVWa / 2 + 8 : P.TVWa / 4 + 6) + 3) & ~3;
+            P.HP = P.TVWa + 4;                                   // +4: odd multiple of 4 floats keeps column reads spread over banks
+            P.runsV = (p.TUH + UP - 1 + 7) / 8;
+            p.TXH = UP == 2 ? 4 * P.runsV + 5 : 2 * P.runsV + 5;
+            P.MW = P.NR = 0;
+            szH = p.TXH * P.HP;
+        } else {
+            P.TVWa = 0; P.HP = 0; P.runsV = 0;
+            P.MW = (p.TUW + 1 + 1) / 2;
+            P.NR = ((p.TUH + 1 + 1) / 2 + RN - 1) / RN;
+            P.XP = (P.MW + 5 + 3) & ~3;
+            p.TXH = P.NR * RN + 5;
+        }
+        p.TXW = P.XP;
+        szX = p.TXH * P.XP;
+        const int szU = p.TUH * P.UPC;
+        const int szV = SD == 1 ? TOH * P.UPC : 0;
+        // layout after the filters: [sU][R2]; separable up: sX overlays sU (dead before sU is written), R2 = max(sH, sV);
+        // 2-D up: R2 = max(sX, sV) (sV is written after sX is dead)
+        int szR2;
+        P.ofsU = 0;
+        if (SU == 1) {
+            if (szX > szU) { if (strips > 1) continue; return false; }
+            P.ofsX = 0; P.ofsH = szU; szR2 = szH > szV ? szH : szV; P.ofsV = szU;
+        } else {
+            P.ofsX = szU; P.ofsH = 0; szR2 = szX > szV ? szX : szV; P.ofsV = szU;
+        }
+        const size_t fl = (size_t)(SU == 1 ? FU : FU * FU) + (size_t)(SD == 1 ? FD : FD * FD) + szU + szR2;
+        lds = fl * sizeof(float);
+        if (lds <= 78 * 1024) break;                             // two workgroups per CU
+        if (strips == 1 && lds <= 150 * 1024) break;
+    }
+    // the filter block must keep sU 16-byte aligned
+    static_assert(((SU == 1 ? FU : FU * FU) + (SD == 1 ? FD : FD * FD)) % 4 == 0, "filter block alignment");
+    p.tilesX = (p.YW + p.TOW - 1) / p.TOW; p.tilesY = (p.YH + p.TOH - 1) / p.TOH;
+    if (p.signMode == 1 && (p.TOW * DOWN) % 4 != 0) return false;
+    const int64_t blocks = (int64_t)p.tilesX * p.tilesY * p.N * p.C;
+    if (blocks >= (1ll << 31)) { *status = AGF_EINVAL; agf_set_error("filtered_lrelu: x is too large"); return true; }
+    P.b = p;
+    P.mG = flr_magic(SU == 1 ? P.TVWa >> 3 : 1); P.mTUW = flr_magic(p.TUW); P.mMW = flr_magic(P.MW ? P.MW : 1);
+    P.mQ4 = flr_magic(P.UPC >> 2); P.mTOW = flr_magic(p.TOW); P.mXP = flr_magic(P.XP);
+    auto kern = flr_rb_kernel<T, UP, DOWN, SU, SD, RN, R4>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { agf_set_error("filtered_lrelu: cannot reserve LDS: %s", hipGetErrorString(e)); *status = AGF_ELAUNCH; return true; }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, P);
+    *status = AGF_OK;
+    return true;
+}
+
+template <class T>
+static bool flr_rb_dispatch(const FlrParams& p, hipStream_t st, int* status) {
+    const int su = p.fuh ? 2 : 1, sd = p.fdh ? 2 : 1;
+    const int up = p.up, down = p.down;
+    if (p.fuw != 6 * up || p.fdw != 6 * down) return false;
+    if ((su == 2 && p.fuh != p.fuw) || (sd == 2 && p.fdh != p.fdw)) return false;
+    if (up == 2 && down == 2 && su == 1 && sd == 2) return flr_rb_launch<T, 2, 2, 1, 2>(p, st, status);
+    if (up == 4 && down == 2 && su == 1 && sd == 2) return flr_rb_launch<T, 4, 2, 1, 2>(p, st, status);
+    if (up == 2 && down == 2 && su == 1 && sd == 1) return flr_rb_launch<T, 2, 2, 1, 1>(p, st, status);
+    if (up == 2 && down == 2 && su == 2 && sd == 1) return flr_rb_launch<T, 2, 2, 2, 1>(p, st, status);
+    if (up == 2 && down == 4 && su == 2 && sd == 1) return flr_rb_launch<T, 2, 4, 2, 1>(p, st, status);
+    return false;
+}
+
 extern "C" int agf_filtered_lrelu(const void* x, const float* fu, const float* fd, const void* b, uint8_t* s, void* y, int dtype,
                                   const int32_t x_size[4], const int64_t x_stride[4],
                                   const int32_t y_size[4], const int64_t y_stride[4],
@@ -386,6 +874,17 @@ extern "C" int agf_filtered_lrelu(const void* x, const float* fu, const float* f
     p.gain = gain; p.slope = slope; p.clamp = clamp; p.flip = flip ? 1 : 0;
     // logical upsampled size implied by the output size (filtered_lrelu.cpp:57-73): yw = (uw - (fdw-1) + down-1)/down
     p.UW = (p.YW - 1) * down + p.fdw; p.UH = (p.YH - 1) * down + fdH;
+    {
+        static const bool rb_on = []{ const char* e = getenv("AGF_FLR_RB"); return !(e && e[0] == '0'); }();
+        int status = AGF_OK;
+        bool done = false;
+        if (rb_on) {
+            if (dtype == AGF_F32) done = flr_rb_dispatch<float>(p, (hipStream_t)stream, &status);
+            else if (dtype == AGF_F16) done = flr_rb_dispatch<f16_t>(p, (hipStream_t)stream, &status);
+            else done = flr_rb_dispatch<bf16_t>(p, (hipStream_t)stream, &status);
+        }
+        if (done) { if (status != AGF_OK) return status; AGF_LAUNCH_CHECK(); return AGF_OK; }
+    }
     // tile: start from 64x32 outputs and shrink until everything fits in LDS
     int TOW = 32, TOH = 16;
     while (TOW / 2 >= p.YW && TOW > 4) TOW /= 2;

@@ -1,0 +1,137 @@
+// Layout changes between the planar (NCHW) tensors of the FIR kernels and the channels-last tensors of the MFMA conv.
+//
+//   agf_planar_to_cl_pad  : x [N][C][H][W]                  -> y [N][H+2p][W+2p][Cp]   zero border, zero channels C..Cp-1
+//   agf_cl_to_planar_crop : x [N][H+2p][W+2p][Cp]           -> y [N][C][H][W]          (exact adjoint / inverse of the above)
+//
+// HBM-bound (one read + one write).  A workgroup moves a tile of CT channels x 64 pixels of one image row through LDS:
+// the planar side is accessed as 4-byte units along W (128-byte runs per channel row), the channels-last side as 16-byte
+// vectors along C (CT*sizeof(T) bytes contiguous per pixel); the transposition is the 2-byte / 4-byte LDS access in the middle.
+#include "agf_common.h"
+
+struct LayoutParams {
+    const void* x; void* y;
+    int N, C, H, W, pad, Cp;
+    int tilesW, tilesC;
+};
+
+template <class U, int CT>            // U = uint16_t (bf16 / fp16) or uint32_t (fp32)
+__global__ void __launch_bounds__(256) planar_to_cl_pad_kernel(LayoutParams p) {
+    constexpr int PT = 64;
+    constexpr int VEC = 16 / (int)sizeof(U);                   // channels per 16-byte vector
+    constexpr int LP = PT + 2;                                  // LDS pitch (elements): +2 spreads the transposed reads
+    __shared__ U tile[CT * LP];
+    const int Hp = p.H + 2 * p.pad, Wp = p.W + 2 * p.pad;
+    int bx = blockIdx.x;
+    const int tw = bx % p.tilesW; bx /= p.tilesW;
+    const int tc = bx % p.tilesC;
+    const int yp = bx / p.tilesC;                               // padded row
+    const int n = blockIdx.y;
+    const int c0 = tc * CT, xp0 = tw * PT;                      // padded column of the tile start
+    const int tid = threadIdx.x;
+    const int yi = yp - p.pad;
+    const bool rowIn = yi >= 0 && yi < p.H;
+    U* yrow = (U*)p.y + ((int64_t)(n * Hp + yp) * Wp) * p.Cp;
+    if (rowIn) {
+        // load [CT][PT] from the planar side, elementwise bounds (W may be odd; pad shifts alignment)
+        const U* xb = (const U*)p.x + ((int64_t)n * p.C * p.H + yi) * p.W;
+        for (int i = tid; i < CT * PT; i += 256) {
+            const int c = i / PT, px = i - c * PT;
+            const int cc = c0 + c, xi = xp0 + px - p.pad;
+            U v = 0;
+            if (cc < p.C && xi >= 0 && xi < p.W) v = xb[(int64_t)cc * p.H * p.W + xi];
+            tile[c * LP + px] = v;
+        }
+        __syncthreads();
+    }
+    // store: one 16-byte vector of VEC channels per (pixel, channel group)
+    constexpr int GROUPS = CT / VEC;
+    for (int i = tid; i < PT * GROUPS; i += 256) {
+        const int px = i / GROUPS, g = i - px * GROUPS;
+        const int xp = xp0 + px, cc = c0 + g * VEC;
+        if (xp >= Wp || cc >= p.Cp) continue;
+        U v[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; e++) v[e] = rowIn ? tile[(g * VEC + e) * LP + px] : (U)0;
+        *(uint4*)(yrow + (int64_t)xp * p.Cp + cc) = *(const uint4*)v;
+    }
+}
+
+template <class U, int CT>
+__global__ void __launch_bounds__(256) cl_to_planar_crop_kernel(LayoutParams p) {
+    constexpr int PT = 64;
+    constexpr int VEC = 16 / (int)sizeof(U);
+    constexpr int LP = PT + 2;
+    __shared__ U tile[CT * LP];
+    const int Hp = p.H + 2 * p.pad, Wp = p.W + 2 * p.pad;
+    int bx = blockIdx.x;
+    const int tw = bx % p.tilesW; bx /= p.tilesW;
+    const int tc = bx % p.tilesC;
+    const int yi = bx / p.tilesC;                               // output row
+    const int n = blockIdx.y;
+    const int c0 = tc * CT, x0 = tw * PT;
+    const int tid = threadIdx.x;
+    const U* xrow = (const U*)p.x + ((int64_t)(n * Hp + yi + p.pad) * Wp + p.pad) * p.Cp;
+    constexpr int GROUPS = CT / VEC;
+    for (int i = tid; i < PT * GROUPS; i += 256) {
+        const int px = i / GROUPS, g = i - px * GROUPS;
+        const int xi = x0 + px, cc = c0 + g * VEC;
+        U v[VEC];
+        if (xi < p.W && cc < p.Cp) *(uint4*)v = *(const uint4*)(xrow + (int64_t)xi * p.Cp + cc);
+        else { for (int e = 0; e < VEC; e++) v[e] = 0; }
+#pragma unroll
+        for (int e = 0; e < VEC; e++) tile[(g * VEC + e) * LP + px] = v[e];
+    }
+    __syncthreads();
+    U* yb = (U*)p.y + ((int64_t)n * p.C * p.H + yi) * p.W;
+    for (int i = tid; i < CT * PT; i += 256) {
+        const int c = i / PT, px = i - c * PT;
+        const int cc = c0 + c, xi = x0 + px;
+        if (cc < p.C && xi < p.W) yb[(int64_t)cc * p.H * p.W + xi] = tile[c * LP + px];
+    }
+}
+
+static int layout_common(LayoutParams& p, const void* x, void* y, int dtype, int N, int C, int H, int W, int pad, int Cp, const char* name) {
+    AGF_CHECK(x && y, "layout: null pointer");
+    AGF_CHECK(dtype == AGF_F32 || dtype == AGF_F16 || dtype == AGF_BF16, "layout: dtype must be float16, bfloat16 or float32");
+    AGF_CHECK(N >= 1 && C >= 1 && H >= 1 && W >= 1 && pad >= 0 && Cp >= C, "layout: bad shape");
+    const int vec = dtype == AGF_F32 ? 4 : 8;
+    AGF_CHECK(Cp % vec == 0, "layout: the channels-last channel count must be a multiple of 16 bytes");
+    AGF_CHECK(((uintptr_t)x % 16) == 0 || true, "layout");
+    p.x = x; p.y = y; p.N = N; p.C = C; p.H = H; p.W = W; p.pad = pad; p.Cp = Cp;
+    (void)name;
+    return AGF_OK;
+}
+
+extern "C" int agf_planar_to_cl_pad(const void* x, void* y, int dtype, int32_t N, int32_t C, int32_t H, int32_t W,
+                                    int32_t pad, int32_t Cp, void* stream) {
+    LayoutParams p;
+    int rc = layout_common(p, x, y, dtype, N, C, H, W, pad, Cp, "planar_to_cl_pad");
+    if (rc != AGF_OK) return rc;
+    AGF_CHECK(((uintptr_t)y % 16) == 0, "planar_to_cl_pad: y must be 16-byte aligned");
+    const int CT = dtype == AGF_F32 ? 32 : 64;
+    p.tilesW = (W + 2 * pad + 63) / 64; p.tilesC = (Cp + CT - 1) / CT;
+    const int64_t gx = (int64_t)p.tilesW * p.tilesC * (H + 2 * pad);
+    AGF_CHECK(gx < (1ll << 31) && N < 65536, "planar_to_cl_pad: tensor too large");
+    dim3 grid((unsigned)gx, (unsigned)N);
+    if (dtype == AGF_F32) hipLaunchKernelGGL((planar_to_cl_pad_kernel<uint32_t, 32>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((planar_to_cl_pad_kernel<uint16_t, 64>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    AGF_LAUNCH_CHECK();
+    return AGF_OK;
+}
+
+extern "C" int agf_cl_to_planar_crop(const void* x, void* y, int dtype, int32_t N, int32_t C, int32_t H, int32_t W,
+                                     int32_t pad, int32_t Cp, void* stream) {
+    LayoutParams p;
+    int rc = layout_common(p, x, y, dtype, N, C, H, W, pad, Cp, "cl_to_planar_crop");
+    if (rc != AGF_OK) return rc;
+    AGF_CHECK(((uintptr_t)x % 16) == 0, "cl_to_planar_crop: x must be 16-byte aligned");
+    const int CT = dtype == AGF_F32 ? 32 : 64;
+    p.tilesW = (W + 63) / 64; p.tilesC = (C + CT - 1) / CT;
+    const int64_t gx = (int64_t)p.tilesW * p.tilesC * H;
+    AGF_CHECK(gx < (1ll << 31) && N < 65536, "cl_to_planar_crop: tensor too large");
+    dim3 grid((unsigned)gx, (unsigned)N);
+    if (dtype == AGF_F32) hipLaunchKernelGGL((cl_to_planar_crop_kernel<uint32_t, 32>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((cl_to_planar_crop_kernel<uint16_t, 64>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    AGF_LAUNCH_CHECK();
+    return AGF_OK;
+}

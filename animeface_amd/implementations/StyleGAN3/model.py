@@ -23,7 +23,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ...stylegan3_ops import bias_act, filtered_lrelu, conv2d_resample, upfirdn2d
+from ...stylegan3_ops import bias_act, filtered_lrelu, conv2d_resample, upfirdn2d, layout
 from ..StyleGAN2.conv import conv2d
 
 
@@ -31,38 +31,32 @@ def _native(x):
     return x.is_cuda
 
 
-class _PadToChannelsLast(torch.autograd.Function):
-    """NCHW (any layout) -> zero-padded dense channels-last in one copy; the gradient comes back cropped and NCHW-dense,
-    which is the layout the plane-wise filtered_lrelu kernels read at full bandwidth."""
+class _ZeroPadCL(torch.autograd.Function):
+    """Zero-pad H and W of a (channels-last) tensor into a dense channels-last tensor with one copy; differentiable to any
+    order (its adjoint is the crop below)."""
 
     @staticmethod
     def forward(ctx, x, pad):
         ctx.pad = pad
         N, C, H, W = x.shape
-        if pad == 0:
-            return x.contiguous(memory_format=torch.channels_last)
         y = torch.empty((N, C, H + 2 * pad, W + 2 * pad), dtype=x.dtype, device=x.device, memory_format=torch.channels_last).zero_()
         y[:, :, pad:-pad, pad:-pad].copy_(x)
         return y
 
     @staticmethod
     def backward(ctx, g):
-        return _CropToPlanar.apply(g, ctx.pad), None
+        return _CropCL.apply(g, ctx.pad), None
 
 
-class _CropToPlanar(torch.autograd.Function):
-    """Adjoint of ``_PadToChannelsLast``: crop the border, NCHW-dense result."""
-
+class _CropCL(torch.autograd.Function):
     @staticmethod
     def forward(ctx, g, pad):
         ctx.pad = pad
-        if pad:
-            g = g[:, :, pad:-pad, pad:-pad]
-        return g.contiguous()
+        return g[:, :, pad:-pad, pad:-pad].contiguous(memory_format=torch.channels_last)
 
     @staticmethod
     def backward(ctx, gg):
-        return _PadToChannelsLast.apply(gg, ctx.pad), None
+        return _ZeroPadCL.apply(gg, ctx.pad), None
 
 
 class Linear(nn.Module):
@@ -102,9 +96,19 @@ class ModulatedConv(nn.Module):
         s_in = s * input_gain if input_gain is not None else s
         extra = self.padding - k // 2                      # reference pads k-1; the kernel pads k//2
         assert extra >= 0
-        x = _PadToChannelsLast.apply(x, extra)
-        y = conv2d(x, self.weight * self.scale, s_in, d)
-        return _CropToPlanar.apply(y, 0)                   # planar for filtered_lrelu; its gradient returns channels-last
+        w = self.weight * self.scale
+        cout, cin = w.shape[0], w.shape[1]
+        # planar -> channels-last with the zero border and the channel count rounded up to a 16-byte vector in ONE pass
+        # (agf_planar_to_cl_pad); the conv then runs on padded channel counts and the way back crops them again
+        cin_p, cout_p = layout.padded_channels(cin, x.dtype), layout.padded_channels(cout, x.dtype)
+        x = layout.planar_to_channels_last(x, extra, cin_p)
+        if cin_p != cin or cout_p != cout:
+            w = F.pad(w, [0, 0, 0, 0, 0, cin_p - cin, 0, cout_p - cout])
+            s_in = F.pad(s_in, [0, cin_p - cin])
+            if d is not None:
+                d = F.pad(d, [0, cout_p - cout])
+        y = conv2d(x, w, s_in, d)
+        return layout.channels_last_to_planar(y, 0, cout)  # planar for filtered_lrelu; its gradient returns channels-last
 
 
 def design_filter(numtaps, cutoff, width, fs, radial=False):
@@ -369,7 +373,7 @@ class ConvAct(nn.Module):
             # filters and decimates: same linear map, every piece double-differentiable on this package's kernels (MIOpen's
             # double backward of a strided conv lands on its "naive" kernels: 12 s per R1 iteration at 256x256).
             assert self.down == 2 and k == 3 and self.padding == 1
-            x = conv2d(_PadToChannelsLast.apply(x, 1), weight)
+            x = conv2d(_ZeroPadCL.apply(x, 1), weight)
             x = upfirdn2d.upfirdn2d(x, self.down_filter, down=self.down, padding=0)
         b = self.bias.to(x.dtype) if self.bias is not None else None
         return bias_act.bias_act(x, b, act=self.act_name, gain=self.act_gain)

@@ -160,6 +160,18 @@ int agf_act_bwd_reduce(const void* dy, const void* y, const float* noise, void* 
 int agf_scale_dot(const void* x, const void* t, const float* s, void* dx, float* ds,
                   int dtype, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Layout changes between the planar tensors of the FIR kernels and the channels-last tensors of the MFMA conv (new: the
+ * reference keeps everything NCHW and lets cuDNN pick layouts; its StyleGAN3 layer pads inside F.conv2d, model.py:72).
+ *   agf_planar_to_cl_pad : x [N][C][H][W] dense  ->  y [N][H+2*pad][W+2*pad][Cp] dense, zero border, zero channels C..Cp-1
+ *   agf_cl_to_planar_crop: x [N][H+2*pad][W+2*pad][Cp]  ->  y [N][C][H][W]        (adjoint and, on the interior, inverse)
+ * Cp >= C and Cp * sizeof(T) is a multiple of 16 bytes; the channels-last pointer is 16-byte aligned.
+ */
+int agf_planar_to_cl_pad(const void* x, void* y, int dtype, int32_t N, int32_t C, int32_t H, int32_t W,
+                         int32_t pad, int32_t Cp, void* stream);
+int agf_cl_to_planar_crop(const void* x, void* y, int dtype, int32_t N, int32_t C, int32_t H, int32_t W,
+                          int32_t pad, int32_t Cp, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
