@@ -410,8 +410,8 @@ static __device__ __forceinline__ uint32_t flr_load_signs(const FlrParams& p, in
     return sb;
 }
 
-template <class T, int UP, int DOWN, int SU, int SD, int RN, int R4>
-__global__ void __launch_bounds__(256, 2) flr_rb_kernel(FlrRbParams P) {
+template <class T, int UP, int DOWN, int SU, int SD, int RN, int R4, int NT>
+__global__ void __launch_bounds__(NT, NT == 256 ? 2 : 2) flr_rb_kernel(FlrRbParams P) {
     constexpr int FU = 6 * UP, FD = 6 * DOWN;
     static_assert(SU == 1 || UP == 2, "2-D up filter: factor 2 only");
     static_assert(SD == 1 || DOWN == 2, "2-D down filter: factor 2 only");
@@ -429,16 +429,16 @@ __global__ void __launch_bounds__(256, 2) flr_rb_kernel(FlrRbParams P) {
 
     // ---- filters.  F(k) = f[size-1-k] unless flip.  2-D up taps are stored in the order the polyphase loop consumes them:
     //      sFu[((a*6 + jy)*6 + jx)*2 + b] = F(1-a+2jy, 1-b+2jx) ----
-    if (SU == 1) { for (int i = tid; i < FU; i += 256) sFu[i] = p.fu[(p.flip ? i : FU - 1 - i) * p.fus0]; }
+    if (SU == 1) { for (int i = tid; i < FU; i += NT) sFu[i] = p.fu[(p.flip ? i : FU - 1 - i) * p.fus0]; }
     else {
-        for (int i = tid; i < FU * FU; i += 256) {
+        for (int i = tid; i < FU * FU; i += NT) {
             int b = i & 1, jx = (i >> 1) % 6, jy = (i / 12) % 6, a = i / 72;
             int ky = 1 - a + 2 * jy, kx = 1 - b + 2 * jx;
             sFu[i] = p.fu[(p.flip ? ky : FU - 1 - ky) * p.fus0 + (p.flip ? kx : FU - 1 - kx) * p.fus1];
         }
     }
-    if (SD == 1) { for (int i = tid; i < FD; i += 256) sFd[i] = p.fd[(p.flip ? i : FD - 1 - i) * p.fds0]; }
-    else { for (int i = tid; i < FD * FD; i += 256) { int ky = i / FD, kx = i - ky * FD;
+    if (SD == 1) { for (int i = tid; i < FD; i += NT) sFd[i] = p.fd[(p.flip ? i : FD - 1 - i) * p.fds0]; }
+    else { for (int i = tid; i < FD * FD; i += NT) { int ky = i / FD, kx = i - ky * FD;
             sFd[i] = p.fd[(p.flip ? ky : FD - 1 - ky) * p.fds0 + (p.flip ? kx : FD - 1 - kx) * p.fds1]; } }
 
     int bid = blockIdx.x;
@@ -458,18 +458,18 @@ __global__ void __launch_bounds__(256, 2) flr_rb_kernel(FlrRbParams P) {
         const T* xb = (const T*)p.x + n * p.xs[0] + c * p.xs[1];
         const float bias = p.b ? (float)Elem<T>::load((const T*)p.b + c) : 0.f;
         const int total = p.TXH * P.XP;
-        for (int i0 = tid; i0 < total; i0 += 256 * 8) {
+        for (int i0 = tid; i0 < total; i0 += NT * 8) {
             float v[8];
 #pragma unroll
             for (int u = 0; u < 8; u++) {
-                const int i = i0 + u * 256;
+                const int i = i0 + u * NT;
                 const int ry = (int)FLR_DIV(i, P.XP, P.mXP), rx = i - ry * P.XP;
                 const int iy = tiy0 + ry, ix = tix0 + rx;
                 v[u] = 0.f;
                 if (i < total && iy >= 0 && iy < p.XH && ix >= 0 && ix < p.XW) v[u] = (float)Elem<T>::load(xb + iy * p.xs[2] + ix * p.xs[3]) + bias;
             }
 #pragma unroll
-            for (int u = 0; u < 8; u++) { const int i = i0 + u * 256; if (i < total) sX[i] = v[u]; }
+            for (int u = 0; u < 8; u++) { const int i = i0 + u * NT; if (i < total) sX[i] = v[u]; }
         }
     }
     __syncthreads();
@@ -483,7 +483,7 @@ __global__ void __launch_bounds__(256, 2) flr_rb_kernel(FlrRbParams P) {
         {
             const int nG = P.TVWa >> 3;
             const int items = p.TXH * nG;
-            for (int it = tid; it < items; it += 256) {
+            for (int it = tid; it < items; it += NT) {
                 const int ry = (int)FLR_DIV(it, nG, P.mG), g = it - ry * nG;
                 constexpr int NIN = UP == 2 ? 12 : 8;
                 float xin[NIN];
@@ -514,7 +514,7 @@ __global__ void __launch_bounds__(256, 2) flr_rb_kernel(FlrRbParams P) {
         // ---- 3. vertical up-FIR: column rux (v = rux + dx), rows vy = 8s .. 8s+7 -> sU[vy - dy][rux] ----
         {
             const int items = P.runsV * p.TUW;
-            for (int it = tid; it < items; it += 256) {
+            for (int it = tid; it < items; it += NT) {
                 const int sr = (int)FLR_DIV(it, p.TUW, P.mTUW), rux = it - sr * p.TUW;
                 constexpr int NROW = UP == 2 ? 9 : 7;
                 const float* src = sH + (UP == 2 ? 4 * sr : 2 * sr) * P.HP + rux + dx;
@@ -537,7 +537,7 @@ __global__ void __launch_bounds__(256, 2) flr_rb_kernel(FlrRbParams P) {
         //      acc[i][a] = (column phase 0, column phase 1) of output row 2(n0+i)+a, updated with packed fp32 FMAs:
         //      (acc.x, acc.y) += (w, w) * (tap of phase 0, tap of phase 1); the taps of step s+1 are fetched during step s ----
         const int items = P.NR * P.MW;
-        for (int it = tid; it < items; it += 256) {
+        for (int it = tid; it < items; it += NT) {
             const int run = (int)FLR_DIV(it, P.MW, P.mMW), m = it - run * P.MW;
             const int n0 = run * RN;
             const float* src = sX + n0 * P.XP + m;
@@ -592,12 +592,12 @@ __global__ void __launch_bounds__(256, 2) flr_rb_kernel(FlrRbParams P) {
         const int coreW = (tx == p.tilesX - 1) ? p.TUW : p.TOW * DOWN;
         const int coreH = (ty == p.tilesY - 1) ? p.TUH : p.TOH * DOWN;
         const int items = p.TUH * q4;
-        for (int it0 = tid; it0 < items; it0 += 256 * 4) {
+        for (int it0 = tid; it0 < items; it0 += NT * 4) {
             uint32_t sbv[4];
             int ruyv[4], qxv[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                const int it = it0 + u * 256;
+                const int it = it0 + u * NT;
                 const int ruy = (int)FLR_DIV(it, q4, P.mQ4), qx = (it - ruy * q4) << 2;
                 ruyv[u] = ruy; qxv[u] = (it < items && qx < p.TUW) ? qx : -1;
                 sbv[u] = 0;
@@ -645,7 +645,7 @@ __global__ void __launch_bounds__(256, 2) flr_rb_kernel(FlrRbParams P) {
         // ---- 4. 2-D down-FIR (DOWN == 2, 12x12): output column rox, strip of R4 rows, sliding window over tap rows ----
         const int strips = p.TOH / R4;
         const int items = strips * p.TOW;
-        for (int it = tid; it < items; it += 256) {
+        for (int it = tid; it < items; it += NT) {
             const int strip = (int)FLR_DIV(it, p.TOW, P.mTOW), rox = it - strip * p.TOW;
             const float* ubase = sU + (strip * R4 * 2) * P.UPC + 2 * rox;
             // acc2[o] = (sum over even kx, sum over odd kx): packed fp32 FMAs on the b64 pairs exactly as they come from LDS
@@ -710,7 +710,7 @@ __global__ void __launch_bounds__(256, 2) flr_rb_kernel(FlrRbParams P) {
         {
             const int strips = p.TOH / RD;
             const int items = strips * p.TUW;
-            for (int it = tid; it < items; it += 256) {
+            for (int it = tid; it < items; it += NT) {
                 const int strip = (int)FLR_DIV(it, p.TUW, P.mTUW), rux = it - strip * p.TUW;
                 const float* src = sU + (strip * RD * DOWN) * P.UPC + rux;
                 float acc[RD];
@@ -733,7 +733,7 @@ __global__ void __launch_bounds__(256, 2) flr_rb_kernel(FlrRbParams P) {
         __syncthreads();
         {
             const int items = p.TOH * p.TOW;
-            for (int it = tid; it < items; it += 256) {
+            for (int it = tid; it < items; it += NT) {
                 const int roy = (int)FLR_DIV(it, p.TOW, P.mTOW), rox = it - roy * p.TOW;
                 const int oy = oy0 + roy, ox = ox0 + rox;
                 if (oy >= p.YH || ox >= p.YW) continue;
@@ -755,9 +755,9 @@ __global__ void __launch_bounds__(256, 2) flr_rb_kernel(FlrRbParams P) {
 
 // host side: tile geometry + launch of the register-blocked kernel; returns false when the configuration is not one of its
 // instantiations (the caller then uses filtered_lrelu_kernel).
-template <class T, int UP, int DOWN, int SU, int SD>
+template <class T, int UP, int DOWN, int SU, int SD, int NT>
 static bool flr_rb_launch(FlrParams p, hipStream_t st, int* status) {
-    constexpr int FU = 6 * UP, FD = 6 * DOWN, RN = 4, R4 = 8;
+    constexpr int FU = 6 * UP, FD = 6 * DOWN, RN = 4, R4 = NT == 256 ? 8 : 4;
     constexpr int RD = DOWN == 2 ? 8 : 4;
     constexpr int ROUT = SD == 2 ? R4 : RD;                   // TOH is a multiple of this
     const int maxW = (SD == 2) ? 64 : (DOWN == 2 ? 64 : 32);
@@ -765,7 +765,7 @@ static bool flr_rb_launch(FlrParams p, hipStream_t st, int* status) {
     int TOW = (p.YW + nTx - 1) / nTx;
     TOW = (TOW + 1) & ~1;
     if (DOWN == 2 && (TOW & 1)) TOW++;
-    int strips = SD == 2 ? 256 / TOW : 4;
+    int strips = SD == 2 ? NT / TOW : 4;
     if (strips < 1) strips = 1;
     int needStrips = (p.YH + ROUT - 1) / ROUT;
     if (strips > needStrips) strips = needStrips;
@@ -821,26 +821,32 @@ static bool flr_rb_launch(FlrParams p, hipStream_t st, int* status) {
     P.b = p;
     P.mG = flr_magic(SU == 1 ? P.TVWa >> 3 : 1); P.mTUW = flr_magic(p.TUW); P.mMW = flr_magic(P.MW ? P.MW : 1);
     P.mQ4 = flr_magic(P.UPC >> 2); P.mTOW = flr_magic(p.TOW); P.mXP = flr_magic(P.XP);
-    auto kern = flr_rb_kernel<T, UP, DOWN, SU, SD, RN, R4>;
+    auto kern = flr_rb_kernel<T, UP, DOWN, SU, SD, RN, R4, NT>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { agf_set_error("filtered_lrelu: cannot reserve LDS: %s", hipGetErrorString(e)); *status = AGF_ELAUNCH; return true; }
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, P);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NT), lds, st, P);
     *status = AGF_OK;
     return true;
 }
 
-template <class T>
-static bool flr_rb_dispatch(const FlrParams& p, hipStream_t st, int* status) {
+template <class T, int NT>
+static bool flr_rb_dispatch_nt(const FlrParams& p, hipStream_t st, int* status) {
     const int su = p.fuh ? 2 : 1, sd = p.fdh ? 2 : 1;
     const int up = p.up, down = p.down;
     if (p.fuw != 6 * up || p.fdw != 6 * down) return false;
     if ((su == 2 && p.fuh != p.fuw) || (sd == 2 && p.fdh != p.fdw)) return false;
-    if (up == 2 && down == 2 && su == 1 && sd == 2) return flr_rb_launch<T, 2, 2, 1, 2>(p, st, status);
-    if (up == 4 && down == 2 && su == 1 && sd == 2) return flr_rb_launch<T, 4, 2, 1, 2>(p, st, status);
-    if (up == 2 && down == 2 && su == 1 && sd == 1) return flr_rb_launch<T, 2, 2, 1, 1>(p, st, status);
-    if (up == 2 && down == 2 && su == 2 && sd == 1) return flr_rb_launch<T, 2, 2, 2, 1>(p, st, status);
-    if (up == 2 && down == 4 && su == 2 && sd == 1) return flr_rb_launch<T, 2, 4, 2, 1>(p, st, status);
+    if (up == 2 && down == 2 && su == 1 && sd == 2) return flr_rb_launch<T, 2, 2, 1, 2, NT>(p, st, status);
+    if (up == 4 && down == 2 && su == 1 && sd == 2) return flr_rb_launch<T, 4, 2, 1, 2, NT>(p, st, status);
+    if (up == 2 && down == 2 && su == 1 && sd == 1) return flr_rb_launch<T, 2, 2, 1, 1, NT>(p, st, status);
+    if (up == 2 && down == 2 && su == 2 && sd == 1) return flr_rb_launch<T, 2, 2, 2, 1, NT>(p, st, status);
+    if (up == 2 && down == 4 && su == 2 && sd == 1) return flr_rb_launch<T, 2, 4, 2, 1, NT>(p, st, status);
     return false;
+}
+
+template <class T>
+static bool flr_rb_dispatch(const FlrParams& p, hipStream_t st, int* status) {
+    static const int nt = []{ const char* e = getenv("AGF_FLR_NT"); return e ? atoi(e) : 512; }();
+    return nt == 512 ? flr_rb_dispatch_nt<T, 512>(p, st, status) : flr_rb_dispatch_nt<T, 256>(p, st, status);
 }
 
 extern "C" int agf_filtered_lrelu(const void* x, const float* fu, const float* fd, const void* b, uint8_t* s, void* y, int dtype,
