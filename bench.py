@@ -51,6 +51,19 @@ def cpu_baseline(image_size, seconds_budget=30.0):
                        f'(oracle/training.py, torch {torch.__version__} CPU)')
 
 
+def measured_traffic():
+    """HBM bytes per launch from the PMC passes of tools/pmc_bench_traffic.sh (rocprofv3 cannot run inside this process);
+    the newest profiles/rNN_conv_fwd_traffic.json is used, None when there is none."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r*_conv_fwd_traffic.json')))
+    if not files:
+        return {}
+    with open(files[-1]) as f:
+        d = json.load(f)
+    d['_source'] = 'profiles/' + os.path.basename(files[-1])
+    return d
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -138,10 +151,23 @@ def main():
         if timer is not None:
             summ = timer.summary()
             k = summ.get('conv2d_fwd_kernel')
+            traffic = measured_traffic()
+            # algorithmic HBM bytes of a launch: activations in + out, weights once (bf16)
+            alg = {}
+            for key, recs in timer.by_shape.items():
+                name, n, cin, cout, h, w, ks = key[:7]
+                alg.setdefault(name, [0, 0])
+                alg[name][0] += len(recs) * (n * h * w * (cin + cout) * 2 + cout * cin * ks * ks * 2)
+                alg[name][1] += len(recs)
             if k:
                 out['roofline'] = {'kernel': 'conv2d_fwd_kernel (MFMA implicit-GEMM 3x3/1x1 conv: forward + data-gradient launches)',
                                    'bound': 'mfma', 'achieved': round(k['tflops'], 2), 'peak': MFMA_BF16_PEAK / 1e12,
-                                   'unit': 'TFLOP/s', 'frac': round(k['tflops'] * 1e12 / MFMA_BF16_PEAK, 4), 'traffic': None,
+                                   'unit': 'TFLOP/s', 'frac': round(k['tflops'] * 1e12 / MFMA_BF16_PEAK, 4),
+                                   'traffic': traffic.get('conv2d_fwd', {}).get('traffic_bytes_per_launch'),
+                                   'traffic_unit': 'HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes of this command: '
+                                                   + traffic.get('_source', 'no profile found') + ')',
+                                   'algorithmic_bytes_per_launch': round(alg['conv2d_fwd_kernel'][0] / max(alg['conv2d_fwd_kernel'][1], 1))
+                                   if 'conv2d_fwd_kernel' in alg else None,
                                    'launches': k['launches'], 'avg_launch_ms': round(k['avg_ms'], 4),
                                    'share_of_step_time': round(k['total_ms'] / (dt * 1e3), 4)}
             kw = summ.get('conv2d_wgrad_kernel')
