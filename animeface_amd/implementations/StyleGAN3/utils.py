@@ -72,6 +72,8 @@ class TrainStep:
         self.optimizer_G.step()
 
         update_ema(G, self.G_ema, copy_buffers=True)
+        if hasattr(self.augment, 'update_p'):                 # ADA pipe (reference implementations/ADA/utils.py:73)
+            self.augment.update_p(real_prob.detach())
         self.batches_done += 1
         return D_loss.detach(), G_loss.detach(), fake
 

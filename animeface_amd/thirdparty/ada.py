@@ -1,0 +1,298 @@
+"""Adaptive-discriminator-augmentation pipeline ("Training GANs with Limited Data") on the MI355X operators.
+
+Same constructor arguments, buffers (``p``, ``Hz_geom``, ``Hz_fbank``) and forward semantics as the reference's
+``thirdparty/ada/augment.py`` (``AugmentPipe`` :102-427), including the order and shapes of the random draws, so a run with
+the same random stream reproduces the reference's output (``tests/test_hip_ada.py`` replays it through
+``animeface_amd.rng.cpu_stream()``).  How it runs here:
+
+  * every per-sample decision becomes one row of a batched 3x3 (geometry) or 4x4 (colour) matrix -- tiny fp32 tensor math;
+  * the geometric warp is: reflect-pad -> ``upfirdn2d.upsample2d`` x2 with the 12-tap sym6 low-pass (HIP kernel) ->
+    ``affine_grid`` + bilinear ``grid_sample`` (ATen) -> ``upfirdn2d.downsample2d`` /2 (HIP kernel), reference :258-288;
+  * the colour transform is ONE batched [B,3,3] x [B,3,HW] product + offset, reference :349-358;
+  * image-space filtering builds a per-sample separable filter from the sym2 filter bank and applies it as two grouped
+    1-D convolutions, reference :364-392.
+"""
+import numpy as np
+import scipy.signal
+import torch
+
+from ..stylegan3_ops import upfirdn2d
+from .. import rng
+
+# Orthogonal wavelet low-pass prototypes used by the pipeline (standard Daubechies "least asymmetric" coefficients).
+_SYM2 = [-0.12940952255092145, 0.22414386804185735, 0.836516303737469, 0.48296291314469025]
+_SYM6 = [0.015404109327027373, 0.0034907120842174702, -0.11799011114819057, -0.048311742585633, 0.4910559419267466,
+         0.787641141030194, 0.3379294217276218, -0.07263752278646252, -0.021060292512300564, 0.04472490177066578,
+         0.0017677118642428036, -0.007800708325034148]
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# batched homogeneous matrices: every argument is a python number or a [B] tensor; the result is [B,n,n] (or [n,n])
+
+def _mat(rows, like=None):
+    tensors = [v for row in rows for v in row if isinstance(v, torch.Tensor)]
+    if not tensors:
+        return torch.tensor(rows, dtype=torch.float32, device=None if like is None else like.device)
+    ref = tensors[0]
+    cols = [v if isinstance(v, torch.Tensor) else torch.full_like(ref, float(v)) for row in rows for v in row]
+    return torch.stack(cols, dim=-1).reshape(ref.shape + (len(rows), len(rows[0])))
+
+
+def _shift2(tx, ty, like=None):
+    return _mat([[1, 0, tx], [0, 1, ty], [0, 0, 1]], like)
+
+
+def _zoom2(sx, sy, like=None):
+    return _mat([[sx, 0, 0], [0, sy, 0], [0, 0, 1]], like)
+
+
+def _spin2(theta):
+    c, s = torch.cos(theta), torch.sin(theta)
+    return _mat([[c, -s, 0], [s, c, 0], [0, 0, 1]])
+
+
+def _shift3(t):
+    return _mat([[1, 0, 0, t], [0, 1, 0, t], [0, 0, 1, t], [0, 0, 0, 1]])
+
+
+def _zoom3(s):
+    return _mat([[s, 0, 0, 0], [0, s, 0, 0], [0, 0, s, 0], [0, 0, 0, 1]])
+
+
+def _spin3(axis, theta):
+    """Rotation by ``theta`` about the unit vector ``axis`` (Rodrigues), homogeneous 4x4."""
+    x, y, z = axis[0], axis[1], axis[2]                      # 0-d fp32 tensors: products round exactly like the reference's
+    s, c = torch.sin(theta), torch.cos(theta)
+    k = 1 - c
+    return _mat([[x * x * k + c, x * y * k - z * s, x * z * k + y * s, 0],
+                 [y * x * k + z * s, y * y * k + c, y * z * k - x * s, 0],
+                 [z * x * k - y * s, z * y * k + x * s, z * z * k + c, 0],
+                 [0, 0, 0, 1]])
+
+
+def _band_filter_bank():
+    """4-band filter bank from the sym2 prototype: row 0 = low-pass cascade, rows 1..3 = band-passes (reference :166-176)."""
+    lo = np.asarray(_SYM2)
+    hi = lo * ((-1) ** np.arange(lo.size))
+    lo2 = np.convolve(lo, lo[::-1]) / 2
+    hi2 = np.convolve(hi, hi[::-1]) / 2
+    bank = np.eye(4, 1)
+    for i in range(1, bank.shape[0]):
+        bank = np.dstack([bank, np.zeros_like(bank)]).reshape(bank.shape[0], -1)[:, :-1]     # zero-stuff (x2)
+        bank = scipy.signal.convolve(bank, [lo2])
+        mid = bank.shape[1]
+        bank[i, (mid - hi2.size) // 2: (mid + hi2.size) // 2] += hi2
+    return torch.as_tensor(bank, dtype=torch.float32)
+
+
+class AugmentPipe(torch.nn.Module):
+    def __init__(self, xflip=0, rotate90=0, xint=0, xint_max=0.125,
+                 scale=0, rotate=0, aniso=0, xfrac=0, scale_std=0.2, rotate_max=1, aniso_std=0.2, xfrac_std=0.125,
+                 brightness=0, contrast=0, lumaflip=0, hue=0, saturation=0, brightness_std=0.2, contrast_std=0.5, hue_max=1,
+                 saturation_std=1, imgfilter=0, imgfilter_bands=[1, 1, 1, 1], imgfilter_std=1,
+                 noise=0, cutout=0, noise_std=0.1, cutout_size=0.5):
+        super().__init__()
+        self.register_buffer('p', torch.ones([]))               # overall probability multiplier (what ADA adapts)
+        for name, val in dict(xflip=xflip, rotate90=rotate90, xint=xint, xint_max=xint_max, scale=scale, rotate=rotate, aniso=aniso,
+                              xfrac=xfrac, scale_std=scale_std, rotate_max=rotate_max, aniso_std=aniso_std, xfrac_std=xfrac_std,
+                              brightness=brightness, contrast=contrast, lumaflip=lumaflip, hue=hue, saturation=saturation,
+                              brightness_std=brightness_std, contrast_std=contrast_std, hue_max=hue_max,
+                              saturation_std=saturation_std, imgfilter=imgfilter, imgfilter_std=imgfilter_std, noise=noise,
+                              cutout=cutout, noise_std=noise_std, cutout_size=cutout_size).items():
+            setattr(self, name, float(val))
+        self.imgfilter_bands = list(imgfilter_bands)
+        self.register_buffer('Hz_geom', upfirdn2d.setup_filter(_SYM6))
+        self.register_buffer('Hz_fbank', _band_filter_bank())
+
+    # -- random decisions ------------------------------------------------------------------------------------------
+    def _gate(self, shape, prob, value, neutral, device):
+        """``value`` where a fresh uniform draw of ``shape`` is below ``prob``, else ``neutral`` (draw order: value first)."""
+        keep = rng.rand(shape, device) < prob
+        return torch.where(keep, value, torch.full_like(value, neutral))
+
+    def forward(self, images, debug_percentile=None):
+        assert isinstance(images, torch.Tensor) and images.ndim == 4
+        B, C, H, W = images.shape
+        dev = images.device
+        dbg = None if debug_percentile is None else torch.as_tensor(debug_percentile, dtype=torch.float32, device=dev)
+        probit = None if dbg is None else torch.erfinv(dbg * 2 - 1)          # debug value of a standard normal draw
+        p = self.p
+
+        # ---- pixel blitting + general geometry: G maps OUTPUT pixel coordinates to INPUT coordinates ----
+        eye3 = torch.eye(3, device=dev)
+        G = eye3
+        if self.xflip > 0:
+            i = torch.floor(rng.rand([B], dev) * 2)
+            i = self._gate([B], self.xflip * p, i, 0., dev)
+            if dbg is not None:
+                i = torch.full_like(i, float(torch.floor(dbg * 2)))
+            G = G @ _zoom2(1 / (1 - 2 * i), 1)
+        if self.rotate90 > 0:
+            i = torch.floor(rng.rand([B], dev) * 4)
+            i = self._gate([B], self.rotate90 * p, i, 0., dev)
+            if dbg is not None:
+                i = torch.full_like(i, float(torch.floor(dbg * 4)))
+            G = G @ _spin2(np.pi / 2 * i)
+        if self.xint > 0:
+            t = (rng.rand([B, 2], dev) * 2 - 1) * self.xint_max
+            t = self._gate([B, 1], self.xint * p, t, 0., dev)
+            if dbg is not None:
+                t = torch.full_like(t, float((dbg * 2 - 1) * self.xint_max))
+            G = G @ _shift2(-torch.round(t[:, 0] * W), -torch.round(t[:, 1] * H))
+        if self.scale > 0:
+            s = torch.exp2(rng.randn([B], dev) * self.scale_std)
+            s = self._gate([B], self.scale * p, s, 1., dev)
+            if dbg is not None:
+                s = torch.full_like(s, float(torch.exp2(probit * self.scale_std)))
+            G = G @ _zoom2(1 / s, 1 / s)
+        p_rot = 1 - torch.sqrt((1 - self.rotate * p).clamp(0, 1))          # two chances (pre / post): P(either) = rotate * p
+        if self.rotate > 0:
+            th = (rng.rand([B], dev) * 2 - 1) * np.pi * self.rotate_max
+            th = self._gate([B], p_rot, th, 0., dev)
+            if dbg is not None:
+                th = torch.full_like(th, float((dbg * 2 - 1) * np.pi * self.rotate_max))
+            G = G @ _spin2(th)
+        if self.aniso > 0:
+            s = torch.exp2(rng.randn([B], dev) * self.aniso_std)
+            s = self._gate([B], self.aniso * p, s, 1., dev)
+            if dbg is not None:
+                s = torch.full_like(s, float(torch.exp2(probit * self.aniso_std)))
+            G = G @ _zoom2(1 / s, s)
+        if self.rotate > 0:
+            th = (rng.rand([B], dev) * 2 - 1) * np.pi * self.rotate_max
+            th = self._gate([B], p_rot, th, 0., dev)
+            if dbg is not None:
+                th = torch.zeros_like(th)
+            G = G @ _spin2(th)
+        if self.xfrac > 0:
+            t = rng.randn([B, 2], dev) * self.xfrac_std
+            t = self._gate([B, 1], self.xfrac * p, t, 0., dev)
+            if dbg is not None:
+                t = torch.full_like(t, float(probit * self.xfrac_std))
+            G = G @ _shift2(-t[:, 0] * W, -t[:, 1] * H)
+
+        if G is not eye3:
+            images = self._warp(images, G)
+
+        # ---- colour: M maps input colour (r,g,b,1) to output colour ----
+        eye4 = torch.eye(4, device=dev)
+        M = eye4
+        luma = torch.as_tensor(np.asarray([1, 1, 1, 0]) / np.sqrt(3), dtype=torch.float32, device=dev)
+        vv = torch.outer(luma, luma)
+        if self.brightness > 0:
+            b = rng.randn([B], dev) * self.brightness_std
+            b = self._gate([B], self.brightness * p, b, 0., dev)
+            if dbg is not None:
+                b = torch.full_like(b, float(probit * self.brightness_std))
+            M = _shift3(b) @ M
+        if self.contrast > 0:
+            c = torch.exp2(rng.randn([B], dev) * self.contrast_std)
+            c = self._gate([B], self.contrast * p, c, 1., dev)
+            if dbg is not None:
+                c = torch.full_like(c, float(torch.exp2(probit * self.contrast_std)))
+            M = _zoom3(c) @ M
+        if self.lumaflip > 0:
+            i = torch.floor(rng.rand([B, 1, 1], dev) * 2)
+            i = self._gate([B, 1, 1], self.lumaflip * p, i, 0., dev)
+            if dbg is not None:
+                i = torch.full_like(i, float(torch.floor(dbg * 2)))
+            M = (eye4 - 2 * vv * i) @ M                                      # Householder reflection about the luma axis
+        if self.hue > 0 and C > 1:
+            th = (rng.rand([B], dev) * 2 - 1) * np.pi * self.hue_max
+            th = self._gate([B], self.hue * p, th, 0., dev)
+            if dbg is not None:
+                th = torch.full_like(th, float((dbg * 2 - 1) * np.pi * self.hue_max))
+            M = _spin3(luma, th) @ M
+        if self.saturation > 0 and C > 1:
+            s = torch.exp2(rng.randn([B, 1, 1], dev) * self.saturation_std)
+            s = self._gate([B, 1, 1], self.saturation * p, s, 1., dev)
+            if dbg is not None:
+                s = torch.full_like(s, float(torch.exp2(probit * self.saturation_std)))
+            M = (vv + (eye4 - vv) * s) @ M
+        if M is not eye4:
+            flat = images.reshape([B, C, H * W])
+            if C == 3:
+                flat = M[:, :3, :3] @ flat + M[:, :3, 3:]
+            elif C == 1:
+                Mg = M[:, :3, :].mean(dim=1, keepdims=True)
+                flat = flat * Mg[:, :, :3].sum(dim=2, keepdims=True) + Mg[:, :, 3:]
+            else:
+                raise ValueError('Image must be RGB (3 channels) or L (1 channel)')
+            images = flat.reshape([B, C, H, W])
+
+        # ---- image-space filtering ----
+        if self.imgfilter > 0:
+            images = self._band_filter(images, p, dbg, probit)
+
+        # ---- corruptions ----
+        if self.noise > 0:
+            sigma = rng.randn([B, 1, 1, 1], dev).abs() * self.noise_std
+            sigma = self._gate([B, 1, 1, 1], self.noise * p, sigma, 0., dev)
+            if dbg is not None:
+                sigma = torch.full_like(sigma, float(torch.erfinv(dbg) * self.noise_std))
+            images = images + rng.randn([B, C, H, W], dev) * sigma
+        if self.cutout > 0:
+            size = torch.full([B, 2, 1, 1, 1], self.cutout_size, device=dev)
+            size = self._gate([B, 1, 1, 1, 1], self.cutout * p, size, 0., dev)
+            center = rng.rand([B, 2, 1, 1, 1], dev)
+            if dbg is not None:
+                size = torch.full_like(size, self.cutout_size)
+                center = torch.full_like(center, float(dbg))
+            xs = (torch.arange(W, device=dev).reshape([1, 1, 1, -1]) + 0.5) / W
+            ys = (torch.arange(H, device=dev).reshape([1, 1, -1, 1]) + 0.5) / H
+            outside = torch.logical_or((xs - center[:, 0]).abs() >= size[:, 0] / 2, (ys - center[:, 1]).abs() >= size[:, 1] / 2)
+            images = images * outside.to(torch.float32)
+        return images
+
+    # -- geometric warp ------------------------------------------------------------------------------------------------
+    def _warp(self, images, G):
+        B, C, H, W = images.shape
+        dev = images.device
+        cx, cy = (W - 1) / 2, (H - 1) / 2
+        taps4 = self.Hz_geom.shape[0] // 4
+        # how far the transformed image corners reach outside the frame decides the reflect padding
+        corners = torch.tensor([[-cx, -cy, 1], [cx, -cy, 1], [cx, cy, 1], [-cx, cy, 1]], dtype=torch.float32, device=dev)
+        reach = (G @ corners.t())[:, :2, :].permute(1, 0, 2).flatten(1)                  # [xy, B*4]
+        reach = torch.cat([-reach, reach]).max(dim=1).values                              # x0, y0, x1, y1
+        slack = torch.tensor([taps4 * 2 - cx, taps4 * 2 - cy] * 2, dtype=torch.float32, device=dev)
+        lim = torch.tensor([W - 1, H - 1] * 2, dtype=torch.float32, device=dev)
+        margin = torch.minimum(torch.clamp(reach + slack, min=0), lim)
+        mx0, my0, mx1, my1 = [int(v) for v in margin.ceil().to(torch.int32).tolist()]
+        images = torch.nn.functional.pad(images, [mx0, mx1, my0, my1], mode='reflect')
+        G = _shift2((mx0 - mx1) / 2, (my0 - my1) / 2, like=images) @ G
+        # x2 upsampling with the orthogonal low-pass
+        images = upfirdn2d.upsample2d(x=images, f=self.Hz_geom, up=2)
+        G = _zoom2(2, 2, like=images) @ G @ _zoom2(0.5, 0.5, like=images)
+        G = _shift2(-0.5, -0.5, like=images) @ G @ _shift2(0.5, 0.5, like=images)
+        # resample
+        out_shape = [B, C, (H + taps4 * 2) * 2, (W + taps4 * 2) * 2]
+        G = _zoom2(2 / images.shape[3], 2 / images.shape[2], like=images) @ G @ _zoom2(out_shape[3] / 2, out_shape[2] / 2, like=images)
+        grid = torch.nn.functional.affine_grid(theta=G[:, :2, :], size=out_shape, align_corners=False)
+        images = torch.nn.functional.grid_sample(images, grid, mode='bilinear', padding_mode='zeros', align_corners=False)
+        # /2 with the same low-pass, cropping the filter margins
+        return upfirdn2d.downsample2d(x=images, f=self.Hz_geom, down=2, padding=-taps4 * 2, flip_filter=True)
+
+    # -- image-space band filter ---------------------------------------------------------------------------------------
+    def _band_filter(self, images, p, dbg, probit):
+        B, C, H, W = images.shape
+        dev = images.device
+        nb = self.Hz_fbank.shape[0]
+        assert len(self.imgfilter_bands) == nb
+        power = torch.tensor(np.array([10, 1, 1, 1]) / 13, dtype=torch.float32, device=dev)      # expected 1/f power per band
+        gain = torch.ones([B, nb], device=dev)
+        for i, strength in enumerate(self.imgfilter_bands):
+            t_i = torch.exp2(rng.randn([B], dev) * self.imgfilter_std)
+            t_i = self._gate([B], self.imgfilter * p * strength, t_i, 1., dev)
+            if dbg is not None:
+                t_i = torch.full_like(t_i, float(torch.exp2(probit * self.imgfilter_std))) if strength > 0 else torch.ones_like(t_i)
+            t = torch.ones([B, nb], device=dev)
+            t[:, i] = t_i
+            t = t / (power * t.square()).sum(dim=-1, keepdims=True).sqrt()                        # keep the expected power
+            gain = gain * t
+        taps = (gain @ self.Hz_fbank).unsqueeze(1).repeat([1, C, 1]).reshape([B * C, 1, -1])      # one 1-D filter per plane
+        pad = self.Hz_fbank.shape[1] // 2
+        x = images.reshape([1, B * C, H, W])
+        x = torch.nn.functional.pad(x, [pad, pad, pad, pad], mode='reflect')
+        x = torch.nn.functional.conv2d(x, taps.unsqueeze(2), groups=B * C)
+        x = torch.nn.functional.conv2d(x, taps.unsqueeze(3), groups=B * C)
+        return x.reshape([B, C, H, W])

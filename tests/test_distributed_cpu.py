@@ -76,3 +76,40 @@ def test_gradient_reducer_matches_single_process_large_batch(tmp_path):
         opt.step()
     for k, v in net.state_dict().items():
         torch.testing.assert_close(dp_state[k], v, rtol=1e-5, atol=1e-6)
+
+
+def _ada_worker(rank, world, port, out):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from animeface_amd import distributed as dp
+    from animeface_amd.nnutils.ada import ADA
+    dp.init_distributed()
+    torch.manual_seed(5)
+    logits = torch.randn(8, 8, 1) + torch.linspace(1.5, -1.5, 8).reshape(8, 1, 1)     # global batch of 8 per iteration
+    ada = ADA(4, 2, 1, 0.6)                                                            # per-rank batch 4
+    traj = []
+    for it in range(8):
+        ada.update_p(logits[it, rank * 4:(rank + 1) * 4])
+        traj.append(float(ada.p))
+    if rank == 0:
+        torch.save(traj, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ada_probability_follows_the_global_batch(tmp_path):
+    """Two ranks with half the batch each must walk the same p trajectory as one process with the whole batch
+    (reference rule nnutils/ada.py:25-36 applied to the global batch)."""
+    from animeface_amd.nnutils.ada import ADA
+    out = str(tmp_path / 'ada.pt')
+    mp.start_processes(_ada_worker, args=(2, _free_port(), out), nprocs=2, join=True, start_method='spawn')
+    torch.manual_seed(5)
+    logits = torch.randn(8, 8, 1) + torch.linspace(1.5, -1.5, 8).reshape(8, 1, 1)
+    ada = ADA(8, 2, 1, 0.6)
+    ref = []
+    for it in range(8):
+        ada.update_p(logits[it])
+        ref.append(float(ada.p))
+    assert torch.load(out) == pytest.approx(ref, abs=1e-7)
+    assert max(ref) > 0

@@ -1,0 +1,104 @@
+"""GPU parity of the ADA augmentation pipe on the HIP operators against outputs of the reference's own AugmentPipe / ADA
+(tools/make_golden.py, fixture ``ada``): deterministic ``debug_percentile`` mode, random mode replayed with the same random
+stream (``rng.cpu_stream``), image gradients, the grey-scale path and the ``p`` schedule."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import t
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+FULL = dict(xflip=1, rotate90=1, xint=1, scale=1, rotate=1, aniso=1, xfrac=1, brightness=1, contrast=1, lumaflip=1, hue=1, saturation=1)
+EVERYTHING = dict(FULL, imgfilter=1, noise=1, cutout=1)
+
+
+def close(a, b, tol=2e-4):
+    a, b = a.detach().float().cpu(), b.float()
+    err = (a - b).abs().max().item()
+    assert err <= tol * max(1.0, b.abs().max().item()), err
+
+
+def test_buffers_match_the_reference(golden):
+    from animeface_amd.thirdparty.ada import AugmentPipe
+    g = golden('ada')
+    pipe = AugmentPipe(**FULL)
+    assert set(pipe.state_dict()) == {'p', 'Hz_geom', 'Hz_fbank'}
+    torch.testing.assert_close(pipe.Hz_geom, t(g['Hz_geom']), rtol=0, atol=0)
+    torch.testing.assert_close(pipe.Hz_fbank, t(g['Hz_fbank']), rtol=1e-6, atol=1e-8)
+
+
+@pytest.mark.parametrize('q', [25, 75])
+def test_debug_percentile_outputs(golden, q):
+    from animeface_amd.thirdparty.ada import AugmentPipe
+    from animeface_amd import rng
+    g = golden('ada')
+    x = t(g['x']).to(DEV)
+    pipe = AugmentPipe(**FULL).to(DEV)
+    close(pipe(x, debug_percentile=q / 100), t(g[f'dbg_{q}']))
+    pipe_all = AugmentPipe(**EVERYTHING).to(DEV)
+    with rng.cpu_stream():
+        torch.manual_seed(32)
+        close(pipe_all(x, debug_percentile=q / 100), t(g[f'dbgall_{q}']))
+
+
+@pytest.mark.parametrize('tag,kw,pv', [('ada', FULL, 0.3), ('ada', FULL, 1.0), ('all', EVERYTHING, 0.7)])
+def test_random_mode_replays_the_reference_and_its_gradient(golden, tag, kw, pv):
+    from animeface_amd.thirdparty.ada import AugmentPipe
+    from animeface_amd import rng
+    g = golden('ada')
+    key = f'rand_{tag}_{int(pv * 10)}'
+    pipe = AugmentPipe(**kw).to(DEV)
+    pipe.p.copy_(torch.tensor(pv))
+    x = t(g['x']).to(DEV).requires_grad_(True)
+    with rng.cpu_stream():
+        torch.manual_seed(33)
+        y = pipe(x)
+    close(y, t(g[key]))
+    (gx,) = torch.autograd.grad(y, x, t(g[key + '_dy']).to(DEV))
+    close(gx, t(g[key + '_gx']), tol=5e-4)
+
+
+def test_grey_scale_path(golden):
+    from animeface_amd.thirdparty.ada import AugmentPipe
+    from animeface_amd import rng
+    g = golden('ada')
+    pipe = AugmentPipe(**FULL).to(DEV)
+    with rng.cpu_stream():
+        torch.manual_seed(34)
+        close(pipe(t(g['grey_in']).to(DEV)), t(g['grey_out']))
+
+
+def test_p_schedule_follows_the_reference(golden):
+    from animeface_amd.nnutils.ada import ADA
+    from animeface_amd.implementations.ADA.model import ADA as ADA2
+    g = golden('ada')
+    for make in (lambda: ADA(8, 2, 1, 0.6), lambda: ADA2(2, 1, 0.6, 8, xflip=1)):
+        ada = make().to(DEV)
+        assert float(ada.p) == 0.0
+        traj = []
+        for logits in t(g['ada_logits']).to(DEV):
+            ada.update_p(logits)
+            traj.append(float(ada.p))
+        np.testing.assert_allclose(traj, g['ada_p'], rtol=1e-6, atol=1e-7)
+
+
+def test_ada_training_steps_run_and_adapt_p():
+    import functools
+    from animeface_amd.implementations.StyleGAN3 import utils as U, model as M
+    from animeface_amd.implementations.ADA.model import ADA
+    from animeface_amd.nnutils import update_ema, freeze
+    torch.manual_seed(0)
+    mk = lambda: M.Generator(32, 16, 6, 2, 32, 16, 16, margin_size=4).to(DEV)
+    G, G_ema = mk(), mk()
+    freeze(G_ema)
+    update_ema(G, G_ema, 0., copy_buffers=True)
+    D = M.Discriminator(32, 3, 8, 16).to(DEV)
+    opt_G, opt_D = U.build_optimizers(G, D, 0.0025, 0.01, (0., 0.99))
+    augment = ADA(2, 0.064, 0.6, 8, **FULL).to(DEV)          # p_delta = 8 * 2 / 64 = 0.25 per update
+    real = torch.rand(8, 3, 32, 32, device=DEV) * 2 - 1
+    hist = U.train(4, [real], 16, torch.randn(2, 16, device=DEV), G, G_ema, D, opt_G, opt_D, 3., 2, augment, torch.device(DEV), True,
+                   log_every=1)
+    assert len(hist) == 4 and all(np.isfinite(h[1]) and np.isfinite(h[2]) for h in hist)
+    assert float(augment.p) in (0.0, 0.25, 0.5)              # two updates of +-0.25, clamped at 0
+    assert augment._num_iter == 0

@@ -602,11 +602,63 @@ def gen_sg3_train():
     save('sg3_train', **arrays)
 
 
+# ------------------------------------------------------------------------------------------------
+# ADA: AugmentPipe (reference thirdparty/ada/augment.py) and the p schedule (nnutils/ada.py, implementations/ADA/model.py)
+
+def gen_ada():
+    from thirdparty.ada.augment import AugmentPipe
+    from nnutils.ada import ADA
+    arrays = {}
+    g = torch.Generator().manual_seed(31)
+    x = torch.rand(4, 3, 32, 32, generator=g) * 2 - 1
+    arrays['x'] = x
+    full = dict(xflip=1, rotate90=1, xint=1, scale=1, rotate=1, aniso=1, xfrac=1, brightness=1, contrast=1, lumaflip=1, hue=1,
+                saturation=1)
+    everything = dict(full, imgfilter=1, noise=1, cutout=1)
+    pipe = AugmentPipe(**full)
+    arrays['Hz_geom'] = pipe.Hz_geom
+    arrays['Hz_fbank'] = pipe.Hz_fbank
+    for q in (0.25, 0.75):
+        arrays[f'dbg_{int(q * 100)}'] = pipe(x, debug_percentile=q)
+    pipe_all = AugmentPipe(**everything)
+    for q in (0.25, 0.75):                                   # noise draws randn even in debug mode: seed it
+        torch.manual_seed(32)
+        arrays[f'dbgall_{int(q * 100)}'] = pipe_all(x, debug_percentile=q)
+    # random mode at three strengths, default ADA augment set and the full set, with gradients w.r.t. the images
+    for tag, kw in (('ada', full), ('all', everything)):
+        for pv in ((0.3, 1.0) if tag == 'ada' else (0.7,)):
+            pipe_r = AugmentPipe(**kw)
+            pipe_r.p.copy_(torch.tensor(pv))
+            xr = x.clone().requires_grad_(True)
+            torch.manual_seed(33)
+            y = pipe_r(xr)
+            dy = torch.randn(y.shape, generator=g)
+            (gx,) = torch.autograd.grad(y, xr, dy)
+            arrays[f'rand_{tag}_{int(pv * 10)}'] = y
+            arrays[f'rand_{tag}_{int(pv * 10)}_dy'] = dy
+            arrays[f'rand_{tag}_{int(pv * 10)}_gx'] = gx
+    # grey-scale path
+    pipe_g = AugmentPipe(**full)
+    torch.manual_seed(34)
+    arrays['grey_in'] = x[:, :1].clone()
+    arrays['grey_out'] = pipe_g(x[:, :1])
+    # p schedule: scripted logits, batch 8, interval 2, target 1 kimg -> p_delta = 0.016
+    ada = ADA(8, 2, 1, 0.6)
+    logits = torch.randn(12, 8, 1, generator=g) + torch.linspace(1.5, -1.5, 12).reshape(12, 1, 1)
+    traj = []
+    for t in range(12):
+        ada.update_p(logits[t])
+        traj.append(float(ada.p))
+    arrays['ada_logits'] = logits
+    arrays['ada_p'] = np.array(traj)
+    save('ada', **arrays)
+
+
 if __name__ == '__main__':
     os.environ.setdefault('PYTHONDONTWRITEBYTECODE', '1')
     torch.set_num_threads(8)
     import_reference()
-    which = sys.argv[1:] or ['upfirdn2d', 'equiv', 'bias_act', 'filtered_lrelu', 'sg2_model', 'train', 'sg3_model', 'sg3_train']
+    which = sys.argv[1:] or ['upfirdn2d', 'equiv', 'bias_act', 'filtered_lrelu', 'sg2_model', 'train', 'sg3_model', 'sg3_train', 'ada']
     if 'upfirdn2d' in which:
         gen_upfirdn2d()
     if 'equiv' in which:
@@ -623,3 +675,5 @@ if __name__ == '__main__':
         gen_sg3_model()
     if 'sg3_train' in which:
         gen_sg3_train()
+    if 'ada' in which:
+        gen_ada()
