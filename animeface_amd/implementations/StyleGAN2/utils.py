@@ -55,7 +55,10 @@ class TrainStep:
         self.G, self.G_ema, self.D = G, G_ema, D
         self.optimizer_G, self.optimizer_D = optimizer_G, optimizer_D
         self.r1_lambda, self.pl_lambda, self.d_k, self.g_k = r1_lambda, pl_lambda, d_k, g_k
-        self.augment = functools.partial(DiffAugment, policy=policy)
+        # policy 'ada' selects the adaptive pipe of BASELINE config "StyleGAN2 256 + ADA + R1" (built on the first batch, whose size
+        # fixes the p step); any other string is a DiffAugment policy as in the reference (utils.py:160)
+        self.ada = None
+        self.augment = (lambda x: self._ada_pipe(x)(x)) if policy == 'ada' else functools.partial(DiffAugment, policy=policy)
         self.latent_dim, self.sampler = latent_dim, sampler
         self.reducer_G, self.reducer_D = reducer_G, reducer_D
         self.loss = NonSaturatingLoss()
@@ -64,6 +67,12 @@ class TrainStep:
         self.batches_done = 0
         if hasattr(G, 'set_fused_epilogue'):
             G.set_fused_epilogue(pl_lambda == 0)     # the fused modulated conv has no double backward (path length needs it)
+
+    def _ada_pipe(self, x):
+        if self.ada is None:
+            from ...nnutils.ada import ADA
+            self.ada = ADA(x.size(0)).to(x.device)
+        return self.ada
 
     def _zero(self, opt, reducer):
         if reducer is not None:
@@ -97,6 +106,8 @@ class TrainStep:
 
         if self.G_ema is not None:
             update_ema(G, self.G_ema)
+        if self.ada is not None:
+            self.ada.update_p(self._real_prob)
         self.batches_done += 1
         return D_loss.detach(), G_loss.detach(), fake
 
@@ -105,6 +116,7 @@ class TrainStep:
         z = self.sampler((real.size(0), self.latent_dim))
         real_aug = self.augment(real)
         real_prob = D(real_aug)
+        self._real_prob = real_prob.detach()
         with torch.no_grad():
             fake, _ = G(z)
         fake_aug = self.augment(fake)
