@@ -135,3 +135,39 @@ extern "C" int agf_cl_to_planar_crop(const void* x, void* y, int dtype, int32_t 
     AGF_LAUNCH_CHECK();
     return AGF_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// agf_prep_weights: fp32 master weights [Cout][Cin][k][k]  ->  the conv kernels' operand layouts in ONE launch:
+//   wq  [Cout][kh][kw][Cin]   = w * coef                                   (forward)
+//   wft [Cin][kh][kw][Cout]   = w[co][ci][k-1-kh][k-1-kw] * coef           (data gradient: flipped taps, swapped channel axes)
+// in the activation dtype.  Replaces 3 + 5 ATen launches (mul, cast, layout copy / flip, transpose, ...) per layer and half-step.
+template <class T>
+__global__ void __launch_bounds__(256) prep_weights_kernel(const float* __restrict__ w, T* __restrict__ wq, T* __restrict__ wft,
+                                                           int Cout, int Cin, int kk, float coef) {
+    const int64_t total = (int64_t)Cout * Cin * kk;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int tap = (int)(i % kk);
+        const int64_t r = i / kk;
+        const int ci = (int)(r % Cin), co = (int)(r / Cin);
+        const float v = w[i] * coef;
+        if (wq) Elem<T>::store(wq + ((int64_t)co * kk + tap) * Cin + ci, v);
+        if (wft) Elem<T>::store(wft + ((int64_t)ci * kk + (kk - 1 - tap)) * Cout + co, v);
+    }
+}
+
+extern "C" int agf_prep_weights(const float* w, void* wq, void* wft, int dtype, int32_t Cout, int32_t Cin, int32_t ksize,
+                                float coef, void* stream) {
+    AGF_CHECK(w && (wq || wft), "prep_weights: null pointer");
+    AGF_CHECK(dtype == AGF_F32 || dtype == AGF_F16 || dtype == AGF_BF16, "prep_weights: dtype must be float16, bfloat16 or float32");
+    AGF_CHECK(Cout >= 1 && Cin >= 1 && ksize >= 1, "prep_weights: bad shape");
+    const int kk = ksize * ksize;
+    const int64_t total = (int64_t)Cout * Cin * kk;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == AGF_F32) hipLaunchKernelGGL((prep_weights_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st, w, (float*)wq, (float*)wft, Cout, Cin, kk, coef);
+    else if (dtype == AGF_F16) hipLaunchKernelGGL((prep_weights_kernel<f16_t>), dim3((unsigned)blocks), dim3(256), 0, st, w, (f16_t*)wq, (f16_t*)wft, Cout, Cin, kk, coef);
+    else hipLaunchKernelGGL((prep_weights_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, st, w, (bf16_t*)wq, (bf16_t*)wft, Cout, Cin, kk, coef);
+    AGF_LAUNCH_CHECK();
+    return AGF_OK;
+}

@@ -60,6 +60,26 @@ def _ohwi(w):
     return w.contiguous(memory_format=torch.channels_last)
 
 
+def _empty_ohwi(cout, cin, k, dtype, device):
+    """Uninitialised [cout,cin,k,k] tensor whose memory order is [cout][kh][kw][cin]."""
+    return torch.empty((cout, k, k, cin), dtype=dtype, device=device).permute(0, 3, 1, 2)
+
+
+def prep_weights_raw(w, coef, dtype, want_q=True, want_ft=False):
+    """One ``agf_prep_weights`` launch: (w * coef) in ``dtype`` as OHWI (``wq``) and / or as the flipped, channel-swapped OHWI
+    weights of the data-gradient convolution (``wft``, logical shape [Cin,Cout,k,k]).  No autograd."""
+    Cout, Cin, k, _ = w.shape
+    w = w.detach()
+    if w.dtype != torch.float32 or not w.is_contiguous():
+        w = w.float().contiguous()
+    wq = _empty_ohwi(Cout, Cin, k, dtype, w.device) if want_q else None
+    wft = _empty_ohwi(Cin, Cout, k, dtype, w.device) if want_ft else None
+    rc = _lib.lib().agf_prep_weights(_lib.ptr(w), _lib.ptr(wq), _lib.ptr(wft), _lib._DTYPES[dtype], Cout, Cin, k, float(coef),
+                                     _lib.stream_ptr(w))
+    _lib.check(rc, 'prep_weights')
+    return wq, wft
+
+
 def conv2d_fwd_raw(x, w, in_scale=None, out_scale=None, bias=None, noise=None, residual=None,
                    act=ACT_LINEAR, alpha=0.2, gain=1.0, prepared=False):
     """One ``agf_conv2d_fwd`` launch.  x: [N,Cin,H,W] bf16 channels_last; w: [Cout,Cin,k,k] (any float dtype).
@@ -72,7 +92,7 @@ def conv2d_fwd_raw(x, w, in_scale=None, out_scale=None, bias=None, noise=None, r
     if x.dtype not in (torch.bfloat16, torch.float32):
         raise RuntimeError('conv2d: activations must be bfloat16 (MFMA path) or float32 (reference-precision path)')
     x = x.contiguous(memory_format=torch.channels_last)
-    wq = w if prepared else _ohwi(w.to(x.dtype))       # prepared: already OHWI in the activation dtype
+    wq = w if prepared else prep_weights_raw(w, 1.0, x.dtype)[0]       # prepared: already OHWI in the activation dtype
     y = torch.empty((N, Cout, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
     in_scale, out_scale, bias, noise = _f32(in_scale), _f32(out_scale), _f32(bias), _f32(noise)
     if residual is not None:
@@ -100,9 +120,7 @@ def conv2d_wgrad_raw(x, dy, ksize, in_scale=None, out_scale=None, scale=1.0):
         raise RuntimeError('conv2d_wgrad: x and dy must both be bfloat16 or both float32')
     x = x.contiguous(memory_format=torch.channels_last)
     dy = dy.contiguous(memory_format=torch.channels_last)
-    dw = torch.zeros((Cout, Cin, ksize, ksize), dtype=torch.float32, device=x.device).contiguous(memory_format=torch.channels_last)
-    if ksize == 1:   # channels_last strides of a [Cout,Cin,1,1] tensor are ambiguous; memory is [Cout][Cin] either way
-        dw = torch.zeros((Cout, Cin, 1, 1), dtype=torch.float32, device=x.device)
+    dw = torch.zeros((Cout, ksize, ksize, Cin), dtype=torch.float32, device=x.device).permute(0, 3, 1, 2)   # memory OHWI, one fill
     in_scale, out_scale = _f32(in_scale), _f32(out_scale)
     timer = KernelTimer.active
     ev0 = timer.start() if timer is not None else None
@@ -219,7 +237,11 @@ def act_bwd_reduce_raw(dy, y, noise, alpha, want_sums):
     """One ``agf_act_bwd_reduce`` launch: g = dy * lrelu'(y) and (optionally) the three per-(n,c) sums."""
     N, C, H, W = y.shape
     g = torch.empty_like(y)
-    sums = [torch.zeros((N, C), dtype=torch.float32, device=y.device) if w else None for w in want_sums]
+    pool = torch.zeros((sum(bool(w) for w in want_sums), N, C), dtype=torch.float32, device=y.device) if any(want_sums) else None
+    sums, j = [], 0
+    for w in want_sums:                                       # one fill for all requested sum buffers
+        sums.append(pool[j] if w else None)
+        j += bool(w)
     rc = _lib.lib().agf_act_bwd_reduce(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(_f32(noise)), _lib.ptr(g),
                                        _lib.ptr(sums[0]), _lib.ptr(sums[1]), _lib.ptr(sums[2]),
                                        _lib.dtype_code(y), N, H, W, C, float(alpha), _lib.stream_ptr(y))
@@ -278,13 +300,11 @@ def prepared_weights(weight, coef, dtype, need_ft=False):
         ent = _Prepared()
         ent.coef, ent.wq_ft = coef, None
         ent.ref = weakref.ref(weight) if cacheable else None
-        with torch.no_grad():
-            ent.wq = _ohwi((weight.detach() * coef).to(dtype))
+        ent.wq, ent.wq_ft = prep_weights_raw(weight, coef, dtype, True, need_ft)
         if cacheable:
             _prep_cache[(id(weight), dtype)] = ent
     if need_ft and ent.wq_ft is None:
-        with torch.no_grad():
-            ent.wq_ft = _ohwi(flip_transpose(weight.detach() * coef).to(dtype))
+        ent.wq_ft = prep_weights_raw(weight, coef, dtype, False, True)[1]
     return ent
 
 

@@ -172,6 +172,13 @@ int agf_planar_to_cl_pad(const void* x, void* y, int dtype, int32_t N, int32_t C
 int agf_cl_to_planar_crop(const void* x, void* y, int dtype, int32_t N, int32_t C, int32_t H, int32_t W,
                           int32_t pad, int32_t Cp, void* stream);
 
+/* fp32 master weights [Cout][Cin][k][k] -> operand layouts of agf_conv2d_fwd in the activation dtype, one launch:
+ *   wq [Cout][kh][kw][Cin] = w * coef (nullable);   wft [Cin][kh][kw][Cout] = w[co][ci][k-1-kh][k-1-kw] * coef (nullable; the
+ *   weights of the data-gradient convolution).  coef is the equalised-learning-rate constant of ELR / ModulatedConv2d
+ *   (implementations/StyleGAN2/model.py:29-37,105), which the reference multiplies into activations or weights on every call. */
+int agf_prep_weights(const float* w, void* wq, void* wft, int dtype, int32_t Cout, int32_t Cin, int32_t ksize,
+                     float coef, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
