@@ -48,7 +48,11 @@ class ELR(nn.Module):
     def forward(self, x):
         if isinstance(self.layer, nn.Conv2d):
             return elr_conv2d(self, x)
-        return F.linear(x.float() * self.coef, self.layer.weight, self.layer.bias)
+        # (x * coef) @ W^T + b with coef folded into the GEMM's alpha: one launch instead of two (and one less in backward)
+        x = x.float()
+        if x.dim() == 2 and self.layer.bias is not None:
+            return torch.addmm(self.layer.bias, x, self.layer.weight.t(), alpha=self.coef)
+        return F.linear(x * self.coef, self.layer.weight, self.layer.bias)
 
 
 def elr_conv2d(elr, x, act=None, residual=None, gain=1.0):

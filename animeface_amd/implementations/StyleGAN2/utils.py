@@ -65,8 +65,17 @@ class TrainStep:
         self.r1_loss = r1_regularizer()
         self.pl_mean = 0.
         self.batches_done = 0
+        import os
+        self.merge_d_passes = os.environ.get('AGF_MERGE_D', '1') != '0'
         if hasattr(G, 'set_fused_epilogue'):
             G.set_fused_epilogue(pl_lambda == 0)     # the fused modulated conv has no double backward (path length needs it)
+
+    def _mbsd_group_size(self):
+        from .model import MiniBatchStdDev
+        for m in self.D.modules():
+            if isinstance(m, MiniBatchStdDev):
+                return m.group_size
+        return None
 
     def _ada_pipe(self, x):
         if self.ada is None:
@@ -115,16 +124,34 @@ class TrainStep:
         G, D = self.G, self.D
         z = self.sampler((real.size(0), self.latent_dim))
         real_aug = self.augment(real)
-        real_prob = D(real_aug)
-        self._real_prob = real_prob.detach()
         with torch.no_grad():
             fake, _ = G(z)
         fake_aug = self.augment(fake)
-        fake_prob = D(fake_aug.detach())
+        B = real.size(0)
+        groups = self._mbsd_group_size()
+        one_pass = self.merge_d_passes and groups is not None and B % groups == 0
         if it % self.d_k == 0 and self.r1_lambda > 0 and it != 0:
+            # the penalty REPLACES the GAN loss: D(real_aug) / D(fake_aug) of the reference (utils.py:63-70) do not reach the loss
+            # and D has no state to update, so they are only evaluated when the ADA statistic needs D(real_aug)
+            if self.ada is not None:
+                with torch.no_grad():
+                    self._real_prob = D(real_aug)
             r1 = self.r1_loss(real, D, None)
-            D_loss = r1 * self.r1_lambda * self.d_k          # replaces the GAN loss on this iteration
+            D_loss = r1 * self.r1_lambda * self.d_k
         else:
+            if one_pass:
+                # D(real_aug) and D(fake_aug) as ONE batch-2B pass.  Samples are independent through D except for the
+                # minibatch-stddev layer, whose groups are {m, m + B/g, m + 2B/g, ...} (reshape(g, -1, ...), model.py:221-236):
+                # interleaving the two batches in chunks of B/g keeps every group inside the real or the fake half, with
+                # exactly the members it has in two separate passes.
+                fake_in = fake_aug.detach()
+                both = torch.cat([c for pair in zip(real_aug.chunk(groups), fake_in.chunk(groups)) for c in pair])
+                prob = D(both).reshape(groups, 2, B // groups, -1)
+                real_prob, fake_prob = prob[:, 0].reshape(B, -1), prob[:, 1].reshape(B, -1)
+            else:
+                real_prob = D(real_aug)
+                fake_prob = D(fake_aug.detach())
+            self._real_prob = real_prob.detach()
             D_loss = self.loss.d_loss(real_prob, fake_prob)
         D_loss.backward()
         return D_loss

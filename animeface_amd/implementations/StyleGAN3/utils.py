@@ -35,6 +35,13 @@ class TrainStep:
         self.gp_fn = r1_regularizer()
         self.batches_done = 0
 
+    def _mbsd_group_size(self):
+        from .model import MinibatchStdDev
+        for m in self.D.modules():
+            if isinstance(m, MinibatchStdDev):
+                return m.group_size
+        return None
+
     @staticmethod
     def _zero(opt, reducer):
         if reducer is not None:
@@ -51,8 +58,16 @@ class TrainStep:
         fake = G(z)
         real_aug = self.augment(real)
         fake_aug = self.augment(fake)
-        real_prob = D(real_aug)
-        fake_prob = D(fake_aug.detach())
+        B, g = real.size(0), self._mbsd_group_size()
+        if g is not None and B % g == 0:
+            # one batch-2B pass; interleaving in chunks of B/g keeps the minibatch-stddev groups {m, m + B/g, ...} of the two
+            # halves exactly as they are in separate passes (same argument as StyleGAN2.utils.TrainStep._d_half)
+            both = torch.cat([c for pair in zip(real_aug.chunk(g), fake_aug.detach().chunk(g)) for c in pair])
+            prob = D(both).reshape(g, 2, B // g, -1)
+            real_prob, fake_prob = prob[:, 0].reshape(B, -1), prob[:, 1].reshape(B, -1)
+        else:
+            real_prob = D(real_aug)
+            fake_prob = D(fake_aug.detach())
         D_loss = self.adv_fn.d_loss(real_prob, fake_prob)
         if self.gp_lambda > 0 and self.batches_done % self.gp_every == 0:
             D_loss = D_loss + self.gp_fn(real, D, None) * self.gp_lambda
