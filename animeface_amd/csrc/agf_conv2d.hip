@@ -306,15 +306,30 @@ __global__ void __launch_bounds__(256) conv2d_fwd_ws_kernel(ConvParams p) {
     const int wm = BM == 64 ? (wave >> 1) : 0, wn = BM == 64 ? (wave & 1) : wave;
     const int l31 = lane & 31, lhi = lane >> 5;
 
-    // ---- weights: once per block ----
-    for (int v = tid; v < TAPS * BM * VPR; v += 256) {
-        int cv = v % VPR, row = v / VPR;
-        int tap = row / BM, co = row - tap * BM;
-        int gco = co0 + co, gc = cv * 8;
-        u32x4 val = {0u, 0u, 0u, 0u};
-        if (gco < p.Cout && gc < p.Cin) val = *(const u32x4*)(p.w + ((int64_t)gco * TAPS + tap) * p.Cin + gc);
-        *(u32x4*)(sW + row * PITCH + cv * 8) = val;
-    }
+    // ---- weights: once per block -- or, with a style scale, once per IMAGE the block works on: the per-(n,ci) input scale is
+    //      folded into the LDS-resident weights (W * s[n]) instead of into every staged activation vector, so the patch staging
+    //      of the scaled instantiation is as cheap as the unscaled one.  A block then walks a CONTIGUOUS range of pixel tiles
+    //      (image-major), so it re-stages the weights only when it crosses into the next image (once or twice per launch) ----
+    auto stage_weights = [&](int n) {
+        for (int v = tid; v < TAPS * BM * VPR; v += 256) {
+            int cv = v % VPR, row = v / VPR;
+            int tap = row / BM, co = row - tap * BM;
+            int gco = co0 + co, gc = cv * 8;
+            u32x4 val = {0u, 0u, 0u, 0u};
+            if (gco < p.Cout && gc < p.Cin) {
+                val = *(const u32x4*)(p.w + ((int64_t)gco * TAPS + tap) * p.Cin + gc);
+                if (IN_SCALE && n < p.N) val = scale_vec8(val, p.in_scale + (int64_t)n * p.Cin + gc);
+            }
+            *(u32x4*)(sW + row * PITCH + cv * 8) = val;
+        }
+    };
+    const int tilesPerImage = p.tilesH * p.tilesW;                  // TI == 1 in this kernel
+    const int perWorker = (p.pixTiles + workers - 1) / workers;
+    const int ptBegin = IN_SCALE ? worker * perWorker : worker;
+    const int ptEnd = IN_SCALE ? (ptBegin + perWorker < p.pixTiles ? ptBegin + perWorker : p.pixTiles) : p.pixTiles;
+    const int ptStep = IN_SCALE ? 1 : workers;
+    int curN = ptBegin / tilesPerImage;
+    stage_weights(curN);
 
     int bBase[NJ], qc[NJ], qr[NJ], qi[NJ];
 #pragma unroll
@@ -345,24 +360,14 @@ __global__ void __launch_bounds__(256) conv2d_fwd_ws_kernel(ConvParams p) {
         const int th = tq % p.tilesH;
         const int tn = tq / p.tilesH;
         const int n0 = tn * p.TI, h0 = th * p.TH, w0 = tw * p.TW;
-        f32x4 sc0 = {1.f, 1.f, 1.f, 1.f}, sc1 = sc0;            // TI == 1 here: one (n, channel group) per thread per tile
-        if (IN_SCALE) {
-            const int gcs = (tid % VPR) * 8;
-            if (n0 < p.N && gcs < p.Cin) {
-                const float* sc = p.in_scale + (int64_t)n0 * p.Cin + gcs;
-                sc0 = *(const f32x4*)sc; sc1 = *(const f32x4*)(sc + 4);
-            }
-        }
 #pragma unroll
         for (int i = 0; i < XV; i++) {
             const int gc = ((tid + i * 256) % VPR) * 8;
             u32x4 val = {0u, 0u, 0u, 0u};
             if (xrel[i] >= 0) {
                 int n = n0 + (xrel[i] >> 20), h = h0 + ((xrel[i] >> 10) & 1023) - 8, w = w0 + (xrel[i] & 1023) - 8;
-                if (n < p.N && h >= 0 && h < p.H && w >= 0 && w < p.W && gc < p.Cin) {
+                if (n < p.N && h >= 0 && h < p.H && w >= 0 && w < p.W && gc < p.Cin)
                     val = *(const u32x4*)(p.x + (((int64_t)n * p.H + h) * p.W + w) * p.Cin + gc);
-                    if (IN_SCALE) val = scale_vec8_reg(val, sc0, sc1);
-                }
             }
             xreg[i] = val;
         }
@@ -382,12 +387,12 @@ __global__ void __launch_bounds__(256) conv2d_fwd_ws_kernel(ConvParams p) {
         f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         ebias[rg] = (p.bias && co < p.Cout) ? *(const f32x4*)(p.bias + co) : zero;
     }
-    int pt = worker;
-    if (pt < p.pixTiles) { load_patch(pt); store_patch(); }
+    int pt = ptBegin;
+    if (pt < ptEnd) { load_patch(pt); store_patch(); }
     __syncthreads();
-    for (; pt < p.pixTiles; pt += workers) {
-        const bool more = pt + workers < p.pixTiles;
-        if (more) load_patch(pt + workers);
+    for (; pt < ptEnd; pt += ptStep) {
+        const bool more = pt + ptStep < ptEnd;
+        if (more) load_patch(pt + ptStep);
         // epilogue operands of THIS tile are fetched now so that their latency hides under the MFMAs (a persistent block
         // has no sibling to cover a dependent load at the end of every tile)
         int en[NJ]; int64_t epix[NJ]; float enz[NJ]; bool eok[NJ];
@@ -467,6 +472,10 @@ __global__ void __launch_bounds__(256) conv2d_fwd_ws_kernel(ConvParams p) {
         if (more) {
             __syncthreads();
             store_patch();
+            if (IN_SCALE) {
+                const int nextN = (pt + ptStep) / tilesPerImage;
+                if (nextN != curN) { curN = nextN; stage_weights(curN); }       // uniform across the block
+            }
             __syncthreads();
         }
     }
