@@ -704,6 +704,8 @@ struct WgradParams {
     int tilesW, tilesH, tilesN, pixTiles;
     int tilesCo, tilesCi, splitK;
     float scale;              // dw += scale * sum
+    int epiScale, perImage;   // epiScale = 1: per-image scales applied to the fp32 partial sums (each block stays inside one image:
+                              // splitK = N * perImage), not to the operands
 };
 
 static __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* base) {
@@ -806,7 +808,7 @@ __global__ void __launch_bounds__(512) conv2d_wgrad_kernel(WgradParams p) {
                 int n = n0 + (drel[i] >> 20), h = h0 + ((drel[i] >> 10) & 1023) - 8, w = w0 + (drel[i] & 1023) - 8;
                 if (n < p.N && h < p.H && w < p.W && gco < p.Cout) {
                     val = *(const u32x4*)(p.dy + (((int64_t)n * p.H + h) * p.W + w) * p.Cout + gco);
-                    if (p.out_scale) val = scale_vec8(val, p.out_scale + (int64_t)n * p.Cout + gco);
+                    if (p.out_scale && !p.epiScale) val = scale_vec8(val, p.out_scale + (int64_t)n * p.Cout + gco);
                 }
             }
             dreg[i] = val;
@@ -818,7 +820,7 @@ __global__ void __launch_bounds__(512) conv2d_wgrad_kernel(WgradParams p) {
                 int n = n0 + (xrel[i] >> 20), h = h0 + ((xrel[i] >> 10) & 1023) - 8, w = w0 + (xrel[i] & 1023) - 8;
                 if (n < p.N && h >= 0 && h < p.H && w >= 0 && w < p.W && gci < p.Cin) {
                     val = *(const u32x4*)(p.x + (((int64_t)n * p.H + h) * p.W + w) * p.Cin + gci);
-                    if (p.in_scale) val = scale_vec8(val, p.in_scale + (int64_t)n * p.Cin + gci);
+                    if (p.in_scale && !p.epiScale) val = scale_vec8(val, p.in_scale + (int64_t)n * p.Cin + gci);
                 }
             }
             xreg[i] = val;
@@ -839,12 +841,38 @@ __global__ void __launch_bounds__(512) conv2d_wgrad_kernel(WgradParams p) {
         }
     };
 
-    int pt = ks;
-    if (pt < p.pixTiles) { load_tile(pt); store_tile(); }
+    // ---- combine: fp32 atomics into dw[co][tap][ci].  With epiScale the per-sample scales s_out[n,co] * s_in[n,ci] multiply the
+    //      partial sums of image n here instead of every staged operand vector (sum_n s_o s_i sum_p dy x: exact in fp32) ----
+    auto flush = [&](int n) {
+        const int ci = ci0 + wb * 32 + (lane & 31);
+        if (ci >= p.Cin) return;
+        float si = p.scale;
+        if (p.epiScale && p.in_scale) si *= p.in_scale[(int64_t)n * p.Cin + ci];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int co = co0 + wa * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (co >= p.Cout) continue;
+            float sc = si;
+            if (p.epiScale && p.out_scale) sc *= p.out_scale[(int64_t)n * p.Cout + co];
+#pragma unroll
+            for (int t = 0; t < TAPS; t++) unsafeAtomicAdd(p.dw + ((int64_t)co * TAPS + t) * p.Cin + ci, acc[t][r] * sc);
+        }
+    };
+    // epiScale (TI == 1): splitK = N * perImage blocks; block ks owns a contiguous run of tiles of ONE image, so a single
+    // scaled flush at the end suffices (an in-loop flush costs the 256-VGPR budget of this kernel dearly)
+    const int tilesPerImage = p.tilesH * p.tilesW;
+    const int curN = p.epiScale ? ks / p.perImage : 0;
+    const int run = (tilesPerImage + p.perImage - 1) / p.perImage;
+    const int ptStep = p.epiScale ? 1 : p.splitK;
+    const int ptBegin = p.epiScale ? curN * tilesPerImage + (ks % p.perImage) * run : ks;
+    int ptEnd = p.pixTiles;
+    if (p.epiScale) { ptEnd = ptBegin + run; if (ptEnd > (curN + 1) * tilesPerImage) ptEnd = (curN + 1) * tilesPerImage; }
+    int pt = ptBegin;
+    if (pt < ptEnd) { load_tile(pt); store_tile(); }
     __syncthreads();
-    for (; pt < p.pixTiles; pt += p.splitK) {
-        const bool more = pt + p.splitK < p.pixTiles;
-        if (more) load_tile(pt + p.splitK);
+    for (; pt < ptEnd; pt += ptStep) {
+        const bool more = pt + ptStep < ptEnd;
+        if (more) load_tile(pt + ptStep);
         // fragment reads are software-pipelined one k-step ahead of the MFMAs (one wave per SIMD: nothing else would
         // hide the LDS latency of the 20 transpose reads a k-step needs)
         auto xrow_of = [&](int s) {
@@ -870,17 +898,7 @@ __global__ void __launch_bounds__(512) conv2d_wgrad_kernel(WgradParams p) {
             __syncthreads();
         }
     }
-    // ---- combine: fp32 atomics into dw[co][tap][ci] ----
-    const int ci = ci0 + wb * 32 + (lane & 31);
-    if (ci < p.Cin) {
-#pragma unroll
-        for (int t = 0; t < TAPS; t++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                int co = co0 + wa * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (co < p.Cout) unsafeAtomicAdd(p.dw + ((int64_t)co * TAPS + t) * p.Cin + ci, acc[t][r] * p.scale);
-            }
-    }
+    if (ptBegin < ptEnd) flush(curN);
 }
 
 template <int KS, bool COMPACT>
@@ -944,6 +962,21 @@ extern "C" int agf_conv2d_wgrad(const void* x, const void* dy, float* dw,
     int want = (512 + base - 1) / base;
     int cap = p.pixTiles / 4 < 1 ? 1 : p.pixTiles / 4;
     p.splitK = want < 1 ? 1 : (want > cap ? cap : want);
+    {
+        static const bool epi_on = []{ const char* e = getenv("AGF_WGRAD_EPI"); return !(e && e[0] == '0'); }();
+        p.epiScale = (epi_on && p.TI == 1 && (in_scale || out_scale)) ? 1 : 0;
+        p.perImage = 1;
+        if (p.epiScale) {
+            const int tpi = p.tilesW * p.tilesH;
+            int m = (want + N - 1) / N;                    // blocks per image so that N * m * base >= 512 ...
+            if (m > tpi / 4) m = tpi / 4;                  // ... but at least 4 tiles per block
+            if (m < 1) m = 1;
+            // one scaled flush per block and image: only worth it while that does not multiply the number of flushes
+            // (small maps: N blocks of one tile each would spend their time in the 64x64x9 atomics)
+            if (N * m > want + want / 2 || tpi < 4) p.epiScale = 0;
+            else { p.perImage = m; p.splitK = N * m; }
+        }
+    }
     AGF_CHECK(DYR <= 256 && XR * 8 <= 6 * 512 && DYR % 16 == 0, "conv2d_wgrad: internal tile too large");
     size_t lds = (size_t)(2 * DYR + 2 * XR) * 32 * sizeof(bf16_t);
     if (lds > 160 * 1024) { agf_set_error("conv2d_wgrad: tile needs %zu bytes of LDS", lds); return AGF_ENOKERNEL; }
