@@ -604,9 +604,10 @@ static int launch_fwd(const ConvParams& p, hipStream_t st) {
     // weight-stationary kernel: Cin <= 32 (two blocks per CU), or Cin <= 64 with Cout <= 32 (32-channel co tile: the
     // generic 64-channel tile would waste half of its MFMAs there); measured per layer in tools/ab_ws.sh
     if (g_ws_enable && KS == 3 && MT == 1 && p.pixTiles >= 2048 && p.TW == 32 && p.TH == 8 && p.TI == 1 &&
-        (p.Cin <= 32 || (p.Cin <= 64 && p.Cout <= 32))) {
+        (p.Cin <= 32 || (p.Cin <= 64 && p.Cout <= 32) || (g_ws_enable >= 2 && p.Cin <= 64 && p.Cout <= 64))) {
         int rc;
-        if (p.Cin <= 32 && p.Cout <= 32) rc = p.in_scale ? launch_fwd_ws<3, true, 32, 32>(p, st) : launch_fwd_ws<3, false, 32, 32>(p, st);
+        if (g_ws_enable == 2 && p.Cin > 32 && p.Cout > 32) rc = p.in_scale ? launch_fwd_ws<3, true, 64, 64>(p, st) : launch_fwd_ws<3, false, 64, 64>(p, st);
+        else if (p.Cin <= 32 && p.Cout <= 32) rc = p.in_scale ? launch_fwd_ws<3, true, 32, 32>(p, st) : launch_fwd_ws<3, false, 32, 32>(p, st);
         else if (p.Cin <= 32)            rc = p.in_scale ? launch_fwd_ws<3, true, 32, 64>(p, st) : launch_fwd_ws<3, false, 32, 64>(p, st);
         else                             rc = p.in_scale ? launch_fwd_ws<3, true, 64, 32>(p, st) : launch_fwd_ws<3, false, 64, 32>(p, st);
         if (rc != AGF_ENOKERNEL) return rc;

@@ -379,8 +379,10 @@ struct FlrRbParams {
     int TVWa;                        // v-lattice width handled by the horizontal pass (multiple of 8)
     int runsV;                       // 8-row runs of the vertical up pass
     int MW, NR;                      // 2-D up: input columns / runs of RN input rows
-    int ofsU, ofsX, ofsH, ofsV;      // LDS offsets (floats) after the filters
+    int ofsU, ofsX, ofsH, ofsV, ofsS;   // LDS offsets (floats) after the filters; sS = staged sign words of the gradient pass
+    int nDw;                         // sign dwords (16 samples each) staged per up-resolution row
     uint32_t mG, mTUW, mMW, mQ4, mTOW, mXP;   // magic numbers for division by nG, TUW, MW, UPC/4, TOW, XP
+    int skip;                        // profiling only (AGF_FLR_SKIP bit mask: 1 load, 2 up-FIR, 4 act, 8 down-FIR): phases left out, results wrong
 };
 
 // Scheduling fence: the value must be materialised here, and no memory access moves across.  Without tying the accumulators
@@ -410,8 +412,14 @@ static __device__ __forceinline__ uint32_t flr_load_signs(const FlrParams& p, in
     return sb;
 }
 
+// 2-bit code of sign sample (sx, sy), 0 outside the sign tensor
+static __device__ __forceinline__ uint32_t flr_sign_at(const FlrParams& p, const uint8_t* splane, int sx, int sy) {
+    if ((uint32_t)sy >= (uint32_t)p.SH || (uint32_t)sx >= (uint32_t)(p.SWB << 2)) return 0;
+    return ((uint32_t)splane[(int64_t)p.SWB * sy + (sx >> 2)] >> ((sx & 3) << 1)) & 3u;
+}
+
 template <class T, int UP, int DOWN, int SU, int SD, int RN, int R4, int NT>
-__global__ void __launch_bounds__(NT, NT == 256 ? 2 : 2) flr_rb_kernel(FlrRbParams P) {
+__global__ void __launch_bounds__(NT, NT == 256 ? 2 : 4) flr_rb_kernel(FlrRbParams P) {
     constexpr int FU = 6 * UP, FD = 6 * DOWN;
     static_assert(SU == 1 || UP == 2, "2-D up filter: factor 2 only");
     static_assert(SD == 1 || DOWN == 2, "2-D down filter: factor 2 only");
@@ -425,6 +433,7 @@ __global__ void __launch_bounds__(NT, NT == 256 ? 2 : 2) flr_rb_kernel(FlrRbPara
     float* sX = base + P.ofsX;
     float* sH = base + P.ofsH;
     float* sV = base + P.ofsV;
+    uint32_t* sS = (uint32_t*)(base + P.ofsS);                  // [TUH][nDw], only when signs are read
     const int tid = threadIdx.x;
 
     // ---- filters.  F(k) = f[size-1-k] unless flip.  2-D up taps are stored in the order the polyphase loop consumes them:
@@ -457,7 +466,7 @@ __global__ void __launch_bounds__(NT, NT == 256 ? 2 : 2) flr_rb_kernel(FlrRbPara
     {
         const T* xb = (const T*)p.x + n * p.xs[0] + c * p.xs[1];
         const float bias = p.b ? (float)Elem<T>::load((const T*)p.b + c) : 0.f;
-        const int total = p.TXH * P.XP;
+        const int total = (P.skip & 1) ? 0 : p.TXH * P.XP;
         for (int i0 = tid; i0 < total; i0 += NT * 8) {
             float v[8];
 #pragma unroll
@@ -471,8 +480,28 @@ __global__ void __launch_bounds__(NT, NT == 256 ? 2 : 2) flr_rb_kernel(FlrRbPara
 #pragma unroll
             for (int u = 0; u < 8; u++) { const int i = i0 + u * NT; if (i < total) sX[i] = v[u]; }
         }
+        if (p.signMode == 2) {
+            // gradient pass: the tile's sign bits (2 per sample, 16 samples per aligned dword) are staged once, coalesced;
+            // the FIR phases then pick their codes from LDS instead of issuing scattered byte loads
+            const uint32_t* splane = (const uint32_t*)(p.s + (int64_t)p.SWB * p.SH * (int64_t)plane);
+            const int dw0 = (ux0 + p.sofsx) >> 4, rowDw = p.SWB >> 2;
+            const int n = p.TUH * P.nDw;
+            for (int i = tid; i < n; i += NT) {
+                const int ruy = i / P.nDw, d = i - ruy * P.nDw;
+                const int sy = uy0 + ruy + p.sofsy, sd = dw0 + d;
+                uint32_t v = 0;
+                if ((uint32_t)sy < (uint32_t)p.SH && (uint32_t)sd < (uint32_t)rowDw) v = splane[(int64_t)rowDw * sy + sd];
+                sS[i] = v;
+            }
+        }
     }
     __syncthreads();
+    const int sxo = (ux0 + p.sofsx) - (((ux0 + p.sofsx) >> 4) << 4);       // sample offset of the tile inside its first sign dword
+    auto sign_code = [&](int ruy, int rux) -> uint32_t {                     // 2-bit code of tile sample (ruy, rux), rows outside -> 0
+        if ((uint32_t)ruy >= (uint32_t)p.TUH) return 0u;
+        const int pos = sxo + rux;
+        return (sS[ruy * P.nDw + (pos >> 4)] >> ((pos & 15) << 1)) & 3u;
+    };
 
     const float upGain = (float)(UP * UP) * p.gain;
     if (SU == 1) {
@@ -482,7 +511,7 @@ __global__ void __launch_bounds__(NT, NT == 256 ? 2 : 2) flr_rb_kernel(FlrRbPara
         // ---- 2. horizontal up-FIR: sH[ry][v], v = 8g .. 8g+7 ----
         {
             const int nG = P.TVWa >> 3;
-            const int items = p.TXH * nG;
+            const int items = (P.skip & 2) ? 0 : p.TXH * nG;
             for (int it = tid; it < items; it += NT) {
                 const int ry = (int)FLR_DIV(it, nG, P.mG), g = it - ry * nG;
                 constexpr int NIN = UP == 2 ? 12 : 8;
@@ -511,13 +540,27 @@ __global__ void __launch_bounds__(NT, NT == 256 ? 2 : 2) flr_rb_kernel(FlrRbPara
             }
         }
         __syncthreads();
-        // ---- 3. vertical up-FIR: column rux (v = rux + dx), rows vy = 8s .. 8s+7 -> sU[vy - dy][rux] ----
+        // ---- 3. vertical up-FIR + activation: column rux (v = rux + dx), rows vy = 8s .. 8s+7 -> sU[vy - dy][rux].
+        //      The up-resolution values are in registers here, so gain / leaky ReLU / clamp and the sign bits are applied before
+        //      the store: no separate pass over sU.  Lanes 4q .. 4q+3 hold the four samples of one sign byte (columns are padded
+        //      to a multiple of 4 so that lane & 3 == rux & 3); the byte is assembled with two quad-permute DPP steps ----
         {
-            const int items = P.runsV * p.TUW;
+            const int64_t plane64 = (int64_t)plane;
+            const int coreW = (tx == p.tilesX - 1) ? p.TUW : p.TOW * DOWN;
+            const int coreH = (ty == p.tilesY - 1) ? p.TUH : p.TOH * DOWN;
+            const int items = (P.skip & 2) ? 0 : P.runsV * P.UPC;
+            const int q4 = P.UPC >> 2;
             for (int it = tid; it < items; it += NT) {
-                const int sr = (int)FLR_DIV(it, p.TUW, P.mTUW), rux = it - sr * p.TUW;
+                const int sr = (int)FLR_DIV(it >> 2, q4, P.mQ4), rux = it - sr * P.UPC;
+                const bool colok = rux < p.TUW;
+                const int ux = ux0 + rux;
                 constexpr int NROW = UP == 2 ? 9 : 7;
-                const float* src = sH + (UP == 2 ? 4 * sr : 2 * sr) * P.HP + rux + dx;
+                const float* src = sH + (UP == 2 ? 4 * sr : 2 * sr) * P.HP + (colok ? rux : 0) + dx;
+                uint32_t scode[8];
+                if (p.signMode == 2) {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) scode[e] = colok ? sign_code(8 * sr + e - dy, rux) : 0u;
+                }
                 float h[NROW];
 #pragma unroll
                 for (int j = 0; j < NROW; j++) h[j] = src[j * P.HP];
@@ -528,7 +571,32 @@ __global__ void __launch_bounds__(NT, NT == 256 ? 2 : 2) flr_rb_kernel(FlrRbPara
 #pragma unroll
                     for (int j = 0; j < 6; j++) a = fmaf(h[b0 + j], fu[k0 + j * UP], a);
                     const int ruy = 8 * sr + e - dy;
-                    if (ruy >= 0 && ruy < p.TUH) sU[ruy * P.UPC + rux] = a * upGain;
+                    const int uy = uy0 + ruy;
+                    const bool rowok = ruy >= 0 && ruy < p.TUH;
+                    float v = a * upGain;
+                    uint32_t code = 0;
+                    const bool inimg = colok && ux < p.UW && uy < p.UH;
+                    if (p.signMode == 2) {                       // uniform branch; everything below is select / med3, no divergence
+                        float mul = (scode[e] & 1) ? p.slope : 1.f;
+                        mul = (scode[e] & 2) ? 0.f : mul;
+                        v *= mul;
+                    } else {
+                        const bool neg = v < 0.f;
+                        v *= neg ? p.slope : 1.f;
+                        const bool cl = fabsf(v) > p.clamp;
+                        v = __builtin_amdgcn_fmed3f(v, -p.clamp, p.clamp);
+                        code = cl ? 2u : (neg ? 1u : 0u);
+                    }
+                    v = inimg ? v : 0.f;
+                    code = inimg ? code : 0u;
+                    if (rowok && colok) sU[ruy * P.UPC + rux] = v;
+                    if (p.signMode == 1) {
+                        uint32_t c4 = code << ((rux & 3) << 1);
+                        c4 |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c4, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+                        c4 |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c4, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+                        if ((rux & 3) == 0 && rowok && rux < coreW && ruy < coreH && uy < p.SH && (ux >> 2) < p.SWB)
+                            p.s[(ux >> 2) + (int64_t)p.SWB * (uy + (int64_t)p.SH * plane64)] = (uint8_t)c4;
+                    }
                 }
             }
         }
@@ -536,11 +604,23 @@ __global__ void __launch_bounds__(NT, NT == 256 ? 2 : 2) flr_rb_kernel(FlrRbPara
         // ---- 3'. 2-D up-FIR (UP == 2, 12x12): input column m -> output columns v = 2m, 2m+1; RN input rows per run.
         //      acc[i][a] = (column phase 0, column phase 1) of output row 2(n0+i)+a, updated with packed fp32 FMAs:
         //      (acc.x, acc.y) += (w, w) * (tap of phase 0, tap of phase 1); the taps of step s+1 are fetched during step s ----
-        const int items = P.NR * P.MW;
+        const int items = (P.skip & 2) ? 0 : P.NR * P.MW;
         for (int it = tid; it < items; it += NT) {
             const int run = (int)FLR_DIV(it, P.MW, P.mMW), m = it - run * P.MW;
             const int n0 = run * RN;
             const float* src = sX + n0 * P.XP + m;
+            uint32_t scode[2 * RN];                              // per output row: codes of the lane's two columns (bits 0-1, 2-3)
+            if (p.signMode == 2) {
+                const int rx = 2 * m - dx;
+#pragma unroll
+                for (int r = 0; r < 2 * RN; r++) {
+                    const int ry = 2 * n0 + r - dy;
+                    scode[r] = (rx >= 0 ? sign_code(ry, rx) : 0u) | (sign_code(ry, rx + 1) << 2);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 2 * RN; r++) scode[r] = 0;
+            }
             float w[RN + 5][6];
 #pragma unroll
             for (int r = 0; r < RN + 5; r++)
@@ -570,6 +650,8 @@ __global__ void __launch_bounds__(NT, NT == 256 ? 2 : 2) flr_rb_kernel(FlrRbPara
 #pragma unroll
                     for (int jx = 0; jx < 6; jx++) acc[i][a] = __builtin_elementwise_fma((v2f)(w[i + jy][jx]), t[st][jx], acc[i][a]);
             }
+            // store; unless signs are WRITTEN (quads straddle lanes when dx == 1: the separate pass below does it) the activation
+            // is applied here, the sign codes of the gradient pass having been fetched before the FIR math
 #pragma unroll
             for (int i = 0; i < RN; i++)
 #pragma unroll
@@ -577,8 +659,24 @@ __global__ void __launch_bounds__(NT, NT == 256 ? 2 : 2) flr_rb_kernel(FlrRbPara
                     const int ruy = 2 * (n0 + i) + a - dy;
                     if (ruy < 0 || ruy >= p.TUH) continue;
                     const int rux0 = 2 * m - dx;
-                    if (rux0 >= 0 && rux0 < p.TUW) sU[ruy * P.UPC + rux0] = acc[i][a].x * upGain;
-                    if (rux0 + 1 >= 0 && rux0 + 1 < p.TUW) sU[ruy * P.UPC + rux0 + 1] = acc[i][a].y * upGain;
+                    const int uy = uy0 + ruy;
+                    float v0 = acc[i][a].x * upGain, v1 = acc[i][a].y * upGain;
+                    if (p.signMode != 1) {                       // uniform branches; selects only inside
+                        const uint32_t sc = scode[2 * i + a];
+                        if (p.signMode == 2) {
+                            float m0 = (sc & 1) ? p.slope : 1.f, m1 = (sc & 4) ? p.slope : 1.f;
+                            m0 = (sc & 2) ? 0.f : m0; m1 = (sc & 8) ? 0.f : m1;
+                            v0 *= m0; v1 *= m1;
+                        } else {
+                            v0 *= v0 < 0.f ? p.slope : 1.f; v1 *= v1 < 0.f ? p.slope : 1.f;
+                            v0 = __builtin_amdgcn_fmed3f(v0, -p.clamp, p.clamp); v1 = __builtin_amdgcn_fmed3f(v1, -p.clamp, p.clamp);
+                        }
+                        const bool rowin = uy < p.UH;
+                        v0 = (rowin && ux0 + rux0 < p.UW) ? v0 : 0.f;
+                        v1 = (rowin && ux0 + rux0 + 1 < p.UW) ? v1 : 0.f;
+                    }
+                    if (rux0 >= 0 && rux0 < p.TUW) sU[ruy * P.UPC + rux0] = v0;
+                    if (rux0 + 1 >= 0 && rux0 + 1 < p.TUW) sU[ruy * P.UPC + rux0 + 1] = v1;
                 }
         }
     }
@@ -591,7 +689,8 @@ __global__ void __launch_bounds__(NT, NT == 256 ? 2 : 2) flr_rb_kernel(FlrRbPara
         const int q4 = P.UPC >> 2;
         const int coreW = (tx == p.tilesX - 1) ? p.TUW : p.TOW * DOWN;
         const int coreH = (ty == p.tilesY - 1) ? p.TUH : p.TOH * DOWN;
-        const int items = p.TUH * q4;
+        const bool separate = SU == 2 && p.signMode == 1;       // every other case is fused into the up-FIR above
+        const int items = (!separate || (P.skip & 4)) ? 0 : p.TUH * q4;
         for (int it0 = tid; it0 < items; it0 += NT * 4) {
             uint32_t sbv[4];
             int ruyv[4], qxv[4];
@@ -644,7 +743,7 @@ __global__ void __launch_bounds__(NT, NT == 256 ? 2 : 2) flr_rb_kernel(FlrRbPara
     if (SD == 2) {
         // ---- 4. 2-D down-FIR (DOWN == 2, 12x12): output column rox, strip of R4 rows, sliding window over tap rows ----
         const int strips = p.TOH / R4;
-        const int items = strips * p.TOW;
+        const int items = (P.skip & 8) ? 0 : strips * p.TOW;
         for (int it = tid; it < items; it += NT) {
             const int strip = (int)FLR_DIV(it, p.TOW, P.mTOW), rox = it - strip * p.TOW;
             const float* ubase = sU + (strip * R4 * 2) * P.UPC + 2 * rox;
@@ -709,7 +808,7 @@ __global__ void __launch_bounds__(NT, NT == 256 ? 2 : 2) flr_rb_kernel(FlrRbPara
         for (int k = 0; k < FD; k++) fd[k] = sFd[k];
         {
             const int strips = p.TOH / RD;
-            const int items = strips * p.TUW;
+            const int items = (P.skip & 8) ? 0 : strips * p.TUW;
             for (int it = tid; it < items; it += NT) {
                 const int strip = (int)FLR_DIV(it, p.TUW, P.mTUW), rux = it - strip * p.TUW;
                 const float* src = sU + (strip * RD * DOWN) * P.UPC + rux;
@@ -732,7 +831,7 @@ __global__ void __launch_bounds__(NT, NT == 256 ? 2 : 2) flr_rb_kernel(FlrRbPara
         }
         __syncthreads();
         {
-            const int items = p.TOH * p.TOW;
+            const int items = (P.skip & 8) ? 0 : p.TOH * p.TOW;
             for (int it = tid; it < items; it += NT) {
                 const int roy = (int)FLR_DIV(it, p.TOW, P.mTOW), rox = it - roy * p.TOW;
                 const int oy = oy0 + roy, ox = ox0 + rox;
@@ -807,7 +906,10 @@ static bool flr_rb_launch(FlrParams p, hipStream_t st, int* status) {
         } else {
             P.ofsX = szU; P.ofsH = 0; szR2 = szX > szV ? szX : szV; P.ofsV = szU;
         }
-        const size_t fl = (size_t)(SU == 1 ? FU : FU * FU) + (size_t)(SD == 1 ? FD : FD * FD) + szU + szR2;
+        P.nDw = (p.TUW + 15 + 15) / 16 + 1;
+        const int szS = p.signMode == 2 ? p.TUH * P.nDw : 0;
+        P.ofsS = szU + szR2;
+        const size_t fl = (size_t)(SU == 1 ? FU : FU * FU) + (size_t)(SD == 1 ? FD : FD * FD) + szU + szR2 + szS;
         lds = fl * sizeof(float);
         if (lds <= 78 * 1024) break;                             // two workgroups per CU
         if (strips == 1 && lds <= 150 * 1024) break;
@@ -821,6 +923,7 @@ static bool flr_rb_launch(FlrParams p, hipStream_t st, int* status) {
     P.b = p;
     P.mG = flr_magic(SU == 1 ? P.TVWa >> 3 : 1); P.mTUW = flr_magic(p.TUW); P.mMW = flr_magic(P.MW ? P.MW : 1);
     P.mQ4 = flr_magic(P.UPC >> 2); P.mTOW = flr_magic(p.TOW); P.mXP = flr_magic(P.XP);
+    { static const int sk = []{ const char* e = getenv("AGF_FLR_SKIP"); return e ? atoi(e) : 0; }(); P.skip = sk; }
     auto kern = flr_rb_kernel<T, UP, DOWN, SU, SD, RN, R4, NT>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { agf_set_error("filtered_lrelu: cannot reserve LDS: %s", hipGetErrorString(e)); *status = AGF_ELAUNCH; return true; }

@@ -26,3 +26,6 @@ tot = sum(r[0] for r in rows)
 print('total conv ms/step', round(tot, 2))
 for ms, key, n, tf in rows[:40]:
     print(f'{ms:6.2f} ms  x{n:4.1f}  {tf:7.1f} TF/s  {key}')
+print('--- by time lost against 1000 TFLOP/s')
+for ms, key, n, tf in sorted(rows, key=lambda r: -r[0] * max(0, 1 - r[3] / 1000))[:30]:
+    print(f'{ms * max(0, 1 - tf / 1000):6.2f} lost of {ms:5.2f} ms  x{n:4.1f}  {tf:7.1f} TF/s  {key}')
