@@ -166,7 +166,12 @@ class _ConvFwd(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = _ConvWgrad.apply(x, dy, s_in, s_out, w.shape[2]).to(w.dtype)
         if s_out is not None and ctx.needs_input_grad[3]:
-            ds_out = (dy.float() * y.float()).sum((2, 3)) / s_out
+            if not torch.is_grad_enabled() and y.shape[1] % 8 == 0 and y.dtype == torch.bfloat16:
+                # sum_hw dy * y in one fused pass (agf_scale_dot) instead of two fp32 copies + product + reduction
+                _, dots = scale_dot_raw(dy.contiguous(memory_format=torch.channels_last), y, s_out, want_dx=False)
+                ds_out = dots / s_out
+            else:
+                ds_out = (dy.float() * y.float()).sum((2, 3)) / s_out
         return dx, dw, ds_in, ds_out
 
 

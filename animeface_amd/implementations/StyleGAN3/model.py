@@ -184,8 +184,11 @@ class StyleLayer(nn.Module):
 
     def forward(self, x, w):
         if self.training:
-            stats = x.detach().to(torch.float32).square().mean()
-            self.ema.copy_(stats.lerp_(self.ema, self.ema_decay))
+            # mean(x^2) in fp32 (reference model.py:174-176).  vector_norm casts inside the reduction: one read of the bf16
+            # activations instead of an fp32 copy + square + mean (three passes over a tensor of up to 630 MB)
+            with torch.no_grad():
+                stats = torch.linalg.vector_norm(x.detach(), 2, dtype=torch.float32).square() / x.numel()
+                self.ema.copy_(stats.lerp_(self.ema, self.ema_decay))
         input_gain = self.ema.rsqrt()
         s = self.affine(w)
         x = self.conv(x, s, input_gain)
