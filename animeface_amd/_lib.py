@@ -59,7 +59,7 @@ def lib():
         L.agf_filtered_lrelu.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, _i32x4, _i64x4, _i32x4, _i64x4,
                                          _i32x2, _i64x2, _i32x2, _i64x2, _i32x2, _i32x2, ctypes.c_int,
                                          ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-                                         ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int, _vp]
+                                         ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int, _vp, _vp]
         L.agf_filtered_lrelu_act.restype = ctypes.c_int
         L.agf_filtered_lrelu_act.argtypes = [_vp, _vp, ctypes.c_int, _i32x4, _i64x4, _i32x2, _i32x2, ctypes.c_int,
                                              ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp]
@@ -77,7 +77,7 @@ def lib():
             fn.argtypes = [_vp, _vp, ctypes.c_int] + [ctypes.c_int32] * 6 + [_vp]
         L.agf_prep_weights.restype = ctypes.c_int
         L.agf_prep_weights.argtypes = [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, _vp]
-        if L.agf_abi_version() != 1:
+        if L.agf_abi_version() != 2:
             raise AgfError('libagf_ops.so ABI version mismatch')
         _lib = L
     return _lib

@@ -138,8 +138,25 @@ extern "C" int agf_filtered_lrelu_act(void* x, uint8_t* s, int dtype,
 // Filters are staged in LDS per workgroup: no __constant__ singleton, so launches on different streams are independent.
 // Sign bytes are written only for a tile's non-overlapping core columns/rows (its width is a multiple of 4 samples, so
 // every byte has exactly one writer); the last tile of a row/column also covers the remainder of the sign plane.
+// per-block sum of `v` over all threads, added to *dst (one atomic per block); scratch = NT/64 floats of LDS
+template <int NTHR>
+static __device__ __forceinline__ void flr_block_sum_to(float v, float* dst, float* scratch) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();                                            // the scratch words alias the filter taps: everyone is done with them
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < NTHR / 64; i++) t += scratch[i];
+        unsafeAtomicAdd(dst, t);
+    }
+}
+
 struct FlrParams {
     const void* x; const float* fu; const float* fd; const void* b; uint8_t* s; void* y;
+    float* ysum;                     // [C] or null: += sum over n,h,w of y (the bias gradient of a gradient pass)
     int N, C, XH, XW, YH, YW;
     int64_t xs[4], ys[4];
     int fuw, fuh, fdw, fdh;          // 2-D sizes; separable filters have fuh == 0 / fdh == 0 (then taps = fuw / fdw both ways)
@@ -306,6 +323,7 @@ __global__ void __launch_bounds__(256) filtered_lrelu_kernel(FlrParams p0) {
 
     // ---- 4. downsampling FIR + store ----
     T* yb = (T*)p.y + n * p.ys[0] + c * p.ys[1];
+    float ysum_local = 0.f;
     if (sepD) {
         for (int i = tid; i < p.TUH * p.TOW; i += 256) {
             int ruy = i / p.TOW, rox = i - ruy * p.TOW;
@@ -333,6 +351,7 @@ __global__ void __launch_bounds__(256) filtered_lrelu_kernel(FlrParams p0) {
                 for (int k = 0; k < fdH; k++, src += p.TOW) v += *src * sFd[k];
             }
             Elem<T>::store(yb + oy * p.ys[2] + ox * p.ys[3], v);
+            ysum_local += v;
         }
     } else {
         for (int i = tid; i < p.TOH * p.TOW; i += 256) {
@@ -351,8 +370,10 @@ __global__ void __launch_bounds__(256) filtered_lrelu_kernel(FlrParams p0) {
                     for (int kx = 0; kx < p.fdw; kx++) v += row[kx] * sFd[ky * p.fdw + kx];
             }
             Elem<T>::store(yb + oy * p.ys[2] + ox * p.ys[3], v);
+            ysum_local += v;
         }
     }
+    if (p.ysum) flr_block_sum_to<256>(ysum_local, p.ysum + c, flr_smem);
 }
 
 
@@ -740,6 +761,7 @@ __global__ void __launch_bounds__(NT, NT == 256 ? 2 : 4) flr_rb_kernel(FlrRbPara
     __syncthreads();
 
     T* yb = (T*)p.y + n * p.ys[0] + c * p.ys[1];
+    float ysum_local = 0.f;
     if (SD == 2) {
         // ---- 4. 2-D down-FIR (DOWN == 2, 12x12): output column rox, strip of R4 rows, sliding window over tap rows ----
         const int strips = p.TOH / R4;
@@ -796,7 +818,7 @@ __global__ void __launch_bounds__(NT, NT == 256 ? 2 : 4) flr_rb_kernel(FlrRbPara
 #pragma unroll
                 for (int o = 0; o < R4; o++) {
                     const int oy = oy0 + strip * R4 + o;
-                    if (oy < p.YH) Elem<T>::store(yb + oy * p.ys[2] + ox * p.ys[3], acc[o]);
+                    if (oy < p.YH) { Elem<T>::store(yb + oy * p.ys[2] + ox * p.ys[3], acc[o]); ysum_local += acc[o]; }
                 }
             }
         }
@@ -847,9 +869,11 @@ __global__ void __launch_bounds__(NT, NT == 256 ? 2 : 4) flr_rb_kernel(FlrRbPara
                         a = fmaf(t.x, fd[4*q], a); a = fmaf(t.y, fd[4*q+1], a); a = fmaf(t.z, fd[4*q+2], a); a = fmaf(t.w, fd[4*q+3], a); }
                 }
                 Elem<T>::store(yb + oy * p.ys[2] + ox * p.ys[3], a);
+                ysum_local += a;
             }
         }
     }
+    if (p.ysum) flr_block_sum_to<NT>(ysum_local, p.ysum + c, flr_smem);
 }
 
 // host side: tile geometry + launch of the register-blocked kernel; returns false when the configuration is not one of its
@@ -959,7 +983,7 @@ extern "C" int agf_filtered_lrelu(const void* x, const float* fu, const float* f
                                   const int32_t fd_size[2], const int64_t fd_stride[2],
                                   const int32_t s_size[2], const int32_t s_ofs[2], int sign_mode,
                                   int up, int down, int px0, int py0,
-                                  float gain, float slope, float clamp, int flip, void* stream) {
+                                  float gain, float slope, float clamp, int flip, float* ysum, void* stream) {
     // validation mirrors filtered_lrelu.cpp:15-32
     AGF_CHECK(x && fu && fd && y, "filtered_lrelu: null pointer");
     AGF_CHECK(dtype == AGF_F32 || dtype == AGF_F16 || dtype == AGF_BF16, "x and b must be float16, bfloat16 or float32");
@@ -968,7 +992,7 @@ extern "C" int agf_filtered_lrelu(const void* x, const float* fu, const float* f
     AGF_CHECK(sign_mode == 0 || s, "signs pointer is null");
     for (int i = 0; i < 4; i++) AGF_CHECK(x_size[i] >= 1 && y_size[i] >= 1, "x is empty");
     FlrParams p;
-    p.x = x; p.fu = fu; p.fd = fd; p.b = b; p.s = s; p.y = y;
+    p.x = x; p.fu = fu; p.fd = fd; p.b = b; p.s = s; p.y = y; p.ysum = ysum;
     p.N = x_size[0]; p.C = x_size[1]; p.XH = x_size[2]; p.XW = x_size[3]; p.YH = y_size[2]; p.YW = y_size[3];
     for (int i = 0; i < 4; i++) { p.xs[i] = x_stride[i]; p.ys[i] = y_stride[i]; }
     // rank-1 filter: size = {taps, 0};  rank-2: {fh, fw}

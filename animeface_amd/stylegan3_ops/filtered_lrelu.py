@@ -39,6 +39,11 @@ def _parse_padding(padding):
     return px0, px1, py0, py1
 
 
+def _dense(t):
+    """contiguous in NCHW or channels-last order (what the kernels read at full width)"""
+    return t.is_contiguous() or t.is_contiguous(memory_format=torch.channels_last)
+
+
 def _f_desc(f):
     """(size[2], stride[2]) in the C ABI's convention: rank-1 = {taps, 0}; rank-2 = {fh, fw}."""
     if f.ndim == 1:
@@ -46,7 +51,7 @@ def _f_desc(f):
     return _lib._i32x2(int(f.shape[0]), int(f.shape[1])), _lib._i64x2(int(f.stride(0)), int(f.stride(1)))
 
 
-def _native_fused(x, fu, fd, b, si, up, down, px0, px1, py0, py1, sx, sy, gain, slope, clamp, flip, write_signs):
+def _native_fused(x, fu, fd, b, si, up, down, px0, px1, py0, py1, sx, sy, gain, slope, clamp, flip, write_signs, ysum=None):
     """Counterpart of ``_plugin.filtered_lrelu`` (reference filtered_lrelu.cpp:10-203): returns (y, so, rc)."""
     N, C, xh, xw = x.shape
     b = b.contiguous()
@@ -78,7 +83,7 @@ def _native_fused(x, fu, fd, b, si, up, down, px0, px1, py0, py1, sx, sy, gain, 
     rc = _lib.lib().agf_filtered_lrelu(
         _lib.ptr(x), _lib.ptr(fu), _lib.ptr(fd), _lib.ptr(b), _lib.ptr(s if mode else None), _lib.ptr(y), _lib.dtype_code(x),
         _lib.sizes4(x), _lib.strides4(x), _lib.sizes4(y), _lib.strides4(y), fus, fust, fds, fdst,
-        ssz, _lib._i32x2(sx, sy), mode, up, down, px0, py0, gain, slope, clamp, int(bool(flip)), _lib.stream_ptr(x))
+        ssz, _lib._i32x2(sx, sy), mode, up, down, px0, py0, gain, slope, clamp, int(bool(flip)), _lib.ptr(ysum), _lib.stream_ptr(x))
     if rc == _lib.AGF_ENOKERNEL:
         return None, None, -1
     _lib.check(rc, 'filtered_lrelu')
@@ -186,9 +191,24 @@ def _filtered_lrelu_hip(up=1, down=1, padding=0, gain=np.sqrt(2), slope=0.2, cla
                 ff = (not flip_filter)
                 sx = sx - (fu.shape[-1] - 1) + px0
                 sy = sy - (fu.shape[0] - 1) + py0
-                dx = _filtered_lrelu_hip(up=down, down=up, padding=pp, gain=gg, slope=slope, clamp=None,
-                                         flip_filter=ff).apply(dy, fd, fu, None, si, sx, sy)
-            if ctx.needs_input_grad[3]:
+                if not torch.is_grad_enabled() and dy.dtype in (torch.float16, torch.bfloat16, torch.float32) and si is not None and si.numel():
+                    # no graph is being recorded: run the gradient pass directly and let the kernel accumulate the bias gradient
+                    # (sum of dx over n, h, w) while it stores dx -- one pass less over dx
+                    dyc = dy if _dense(dy) else dy.contiguous()
+                    ysum = torch.zeros(dy.shape[1], dtype=torch.float32, device=dy.device) if ctx.needs_input_grad[3] else None
+                    zb = torch.zeros(dy.shape[1], dtype=dy.dtype, device=dy.device)
+                    fu2 = fd if fd.ndim == 2 or down > 1 or fd.shape[0] > 1 else fd.square()[None]
+                    fd2 = fu if fu.ndim == 2 or up > 1 or fu.shape[0] > 1 else fu.square()[None]
+                    dx, _, rc = _native_fused(dyc, fu2, fd2, zb, si, down, up, pp[0], pp[1], pp[2], pp[3], sx, sy, gg, slope,
+                                              float('inf'), ff, False, ysum=ysum)
+                    if rc < 0:
+                        dx = None
+                    elif ysum is not None:
+                        db = ysum.to(dy.dtype)
+                if dx is None:
+                    dx = _filtered_lrelu_hip(up=down, down=up, padding=pp, gain=gg, slope=slope, clamp=None,
+                                             flip_filter=ff).apply(dy, fd, fu, None, si, sx, sy)
+            if ctx.needs_input_grad[3] and db is None:
                 db = dx.sum([0, 2, 3])
             return dx, None, None, db, None, None, None
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define AGF_ABI_VERSION 1
+#define AGF_ABI_VERSION 2
 
 /* element types of activation tensors */
 enum { AGF_F32 = 0, AGF_F16 = 1, AGF_BF16 = 2, AGF_F64 = 3 };
@@ -93,6 +93,8 @@ int agf_bias_act(const void* x, const void* b, const void* xref, const void* yre
  * Sign tensor s: uint8 [N, C, s_size[0], s_size[1]] contiguous, 2 bits per element of the upsampled
  * image, 4 elements per byte, row width = ceil16(active width) / 4 bytes (filtered_lrelu.cpp:81-88);
  * sign_mode 0 = none, 1 = write, 2 = read (then s_ofs = {sx, sy} offsets it against the upsampled image).
+ * ysum (nullable, fp32 [C]): += sum over n,h,w of y -- the bias gradient when the call is a gradient pass (the reference
+ * computes dx.sum([0,2,3]) as a separate reduction, filtered_lrelu.py:257); zero it first.
  * Returns AGF_ENOKERNEL where the reference returns rc = -1; callers then use the generic path
  * (agf_upfirdn2d + agf_filtered_lrelu_act), exactly as filtered_lrelu.py:217-223 does.
  */
@@ -103,7 +105,7 @@ int agf_filtered_lrelu(const void* x, const float* fu, const float* fd, const vo
                        const int32_t fd_size[2], const int64_t fd_stride[2],
                        const int32_t s_size[2], const int32_t s_ofs[2], int sign_mode,
                        int up, int down, int px0, int py0,
-                       float gain, float slope, float clamp, int flip, void* stream);
+                       float gain, float slope, float clamp, int flip, float* ysum, void* stream);
 
 /* filtered_lrelu_act_  --  replaces  Tensor filtered_lrelu_act_(x, si, sx, sy, gain, slope, clamp, writeSigns)
  *                          filtered_lrelu.cpp:207-284 (pybind at :291), kernel filtered_lrelu.cu:1099-1210.
