@@ -55,12 +55,19 @@ class ELR(nn.Module):
         return F.linear(x * self.coef, self.layer.weight, self.layer.bias)
 
 
-def elr_conv2d(elr, x, act=None, residual=None, gain=1.0):
-    """``ELR(nn.Conv2d)`` on the MFMA conv; coef is folded into the weights; optional fused-order bias + lrelu."""
+def elr_conv2d(elr, x, act=None, residual=None, gain=1.0, out_gain=1.0):
+    """``ELR(nn.Conv2d)`` on the MFMA conv; coef is folded into the weights; optional fused-order bias + lrelu.
+    ``out_gain`` (linear layers only) scales the conv + bias part of the output by a constant for free: it is folded into the
+    weight coefficient and the bias instead of being applied to the output tensor (nothing to undo in backward either)."""
     conv = elr.layer
     k = conv.kernel_size[0]
     assert conv.stride == (1, 1) and conv.padding == (k // 2, k // 2) and k in (1, 3)
-    return conv2d_act(x, conv.weight, conv.bias, alpha=0.2, fused=FUSED_EPILOGUE, coef=elr.coef,
+    bias, coef = conv.bias, elr.coef
+    if out_gain != 1.0:
+        assert act != 'lrelu'
+        coef = coef * out_gain
+        bias = bias * out_gain if bias is not None else None
+    return conv2d_act(x, conv.weight, bias, alpha=0.2, fused=FUSED_EPILOGUE, coef=coef,
                       act='lrelu' if act == 'lrelu' else 'linear', residual=residual, gain=gain)
 
 
@@ -257,8 +264,9 @@ class DBlock(nn.Module):
         c = float(1 / np.sqrt(2))
         if isinstance(self.down, _AvgPool2x):
             # avg-pool commutes with the 1x1 skip conv: pool first (4x less work), identical result
-            # (skip(pool(t)) + pool(x)) / sqrt(2): the residual add and the gain run in the 1x1 conv's epilogue
-            return elr_conv2d(self.skip, self.down(t), residual=self.down(x), gain=c)
+            # (skip(pool(t)) + pool(x)) / sqrt(2): the residual add runs in the 1x1 conv's epilogue; the 1/sqrt(2) costs nothing:
+            # it is folded into the skip conv's weight coefficient / bias and into the gain of the pooling FIR of x
+            return elr_conv2d(self.skip, self.down(t), residual=self.down(x, gain=c), out_gain=c)
         t = self.skip(t)
         return (self.down(x) + self.down(t)) / np.sqrt(2)
 
