@@ -183,3 +183,32 @@ def test_bf16_training_steps_run_and_stay_finite():
     assert len(hist) == 3 and all(np.isfinite(h[1]) and np.isfinite(h[2]) for h in hist)
     for p in list(G.parameters()) + list(D.parameters()) + list(G_ema.parameters()):
         assert torch.isfinite(p).all()
+
+
+def test_hip_model_vs_cpu_oracle_on_a_second_configuration():
+    """A configuration / seed the fixtures do not contain: HIP fp32 networks against the CPU oracle (oracle/stylegan3.py, itself
+    pinned to the reference by tests/test_oracle_sg3.py) on the same state_dict."""
+    from animeface_amd.implementations.StyleGAN3 import model as M
+    from oracle import stylegan3 as S3
+    torch.manual_seed(5)
+    kw = dict(image_size=64, latent_dim=24, num_layers=8, map_num_layers=2, channels=16, max_channels=24, style_dim=24, margin_size=6)
+    G = M.Generator(kw['image_size'], kw['latent_dim'], kw['num_layers'], kw['map_num_layers'], kw['channels'], kw['max_channels'],
+                    kw['style_dim'], margin_size=kw['margin_size'], compute_dtype=torch.float32)
+    D = M.Discriminator(64, 3, 8, 24, compute_dtype=torch.float32)
+    with torch.no_grad():
+        for n, p in list(G.named_parameters()) + list(D.named_parameters()):
+            if n.endswith('bias') and 'affine' not in n:
+                p.normal_(0, 0.2)
+    sdG = {k: v.clone() for k, v in G.state_dict().items()}
+    sdD = {k: v.clone() for k, v in D.state_dict().items()}
+    cfg = S3.Config(d_channels=8, d_max_channels=24, **kw)
+    z = torch.randn(3, 24)
+    ref_img, stats = S3.generator(sdG, cfg, z, training=True)
+    ref_logits = S3.discriminator(sdD, cfg, ref_img)
+    G, D = G.to(DEV).train(), D.to(DEV)
+    img = G(z.to(DEV))
+    assert relerr(img, ref_img) < 1e-3
+    assert relerr(D(img), ref_logits) < 1e-3
+    torch.testing.assert_close(G.map.w_avg.cpu(), stats['w_avg'], rtol=1e-4, atol=1e-6)
+    for i, e in stats['ema'].items():
+        torch.testing.assert_close(G.synthesis.net[i].ema.cpu(), e, rtol=1e-3, atol=1e-6)
