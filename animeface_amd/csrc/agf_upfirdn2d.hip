@@ -16,6 +16,7 @@
 //              with coalesced row loads and computes a 64x16 output tile from it (polyphase taps from LDS).
 //   generic  : any strides / sizes; one thread per output, gathers from global memory.
 #include "agf_common.h"
+#include <stdlib.h>
 
 struct UpfirdnParams {
     const void* x;
@@ -327,6 +328,144 @@ __global__ void __launch_bounds__(256) upfirdn2d_nchw_tile(UpfirdnParams p) {
 }
 
 // -------------------------------------------------------------------------------------------------
+// planar_rows: NCHW planes (the reference's own layout), compile-time factors / filter size.
+// A 256-thread workgroup = 256 output columns x ROWS output rows of one plane.  The input rows the strip needs are staged in LDS
+// as fp32 with coalesced loads; each lane then owns one output column: it builds its (vertical phase, tap row, tap column) table
+// in registers once (the horizontal polyphase offset differs per lane, the vertical one per block: PM = template parameter, so
+// every row / tap index below is a compile-time constant) and walks down the input rows, reading the few samples of its column
+// window once per row and feeding every output row that uses them.  LDS traffic drops from fh*fw reads per output (nchw_tile) to
+// about one read per fh FMAs, and nothing but the staging touches global memory.
+template <class T, int UPX, int UPY, int DNX, int DNY, int FW, int FH, int ROWS, int PM>
+static __device__ __forceinline__ void planar_rows_body(const UpfirdnParams& p, const float* sf, const float* sX, int pitch,
+                                                        int oy0, int ox, int cx, int kx0, T* yb) {
+    constexpr int NTX = (FW + UPX - 1) / UPX, NTY = (FH + UPY - 1) / UPY;
+    constexpr int NR = ((ROWS - 1) * DNY + PM) / UPY + NTY;          // input rows the strip touches
+    // taps of this lane's horizontal phase: tx[ky][jx] = F(ky, kx0 + jx*UPX) (0 beyond the filter)
+    float tx[FH][NTX];
+#pragma unroll
+    for (int ky = 0; ky < FH; ky++)
+#pragma unroll
+        for (int jx = 0; jx < NTX; jx++) { const int kx = kx0 + jx * UPX; tx[ky][jx] = kx < FW ? sf[ky * FW + kx] : 0.f; }
+    float acc[ROWS];
+#pragma unroll
+    for (int e = 0; e < ROWS; e++) acc[e] = 0.f;
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+        float v[NTX];
+#pragma unroll
+        for (int jx = 0; jx < NTX; jx++) v[jx] = sX[r * pitch + cx + jx];
+#pragma unroll
+        for (int e = 0; e < ROWS; e++) {
+            constexpr int dummy = 0; (void)dummy;
+            const int m = PM + e * DNY;                                // mid of output row e relative to the strip's first input row
+            const int r0 = m / UPY, ky0 = UPY - 1 - (m % UPY);
+            const int jy = r - r0;                                     // this input row is tap row ky0 + jy*UPY of output row e
+            if (jy >= 0 && jy < NTY && ky0 + jy * UPY < FH) {
+#pragma unroll
+                for (int jx = 0; jx < NTX; jx++) acc[e] = fmaf(v[jx], tx[ky0 + jy * UPY][jx], acc[e]);
+            }
+        }
+    }
+    if (ox < p.OW) {
+#pragma unroll
+        for (int e = 0; e < ROWS; e++) {
+            const int oy = oy0 + e;
+            if (oy < p.OH) Elem<T>::store(yb + (int64_t)oy * p.OW + ox, acc[e] * p.gain);
+        }
+    }
+}
+
+template <class T, int UPX, int UPY, int DNX, int DNY, int FW, int FH, int ROWS>
+__global__ void __launch_bounds__(256) upfirdn2d_planar_rows(UpfirdnParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NTX = (FW + UPX - 1) / UPX, NTY = (FH + UPY - 1) / UPY;
+    constexpr int NRMAX = ((ROWS - 1) * DNY + UPY - 1) / UPY + NTY;
+    constexpr int NC = (255 * DNX + UPX - 1) / UPX + NTX;             // input columns a 256-column strip touches
+    constexpr int PITCH = NC + 1;
+    float* sf = smem;                                                  // [FH*FW]
+    float* sX = smem + ((FH * FW + 3) & ~3);                           // [NRMAX][PITCH]
+    stage_filter<256>(p, sf);
+    int bid = blockIdx.x;
+    const int tx = bid % p.tilesX; bid /= p.tilesX;
+    const int ty = bid % p.tilesY;
+    const int plane = bid / p.tilesY;
+    const int oy0 = ty * ROWS, ox0 = tx * 256;
+    const int midy0 = oy0 * DNY + UPY - 1 - p.pady0, midx0 = ox0 * DNX + UPX - 1 - p.padx0;
+    const int iy_lo = agf_floor_div(midy0, UPY), ix_lo = agf_floor_div(midx0, UPX);
+    const int pm = midy0 - iy_lo * UPY;                                // vertical phase of the strip (uniform)
+    const T* xb = (const T*)p.x + (int64_t)plane * p.H * p.W;
+    // staging (NC is a compile-time constant: the index split is a multiply-shift); four independent loads in flight per lane
+    for (int i0 = threadIdx.x; i0 < NRMAX * NC; i0 += 256 * 4) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = i0 + u * 256;
+            const int r = i / NC, c = i - r * NC;
+            int iy = iy_lo + r, ix = ix_lo + c;
+            v[u] = 0.f;
+            if (i < NRMAX * NC) {
+                if (p.clamp_edge) v[u] = (float)Elem<T>::load(xb + (int64_t)min(max(iy, 0), p.H - 1) * p.W + min(max(ix, 0), p.W - 1));
+                else if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) v[u] = (float)Elem<T>::load(xb + (int64_t)iy * p.W + ix);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = i0 + u * 256;
+            if (i < NRMAX * NC) { const int r = i / NC; sX[r * PITCH + (i - r * NC)] = v[u]; }
+        }
+    }
+    __syncthreads();
+    const int ox = ox0 + threadIdx.x;
+    const int midx = ox * DNX + UPX - 1 - p.padx0;
+    const int inx0 = agf_floor_div(midx, UPX);
+    const int kx0 = (inx0 + 1) * UPX - midx - 1;
+    const int cx = inx0 - ix_lo;
+    T* yb = (T*)p.y + (int64_t)plane * p.OH * p.OW;
+    if (UPY == 1 || pm == 0) planar_rows_body<T, UPX, UPY, DNX, DNY, FW, FH, ROWS, 0>(p, sf, sX, PITCH, oy0, ox, cx, kx0, yb);
+    else if (UPY >= 2 && pm == 1) planar_rows_body<T, UPX, UPY, DNX, DNY, FW, FH, ROWS, (UPY >= 2 ? 1 : 0)>(p, sf, sX, PITCH, oy0, ox, cx, kx0, yb);
+    else if (UPY >= 3 && pm == 2) planar_rows_body<T, UPX, UPY, DNX, DNY, FW, FH, ROWS, (UPY >= 3 ? 2 : 0)>(p, sf, sX, PITCH, oy0, ox, cx, kx0, yb);
+    else planar_rows_body<T, UPX, UPY, DNX, DNY, FW, FH, ROWS, (UPY >= 4 ? 3 : 0)>(p, sf, sX, PITCH, oy0, ox, cx, kx0, yb);
+}
+
+template <class T, int UPX, int UPY, int DNX, int DNY, int FW, int FH, int ROWS>
+static void launch_planar(UpfirdnParams p, hipStream_t st) {
+    constexpr int NTX = (FW + UPX - 1) / UPX, NTY = (FH + UPY - 1) / UPY;
+    constexpr int NRMAX = ((ROWS - 1) * DNY + UPY - 1) / UPY + NTY;
+    constexpr int NC = (255 * DNX + UPX - 1) / UPX + NTX;
+    constexpr size_t lds = (size_t)(((FH * FW + 3) & ~3) + NRMAX * (NC + 1)) * sizeof(float);
+    static_assert(lds <= 64 * 1024, "planar_rows tile too large");
+    static_assert(UPY <= 4, "vertical phases up to 4");
+    p.tilesX = (p.OW + 255) / 256; p.tilesY = (p.OH + ROWS - 1) / ROWS;
+    const int64_t blocks = (int64_t)p.tilesX * p.tilesY * p.N * p.C;
+    hipLaunchKernelGGL((upfirdn2d_planar_rows<T, UPX, UPY, DNX, DNY, FW, FH, ROWS>), dim3((unsigned)blocks), dim3(256), lds, st, p);
+}
+
+// the filter / factor combinations the networks and the ADA pipe use on planar tensors; false = no instantiation
+template <class T>
+static bool launch_planar_cases(const UpfirdnParams& p, hipStream_t st) {
+    if ((int64_t)((p.OW + 255) / 256) * ((p.OH + 3) / 4) * p.N * p.C >= (1ll << 31)) return false;
+#define PLANAR_CASE(ux, uy, dx, dy, w, h, rows)                                                                          \
+    if (p.upx == ux && p.upy == uy && p.downx == dx && p.downy == dy && p.fw == w && p.fh == h) {                        \
+        launch_planar<T, ux, uy, dx, dy, w, h, rows>(p, st); return true; }
+    PLANAR_CASE(2, 2, 1, 1, 4, 4, 8)      // 2x upsample [1,3,3,1]
+    PLANAR_CASE(1, 1, 1, 1, 3, 3, 8)      // blur [1,2,1]
+    PLANAR_CASE(1, 1, 2, 2, 2, 2, 4)      // 2x2 average pooling
+    // (1,1,2,2,4,4): the 2-D [1,3,3,1] decimation stays on nchw_tile -- its 10 x 515 staging makes the strip kernel slower there
+    PLANAR_CASE(2, 2, 1, 1, 2, 2, 8)      // adjoint of the average pooling
+    PLANAR_CASE(1, 1, 1, 1, 4, 4, 4)      // filter2d 4x4
+    PLANAR_CASE(2, 1, 1, 1, 12, 1, 8)     // separable 12-tap passes (ADA sym6 low-pass, StyleGAN3 generic path): up x
+    PLANAR_CASE(1, 2, 1, 1, 1, 12, 8)     //   up y
+    PLANAR_CASE(1, 1, 2, 1, 12, 1, 8)     //   down x
+    PLANAR_CASE(1, 1, 1, 2, 1, 12, 4)     //   down y
+    PLANAR_CASE(2, 1, 1, 1, 4, 1, 8)      // separable [1,3,3,1] passes
+    PLANAR_CASE(1, 2, 1, 1, 1, 4, 8)
+    PLANAR_CASE(1, 1, 2, 1, 4, 1, 8)
+    PLANAR_CASE(1, 1, 1, 2, 1, 4, 4)
+#undef PLANAR_CASE
+    return false;
+}
+
+// -------------------------------------------------------------------------------------------------
 template <class T, int VEC>
 static bool launch_nhwc(const UpfirdnParams& p, hipStream_t st) {
     const int CG = p.C / VEC;
@@ -362,6 +501,10 @@ static int launch_typed(UpfirdnParams& p, bool dense_nchw, bool dense_nhwc, int 
         if constexpr (sizeof(T) == 4) ok = launch_nhwc<T, 4>(p, st);
         else if constexpr (sizeof(T) == 2) ok = launch_nhwc<T, 8>(p, st);
         if (ok) return AGF_OK;
+    }
+    if (dense_nchw && sizeof(T) <= 4 && p.OW >= 64) {
+        static const bool planar_on = []{ const char* e = getenv("AGF_UPFIRDN_PLANAR"); return !(e && e[0] == '0'); }();
+        if (planar_on && launch_planar_cases<T>(p, st)) return AGF_OK;
     }
     if (dense_nchw && sizeof(T) <= 4) {      // fp64 keeps full precision through the generic kernel
         p.tileInW = ((TILE_OW - 1) * p.downx + p.fw - 1) / p.upx + 1;
