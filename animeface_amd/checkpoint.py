@@ -1,0 +1,60 @@
+"""Full resume state of a training run.
+
+The reference saves only ``G_ema.state_dict()`` every ``save`` iterations (implementations/StyleGAN2/utils.py:119-123,
+implementations/StyleGAN3/utils.py:83-85); that file format is kept (``save_generator`` / any ``G_*.pt`` of the reference loads
+into this package's ``Generator``: identical keys).  A run at MI355X speed also needs to stop and continue, so ``save`` /
+``load`` carry everything an iteration depends on: G, G_ema, D, both Adam states, the iteration counter, the path-length mean,
+the ADA probability / statistic and the random-generator states of the rank."""
+import torch
+
+
+def save_generator(G_ema, path):
+    """The reference's checkpoint: the EMA generator's state_dict."""
+    torch.save(G_ema.state_dict(), path)
+
+
+def _ada_of(step):
+    ada = getattr(step, 'ada', None)
+    if ada is None and hasattr(getattr(step, 'augment', None), 'update_p'):
+        ada = step.augment
+    return ada
+
+
+def state(step):
+    """Resume state of a ``TrainStep`` (StyleGAN2 or StyleGAN3 / ADA flavour) as a plain dict of tensors and numbers."""
+    out = dict(G=step.G.state_dict(), G_ema=step.G_ema.state_dict() if step.G_ema is not None else None, D=step.D.state_dict(),
+               optimizer_G=step.optimizer_G.state_dict(), optimizer_D=step.optimizer_D.state_dict(),
+               batches_done=step.batches_done, pl_mean=getattr(step, 'pl_mean', 0.),
+               rng_cpu=torch.get_rng_state(),
+               rng_cuda=torch.cuda.get_rng_state() if torch.cuda.is_available() else None)
+    ada = _ada_of(step)
+    if ada is not None:
+        out['ada'] = dict(state=ada.state_dict(), num_iter=ada._num_iter)
+    return out
+
+
+def save(step, path):
+    torch.save(state(step), path)
+
+
+def load(step, path_or_state, map_location=None):
+    """Restore a ``TrainStep`` in place; the next call of ``step(real)`` continues the run it was saved from."""
+    st = torch.load(path_or_state, map_location=map_location, weights_only=False) if isinstance(path_or_state, str) else path_or_state
+    step.G.load_state_dict(st['G'])
+    step.D.load_state_dict(st['D'])
+    if step.G_ema is not None and st.get('G_ema') is not None:
+        step.G_ema.load_state_dict(st['G_ema'])
+    step.optimizer_G.load_state_dict(st['optimizer_G'])
+    step.optimizer_D.load_state_dict(st['optimizer_D'])
+    step.batches_done = int(st['batches_done'])
+    if hasattr(step, 'pl_mean'):
+        step.pl_mean = st.get('pl_mean', 0.)
+    ada = _ada_of(step)
+    if ada is not None and 'ada' in st:
+        ada.load_state_dict(st['ada']['state'])
+        ada._num_iter = int(st['ada']['num_iter'])
+    if st.get('rng_cpu') is not None:
+        torch.set_rng_state(st['rng_cpu'].cpu())
+    if st.get('rng_cuda') is not None and torch.cuda.is_available():
+        torch.cuda.set_rng_state(st['rng_cuda'].cpu())
+    return step

@@ -184,18 +184,24 @@ def build_optimizers(G, D, lr, betas, r1_lambda, pl_lambda, d_k, g_k):
 def train(max_iter, dataset, sampler, const_z, latent_dim,
           G, G_ema, D, optimizer_G, optimizer_D,
           r1_lambda, pl_lambda, d_k, g_k, policy,
-          device, amp, save=1000, log_every=50, on_save=None, reducer_G=None, reducer_D=None):
+          device, amp, save=1000, log_every=50, on_save=None, reducer_G=None, reducer_D=None, resume=None, checkpoint_path=None):
     """Same positional signature as the reference's ``train`` (utils.py:35-41)."""
     if G_ema is not None:
         G_ema.eval()
     step = TrainStep(G, G_ema, D, optimizer_G, optimizer_D, r1_lambda, pl_lambda, d_k, g_k, policy,
                      latent_dim, sampler, reducer_G, reducer_D)
+    if resume is not None:                                  # full resume state (animeface_amd/checkpoint.py), not just G_ema
+        from ... import checkpoint
+        checkpoint.load(step, resume, map_location=device)
     history = []
     while step.batches_done < max_iter:
         for real in dataset:
             real = real.to(device, non_blocking=True)
             it = step.batches_done
             D_loss, G_loss, fake = step(real)
+            if it % save == 0 and checkpoint_path is not None and it > 0:
+                from ... import checkpoint
+                checkpoint.save(step, checkpoint_path)
             if it % save == 0 and on_save is not None:
                 with torch.no_grad():
                     images, _ = G_ema(const_z)

@@ -96,15 +96,22 @@ class TrainStep:
 def train(max_iters, dataset, latent_dim, const_input,
           G, G_ema, D, optimizer_G, optimizer_D,
           gp_lambda, gp_every, augment,
-          device, amp, save=1000, log_file=None, log_every=50, on_save=None, reducer_G=None, reducer_D=None):
+          device, amp, save=1000, log_file=None, log_every=50, on_save=None, reducer_G=None, reducer_D=None, resume=None,
+          checkpoint_path=None):
     """Same positional signature as the reference's ``train`` (utils.py:15-20)."""
     step = TrainStep(G, G_ema, D, optimizer_G, optimizer_D, gp_lambda, gp_every, augment, latent_dim, reducer_G, reducer_D)
+    if resume is not None:                                  # full resume state (animeface_amd/checkpoint.py), not just G_ema
+        from ... import checkpoint
+        checkpoint.load(step, resume, map_location=device)
     history = []
     while step.batches_done < max_iters:
         for real in dataset:
             real = real.to(device, non_blocking=True)
             it = step.batches_done
             D_loss, G_loss, fake = step(real)
+            if it % save == 0 and checkpoint_path is not None and it > 0:
+                from ... import checkpoint
+                checkpoint.save(step, checkpoint_path)
             if it % save == 0 and on_save is not None:
                 with torch.no_grad():
                     on_save(it, G_ema(const_input), G_ema)

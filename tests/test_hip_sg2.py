@@ -193,3 +193,41 @@ def test_bf16_training_step_runs_and_stays_finite():
         dl, gl, fake = step(real)
         assert torch.isfinite(dl) and torch.isfinite(gl) and torch.isfinite(fake).all()
     assert all(torch.isfinite(p).all() for p in list(G.parameters()) + list(D.parameters()))
+
+
+def test_checkpoint_resume_continues_the_run(tmp_path):
+    """save -> two more iterations == load into fresh objects -> the same two iterations (weights, Adam state, RNG, counters);
+    equal up to the summation order of the split-K atomics of the weight-gradient kernel."""
+    import functools
+    from animeface_amd.implementations.StyleGAN2 import utils as U
+    from animeface_amd.nnutils import sample_nnoise, update_ema
+    from animeface_amd import checkpoint
+
+    def make(seed):
+        torch.manual_seed(seed)
+        M, G, D = build(torch.float32)
+        _, G_ema, _ = build(torch.float32)
+        G.init_weight(functools.partial(M.init_weight_N01, lr=0.01), M.init_weight_N01)
+        D.apply(M.init_weight_N01)
+        G_ema.eval()
+        update_ema(G, G_ema, decay=0)
+        oG, oD = U.build_optimizers(G, D, 0.001, (0., 0.99), 10., 2., 2, 2)
+        return U.TrainStep(G, G_ema, D, oG, oD, 10., 2., 2, 2, 'color,translation', TINY['style_dim'], functools.partial(sample_nnoise, device=DEV))
+    real = torch.rand(4, 3, 16, 16, device=DEV) * 2 - 1
+    a = make(1)
+    for _ in range(3):
+        a(real)
+    path = str(tmp_path / 'run.pt')
+    checkpoint.save(a, path)
+    ref = [a(real)[:2] for _ in range(2)]
+    b = checkpoint.load(make(2), path)
+    assert b.batches_done == 3 and b.pl_mean == pytest.approx(checkpoint.state(b)['pl_mean'])
+    got = [b(real)[:2] for _ in range(2)]
+    for (d0, g0), (d1, g1) in zip(ref, got):
+        assert d0.item() == pytest.approx(d1.item(), rel=1e-4, abs=1e-6) and g0.item() == pytest.approx(g1.item(), rel=1e-4, abs=1e-6)
+    for (k, v), (_, w) in zip(a.G.state_dict().items(), b.G.state_dict().items()):
+        torch.testing.assert_close(v, w, rtol=1e-4, atol=1e-5, msg=lambda m, k=k: f'{k}: {m}')
+    for (k, v), (_, w) in zip(a.D.state_dict().items(), b.D.state_dict().items()):
+        torch.testing.assert_close(v, w, rtol=1e-4, atol=1e-5, msg=lambda m, k=k: f'{k}: {m}')
+    for (k, v), (_, w) in zip(a.G_ema.state_dict().items(), b.G_ema.state_dict().items()):
+        torch.testing.assert_close(v, w, rtol=1e-4, atol=1e-5, msg=lambda m, k=k: f'{k}: {m}')
