@@ -61,6 +61,7 @@ struct ConvParams {
     int act;                  // 1 linear, 3 lrelu
     float alpha, gain;
     int hoist;                // A/B switch: hoist the style-scale loads out of the per-vector staging loop
+    int wsSlices;             // ping-pong weight-stationary kernel: blocks per image
 };
 
 // NWN = waves along the pixel axis (2 or 4): block = 2 x NWN waves, tile = (64*MT) co x (128*NWN) pixels.
@@ -342,15 +343,16 @@ __global__ void __launch_bounds__(256) conv2d_fwd_ws_kernel(ConvParams p) {
 
     // tile-invariant patch geometry: (image-in-tile, dh, dw) per staged vector, packed; -1 = beyond the patch
     constexpr int XV = (340 * VPR + 255) / 256;                      // the launcher only uses 8x32 tiles (P = 340)
-    int xrel[XV];
+    int xrel[XV], xofs[XV];
 #pragma unroll
     for (int i = 0; i < XV; i++) {
         int v = tid + i * 256;
         int pix = v / VPR;
-        xrel[i] = -1;
-        if (pix < P) {
+        xrel[i] = -1; xofs[i] = 0;
+        if (pix < P && (v % VPR) * 8 < p.Cin) {
             int pc = pix % PW; int t2 = pix / PW; int pr = t2 % PH; int ti = t2 / PH;
             xrel[i] = (ti << 20) | ((pr - HALO + 8) << 10) | (pc - HALO + 8);
+            xofs[i] = ((pr - HALO) * p.W + (pc - HALO)) * p.Cin + (v % VPR) * 8;   // from the tile's first pixel (TI == 1)
         }
     }
     u32x4 xreg[XV];
@@ -360,16 +362,26 @@ __global__ void __launch_bounds__(256) conv2d_fwd_ws_kernel(ConvParams p) {
         const int th = tq % p.tilesH;
         const int tn = tq / p.tilesH;
         const int n0 = tn * p.TI, h0 = th * p.TH, w0 = tw * p.TW;
+        // tiles whose halo lies inside the image need no per-vector bounds checks or index arithmetic
+        const bool interior = n0 < p.N && h0 >= HALO && w0 >= HALO && h0 + p.TH + HALO <= p.H && w0 + p.TW + HALO <= p.W;
+        const bf16_t* org = p.x + (((int64_t)n0 * p.H + h0) * p.W + w0) * p.Cin;
+        if (interior) {
 #pragma unroll
-        for (int i = 0; i < XV; i++) {
-            const int gc = ((tid + i * 256) % VPR) * 8;
-            u32x4 val = {0u, 0u, 0u, 0u};
-            if (xrel[i] >= 0) {
-                int n = n0 + (xrel[i] >> 20), h = h0 + ((xrel[i] >> 10) & 1023) - 8, w = w0 + (xrel[i] & 1023) - 8;
-                if (n < p.N && h >= 0 && h < p.H && w >= 0 && w < p.W && gc < p.Cin)
-                    val = *(const u32x4*)(p.x + (((int64_t)n * p.H + h) * p.W + w) * p.Cin + gc);
+            for (int i = 0; i < XV; i++) {
+                u32x4 val = {0u, 0u, 0u, 0u};
+                if (xrel[i] >= 0) val = *(const u32x4*)(org + xofs[i]);
+                xreg[i] = val;
             }
-            xreg[i] = val;
+        } else {
+#pragma unroll
+            for (int i = 0; i < XV; i++) {
+                u32x4 val = {0u, 0u, 0u, 0u};
+                if (xrel[i] >= 0) {
+                    int n = n0 + (xrel[i] >> 20), h = h0 + ((xrel[i] >> 10) & 1023) - 8, w = w0 + (xrel[i] & 1023) - 8;
+                    if (n < p.N && h >= 0 && h < p.H && w >= 0 && w < p.W) val = *(const u32x4*)(org + xofs[i]);
+                }
+                xreg[i] = val;
+            }
         }
     };
     auto store_patch = [&]() {
@@ -479,6 +491,228 @@ __global__ void __launch_bounds__(256) conv2d_fwd_ws_kernel(ConvParams p) {
             __syncthreads();
         }
     }
+}
+
+// =================================================================================================
+// Ping-pong variant of the weight-stationary kernel (512 threads = two groups of 4 waves).
+// In the kernel above a tile's phases -- patch loads, index math, MFMAs, result stores -- run one after the other on the single
+// wave each SIMD holds; timing it with phases removed (AGF_CONV_SKIP experiments) showed their costs simply ADD: 0.21 ms loads +
+// 0.24 ms MFMA + 0.16 ms stores + 0.2 ms bookkeeping for 64->32 @256^2, B=128.  Here the two groups share the LDS-resident
+// weights but own a patch buffer each and work half a tile apart: while one group contracts its tile on the MFMA pipe, the
+// other stores its previous results, moves its prefetched patch into LDS and issues the loads of the tile after next.  One
+// block-wide barrier per half step keeps the groups in step; loads get two half steps to arrive.
+// A block only works on tiles of ONE image (worker = image x slice), so a style scale folded into the weights never changes.
+template <int KS, bool IN_SCALE, int CINP, int BM>
+__global__ void __launch_bounds__(512, 2) conv2d_fwd_ws2_kernel(ConvParams p) {
+    constexpr int PITCH = CINP + 8;
+    constexpr int TAPS = KS * KS;
+    constexpr int HALO = KS / 2;
+    constexpr int NJ = BM == 64 ? 4 : 2;
+    constexpr int VPR = CINP / 8;
+    constexpr int PMAXP = 340;                                       // 8 x 32 pixel tiles only
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* sW = (bf16_t*)smem_raw;                                  // [TAPS][BM][PITCH]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = wave >> 2, gw = wave & 3, gtid = tid & 255;
+    bf16_t* sX = sW + TAPS * BM * PITCH + grp * (PMAXP * PITCH);     // this group's [P][PITCH]
+
+    const int coTile = blockIdx.x % p.tilesCo;
+    const int worker = blockIdx.x / p.tilesCo;
+    const int co0 = coTile * BM;
+    const int PW = p.TW + 2 * HALO, PH = p.TH + 2 * HALO;
+    const int P = PH * PW;                                           // TI == 1
+    const int wm = BM == 64 ? (gw >> 1) : 0, wn = BM == 64 ? (gw & 1) : gw;
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    const int tilesPerImage = p.tilesH * p.tilesW;
+    const int img = worker / p.wsSlices, slice = worker - img * p.wsSlices;
+    const int run = (tilesPerImage + p.wsSlices - 1) / p.wsSlices;
+    const int tBegin = slice * run;
+    const int T = (tBegin + run <= tilesPerImage ? run : tilesPerImage - tBegin);     // tiles of this block (may be <= 0)
+
+    for (int v = tid; v < TAPS * BM * VPR; v += 512) {
+        int cv = v % VPR, row = v / VPR;
+        int tap = row / BM, co = row - tap * BM;
+        int gco = co0 + co, gc = cv * 8;
+        u32x4 val = {0u, 0u, 0u, 0u};
+        if (gco < p.Cout && gc < p.Cin) {
+            val = *(const u32x4*)(p.w + ((int64_t)gco * TAPS + tap) * p.Cin + gc);
+            if (IN_SCALE) val = scale_vec8(val, p.in_scale + (int64_t)img * p.Cin + gc);
+        }
+        *(u32x4*)(sW + row * PITCH + cv * 8) = val;
+    }
+
+    int bBase[NJ], qc[NJ], qr[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+        int q = wn * (NJ * 32) + j * 32 + l31;
+        qc[j] = q % p.TW; qr[j] = q / p.TW;
+        bBase[j] = (qr[j] * PW + qc[j]) * PITCH + lhi * 8;
+    }
+    const int aBase = (wm * 32 + l31) * PITCH + lhi * 8;
+
+    constexpr int XV = (PMAXP * VPR + 255) / 256;
+    int xrel[XV], xofs[XV];
+#pragma unroll
+    for (int i = 0; i < XV; i++) {
+        int v = gtid + i * 256;
+        int pix = v / VPR;
+        xrel[i] = -1;
+        xofs[i] = 0;
+        if (pix < P) {
+            int pc = pix % PW, pr = pix / PW;
+            const int gc = (v % VPR) * 8;
+            if (gc < p.Cin) {
+                xrel[i] = ((pr - HALO + 8) << 10) | (pc - HALO + 8);
+                xofs[i] = ((pr - HALO) * p.W + (pc - HALO)) * p.Cin + gc;     // element offset from the tile's first pixel
+            }
+        }
+    }
+    u32x4 xreg[XV];
+    const bf16_t* ximg = p.x + (int64_t)img * p.H * p.W * p.Cin;
+    auto load_patch = [&](int ti) {                                  // ti = tile index inside the image slice
+        int tq = tBegin + ti;
+        const int tw = tq % p.tilesW, th = tq / p.tilesW;
+        const int h0 = th * p.TH, w0 = tw * p.TW;
+        const bf16_t* org = ximg + ((int64_t)h0 * p.W + w0) * p.Cin;
+        // tiles whose halo lies inside the image (all but the border ring) need no per-vector bounds checks
+        const bool interior = h0 >= HALO && w0 >= HALO && h0 + p.TH + HALO <= p.H && w0 + p.TW + HALO <= p.W;
+        if (interior) {
+#pragma unroll
+            for (int i = 0; i < XV; i++) {
+                u32x4 val = {0u, 0u, 0u, 0u};
+                if (xrel[i] >= 0) val = *(const u32x4*)(org + xofs[i]);
+                xreg[i] = val;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < XV; i++) {
+                u32x4 val = {0u, 0u, 0u, 0u};
+                if (xrel[i] >= 0) {
+                    int h = h0 + (xrel[i] >> 10) - 8, w = w0 + (xrel[i] & 1023) - 8;
+                    if (h >= 0 && h < p.H && w >= 0 && w < p.W) val = *(const u32x4*)(org + xofs[i]);
+                }
+                xreg[i] = val;
+            }
+        }
+    };
+    auto store_patch = [&]() {
+#pragma unroll
+        for (int i = 0; i < XV; i++) {
+            int v = gtid + i * 256;
+            if (xrel[i] >= 0) *(u32x4*)(sX + (v / VPR) * PITCH + (v % VPR) * 8) = xreg[i];
+        }
+    };
+
+    f32x4 ebias[4];
+#pragma unroll
+    for (int rg = 0; rg < 4; rg++) {
+        int co = co0 + wm * 32 + rg * 8 + lhi * 4;
+        f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        ebias[rg] = (p.bias && co < p.Cout) ? *(const f32x4*)(p.bias + co) : zero;
+    }
+
+    int mine = grp;                                                  // tile (index in the slice) this group contracts next
+    if (mine < T) { load_patch(mine); store_patch(); }
+    if (mine + 2 < T) load_patch(mine + 2);
+    __syncthreads();
+    f32x16 acc[NJ];
+    bool have = false;
+    for (int ph = 0; ph <= T; ph++) {
+        if ((ph & 1) == grp) {
+            // ---- contract ----
+            if (mine < T) {
+#pragma unroll
+                for (int j = 0; j < NJ; j++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
+#pragma unroll
+                for (int kh = 0; kh < KS; kh++)
+#pragma unroll
+                    for (int kw = 0; kw < KS; kw++)
+#pragma unroll
+                        for (int ks = 0; ks < CINP / 16; ks++) {
+                            const bf16x8 af = *(const bf16x8*)(sW + (kh * KS + kw) * BM * PITCH + aBase + ks * 16);
+#pragma unroll
+                            for (int j = 0; j < NJ; j++) {
+                                const bf16x8 bfr = *(const bf16x8*)(sX + (kh * PW + kw) * PITCH + bBase[j] + ks * 16);
+                                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[j], 0, 0, 0);
+                            }
+                        }
+                have = true;
+            }
+        } else if (have) {
+            // ---- results of the tile contracted in the previous half step, then the next patch ----
+            {
+                int tq = tBegin + mine;
+                const int tw = tq % p.tilesW, th = tq / p.tilesW;
+                const int h0 = th * p.TH, w0 = tw * p.TW;
+#pragma unroll
+                for (int j = 0; j < NJ; j++) {
+                    const int h = h0 + qr[j], w = w0 + qc[j];
+                    if (h >= p.H || w >= p.W) continue;
+                    const int64_t pixIdx = ((int64_t)img * p.H + h) * p.W + w;
+                    const float nz = p.noise ? p.noise[pixIdx] : 0.f;
+#pragma unroll
+                    for (int rg = 0; rg < 4; rg++) {
+                        int co = co0 + wm * 32 + rg * 8 + lhi * 4;
+                        if (co >= p.Cout) continue;
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; e++) v[e] = acc[j][rg * 4 + e];
+                        if (p.out_scale) {
+                            f32x4 sc = *(const f32x4*)(p.out_scale + (int64_t)img * p.Cout + co);
+                            v[0] *= sc.x; v[1] *= sc.y; v[2] *= sc.z; v[3] *= sc.w;
+                        }
+                        v[0] += ebias[rg].x + nz; v[1] += ebias[rg].y + nz; v[2] += ebias[rg].z + nz; v[3] += ebias[rg].w + nz;
+                        if (p.residual) {
+                            u32x2 rr = *(const u32x2*)(p.residual + pixIdx * p.Cout + co);
+                            float a0, a1;
+                            Pack16<bf16_t>::unpack(rr.x, a0, a1); v[0] += a0; v[1] += a1;
+                            Pack16<bf16_t>::unpack(rr.y, a0, a1); v[2] += a0; v[3] += a1;
+                        }
+                        if (p.act == 3) {
+#pragma unroll
+                            for (int e = 0; e < 4; e++) v[e] = v[e] > 0.f ? v[e] : v[e] * p.alpha;
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; e++) v[e] *= p.gain;
+                        u32x2 o;
+                        o.x = Pack16<bf16_t>::pack(v[0], v[1]);
+                        o.y = Pack16<bf16_t>::pack(v[2], v[3]);
+                        *(u32x2*)(p.y + pixIdx * p.Cout + co) = o;
+                    }
+                }
+            }
+            have = false;
+            mine += 2;
+            if (mine < T) {
+                store_patch();                                       // xreg holds tile `mine` (loaded two half steps ago)
+                if (mine + 2 < T) load_patch(mine + 2);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int KS, bool SC, int CINP, int BM>
+static int launch_fwd_ws2(const ConvParams& p0, hipStream_t st) {
+    constexpr int TAPS = KS * KS, HALO = KS / 2, PITCH = CINP + 8;
+    ConvParams p = p0;
+    p.tilesCo = (p.Cout + BM - 1) / BM;
+    const int P = (p.TH + 2 * HALO) * (p.TW + 2 * HALO);
+    if (p.TI != 1 || P > 340) return AGF_ENOKERNEL;
+    size_t lds = (size_t)(TAPS * BM + 2 * 340) * PITCH * sizeof(bf16_t);
+    if (lds > 160 * 1024) return AGF_ENOKERNEL;
+    const int tpi = p.tilesH * p.tilesW;
+    int m = 256 / (p.N * p.tilesCo);                                 // slices per image: about one 8-wave block per CU
+    if (m < 1) m = 1;
+    if (m > tpi / 4) m = tpi / 4 > 0 ? tpi / 4 : 1;
+    p.wsSlices = m;
+    hipError_t e = hipFuncSetAttribute((const void*)conv2d_fwd_ws2_kernel<KS, SC, CINP, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { agf_set_error("conv2d_fwd: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e)); return AGF_ELAUNCH; }
+    hipLaunchKernelGGL((conv2d_fwd_ws2_kernel<KS, SC, CINP, BM>), dim3((unsigned)(p.N * m * p.tilesCo)), dim3(512), lds, st, p);
+    return AGF_OK;
 }
 
 // =================================================================================================
@@ -606,6 +840,13 @@ static int launch_fwd(const ConvParams& p, hipStream_t st) {
     if (g_ws_enable && KS == 3 && MT == 1 && p.pixTiles >= 2048 && p.TW == 32 && p.TH == 8 && p.TI == 1 &&
         (p.Cin <= 32 || (p.Cin <= 64 && p.Cout <= 32) || (g_ws_enable >= 2 && p.Cin <= 64 && p.Cout <= 64))) {
         int rc;
+        static const int ws2 = []{ const char* e = getenv("AGF_CONV_WS2"); return e ? atoi(e) : 1; }();
+        if ((ws2 == 1 && !(p.Cin <= 32 && p.Cout <= 32) && !(p.Cin > 32 && p.Cout > 32)) || (ws2 == 2 && !(p.Cin > 32 && p.Cout > 32))) {
+            if (p.Cin <= 32 && p.Cout <= 32) rc = p.in_scale ? launch_fwd_ws2<3, true, 32, 32>(p, st) : launch_fwd_ws2<3, false, 32, 32>(p, st);
+            else if (p.Cin <= 32)            rc = p.in_scale ? launch_fwd_ws2<3, true, 32, 64>(p, st) : launch_fwd_ws2<3, false, 32, 64>(p, st);
+            else                             rc = p.in_scale ? launch_fwd_ws2<3, true, 64, 32>(p, st) : launch_fwd_ws2<3, false, 64, 32>(p, st);
+            if (rc != AGF_ENOKERNEL) return rc;
+        }
         if (g_ws_enable == 2 && p.Cin > 32 && p.Cout > 32) rc = p.in_scale ? launch_fwd_ws<3, true, 64, 64>(p, st) : launch_fwd_ws<3, false, 64, 64>(p, st);
         else if (p.Cin <= 32 && p.Cout <= 32) rc = p.in_scale ? launch_fwd_ws<3, true, 32, 32>(p, st) : launch_fwd_ws<3, false, 32, 32>(p, st);
         else if (p.Cin <= 32)            rc = p.in_scale ? launch_fwd_ws<3, true, 32, 64>(p, st) : launch_fwd_ws<3, false, 32, 64>(p, st);
