@@ -62,6 +62,8 @@ struct ConvParams {
     float alpha, gain;
     int hoist;                // A/B switch: hoist the style-scale loads out of the per-vector staging loop
     int wsSlices;             // ping-pong weight-stationary kernel: blocks per image
+    int twShift, thShift;     // TW = 1 << twShift, TH = 1 << thShift (both are powers of two)
+    uint32_t mPW, mPH;        // magic multipliers for division by PW, PH (operands < 2^16)
 };
 
 // NWN = waves along the pixel axis (2 or 4): block = 2 x NWN waves, tile = (64*MT) co x (128*NWN) pixels.
@@ -105,7 +107,7 @@ __global__ void __launch_bounds__(128 * NWN, 2) conv2d_fwd_kernel(ConvParams p) 
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         int q = wn * 128 + j * 32 + l31;
-        int c = q % p.TW; int r = (q / p.TW) % p.TH; int ti = q / (p.TW * p.TH);
+        int c = q & (p.TW - 1); int r = (q >> p.twShift) & (p.TH - 1); int ti = q >> (p.twShift + p.thShift);
         bBase[j] = ((ti * PH + r) * PW + c) * PITCH + lhi * 8;
     }
     int aBase[MT];
@@ -135,7 +137,9 @@ __global__ void __launch_bounds__(128 * NWN, 2) conv2d_fwd_kernel(ConvParams p) 
         int cv = v % (KC / 8), pix = v / (KC / 8);
         xoff[i] = -1; xn[i] = 0;
         if (pix < P) {
-            int pc = pix % PW; int t2 = pix / PW; int pr = t2 % PH; int ti = t2 / PH;
+            // PW, PH are not powers of two: multiply-high by host-made reciprocals instead of integer divisions
+            int t2 = PW == 1 ? pix : (int)__umulhi((uint32_t)pix, p.mPW); int pc = pix - t2 * PW;
+            int ti = PH == 1 ? t2 : (int)__umulhi((uint32_t)t2, p.mPH); int pr = t2 - ti * PH;
             int n = n0 + ti, h = h0 + pr - HALO, w = w0 + pc - HALO;
             if (n < p.N && h >= 0 && h < p.H && w >= 0 && w < p.W) {
                 xoff[i] = (((n * p.H + h) * p.W + w)) ;    // pixel index; multiplied by Cin at use (fits int for < 2^31 pixels)
@@ -234,7 +238,7 @@ __global__ void __launch_bounds__(128 * NWN, 2) conv2d_fwd_kernel(ConvParams p) 
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         int q = wn * 128 + j * 32 + l31;
-        int c = q % p.TW; int r = (q / p.TW) % p.TH; int ti = q / (p.TW * p.TH);
+        int c = q & (p.TW - 1); int r = (q >> p.twShift) & (p.TH - 1); int ti = q >> (p.twShift + p.thShift);
         int n = n0 + ti, h = h0 + r, w = w0 + c;
         if (n >= p.N || h >= p.H || w >= p.W) continue;
         const int64_t pixIdx = ((int64_t)n * p.H + h) * p.W + w;
@@ -910,6 +914,14 @@ extern "C" int agf_conv2d_fwd(const void* x, const void* w, void* y,
     p.tilesW = (W + p.TW - 1) / p.TW; p.tilesH = (H + p.TH - 1) / p.TH; p.tilesN = (N + p.TI - 1) / p.TI;
     p.pixTiles = p.tilesW * p.tilesH * p.tilesN;
     p.tilesCo = (Cout + 64 * MT - 1) / (64 * MT);
+    p.twShift = 0; while ((1 << p.twShift) < p.TW) p.twShift++;
+    p.thShift = 0; while ((1 << p.thShift) < p.TH) p.thShift++;
+    {
+        const int halo = ksize / 2;
+        const uint32_t pw = (uint32_t)(p.TW + 2 * halo), ph = (uint32_t)(p.TH + 2 * halo);
+        p.mPW = pw <= 1 ? 0u : (uint32_t)(0xFFFFFFFFull / pw) + 1u;      // exact for operands < 2^16
+        p.mPH = ph <= 1 ? 0u : (uint32_t)(0xFFFFFFFFull / ph) + 1u;
+    }
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if (ksize == 3) rc = MT == 2 ? launch_fwd<3, 2>(p, st) : launch_fwd<3, 1>(p, st);
