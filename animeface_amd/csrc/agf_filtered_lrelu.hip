@@ -947,7 +947,11 @@ static bool flr_rb_launch(FlrParams p, hipStream_t st, int* status) {
     P.b = p;
     P.mG = flr_magic(SU == 1 ? P.TVWa >> 3 : 1); P.mTUW = flr_magic(p.TUW); P.mMW = flr_magic(P.MW ? P.MW : 1);
     P.mQ4 = flr_magic(P.UPC >> 2); P.mTOW = flr_magic(p.TOW); P.mXP = flr_magic(P.XP);
+#ifdef AGF_PROFILE_PHASES      // build with -DAGF_PROFILE_PHASES for tools/flr_phases.sh; a product build cannot leave phases out
     { static const int sk = []{ const char* e = getenv("AGF_FLR_SKIP"); return e ? atoi(e) : 0; }(); P.skip = sk; }
+#else
+    P.skip = 0;
+#endif
     auto kern = flr_rb_kernel<T, UP, DOWN, SU, SD, RN, R4, NT>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { agf_set_error("filtered_lrelu: cannot reserve LDS: %s", hipGetErrorString(e)); *status = AGF_ELAUNCH; return true; }

@@ -1,5 +1,6 @@
 #!/bin/bash
-# kernel time of one filtered_lrelu layer with phases left out (AGF_FLR_SKIP) -> how the time splits
+# kernel time of one filtered_lrelu layer with phases left out (AGF_FLR_SKIP) -> how the time splits.
+# Needs a library built with -DAGF_PROFILE_PHASES (add it to FLAGS in animeface_amd/csrc/build.sh); the product build ignores the variable.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for sk in 0 1 2 4 8 15; do
   rm -rf /tmp/pk; AGF_FLR_SKIP=$sk rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pk -- python tools/flr_one.py "$@" 3 > /dev/null 2>&1
