@@ -26,6 +26,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define BLOCK_PIX 256
+#define XNONE (-2147483647 - 1)     // "no load" marker of the precomputed patch offsets (real offsets can be negative: halo)
 
 static __device__ __forceinline__ u32x4 scale_vec8_reg(u32x4 val, f32x4 s0, f32x4 s1) {
     float a0, a1;
@@ -352,11 +353,11 @@ __global__ void __launch_bounds__(256) conv2d_fwd_ws_kernel(ConvParams p) {
     for (int i = 0; i < XV; i++) {
         int v = tid + i * 256;
         int pix = v / VPR;
-        xrel[i] = -1; xofs[i] = 0;
-        if (pix < P && (v % VPR) * 8 < p.Cin) {
+        xrel[i] = -1; xofs[i] = XNONE;                   // XNONE: channel group beyond Cin -> the LDS slot is zero-filled
+        if (pix < P) {
             int pc = pix % PW; int t2 = pix / PW; int pr = t2 % PH; int ti = t2 / PH;
             xrel[i] = (ti << 20) | ((pr - HALO + 8) << 10) | (pc - HALO + 8);
-            xofs[i] = ((pr - HALO) * p.W + (pc - HALO)) * p.Cin + (v % VPR) * 8;   // from the tile's first pixel (TI == 1)
+            if ((v % VPR) * 8 < p.Cin) xofs[i] = ((pr - HALO) * p.W + (pc - HALO)) * p.Cin + (v % VPR) * 8;   // from the tile's first pixel (TI == 1)
         }
     }
     u32x4 xreg[XV];
@@ -373,14 +374,14 @@ __global__ void __launch_bounds__(256) conv2d_fwd_ws_kernel(ConvParams p) {
 #pragma unroll
             for (int i = 0; i < XV; i++) {
                 u32x4 val = {0u, 0u, 0u, 0u};
-                if (xrel[i] >= 0) val = *(const u32x4*)(org + xofs[i]);
+                if (xofs[i] != XNONE) val = *(const u32x4*)(org + xofs[i]);
                 xreg[i] = val;
             }
         } else {
 #pragma unroll
             for (int i = 0; i < XV; i++) {
                 u32x4 val = {0u, 0u, 0u, 0u};
-                if (xrel[i] >= 0) {
+                if (xofs[i] != XNONE) {
                     int n = n0 + (xrel[i] >> 20), h = h0 + ((xrel[i] >> 10) & 1023) - 8, w = w0 + (xrel[i] & 1023) - 8;
                     if (n < p.N && h >= 0 && h < p.H && w >= 0 && w < p.W) val = *(const u32x4*)(org + xofs[i]);
                 }
@@ -562,14 +563,12 @@ __global__ void __launch_bounds__(512, 2) conv2d_fwd_ws2_kernel(ConvParams p) {
         int v = gtid + i * 256;
         int pix = v / VPR;
         xrel[i] = -1;
-        xofs[i] = 0;
+        xofs[i] = XNONE;                                  // channel group beyond Cin -> the LDS slot is zero-filled
         if (pix < P) {
             int pc = pix % PW, pr = pix / PW;
             const int gc = (v % VPR) * 8;
-            if (gc < p.Cin) {
-                xrel[i] = ((pr - HALO + 8) << 10) | (pc - HALO + 8);
-                xofs[i] = ((pr - HALO) * p.W + (pc - HALO)) * p.Cin + gc;     // element offset from the tile's first pixel
-            }
+            xrel[i] = ((pr - HALO + 8) << 10) | (pc - HALO + 8);
+            if (gc < p.Cin) xofs[i] = ((pr - HALO) * p.W + (pc - HALO)) * p.Cin + gc;     // element offset from the tile's first pixel
         }
     }
     u32x4 xreg[XV];
@@ -585,14 +584,14 @@ __global__ void __launch_bounds__(512, 2) conv2d_fwd_ws2_kernel(ConvParams p) {
 #pragma unroll
             for (int i = 0; i < XV; i++) {
                 u32x4 val = {0u, 0u, 0u, 0u};
-                if (xrel[i] >= 0) val = *(const u32x4*)(org + xofs[i]);
+                if (xofs[i] != XNONE) val = *(const u32x4*)(org + xofs[i]);
                 xreg[i] = val;
             }
         } else {
 #pragma unroll
             for (int i = 0; i < XV; i++) {
                 u32x4 val = {0u, 0u, 0u, 0u};
-                if (xrel[i] >= 0) {
+                if (xofs[i] != XNONE) {
                     int h = h0 + (xrel[i] >> 10) - 8, w = w0 + (xrel[i] & 1023) - 8;
                     if (h >= 0 && h < p.H && w >= 0 && w < p.W) val = *(const u32x4*)(org + xofs[i]);
                 }

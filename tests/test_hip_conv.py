@@ -1,0 +1,125 @@
+"""GPU parity of the MFMA conv kernels at the kernel level: every tiling / variant the launcher can pick (generic 4-wave, 8-wave
+128x512, weight-stationary, ping-pong weight-stationary, 1x1, fp32 VALU path) and the weight-gradient kernel (compact / padded
+staging, split-K, per-image epilogue scales), against an fp32 ATen convolution of the same bf16-rounded operands."""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def rel(a, b):
+    return ((a.float() - b.float()).abs().max() / b.float().abs().max().clamp_min(1e-6)).item()
+
+
+def make(N, Cin, Cout, H, W, k, seed=0):
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    x = torch.randn(N, Cin, H, W, generator=g).to(torch.bfloat16).to(DEV).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).to(torch.bfloat16).to(DEV)
+    return x, w, g
+
+
+# (N, Cin, Cout, H, W, k, forced tiling or None, what it exercises)
+FWD_CASES = [
+    (4, 64, 64, 32, 32, 3, None, 'generic 64x256'),
+    (2, 72, 40, 19, 38, 3, None, 'generic, ragged map, partial co tile'),
+    (3, 128, 128, 32, 64, 3, '2', '8-wave 128x512'),
+    (2, 64, 136, 16, 32, 3, '2', '8-wave, partial co tile'),
+    (8, 32, 32, 256, 256, 3, None, 'weight-stationary 32->32'),
+    (8, 32, 64, 256, 256, 3, None, 'ping-pong weight-stationary 32->64'),
+    (8, 64, 32, 256, 256, 3, None, 'ping-pong weight-stationary 64->32'),
+    (9, 24, 16, 256, 256, 3, None, 'weight-stationary, channel tails, odd batch'),
+    (16, 512, 512, 4, 4, 3, None, 'multi-image tiles (4x4 maps)'),
+    (5, 512, 64, 8, 8, 3, None, 'multi-image tiles (8x8 maps)'),
+    (4, 64, 8, 64, 64, 1, None, '1x1 (ToImage shape)'),
+    (4, 8, 32, 64, 64, 1, None, '1x1 (from_rgb shape)'),
+]
+
+
+@pytest.mark.parametrize('case', FWD_CASES, ids=[c[-1] for c in FWD_CASES])
+@pytest.mark.parametrize('scaled', [False, True])
+def test_conv_fwd_variants_vs_aten(case, scaled, monkeypatch):
+    from animeface_amd.implementations.StyleGAN2.conv import conv2d_fwd_raw, ACT_LRELU, ACT_LINEAR
+    N, Cin, Cout, H, W, k, forced, _ = case
+    if forced:
+        monkeypatch.setenv('AGF_CONV_MT', forced)
+    x, w, g = make(N, Cin, Cout, H, W, k)
+    s_in = (torch.rand(N, Cin, generator=g) + 0.5).to(DEV) if scaled else None
+    s_out = (torch.rand(N, Cout, generator=g) + 0.5).to(DEV) if scaled else None
+    bias = torch.randn(Cout, generator=g).to(DEV)
+    noise = torch.randn(N, 1, H, W, generator=g).to(DEV) if scaled else None
+    res = None if scaled else torch.randn(N, Cout, H, W, generator=g).to(torch.bfloat16).to(DEV).contiguous(memory_format=torch.channels_last)
+    act = ACT_LRELU if scaled else ACT_LINEAR
+    gain = 1.0 if scaled else 0.7
+    y = conv2d_fwd_raw(x, w, in_scale=s_in, out_scale=s_out, bias=bias, noise=noise, residual=res, act=act, alpha=0.2, gain=gain)
+    xf = x.float() * (s_in[:, :, None, None] if scaled else 1.0)
+    ref = F.conv2d(xf, w.float(), padding=k // 2)
+    if scaled:
+        ref = ref * s_out[:, :, None, None]
+    ref = ref + bias[None, :, None, None]
+    if noise is not None:
+        ref = ref + noise
+    if res is not None:
+        ref = ref + res.float()
+    if scaled:
+        ref = F.leaky_relu(ref, 0.2)
+    ref = ref * gain
+    assert y.shape == ref.shape and y.dtype == torch.bfloat16
+    # bf16 output (2^-8) + bf16 rounding of the style-scaled operand on the scaled paths
+    assert rel(y, ref) < (1.2e-2 if scaled else 6e-3)
+
+
+WGRAD_CASES = [
+    (4, 64, 64, 32, 32, 3, 'compact tiles'),
+    (2, 72, 40, 19, 38, 3, 'ragged map, channel tails'),
+    (8, 32, 64, 256, 256, 3, 'large map: blocks inside one image'),
+    (16, 512, 512, 4, 4, 3, 'padded staging (4x4 maps)'),
+    (6, 256, 128, 8, 8, 3, 'padded staging (8x8 maps)'),
+    (4, 64, 8, 64, 64, 1, '1x1'),
+]
+
+
+@pytest.mark.parametrize('case', WGRAD_CASES, ids=[c[-1] for c in WGRAD_CASES])
+@pytest.mark.parametrize('scaled', [False, True])
+def test_conv_wgrad_variants_vs_aten(case, scaled):
+    from animeface_amd.implementations.StyleGAN2.conv import conv2d_wgrad_raw
+    N, Cin, Cout, H, W, k, _ = case
+    x, _, g = make(N, Cin, Cout, H, W, k, seed=1)
+    dy = torch.randn(N, Cout, H, W, generator=g).to(torch.bfloat16).to(DEV).contiguous(memory_format=torch.channels_last)
+    s_in = (torch.rand(N, Cin, generator=g) + 0.5).to(DEV) if scaled else None
+    s_out = (torch.rand(N, Cout, generator=g) + 0.5).to(DEV) if scaled else None
+    dw = conv2d_wgrad_raw(x, dy, k, in_scale=s_in, out_scale=s_out, scale=0.5)
+    xf = (x.float() * (s_in[:, :, None, None] if scaled else 1.0)).requires_grad_(False)
+    dyf = dy.float() * (s_out[:, :, None, None] if scaled else 1.0)
+    wz = torch.zeros(Cout, Cin, k, k, device=DEV, requires_grad=True)
+    (ref,) = torch.autograd.grad(F.conv2d(xf, wz, padding=k // 2), wz, dyf)
+    ref = ref * 0.5
+    assert tuple(dw.shape) == (Cout, Cin, k, k) and dw.dtype == torch.float32
+    assert rel(dw, ref) < (8e-3 if scaled else 1e-3)
+
+
+def test_conv_fp32_reference_precision_path():
+    from animeface_amd.implementations.StyleGAN2.conv import conv2d_fwd_raw, conv2d_wgrad_raw
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 12, 9, 11, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(7, 12, 3, 3, generator=g).to(DEV)
+    s = (torch.rand(2, 12, generator=g) + 0.5).to(DEV)
+    y = conv2d_fwd_raw(x, w, in_scale=s)
+    ref = F.conv2d(x * s[:, :, None, None], w, padding=1)
+    assert y.dtype == torch.float32 and rel(y, ref) < 1e-5
+    dy = torch.randn(2, 7, 9, 11, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    dw = conv2d_wgrad_raw(x, dy, 3, in_scale=s)
+    wz = torch.zeros_like(w, requires_grad=True)
+    (refw,) = torch.autograd.grad(F.conv2d(x * s[:, :, None, None], wz, padding=1), wz, dy)
+    assert rel(dw, refw) < 1e-5
+
+
+def test_prep_weights_layouts():
+    from animeface_amd.implementations.StyleGAN2.conv import prep_weights_raw, flip_transpose
+    w = torch.randn(24, 40, 3, 3, device=DEV)
+    wq, wft = prep_weights_raw(w, 0.37, torch.bfloat16, True, True)
+    assert torch.equal(wq, (w * 0.37).to(torch.bfloat16)) and wq.permute(0, 2, 3, 1).is_contiguous()
+    assert torch.equal(wft, flip_transpose(w * 0.37).to(torch.bfloat16)) and wft.permute(0, 2, 3, 1).is_contiguous()
