@@ -123,3 +123,30 @@ def test_prep_weights_layouts():
     wq, wft = prep_weights_raw(w, 0.37, torch.bfloat16, True, True)
     assert torch.equal(wq, (w * 0.37).to(torch.bfloat16)) and wq.permute(0, 2, 3, 1).is_contiguous()
     assert torch.equal(wft, flip_transpose(w * 0.37).to(torch.bfloat16)) and wft.permute(0, 2, 3, 1).is_contiguous()
+
+
+@pytest.mark.parametrize('shape', [(3, 64, 32, 32), (2, 40, 19, 38), (5, 512, 4, 4), (2, 8, 64, 64)])
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+def test_epilogue_backward_kernels_vs_torch(shape, dtype):
+    """agf_act_bwd_reduce (g, sum g*y0, sum g, sum g*noise) and agf_scale_dot (dx = t*s, ds = sum x*t)."""
+    from animeface_amd.implementations.StyleGAN2.conv import act_bwd_reduce_raw, scale_dot_raw
+    N, C, H, W = shape
+    g0 = torch.Generator().manual_seed(4)
+    y = torch.randn(N, C, H, W, generator=g0).to(dtype).to(DEV).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(N, C, H, W, generator=g0).to(dtype).to(DEV).contiguous(memory_format=torch.channels_last)
+    nz = torch.randn(N, 1, H, W, generator=g0).to(DEV)
+    alpha = 0.2
+    g, (A, B, Cn) = act_bwd_reduce_raw(dy, y, nz, alpha, (True, True, True))
+    yf, dyf = y.float(), dy.float()
+    gref = dyf * torch.where(yf > 0, 1.0, alpha)
+    y0 = torch.where(yf > 0, yf, yf / alpha)
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert rel(g, gref) < tol
+    assert rel(A, (gref * y0).sum((2, 3))) < 2e-3 and rel(B, gref.sum((2, 3))) < 2e-3 and rel(Cn, (gref * nz).sum((2, 3))) < 2e-3
+    _, (A2, B2, C2) = act_bwd_reduce_raw(dy, y, None, alpha, (False, True, False))
+    assert A2 is None and C2 is None and rel(B2, gref.sum((2, 3))) < 2e-3
+    s = (torch.rand(N, C, generator=g0) + 0.5).to(DEV)
+    dx, ds = scale_dot_raw(y, dy, s)
+    assert rel(dx, dyf * s[:, :, None, None]) < tol and rel(ds, (yf * dyf).sum((2, 3))) < 2e-3
+    none_dx, ds2 = scale_dot_raw(y, dy, s, want_dx=False)
+    assert none_dx is None and rel(ds2, (yf * dyf).sum((2, 3))) < 2e-3
