@@ -65,6 +65,8 @@ struct ConvParams {
     int wsSlices;             // ping-pong weight-stationary kernel: blocks per image
     int twShift, thShift;     // TW = 1 << twShift, TH = 1 << thShift (both are powers of two)
     uint32_t mPW, mPH;        // magic multipliers for division by PW, PH (operands < 2^16)
+    int flat, flatTiles;      // flat tiling: a tile = 256 consecutive pixels (row-major) of one image; flatTiles = tiles per image
+    uint32_t mW;              // magic multiplier for division by W (flat tiling)
 };
 
 // NWN = waves along the pixel axis (2 or 4): block = 2 x NWN waves, tile = (64*MT) co x (128*NWN) pixels.
@@ -90,11 +92,21 @@ __global__ void __launch_bounds__(128 * NWN, 2) conv2d_fwd_kernel(ConvParams p) 
     const int pixTile = (slot / p.tilesCo) * 8 + xcd;
     const int coTile = slot % p.tilesCo;
     if (pixTile >= p.pixTiles) return;
-    int tq = pixTile;
-    const int tw = tq % p.tilesW; tq /= p.tilesW;
-    const int th = tq % p.tilesH;
-    const int tn = tq / p.tilesH;
-    const int n0 = tn * p.TI, h0 = th * p.TH, w0 = tw * p.TW;
+    // rectangular tiling: (TI images) x TH x TW pixels.  Flat tiling (maps whose width is not a multiple of the tile: StyleGAN3's
+    // 38 / 54 / 66 / 86-wide maps waste up to half of a rectangular tile): 128*NWN consecutive pixels of one image in row-major
+    // order; the patch is then the rows they touch plus halo, TW = W and TH = the most rows a tile can span.
+    int n0, h0, w0, flatP0 = 0;
+    if (p.flat) {
+        const int tn = pixTile / p.flatTiles;
+        flatP0 = (pixTile - tn * p.flatTiles) * (128 * NWN);
+        n0 = tn; w0 = 0; h0 = (int)__umulhi((uint32_t)flatP0, p.mW);
+    } else {
+        int tq = pixTile;
+        const int tw = tq % p.tilesW; tq /= p.tilesW;
+        const int th = tq % p.tilesH;
+        const int tn = tq / p.tilesH;
+        n0 = tn * p.TI; h0 = th * p.TH; w0 = tw * p.TW;
+    }
     const int co0 = coTile * BM;
     const int PW = p.TW + 2 * HALO, PH = p.TH + 2 * HALO;
     const int P = p.TI * PH * PW;
@@ -108,7 +120,10 @@ __global__ void __launch_bounds__(128 * NWN, 2) conv2d_fwd_kernel(ConvParams p) 
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         int q = wn * 128 + j * 32 + l31;
-        int c = q & (p.TW - 1); int r = (q >> p.twShift) & (p.TH - 1); int ti = q >> (p.twShift + p.thShift);
+        int c, r, ti;
+        if (p.flat) { const int pg = flatP0 + q; const int row = (int)__umulhi((uint32_t)pg, p.mW); c = pg - row * p.W; r = row - h0; ti = 0;
+                      if (r >= p.TH) { r = 0; c = 0; } }                 // beyond the image: any in-patch address, result discarded
+        else { c = q & (p.TW - 1); r = (q >> p.twShift) & (p.TH - 1); ti = q >> (p.twShift + p.thShift); }
         bBase[j] = ((ti * PH + r) * PW + c) * PITCH + lhi * 8;
     }
     int aBase[MT];
@@ -239,7 +254,9 @@ __global__ void __launch_bounds__(128 * NWN, 2) conv2d_fwd_kernel(ConvParams p) 
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         int q = wn * 128 + j * 32 + l31;
-        int c = q & (p.TW - 1); int r = (q >> p.twShift) & (p.TH - 1); int ti = q >> (p.twShift + p.thShift);
+        int c, r, ti;
+        if (p.flat) { const int pg = flatP0 + q; const int row = (int)__umulhi((uint32_t)pg, p.mW); c = pg - row * p.W; r = row - h0; ti = 0; }
+        else { c = q & (p.TW - 1); r = (q >> p.twShift) & (p.TH - 1); ti = q >> (p.twShift + p.thShift); }
         int n = n0 + ti, h = h0 + r, w = w0 + c;
         if (n >= p.N || h >= p.H || w >= p.W) continue;
         const int64_t pixIdx = ((int64_t)n * p.H + h) * p.W + w;
@@ -905,13 +922,31 @@ extern "C" int agf_conv2d_fwd(const void* x, const void* w, void* y,
         if (forced == 2 || (forced != 1 && ksize == 3 && W >= 32 && H >= 16 && Cout >= 128 && Cin >= 64 && bigBlocks >= 384)) MT = 2;
         if (MT == 2 && !(W >= 32 && H >= 16)) MT = 1;
     }
-    const int blockPix = MT == 2 ? 512 : BLOCK_PIX;
+    int blockPix = MT == 2 ? 512 : BLOCK_PIX;
     p.TW = pow2_ceil(W) < 32 ? pow2_ceil(W) : 32;
     int th = pow2_ceil(H);
     p.TH = th < blockPix / p.TW ? th : blockPix / p.TW;
     p.TI = blockPix / (p.TW * p.TH);
     p.tilesW = (W + p.TW - 1) / p.TW; p.tilesH = (H + p.TH - 1) / p.TH; p.tilesN = (N + p.TI - 1) / p.TI;
     p.pixTiles = p.tilesW * p.tilesH * p.tilesN;
+    p.flat = 0; p.flatTiles = 0; p.mW = 0;
+    {
+        // flat tiling when the rectangular tiles would waste more than ~30 % of their pixels and the row patch stays small (wide
+        // maps stage too many halo pixels per output: 86x86 ran 2x slower flat, 38x38 1.45x faster -- tools/time_conv.py)
+        static const bool flat_on = []{ const char* e = getenv("AGF_CONV_FLAT"); return !(e && e[0] == '0'); }();
+        const int halo = ksize / 2;
+        const int span = (BLOCK_PIX + W - 2) / W + 1;                  // most rows 256 consecutive pixels can touch
+        const int Pflat = (span + 2 * halo) * (W + 2 * halo);
+        const double used = (double)N * H * W / ((double)p.pixTiles * blockPix);
+        if (flat_on && p.TI == 1 && W > 1 && H * W >= BLOCK_PIX && used < 0.72 && Pflat <= (ksize == 3 ? 450 : 256) && H * W < 65536) {
+            MT = 1; blockPix = BLOCK_PIX;
+            p.flat = 1; p.TI = 1; p.TW = W; p.TH = span;
+            p.flatTiles = (H * W + BLOCK_PIX - 1) / BLOCK_PIX;
+            p.pixTiles = N * p.flatTiles;
+            p.mW = (uint32_t)(0xFFFFFFFFull / (uint32_t)W) + 1u;
+            p.tilesW = 1; p.tilesH = p.flatTiles; p.tilesN = N;
+        }
+    }
     p.tilesCo = (Cout + 64 * MT - 1) / (64 * MT);
     p.twShift = 0; while ((1 << p.twShift) < p.TW) p.twShift++;
     p.thShift = 0; while ((1 << p.thShift) < p.TH) p.thShift++;

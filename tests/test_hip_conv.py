@@ -25,7 +25,10 @@ def make(N, Cin, Cout, H, W, k, seed=0):
 # (N, Cin, Cout, H, W, k, forced tiling or None, what it exercises)
 FWD_CASES = [
     (4, 64, 64, 32, 32, 3, None, 'generic 64x256'),
-    (2, 72, 40, 19, 38, 3, None, 'generic, ragged map, partial co tile'),
+    (2, 72, 40, 19, 38, 3, None, 'flat tiling, ragged map, partial co tile'),
+    (3, 128, 128, 38, 38, 3, None, 'flat tiling 38x38'),
+    (2, 64, 64, 54, 54, 3, None, 'flat tiling 54x54'),
+    (2, 64, 72, 86, 54, 3, None, 'ragged 86x54'),
     (3, 128, 128, 32, 64, 3, '2', '8-wave 128x512'),
     (2, 64, 136, 16, 32, 3, '2', '8-wave, partial co tile'),
     (8, 32, 32, 256, 256, 3, None, 'weight-stationary 32->32'),
