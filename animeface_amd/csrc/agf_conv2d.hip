@@ -1261,7 +1261,9 @@ extern "C" int agf_conv2d_wgrad(const void* x, const void* dy, float* dw,
             if (m < 1) m = 1;
             // one scaled flush per block and image: only worth it while that does not multiply the number of flushes
             // (small maps: N blocks of one tile each would spend their time in the 64x64x9 atomics)
-            if (N * m > want + want / 2 || tpi < 4) p.epiScale = 0;
+            // (with >= 12 tiles per block the extra flushes are cheap next to the operand scaling they replace: StyleGAN3's 38x38 ...
+            //  150x150 maps at batch 32)
+            if ((N * m > want + want / 2 && tpi / m < 12) || tpi < 4) p.epiScale = 0;
             else { p.perImage = m; p.splitK = N * m; }
         }
     }
