@@ -177,7 +177,7 @@ def main():
                 alg[name][0] += len(recs) * (n * h * w * (cin + cout) * 2 + cout * cin * ks * ks * 2)
                 alg[name][1] += len(recs)
             if k:
-                out['roofline'] = {'kernel': 'conv2d_fwd_kernel (MFMA implicit-GEMM 3x3/1x1 conv: forward + data-gradient launches)',
+                out['roofline'] = {'kernel': 'conv2d_fwd* (MFMA implicit-GEMM 3x3/1x1 conv, every instantiation: generic, 8-wave, weight-stationary, ping-pong; forward + data-gradient launches)',
                                    'bound': 'mfma', 'achieved': round(k['tflops'], 2), 'peak': MFMA_BF16_PEAK / 1e12,
                                    'unit': 'TFLOP/s', 'frac': round(k['tflops'] * 1e12 / MFMA_BF16_PEAK, 4),
                                    'traffic': traffic.get('conv2d_fwd', {}).get('traffic_bytes_per_launch'),
