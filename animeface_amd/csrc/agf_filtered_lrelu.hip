@@ -414,31 +414,6 @@ static __device__ __forceinline__ uint32_t flr_div(uint32_t a, uint32_t magic) {
 static inline uint32_t flr_magic(uint32_t d) { return d <= 1 ? 0u : (uint32_t)(0xFFFFFFFFull / d) + 1u; }
 #define FLR_DIV(a, d, magic) ((d) <= 1 ? (uint32_t)(a) : flr_div((uint32_t)(a), (magic)))
 
-// 2-bit codes of the four samples sx .. sx+3 of sign row sy (0 where the sign tensor does not cover them)
-static __device__ __forceinline__ uint32_t flr_load_signs(const FlrParams& p, int64_t plane64, int sx, int sy) {
-    if ((uint32_t)sy >= (uint32_t)p.SH) return 0;
-    const uint8_t* row = p.s + (int64_t)p.SWB * (sy + (int64_t)p.SH * plane64);
-    if (sx >= 0) {
-        const uint32_t b0 = (uint32_t)sx >> 2, b1 = b0 + 1;
-        uint32_t lo = b0 < (uint32_t)p.SWB ? row[b0] : 0u;
-        uint32_t hi = ((sx & 3) && b1 < (uint32_t)p.SWB) ? row[b1] : 0u;
-        return ((lo | (hi << 8)) >> ((sx & 3) << 1)) & 0xffu;
-    }
-    uint32_t sb = 0;                                             // left border: sample by sample
-#pragma unroll
-    for (int e = 0; e < 4; e++) {
-        const int sx1 = sx + e;
-        if (sx1 >= 0 && (uint32_t)(sx1 >> 2) < (uint32_t)p.SWB) sb |= ((uint32_t)(row[sx1 >> 2] >> ((sx1 & 3) << 1)) & 3u) << (e << 1);
-    }
-    return sb;
-}
-
-// 2-bit code of sign sample (sx, sy), 0 outside the sign tensor
-static __device__ __forceinline__ uint32_t flr_sign_at(const FlrParams& p, const uint8_t* splane, int sx, int sy) {
-    if ((uint32_t)sy >= (uint32_t)p.SH || (uint32_t)sx >= (uint32_t)(p.SWB << 2)) return 0;
-    return ((uint32_t)splane[(int64_t)p.SWB * sy + (sx >> 2)] >> ((sx & 3) << 1)) & 3u;
-}
-
 template <class T, int UP, int DOWN, int SU, int SD, int RN, int R4, int NT>
 __global__ void __launch_bounds__(NT, NT == 256 ? 2 : 4) flr_rb_kernel(FlrRbParams P) {
     constexpr int FU = 6 * UP, FD = 6 * DOWN;
@@ -720,8 +695,7 @@ __global__ void __launch_bounds__(NT, NT == 256 ? 2 : 4) flr_rb_kernel(FlrRbPara
                 const int it = it0 + u * NT;
                 const int ruy = (int)FLR_DIV(it, q4, P.mQ4), qx = (it - ruy * q4) << 2;
                 ruyv[u] = ruy; qxv[u] = (it < items && qx < p.TUW) ? qx : -1;
-                sbv[u] = 0;
-                if (p.signMode == 2 && qxv[u] >= 0) sbv[u] = flr_load_signs(p, plane64, ux0 + qx + p.sofsx, uy0 + ruy + p.sofsy);
+                sbv[u] = 0;                                          // (this pass only runs in sign-WRITE mode)
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
