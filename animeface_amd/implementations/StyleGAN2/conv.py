@@ -356,32 +356,36 @@ class _FusedConv(torch.autograd.Function):
             if need_w:
                 dw = (_ConvWgrad.apply(x, g, None, None, k) * coef).to(weight.dtype)
             return dx, dw, None, None, None, db, None, dres, None, None, None
+        # the output gain is not applied to the gradient tensor: it rides along in the data-gradient launch's epilogue gain, in the
+        # weight-gradient scale and in the bias sum (no pass over the tensor for it)
+        pg = float(gain)
         if act == ACT_LRELU:
-            assert gain == 1.0
+            assert gain == 1.0 or s_out is None, 'demodulated layers use unit gain'
             want_so = s_out is not None and need_so
             g, (A, B, Cn) = act_bwd_reduce_raw(dy, y, noise, alpha,
                                                (want_so, want_so or (need_b and bias is not None), want_so and noise is not None))
             if need_b and bias is not None:
-                db = B.sum(0).to(bias.dtype)
+                db = (B.sum(0) * pg if pg != 1.0 else B.sum(0)).to(bias.dtype)
             if want_so:
                 num = A - (bias.float()[None, :] * B if bias is not None else 0) - (Cn if Cn is not None else 0)
                 dso = num / s_out
         else:
             assert s_out is None, 'linear epilogue with a demodulation scale is not used by the networks'
-            g = dy * gain if gain != 1 else dy
+            g = dy
             if need_b and bias is not None:
-                db = g.sum((0, 2, 3), dtype=torch.float32).to(bias.dtype)
+                db = g.sum((0, 2, 3), dtype=torch.float32)
+                db = (db * pg if pg != 1.0 else db).to(bias.dtype)
         if need_r:
-            dres = g
+            dres = g * pg if pg != 1.0 else g
         if need_x or (s_in is not None and need_si):
             prep = prepared_weights(weight, coef, x.dtype, need_ft=True)
-            t = conv2d_fwd_raw(g, prep.wq_ft, in_scale=s_out, prepared=True)
+            t = conv2d_fwd_raw(g, prep.wq_ft, in_scale=s_out, prepared=True, gain=pg)
             if s_in is None:
                 dx = t
             else:
                 dx, dsi = scale_dot_raw(x, t, s_in, want_dx=need_x)
         if need_w:
-            dw = conv2d_wgrad_raw(x, g, k, in_scale=s_in, out_scale=s_out, scale=coef).to(weight.dtype)
+            dw = conv2d_wgrad_raw(x, g, k, in_scale=s_in, out_scale=s_out, scale=coef * pg).to(weight.dtype)
         return dx, dw, None, dsi, dso, db, None, dres, None, None, None
 
 
@@ -392,7 +396,7 @@ def conv2d_act(x, weight, bias=None, s_in=None, s_out=None, noise=None, alpha=0.
     ``fused=False`` evaluates the same expression with the separately differentiable ops (any-order gradients)."""
     from ...stylegan3_ops import bias_act as _ba
     Cout, Cin = weight.shape[0], weight.shape[1]
-    if fused and Cout % 8 == 0 and (act == 'linear' or gain == 1.0) and not (act == 'linear' and s_out is not None):
+    if fused and Cout % 8 == 0 and (act == 'linear' or gain == 1.0 or s_out is None) and not (act == 'linear' and s_out is not None):
         if x.dtype == torch.bfloat16 and Cin % 8:
             x = _pad_channels(x, 8, 1).contiguous(memory_format=torch.channels_last)
             weight = _pad_channels(weight, 8, 1)

@@ -24,7 +24,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ...stylegan3_ops import bias_act, filtered_lrelu, conv2d_resample, upfirdn2d, layout
-from ..StyleGAN2.conv import conv2d
+from ..StyleGAN2.conv import conv2d, conv2d_act
 
 
 def _native(x):
@@ -363,12 +363,19 @@ class ConvAct(nn.Module):
         if not _native(x):
             x = conv2d_resample.conv2d_resample(x, weight.to(x.dtype), self.down_filter, 1, self.down, self.padding)
         elif self.down == 1:
-            x = conv2d(x.contiguous(memory_format=torch.channels_last), weight)             # MFMA conv, "same" padding
+            # MFMA conv ("same" padding) with bias + activation + gain in its epilogue (and the fused backward of that epilogue)
+            return conv2d_act(x.contiguous(memory_format=torch.channels_last), self.weight, self.bias, coef=self.scale,
+                              act=self.act_name, gain=self.act_gain) if self.act_name in ('lrelu', 'linear') else \
+                bias_act.bias_act(conv2d(x.contiguous(memory_format=torch.channels_last), weight),
+                                  self.bias.to(x.dtype) if self.bias is not None else None, act=self.act_name, gain=self.act_gain)
         elif k == 1:
             # conv2d_resample's "1x1 + down" order (conv2d_resample.py:88-91): FIR-downsample first, then the 1x1 conv on MFMA
             f = self.down_filter
             p0, p1 = (f.shape[-1] - self.down + 1) // 2, (f.shape[-1] - self.down) // 2
             x = upfirdn2d.upfirdn2d(x, f, down=self.down, padding=[p0, p1, p0, p1])
+            if self.act_name in ('lrelu', 'linear'):
+                return conv2d_act(x.contiguous(memory_format=torch.channels_last), self.weight, self.bias, coef=self.scale,
+                                  act=self.act_name, gain=self.act_gain)
             x = conv2d(x.contiguous(memory_format=torch.channels_last), weight)
         else:
             # FIR + stride-2 conv of conv2d_resample.py:100-103.  The FIR and the (channel-mixing) conv commute, so the conv
