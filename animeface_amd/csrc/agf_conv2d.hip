@@ -164,6 +164,9 @@ __global__ void __launch_bounds__(128 * NWN, 2) conv2d_fwd_kernel(ConvParams p) 
         }
         (void)cv;
     }
+    f32x4 sc0 = {1.f, 1.f, 1.f, 1.f}, sc1 = sc0;
+    int scC0 = 0;
+    const bool oneImage = p.hoist && p.TI == 1 && (NTHR % (KC / 8)) == 0;
     auto load_chunk = [&](int c0) {
 #pragma unroll
         for (int i = 0; i < WV; i++) {
@@ -178,30 +181,36 @@ __global__ void __launch_bounds__(128 * NWN, 2) conv2d_fwd_kernel(ConvParams p) 
         }
         // style scale: when the tile lies in ONE image (TI == 1) every vector of this thread shares (n, channel group),
         // so the 8 scale values are loaded once per chunk instead of once per vector
-        f32x4 sc0 = {1.f, 1.f, 1.f, 1.f}, sc1 = sc0;
-        const bool oneImage = p.hoist && p.TI == 1 && (NTHR % (KC / 8)) == 0;
+        // The scales are applied in store_chunk(), AFTER the MFMAs of the previous chunk: multiplying here would make the
+        // thread wait for the patch loads it has just issued and expose their latency every chunk.
         if (IN_SCALE && oneImage) {
+            sc0 = sc1 = f32x4{1.f, 1.f, 1.f, 1.f};
             const int gcs = c0 + (tid % (KC / 8)) * 8;
             if (n0 < p.N && gcs < p.Cin) {
                 const float* sc = p.in_scale + (int64_t)n0 * p.Cin + gcs;
                 sc0 = *(const f32x4*)sc; sc1 = *(const f32x4*)(sc + 4);
             }
         }
+        scC0 = c0;
 #pragma unroll
         for (int i = 0; i < XV; i++) {
             int cv = (tid + i * NTHR) % (KC / 8), gc = c0 + cv * 8;
             u32x4 val = {0u, 0u, 0u, 0u};
-            if (xoff[i] >= 0 && gc < p.Cin) {
-                val = *(const u32x4*)(p.x + (int64_t)xoff[i] * p.Cin + gc);
-                if (IN_SCALE) {
-                    if (oneImage) val = scale_vec8_reg(val, sc0, sc1);
-                    else val = scale_vec8(val, p.in_scale + (int64_t)xn[i] * p.Cin + gc);
-                }
-            }
+            if (xoff[i] >= 0 && gc < p.Cin) val = *(const u32x4*)(p.x + (int64_t)xoff[i] * p.Cin + gc);
             xreg[i] = val;
         }
     };
     auto store_chunk = [&]() {
+        if (IN_SCALE) {
+#pragma unroll
+            for (int i = 0; i < XV; i++) {
+                if (oneImage) xreg[i] = scale_vec8_reg(xreg[i], sc0, sc1);
+                else {
+                    const int gc = scC0 + ((tid + i * NTHR) % (KC / 8)) * 8;
+                    if (xoff[i] >= 0 && gc < p.Cin) xreg[i] = scale_vec8(xreg[i], p.in_scale + (int64_t)xn[i] * p.Cin + gc);
+                }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < WV; i++) {
             int v = tid + i * NTHR;
