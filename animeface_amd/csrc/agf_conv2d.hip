@@ -61,6 +61,7 @@ struct ConvParams {
     int tilesW, tilesH, tilesN, tilesCo, pixTiles;
     int act;                  // 1 linear, 3 lrelu
     float alpha, gain;
+    int vecStore;             // epilogue: transpose through LDS and store 16-byte vectors (needs Cout % 8 == 0, y 16-byte aligned)
     int hoist;                // A/B switch: hoist the style-scale loads out of the per-vector staging loop
     int wsSlices;             // ping-pong weight-stationary kernel: blocks per image
     int twShift, thShift;     // TW = 1 << twShift, TH = 1 << thShift (both are powers of two)
@@ -74,14 +75,17 @@ struct ConvParams {
 //   <MT=2, NWN=4>: 128 co x 512 px, 8 waves (2 per SIMD), 141 KB LDS, one block per CU: half the staging traffic and
 //                  0.75 instead of 1.25 LDS fragment reads per MFMA (large maps with many channels)
 // PMAX = largest patch (pixels incl. halo) the launcher will use with this instantiation (sizes the staging registers).
-template <int KS, int MT, bool IN_SCALE, int KC, int NWN, int PMAX>
-__global__ void __launch_bounds__(128 * NWN, 2) conv2d_fwd_kernel(ConvParams p) {   // 2 waves per SIMD: two 4-wave blocks or one 8-wave block per CU
-    constexpr int NTHR = 128 * NWN;
+//   <MT=2, NWN=4, NWM=1>: 64 co x 512 px, 4 waves of 64 co x 128 px, 57 KB LDS, two blocks per CU -- the 64-output-channel layers.
+//     A wave tile of 32 co x 128 px reads 1 A + 4 B fragments (5 KB of LDS) per 4 MFMAs: four SIMDs then ask for 160 B/clk of
+//     the CU's 128 B/clk of LDS bandwidth; 64 co x 128 px reads 2 A + 4 B per 8 MFMAs (96 B/clk).
+template <int KS, int MT, bool IN_SCALE, int KC, int NWN, int PMAX, int NWM = 2, int NJ = 4, int OCC = 2>
+__global__ void __launch_bounds__(64 * NWM * NWN, OCC) conv2d_fwd_kernel(ConvParams p) {   // 2 waves per SIMD: two 4-wave blocks or one 8-wave block per CU
+    constexpr int NTHR = 64 * NWM * NWN;
     // KC = channels per K chunk (16 or 32); LDS row pitch = KC + 8 elements (48 / 80 bytes: conflict-free ds_read_b128)
     constexpr int PITCH = KC + 8;
     constexpr int TAPS = KS * KS;
     constexpr int HALO = KS / 2;
-    constexpr int BM = 64 * MT;
+    constexpr int BM = 32 * NWM * MT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* sW = (bf16_t*)smem_raw;                                  // [TAPS][BM][PITCH]
     bf16_t* sX = sW + TAPS * BM * PITCH;                             // [P][PITCH]
@@ -98,7 +102,7 @@ __global__ void __launch_bounds__(128 * NWN, 2) conv2d_fwd_kernel(ConvParams p) 
     int n0, h0, w0, flatP0 = 0;
     if (p.flat) {
         const int tn = pixTile / p.flatTiles;
-        flatP0 = (pixTile - tn * p.flatTiles) * (128 * NWN);
+        flatP0 = (pixTile - tn * p.flatTiles) * (32 * NJ * NWN);
         n0 = tn; w0 = 0; h0 = (int)__umulhi((uint32_t)flatP0, p.mW);
     } else {
         int tq = pixTile;
@@ -116,10 +120,10 @@ __global__ void __launch_bounds__(128 * NWN, 2) conv2d_fwd_kernel(ConvParams p) 
     const int l31 = lane & 31, lhi = lane >> 5;
 
     // per-lane LDS base (in elements) of the B fragment of each of the wave's 4 pixel sub-tiles, tap (0,0), k-step 0
-    int bBase[4];
+    int bBase[NJ];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        int q = wn * 128 + j * 32 + l31;
+    for (int j = 0; j < NJ; j++) {
+        int q = wn * (32 * NJ) + j * 32 + l31;
         int c, r, ti;
         if (p.flat) { const int pg = flatP0 + q; const int row = (int)__umulhi((uint32_t)pg, p.mW); c = pg - row * p.W; r = row - h0; ti = 0;
                       if (r >= p.TH) { r = 0; c = 0; } }                 // beyond the image: any in-patch address, result discarded
@@ -130,11 +134,11 @@ __global__ void __launch_bounds__(128 * NWN, 2) conv2d_fwd_kernel(ConvParams p) 
 #pragma unroll
     for (int i = 0; i < MT; i++) aBase[i] = (wm * 32 * MT + i * 32 + l31) * PITCH + lhi * 8;
 
-    f32x16 acc[MT][4];
+    f32x16 acc[MT][NJ];
 #pragma unroll
     for (int i = 0; i < MT; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++)
+        for (int j = 0; j < NJ; j++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
@@ -239,15 +243,15 @@ __global__ void __launch_bounds__(128 * NWN, 2) conv2d_fwd_kernel(ConvParams p) 
                 const int tapOffA = tap * BM * PITCH;
 #pragma unroll
                 for (int ks = 0; ks < KC / 16; ks++) {
-                    bf16x8 af[MT], bfr[4];
+                    bf16x8 af[MT], bfr[NJ];
 #pragma unroll
                     for (int i = 0; i < MT; i++) af[i] = *(const bf16x8*)(sW + tapOffA + aBase[i] + ks * 16);
 #pragma unroll
-                    for (int j = 0; j < 4; j++) bfr[j] = *(const bf16x8*)(sX + tapOffB + bBase[j] + ks * 16);
+                    for (int j = 0; j < NJ; j++) bfr[j] = *(const bf16x8*)(sX + tapOffB + bBase[j] + ks * 16);
 #pragma unroll
                     for (int i = 0; i < MT; i++)
 #pragma unroll
-                        for (int j = 0; j < 4; j++)
+                        for (int j = 0; j < NJ; j++)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
                 }
             }
@@ -259,17 +263,29 @@ __global__ void __launch_bounds__(128 * NWN, 2) conv2d_fwd_kernel(ConvParams p) 
         }
     }
 
-    // ---- epilogue: lane holds, per accumulator tile, one pixel (col) x 4 groups of 4 consecutive channels ----
+    // ---- epilogue.  A lane holds, per accumulator tile, ONE pixel (column) x 4 groups of 4 consecutive channels: written
+    //      straight to memory that is 8 bytes per lane with lanes a whole pixel row (2*Cout bytes) apart -- 64 partial-line
+    //      accesses per store instruction, and the address unit handles about one line per clock (timed with the stores removed:
+    //      25 % of the 64-channel 256x256 layer, 18 % at 128 channels, 12 % at 256).  So each wave transposes its tile through a
+    //      private LDS strip (the staging buffers are free by now): rows of 32*MT channels come back as 16-byte vectors and
+    //      consecutive lanes store consecutive addresses (64*MT contiguous bytes per pixel). ----
+    constexpr int EROW = 64 * MT + 16;                                // staged pixel row: 32*MT bf16 channels + the pixel's global index
+    const bool vecStore = p.vecStore;                                  // Cout % 8 == 0 and y 16-byte aligned (else the direct path)
+    unsigned char* sE = smem_raw + wave * (32 * EROW);
+    if (vecStore) __syncthreads();                                     // every wave is done reading sW / sX
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        int q = wn * 128 + j * 32 + l31;
+    for (int j = 0; j < NJ; j++) {
+        int q = wn * (32 * NJ) + j * 32 + l31;
         int c, r, ti;
         if (p.flat) { const int pg = flatP0 + q; const int row = (int)__umulhi((uint32_t)pg, p.mW); c = pg - row * p.W; r = row - h0; ti = 0; }
         else { c = q & (p.TW - 1); r = (q >> p.twShift) & (p.TH - 1); ti = q >> (p.twShift + p.thShift); }
         int n = n0 + ti, h = h0 + r, w = w0 + c;
-        if (n >= p.N || h >= p.H || w >= p.W) continue;
-        const int64_t pixIdx = ((int64_t)n * p.H + h) * p.W + w;
+        const bool valid = n < p.N && h < p.H && w < p.W;
+        if (!vecStore && !valid) continue;
+        const int64_t pixIdx = valid ? ((int64_t)n * p.H + h) * p.W + w : 0;
+        if (!valid) n = 0;
         const float nz = p.noise ? p.noise[pixIdx] : 0.f;
+        if (vecStore && lhi == 0) *(int64_t*)(sE + l31 * EROW + 64 * MT) = valid ? pixIdx : (int64_t)-1;
 #pragma unroll
         for (int i = 0; i < MT; i++) {
 #pragma unroll
@@ -304,10 +320,45 @@ __global__ void __launch_bounds__(128 * NWN, 2) conv2d_fwd_kernel(ConvParams p) 
                 u32x2 o;
                 o.x = Pack16<bf16_t>::pack(v[0], v[1]);
                 o.y = Pack16<bf16_t>::pack(v[2], v[3]);
-                *(u32x2*)(p.y + pixIdx * p.Cout + co) = o;
+                if (vecStore) *(u32x2*)(sE + l31 * EROW + (i * 32 + rg * 8 + lhi * 4) * 2) = o;
+                else *(u32x2*)(p.y + pixIdx * p.Cout + co) = o;
             }
         }
+        if (vecStore) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int t = 0; t < 2 * MT; t++) {
+                const int v = lane + 64 * t;
+                const int px = v / (4 * MT), cv = v % (4 * MT);
+                const int64_t pi = *(const int64_t*)(sE + px * EROW + 64 * MT);
+                const u32x4 val = *(const u32x4*)(sE + px * EROW + cv * 16);
+                const int co = co0 + wm * 32 * MT + cv * 8;
+                if (pi >= 0 && co < p.Cout) *(u32x4*)(p.y + pi * p.Cout + co) = val;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
     }
+}
+
+
+// Second half of the LDS-transposed epilogue of the weight-stationary kernels (see conv2d_fwd_kernel): the wave's strip holds
+// 32 pixel rows of 32 channels + the pixel's global index (-1 = outside the image); lanes store 16-byte vectors, 4 per pixel.
+static __device__ __forceinline__ void strip_store32(const unsigned char* sE, int lane, bf16_t* y, int Cout, int coBase) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const int v = lane + 64 * t;
+        const int px = v >> 2, cv = v & 3;
+        const int64_t pi = *(const int64_t*)(sE + px * 80 + 64);
+        const u32x4 val = *(const u32x4*)(sE + px * 80 + cv * 16);
+        const int co = coBase + cv * 8;
+        if (pi >= 0 && co < Cout) *(u32x4*)(y + pi * Cout + co) = val;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 }
 
 
@@ -334,6 +385,8 @@ __global__ void __launch_bounds__(256) conv2d_fwd_ws_kernel(ConvParams p) {
     const int PW = p.TW + 2 * HALO, PH = p.TH + 2 * HALO;
     const int P = p.TI * PH * PW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned char* sE = (unsigned char*)(sX + P * PITCH) + wave * (32 * 80);      // this wave's epilogue strip (LDS-transposed stores)
+    const bool vecStore = p.vecStore;
     // BM = 64: waves 2 (co) x 2 (pixel halves), 32 co x 128 px each;  BM = 32: waves 1 x 4, 32 co x 64 px each
     const int wm = BM == 64 ? (wave >> 1) : 0, wn = BM == 64 ? (wave & 1) : wave;
     const int l31 = lane & 31, lhi = lane >> 5;
@@ -373,7 +426,7 @@ __global__ void __launch_bounds__(256) conv2d_fwd_ws_kernel(ConvParams p) {
     const int aBase = (wm * 32 + l31) * PITCH + lhi * 8;
 
     // tile-invariant patch geometry: (image-in-tile, dh, dw) per staged vector, packed; -1 = beyond the patch
-    constexpr int XV = (340 * VPR + 255) / 256;                      // the launcher only uses 8x32 tiles (P = 340)
+    constexpr int XV = ((KS == 3 ? 340 : 256) * VPR + 255) / 256;    // the launcher only uses 8x32 tiles (P = 340, or 256 for 1x1)
     int xrel[XV], xofs[XV];
 #pragma unroll
     for (int i = 0; i < XV; i++) {
@@ -451,7 +504,7 @@ __global__ void __launch_bounds__(256) conv2d_fwd_ws_kernel(ConvParams p) {
                 int n = n0 + qi[j], h = h0 + qr[j], w = w0 + qc[j];
                 eok[j] = n < p.N && h < p.H && w < p.W;
                 en[j] = n;
-                epix[j] = ((int64_t)n * p.H + h) * p.W + w;
+                epix[j] = eok[j] ? ((int64_t)n * p.H + h) * p.W + w : 0;
                 enz[j] = (eok[j] && p.noise) ? p.noise[epix[j]] : 0.f;
 #pragma unroll
                 for (int rg = 0; rg < 4; rg++) {
@@ -482,9 +535,10 @@ __global__ void __launch_bounds__(256) conv2d_fwd_ws_kernel(ConvParams p) {
         // ---- epilogue of this tile ----
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
-            if (!eok[j]) continue;
+            if (!vecStore && !eok[j]) continue;
             const int64_t pixIdx = epix[j];
             const float nz = enz[j];
+            if (vecStore && lhi == 0) *(int64_t*)(sE + l31 * 80 + 64) = eok[j] ? pixIdx : (int64_t)-1;
 #pragma unroll
             for (int rg = 0; rg < 4; rg++) {
                 int co = co0 + wm * 32 + rg * 8 + lhi * 4;
@@ -509,8 +563,10 @@ __global__ void __launch_bounds__(256) conv2d_fwd_ws_kernel(ConvParams p) {
                 u32x2 o;
                 o.x = Pack16<bf16_t>::pack(v[0], v[1]);
                 o.y = Pack16<bf16_t>::pack(v[2], v[3]);
-                *(u32x2*)(p.y + pixIdx * p.Cout + co) = o;
+                if (vecStore) *(u32x2*)(sE + l31 * 80 + (rg * 8 + lhi * 4) * 2) = o;
+                else *(u32x2*)(p.y + pixIdx * p.Cout + co) = o;
             }
+            if (vecStore) strip_store32(sE, lane, p.y, p.Cout, co0 + wm * 32);
         }
         if (more) {
             __syncthreads();
@@ -546,6 +602,8 @@ __global__ void __launch_bounds__(512, 2) conv2d_fwd_ws2_kernel(ConvParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int grp = wave >> 2, gw = wave & 3, gtid = tid & 255;
     bf16_t* sX = sW + TAPS * BM * PITCH + grp * (PMAXP * PITCH);     // this group's [P][PITCH]
+    unsigned char* sE = (unsigned char*)(sW + (TAPS * BM + 2 * PMAXP) * PITCH) + wave * (32 * 80);   // this wave's epilogue strip
+    const bool vecStore = p.vecStore;
 
     const int coTile = blockIdx.x % p.tilesCo;
     const int worker = blockIdx.x / p.tilesCo;
@@ -679,9 +737,11 @@ __global__ void __launch_bounds__(512, 2) conv2d_fwd_ws2_kernel(ConvParams p) {
 #pragma unroll
                 for (int j = 0; j < NJ; j++) {
                     const int h = h0 + qr[j], w = w0 + qc[j];
-                    if (h >= p.H || w >= p.W) continue;
-                    const int64_t pixIdx = ((int64_t)img * p.H + h) * p.W + w;
+                    const bool valid = h < p.H && w < p.W;
+                    if (!vecStore && !valid) continue;
+                    const int64_t pixIdx = valid ? ((int64_t)img * p.H + h) * p.W + w : 0;
                     const float nz = p.noise ? p.noise[pixIdx] : 0.f;
+                    if (vecStore && lhi == 0) *(int64_t*)(sE + l31 * 80 + 64) = valid ? pixIdx : (int64_t)-1;
 #pragma unroll
                     for (int rg = 0; rg < 4; rg++) {
                         int co = co0 + wm * 32 + rg * 8 + lhi * 4;
@@ -709,8 +769,10 @@ __global__ void __launch_bounds__(512, 2) conv2d_fwd_ws2_kernel(ConvParams p) {
                         u32x2 o;
                         o.x = Pack16<bf16_t>::pack(v[0], v[1]);
                         o.y = Pack16<bf16_t>::pack(v[2], v[3]);
-                        *(u32x2*)(p.y + pixIdx * p.Cout + co) = o;
+                        if (vecStore) *(u32x2*)(sE + l31 * 80 + (rg * 8 + lhi * 4) * 2) = o;
+                        else *(u32x2*)(p.y + pixIdx * p.Cout + co) = o;
                     }
+                    if (vecStore) strip_store32(sE, lane, p.y, p.Cout, co0 + wm * 32);
                 }
             }
             have = false;
@@ -731,7 +793,7 @@ static int launch_fwd_ws2(const ConvParams& p0, hipStream_t st) {
     p.tilesCo = (p.Cout + BM - 1) / BM;
     const int P = (p.TH + 2 * HALO) * (p.TW + 2 * HALO);
     if (p.TI != 1 || P > 340) return AGF_ENOKERNEL;
-    size_t lds = (size_t)(TAPS * BM + 2 * 340) * PITCH * sizeof(bf16_t);
+    size_t lds = (size_t)(TAPS * BM + 2 * 340) * PITCH * sizeof(bf16_t) + 8 * 32 * 80;       // + the waves' epilogue strips
     if (lds > 160 * 1024) return AGF_ENOKERNEL;
     const int tpi = p.tilesH * p.tilesW;
     int m = 256 / (p.N * p.tilesCo);                                 // slices per image: about one 8-wave block per CU
@@ -826,18 +888,20 @@ __global__ void __launch_bounds__(256) conv2d_wgrad_f32_kernel(WgradF32Params p)
 
 static int pow2_ceil(int v) { int r = 1; while (r < v) r <<= 1; return r; }
 
-template <int KS, int MT, bool SC, int KC, int NWN, int PMAX>
-static int launch_fwd_v(const ConvParams& p, hipStream_t st) {
-    constexpr int TAPS = KS * KS, HALO = KS / 2, BM = 64 * MT, PITCH = KC + 8;
+template <int KS, int MT, bool SC, int KC, int NWN, int PMAX, int NWM = 2, int NJ = 4, int OCC = 2>
+static int launch_fwd_v(const ConvParams& p0, hipStream_t st) {
+    constexpr int TAPS = KS * KS, HALO = KS / 2, BM = 32 * NWM * MT, PITCH = KC + 8;
+    ConvParams p = p0;
+    p.tilesCo = (p.Cout + BM - 1) / BM;
     const int P = p.TI * (p.TH + 2 * HALO) * (p.TW + 2 * HALO);
     if (P > PMAX) { agf_set_error("conv2d_fwd: internal patch %d exceeds %d", P, PMAX); return AGF_ENOKERNEL; }
     size_t lds = (size_t)(TAPS * BM + P) * PITCH * sizeof(bf16_t);
     if (lds > 160 * 1024) { agf_set_error("conv2d_fwd: tile needs %zu bytes of LDS", lds); return AGF_ENOKERNEL; }
     const int slots = ((p.pixTiles + 7) / 8) * p.tilesCo;
-    dim3 grid((unsigned)(slots * 8)), block(128 * NWN);
-    hipError_t e = hipFuncSetAttribute((const void*)conv2d_fwd_kernel<KS, MT, SC, KC, NWN, PMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    dim3 grid((unsigned)(slots * 8)), block(64 * NWM * NWN);
+    hipError_t e = hipFuncSetAttribute((const void*)conv2d_fwd_kernel<KS, MT, SC, KC, NWN, PMAX, NWM, NJ, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { agf_set_error("conv2d_fwd: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e)); return AGF_ELAUNCH; }
-    hipLaunchKernelGGL((conv2d_fwd_kernel<KS, MT, SC, KC, NWN, PMAX>), grid, block, lds, st, p);
+    hipLaunchKernelGGL((conv2d_fwd_kernel<KS, MT, SC, KC, NWN, PMAX, NWM, NJ, OCC>), grid, block, lds, st, p);
     return AGF_OK;
 }
 
@@ -847,9 +911,9 @@ static int launch_fwd_ws(const ConvParams& p0, hipStream_t st) {
     ConvParams p = p0;
     p.tilesCo = (p.Cout + BM - 1) / BM;
     const int P = p.TI * (p.TH + 2 * HALO) * (p.TW + 2 * HALO);
-    size_t lds = (size_t)(TAPS * BM + P) * PITCH * sizeof(bf16_t);
+    size_t lds = (size_t)(TAPS * BM + P) * PITCH * sizeof(bf16_t) + 4 * 32 * 80;      // + the waves' epilogue strips
     if (lds > 160 * 1024) return AGF_ENOKERNEL;
-    const int perCU = lds <= 80 * 1024 ? 2 : 1;
+    const int perCU = KS == 1 ? 4 : lds <= 80 * 1024 ? 2 : 1;       // 1x1: HBM streaming, more blocks in flight per CU
     int workers = (256 * perCU) / p.tilesCo;
     if (workers < 1) workers = 1;
     if (workers > p.pixTiles) workers = p.pixTiles;
@@ -866,6 +930,15 @@ static int launch_fwd(const ConvParams& p, hipStream_t st) {
     if (g_ws_enable < 0) { const char* e = getenv("AGF_CONV_WS"); g_ws_enable = e ? atoi(e) : 1; }
     // weight-stationary kernel: Cin <= 32 (two blocks per CU), or Cin <= 64 with Cout <= 32 (32-channel co tile: the
     // generic 64-channel tile would waste half of its MFMAs there); measured per layer in tools/ab_ws.sh
+    static const int ws1 = []{ const char* e = getenv("AGF_CONV_WS1"); return e ? atoi(e) : 1; }();
+    if (g_ws_enable && ws1 && (ws1 == 2 || p.in_scale) && KS == 1 && MT == 1 && p.pixTiles >= 2048 && p.TW == 32 && p.TH == 8 && p.TI == 1 && p.Cin <= 32 && p.Cout <= 64) {
+        // 1x1 convs with few channels (FromRGB / ToRGB / the 32 -> 64 skip): pure streaming work.  One 256-pixel tile per block left
+        // them at ~2 TB/s (block prologue per 20 KB of traffic); the persistent kernel keeps the weights in LDS and streams tiles.
+        int rc;
+        if (p.Cout <= 32) rc = p.in_scale ? launch_fwd_ws<1, true, 32, 32>(p, st) : launch_fwd_ws<1, false, 32, 32>(p, st);
+        else              rc = p.in_scale ? launch_fwd_ws<1, true, 32, 64>(p, st) : launch_fwd_ws<1, false, 32, 64>(p, st);
+        if (rc != AGF_ENOKERNEL) return rc;
+    }
     if (g_ws_enable && KS == 3 && MT == 1 && p.pixTiles >= 2048 && p.TW == 32 && p.TH == 8 && p.TI == 1 &&
         (p.Cin <= 32 || (p.Cin <= 64 && p.Cout <= 32) || (g_ws_enable >= 2 && p.Cin <= 64 && p.Cout <= 64))) {
         int rc;
@@ -882,6 +955,10 @@ static int launch_fwd(const ConvParams& p, hipStream_t st) {
         else                             rc = p.in_scale ? launch_fwd_ws<3, true, 64, 32>(p, st) : launch_fwd_ws<3, false, 64, 32>(p, st);
         if (rc != AGF_ENOKERNEL) return rc;
     }
+    static const int w64b = []{ const char* e = getenv("AGF_CONV_W64B"); return e ? atoi(e) : 0; }();
+    if (w64b && KS == 3 && MT == 1 && !p.flat && p.TI == 1 && p.TW == 32 && p.TH == 8 && p.Cout > 32 && p.Cout <= 64 && p.Cin >= 32)
+        return p.in_scale ? launch_fwd_v<KS, 2, true, 16, 4, 340, 1, 2, 3>(p, st) : launch_fwd_v<KS, 2, false, 16, 4, 340, 1, 2, 3>(p, st);
+    if (MT == 2 && p.Cout <= 64) return p.in_scale ? launch_fwd_v<KS, 2, true, 16, 4, 612, 1>(p, st) : launch_fwd_v<KS, 2, false, 16, 4, 612, 1>(p, st);
     if (MT == 2) return p.in_scale ? launch_fwd_v<KS, 2, true, 16, 4, 612>(p, st) : launch_fwd_v<KS, 2, false, 16, 4, 612>(p, st);
     return p.in_scale ? launch_fwd_v<KS, 1, true, 32, 2, (KS == 3 ? 576 : 256)>(p, st) : launch_fwd_v<KS, 1, false, 32, 2, (KS == 3 ? 576 : 256)>(p, st);
 }
@@ -921,6 +998,8 @@ extern "C" int agf_conv2d_fwd(const void* x, const void* w, void* y,
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
     p.act = act; p.alpha = alpha; p.gain = act_gain;
     { static int h = -1; if (h < 0) { const char* e = getenv("AGF_CONV_HOIST"); h = e ? atoi(e) : 1; } p.hoist = h; }
+    { static const int vs = []{ const char* e = getenv("AGF_CONV_VSTORE"); return e ? atoi(e) : 1; }();
+      p.vecStore = vs && (Cout % 8) == 0 && ((uintptr_t)y % 16) == 0; }
     // Two tilings.  Large: 128 co x 512 px (16x32 pixel tile), 8 waves -- when the map is at least 16x32, there are at
     // least 128 output channels and the grid still fills the chip (>= 384 blocks).  Default: 64 co x 256 px, 4 waves.
     int MT = 1;
@@ -929,6 +1008,10 @@ extern "C" int agf_conv2d_fwd(const void* x, const void* w, void* y,
         int forced = e ? atoi(e) : 0;
         int64_t bigBlocks = (int64_t)N * ((H + 15) / 16) * ((W + 31) / 32) * ((Cout + 127) / 128);
         if (forced == 2 || (forced != 1 && ksize == 3 && W >= 32 && H >= 16 && Cout >= 128 && Cin >= 64 && bigBlocks >= 384)) MT = 2;
+        // 64 output channels: the 64 co x 512 px tile of four 64 co x 128 px waves (see the kernel comment)
+        static const int w64 = []{ const char* e = getenv("AGF_CONV_W64"); return e ? atoi(e) : 2; }();      // 1: only Cin >= 64
+        if (w64 && forced != 1 && ksize == 3 && W >= 32 && H >= 16 && Cout > 32 && Cout <= 64 && Cin >= (w64 == 2 ? 32 : 64) &&
+            (int64_t)N * ((H + 15) / 16) * ((W + 31) / 32) >= 512) MT = 2;
         if (MT == 2 && !(W >= 32 && H >= 16)) MT = 1;
     }
     int blockPix = MT == 2 ? 512 : BLOCK_PIX;

@@ -39,6 +39,12 @@ FWD_CASES = [
     (5, 512, 64, 8, 8, 3, None, 'multi-image tiles (8x8 maps)'),
     (4, 64, 8, 64, 64, 1, None, '1x1 (ToImage shape)'),
     (4, 8, 32, 64, 64, 1, None, '1x1 (from_rgb shape)'),
+    (16, 64, 64, 128, 128, 3, None, '4-wave 64co x 512px tile'),
+    (16, 32, 48, 128, 128, 3, None, '4-wave 64co x 512px tile, partial co tile, Cin 32'),
+    (2, 64, 12, 32, 32, 3, None, 'Cout % 8 != 0: direct (untransposed) stores'),
+    (8, 32, 12, 256, 256, 3, None, 'weight-stationary, direct stores'),
+    (8, 32, 8, 256, 256, 1, None, '1x1 weight-stationary (ToImage at 256x256)'),
+    (8, 32, 64, 256, 256, 1, None, '1x1 weight-stationary 32->64'),
 ]
 
 

@@ -3,8 +3,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from animeface_amd.implementations.StyleGAN2.conv import conv2d_fwd_raw
 N, Cin, Cout, H, W = [int(v) for v in sys.argv[1:6]]
+KS = int(sys.argv[6]) if len(sys.argv) > 6 else 3
 x = torch.randn(N, Cin, H, W, device='cuda').to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-w = (torch.randn(Cout, Cin, 3, 3, device='cuda') / (Cin * 9) ** 0.5).to(torch.bfloat16)
+w = (torch.randn(Cout, Cin, KS, KS, device='cuda') / (Cin * KS * KS) ** 0.5).to(torch.bfloat16)
 sc = (torch.rand(N, Cin, device='cuda') + 0.5) if os.environ.get('SCALED') == '1' else None
 for _ in range(3):
     conv2d_fwd_raw(x, w, in_scale=sc)
@@ -16,4 +17,5 @@ for _ in range(20):
 e.record(); torch.cuda.synchronize()
 ms = s.elapsed_time(e) / 20
 print(json.dumps(dict(variant=os.environ.get('AGF_CONV_VARIANT'), MT=os.environ.get('AGF_CONV_MT'), shape=[N, Cin, Cout, H, W], ms=round(ms, 4),
-                      TFLOPs=round(2.0 * N * H * W * Cin * Cout * 9 / ms / 1e9, 1))))
+                      TFLOPs=round(2.0 * N * H * W * Cin * Cout * KS * KS / ms / 1e9, 1),
+                      GBps=round(2.0 * N * H * W * (Cin + Cout) / ms / 1e6, 1))))
