@@ -1339,7 +1339,13 @@ extern "C" int agf_conv2d_wgrad(const void* x, const void* dy, float* dw,
     int base = p.tilesCo * p.tilesCi;
     // split K over blocks: aim at >= 512 blocks, but keep >= 4 pixel tiles per block so that the MFMA work of a block
     // outweighs its 2 x 64x64x9 fp32 atomics (small maps used to be dominated by the atomic epilogue)
-    int want = (512 + base - 1) / base;
+    // 3x3: ONE 8-wave block per CU (the kernel's 256 registers allow no more) and one round of blocks: every extra block adds
+    // 64x64x9 fp32 atomics, which are memory-side operations on this part (WRITE_SIZE counts them: 94 MB per launch at 512 blocks);
+    // 256 instead of 512 blocks: 770 -> 830 TFLOP/s on the large layers, 550 -> 670 on the 16x16 maps.  1x1 (128 registers, two
+    // blocks per CU, pure streaming) keeps 512.  (A two-stage combine -- partial tiles to scratch with plain stores + a reduce
+    // kernel -- was measured slower than these atomics.)
+    static const int wantBlocks = []{ const char* e = getenv("AGF_WGRAD_BLOCKS"); return e ? atoi(e) : 0; }();
+    int want = ((wantBlocks ? wantBlocks : (ksize == 3 ? 256 : 512)) + base - 1) / base;
     int cap = p.pixTiles / 4 < 1 ? 1 : p.pixTiles / 4;
     p.splitK = want < 1 ? 1 : (want > cap ? cap : want);
     {
