@@ -1278,7 +1278,35 @@ __global__ void __launch_bounds__(512) conv2d_wgrad_kernel(WgradParams p) {
             __syncthreads();
         }
     }
-    if (ptBegin < ptEnd) flush(curN);
+    if (ptBegin >= ptEnd) return;                        // block-uniform
+    // The two k-halves hold partial sums of the SAME four quadrants: add them through LDS (the staging buffers are free now; three
+    // taps = 48 KB per round) so that only one half issues the atomics -- they are the expensive part of this epilogue.
+    {
+        float* sRed = (float*)smem_raw;
+        const int quad = wave & 3;
+#pragma unroll
+        for (int t0 = 0; t0 < TAPS; t0 += 3) {
+            __syncthreads();
+            if (khalf == 1) {
+#pragma unroll
+                for (int t = 0; t < 3; t++)
+                    if (t0 + t < TAPS) {
+#pragma unroll
+                        for (int r = 0; r < 16; r++) sRed[((quad * 3 + t) * 16 + r) * 64 + lane] = acc[t0 + t < TAPS ? t0 + t : 0][r];
+                    }
+            }
+            __syncthreads();
+            if (khalf == 0) {
+#pragma unroll
+                for (int t = 0; t < 3; t++)
+                    if (t0 + t < TAPS) {
+#pragma unroll
+                        for (int r = 0; r < 16; r++) acc[t0 + t < TAPS ? t0 + t : 0][r] += sRed[((quad * 3 + t) * 16 + r) * 64 + lane];
+                    }
+            }
+        }
+    }
+    if (khalf == 0) flush(curN);
 }
 
 template <int KS, bool COMPACT>
@@ -1367,6 +1395,7 @@ extern "C" int agf_conv2d_wgrad(const void* x, const void* dy, float* dw,
     }
     AGF_CHECK(DYR <= 256 && XR * 8 <= 6 * 512 && DYR % 16 == 0, "conv2d_wgrad: internal tile too large");
     size_t lds = (size_t)(2 * DYR + 2 * XR) * 32 * sizeof(bf16_t);
+    if (lds < 4 * 3 * 16 * 64 * sizeof(float)) lds = 4 * 3 * 16 * 64 * sizeof(float);      // the epilogue's k-half reduction strip
     if (lds > 160 * 1024) { agf_set_error("conv2d_wgrad: tile needs %zu bytes of LDS", lds); return AGF_ENOKERNEL; }
     hipStream_t st = (hipStream_t)stream;
     int rc;
