@@ -1099,7 +1099,7 @@ static __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* base) {
 
 
 template <int KS, bool COMPACT>
-__global__ void __launch_bounds__(512) conv2d_wgrad_kernel(WgradParams p) {
+__global__ void __launch_bounds__(512, KS == 1 ? 4 : 2) conv2d_wgrad_kernel(WgradParams p) {     // 1x1: 128 registers, two blocks per CU
     // 8 waves: waves 0-3 and 4-7 own the same four (co32 x ci32) quadrants but alternate k-steps (even / odd); both
     // halves add their partial sums with the same atomics that already combine the split-K blocks.  Two waves per SIMD
     // is what hides the LDS latency of the 20 transpose reads per k-step (one wave per SIMD ran the MFMA pipe at 20 %).
@@ -1125,8 +1125,12 @@ __global__ void __launch_bounds__(512) conv2d_wgrad_kernel(WgradParams p) {
     const int co0 = tco * 64, ci0 = tci * 64;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int khalf = wave >> 2;                         // which k-steps this wave contracts
-    const int wa = (wave >> 1) & 1, wb = wave & 1;       // co block, ci block
+    // 8 waves = realQ (co32 x ci32) quadrants x kSplit interleaved k-step subsets.  A layer with <= 32 input (output) channels has
+    // only one ci (co) block: its waves take more k-steps instead of contracting zero padding (32 -> 64 channels: 2 x 4, 32 -> 32: 1 x 8).
+    const int realQ = (p.Cout > 32 ? 2 : 1) * (p.Cin > 32 ? 2 : 1);
+    const int quad = wave & (realQ - 1), kidx = wave / realQ, kSplit = 8 / realQ;
+    const int wa = p.Cout > 32 ? (p.Cin > 32 ? quad >> 1 : quad) : 0;      // co block
+    const int wb = p.Cin > 32 ? (quad & 1) : 0;                            // ci block
     const int li = lane & 15, lg = (lane >> 4) & 1, lk = lane >> 5;
     const int laneOff = (8 * lk + (li >> 2)) * 32 + 16 * lg + 4 * (li & 3);
     const bf16_t* aPtr = sDy + wa * DYR * 32 + laneOff;
@@ -1260,7 +1264,7 @@ __global__ void __launch_bounds__(512) conv2d_wgrad_kernel(WgradParams p) {
             return s * 16 - (HALO * PW + HALO);
         };
         const int nSteps = DYR / 16;
-        for (int sc = khalf; sc < nSteps; sc += 2) {
+        for (int sc = kidx; sc < nSteps; sc += kSplit) {
             const int xr = xrow_of(sc);
             const bf16x8 af = tr_frag(aPtr + sc * 16 * 32);
             bf16x8 bfr[TAPS];
@@ -1279,34 +1283,27 @@ __global__ void __launch_bounds__(512) conv2d_wgrad_kernel(WgradParams p) {
         }
     }
     if (ptBegin >= ptEnd) return;                        // block-uniform
-    // The two k-halves hold partial sums of the SAME four quadrants: add them through LDS (the staging buffers are free now; three
-    // taps = 48 KB per round) so that only one half issues the atomics -- they are the expensive part of this epilogue.
+    // The k-step subsets hold partial sums of the SAME quadrants: add them through LDS (the staging buffers are free now; one tap =
+    // 8 waves x 4 KB per round) so that only one wave per quadrant issues the atomics -- they are the expensive part of this epilogue.
     {
         float* sRed = (float*)smem_raw;
-        const int quad = wave & 3;
 #pragma unroll
-        for (int t0 = 0; t0 < TAPS; t0 += 3) {
+        for (int t = 0; t < TAPS; t++) {
             __syncthreads();
-            if (khalf == 1) {
+            if (kidx != 0) {
 #pragma unroll
-                for (int t = 0; t < 3; t++)
-                    if (t0 + t < TAPS) {
-#pragma unroll
-                        for (int r = 0; r < 16; r++) sRed[((quad * 3 + t) * 16 + r) * 64 + lane] = acc[t0 + t < TAPS ? t0 + t : 0][r];
-                    }
+                for (int r = 0; r < 16; r++) sRed[(wave * 16 + r) * 64 + lane] = acc[t][r];
             }
             __syncthreads();
-            if (khalf == 0) {
+            if (kidx == 0) {
+                for (int k = 1; k < kSplit; k++) {
 #pragma unroll
-                for (int t = 0; t < 3; t++)
-                    if (t0 + t < TAPS) {
-#pragma unroll
-                        for (int r = 0; r < 16; r++) acc[t0 + t < TAPS ? t0 + t : 0][r] += sRed[((quad * 3 + t) * 16 + r) * 64 + lane];
-                    }
+                    for (int r = 0; r < 16; r++) acc[t][r] += sRed[((k * realQ + quad) * 16 + r) * 64 + lane];
+                }
             }
         }
     }
-    if (khalf == 0) flush(curN);
+    if (kidx == 0) flush(curN);
 }
 
 template <int KS, bool COMPACT>
@@ -1395,7 +1392,7 @@ extern "C" int agf_conv2d_wgrad(const void* x, const void* dy, float* dw,
     }
     AGF_CHECK(DYR <= 256 && XR * 8 <= 6 * 512 && DYR % 16 == 0, "conv2d_wgrad: internal tile too large");
     size_t lds = (size_t)(2 * DYR + 2 * XR) * 32 * sizeof(bf16_t);
-    if (lds < 4 * 3 * 16 * 64 * sizeof(float)) lds = 4 * 3 * 16 * 64 * sizeof(float);      // the epilogue's k-half reduction strip
+    if (lds < 8 * 16 * 64 * sizeof(float)) lds = 8 * 16 * 64 * sizeof(float);      // the epilogue's k-half reduction strip
     if (lds > 160 * 1024) { agf_set_error("conv2d_wgrad: tile needs %zu bytes of LDS", lds); return AGF_ENOKERNEL; }
     hipStream_t st = (hipStream_t)stream;
     int rc;
