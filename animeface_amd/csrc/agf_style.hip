@@ -1,0 +1,185 @@
+// Style / demodulation scalars of the modulated convolution (reference implementations/StyleGAN2/model.py:105-121):
+//     s[b,ci] = affine(w_latent)[b,ci] + 1                        (the affine GEMM itself stays a library GEMM)
+//     d[b,co] = rsqrt( coef^2 * sum_ci s[b,ci]^2 * wsq[co,ci] + eps ),    wsq[co,ci] = sum_taps W[co,ci,kh,kw]^2
+// The reference materialises W * s per sample and reduces that; evaluated through wsq the whole thing is two tiny GEMM-shaped
+// reductions -- but as torch ops it is 9 launches forward and ~15 backward per layer of 4-5 us each (a fifth of the training step
+// was such glue).  Here: one launch forward, two backward, plus one per weight version for wsq.  fp32 throughout.
+#include "agf_common.h"
+
+// wsq[co][ci] and its transpose wsq_t[ci][co]: 16x16 tile per block, lanes along ci for the 36-byte tap runs, LDS transpose
+__global__ void __launch_bounds__(256) wsq_kernel(const float* __restrict__ w, float* __restrict__ wsq, float* __restrict__ wsq_t,
+                                                  int Cout, int Cin, int taps) {
+    __shared__ float tile[16][17];
+    const int tid = threadIdx.x, a = tid & 15, b = tid >> 4;
+    const int ci = blockIdx.x * 16 + a, co = blockIdx.y * 16 + b;
+    float v = 0.f;
+    if (ci < Cin && co < Cout) {
+        const float* p = w + ((int64_t)co * Cin + ci) * taps;
+        for (int t = 0; t < taps; t++) v += p[t] * p[t];
+        wsq[(int64_t)co * Cin + ci] = v;
+    }
+    tile[b][a] = v;
+    __syncthreads();
+    const int co2 = blockIdx.y * 16 + a, ci2 = blockIdx.x * 16 + b;
+    if (ci2 < Cin && co2 < Cout) wsq_t[(int64_t)ci2 * Cout + co2] = tile[a][b];
+}
+
+// forward: block = 64 output channels x 4 batch rows; 4 wave-sized slices split the ci sum.  Dynamic LDS: s^2 [4][Cin].
+__global__ void __launch_bounds__(256) style_demod_fwd_kernel(const float* __restrict__ s_raw, const float* __restrict__ wsq_t,
+                                                              float* __restrict__ s, float* __restrict__ d,
+                                                              int B, int Cin, int Cout, float c2, float eps) {
+    extern __shared__ float smem[];
+    float* s2 = smem;                                    // [4][Cin]
+    __shared__ float red[4][4][64];
+    const int tid = threadIdx.x, col = tid & 63, slice = tid >> 6;
+    const int co = blockIdx.x * 64 + col, b0 = blockIdx.y * 4;
+    for (int idx = tid; idx < 4 * Cin; idx += 256) {
+        const int bt = idx / Cin, ci = idx - bt * Cin, b = b0 + bt;
+        float v = 0.f;
+        if (b < B) {
+            v = s_raw[(int64_t)b * Cin + ci] + 1.f;
+            if (blockIdx.x == 0) s[(int64_t)b * Cin + ci] = v;
+        }
+        s2[idx] = v * v;
+    }
+    __syncthreads();
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (co < Cout) {
+        for (int ci = slice; ci < Cin; ci += 4) {
+            const float wv = wsq_t[(int64_t)ci * Cout + co];
+#pragma unroll
+            for (int bt = 0; bt < 4; bt++) acc[bt] += s2[bt * Cin + ci] * wv;
+        }
+    }
+#pragma unroll
+    for (int bt = 0; bt < 4; bt++) red[slice][bt][col] = acc[bt];
+    __syncthreads();
+    if (slice == 0 && co < Cout) {
+#pragma unroll
+        for (int bt = 0; bt < 4; bt++) {
+            const int b = b0 + bt;
+            if (b < B) d[(int64_t)b * Cout + co] = rsqrtf(c2 * (red[0][bt][col] + red[1][bt][col] + red[2][bt][col] + red[3][bt][col]) + eps);
+        }
+    }
+}
+
+// backward, style part:  g = dd * d' = -0.5 * c2 * d^3 * dd;   ds_raw[b,ci] = ds[b,ci] + 2 s[b,ci] * sum_co g[b,co] wsq[co,ci]
+// Dynamic LDS: g [4][Cout].
+__global__ void __launch_bounds__(256) style_demod_bwd_ds_kernel(const float* __restrict__ s, const float* __restrict__ d,
+                                                                 const float* __restrict__ dd, const float* __restrict__ ds,
+                                                                 const float* __restrict__ wsq, float* __restrict__ ds_raw,
+                                                                 int B, int Cin, int Cout, float c2) {
+    extern __shared__ float smem[];
+    float* g = smem;                                     // [4][Cout]
+    __shared__ float red[4][4][64];
+    const int tid = threadIdx.x, col = tid & 63, slice = tid >> 6;
+    const int ci = blockIdx.x * 64 + col, b0 = blockIdx.y * 4;
+    for (int idx = tid; idx < 4 * Cout; idx += 256) {
+        const int bt = idx / Cout, co = idx - bt * Cout, b = b0 + bt;
+        float v = 0.f;
+        if (b < B) { const float dv = d[(int64_t)b * Cout + co]; v = -0.5f * c2 * dv * dv * dv * dd[(int64_t)b * Cout + co]; }
+        g[idx] = v;
+    }
+    __syncthreads();
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ci < Cin) {
+        for (int co = slice; co < Cout; co += 4) {
+            const float wv = wsq[(int64_t)co * Cin + ci];
+#pragma unroll
+            for (int bt = 0; bt < 4; bt++) acc[bt] += g[bt * Cout + co] * wv;
+        }
+    }
+#pragma unroll
+    for (int bt = 0; bt < 4; bt++) red[slice][bt][col] = acc[bt];
+    __syncthreads();
+    if (slice == 0 && ci < Cin) {
+#pragma unroll
+        for (int bt = 0; bt < 4; bt++) {
+            const int b = b0 + bt;
+            if (b < B) {
+                const int64_t o = (int64_t)b * Cin + ci;
+                const float sum = red[0][bt][col] + red[1][bt][col] + red[2][bt][col] + red[3][bt][col];
+                ds_raw[o] = (ds ? ds[o] : 0.f) + 2.f * s[o] * sum;
+            }
+        }
+    }
+}
+
+// backward, weight part:  dw[co,ci,t] = 2 W[co,ci,t] * sum_b g[b,co] s[b,ci]^2.   Block = 16 co x 64 ci, batch in chunks of 64.
+__global__ void __launch_bounds__(256) style_demod_bwd_dw_kernel(const float* __restrict__ s, const float* __restrict__ d,
+                                                                 const float* __restrict__ dd, const float* __restrict__ w,
+                                                                 float* __restrict__ dw, int B, int Cin, int Cout, int taps, float c2) {
+    __shared__ float gs[64][16];
+    __shared__ float s2[64][64];
+    const int tid = threadIdx.x, col = tid & 63, sub = tid >> 6;
+    const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 16;
+    const int ci = ci0 + col;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int bb = 0; bb < B; bb += 64) {
+        for (int idx = tid; idx < 64 * 16; idx += 256) {
+            const int bl = idx >> 4, c = idx & 15, b = bb + bl, co = co0 + c;
+            float v = 0.f;
+            if (b < B && co < Cout) { const float dv = d[(int64_t)b * Cout + co]; v = -0.5f * c2 * dv * dv * dv * dd[(int64_t)b * Cout + co]; }
+            gs[bl][c] = v;
+        }
+        for (int idx = tid; idx < 64 * 64; idx += 256) {
+            const int bl = idx >> 6, c = idx & 63, b = bb + bl;
+            float v = 0.f;
+            if (b < B && ci0 + c < Cin) { v = s[(int64_t)b * Cin + ci0 + c]; v *= v; }
+            s2[bl][c] = v;
+        }
+        __syncthreads();
+        const int nb = B - bb < 64 ? B - bb : 64;
+        for (int bl = 0; bl < nb; bl++) {
+            const float sv = s2[bl][col];
+#pragma unroll
+            for (int k = 0; k < 4; k++) acc[k] += gs[bl][sub * 4 + k] * sv;
+        }
+        __syncthreads();
+    }
+    if (ci >= Cin) return;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int co = co0 + sub * 4 + k;
+        if (co >= Cout) continue;
+        const int64_t o = ((int64_t)co * Cin + ci) * taps;
+        const float f = 2.f * acc[k];
+        for (int t = 0; t < taps; t++) dw[o + t] = w[o + t] * f;
+    }
+}
+
+extern "C" int agf_wsq(const float* w, float* wsq, float* wsq_t, int32_t Cout, int32_t Cin, int32_t taps, void* stream) {
+    AGF_CHECK(w && wsq && wsq_t, "wsq: null pointer");
+    AGF_CHECK(Cout >= 1 && Cin >= 1 && taps >= 1, "wsq: empty tensor");
+    hipLaunchKernelGGL(wsq_kernel, dim3((unsigned)agf_ceil_div(Cin, 16), (unsigned)agf_ceil_div(Cout, 16)), dim3(256), 0,
+                       (hipStream_t)stream, w, wsq, wsq_t, Cout, Cin, taps);
+    AGF_LAUNCH_CHECK();
+    return AGF_OK;
+}
+
+extern "C" int agf_style_demod_fwd(const float* s_raw, const float* wsq_t, float* s, float* d,
+                                   int32_t B, int32_t Cin, int32_t Cout, float c2, float eps, void* stream) {
+    AGF_CHECK(s_raw && wsq_t && s && d, "style_demod_fwd: null pointer");
+    AGF_CHECK(B >= 1 && Cin >= 1 && Cout >= 1, "style_demod_fwd: empty tensor");
+    AGF_CHECK((size_t)4 * Cin * sizeof(float) <= 48 * 1024, "style_demod_fwd: Cin = %d is too large", Cin);
+    hipLaunchKernelGGL(style_demod_fwd_kernel, dim3((unsigned)agf_ceil_div(Cout, 64), (unsigned)agf_ceil_div(B, 4)), dim3(256),
+                       (size_t)4 * Cin * sizeof(float), (hipStream_t)stream, s_raw, wsq_t, s, d, B, Cin, Cout, c2, eps);
+    AGF_LAUNCH_CHECK();
+    return AGF_OK;
+}
+
+extern "C" int agf_style_demod_bwd(const float* s, const float* d, const float* dd, const float* ds, const float* wsq, const float* w,
+                                   float* ds_raw, float* dw, int32_t B, int32_t Cin, int32_t Cout, int32_t taps, float c2, void* stream) {
+    AGF_CHECK(s && d && dd && wsq, "style_demod_bwd: null pointer");
+    AGF_CHECK(B >= 1 && Cin >= 1 && Cout >= 1 && taps >= 1, "style_demod_bwd: empty tensor");
+    AGF_CHECK((size_t)4 * Cout * sizeof(float) <= 48 * 1024, "style_demod_bwd: Cout = %d is too large", Cout);
+    AGF_CHECK(!dw || w, "style_demod_bwd: dw needs w");
+    if (ds_raw)
+        hipLaunchKernelGGL(style_demod_bwd_ds_kernel, dim3((unsigned)agf_ceil_div(Cin, 64), (unsigned)agf_ceil_div(B, 4)), dim3(256),
+                           (size_t)4 * Cout * sizeof(float), (hipStream_t)stream, s, d, dd, ds, wsq, ds_raw, B, Cin, Cout, c2);
+    if (dw)
+        hipLaunchKernelGGL(style_demod_bwd_dw_kernel, dim3((unsigned)agf_ceil_div(Cin, 64), (unsigned)agf_ceil_div(Cout, 16)), dim3(256),
+                           0, (hipStream_t)stream, s, d, dd, w, dw, B, Cin, Cout, taps, c2);
+    AGF_LAUNCH_CHECK();
+    return AGF_OK;
+}

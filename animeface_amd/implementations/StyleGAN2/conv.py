@@ -313,6 +313,73 @@ def prepared_weights(weight, coef, dtype, need_ft=False):
     return ent
 
 
+def _wsq_pair(weight):
+    """(wsq [Cout,Cin], wsq_t [Cin,Cout]) = sum over taps of W^2, fp32; cached per half-step like the prepared weights."""
+    cacheable = _prep_cache_on and isinstance(weight, torch.nn.Parameter)
+    key = (id(weight), 'wsq')
+    if cacheable:
+        ent = _prep_cache.get(key)
+        if ent is not None and ent[0]() is weight:
+            return ent[1], ent[2]
+    import weakref
+    w = _f32(weight.detach())
+    Cout, Cin = w.shape[0], w.shape[1]
+    wsq = torch.empty(Cout, Cin, dtype=torch.float32, device=w.device)
+    wsq_t = torch.empty(Cin, Cout, dtype=torch.float32, device=w.device)
+    rc = _lib.lib().agf_wsq(_lib.ptr(w), _lib.ptr(wsq), _lib.ptr(wsq_t), Cout, Cin, w.shape[2] * w.shape[3], _lib.stream_ptr(w))
+    _lib.check(rc, 'wsq')
+    if cacheable:
+        _prep_cache[key] = (weakref.ref(weight), wsq, wsq_t)
+    return wsq, wsq_t
+
+
+class _StyleDemod(torch.autograd.Function):
+    """(s, d) = (s_raw + 1, rsqrt(coef^2 * (s^2 @ wsq^T) + 1e-4)) in one launch (reference model.py:105-121); backward in two.
+    First-order only, like the fused modulated conv it feeds (``fused_epilogue=False`` selects the composite expression)."""
+
+    @staticmethod
+    def forward(ctx, s_raw, weight, coef, eps):
+        _lib.require_gpu(s_raw, 'style_demod')
+        s_raw = _f32(s_raw)
+        B, Cin = s_raw.shape
+        Cout = weight.shape[0]
+        wsq, wsq_t = _wsq_pair(weight)
+        s = torch.empty_like(s_raw)
+        d = torch.empty(B, Cout, dtype=torch.float32, device=s_raw.device)
+        rc = _lib.lib().agf_style_demod_fwd(_lib.ptr(s_raw), _lib.ptr(wsq_t), _lib.ptr(s), _lib.ptr(d), B, Cin, Cout,
+                                            float(coef * coef), float(eps), _lib.stream_ptr(s_raw))
+        _lib.check(rc, 'style_demod_fwd')
+        ctx.save_for_backward(s, d, weight, wsq)
+        ctx.c2 = float(coef * coef)
+        return s, d
+
+    @staticmethod
+    def backward(ctx, ds, dd):
+        s, d, weight, wsq = ctx.saved_tensors
+        if torch.is_grad_enabled() and (ds is not None and ds.requires_grad or dd is not None and dd.requires_grad):
+            raise RuntimeError('the fused style / demodulation op has no double backward; build the generator with '
+                               'fused_epilogue=False when pl_lambda > 0')
+        need_s, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if dd is None:
+            return (ds if need_s else None), None, None, None
+        B, Cin = s.shape
+        Cout = d.shape[1]
+        dd = _f32(dd).contiguous()
+        ds = _f32(ds).contiguous() if ds is not None else None
+        w = _f32(weight.detach())
+        ds_raw = torch.empty_like(s) if need_s else None
+        dw = torch.empty_like(w) if need_w else None
+        rc = _lib.lib().agf_style_demod_bwd(_lib.ptr(s), _lib.ptr(d), _lib.ptr(dd), _lib.ptr(ds), _lib.ptr(wsq), _lib.ptr(w),
+                                            _lib.ptr(ds_raw), _lib.ptr(dw), B, Cin, Cout, w.shape[2] * w.shape[3], ctx.c2,
+                                            _lib.stream_ptr(s))
+        _lib.check(rc, 'style_demod_bwd')
+        return ds_raw, (dw.to(weight.dtype) if dw is not None else None), None, None
+
+
+def style_demod(s_raw, weight, coef, eps=1e-4):
+    return _StyleDemod.apply(s_raw, weight, coef, eps)
+
+
 class _FusedConv(torch.autograd.Function):
     """y = act( s_out * conv(x * s_in, weight * coef) + bias + noise + residual ) * gain   in one launch.
     act = lrelu (gain must be 1) or linear.  The backward is fused too unless a graph is being recorded."""

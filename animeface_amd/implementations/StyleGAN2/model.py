@@ -20,6 +20,7 @@ Activations run channels-last in ``compute_dtype`` (bf16 for training, fp32 for 
 parameters stay fp32.  The skip path of ``DBlock`` pools before its 1x1 conv (the two commute exactly).
 """
 import functools
+import os
 
 import numpy as np
 import torch
@@ -28,13 +29,14 @@ import torch.nn.functional as F
 
 from ...stylegan3_ops import upfirdn2d, bias_act
 from ... import rng
-from .conv import conv2d, conv2d_act
+from .conv import conv2d, conv2d_act, style_demod
 
 
 # bias / noise / leaky-ReLU run in the conv kernel's epilogue (with a fused backward).  The fused modulated conv has
 # no double backward, so the generator falls back to the separately differentiable ops when ``fused_epilogue=False``
 # (needed only for the path-length penalty, pl_lambda > 0).
 FUSED_EPILOGUE = True
+_STYLE_FUSED = os.environ.get('AGF_STYLE_FUSED', '1') != '0'      # A/B switch: one-launch style / demodulation scalars
 
 
 class ELR(nn.Module):
@@ -174,6 +176,8 @@ class ModulatedConv2d(nn.Module):
     def scales(self, y):
         """style scale s [B,Cin] and demodulation d [B,Cout] (fp32).
         sum_{ci,kh,kw} (W*coef*s)^2  ==  coef^2 * (s^2 @ (sum_{kh,kw} W^2)^T): no scaled copy of the weights is made."""
+        if self.demod and FUSED_EPILOGUE and _STYLE_FUSED and getattr(self, 'fused_epilogue', True) and y.is_cuda:
+            return style_demod(self.affine(y), self.weight, self.coef, 1e-4)
         s = self.affine(y) + 1
         d = None
         if self.demod:

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define AGF_ABI_VERSION 2
+#define AGF_ABI_VERSION 3
 
 /* element types of activation tensors */
 enum { AGF_F32 = 0, AGF_F16 = 1, AGF_BF16 = 2, AGF_F64 = 3 };
@@ -180,6 +180,19 @@ int agf_cl_to_planar_crop(const void* x, void* y, int dtype, int32_t N, int32_t 
  *   (implementations/StyleGAN2/model.py:29-37,105), which the reference multiplies into activations or weights on every call. */
 int agf_prep_weights(const float* w, void* wq, void* wft, int dtype, int32_t Cout, int32_t Cin, int32_t ksize,
                      float coef, void* stream);
+
+/* Style / demodulation scalars of ModulatedConv2d (implementations/StyleGAN2/model.py:105-121; the reference scales a per-sample
+ * copy of the weights by the style and reduces it: `weight * style`, `rsqrt(weight.pow(2).sum([2,3,4]) + 1e-4)`).  Evaluated here
+ * through wsq[co][ci] = sum_taps W[co][ci][kh][kw]^2 without materialising scaled weights; everything fp32.
+ *   agf_wsq:              wsq [Cout][Cin] and its transpose wsq_t [Cin][Cout] from W [Cout][Cin][taps]       (once per weight version)
+ *   agf_style_demod_fwd:  s = s_raw + 1 [B][Cin];  d[b][co] = rsqrt(c2 * sum_ci s[b][ci]^2 wsq_t[ci][co] + eps)   (c2 = coef^2)
+ *   agf_style_demod_bwd:  with g = -c2/2 * d^3 * dd:  ds_raw = ds + 2 s * (g @ wsq)  (ds nullable; ds_raw nullable = skip),
+ *                         dw[co][ci][t] = 2 W[co][ci][t] * sum_b g[b][co] s[b][ci]^2       (dw nullable = skip; needs w) */
+int agf_wsq(const float* w, float* wsq, float* wsq_t, int32_t Cout, int32_t Cin, int32_t taps, void* stream);
+int agf_style_demod_fwd(const float* s_raw, const float* wsq_t, float* s, float* d,
+                        int32_t B, int32_t Cin, int32_t Cout, float c2, float eps, void* stream);
+int agf_style_demod_bwd(const float* s, const float* d, const float* dd, const float* ds, const float* wsq, const float* w,
+                        float* ds_raw, float* dw, int32_t B, int32_t Cin, int32_t Cout, int32_t taps, float c2, void* stream);
 
 #ifdef __cplusplus
 }

@@ -159,3 +159,28 @@ def test_epilogue_backward_kernels_vs_torch(shape, dtype):
     assert rel(dx, dyf * s[:, :, None, None]) < tol and rel(ds, (yf * dyf).sum((2, 3))) < 2e-3
     none_dx, ds2 = scale_dot_raw(y, dy, s, want_dx=False)
     assert none_dx is None and rel(ds2, (yf * dyf).sum((2, 3))) < 2e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(64, 512, 512, 3), (6, 64, 32, 3), (5, 40, 72, 3), (3, 512, 8, 1)])
+def test_style_demod_vs_composite(shape):
+    """agf_wsq / agf_style_demod_fwd / agf_style_demod_bwd against the composite torch expression of ModulatedConv2d.scales."""
+    from animeface_amd.implementations.StyleGAN2.conv import style_demod
+    B, Cin, Cout, k = shape
+    g0 = torch.Generator().manual_seed(7)
+    s_raw = (torch.randn(B, Cin, generator=g0) * 0.5).to(DEV).requires_grad_(True)
+    w = torch.randn(Cout, Cin, k, k, generator=g0).to(DEV).requires_grad_(True)
+    coef = 1.0 / (Cin * k * k) ** 0.5
+    gs = torch.randn(B, Cin, generator=g0).to(DEV)
+    gd = torch.randn(B, Cout, generator=g0).to(DEV)
+    s, d = style_demod(s_raw, w, coef)
+    ds_raw, dw = torch.autograd.grad([s, d], [s_raw, w], [gs, gd])
+    s_ref = s_raw + 1
+    d_ref = torch.rsqrt((s_ref.square() @ w.square().sum((2, 3)).t()) * (coef * coef) + 1e-4)
+    ds_ref, dw_ref = torch.autograd.grad([s_ref, d_ref], [s_raw, w], [gs, gd])
+    assert rel(s, s_ref) < 1e-6 and rel(d, d_ref) < 1e-5
+    assert rel(ds_raw, ds_ref) < 1e-4 and rel(dw, dw_ref) < 1e-4
+    # only the demodulation gradient (ds None is not a case autograd produces for s, but zero is) and weight-only / style-only requests
+    (dw2,) = torch.autograd.grad(style_demod(s_raw.detach(), w, coef)[1], [w], [gd])
+    (ref2,) = torch.autograd.grad(torch.rsqrt(((s_raw.detach() + 1).square() @ w.square().sum((2, 3)).t()) * (coef * coef) + 1e-4), [w], [gd])
+    assert rel(dw2, ref2) < 1e-4
