@@ -807,6 +807,72 @@ static int launch_fwd_ws2(const ConvParams& p0, hipStream_t st) {
 }
 
 // =================================================================================================
+// Pointwise (1x1) conv from 8 input channels -- FromRGB (3 -> 32, RGB padded to 8) and ToRGB's data gradient at 256x256.
+// Pure streaming work (16 bytes in, 64 bytes out and 64 FMAs per lane-pixel): no MFMA, no LDS; a lane owns one group of 8 output
+// channels of one pixel, its 8x8 weight block lives in registers, every load / store is a 16-byte vector, the Cout/8 lanes of a
+// pixel share the input vector and store 2*Cout contiguous bytes.  The MFMA kernel ran this layer at 2.1 TB/s (one 256-pixel tile
+// per block, 3/4 of the staged K zero padding); this one reaches 3.5.  Epilogue as in conv2d_fwd_kernel minus noise / residual
+// (the launcher routes those, wider outputs and the C -> 8 direction to the MFMA kernels, which measured faster there).
+__global__ void __launch_bounds__(256) conv2d_pw8_kernel(ConvParams p, int G, int64_t pixels) {
+    const int64_t t0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int g = (int)(t0 % G);                                     // constant per thread: the grid stride is a multiple of G
+    const int64_t pstride = ((int64_t)gridDim.x * 256) / G;
+    const int HW = p.H * p.W;
+    float wv[8][8];                                                  // [co][ci] block of this lane
+#pragma unroll
+    for (int j = 0; j < 8; j++) VecIO<bf16_t, 8>::load(p.w + (8 * g + j) * 8, wv[j]);
+    float bias[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) bias[j] = p.bias ? p.bias[8 * g + j] : 0.f;
+    // four pixels per iteration: their loads are all issued before the first is consumed (one load per ~2 us round trip left the
+    // kernel latency-bound at 2.9 TB/s)
+    constexpr int U = 4;
+    for (int64_t pix0 = t0 / G; pix0 < pixels; pix0 += U * pstride) {
+        u32x4 raw[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int64_t pix = pix0 + u * pstride;
+            raw[u] = u32x4{0u, 0u, 0u, 0u};
+            if (pix < pixels) raw[u] = *(const u32x4*)(p.x + pix * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int64_t pix = pix0 + u * pstride;
+            if (pix >= pixels) break;
+            float x[8], o[8];
+            Pack16<bf16_t>::unpack(raw[u].x, x[0], x[1]); Pack16<bf16_t>::unpack(raw[u].y, x[2], x[3]);
+            Pack16<bf16_t>::unpack(raw[u].z, x[4], x[5]); Pack16<bf16_t>::unpack(raw[u].w, x[6], x[7]);
+            int n = 0;
+            if (p.in_scale || p.out_scale) n = (int)(pix / HW);
+            if (p.in_scale) {
+                const float* sc = p.in_scale + (int64_t)n * 8;
+                const f32x4 s0 = *(const f32x4*)sc, s1 = *(const f32x4*)(sc + 4);
+                x[0] *= s0.x; x[1] *= s0.y; x[2] *= s0.z; x[3] *= s0.w; x[4] *= s1.x; x[5] *= s1.y; x[6] *= s1.z; x[7] *= s1.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                float a = 0.f;
+#pragma unroll
+                for (int c = 0; c < 8; c++) a += wv[j][c] * x[c];
+                o[j] = a;
+            }
+            if (p.out_scale) {
+                const float* sc = p.out_scale + (int64_t)n * p.Cout + 8 * g;
+                const f32x4 s0 = *(const f32x4*)sc, s1 = *(const f32x4*)(sc + 4);
+                o[0] *= s0.x; o[1] *= s0.y; o[2] *= s0.z; o[3] *= s0.w; o[4] *= s1.x; o[5] *= s1.y; o[6] *= s1.z; o[7] *= s1.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                float v = o[j] + bias[j];
+                if (p.act == 3) v = v > 0.f ? v : v * p.alpha;
+                o[j] = v * p.gain;
+            }
+            VecIO<bf16_t, 8>::store(p.y + pix * p.Cout + 8 * g, o);
+        }
+    }
+}
+
+// =================================================================================================
 // fp32 reference-precision path (the reference's --disable-amp configuration and the <= 1e-3 parity tests).
 // Plain VALU FMAs in fp32, same layouts (NHWC activations, OHWI weights), same fused scales / epilogue.
 // Not a throughput path: the bf16 MFMA kernels above are.
@@ -997,6 +1063,20 @@ extern "C" int agf_conv2d_fwd(const void* x, const void* w, void* y,
     p.in_scale = in_scale; p.out_scale = out_scale; p.bias = bias; p.noise = noise; p.residual = (const bf16_t*)residual;
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
     p.act = act; p.alpha = alpha; p.gain = act_gain;
+    {
+        // 1x1 conv from 8 input channels to <= 32 outputs on a large map: the streaming kernel (see conv2d_pw8_kernel)
+        static const bool pw8 = []{ const char* e = getenv("AGF_CONV_PW8"); return !(e && e[0] == '0'); }();
+        const bool pow2 = (Cout & (Cout - 1)) == 0;
+        if (pw8 && ksize == 1 && !noise && !residual && Cin == 8 && Cout >= 8 && Cout <= 32 && pow2 && H * W >= 4096 && ((uintptr_t)y % 16) == 0) {
+            const int G = Cout / 8;
+            const int64_t pixels = (int64_t)N * H * W;
+            int64_t blocks = agf_ceil_div(pixels * G, (int64_t)256 * 4);
+            if (blocks > 256 * 16) blocks = 256 * 16;
+            hipLaunchKernelGGL(conv2d_pw8_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, G, pixels);
+            AGF_LAUNCH_CHECK();
+            return AGF_OK;
+        }
+    }
     { static int h = -1; if (h < 0) { const char* e = getenv("AGF_CONV_HOIST"); h = e ? atoi(e) : 1; } p.hoist = h; }
     { static const int vs = []{ const char* e = getenv("AGF_CONV_VSTORE"); return e ? atoi(e) : 1; }();
       p.vecStore = vs && (Cout % 8) == 0 && ((uintptr_t)y % 16) == 0; }

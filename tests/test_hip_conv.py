@@ -81,6 +81,30 @@ def test_conv_fwd_variants_vs_aten(case, scaled, monkeypatch):
     assert rel(y, ref) < (1.2e-2 if scaled else 6e-3)
 
 
+@pytest.mark.parametrize('shape', [(5, 8, 32, 256, 256), (3, 8, 16, 128, 128), (2, 8, 8, 64, 64), (3, 8, 32, 70, 66),
+                                   (3, 32, 8, 256, 256), (3, 8, 128, 64, 64)])
+@pytest.mark.parametrize('scaled', [False, True])
+def test_conv_pointwise8_vs_aten(shape, scaled):
+    """conv2d_pw8_kernel (1x1 conv from 8 input channels to <= 32 outputs on >= 64x64 maps: FromRGB) and its MFMA neighbours."""
+    from animeface_amd.implementations.StyleGAN2.conv import conv2d_fwd_raw, ACT_LRELU, ACT_LINEAR
+    N, Cin, Cout, H, W = shape
+    x, w, g = make(N, Cin, Cout, H, W, 1, seed=3)
+    s_in = (torch.rand(N, Cin, generator=g) + 0.5).to(DEV) if scaled else None
+    s_out = (torch.rand(N, Cout, generator=g) + 0.5).to(DEV) if scaled else None
+    bias = torch.randn(Cout, generator=g).to(DEV)
+    act, gain = (ACT_LRELU, 1.0) if scaled else (ACT_LINEAR, 0.7)
+    y = conv2d_fwd_raw(x, w, in_scale=s_in, out_scale=s_out, bias=bias, act=act, alpha=0.2, gain=gain)
+    ref = F.conv2d(x.float() * (s_in[:, :, None, None] if scaled else 1.0), w.float())
+    if scaled:
+        ref = ref * s_out[:, :, None, None]
+    ref = ref + bias[None, :, None, None]
+    if scaled:
+        ref = F.leaky_relu(ref, 0.2)
+    ref = ref * gain
+    assert y.shape == ref.shape and y.dtype == torch.bfloat16
+    assert rel(y, ref) < 6e-3                                # fp32 arithmetic, bf16 output rounding only
+
+
 WGRAD_CASES = [
     (4, 64, 64, 32, 32, 3, 'compact tiles'),
     (2, 72, 40, 19, 38, 3, 'ragged map, channel tails'),

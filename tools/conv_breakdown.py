@@ -24,7 +24,7 @@ for key, recs in t.by_shape.items():
 rows.sort(reverse=True)
 tot = sum(r[0] for r in rows)
 print('total conv ms/step', round(tot, 2))
-for ms, key, n, tf in rows[:40]:
+for ms, key, n, tf in rows[:int(os.environ.get("ROWS", "40"))]:
     print(f'{ms:6.2f} ms  x{n:4.1f}  {tf:7.1f} TF/s  {key}')
 print('--- by time lost against 1000 TFLOP/s')
 for ms, key, n, tf in sorted(rows, key=lambda r: -r[0] * max(0, 1 - r[3] / 1000))[:30]:
