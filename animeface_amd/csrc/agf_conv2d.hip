@@ -70,6 +70,90 @@ struct ConvParams {
     uint32_t mW;              // magic multiplier for division by W (flat tiling)
 };
 
+// ---- epilogue shared by conv2d_fwd_kernel and conv2d_fwd_dl_kernel.  A lane holds, per accumulator tile, ONE pixel (column) x 4
+//      groups of 4 consecutive channels: written
+//      straight to memory that is 8 bytes per lane with lanes a whole pixel row (2*Cout bytes) apart -- 64 partial-line
+//      accesses per store instruction, and the address unit handles about one line per clock (timed with the stores removed:
+//      25 % of the 64-channel 256x256 layer, 18 % at 128 channels, 12 % at 256).  So each wave transposes its tile through a
+//      private LDS strip (the staging buffers are free by now): rows of 32*MT channels come back as 16-byte vectors and
+//      consecutive lanes store consecutive addresses (64*MT contiguous bytes per pixel). ----
+template <int MT, int NJ>
+static __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)[MT][NJ], unsigned char* smem_raw,
+                                                     int wave, int lane, int wm, int wn, int n0, int h0, int w0, int flatP0, int co0) {
+    const int l31 = lane & 31, lhi = lane >> 5;
+    constexpr int EROW = 64 * MT + 16;                                // staged pixel row: 32*MT bf16 channels + the pixel's global index
+    const bool vecStore = p.vecStore;                                  // Cout % 8 == 0 and y 16-byte aligned (else the direct path)
+    unsigned char* sE = smem_raw + wave * (32 * EROW);
+    if (vecStore) __syncthreads();                                     // every wave is done reading sW / sX
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+        int q = wn * (32 * NJ) + j * 32 + l31;
+        int c, r, ti;
+        if (p.flat) { const int pg = flatP0 + q; const int row = (int)__umulhi((uint32_t)pg, p.mW); c = pg - row * p.W; r = row - h0; ti = 0; }
+        else { c = q & (p.TW - 1); r = (q >> p.twShift) & (p.TH - 1); ti = q >> (p.twShift + p.thShift); }
+        int n = n0 + ti, h = h0 + r, w = w0 + c;
+        const bool valid = n < p.N && h < p.H && w < p.W;
+        if (!vecStore && !valid) continue;
+        const int64_t pixIdx = valid ? ((int64_t)n * p.H + h) * p.W + w : 0;
+        if (!valid) n = 0;
+        const float nz = p.noise ? p.noise[pixIdx] : 0.f;
+        if (vecStore && lhi == 0) *(int64_t*)(sE + l31 * EROW + 64 * MT) = valid ? pixIdx : (int64_t)-1;
+#pragma unroll
+        for (int i = 0; i < MT; i++) {
+#pragma unroll
+            for (int rg = 0; rg < 4; rg++) {
+                int co = co0 + wm * 32 * MT + i * 32 + rg * 8 + lhi * 4;
+                if (co >= p.Cout) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = acc[i][j][rg * 4 + e];
+                if (p.out_scale) {
+                    f32x4 s = *(const f32x4*)(p.out_scale + (int64_t)n * p.Cout + co);
+                    v[0] *= s.x; v[1] *= s.y; v[2] *= s.z; v[3] *= s.w;
+                }
+                if (p.bias) {
+                    f32x4 bb = *(const f32x4*)(p.bias + co);
+                    v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] += nz;
+                if (p.residual) {
+                    u32x2 rr = *(const u32x2*)(p.residual + pixIdx * p.Cout + co);
+                    float a0, a1;
+                    Pack16<bf16_t>::unpack(rr.x, a0, a1); v[0] += a0; v[1] += a1;
+                    Pack16<bf16_t>::unpack(rr.y, a0, a1); v[2] += a0; v[3] += a1;
+                }
+                if (p.act == 3) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = v[e] > 0.f ? v[e] : v[e] * p.alpha;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] *= p.gain;
+                u32x2 o;
+                o.x = Pack16<bf16_t>::pack(v[0], v[1]);
+                o.y = Pack16<bf16_t>::pack(v[2], v[3]);
+                if (vecStore) *(u32x2*)(sE + l31 * EROW + (i * 32 + rg * 8 + lhi * 4) * 2) = o;
+                else *(u32x2*)(p.y + pixIdx * p.Cout + co) = o;
+            }
+        }
+        if (vecStore) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int t = 0; t < 2 * MT; t++) {
+                const int v = lane + 64 * t;
+                const int px = v / (4 * MT), cv = v % (4 * MT);
+                const int64_t pi = *(const int64_t*)(sE + px * EROW + 64 * MT);
+                const u32x4 val = *(const u32x4*)(sE + px * EROW + cv * 16);
+                const int co = co0 + wm * 32 * MT + cv * 8;
+                if (pi >= 0 && co < p.Cout) *(u32x4*)(p.y + pi * p.Cout + co) = val;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
 // NWN = waves along the pixel axis (2 or 4): block = 2 x NWN waves, tile = (64*MT) co x (128*NWN) pixels.
 //   <MT=1, NWN=2>: 64 co x 256 px, 4 waves, 73 KB LDS -> two blocks per CU            (default)
 //   <MT=2, NWN=4>: 128 co x 512 px, 8 waves (2 per SIMD), 141 KB LDS, one block per CU: half the staging traffic and
@@ -263,85 +347,170 @@ __global__ void __launch_bounds__(64 * NWM * NWN, OCC) conv2d_fwd_kernel(ConvPar
         }
     }
 
-    // ---- epilogue.  A lane holds, per accumulator tile, ONE pixel (column) x 4 groups of 4 consecutive channels: written
-    //      straight to memory that is 8 bytes per lane with lanes a whole pixel row (2*Cout bytes) apart -- 64 partial-line
-    //      accesses per store instruction, and the address unit handles about one line per clock (timed with the stores removed:
-    //      25 % of the 64-channel 256x256 layer, 18 % at 128 channels, 12 % at 256).  So each wave transposes its tile through a
-    //      private LDS strip (the staging buffers are free by now): rows of 32*MT channels come back as 16-byte vectors and
-    //      consecutive lanes store consecutive addresses (64*MT contiguous bytes per pixel). ----
-    constexpr int EROW = 64 * MT + 16;                                // staged pixel row: 32*MT bf16 channels + the pixel's global index
-    const bool vecStore = p.vecStore;                                  // Cout % 8 == 0 and y 16-byte aligned (else the direct path)
-    unsigned char* sE = smem_raw + wave * (32 * EROW);
-    if (vecStore) __syncthreads();                                     // every wave is done reading sW / sX
-#pragma unroll
-    for (int j = 0; j < NJ; j++) {
-        int q = wn * (32 * NJ) + j * 32 + l31;
-        int c, r, ti;
-        if (p.flat) { const int pg = flatP0 + q; const int row = (int)__umulhi((uint32_t)pg, p.mW); c = pg - row * p.W; r = row - h0; ti = 0; }
-        else { c = q & (p.TW - 1); r = (q >> p.twShift) & (p.TH - 1); ti = q >> (p.twShift + p.thShift); }
-        int n = n0 + ti, h = h0 + r, w = w0 + c;
-        const bool valid = n < p.N && h < p.H && w < p.W;
-        if (!vecStore && !valid) continue;
-        const int64_t pixIdx = valid ? ((int64_t)n * p.H + h) * p.W + w : 0;
-        if (!valid) n = 0;
-        const float nz = p.noise ? p.noise[pixIdx] : 0.f;
-        if (vecStore && lhi == 0) *(int64_t*)(sE + l31 * EROW + 64 * MT) = valid ? pixIdx : (int64_t)-1;
-#pragma unroll
-        for (int i = 0; i < MT; i++) {
-#pragma unroll
-            for (int rg = 0; rg < 4; rg++) {
-                int co = co0 + wm * 32 * MT + i * 32 + rg * 8 + lhi * 4;
-                if (co >= p.Cout) continue;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; e++) v[e] = acc[i][j][rg * 4 + e];
-                if (p.out_scale) {
-                    f32x4 s = *(const f32x4*)(p.out_scale + (int64_t)n * p.Cout + co);
-                    v[0] *= s.x; v[1] *= s.y; v[2] *= s.z; v[3] *= s.w;
-                }
-                if (p.bias) {
-                    f32x4 bb = *(const f32x4*)(p.bias + co);
-                    v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
-                }
-#pragma unroll
-                for (int e = 0; e < 4; e++) v[e] += nz;
-                if (p.residual) {
-                    u32x2 rr = *(const u32x2*)(p.residual + pixIdx * p.Cout + co);
-                    float a0, a1;
-                    Pack16<bf16_t>::unpack(rr.x, a0, a1); v[0] += a0; v[1] += a1;
-                    Pack16<bf16_t>::unpack(rr.y, a0, a1); v[2] += a0; v[3] += a1;
-                }
-                if (p.act == 3) {
-#pragma unroll
-                    for (int e = 0; e < 4; e++) v[e] = v[e] > 0.f ? v[e] : v[e] * p.alpha;
-                }
-#pragma unroll
-                for (int e = 0; e < 4; e++) v[e] *= p.gain;
-                u32x2 o;
-                o.x = Pack16<bf16_t>::pack(v[0], v[1]);
-                o.y = Pack16<bf16_t>::pack(v[2], v[3]);
-                if (vecStore) *(u32x2*)(sE + l31 * EROW + (i * 32 + rg * 8 + lhi * 4) * 2) = o;
-                else *(u32x2*)(p.y + pixIdx * p.Cout + co) = o;
-            }
-        }
-        if (vecStore) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int t = 0; t < 2 * MT; t++) {
-                const int v = lane + 64 * t;
-                const int px = v / (4 * MT), cv = v % (4 * MT);
-                const int64_t pi = *(const int64_t*)(sE + px * EROW + 64 * MT);
-                const u32x4 val = *(const u32x4*)(sE + px * EROW + cv * 16);
-                const int co = co0 + wm * 32 * MT + cv * 8;
-                if (pi >= 0 && co < p.Cout) *(u32x4*)(p.y + pi * p.Cout + co) = val;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
+    conv_epilogue<MT, NJ>(p, acc, smem_raw, wave, lane, wm, wn, n0, h0, w0, flatP0, co0);
 }
 
+
+// =================================================================================================
+// Direct-to-LDS, double-buffered variant of conv2d_fwd_kernel for inputs without a style scale (the discriminator's convs and every
+// data-gradient launch).  The generic kernel prefetches a 16-channel chunk into 32 staging registers, contracts the previous chunk,
+// and then spends a barrier + 8 ds_write_b128 per thread + a barrier moving the registers into the single LDS buffer -- with all
+// eight waves in lock step, nothing overlaps that phase.  Here `buffer_load_dwordx4 ... lds` writes each chunk straight into the
+// OTHER of two LDS buffers while the MFMAs read the current one: no staging registers, no store phase, one barrier per chunk.
+// A wave-level load lands as 64 consecutive 16-byte slots, so both tiles are stored UNPADDED ([row][16 channels] = 32-byte rows;
+// a fragment read is then 32 rows x 2 halves = 1 KB contiguous: conflict-free without the generic kernel's row padding).
+// Out-of-image halo pixels, channel tails and co tails are lanes whose buffer offset is out of range: the hardware writes zeros.
+template <int KS, int MT, int NWN, int PMAX, int NWM, int NJ>
+__global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_dl_kernel(ConvParams p) {
+    constexpr int NTHR = 64 * NWM * NWN;
+    constexpr int KC = 16;
+    constexpr int TAPS = KS * KS;
+    constexpr int HALO = KS / 2;
+    constexpr int BM = 32 * NWM * MT;
+    constexpr int WTOT = TAPS * BM * 2;                               // 16-byte vectors of one weight chunk
+    constexpr int WV = (WTOT + NTHR - 1) / NTHR;
+    constexpr int XV = (PMAX * 2 + NTHR - 1) / NTHR;
+    constexpr int WBUF = WV * NTHR * 8;                               // elements per weight buffer (whole wave-loads)
+    constexpr int XBUF = XV * NTHR * 8;
+    constexpr int OOB = 0x70000000;                                   // byte offset beyond any buffer: the load returns zeros
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* sW = (bf16_t*)smem_raw;                                  // [2][WBUF]
+    bf16_t* sX = sW + 2 * WBUF;                                      // [2][XBUF]
+
+    const int b = blockIdx.x;
+    const int xcd = b & 7, slot = b >> 3;
+    const int pixTile = (slot / p.tilesCo) * 8 + xcd;
+    const int coTile = slot % p.tilesCo;
+    if (pixTile >= p.pixTiles) return;
+    int tq = pixTile;
+    const int tw = tq % p.tilesW; tq /= p.tilesW;
+    const int th = tq % p.tilesH;
+    const int tn = tq / p.tilesH;
+    const int n0 = tn * p.TI, h0 = th * p.TH, w0 = tw * p.TW;
+    const int co0 = coTile * BM;
+    const int PW = p.TW + 2 * HALO, PH = p.TH + 2 * HALO;
+    const int P = p.TI * PH * PW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / NWN, wn = wave % NWN;
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    int bBase[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+        const int q = wn * (32 * NJ) + j * 32 + l31;
+        const int c = q & (p.TW - 1), r = (q >> p.twShift) & (p.TH - 1), ti = q >> (p.twShift + p.thShift);
+        bBase[j] = ((ti * PH + r) * PW + c) * KC + lhi * 8;
+    }
+    int aBase[MT];
+#pragma unroll
+    for (int i = 0; i < MT; i++) aBase[i] = (wm * 32 * MT + i * 32 + l31) * KC + lhi * 8;
+
+    f32x16 acc[MT][NJ];
+#pragma unroll
+    for (int i = 0; i < MT; i++)
+#pragma unroll
+        for (int j = 0; j < NJ; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    // buffer descriptors: the block's TI images of x (offsets stay below 2^31 for any image size), the whole weight tensor
+    const int64_t imgBytes = (int64_t)p.H * p.W * p.Cin * 2;
+    int64_t xBytes = imgBytes * (n0 + p.TI <= p.N ? p.TI : p.N - n0);
+    if (xBytes > 0x60000000) xBytes = 0x60000000;
+    const __amdgpu_buffer_rsrc_t xRes = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (int64_t)n0 * p.H * p.W * p.Cin), 0, (int)xBytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wRes = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.Cout * TAPS * p.Cin * 2, 0x00020000);
+    // chunk-invariant byte offsets of this thread's vectors (channel 0 of the chunk), OOB for halo pixels outside the image / co tails
+    int xoff[XV], woff[WV];
+#pragma unroll
+    for (int i = 0; i < XV; i++) {
+        const int v = tid + i * NTHR;
+        const int pix = v >> 1;
+        xoff[i] = OOB;
+        if (pix < P) {
+            const int t2 = PW == 1 ? pix : (int)__umulhi((uint32_t)pix, p.mPW); const int pc = pix - t2 * PW;
+            const int ti = PH == 1 ? t2 : (int)__umulhi((uint32_t)t2, p.mPH); const int pr = t2 - ti * PH;
+            const int n = n0 + ti, h = h0 + pr - HALO, w = w0 + pc - HALO;
+            if (n < p.N && h >= 0 && h < p.H && w >= 0 && w < p.W) xoff[i] = (((ti * p.H + h) * p.W + w) * p.Cin + (v & 1) * 8) * 2;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < WV; i++) {
+        const int v = tid + i * NTHR;
+        const int row = v >> 1;
+        const int tap = row / BM, co = row - tap * BM;
+        woff[i] = OOB;
+        if (v < WTOT && co0 + co < p.Cout) woff[i] = (((co0 + co) * TAPS + tap) * p.Cin + (v & 1) * 8) * 2;
+    }
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    auto issue = [&](int c0, int buf) {
+        // lanes of a wave write consecutive 16-byte slots from the (wave-uniform) base: slot index = v
+        const bool tail = c0 + 8 >= p.Cin;                            // Cin % 16 == 8: the chunk's second half does not exist
+#pragma unroll
+        for (int i = 0; i < WV; i++) {
+            int off = woff[i] + c0 * 2;
+            if (tail && (tid & 1)) off = OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wRes, (lds_ptr)(sW + buf * WBUF + (i * NTHR + wave * 64) * 8), 16, off, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < XV; i++) {
+            int off = xoff[i] + c0 * 2;
+            if (tail && (tid & 1)) off = OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xRes, (lds_ptr)(sX + buf * XBUF + (i * NTHR + wave * 64) * 8), 16, off, 0, 0, 0);
+        }
+    };
+
+    const int nChunks = (p.Cin + KC - 1) / KC;
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int ch = 0; ch < nChunks; ch++) {
+        const int cur = ch & 1;
+        if (ch + 1 < nChunks) issue((ch + 1) * KC, cur ^ 1);
+        const bf16_t* cW = sW + cur * WBUF;
+        const bf16_t* cX = sX + cur * XBUF;
+        // (explicitly double-buffering the fragment registers across taps -- there is room for it here -- measured no gain)
+#pragma unroll
+        for (int kh = 0; kh < KS; kh++) {
+#pragma unroll
+            for (int kw = 0; kw < KS; kw++) {
+                const int tap = kh * KS + kw;
+                bf16x8 af[MT], bfr[NJ];
+#pragma unroll
+                for (int i = 0; i < MT; i++) af[i] = *(const bf16x8*)(cW + tap * BM * KC + aBase[i]);
+#pragma unroll
+                for (int j = 0; j < NJ; j++) bfr[j] = *(const bf16x8*)(cX + (kh * PW + kw) * KC + bBase[j]);
+#pragma unroll
+                for (int i = 0; i < MT; i++)
+#pragma unroll
+                    for (int j = 0; j < NJ; j++)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (ch + 1 < nChunks) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's loads of the next chunk have landed ...
+            __syncthreads();                                          // ... and so have everyone's; everyone is done with `cur`
+        }
+    }
+    conv_epilogue<MT, NJ>(p, acc, smem_raw, wave, lane, wm, wn, n0, h0, w0, 0, co0);
+}
+
+template <int KS, int MT, int NWN, int PMAX, int NWM, int NJ>
+static int launch_fwd_dl(const ConvParams& p0, hipStream_t st) {
+    constexpr int TAPS = KS * KS, HALO = KS / 2, BM = 32 * NWM * MT, NTHR = 64 * NWM * NWN;
+    constexpr int WV = (TAPS * BM * 2 + NTHR - 1) / NTHR, XV = (PMAX * 2 + NTHR - 1) / NTHR;
+    ConvParams p = p0;
+    p.tilesCo = (p.Cout + BM - 1) / BM;
+    const int P = p.TI * (p.TH + 2 * HALO) * (p.TW + 2 * HALO);
+    if (P > PMAX || p.flat || p.in_scale) return AGF_ENOKERNEL;
+    if ((int64_t)p.Cout * TAPS * p.Cin * 2 >= 0x60000000ll || (int64_t)p.TI * p.H * p.W * p.Cin * 2 >= 0x60000000ll) return AGF_ENOKERNEL;
+    size_t lds = (size_t)2 * (WV + XV) * NTHR * 16;
+    if (lds > 160 * 1024) return AGF_ENOKERNEL;
+    const int slots = ((p.pixTiles + 7) / 8) * p.tilesCo;
+    hipError_t e = hipFuncSetAttribute((const void*)conv2d_fwd_dl_kernel<KS, MT, NWN, PMAX, NWM, NJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { agf_set_error("conv2d_fwd: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e)); return AGF_ELAUNCH; }
+    hipLaunchKernelGGL((conv2d_fwd_dl_kernel<KS, MT, NWN, PMAX, NWM, NJ>), dim3((unsigned)(slots * 8)), dim3(NTHR), lds, st, p);
+    return AGF_OK;
+}
 
 // Second half of the LDS-transposed epilogue of the weight-stationary kernels (see conv2d_fwd_kernel): the wave's strip holds
 // 32 pixel rows of 32 channels + the pixel's global index (-1 = outside the image); lanes store 16-byte vectors, 4 per pixel.
@@ -1024,6 +1193,11 @@ static int launch_fwd(const ConvParams& p, hipStream_t st) {
     static const int w64b = []{ const char* e = getenv("AGF_CONV_W64B"); return e ? atoi(e) : 0; }();
     if (w64b && KS == 3 && MT == 1 && !p.flat && p.TI == 1 && p.TW == 32 && p.TH == 8 && p.Cout > 32 && p.Cout <= 64 && p.Cin >= 32)
         return p.in_scale ? launch_fwd_v<KS, 2, true, 16, 4, 340, 1, 2, 3>(p, st) : launch_fwd_v<KS, 2, false, 16, 4, 340, 1, 2, 3>(p, st);
+    static const int dl = []{ const char* e = getenv("AGF_CONV_DL"); return e ? atoi(e) : 1; }();
+    if (dl && KS == 3 && MT == 2 && !p.in_scale && !p.flat) {
+        const int rc = p.Cout <= 64 ? launch_fwd_dl<KS, 2, 4, 612, 1, 4>(p, st) : launch_fwd_dl<KS, 2, 4, 612, 2, 4>(p, st);
+        if (rc != AGF_ENOKERNEL) return rc;
+    }
     if (MT == 2 && p.Cout <= 64) return p.in_scale ? launch_fwd_v<KS, 2, true, 16, 4, 612, 1>(p, st) : launch_fwd_v<KS, 2, false, 16, 4, 612, 1>(p, st);
     if (MT == 2) return p.in_scale ? launch_fwd_v<KS, 2, true, 16, 4, 612>(p, st) : launch_fwd_v<KS, 2, false, 16, 4, 612>(p, st);
     return p.in_scale ? launch_fwd_v<KS, 1, true, 32, 2, (KS == 3 ? 576 : 256)>(p, st) : launch_fwd_v<KS, 1, false, 32, 2, (KS == 3 ? 576 : 256)>(p, st);

@@ -45,6 +45,8 @@ FWD_CASES = [
     (8, 32, 12, 256, 256, 3, None, 'weight-stationary, direct stores'),
     (8, 32, 8, 256, 256, 1, None, '1x1 weight-stationary (ToImage at 256x256)'),
     (8, 32, 64, 256, 256, 1, None, '1x1 weight-stationary 32->64'),
+    (4, 72, 136, 32, 64, 3, '2', 'direct-to-LDS 8-wave, Cin % 16 == 8, partial co tile'),
+    (3, 40, 56, 48, 40, 3, '2', 'direct-to-LDS 4-wave 64 co, ragged map, channel tails'),
 ]
 
 
