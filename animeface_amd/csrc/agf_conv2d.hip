@@ -1352,8 +1352,16 @@ static __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* base) {
 }
 
 
-template <int KS, bool COMPACT>
+template <int KS, bool COMPACT, bool DL>
 __global__ void __launch_bounds__(512, KS == 1 ? 4 : 2) conv2d_wgrad_kernel(WgradParams p) {     // 1x1: 128 registers, two blocks per CU
+    // DL: the tiles are loaded straight into the OTHER of two LDS buffer sets with `buffer_load_dwordx4 ... lds` while the current one
+    //   is contracted -- no staging registers (40 of this kernel's 256), no store phase, one barrier per tile instead of two.  The tiles
+    //   are unpadded 64-byte rows, so a wave-level load (64 consecutive 16-byte slots) is 16 rows of one channel block; out-of-image
+    //   halo pixels and channel tails are out-of-range buffer offsets (the hardware writes zeros).  Operand scaling on load does not
+    //   exist in this mode: the launcher uses it when the per-sample scales ride in the epilogue (epiScale) or are absent.
+    //   Measured: time-neutral (PMC: MFMA busy 37 %, LDS busy 21 %, waves waiting on vmcnt ~45 % -- the kernel is bound by the one tile
+    //   set (76 KB per CU) it can keep in flight against a ~2.4 us MFMA phase; a rolling 3-row operand window that cut the LDS fragment
+    //   reads from 10 to 4 per 9 MFMAs was correct and slower).  tools/pmc_wgrad.sh.
     // 8 waves: waves 0-3 and 4-7 own the same four (co32 x ci32) quadrants but alternate k-steps (even / odd); both
     // halves add their partial sums with the same atomics that already combine the split-K blocks.  Two waves per SIMD
     // is what hides the LDS latency of the 20 transpose reads per k-step (one wave per SIMD ran the MFMA pipe at 20 %).
@@ -1371,6 +1379,7 @@ __global__ void __launch_bounds__(512, KS == 1 ? 4 : 2) conv2d_wgrad_kernel(Wgra
     const int XR = COMPACT ? ((P + 15) & ~15) : DYR + 2 * MARGIN;        // rows of one x block
     bf16_t* sDy = (bf16_t*)smem_raw;                                     // [2][DYR][32]
     bf16_t* sX = sDy + 2 * DYR * 32;                                     // [2][XR][32]
+    const int BUFE = (2 * DYR + 2 * XR) * 32;                            // DL: elements of one buffer set (two sets)
 
     int bid = blockIdx.x;
     const int ks = bid % p.splitK; bid /= p.splitK;
@@ -1400,16 +1409,23 @@ __global__ void __launch_bounds__(512, KS == 1 ? 4 : 2) conv2d_wgrad_kernel(Wgra
     // register-staged software pipeline (as in the forward kernel): tile pt+splitK is loaded while tile pt is contracted
     constexpr int NT = 512;
     constexpr int DV = 4, XV = 6;                         // vectors per thread: DYR*8/512 <= 4 (DYR <= 256), XR*8/512 <= 6
-    u32x4 dreg[DV], xreg[XV];
+    u32x4 dreg[DL ? 1 : DV], xreg[DL ? 1 : XV];
     // tile-invariant part of the staging index math (no divisions inside the tile loop): per vector the pixel's
     // (image-in-tile, row, col) relative to the tile origin, packed as ti<<20 | (dh+8)<<10 | (dw+8); -1 = always zero.
     int drel[DV], xrel[XV];
+    int dch[DL ? DV : 1], xch[DL ? XV : 1];               // DL: channel offset of each vector (fixed for the thread otherwise)
 #pragma unroll
     for (int i = 0; i < DV; i++) {
         int v = tid + i * NT;
         int q = v >> 3;
+        if (DL) {                                         // LDS-linear order [block][row][16-byte chunk]
+            const int blk = v / (DYR * 4), rem = v - blk * (DYR * 4);
+            q = v < DYR * 8 ? rem >> 2 : DYR;
+            dch[i] = (blk * 4 + (rem & 3)) * 8;
+        }
         drel[i] = -1;
-        if (q < DYR) {
+        if (DL && v >= DYR * 8) drel[i] = -2;             // beyond the tile: this lane issues no load
+        else if (q < DYR) {
             if (COMPACT) {
                 int c = q % p.TW; int t2 = q / p.TW; int r = t2 % p.TH; int ti = t2 / p.TH;
                 drel[i] = (ti << 20) | ((r + 8) << 10) | (c + 8);
@@ -1424,9 +1440,15 @@ __global__ void __launch_bounds__(512, KS == 1 ? 4 : 2) conv2d_wgrad_kernel(Wgra
     for (int i = 0; i < XV; i++) {
         int v = tid + i * NT;
         int row = v >> 3;
+        if (DL) {
+            const int blk = v / (XR * 4), rem = v - blk * (XR * 4);
+            row = v < XR * 8 ? rem >> 2 : XR;
+            xch[i] = (blk * 4 + (rem & 3)) * 8;
+        }
         int q = row - MARGIN;
         xrel[i] = -1;
-        if (row < XR && q >= 0 && q < P) {
+        if (DL && v >= XR * 8) xrel[i] = -2;
+        else if (row < XR && q >= 0 && q < P) {
             int pc = q % PW; int t2 = q / PW; int pr = t2 % PH; int ti = t2 / PH;
             xrel[i] = (ti << 20) | ((pr - HALO + 8) << 10) | (pc - HALO + 8);
         }
@@ -1479,6 +1501,45 @@ __global__ void __launch_bounds__(512, KS == 1 ? 4 : 2) conv2d_wgrad_kernel(Wgra
         }
     };
 
+    constexpr int OOB = 0x70000000;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    auto issue_tile = [&](int pt, int buf) {              // DL
+        int tq = pt;
+        const int tw = tq % p.tilesW; tq /= p.tilesW;
+        const int th = tq % p.tilesH;
+        const int tn = tq / p.tilesH;
+        const int n0 = tn * p.TI, h0 = th * p.TH, w0 = tw * p.TW;
+        const int nImg = n0 + p.TI <= p.N ? p.TI : p.N - n0;
+        const __amdgpu_buffer_rsrc_t dRes = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dy + (int64_t)n0 * p.H * p.W * p.Cout), 0,
+                                                                              nImg * p.H * p.W * p.Cout * 2, 0x00020000);
+        const __amdgpu_buffer_rsrc_t xRes = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (int64_t)n0 * p.H * p.W * p.Cin), 0,
+                                                                              nImg * p.H * p.W * p.Cin * 2, 0x00020000);
+        bf16_t* bDy = sDy + buf * BUFE;
+        bf16_t* bX = sX + buf * BUFE;
+#pragma unroll
+        for (int i = 0; i < DV; i++) {
+            if (drel[i] == -2) continue;
+            int off = OOB;
+            if (drel[i] >= 0) {
+                const int ti = drel[i] >> 20, h = h0 + ((drel[i] >> 10) & 1023) - 8, w = w0 + (drel[i] & 1023) - 8;
+                const int gco = co0 + dch[DL ? i : 0];
+                if (ti < nImg && h < p.H && w < p.W && gco < p.Cout) off = (((ti * p.H + h) * p.W + w) * p.Cout + gco) * 2;
+            }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(dRes, (lds_ptr)(bDy + (i * NT + wave * 64) * 8), 16, off, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < XV; i++) {
+            if (xrel[i] == -2) continue;
+            int off = OOB;
+            if (xrel[i] >= 0) {
+                const int ti = xrel[i] >> 20, h = h0 + ((xrel[i] >> 10) & 1023) - 8, w = w0 + (xrel[i] & 1023) - 8;
+                const int gci = ci0 + xch[DL ? i : 0];
+                if (ti < nImg && h >= 0 && h < p.H && w >= 0 && w < p.W && gci < p.Cin) off = (((ti * p.H + h) * p.W + w) * p.Cin + gci) * 2;
+            }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xRes, (lds_ptr)(bX + (i * NT + wave * 64) * 8), 16, off, 0, 0, 0);
+        }
+    };
+
     // ---- combine: fp32 atomics into dw[co][tap][ci].  With epiScale the per-sample scales s_out[n,co] * s_in[n,ci] multiply the
     //      partial sums of image n here instead of every staged operand vector (sum_n s_o s_i sum_p dy x: exact in fp32) ----
     auto flush = [&](int n) {
@@ -1506,11 +1567,15 @@ __global__ void __launch_bounds__(512, KS == 1 ? 4 : 2) conv2d_wgrad_kernel(Wgra
     int ptEnd = p.pixTiles;
     if (p.epiScale) { ptEnd = ptBegin + run; if (ptEnd > (curN + 1) * tilesPerImage) ptEnd = (curN + 1) * tilesPerImage; }
     int pt = ptBegin;
-    if (pt < ptEnd) { load_tile(pt); store_tile(); }
+    int cur = 0;
+    if (DL) { if (pt < ptEnd) issue_tile(pt, 0); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    else if (pt < ptEnd) { load_tile(pt); store_tile(); }
     __syncthreads();
     for (; pt < ptEnd; pt += ptStep) {
         const bool more = pt + ptStep < ptEnd;
-        if (more) load_tile(pt + ptStep);
+        if (more) { if (DL) issue_tile(pt + ptStep, cur ^ 1); else load_tile(pt + ptStep); }
+        const bf16_t* aCur = aPtr + (DL ? cur * BUFE : 0);
+        const bf16_t* bCur = bPtr + (DL ? cur * BUFE : 0);
         // fragment reads are software-pipelined one k-step ahead of the MFMAs (one wave per SIMD: nothing else would
         // hide the LDS latency of the 20 transpose reads a k-step needs)
         auto xrow_of = [&](int s) {
@@ -1520,20 +1585,26 @@ __global__ void __launch_bounds__(512, KS == 1 ? 4 : 2) conv2d_wgrad_kernel(Wgra
         const int nSteps = DYR / 16;
         for (int sc = kidx; sc < nSteps; sc += kSplit) {
             const int xr = xrow_of(sc);
-            const bf16x8 af = tr_frag(aPtr + sc * 16 * 32);
+            const bf16x8 af = tr_frag(aCur + sc * 16 * 32);
             bf16x8 bfr[TAPS];
 #pragma unroll
             for (int kh = 0; kh < KS; kh++)
 #pragma unroll
-                for (int kw = 0; kw < KS; kw++) bfr[kh * KS + kw] = tr_frag(bPtr + (xr + kh * PW + kw) * 32);
+                for (int kw = 0; kw < KS; kw++) bfr[kh * KS + kw] = tr_frag(bCur + (xr + kh * PW + kw) * 32);
 #pragma unroll
             for (int t = 0; t < TAPS; t++)
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr[t], acc[t], 0, 0, 0);
         }
         if (more) {
-            __syncthreads();
-            store_tile();
-            __syncthreads();
+            if (DL) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's loads of the next tile have landed ...
+                __syncthreads();                                      // ... and everyone's; everyone is done with `cur`
+                cur ^= 1;
+            } else {
+                __syncthreads();
+                store_tile();
+                __syncthreads();
+            }
         }
     }
     if (ptBegin >= ptEnd) return;                        // block-uniform
@@ -1560,12 +1631,12 @@ __global__ void __launch_bounds__(512, KS == 1 ? 4 : 2) conv2d_wgrad_kernel(Wgra
     if (kidx == 0) flush(curN);
 }
 
-template <int KS, bool COMPACT>
+template <int KS, bool COMPACT, bool DL = false>
 static int launch_wgrad(const WgradParams& p, size_t lds, hipStream_t st) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv2d_wgrad_kernel<KS, COMPACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)conv2d_wgrad_kernel<KS, COMPACT, DL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { agf_set_error("conv2d_wgrad: cannot reserve LDS: %s", hipGetErrorString(e)); return AGF_ELAUNCH; }
     dim3 grid((unsigned)(p.tilesCo * p.tilesCi * p.splitK)), block(512);
-    hipLaunchKernelGGL((conv2d_wgrad_kernel<KS, COMPACT>), grid, block, lds, st, p);
+    hipLaunchKernelGGL((conv2d_wgrad_kernel<KS, COMPACT, DL>), grid, block, lds, st, p);
     return AGF_OK;
 }
 
@@ -1650,7 +1721,11 @@ extern "C" int agf_conv2d_wgrad(const void* x, const void* dy, float* dw,
     if (lds > 160 * 1024) { agf_set_error("conv2d_wgrad: tile needs %zu bytes of LDS", lds); return AGF_ENOKERNEL; }
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    if (ksize == 3) rc = compact ? launch_wgrad<3, true>(p, lds, st) : launch_wgrad<3, false>(p, lds, st);
+    static const bool dl_on = []{ const char* e = getenv("AGF_WGRAD_DL"); return !(e && e[0] == '0'); }();
+    const bool dl = dl_on && ksize == 3 && compact && 2 * lds <= 160 * 1024 && !((in_scale || out_scale) && !p.epiScale) &&
+                    (int64_t)p.TI * H * W * (Cin > Cout ? Cin : Cout) * 2 < 0x60000000ll;
+    if (dl) rc = launch_wgrad<3, true, true>(p, 2 * lds, st);
+    else if (ksize == 3) rc = compact ? launch_wgrad<3, true>(p, lds, st) : launch_wgrad<3, false>(p, lds, st);
     else            rc = compact ? launch_wgrad<1, true>(p, lds, st) : launch_wgrad<1, false>(p, lds, st);
     if (rc != AGF_OK) return rc;
     AGF_LAUNCH_CHECK();
