@@ -394,16 +394,19 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_dl_kernel(ConvPa
     const int wm = wave / NWN, wn = wave % NWN;
     const int l31 = lane & 31, lhi = lane >> 5;
 
-    int bBase[NJ];
+    // Swizzle: row r keeps its two 16-byte halves swapped when bit 3 of r is set.  A 16-lane pass of a ds_read_b128 then covers 16
+    // distinct 16-byte bank groups for ANY run of 16 consecutive rows (rows r and r+8 hit the two different halves of a 32-byte
+    // bank column); the plain [row][2] order is a 2-way conflict on every fragment read (PMC: half of the LDS-active cycles).
+    int bPix[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; j++) {
         const int q = wn * (32 * NJ) + j * 32 + l31;
         const int c = q & (p.TW - 1), r = (q >> p.twShift) & (p.TH - 1), ti = q >> (p.twShift + p.thShift);
-        bBase[j] = ((ti * PH + r) * PW + c) * KC + lhi * 8;
+        bPix[j] = (ti * PH + r) * PW + c;
     }
     int aBase[MT];
 #pragma unroll
-    for (int i = 0; i < MT; i++) aBase[i] = (wm * 32 * MT + i * 32 + l31) * KC + lhi * 8;
+    for (int i = 0; i < MT; i++) aBase[i] = (wm * 32 * MT + i * 32 + l31) * KC + ((lhi ^ ((l31 >> 3) & 1)) << 3);
 
     f32x16 acc[MT][NJ];
 #pragma unroll
@@ -421,6 +424,7 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_dl_kernel(ConvPa
     const __amdgpu_buffer_rsrc_t wRes = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.Cout * TAPS * p.Cin * 2, 0x00020000);
     // chunk-invariant byte offsets of this thread's vectors (channel 0 of the chunk), OOB for halo pixels outside the image / co tails
     int xoff[XV], woff[WV];
+    const int half = (tid & 1) ^ ((tid >> 4) & 1);                    // which 8-channel half this lane's LDS slot holds (swizzle above)
 #pragma unroll
     for (int i = 0; i < XV; i++) {
         const int v = tid + i * NTHR;
@@ -430,7 +434,7 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_dl_kernel(ConvPa
             const int t2 = PW == 1 ? pix : (int)__umulhi((uint32_t)pix, p.mPW); const int pc = pix - t2 * PW;
             const int ti = PH == 1 ? t2 : (int)__umulhi((uint32_t)t2, p.mPH); const int pr = t2 - ti * PH;
             const int n = n0 + ti, h = h0 + pr - HALO, w = w0 + pc - HALO;
-            if (n < p.N && h >= 0 && h < p.H && w >= 0 && w < p.W) xoff[i] = (((ti * p.H + h) * p.W + w) * p.Cin + (v & 1) * 8) * 2;
+            if (n < p.N && h >= 0 && h < p.H && w >= 0 && w < p.W) xoff[i] = (((ti * p.H + h) * p.W + w) * p.Cin + half * 8) * 2;
         }
     }
 #pragma unroll
@@ -439,7 +443,7 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_dl_kernel(ConvPa
         const int row = v >> 1;
         const int tap = row / BM, co = row - tap * BM;
         woff[i] = OOB;
-        if (v < WTOT && co0 + co < p.Cout) woff[i] = (((co0 + co) * TAPS + tap) * p.Cin + (v & 1) * 8) * 2;
+        if (v < WTOT && co0 + co < p.Cout) woff[i] = (((co0 + co) * TAPS + tap) * p.Cin + half * 8) * 2;
     }
     typedef __attribute__((address_space(3))) void* lds_ptr;
     auto issue = [&](int c0, int buf) {
@@ -448,13 +452,13 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_dl_kernel(ConvPa
 #pragma unroll
         for (int i = 0; i < WV; i++) {
             int off = woff[i] + c0 * 2;
-            if (tail && (tid & 1)) off = OOB;
+            if (tail && half) off = OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wRes, (lds_ptr)(sW + buf * WBUF + (i * NTHR + wave * 64) * 8), 16, off, 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < XV; i++) {
             int off = xoff[i] + c0 * 2;
-            if (tail && (tid & 1)) off = OOB;
+            if (tail && half) off = OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xRes, (lds_ptr)(sX + buf * XBUF + (i * NTHR + wave * 64) * 8), 16, off, 0, 0, 0);
         }
     };
@@ -478,7 +482,10 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_dl_kernel(ConvPa
 #pragma unroll
                 for (int i = 0; i < MT; i++) af[i] = *(const bf16x8*)(cW + tap * BM * KC + aBase[i]);
 #pragma unroll
-                for (int j = 0; j < NJ; j++) bfr[j] = *(const bf16x8*)(cX + (kh * PW + kw) * KC + bBase[j]);
+                for (int j = 0; j < NJ; j++) {
+                    const int pix = bPix[j] + kh * PW + kw;
+                    bfr[j] = *(const bf16x8*)(cX + pix * KC + ((lhi ^ ((pix >> 3) & 1)) << 3));
+                }
 #pragma unroll
                 for (int i = 0; i < MT; i++)
 #pragma unroll
