@@ -20,7 +20,7 @@ EDGE_ZERO, EDGE_CLAMP = 0, 1
 _DTYPES = {torch.float32: AGF_F32, torch.float16: AGF_F16, torch.bfloat16: AGF_BF16, torch.float64: AGF_F64}
 
 EXPORTS = ['agf_abi_version', 'agf_last_error', 'agf_device_info', 'agf_upfirdn2d', 'agf_upfirdn2d_fold_border', 'agf_bias_act',
-           'agf_filtered_lrelu', 'agf_filtered_lrelu_act', 'agf_conv2d_fwd', 'agf_conv2d_wgrad',
+           'agf_filtered_lrelu', 'agf_filtered_lrelu_act', 'agf_conv2d_fwd', 'agf_conv2d_fwd_mask', 'agf_conv2d_wgrad',
            'agf_act_bwd_reduce', 'agf_scale_dot', 'agf_planar_to_cl_pad', 'agf_cl_to_planar_crop', 'agf_prep_weights',
            'agf_wsq', 'agf_style_demod_fwd', 'agf_style_demod_bwd']
 
@@ -67,6 +67,9 @@ def lib():
         L.agf_conv2d_fwd.restype = ctypes.c_int
         L.agf_conv2d_fwd.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int] + [ctypes.c_int32] * 6 + \
                                     [ctypes.c_int, ctypes.c_float, ctypes.c_float, _vp]
+        L.agf_conv2d_fwd_mask.restype = ctypes.c_int
+        L.agf_conv2d_fwd_mask.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int] + [ctypes.c_int32] * 6 + \
+                                         [ctypes.c_int, ctypes.c_float, ctypes.c_float, _vp, ctypes.c_float, _vp, _vp]
         L.agf_conv2d_wgrad.restype = ctypes.c_int
         L.agf_conv2d_wgrad.argtypes = [_vp, _vp, _vp, _vp, _vp, ctypes.c_int] + [ctypes.c_int32] * 6 + [ctypes.c_float, _vp]
         L.agf_act_bwd_reduce.restype = ctypes.c_int
@@ -84,7 +87,7 @@ def lib():
         L.agf_style_demod_fwd.argtypes = [_vp] * 4 + [ctypes.c_int32] * 3 + [ctypes.c_float, ctypes.c_float, _vp]
         L.agf_style_demod_bwd.restype = ctypes.c_int
         L.agf_style_demod_bwd.argtypes = [_vp] * 8 + [ctypes.c_int32] * 4 + [ctypes.c_float, _vp]
-        if L.agf_abi_version() != 3:
+        if L.agf_abi_version() != 4:
             raise AgfError('libagf_ops.so ABI version mismatch')
         _lib = L
     return _lib

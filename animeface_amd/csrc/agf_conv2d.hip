@@ -61,6 +61,9 @@ struct ConvParams {
     int tilesW, tilesH, tilesN, tilesCo, pixTiles;
     int act;                  // 1 linear, 3 lrelu
     float alpha, gain;
+    const bf16_t* mask_y;     // fused lrelu gradient (agf_conv2d_fwd_mask): y *= mask_y > 0 ? 1 : mask_alpha; null = off
+    float mask_alpha;
+    float* mask_sum;          // [Cout] fp32: += sum over pixels of the masked output (nullable)
     int vecStore;             // epilogue: transpose through LDS and store 16-byte vectors (needs Cout % 8 == 0, y 16-byte aligned)
     int hoist;                // A/B switch: hoist the style-scale loads out of the per-vector staging loop
     int wsSlices;             // ping-pong weight-stationary kernel: blocks per image
@@ -79,12 +82,14 @@ struct ConvParams {
 //      consecutive lanes store consecutive addresses (64*MT contiguous bytes per pixel). ----
 template <int MT, int NJ>
 static __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)[MT][NJ], unsigned char* smem_raw,
-                                                     int wave, int lane, int wm, int wn, int n0, int h0, int w0, int flatP0, int co0) {
+                                                     int wave, int lane, int wm, int wn, int n0, int h0, int w0, int flatP0, int co0,
+                                                     int nwn, int nwaves, int slot) {
     const int l31 = lane & 31, lhi = lane >> 5;
     constexpr int EROW = 64 * MT + 16;                                // staged pixel row: 32*MT bf16 channels + the pixel's global index
     const bool vecStore = p.vecStore;                                  // Cout % 8 == 0 and y 16-byte aligned (else the direct path)
     unsigned char* sE = smem_raw + wave * (32 * EROW);
     if (vecStore) __syncthreads();                                     // every wave is done reading sW / sX
+    float msum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};         // mask mode: this lane's channel group (cv is the same for every t, j)
 #pragma unroll
     for (int j = 0; j < NJ; j++) {
         int q = wn * (32 * NJ) + j * 32 + l31;
@@ -144,12 +149,53 @@ static __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16
                 const int v = lane + 64 * t;
                 const int px = v / (4 * MT), cv = v % (4 * MT);
                 const int64_t pi = *(const int64_t*)(sE + px * EROW + 64 * MT);
-                const u32x4 val = *(const u32x4*)(sE + px * EROW + cv * 16);
+                u32x4 val = *(const u32x4*)(sE + px * EROW + cv * 16);
                 const int co = co0 + wm * 32 * MT + cv * 8;
-                if (pi >= 0 && co < p.Cout) *(u32x4*)(p.y + pi * p.Cout + co) = val;
+                if (pi >= 0 && co < p.Cout) {
+                    if (p.mask_y) {
+                        // the layer below's lrelu gradient, applied where the gradient tensor is produced (its own pass over the
+                        // tensor -- read dy, read y, write g -- disappears; y comes in as full 16-byte vectors here)
+                        const u32x4 yv = *(const u32x4*)(p.mask_y + pi * p.Cout + co);
+                        float g[8], a[8];
+                        Pack16<bf16_t>::unpack(val.x, g[0], g[1]); Pack16<bf16_t>::unpack(val.y, g[2], g[3]);
+                        Pack16<bf16_t>::unpack(val.z, g[4], g[5]); Pack16<bf16_t>::unpack(val.w, g[6], g[7]);
+                        Pack16<bf16_t>::unpack(yv.x, a[0], a[1]); Pack16<bf16_t>::unpack(yv.y, a[2], a[3]);
+                        Pack16<bf16_t>::unpack(yv.z, a[4], a[5]); Pack16<bf16_t>::unpack(yv.w, a[6], a[7]);
+#pragma unroll
+                        for (int e = 0; e < 8; e++) { g[e] = a[e] > 0.f ? g[e] : g[e] * p.mask_alpha; msum[e] += g[e]; }
+                        val.x = Pack16<bf16_t>::pack(g[0], g[1]); val.y = Pack16<bf16_t>::pack(g[2], g[3]);
+                        val.z = Pack16<bf16_t>::pack(g[4], g[5]); val.w = Pack16<bf16_t>::pack(g[6], g[7]);
+                    }
+                    *(u32x4*)(p.y + pi * p.Cout + co) = val;
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (vecStore && p.mask_y && p.mask_sum) {             // block-uniform
+        // lanes with equal lane % (4*MT) hold the same 8 channels: butterfly over the other lane bits, add the waves that share the
+        // channels through LDS, then ONE atomic per channel and block into slot (pixel tile % 256) of mask_sum [256][Cout] -- thousands
+        // of blocks adding into Cout addresses serialise at the memory side (the first version ran the step 40 % slower)
+#pragma unroll
+        for (int m = 4 * MT; m < 64; m <<= 1) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) msum[e] += __shfl_xor(msum[e], m);
+        }
+        float* red = (float*)(smem_raw + nwaves * (32 * EROW));          // [nwaves][4*MT][8]
+        if (lane < 4 * MT) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) red[(wave * 4 * MT + lane) * 8 + e] = msum[e];
+        }
+        __syncthreads();
+        const int co = co0 + wm * 32 * MT + lane * 8;
+        if (wn == 0 && lane < 4 * MT && co < p.Cout) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                float v = 0.f;
+                for (int k = 0; k < nwn; k++) v += red[((wm * nwn + k) * 4 * MT + lane) * 8 + e];
+                unsafeAtomicAdd(p.mask_sum + (int64_t)slot * p.Cout + co + e, v);
+            }
         }
     }
 }
@@ -347,7 +393,7 @@ __global__ void __launch_bounds__(64 * NWM * NWN, OCC) conv2d_fwd_kernel(ConvPar
         }
     }
 
-    conv_epilogue<MT, NJ>(p, acc, smem_raw, wave, lane, wm, wn, n0, h0, w0, flatP0, co0);
+    conv_epilogue<MT, NJ>(p, acc, smem_raw, wave, lane, wm, wn, n0, h0, w0, flatP0, co0, NWN, NWM * NWN, pixTile & 255);
 }
 
 
@@ -498,7 +544,7 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_dl_kernel(ConvPa
             __syncthreads();                                          // ... and so have everyone's; everyone is done with `cur`
         }
     }
-    conv_epilogue<MT, NJ>(p, acc, smem_raw, wave, lane, wm, wn, n0, h0, w0, 0, co0);
+    conv_epilogue<MT, NJ>(p, acc, smem_raw, wave, lane, wm, wn, n0, h0, w0, 0, co0, NWN, NWM * NWN, pixTile & 255);
 }
 
 template <int KS, int MT, int NWN, int PMAX, int NWM, int NJ>
@@ -1173,7 +1219,7 @@ static int launch_fwd(const ConvParams& p, hipStream_t st) {
     // weight-stationary kernel: Cin <= 32 (two blocks per CU), or Cin <= 64 with Cout <= 32 (32-channel co tile: the
     // generic 64-channel tile would waste half of its MFMAs there); measured per layer in tools/ab_ws.sh
     static const int ws1 = []{ const char* e = getenv("AGF_CONV_WS1"); return e ? atoi(e) : 1; }();
-    if (g_ws_enable && ws1 && (ws1 == 2 || p.in_scale) && KS == 1 && MT == 1 && p.pixTiles >= 2048 && p.TW == 32 && p.TH == 8 && p.TI == 1 && p.Cin <= 32 && p.Cout <= 64) {
+    if (g_ws_enable && !p.mask_y && ws1 && (ws1 == 2 || p.in_scale) && KS == 1 && MT == 1 && p.pixTiles >= 2048 && p.TW == 32 && p.TH == 8 && p.TI == 1 && p.Cin <= 32 && p.Cout <= 64) {
         // 1x1 convs with few channels (FromRGB / ToRGB / the 32 -> 64 skip): pure streaming work.  One 256-pixel tile per block left
         // them at ~2 TB/s (block prologue per 20 KB of traffic); the persistent kernel keeps the weights in LDS and streams tiles.
         int rc;
@@ -1181,7 +1227,7 @@ static int launch_fwd(const ConvParams& p, hipStream_t st) {
         else              rc = p.in_scale ? launch_fwd_ws<1, true, 32, 64>(p, st) : launch_fwd_ws<1, false, 32, 64>(p, st);
         if (rc != AGF_ENOKERNEL) return rc;
     }
-    if (g_ws_enable && KS == 3 && MT == 1 && p.pixTiles >= 2048 && p.TW == 32 && p.TH == 8 && p.TI == 1 &&
+    if (g_ws_enable && !p.mask_y && KS == 3 && MT == 1 && p.pixTiles >= 2048 && p.TW == 32 && p.TH == 8 && p.TI == 1 &&
         (p.Cin <= 32 || (p.Cin <= 64 && p.Cout <= 32) || (g_ws_enable >= 2 && p.Cin <= 64 && p.Cout <= 64))) {
         int rc;
         static const int ws2 = []{ const char* e = getenv("AGF_CONV_WS2"); return e ? atoi(e) : 1; }();
@@ -1210,13 +1256,18 @@ static int launch_fwd(const ConvParams& p, hipStream_t st) {
     return p.in_scale ? launch_fwd_v<KS, 1, true, 32, 2, (KS == 3 ? 576 : 256)>(p, st) : launch_fwd_v<KS, 1, false, 32, 2, (KS == 3 ? 576 : 256)>(p, st);
 }
 
-extern "C" int agf_conv2d_fwd(const void* x, const void* w, void* y,
-                              const float* in_scale, const float* out_scale, const float* bias,
-                              const float* noise, const void* residual,
-                              int dtype, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
-                              int act, float alpha, float act_gain, void* stream) {
+static int conv2d_fwd_impl(const void* x, const void* w, void* y,
+                           const float* in_scale, const float* out_scale, const float* bias,
+                           const float* noise, const void* residual,
+                           int dtype, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
+                           int act, float alpha, float act_gain,
+                           const void* mask_y, float mask_alpha, float* mask_sum, void* stream) {
     AGF_CHECK(x && w && y, "conv2d_fwd: null pointer");
     AGF_CHECK(dtype == AGF_BF16 || dtype == AGF_F32, "conv2d_fwd: dtype must be bf16 or f32");
+    if (mask_y && (dtype != AGF_BF16 || (Cout % 8) != 0 || ((uintptr_t)y % 16) != 0 || ((uintptr_t)mask_y % 16) != 0)) {
+        agf_set_error("conv2d_fwd_mask: needs bf16, Cout %% 8 == 0 and 16-byte aligned tensors");
+        return AGF_ENOKERNEL;
+    }
     if (dtype == AGF_F32) {
         AGF_CHECK(N >= 1 && H >= 1 && W >= 1 && Cin >= 1 && Cout >= 1, "conv2d_fwd: empty tensor");
         AGF_CHECK(ksize == 1 || ksize == 3, "conv2d_fwd: kernel size must be 1 or 3 (got %d)", ksize);
@@ -1244,11 +1295,12 @@ extern "C" int agf_conv2d_fwd(const void* x, const void* w, void* y,
     p.in_scale = in_scale; p.out_scale = out_scale; p.bias = bias; p.noise = noise; p.residual = (const bf16_t*)residual;
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
     p.act = act; p.alpha = alpha; p.gain = act_gain;
+    p.mask_y = (const bf16_t*)mask_y; p.mask_alpha = mask_alpha; p.mask_sum = mask_sum;
     {
         // 1x1 conv from 8 input channels to <= 32 outputs on a large map: the streaming kernel (see conv2d_pw8_kernel)
         static const bool pw8 = []{ const char* e = getenv("AGF_CONV_PW8"); return !(e && e[0] == '0'); }();
         const bool pow2 = (Cout & (Cout - 1)) == 0;
-        if (pw8 && ksize == 1 && !noise && !residual && Cin == 8 && Cout >= 8 && Cout <= 32 && pow2 && H * W >= 4096 && ((uintptr_t)y % 16) == 0) {
+        if (pw8 && !mask_y && ksize == 1 && !noise && !residual && Cin == 8 && Cout >= 8 && Cout <= 32 && pow2 && H * W >= 4096 && ((uintptr_t)y % 16) == 0) {
             const int G = Cout / 8;
             const int64_t pixels = (int64_t)N * H * W;
             int64_t blocks = agf_ceil_div(pixels * G, (int64_t)256 * 4);
@@ -1260,7 +1312,7 @@ extern "C" int agf_conv2d_fwd(const void* x, const void* w, void* y,
     }
     { static int h = -1; if (h < 0) { const char* e = getenv("AGF_CONV_HOIST"); h = e ? atoi(e) : 1; } p.hoist = h; }
     { static const int vs = []{ const char* e = getenv("AGF_CONV_VSTORE"); return e ? atoi(e) : 1; }();
-      p.vecStore = vs && (Cout % 8) == 0 && ((uintptr_t)y % 16) == 0; }
+      p.vecStore = (vs || mask_y) && (Cout % 8) == 0 && ((uintptr_t)y % 16) == 0; }
     // Two tilings.  Large: 128 co x 512 px (16x32 pixel tile), 8 waves -- when the map is at least 16x32, there are at
     // least 128 output channels and the grid still fills the chip (>= 384 blocks).  Default: 64 co x 256 px, 4 waves.
     int MT = 1;
@@ -1316,6 +1368,26 @@ extern "C" int agf_conv2d_fwd(const void* x, const void* w, void* y,
     if (rc != AGF_OK) return rc;
     AGF_LAUNCH_CHECK();
     return AGF_OK;
+}
+
+extern "C" int agf_conv2d_fwd(const void* x, const void* w, void* y,
+                              const float* in_scale, const float* out_scale, const float* bias,
+                              const float* noise, const void* residual,
+                              int dtype, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
+                              int act, float alpha, float act_gain, void* stream) {
+    return conv2d_fwd_impl(x, w, y, in_scale, out_scale, bias, noise, residual, dtype, N, H, W, Cin, Cout, ksize, act, alpha, act_gain,
+                           nullptr, 0.f, nullptr, stream);
+}
+
+extern "C" int agf_conv2d_fwd_mask(const void* x, const void* w, void* y,
+                                   const float* in_scale, const float* out_scale, const float* bias,
+                                   const float* noise, const void* residual,
+                                   int dtype, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
+                                   int act, float alpha, float act_gain,
+                                   const void* mask_y, float mask_alpha, float* mask_sum, void* stream) {
+    AGF_CHECK(mask_y, "conv2d_fwd_mask: null mask tensor");
+    return conv2d_fwd_impl(x, w, y, in_scale, out_scale, bias, noise, residual, dtype, N, H, W, Cin, Cout, ksize, act, alpha, act_gain,
+                           mask_y, mask_alpha, mask_sum, stream);
 }
 
 // =================================================================================================

@@ -10,6 +10,8 @@ the discriminator twice, the path-length penalty the generator) compose from thr
     fwd(x, w)            -> dx = fwd(dy, flipT(w)),  dw = wgrad(x, dy)
     wgrad(x, dy)         -> dx = fwd(dy, flipT(ddw)),  d(dy) = fwd(x, ddw)
 """
+import os
+
 import torch
 
 from ... import _lib
@@ -81,7 +83,7 @@ def prep_weights_raw(w, coef, dtype, want_q=True, want_ft=False):
 
 
 def conv2d_fwd_raw(x, w, in_scale=None, out_scale=None, bias=None, noise=None, residual=None,
-                   act=ACT_LINEAR, alpha=0.2, gain=1.0, prepared=False):
+                   act=ACT_LINEAR, alpha=0.2, gain=1.0, prepared=False, mask_y=None, mask_alpha=0.2, mask_sum=None):
     """One ``agf_conv2d_fwd`` launch.  x: [N,Cin,H,W] bf16 channels_last; w: [Cout,Cin,k,k] (any float dtype).
     in_scale [N,Cin], out_scale [N,Cout], bias [Cout], noise [N,1,H,W] are fp32; residual like y.  Returns y bf16 channels_last."""
     _lib.require_gpu(x, 'conv2d')
@@ -99,9 +101,18 @@ def conv2d_fwd_raw(x, w, in_scale=None, out_scale=None, bias=None, noise=None, r
         residual = residual.to(x.dtype).contiguous(memory_format=torch.channels_last)
     timer = KernelTimer.active
     ev0 = timer.start() if timer is not None else None
-    rc = _lib.lib().agf_conv2d_fwd(_lib.ptr(x), _lib.ptr(wq), _lib.ptr(y), _lib.ptr(in_scale), _lib.ptr(out_scale),
-                                   _lib.ptr(bias), _lib.ptr(noise), _lib.ptr(residual), _lib.dtype_code(x),
-                                   N, H, W, Cin, Cout, k, act, float(alpha), float(gain), _lib.stream_ptr(x))
+    if mask_y is not None:
+        # ``agf_conv2d_fwd_mask``: the result is multiplied by the leaky-ReLU derivative taken from ``mask_y`` (same shape as y) and its
+        # per-channel sum is accumulated into ``mask_sum`` -- the lrelu backward of the layer below, fused into this data-gradient launch
+        assert mask_y.shape == y.shape and mask_y.dtype == x.dtype and mask_y.is_contiguous(memory_format=torch.channels_last)
+        rc = _lib.lib().agf_conv2d_fwd_mask(_lib.ptr(x), _lib.ptr(wq), _lib.ptr(y), _lib.ptr(in_scale), _lib.ptr(out_scale),
+                                            _lib.ptr(bias), _lib.ptr(noise), _lib.ptr(residual), _lib.dtype_code(x),
+                                            N, H, W, Cin, Cout, k, act, float(alpha), float(gain),
+                                            _lib.ptr(mask_y), float(mask_alpha), _lib.ptr(mask_sum), _lib.stream_ptr(x))
+    else:
+        rc = _lib.lib().agf_conv2d_fwd(_lib.ptr(x), _lib.ptr(wq), _lib.ptr(y), _lib.ptr(in_scale), _lib.ptr(out_scale),
+                                       _lib.ptr(bias), _lib.ptr(noise), _lib.ptr(residual), _lib.dtype_code(x),
+                                       N, H, W, Cin, Cout, k, act, float(alpha), float(gain), _lib.stream_ptr(x))
     if timer is not None:
         timer.stop('conv2d_fwd_kernel', ev0, 2.0 * N * H * W * Cin * Cout * k * k, (N, Cin, Cout, H, W, k, in_scale is not None))
     _lib.check(rc, 'conv2d_fwd')
@@ -380,18 +391,36 @@ def style_demod(s_raw, weight, coef, eps=1e-4):
     return _StyleDemod.apply(s_raw, weight, coef, eps)
 
 
+class PremaskLink:
+    """Handshake between two chained fused convs  y1 = lrelu(conv1(x) + b1);  y2 = conv2(y1)  where conv2 is the ONLY consumer of y1
+    (the caller guarantees that: DBlock).  conv2's backward then produces the gradient of y1 already multiplied by lrelu'(y1) and its
+    per-channel sums (``agf_conv2d_fwd_mask``), and conv1's backward skips its own pass over the tensor (``agf_act_bwd_reduce``)."""
+    __slots__ = ('armed', 'alpha', 'premasked', 'bsum')
+
+    def __init__(self):
+        self.armed, self.alpha, self.premasked, self.bsum = False, 0.2, False, None
+
+
+_PREMASK = os.environ.get('AGF_PREMASK', '1') != '0'       # A/B switch
+
+
 class _FusedConv(torch.autograd.Function):
     """y = act( s_out * conv(x * s_in, weight * coef) + bias + noise + residual ) * gain   in one launch.
     act = lrelu (gain must be 1) or linear.  The backward is fused too unless a graph is being recorded."""
 
     @staticmethod
-    def forward(ctx, x, weight, coef, s_in, s_out, bias, noise, residual, act, alpha, gain):
+    def forward(ctx, x, weight, coef, s_in, s_out, bias, noise, residual, act, alpha, gain, pre_link=None, post_link=None):
         prep = prepared_weights(weight, coef, x.dtype)
         y = conv2d_fwd_raw(x, prep.wq, in_scale=s_in, out_scale=s_out, bias=bias, noise=noise, residual=residual,
                            act=act, alpha=alpha, gain=gain, prepared=True)
         ctx.save_for_backward(x, weight, s_in, s_out, bias, noise, y if (act == ACT_LRELU or s_out is not None) else None)
         ctx.coef, ctx.act, ctx.alpha, ctx.gain = coef, act, alpha, gain
         ctx.has_residual = residual is not None
+        ctx.pre_link, ctx.post_link = pre_link, None
+        if post_link is not None and _PREMASK and act == ACT_LRELU and gain == 1.0 and s_out is None and noise is None \
+                and x.dtype == torch.bfloat16:
+            post_link.armed, post_link.alpha, post_link.premasked = True, float(alpha), False
+            ctx.post_link = post_link
         return y
 
     @staticmethod
@@ -422,11 +451,19 @@ class _FusedConv(torch.autograd.Function):
                 dx = _ConvFwd.apply(g, flip_transpose(w), None, None)
             if need_w:
                 dw = (_ConvWgrad.apply(x, g, None, None, k) * coef).to(weight.dtype)
-            return dx, dw, None, None, None, db, None, dres, None, None, None
+            return dx, dw, None, None, None, db, None, dres, None, None, None, None, None
         # the output gain is not applied to the gradient tensor: it rides along in the data-gradient launch's epilogue gain, in the
         # weight-gradient scale and in the bias sum (no pass over the tensor for it)
         pg = float(gain)
-        if act == ACT_LRELU:
+        link = ctx.post_link
+        if link is not None and link.premasked:
+            # the consumer's data-gradient launch already applied lrelu'(y) and summed the channels (agf_conv2d_fwd_mask)
+            link.premasked = False
+            g = dy
+            if need_b and bias is not None:
+                db = link.bsum.sum(0).to(bias.dtype)
+            link.bsum = None
+        elif act == ACT_LRELU:
             assert gain == 1.0 or s_out is None, 'demodulated layers use unit gain'
             want_so = s_out is not None and need_so
             g, (A, B, Cn) = act_bwd_reduce_raw(dy, y, noise, alpha,
@@ -446,18 +483,25 @@ class _FusedConv(torch.autograd.Function):
             dres = g * pg if pg != 1.0 else g
         if need_x or (s_in is not None and need_si):
             prep = prepared_weights(weight, coef, x.dtype, need_ft=True)
-            t = conv2d_fwd_raw(g, prep.wq_ft, in_scale=s_out, prepared=True, gain=pg)
+            pre = ctx.pre_link
+            if pre is not None and pre.armed and s_in is None and need_x and x.dtype == torch.bfloat16 and x.shape[1] % 8 == 0:
+                # x is the lrelu output of the producer this link came from and we are its only consumer: hand it the masked gradient
+                pre.bsum = torch.zeros(256, x.shape[1], dtype=torch.float32, device=x.device)
+                t = conv2d_fwd_raw(g, prep.wq_ft, in_scale=s_out, prepared=True, gain=pg, mask_y=x, mask_alpha=pre.alpha, mask_sum=pre.bsum)
+                pre.premasked = True
+            else:
+                t = conv2d_fwd_raw(g, prep.wq_ft, in_scale=s_out, prepared=True, gain=pg)
             if s_in is None:
                 dx = t
             else:
                 dx, dsi = scale_dot_raw(x, t, s_in, want_dx=need_x)
         if need_w:
             dw = conv2d_wgrad_raw(x, g, k, in_scale=s_in, out_scale=s_out, scale=coef * pg).to(weight.dtype)
-        return dx, dw, None, dsi, dso, db, None, dres, None, None, None
+        return dx, dw, None, dsi, dso, db, None, dres, None, None, None, None, None
 
 
 def conv2d_act(x, weight, bias=None, s_in=None, s_out=None, noise=None, alpha=0.2, fused=True, coef=1.0,
-               act='lrelu', residual=None, gain=1.0):
+               act='lrelu', residual=None, gain=1.0, pre_link=None, post_link=None):
     """act( s_out * conv(x * s_in, weight * coef) + bias + noise + residual ) * gain; act = 'lrelu' | 'linear'.
     bias [Cout], noise [N,1,H,W] (no gradient), residual like the output.
     ``fused=False`` evaluates the same expression with the separately differentiable ops (any-order gradients)."""
@@ -469,7 +513,7 @@ def conv2d_act(x, weight, bias=None, s_in=None, s_out=None, noise=None, alpha=0.
             weight = _pad_channels(weight, 8, 1)
             s_in = _pad_channels(s_in, 8, 1) if s_in is not None else None
         return _FusedConv.apply(x, weight, coef, s_in, s_out, bias, noise, residual,
-                                ACT_LRELU if act == 'lrelu' else ACT_LINEAR, alpha, gain)
+                                ACT_LRELU if act == 'lrelu' else ACT_LINEAR, alpha, gain, pre_link, post_link)
     out = conv2d(x, weight * coef if coef != 1.0 else weight, s_in, s_out)
     if noise is not None:
         out = out + noise.to(out.dtype)

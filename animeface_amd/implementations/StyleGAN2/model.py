@@ -29,7 +29,7 @@ import torch.nn.functional as F
 
 from ...stylegan3_ops import upfirdn2d, bias_act
 from ... import rng
-from .conv import conv2d, conv2d_act, style_demod
+from .conv import conv2d, conv2d_act, style_demod, PremaskLink
 
 
 # bias / noise / leaky-ReLU run in the conv kernel's epilogue (with a fused backward).  The fused modulated conv has
@@ -57,7 +57,7 @@ class ELR(nn.Module):
         return F.linear(x * self.coef, self.layer.weight, self.layer.bias)
 
 
-def elr_conv2d(elr, x, act=None, residual=None, gain=1.0, out_gain=1.0):
+def elr_conv2d(elr, x, act=None, residual=None, gain=1.0, out_gain=1.0, pre_link=None, post_link=None):
     """``ELR(nn.Conv2d)`` on the MFMA conv; coef is folded into the weights; optional fused-order bias + lrelu.
     ``out_gain`` (linear layers only) scales the conv + bias part of the output by a constant for free: it is folded into the
     weight coefficient and the bias instead of being applied to the output tensor (nothing to undo in backward either)."""
@@ -70,7 +70,8 @@ def elr_conv2d(elr, x, act=None, residual=None, gain=1.0, out_gain=1.0):
         coef = coef * out_gain
         bias = bias * out_gain if bias is not None else None
     return conv2d_act(x, conv.weight, bias, alpha=0.2, fused=FUSED_EPILOGUE, coef=coef,
-                      act='lrelu' if act == 'lrelu' else 'linear', residual=residual, gain=gain)
+                      act='lrelu' if act == 'lrelu' else 'linear', residual=residual, gain=gain,
+                      pre_link=pre_link, post_link=post_link)
 
 
 def Linear(name, *args, **kwargs):
@@ -263,8 +264,13 @@ class DBlock(nn.Module):
     def forward(self, x):
         t = x
         mods = list(self.block)
+        # conv -> lrelu -> conv chains: the next conv is the only consumer of the activation, so its data-gradient launch applies the
+        # lrelu gradient of the layer below (PremaskLink / agf_conv2d_fwd_mask) instead of a separate pass over the tensor
+        pre = None
         for i in range(0, len(mods), 2):
-            x = elr_conv2d(mods[i], x, act='lrelu')
+            post = PremaskLink() if i + 2 < len(mods) else None
+            x = elr_conv2d(mods[i], x, act='lrelu', pre_link=pre, post_link=post)
+            pre = post
         c = float(1 / np.sqrt(2))
         if isinstance(self.down, _AvgPool2x):
             # avg-pool commutes with the 1x1 skip conv: pool first (4x less work), identical result

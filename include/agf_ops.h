@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define AGF_ABI_VERSION 3
+#define AGF_ABI_VERSION 4
 
 /* element types of activation tensors */
 enum { AGF_F32 = 0, AGF_F16 = 1, AGF_BF16 = 2, AGF_F64 = 3 };
@@ -137,6 +137,20 @@ int agf_conv2d_fwd(const void* x, const void* w, void* y,
                    const float* noise, const void* residual,
                    int dtype, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
                    int act, float alpha, float act_gain, void* stream);
+
+/* agf_conv2d_fwd followed, in the same epilogue, by the leaky-ReLU gradient of the layer BELOW -- for data-gradient launches whose
+ * result is the gradient w.r.t. that layer's activated output (nn.Conv2d -> nn.LeakyReLU -> nn.Conv2d chains of DBlock,
+ * implementations/StyleGAN2/model.py:192-202; autograd runs LeakyReluBackward as a separate pass there):
+ *   y = epilogue(...) * (mask_y > 0 ? 1 : mask_alpha),   mask_y [N,H,W,Cout] = the layer-below's lrelu OUTPUT (this conv's forward input)
+ *   mask_sum [256][Cout] fp32, nullable, accumulated: sum over its 256 rows = sum_{n,h,w} y[n,h,w,co], the layer-below's bias gradient
+ *                (256 slots keep the per-block atomics from piling onto Cout addresses)
+ * bf16, Cout % 8 == 0, 16-byte aligned tensors; AGF_ENOKERNEL otherwise (callers then run agf_conv2d_fwd + agf_act_bwd_reduce). */
+int agf_conv2d_fwd_mask(const void* x, const void* w, void* y,
+                        const float* in_scale, const float* out_scale, const float* bias,
+                        const float* noise, const void* residual,
+                        int dtype, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
+                        int act, float alpha, float act_gain,
+                        const void* mask_y, float mask_alpha, float* mask_sum, void* stream);
 
 /* weight gradient of the same contraction:
  *   dw[co,kh,kw,ci] += scale * sum_{n,h,w} dy[n,h,w,co] * out_scale[n,co] * x[n,h+kh-p,w+kw-p,ci] * in_scale[n,ci]
