@@ -18,6 +18,8 @@ struct ActBwdParams {
     float *sumA, *sumB, *sumC;
     int N, HW, C, CG, pixLanes, pixPerBlock, chunks;
     float alpha, inv_alpha;
+    int pooled, W;            // pooled: dy is [N,H/2,W/2,C], the gradient of a 2x2 box average: every input pixel of a 2x2 cell gets dy * dy_scale
+    float dy_scale;
 };
 
 template <class T, int VEC>
@@ -39,11 +41,23 @@ __global__ void __launch_bounds__(256) act_bwd_reduce_kernel(ActBwdParams p) {
             const int px2 = px + p.pixLanes;
             const bool two = px2 < p1;
             float dy[2][VEC], y[2][VEC], g[VEC];
-            VecIO<T, VEC>::load((const T*)p.dy + base + (int64_t)px * p.C, dy[0]);
+            if (p.pooled) {
+                // the adjoint of the 2x2 average fused in: no full-resolution gradient tensor is ever written / re-read
+                const int h = px / p.W, w = px - h * p.W;
+                VecIO<T, VEC>::load((const T*)p.dy + ((int64_t)n * (p.HW >> 2) + (h >> 1) * (p.W >> 1) + (w >> 1)) * p.C + cg * VEC, dy[0]);
+                if (two) {
+                    const int h2 = px2 / p.W, w2 = px2 - h2 * p.W;
+                    VecIO<T, VEC>::load((const T*)p.dy + ((int64_t)n * (p.HW >> 2) + (h2 >> 1) * (p.W >> 1) + (w2 >> 1)) * p.C + cg * VEC, dy[1]);
+                }
+            } else {
+                VecIO<T, VEC>::load((const T*)p.dy + base + (int64_t)px * p.C, dy[0]);
+                if (two) VecIO<T, VEC>::load((const T*)p.dy + base + (int64_t)px2 * p.C, dy[1]);
+            }
             VecIO<T, VEC>::load((const T*)p.y + base + (int64_t)px * p.C, y[0]);
-            if (two) {
-                VecIO<T, VEC>::load((const T*)p.dy + base + (int64_t)px2 * p.C, dy[1]);
-                VecIO<T, VEC>::load((const T*)p.y + base + (int64_t)px2 * p.C, y[1]);
+            if (two) VecIO<T, VEC>::load((const T*)p.y + base + (int64_t)px2 * p.C, y[1]);
+            if (p.pooled) {
+#pragma unroll
+                for (int i = 0; i < VEC; i++) { dy[0][i] *= p.dy_scale; dy[1][i] *= p.dy_scale; }
             }
             const float nz0 = p.noise ? p.noise[(int64_t)n * p.HW + px] : 0.f;
             const float nz1 = (p.noise && two) ? p.noise[(int64_t)n * p.HW + px2] : 0.f;
@@ -150,9 +164,9 @@ static int plan(int C, int vec, int HW, int N, int* CG, int* pixLanes, int* pixP
     return 1;
 }
 
-extern "C" int agf_act_bwd_reduce(const void* dy, const void* y, const float* noise, void* g,
-                                  float* sum_gy0, float* sum_g, float* sum_gnoise,
-                                  int dtype, int32_t N, int32_t H, int32_t W, int32_t C, float alpha, void* stream) {
+static int act_bwd_reduce_impl(const void* dy, const void* y, const float* noise, void* g,
+                               float* sum_gy0, float* sum_g, float* sum_gnoise,
+                               int dtype, int32_t N, int32_t H, int32_t W, int32_t C, float alpha, int pooled, float dy_scale, void* stream) {
     AGF_CHECK(dy && y && g, "act_bwd_reduce: null pointer");
     AGF_CHECK(dtype == AGF_BF16 || dtype == AGF_F32, "act_bwd_reduce: dtype must be bf16 or f32");
     AGF_CHECK(alpha > 0.f, "act_bwd_reduce: the leaky slope must be positive");
@@ -160,6 +174,7 @@ extern "C" int agf_act_bwd_reduce(const void* dy, const void* y, const float* no
     ActBwdParams p;
     p.dy = dy; p.y = y; p.noise = noise; p.g = g; p.sumA = sum_gy0; p.sumB = sum_g; p.sumC = sum_gnoise;
     p.N = N; p.HW = H * W; p.C = C; p.alpha = alpha; p.inv_alpha = 1.f / alpha;
+    p.pooled = pooled; p.W = W; p.dy_scale = dy_scale;
     const int vec = dtype == AGF_BF16 ? 8 : 4;
     if (!plan(C, vec, p.HW, N, &p.CG, &p.pixLanes, &p.pixPerBlock, &p.chunks)) {
         agf_set_error("act_bwd_reduce: C=%d is not a multiple of %d (or too wide)", C, vec);
@@ -170,6 +185,18 @@ extern "C" int agf_act_bwd_reduce(const void* dy, const void* y, const float* no
     else hipLaunchKernelGGL((act_bwd_reduce_kernel<float, 4>), grid, block, 0, (hipStream_t)stream, p);
     AGF_LAUNCH_CHECK();
     return AGF_OK;
+}
+
+extern "C" int agf_act_bwd_reduce(const void* dy, const void* y, const float* noise, void* g,
+                                  float* sum_gy0, float* sum_g, float* sum_gnoise,
+                                  int dtype, int32_t N, int32_t H, int32_t W, int32_t C, float alpha, void* stream) {
+    return act_bwd_reduce_impl(dy, y, noise, g, sum_gy0, sum_g, sum_gnoise, dtype, N, H, W, C, alpha, 0, 1.f, stream);
+}
+
+extern "C" int agf_act_bwd_reduce_pooled(const void* dy_half, const void* y, void* g, float* sum_g,
+                                         int dtype, int32_t N, int32_t H, int32_t W, int32_t C, float alpha, float dy_scale, void* stream) {
+    AGF_CHECK(H % 2 == 0 && W % 2 == 0, "act_bwd_reduce_pooled: H and W must be even");
+    return act_bwd_reduce_impl(dy_half, y, nullptr, g, nullptr, sum_g, nullptr, dtype, N, H, W, C, alpha, 1, dy_scale, stream);
 }
 
 extern "C" int agf_scale_dot(const void* x, const void* t, const float* s, void* dx, float* ds,

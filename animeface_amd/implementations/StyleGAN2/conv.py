@@ -265,6 +265,18 @@ def act_bwd_reduce_raw(dy, y, noise, alpha, want_sums):
     return g, sums
 
 
+def act_bwd_reduce_pooled_raw(dy_half, y, alpha, dy_scale, want_sum):
+    """One ``agf_act_bwd_reduce_pooled`` launch: g = dy_scale * dy_half[h/2, w/2] * lrelu'(y) and its per-(n,c) sum."""
+    N, C, H, W = y.shape
+    assert dy_half.shape == (N, C, H // 2, W // 2) and dy_half.dtype == y.dtype
+    g = torch.empty_like(y)
+    B = torch.zeros((N, C), dtype=torch.float32, device=y.device) if want_sum else None
+    rc = _lib.lib().agf_act_bwd_reduce_pooled(_lib.ptr(dy_half), _lib.ptr(y), _lib.ptr(g), _lib.ptr(B),
+                                              _lib.dtype_code(y), N, H, W, C, float(alpha), float(dy_scale), _lib.stream_ptr(y))
+    _lib.check(rc, 'act_bwd_reduce_pooled')
+    return g, B
+
+
 def scale_dot_raw(x, t, s, want_dx=True):
     """One ``agf_scale_dot`` launch: dx = t * s[n,c], ds[n,c] = sum_hw x * t."""
     N, C, H, W = x.shape
@@ -395,10 +407,43 @@ class PremaskLink:
     """Handshake between two chained fused convs  y1 = lrelu(conv1(x) + b1);  y2 = conv2(y1)  where conv2 is the ONLY consumer of y1
     (the caller guarantees that: DBlock).  conv2's backward then produces the gradient of y1 already multiplied by lrelu'(y1) and its
     per-channel sums (``agf_conv2d_fwd_mask``), and conv1's backward skips its own pass over the tensor (``agf_act_bwd_reduce``)."""
-    __slots__ = ('armed', 'alpha', 'premasked', 'bsum')
+    __slots__ = ('armed', 'alpha', 'premasked', 'bsum', 'pooled')
 
     def __init__(self):
-        self.armed, self.alpha, self.premasked, self.bsum = False, 0.2, False, None
+        self.armed, self.alpha, self.premasked, self.bsum, self.pooled = False, 0.2, False, None, None
+
+
+class _PoolLinked(torch.autograd.Function):
+    """2x2 box average (``downsample2d`` with the [1,1] filter) as the ONLY consumer of a fused conv's lrelu output: instead of writing
+    the full-resolution gradient (an upsampling FIR pass) it hands the pooled gradient to the producer's backward through the link, where
+    ``agf_act_bwd_reduce_pooled`` reads it at half resolution.  Autograd still needs a tensor of the input's shape: a zero-stride view."""
+
+    @staticmethod
+    def forward(ctx, x, f, gain, link):
+        from ...stylegan3_ops import upfirdn2d
+        ctx.save_for_backward(f)
+        ctx.gain, ctx.link, ctx.x_shape = gain, link, x.shape
+        return upfirdn2d.downsample2d(x.detach(), f, down=2, gain=gain)
+
+    @staticmethod
+    def backward(ctx, dy):
+        from ...stylegan3_ops import upfirdn2d
+        f, = ctx.saved_tensors
+        link, gain = ctx.link, ctx.gain
+        _, _, ih, iw = ctx.x_shape
+        if link is not None and link.armed and _PREMASK and not torch.is_grad_enabled() and dy.dtype == torch.bfloat16 \
+                and ih % 2 == 0 and iw % 2 == 0:
+            link.pooled = (dy.contiguous(memory_format=torch.channels_last), float(gain) * 0.25)
+            return dy.new_empty(1).expand(ctx.x_shape), None, None, None
+        # the ordinary adjoint (also the differentiable one): zero-insert x2, [1,1] x [1,1] / 4 filter, same gain
+        _, _, oh, ow = dy.shape
+        p = [1, iw - 2 * ow, 1, ih - 2 * oh]
+        dx = upfirdn2d.upfirdn2d(dy, f, up=2, padding=p, flip_filter=True, gain=gain)
+        return dx, None, None, None
+
+
+def pool2x_linked(x, f, gain, link):
+    return _PoolLinked.apply(x, f, gain, link)
 
 
 _PREMASK = os.environ.get('AGF_PREMASK', '1') != '0'       # A/B switch
@@ -419,7 +464,7 @@ class _FusedConv(torch.autograd.Function):
         ctx.pre_link, ctx.post_link = pre_link, None
         if post_link is not None and _PREMASK and act == ACT_LRELU and gain == 1.0 and s_out is None and noise is None \
                 and x.dtype == torch.bfloat16:
-            post_link.armed, post_link.alpha, post_link.premasked = True, float(alpha), False
+            post_link.armed, post_link.alpha, post_link.premasked, post_link.pooled = True, float(alpha), False, None
             ctx.post_link = post_link
         return y
 
@@ -429,7 +474,12 @@ class _FusedConv(torch.autograd.Function):
         coef, act, alpha, gain = ctx.coef, ctx.act, ctx.alpha, ctx.gain
         need_x, need_w, _, need_si, need_so, need_b, _, need_r = ctx.needs_input_grad[:8]
         need_r = need_r and ctx.has_residual
-        dy = dy.to(x.dtype).contiguous(memory_format=torch.channels_last)
+        link = ctx.post_link
+        pooled = None
+        if link is not None and link.pooled is not None:
+            pooled, link.pooled = link.pooled, None                 # dy is a zero-stride placeholder: the real gradient is pooled[0]
+        else:
+            dy = dy.to(x.dtype).contiguous(memory_format=torch.channels_last)
         k = weight.shape[2]
         dx = dw = dsi = dso = db = dres = None
         if torch.is_grad_enabled():
@@ -455,8 +505,11 @@ class _FusedConv(torch.autograd.Function):
         # the output gain is not applied to the gradient tensor: it rides along in the data-gradient launch's epilogue gain, in the
         # weight-gradient scale and in the bias sum (no pass over the tensor for it)
         pg = float(gain)
-        link = ctx.post_link
-        if link is not None and link.premasked:
+        if pooled is not None:
+            g, B = act_bwd_reduce_pooled_raw(pooled[0], y, alpha, pooled[1], need_b and bias is not None)
+            if need_b and bias is not None:
+                db = B.sum(0).to(bias.dtype)
+        elif link is not None and link.premasked:
             # the consumer's data-gradient launch already applied lrelu'(y) and summed the channels (agf_conv2d_fwd_mask)
             link.premasked = False
             g = dy

@@ -29,7 +29,7 @@ import torch.nn.functional as F
 
 from ...stylegan3_ops import upfirdn2d, bias_act
 from ... import rng
-from .conv import conv2d, conv2d_act, style_demod, PremaskLink
+from .conv import conv2d, conv2d_act, style_demod, PremaskLink, pool2x_linked
 
 
 # bias / noise / leaky-ReLU run in the conv kernel's epilogue (with a fused backward).  The fused modulated conv has
@@ -106,7 +106,9 @@ class _AvgPool2x(nn.Module):
         super().__init__()
         self.register_buffer('f', upfirdn2d.setup_filter([1, 1]), persistent=False)
 
-    def forward(self, x, gain=1):
+    def forward(self, x, gain=1, link=None):
+        if link is not None:
+            return pool2x_linked(x, self.f, gain, link)       # x is a fused conv's lrelu output and this is its only consumer
         return upfirdn2d.downsample2d(x, self.f, down=2, gain=gain)
 
 
@@ -267,8 +269,9 @@ class DBlock(nn.Module):
         # conv -> lrelu -> conv chains: the next conv is the only consumer of the activation, so its data-gradient launch applies the
         # lrelu gradient of the layer below (PremaskLink / agf_conv2d_fwd_mask) instead of a separate pass over the tensor
         pre = None
+        pooled = isinstance(self.down, _AvgPool2x) and FUSED_EPILOGUE
         for i in range(0, len(mods), 2):
-            post = PremaskLink() if i + 2 < len(mods) else None
+            post = PremaskLink() if (i + 2 < len(mods) or pooled) else None
             x = elr_conv2d(mods[i], x, act='lrelu', pre_link=pre, post_link=post)
             pre = post
         c = float(1 / np.sqrt(2))
@@ -276,7 +279,7 @@ class DBlock(nn.Module):
             # avg-pool commutes with the 1x1 skip conv: pool first (4x less work), identical result
             # (skip(pool(t)) + pool(x)) / sqrt(2): the residual add runs in the 1x1 conv's epilogue; the 1/sqrt(2) costs nothing:
             # it is folded into the skip conv's weight coefficient / bias and into the gain of the pooling FIR of x
-            return elr_conv2d(self.skip, self.down(t), residual=self.down(x, gain=c), out_gain=c)
+            return elr_conv2d(self.skip, self.down(t), residual=self.down(x, gain=c, link=pre), out_gain=c)
         t = self.skip(t)
         return (self.down(x) + self.down(t)) / np.sqrt(2)
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define AGF_ABI_VERSION 4
+#define AGF_ABI_VERSION 5
 
 /* element types of activation tensors */
 enum { AGF_F32 = 0, AGF_F16 = 1, AGF_BF16 = 2, AGF_F64 = 3 };
@@ -171,6 +171,13 @@ int agf_conv2d_wgrad(const void* x, const void* dy, float* dw,
 int agf_act_bwd_reduce(const void* dy, const void* y, const float* noise, void* g,
                        float* sum_gy0, float* sum_g, float* sum_gnoise,
                        int dtype, int32_t N, int32_t H, int32_t W, int32_t C, float alpha, void* stream);
+
+/* agf_act_bwd_reduce for an activation whose only consumer is a 2x2 box average (nn.AvgPool2d(2) after the last LeakyReLU of a DBlock,
+ * implementations/StyleGAN2/model.py:204-212): dy_half [N,H/2,W/2,C] is the gradient of the POOLED tensor; every pixel of a 2x2 cell
+ * receives dy_half * dy_scale (dy_scale = gain / 4), so g = dy_scale * dy_half[h/2,w/2] * lrelu'(y) and sum_g[n,c] = sum_p g --
+ * the full-resolution gradient of the pooling is never written or re-read.  H, W even. */
+int agf_act_bwd_reduce_pooled(const void* dy_half, const void* y, void* g, float* sum_g,
+                              int dtype, int32_t N, int32_t H, int32_t W, int32_t C, float alpha, float dy_scale, void* stream);
 
 /*   dx = t * s[n,c]  (nullable),   ds[n,c] += sum_{h,w} x * t */
 int agf_scale_dot(const void* x, const void* t, const float* s, void* dx, float* ds,

@@ -210,3 +210,58 @@ def test_style_demod_vs_composite(shape):
     (dw2,) = torch.autograd.grad(style_demod(s_raw.detach(), w, coef)[1], [w], [gd])
     (ref2,) = torch.autograd.grad(torch.rsqrt(((s_raw.detach() + 1).square() @ w.square().sum((2, 3)).t()) * (coef * coef) + 1e-4), [w], [gd])
     assert rel(dw2, ref2) < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(4, 64, 64, 64, 64, None), (3, 128, 136, 32, 64, '2'), (16, 64, 64, 128, 128, None), (5, 512, 512, 8, 8, None),
+                                   (2, 72, 40, 19, 38, None)])
+def test_conv_fwd_mask_vs_composite(shape, monkeypatch):
+    """agf_conv2d_fwd_mask: conv, then the lrelu gradient of the layer below (mask from its activation output) and the channel sums."""
+    from animeface_amd.implementations.StyleGAN2.conv import conv2d_fwd_raw
+    N, Cin, Cout, H, W, forced = shape
+    if forced:
+        monkeypatch.setenv('AGF_CONV_MT', forced)
+    x, w, g = make(N, Cin, Cout, H, W, 3, seed=5)
+    a = torch.randn(N, Cout, H, W, generator=g).to(torch.bfloat16).to(DEV).contiguous(memory_format=torch.channels_last)
+    msum = torch.zeros(256, Cout, device=DEV)
+    y = conv2d_fwd_raw(x, w, gain=0.9, mask_y=a, mask_alpha=0.2, mask_sum=msum)
+    ref = F.conv2d(x.float(), w.float(), padding=1) * 0.9
+    ref = ref.to(torch.bfloat16).float() * torch.where(a.float() > 0, 1.0, 0.2)
+    assert rel(y, ref) < 8e-3
+    assert rel(msum.sum(0), ref.sum((0, 2, 3))) < 5e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(3, 64, 32, 32), (2, 40, 18, 38), (5, 512, 4, 4), (2, 8, 64, 64)])
+def test_act_bwd_reduce_pooled_vs_composite(shape):
+    from animeface_amd.implementations.StyleGAN2.conv import act_bwd_reduce_pooled_raw
+    N, C, H, W = shape
+    g0 = torch.Generator().manual_seed(9)
+    y = torch.randn(N, C, H, W, generator=g0).to(torch.bfloat16).to(DEV).contiguous(memory_format=torch.channels_last)
+    d = torch.randn(N, C, H // 2, W // 2, generator=g0).to(torch.bfloat16).to(DEV).contiguous(memory_format=torch.channels_last)
+    g, B = act_bwd_reduce_pooled_raw(d, y, 0.2, 0.3, True)
+    up = d.float().repeat_interleave(2, 2).repeat_interleave(2, 3) * 0.3
+    ref = up * torch.where(y.float() > 0, 1.0, 0.2)
+    assert rel(g, ref) < 8e-3
+    assert rel(B, ref.sum((2, 3))) < 5e-3
+
+
+@pytest.mark.gpu
+def test_dblock_linked_backward_matches_unlinked(monkeypatch):
+    """DBlock with the PremaskLink / pooled-gradient fusions against the same block with them switched off (bf16, same inputs)."""
+    from animeface_amd.implementations.StyleGAN2 import model as M, conv as C
+    torch.manual_seed(3)
+    blk = M.DBlock(32, 64).to(DEV)
+    blk.apply(M.init_weight_N01)
+    x0 = torch.randn(4, 32, 64, 64, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(4, 64, 32, 32, device=DEV).to(torch.bfloat16)
+    outs = []
+    for on in (True, False):
+        monkeypatch.setattr(C, '_PREMASK', on)
+        x = x0.clone().requires_grad_(True)
+        y = blk(x)
+        grads = torch.autograd.grad(y, [x] + list(blk.parameters()), gy)
+        outs.append((y, grads))
+    assert rel(outs[0][0], outs[1][0]) == 0
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert rel(a, b) < 2e-2, (a.shape, rel(a, b))
