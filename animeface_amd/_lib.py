@@ -69,7 +69,7 @@ def lib():
                                     [ctypes.c_int, ctypes.c_float, ctypes.c_float, _vp]
         L.agf_conv2d_fwd_mask.restype = ctypes.c_int
         L.agf_conv2d_fwd_mask.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int] + [ctypes.c_int32] * 6 + \
-                                         [ctypes.c_int, ctypes.c_float, ctypes.c_float, _vp, ctypes.c_float, _vp, _vp]
+                                         [ctypes.c_int, ctypes.c_float, ctypes.c_float, _vp, ctypes.c_float, _vp, _vp, ctypes.c_float, _vp]
         L.agf_conv2d_wgrad.restype = ctypes.c_int
         L.agf_conv2d_wgrad.argtypes = [_vp, _vp, _vp, _vp, _vp, ctypes.c_int] + [ctypes.c_int32] * 6 + [ctypes.c_float, _vp]
         L.agf_act_bwd_reduce.restype = ctypes.c_int
@@ -89,7 +89,7 @@ def lib():
         L.agf_style_demod_fwd.argtypes = [_vp] * 4 + [ctypes.c_int32] * 3 + [ctypes.c_float, ctypes.c_float, _vp]
         L.agf_style_demod_bwd.restype = ctypes.c_int
         L.agf_style_demod_bwd.argtypes = [_vp] * 8 + [ctypes.c_int32] * 4 + [ctypes.c_float, _vp]
-        if L.agf_abi_version() != 5:
+        if L.agf_abi_version() != 6:
             raise AgfError('libagf_ops.so ABI version mismatch')
         _lib = L
     return _lib

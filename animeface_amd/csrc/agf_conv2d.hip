@@ -63,7 +63,9 @@ struct ConvParams {
     float alpha, gain;
     const bf16_t* mask_y;     // fused lrelu gradient (agf_conv2d_fwd_mask): y *= mask_y > 0 ? 1 : mask_alpha; null = off
     float mask_alpha;
-    float* mask_sum;          // [Cout] fp32: += sum over pixels of the masked output (nullable)
+    float* mask_sum;          // [256][Cout] fp32: += sum over pixels of the masked output (nullable)
+    const bf16_t* res_pooled; // [N,H/2,W/2,Cout]: y += res_scale * res_pooled[h/2,w/2] before the mask (the adjoint of a 2x2 average that shares
+    float res_scale;          //   this conv's input: the other branch of a residual block); null = off
     int vecStore;             // epilogue: transpose through LDS and store 16-byte vectors (needs Cout % 8 == 0, y 16-byte aligned)
     int hoist;                // A/B switch: hoist the style-scale loads out of the per-vector staging loop
     int wsSlices;             // ping-pong weight-stationary kernel: blocks per image
@@ -103,6 +105,8 @@ static __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16
         if (!valid) n = 0;
         const float nz = p.noise ? p.noise[pixIdx] : 0.f;
         if (vecStore && lhi == 0) *(int64_t*)(sE + l31 * EROW + 64 * MT) = valid ? pixIdx : (int64_t)-1;
+        if (vecStore && lhi == 1 && p.res_pooled)                        // second header word: the pixel's 2x2 cell in the pooled tensor
+            *(int64_t*)(sE + l31 * EROW + 64 * MT + 8) = ((int64_t)n * (p.H >> 1) + (h >> 1)) * (p.W >> 1) + (w >> 1);
 #pragma unroll
         for (int i = 0; i < MT; i++) {
 #pragma unroll
@@ -152,6 +156,20 @@ static __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16
                 u32x4 val = *(const u32x4*)(sE + px * EROW + cv * 16);
                 const int co = co0 + wm * 32 * MT + cv * 8;
                 if (pi >= 0 && co < p.Cout) {
+                    if (p.res_pooled) {
+                        // gradient of the pooled skip branch, read at half resolution (no upsampled tensor, no separate add)
+                        const int64_t qi = *(const int64_t*)(sE + px * EROW + 64 * MT + 8);
+                        const u32x4 rv = *(const u32x4*)(p.res_pooled + qi * p.Cout + co);
+                        float g[8], r[8];
+                        Pack16<bf16_t>::unpack(val.x, g[0], g[1]); Pack16<bf16_t>::unpack(val.y, g[2], g[3]);
+                        Pack16<bf16_t>::unpack(val.z, g[4], g[5]); Pack16<bf16_t>::unpack(val.w, g[6], g[7]);
+                        Pack16<bf16_t>::unpack(rv.x, r[0], r[1]); Pack16<bf16_t>::unpack(rv.y, r[2], r[3]);
+                        Pack16<bf16_t>::unpack(rv.z, r[4], r[5]); Pack16<bf16_t>::unpack(rv.w, r[6], r[7]);
+#pragma unroll
+                        for (int e = 0; e < 8; e++) g[e] += r[e] * p.res_scale;
+                        val.x = Pack16<bf16_t>::pack(g[0], g[1]); val.y = Pack16<bf16_t>::pack(g[2], g[3]);
+                        val.z = Pack16<bf16_t>::pack(g[4], g[5]); val.w = Pack16<bf16_t>::pack(g[6], g[7]);
+                    }
                     if (p.mask_y) {
                         // the layer below's lrelu gradient, applied where the gradient tensor is produced (its own pass over the
                         // tensor -- read dy, read y, write g -- disappears; y comes in as full 16-byte vectors here)
@@ -566,8 +584,10 @@ static int launch_fwd_dl(const ConvParams& p0, hipStream_t st) {
 }
 
 // Second half of the LDS-transposed epilogue of the weight-stationary kernels (see conv2d_fwd_kernel): the wave's strip holds
-// 32 pixel rows of 32 channels + the pixel's global index (-1 = outside the image); lanes store 16-byte vectors, 4 per pixel.
-static __device__ __forceinline__ void strip_store32(const unsigned char* sE, int lane, bf16_t* y, int Cout, int coBase) {
+// 32 pixel rows of 32 channels + the pixel's global index (-1 = outside the image) + its index in the pooled tensor; lanes store
+// 16-byte vectors, 4 per pixel.  The pooled residual and the lrelu mask of agf_conv2d_fwd_mask are applied here as in conv_epilogue;
+// msum accumulates the masked values of this lane's 8 channels over all tiles of the persistent block.
+static __device__ __forceinline__ void strip_store32(const unsigned char* sE, int lane, const ConvParams& p, int coBase, float (&msum)[8]) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -575,12 +595,53 @@ static __device__ __forceinline__ void strip_store32(const unsigned char* sE, in
         const int v = lane + 64 * t;
         const int px = v >> 2, cv = v & 3;
         const int64_t pi = *(const int64_t*)(sE + px * 80 + 64);
-        const u32x4 val = *(const u32x4*)(sE + px * 80 + cv * 16);
+        u32x4 val = *(const u32x4*)(sE + px * 80 + cv * 16);
         const int co = coBase + cv * 8;
-        if (pi >= 0 && co < Cout) *(u32x4*)(y + pi * Cout + co) = val;
+        if (pi >= 0 && co < p.Cout) {
+            if (p.res_pooled || p.mask_y) {
+                float g[8];
+                Pack16<bf16_t>::unpack(val.x, g[0], g[1]); Pack16<bf16_t>::unpack(val.y, g[2], g[3]);
+                Pack16<bf16_t>::unpack(val.z, g[4], g[5]); Pack16<bf16_t>::unpack(val.w, g[6], g[7]);
+                if (p.res_pooled) {
+                    const int64_t qi = *(const int64_t*)(sE + px * 80 + 72);
+                    const u32x4 rv = *(const u32x4*)(p.res_pooled + qi * p.Cout + co);
+                    float r[8];
+                    Pack16<bf16_t>::unpack(rv.x, r[0], r[1]); Pack16<bf16_t>::unpack(rv.y, r[2], r[3]);
+                    Pack16<bf16_t>::unpack(rv.z, r[4], r[5]); Pack16<bf16_t>::unpack(rv.w, r[6], r[7]);
+#pragma unroll
+                    for (int e = 0; e < 8; e++) g[e] += r[e] * p.res_scale;
+                }
+                if (p.mask_y) {
+                    const u32x4 yv = *(const u32x4*)(p.mask_y + pi * p.Cout + co);
+                    float a[8];
+                    Pack16<bf16_t>::unpack(yv.x, a[0], a[1]); Pack16<bf16_t>::unpack(yv.y, a[2], a[3]);
+                    Pack16<bf16_t>::unpack(yv.z, a[4], a[5]); Pack16<bf16_t>::unpack(yv.w, a[6], a[7]);
+#pragma unroll
+                    for (int e = 0; e < 8; e++) { g[e] = a[e] > 0.f ? g[e] : g[e] * p.mask_alpha; msum[e] += g[e]; }
+                }
+                val.x = Pack16<bf16_t>::pack(g[0], g[1]); val.y = Pack16<bf16_t>::pack(g[2], g[3]);
+                val.z = Pack16<bf16_t>::pack(g[4], g[5]); val.w = Pack16<bf16_t>::pack(g[6], g[7]);
+            }
+            *(u32x4*)(p.y + pi * p.Cout + co) = val;
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+}
+
+// end of a persistent weight-stationary block: lanes with equal lane % 4 hold the same 8 channels; one atomic per channel and wave
+static __device__ __forceinline__ void strip_flush_sums(const ConvParams& p, int lane, int coBase, float (&msum)[8]) {
+    if (!(p.mask_y && p.mask_sum)) return;
+#pragma unroll
+    for (int m = 4; m < 64; m <<= 1) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) msum[e] += __shfl_xor(msum[e], m);
+    }
+    const int co = coBase + lane * 8;
+    if (lane < 4 && co < p.Cout) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) unsafeAtomicAdd(p.mask_sum + (int64_t)(blockIdx.x & 255) * p.Cout + co + e, msum[e]);
+    }
 }
 
 
@@ -698,6 +759,7 @@ __global__ void __launch_bounds__(256) conv2d_fwd_ws_kernel(ConvParams p) {
         }
     };
 
+    float msum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};          // agf_conv2d_fwd_mask: channel sums of the masked output
     f32x4 ebias[4];
 #pragma unroll
     for (int rg = 0; rg < 4; rg++) {
@@ -713,7 +775,7 @@ __global__ void __launch_bounds__(256) conv2d_fwd_ws_kernel(ConvParams p) {
         if (more) load_patch(pt + ptStep);
         // epilogue operands of THIS tile are fetched now so that their latency hides under the MFMAs (a persistent block
         // has no sibling to cover a dependent load at the end of every tile)
-        int en[NJ]; int64_t epix[NJ]; float enz[NJ]; bool eok[NJ];
+        int en[NJ]; int64_t epix[NJ]; float enz[NJ]; bool eok[NJ]; int eq[NJ];
         f32x4 esc[NJ][4];
         {
             int tq = pt;
@@ -727,6 +789,7 @@ __global__ void __launch_bounds__(256) conv2d_fwd_ws_kernel(ConvParams p) {
                 eok[j] = n < p.N && h < p.H && w < p.W;
                 en[j] = n;
                 epix[j] = eok[j] ? ((int64_t)n * p.H + h) * p.W + w : 0;
+                eq[j] = (eok[j] && p.res_pooled) ? (int)(((int64_t)n * (p.H >> 1) + (h >> 1)) * (p.W >> 1) + (w >> 1)) : 0;
                 enz[j] = (eok[j] && p.noise) ? p.noise[epix[j]] : 0.f;
 #pragma unroll
                 for (int rg = 0; rg < 4; rg++) {
@@ -761,6 +824,7 @@ __global__ void __launch_bounds__(256) conv2d_fwd_ws_kernel(ConvParams p) {
             const int64_t pixIdx = epix[j];
             const float nz = enz[j];
             if (vecStore && lhi == 0) *(int64_t*)(sE + l31 * 80 + 64) = eok[j] ? pixIdx : (int64_t)-1;
+            if (vecStore && lhi == 1 && p.res_pooled) *(int64_t*)(sE + l31 * 80 + 72) = eq[j];
 #pragma unroll
             for (int rg = 0; rg < 4; rg++) {
                 int co = co0 + wm * 32 + rg * 8 + lhi * 4;
@@ -788,7 +852,7 @@ __global__ void __launch_bounds__(256) conv2d_fwd_ws_kernel(ConvParams p) {
                 if (vecStore) *(u32x2*)(sE + l31 * 80 + (rg * 8 + lhi * 4) * 2) = o;
                 else *(u32x2*)(p.y + pixIdx * p.Cout + co) = o;
             }
-            if (vecStore) strip_store32(sE, lane, p.y, p.Cout, co0 + wm * 32);
+            if (vecStore) strip_store32(sE, lane, p, co0 + wm * 32, msum);
         }
         if (more) {
             __syncthreads();
@@ -800,6 +864,7 @@ __global__ void __launch_bounds__(256) conv2d_fwd_ws_kernel(ConvParams p) {
             __syncthreads();
         }
     }
+    strip_flush_sums(p, lane, co0 + wm * 32, msum);
 }
 
 // =================================================================================================
@@ -913,6 +978,7 @@ __global__ void __launch_bounds__(512, 2) conv2d_fwd_ws2_kernel(ConvParams p) {
         }
     };
 
+    float msum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};          // agf_conv2d_fwd_mask: channel sums of the masked output
     f32x4 ebias[4];
 #pragma unroll
     for (int rg = 0; rg < 4; rg++) {
@@ -964,6 +1030,8 @@ __global__ void __launch_bounds__(512, 2) conv2d_fwd_ws2_kernel(ConvParams p) {
                     const int64_t pixIdx = valid ? ((int64_t)img * p.H + h) * p.W + w : 0;
                     const float nz = p.noise ? p.noise[pixIdx] : 0.f;
                     if (vecStore && lhi == 0) *(int64_t*)(sE + l31 * 80 + 64) = valid ? pixIdx : (int64_t)-1;
+                    if (vecStore && lhi == 1 && p.res_pooled)
+                        *(int64_t*)(sE + l31 * 80 + 72) = ((int64_t)img * (p.H >> 1) + (h >> 1)) * (p.W >> 1) + (w >> 1);
 #pragma unroll
                     for (int rg = 0; rg < 4; rg++) {
                         int co = co0 + wm * 32 + rg * 8 + lhi * 4;
@@ -994,7 +1062,7 @@ __global__ void __launch_bounds__(512, 2) conv2d_fwd_ws2_kernel(ConvParams p) {
                         if (vecStore) *(u32x2*)(sE + l31 * 80 + (rg * 8 + lhi * 4) * 2) = o;
                         else *(u32x2*)(p.y + pixIdx * p.Cout + co) = o;
                     }
-                    if (vecStore) strip_store32(sE, lane, p.y, p.Cout, co0 + wm * 32);
+                    if (vecStore) strip_store32(sE, lane, p, co0 + wm * 32, msum);
                 }
             }
             have = false;
@@ -1006,6 +1074,7 @@ __global__ void __launch_bounds__(512, 2) conv2d_fwd_ws2_kernel(ConvParams p) {
         }
         __syncthreads();
     }
+    strip_flush_sums(p, lane, co0 + wm * 32, msum);
 }
 
 template <int KS, bool SC, int CINP, int BM>
@@ -1219,7 +1288,7 @@ static int launch_fwd(const ConvParams& p, hipStream_t st) {
     // weight-stationary kernel: Cin <= 32 (two blocks per CU), or Cin <= 64 with Cout <= 32 (32-channel co tile: the
     // generic 64-channel tile would waste half of its MFMAs there); measured per layer in tools/ab_ws.sh
     static const int ws1 = []{ const char* e = getenv("AGF_CONV_WS1"); return e ? atoi(e) : 1; }();
-    if (g_ws_enable && !p.mask_y && ws1 && (ws1 == 2 || p.in_scale) && KS == 1 && MT == 1 && p.pixTiles >= 2048 && p.TW == 32 && p.TH == 8 && p.TI == 1 && p.Cin <= 32 && p.Cout <= 64) {
+    if (g_ws_enable && ws1 && (ws1 == 2 || p.in_scale) && KS == 1 && MT == 1 && p.pixTiles >= 2048 && p.TW == 32 && p.TH == 8 && p.TI == 1 && p.Cin <= 32 && p.Cout <= 64) {
         // 1x1 convs with few channels (FromRGB / ToRGB / the 32 -> 64 skip): pure streaming work.  One 256-pixel tile per block left
         // them at ~2 TB/s (block prologue per 20 KB of traffic); the persistent kernel keeps the weights in LDS and streams tiles.
         int rc;
@@ -1227,7 +1296,7 @@ static int launch_fwd(const ConvParams& p, hipStream_t st) {
         else              rc = p.in_scale ? launch_fwd_ws<1, true, 32, 64>(p, st) : launch_fwd_ws<1, false, 32, 64>(p, st);
         if (rc != AGF_ENOKERNEL) return rc;
     }
-    if (g_ws_enable && !p.mask_y && KS == 3 && MT == 1 && p.pixTiles >= 2048 && p.TW == 32 && p.TH == 8 && p.TI == 1 &&
+    if (g_ws_enable && KS == 3 && MT == 1 && p.pixTiles >= 2048 && p.TW == 32 && p.TH == 8 && p.TI == 1 &&
         (p.Cin <= 32 || (p.Cin <= 64 && p.Cout <= 32) || (g_ws_enable >= 2 && p.Cin <= 64 && p.Cout <= 64))) {
         int rc;
         static const int ws2 = []{ const char* e = getenv("AGF_CONV_WS2"); return e ? atoi(e) : 1; }();
@@ -1261,11 +1330,12 @@ static int conv2d_fwd_impl(const void* x, const void* w, void* y,
                            const float* noise, const void* residual,
                            int dtype, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
                            int act, float alpha, float act_gain,
-                           const void* mask_y, float mask_alpha, float* mask_sum, void* stream) {
+                           const void* mask_y, float mask_alpha, float* mask_sum, const void* res_pooled, float res_scale, void* stream) {
     AGF_CHECK(x && w && y, "conv2d_fwd: null pointer");
     AGF_CHECK(dtype == AGF_BF16 || dtype == AGF_F32, "conv2d_fwd: dtype must be bf16 or f32");
-    if (mask_y && (dtype != AGF_BF16 || (Cout % 8) != 0 || ((uintptr_t)y % 16) != 0 || ((uintptr_t)mask_y % 16) != 0)) {
-        agf_set_error("conv2d_fwd_mask: needs bf16, Cout %% 8 == 0 and 16-byte aligned tensors");
+    if ((mask_y || res_pooled) && (dtype != AGF_BF16 || (Cout % 8) != 0 || ((uintptr_t)y % 16) != 0 || ((uintptr_t)mask_y % 16) != 0 ||
+                                   ((uintptr_t)res_pooled % 16) != 0 || (res_pooled && (act != 1 || (H & 1) || (W & 1))))) {
+        agf_set_error("conv2d_fwd_mask: needs bf16, Cout %% 8 == 0, 16-byte aligned tensors (and a linear epilogue on an even map for res_pooled)");
         return AGF_ENOKERNEL;
     }
     if (dtype == AGF_F32) {
@@ -1296,11 +1366,12 @@ static int conv2d_fwd_impl(const void* x, const void* w, void* y,
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
     p.act = act; p.alpha = alpha; p.gain = act_gain;
     p.mask_y = (const bf16_t*)mask_y; p.mask_alpha = mask_alpha; p.mask_sum = mask_sum;
+    p.res_pooled = (const bf16_t*)res_pooled; p.res_scale = res_scale;
     {
         // 1x1 conv from 8 input channels to <= 32 outputs on a large map: the streaming kernel (see conv2d_pw8_kernel)
         static const bool pw8 = []{ const char* e = getenv("AGF_CONV_PW8"); return !(e && e[0] == '0'); }();
         const bool pow2 = (Cout & (Cout - 1)) == 0;
-        if (pw8 && !mask_y && ksize == 1 && !noise && !residual && Cin == 8 && Cout >= 8 && Cout <= 32 && pow2 && H * W >= 4096 && ((uintptr_t)y % 16) == 0) {
+        if (pw8 && !mask_y && !res_pooled && ksize == 1 && !noise && !residual && Cin == 8 && Cout >= 8 && Cout <= 32 && pow2 && H * W >= 4096 && ((uintptr_t)y % 16) == 0) {
             const int G = Cout / 8;
             const int64_t pixels = (int64_t)N * H * W;
             int64_t blocks = agf_ceil_div(pixels * G, (int64_t)256 * 4);
@@ -1312,7 +1383,7 @@ static int conv2d_fwd_impl(const void* x, const void* w, void* y,
     }
     { static int h = -1; if (h < 0) { const char* e = getenv("AGF_CONV_HOIST"); h = e ? atoi(e) : 1; } p.hoist = h; }
     { static const int vs = []{ const char* e = getenv("AGF_CONV_VSTORE"); return e ? atoi(e) : 1; }();
-      p.vecStore = (vs || mask_y) && (Cout % 8) == 0 && ((uintptr_t)y % 16) == 0; }
+      p.vecStore = (vs || mask_y || res_pooled) && (Cout % 8) == 0 && ((uintptr_t)y % 16) == 0; }
     // Two tilings.  Large: 128 co x 512 px (16x32 pixel tile), 8 waves -- when the map is at least 16x32, there are at
     // least 128 output channels and the grid still fills the chip (>= 384 blocks).  Default: 64 co x 256 px, 4 waves.
     int MT = 1;
@@ -1376,7 +1447,7 @@ extern "C" int agf_conv2d_fwd(const void* x, const void* w, void* y,
                               int dtype, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
                               int act, float alpha, float act_gain, void* stream) {
     return conv2d_fwd_impl(x, w, y, in_scale, out_scale, bias, noise, residual, dtype, N, H, W, Cin, Cout, ksize, act, alpha, act_gain,
-                           nullptr, 0.f, nullptr, stream);
+                           nullptr, 0.f, nullptr, nullptr, 0.f, stream);
 }
 
 extern "C" int agf_conv2d_fwd_mask(const void* x, const void* w, void* y,
@@ -1384,10 +1455,11 @@ extern "C" int agf_conv2d_fwd_mask(const void* x, const void* w, void* y,
                                    const float* noise, const void* residual,
                                    int dtype, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
                                    int act, float alpha, float act_gain,
-                                   const void* mask_y, float mask_alpha, float* mask_sum, void* stream) {
-    AGF_CHECK(mask_y, "conv2d_fwd_mask: null mask tensor");
+                                   const void* mask_y, float mask_alpha, float* mask_sum,
+                                   const void* res_pooled, float res_scale, void* stream) {
+    AGF_CHECK(mask_y || res_pooled, "conv2d_fwd_mask: neither a mask nor a pooled residual");
     return conv2d_fwd_impl(x, w, y, in_scale, out_scale, bias, noise, residual, dtype, N, H, W, Cin, Cout, ksize, act, alpha, act_gain,
-                           mask_y, mask_alpha, mask_sum, stream);
+                           mask_y, mask_alpha, mask_sum, res_pooled, res_scale, stream);
 }
 
 // =================================================================================================

@@ -83,7 +83,8 @@ def prep_weights_raw(w, coef, dtype, want_q=True, want_ft=False):
 
 
 def conv2d_fwd_raw(x, w, in_scale=None, out_scale=None, bias=None, noise=None, residual=None,
-                   act=ACT_LINEAR, alpha=0.2, gain=1.0, prepared=False, mask_y=None, mask_alpha=0.2, mask_sum=None):
+                   act=ACT_LINEAR, alpha=0.2, gain=1.0, prepared=False, mask_y=None, mask_alpha=0.2, mask_sum=None,
+                   res_pooled=None, res_scale=1.0):
     """One ``agf_conv2d_fwd`` launch.  x: [N,Cin,H,W] bf16 channels_last; w: [Cout,Cin,k,k] (any float dtype).
     in_scale [N,Cin], out_scale [N,Cout], bias [Cout], noise [N,1,H,W] are fp32; residual like y.  Returns y bf16 channels_last."""
     _lib.require_gpu(x, 'conv2d')
@@ -101,14 +102,18 @@ def conv2d_fwd_raw(x, w, in_scale=None, out_scale=None, bias=None, noise=None, r
         residual = residual.to(x.dtype).contiguous(memory_format=torch.channels_last)
     timer = KernelTimer.active
     ev0 = timer.start() if timer is not None else None
-    if mask_y is not None:
-        # ``agf_conv2d_fwd_mask``: the result is multiplied by the leaky-ReLU derivative taken from ``mask_y`` (same shape as y) and its
-        # per-channel sum is accumulated into ``mask_sum`` -- the lrelu backward of the layer below, fused into this data-gradient launch
-        assert mask_y.shape == y.shape and mask_y.dtype == x.dtype and mask_y.is_contiguous(memory_format=torch.channels_last)
+    if mask_y is not None or res_pooled is not None:
+        # ``agf_conv2d_fwd_mask``: + res_scale * res_pooled[h/2, w/2] (the gradient of a pooled sibling branch), then multiplied by the
+        # leaky-ReLU derivative taken from ``mask_y`` (same shape as y) with the per-channel sum accumulated into ``mask_sum`` [256, Cout]
+        # -- the add and the lrelu backward of the layer below, fused into this data-gradient launch
+        assert mask_y is None or (mask_y.shape == y.shape and mask_y.dtype == x.dtype and mask_y.is_contiguous(memory_format=torch.channels_last))
+        assert res_pooled is None or (res_pooled.shape == (N, Cout, H // 2, W // 2) and res_pooled.dtype == x.dtype
+                                      and res_pooled.is_contiguous(memory_format=torch.channels_last))
         rc = _lib.lib().agf_conv2d_fwd_mask(_lib.ptr(x), _lib.ptr(wq), _lib.ptr(y), _lib.ptr(in_scale), _lib.ptr(out_scale),
                                             _lib.ptr(bias), _lib.ptr(noise), _lib.ptr(residual), _lib.dtype_code(x),
                                             N, H, W, Cin, Cout, k, act, float(alpha), float(gain),
-                                            _lib.ptr(mask_y), float(mask_alpha), _lib.ptr(mask_sum), _lib.stream_ptr(x))
+                                            _lib.ptr(mask_y), float(mask_alpha), _lib.ptr(mask_sum),
+                                            _lib.ptr(res_pooled), float(res_scale), _lib.stream_ptr(x))
     else:
         rc = _lib.lib().agf_conv2d_fwd(_lib.ptr(x), _lib.ptr(wq), _lib.ptr(y), _lib.ptr(in_scale), _lib.ptr(out_scale),
                                        _lib.ptr(bias), _lib.ptr(noise), _lib.ptr(residual), _lib.dtype_code(x),
@@ -413,6 +418,44 @@ class PremaskLink:
         self.armed, self.alpha, self.premasked, self.bsum, self.pooled = False, 0.2, False, None, None
 
 
+class SkipLink:
+    """Handshake between the first conv of a residual block and the 2x2 average of the block's skip branch, which share their input:
+    the pool's backward leaves the pooled gradient here (and returns no gradient), the conv's data-gradient launch adds it at half
+    resolution (``agf_conv2d_fwd_mask`` res_pooled).  Whichever of the two backward nodes runs second finds the other's mark, so the
+    result does not depend on autograd's execution order: if the conv ran first the pool simply returns its ordinary gradient."""
+    __slots__ = ('armed', 'pooled', 'consumed')
+
+    def __init__(self):
+        self.armed, self.pooled, self.consumed = False, None, False
+
+
+class _PoolSkip(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, f, gain, link):
+        from ...stylegan3_ops import upfirdn2d
+        ctx.save_for_backward(f)
+        ctx.gain, ctx.link, ctx.x_shape = gain, link, x.shape
+        return upfirdn2d.downsample2d(x.detach(), f, down=2, gain=gain)
+
+    @staticmethod
+    def backward(ctx, dy):
+        from ...stylegan3_ops import upfirdn2d
+        f, = ctx.saved_tensors
+        link, gain = ctx.link, ctx.gain
+        _, _, ih, iw = ctx.x_shape
+        if link is not None and link.armed and not link.consumed and _PREMASK and not torch.is_grad_enabled() \
+                and dy.dtype == torch.bfloat16:
+            link.pooled = (dy.contiguous(memory_format=torch.channels_last), float(gain) * 0.25)
+            return None, None, None, None
+        _, _, oh, ow = dy.shape
+        dx = upfirdn2d.upfirdn2d(dy, f, up=2, padding=[1, iw - 2 * ow, 1, ih - 2 * oh], flip_filter=True, gain=gain)
+        return dx, None, None, None
+
+
+def pool2x_skip(x, f, gain, link):
+    return _PoolSkip.apply(x, f, gain, link)
+
+
 class _PoolLinked(torch.autograd.Function):
     """2x2 box average (``downsample2d`` with the [1,1] filter) as the ONLY consumer of a fused conv's lrelu output: instead of writing
     the full-resolution gradient (an upsampling FIR pass) it hands the pooled gradient to the producer's backward through the link, where
@@ -454,14 +497,18 @@ class _FusedConv(torch.autograd.Function):
     act = lrelu (gain must be 1) or linear.  The backward is fused too unless a graph is being recorded."""
 
     @staticmethod
-    def forward(ctx, x, weight, coef, s_in, s_out, bias, noise, residual, act, alpha, gain, pre_link=None, post_link=None):
+    def forward(ctx, x, weight, coef, s_in, s_out, bias, noise, residual, act, alpha, gain, pre_link=None, post_link=None, skip_link=None):
         prep = prepared_weights(weight, coef, x.dtype)
         y = conv2d_fwd_raw(x, prep.wq, in_scale=s_in, out_scale=s_out, bias=bias, noise=noise, residual=residual,
                            act=act, alpha=alpha, gain=gain, prepared=True)
         ctx.save_for_backward(x, weight, s_in, s_out, bias, noise, y if (act == ACT_LRELU or s_out is not None) else None)
         ctx.coef, ctx.act, ctx.alpha, ctx.gain = coef, act, alpha, gain
         ctx.has_residual = residual is not None
-        ctx.pre_link, ctx.post_link = pre_link, None
+        ctx.pre_link, ctx.post_link, ctx.skip_link = pre_link, None, None
+        if skip_link is not None and _PREMASK and s_in is None and x.dtype == torch.bfloat16 and x.shape[1] % 8 == 0 \
+                and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0:
+            skip_link.armed, skip_link.pooled, skip_link.consumed = True, None, False
+            ctx.skip_link = skip_link
         if post_link is not None and _PREMASK and act == ACT_LRELU and gain == 1.0 and s_out is None and noise is None \
                 and x.dtype == torch.bfloat16:
             post_link.armed, post_link.alpha, post_link.premasked, post_link.pooled = True, float(alpha), False, None
@@ -482,6 +529,12 @@ class _FusedConv(torch.autograd.Function):
             dy = dy.to(x.dtype).contiguous(memory_format=torch.channels_last)
         k = weight.shape[2]
         dx = dw = dsi = dso = db = dres = None
+        skip = ctx.skip_link
+        res_pooled, res_scale = (None, 1.0)
+        if skip is not None:
+            if skip.pooled is not None and not torch.is_grad_enabled():
+                res_pooled, res_scale = skip.pooled
+            skip.pooled, skip.consumed = None, True             # a pool backward that runs after this point returns its own gradient
         if torch.is_grad_enabled():
             # a graph is being recorded (R1 differentiates D twice): compose from differentiable ops
             if s_in is not None or s_out is not None or noise is not None:
@@ -501,7 +554,7 @@ class _FusedConv(torch.autograd.Function):
                 dx = _ConvFwd.apply(g, flip_transpose(w), None, None)
             if need_w:
                 dw = (_ConvWgrad.apply(x, g, None, None, k) * coef).to(weight.dtype)
-            return dx, dw, None, None, None, db, None, dres, None, None, None, None, None
+            return dx, dw, None, None, None, db, None, dres, None, None, None, None, None, None
         # the output gain is not applied to the gradient tensor: it rides along in the data-gradient launch's epilogue gain, in the
         # weight-gradient scale and in the bias sum (no pass over the tensor for it)
         pg = float(gain)
@@ -540,21 +593,22 @@ class _FusedConv(torch.autograd.Function):
             if pre is not None and pre.armed and s_in is None and need_x and x.dtype == torch.bfloat16 and x.shape[1] % 8 == 0:
                 # x is the lrelu output of the producer this link came from and we are its only consumer: hand it the masked gradient
                 pre.bsum = torch.zeros(256, x.shape[1], dtype=torch.float32, device=x.device)
-                t = conv2d_fwd_raw(g, prep.wq_ft, in_scale=s_out, prepared=True, gain=pg, mask_y=x, mask_alpha=pre.alpha, mask_sum=pre.bsum)
+                t = conv2d_fwd_raw(g, prep.wq_ft, in_scale=s_out, prepared=True, gain=pg, mask_y=x, mask_alpha=pre.alpha, mask_sum=pre.bsum,
+                                   res_pooled=res_pooled, res_scale=res_scale)
                 pre.premasked = True
             else:
-                t = conv2d_fwd_raw(g, prep.wq_ft, in_scale=s_out, prepared=True, gain=pg)
+                t = conv2d_fwd_raw(g, prep.wq_ft, in_scale=s_out, prepared=True, gain=pg, res_pooled=res_pooled, res_scale=res_scale)
             if s_in is None:
                 dx = t
             else:
                 dx, dsi = scale_dot_raw(x, t, s_in, want_dx=need_x)
         if need_w:
             dw = conv2d_wgrad_raw(x, g, k, in_scale=s_in, out_scale=s_out, scale=coef * pg).to(weight.dtype)
-        return dx, dw, None, dsi, dso, db, None, dres, None, None, None, None, None
+        return dx, dw, None, dsi, dso, db, None, dres, None, None, None, None, None, None
 
 
 def conv2d_act(x, weight, bias=None, s_in=None, s_out=None, noise=None, alpha=0.2, fused=True, coef=1.0,
-               act='lrelu', residual=None, gain=1.0, pre_link=None, post_link=None):
+               act='lrelu', residual=None, gain=1.0, pre_link=None, post_link=None, skip_link=None):
     """act( s_out * conv(x * s_in, weight * coef) + bias + noise + residual ) * gain; act = 'lrelu' | 'linear'.
     bias [Cout], noise [N,1,H,W] (no gradient), residual like the output.
     ``fused=False`` evaluates the same expression with the separately differentiable ops (any-order gradients)."""
@@ -565,8 +619,9 @@ def conv2d_act(x, weight, bias=None, s_in=None, s_out=None, noise=None, alpha=0.
             x = _pad_channels(x, 8, 1).contiguous(memory_format=torch.channels_last)
             weight = _pad_channels(weight, 8, 1)
             s_in = _pad_channels(s_in, 8, 1) if s_in is not None else None
+            pre_link = skip_link = None               # the links describe the UNPADDED input tensor
         return _FusedConv.apply(x, weight, coef, s_in, s_out, bias, noise, residual,
-                                ACT_LRELU if act == 'lrelu' else ACT_LINEAR, alpha, gain, pre_link, post_link)
+                                ACT_LRELU if act == 'lrelu' else ACT_LINEAR, alpha, gain, pre_link, post_link, skip_link)
     out = conv2d(x, weight * coef if coef != 1.0 else weight, s_in, s_out)
     if noise is not None:
         out = out + noise.to(out.dtype)

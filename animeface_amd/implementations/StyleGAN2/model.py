@@ -29,7 +29,7 @@ import torch.nn.functional as F
 
 from ...stylegan3_ops import upfirdn2d, bias_act
 from ... import rng
-from .conv import conv2d, conv2d_act, style_demod, PremaskLink, pool2x_linked
+from .conv import conv2d, conv2d_act, style_demod, PremaskLink, SkipLink, pool2x_linked, pool2x_skip
 
 
 # bias / noise / leaky-ReLU run in the conv kernel's epilogue (with a fused backward).  The fused modulated conv has
@@ -57,7 +57,7 @@ class ELR(nn.Module):
         return F.linear(x * self.coef, self.layer.weight, self.layer.bias)
 
 
-def elr_conv2d(elr, x, act=None, residual=None, gain=1.0, out_gain=1.0, pre_link=None, post_link=None):
+def elr_conv2d(elr, x, act=None, residual=None, gain=1.0, out_gain=1.0, pre_link=None, post_link=None, skip_link=None):
     """``ELR(nn.Conv2d)`` on the MFMA conv; coef is folded into the weights; optional fused-order bias + lrelu.
     ``out_gain`` (linear layers only) scales the conv + bias part of the output by a constant for free: it is folded into the
     weight coefficient and the bias instead of being applied to the output tensor (nothing to undo in backward either)."""
@@ -71,7 +71,7 @@ def elr_conv2d(elr, x, act=None, residual=None, gain=1.0, out_gain=1.0, pre_link
         bias = bias * out_gain if bias is not None else None
     return conv2d_act(x, conv.weight, bias, alpha=0.2, fused=FUSED_EPILOGUE, coef=coef,
                       act='lrelu' if act == 'lrelu' else 'linear', residual=residual, gain=gain,
-                      pre_link=pre_link, post_link=post_link)
+                      pre_link=pre_link, post_link=post_link, skip_link=skip_link)
 
 
 def Linear(name, *args, **kwargs):
@@ -106,7 +106,9 @@ class _AvgPool2x(nn.Module):
         super().__init__()
         self.register_buffer('f', upfirdn2d.setup_filter([1, 1]), persistent=False)
 
-    def forward(self, x, gain=1, link=None):
+    def forward(self, x, gain=1, link=None, skip_link=None):
+        if skip_link is not None:
+            return pool2x_skip(x, self.f, gain, skip_link)    # x is also the input of the block's first conv (SkipLink)
         if link is not None:
             return pool2x_linked(x, self.f, gain, link)       # x is a fused conv's lrelu output and this is its only consumer
         return upfirdn2d.downsample2d(x, self.f, down=2, gain=gain)
@@ -263,23 +265,28 @@ class DBlock(nn.Module):
         self.down = Downsample2x(down_name)
         self.skip = Conv2d('elr', in_channels, out_channels, 1)
 
-    def forward(self, x):
+    def forward(self, x, in_link=None):
+        """``in_link``: PremaskLink armed by the producer of x when x is its lrelu output and this block is its only consumer."""
         t = x
         mods = list(self.block)
         # conv -> lrelu -> conv chains: the next conv is the only consumer of the activation, so its data-gradient launch applies the
         # lrelu gradient of the layer below (PremaskLink / agf_conv2d_fwd_mask) instead of a separate pass over the tensor
-        pre = None
         pooled = isinstance(self.down, _AvgPool2x) and FUSED_EPILOGUE
+        # the block input feeds the first conv AND the pooled skip branch: the skip branch's gradient joins the first conv's
+        # data-gradient launch at half resolution (SkipLink) -- then that launch is the only source of the input's gradient and may
+        # also apply the producer's lrelu gradient (in_link)
+        skip_link = SkipLink() if pooled else None
+        pre = in_link if pooled else None
         for i in range(0, len(mods), 2):
             post = PremaskLink() if (i + 2 < len(mods) or pooled) else None
-            x = elr_conv2d(mods[i], x, act='lrelu', pre_link=pre, post_link=post)
+            x = elr_conv2d(mods[i], x, act='lrelu', pre_link=pre, post_link=post, skip_link=skip_link if i == 0 else None)
             pre = post
         c = float(1 / np.sqrt(2))
         if isinstance(self.down, _AvgPool2x):
             # avg-pool commutes with the 1x1 skip conv: pool first (4x less work), identical result
             # (skip(pool(t)) + pool(x)) / sqrt(2): the residual add runs in the 1x1 conv's epilogue; the 1/sqrt(2) costs nothing:
             # it is folded into the skip conv's weight coefficient / bias and into the gain of the pooling FIR of x
-            return elr_conv2d(self.skip, self.down(t), residual=self.down(x, gain=c, link=pre), out_gain=c)
+            return elr_conv2d(self.skip, self.down(t, skip_link=skip_link), residual=self.down(x, gain=c, link=pre), out_gain=c)
         t = self.skip(t)
         return (self.down(x) + self.down(t)) / np.sqrt(2)
 
@@ -446,11 +453,18 @@ class Discriminator(nn.Module):
 
     def forward(self, x):
         x = x.to(self.compute_dtype)
-        x = elr_conv2d(self.from_rgb[0], x, act='lrelu')
         mods = list(self.blocks)
+        # from_rgb -> first DBlock: with the block's skip-branch gradient folded into its first conv's data-gradient launch that launch
+        # is the only source of from_rgb's output gradient, so it can apply from_rgb's lrelu gradient too
+        rgb_link = PremaskLink() if (FUSED_EPILOGUE and mods and isinstance(mods[0], DBlock) and isinstance(mods[0].down, _AvgPool2x)) else None
+        x = elr_conv2d(self.from_rgb[0], x, act='lrelu', post_link=rgb_link)
         i = 0
         while i < len(mods):
             m = mods[i]
+            if i == 0 and rgb_link is not None:
+                x = m(x, in_link=rgb_link)
+                i += 1
+                continue
             if isinstance(m, ELR) and isinstance(m.layer, nn.Conv2d) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.LeakyReLU):
                 x = elr_conv2d(m, x, act='lrelu')
                 i += 2

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define AGF_ABI_VERSION 5
+#define AGF_ABI_VERSION 6
 
 /* element types of activation tensors */
 enum { AGF_F32 = 0, AGF_F16 = 1, AGF_BF16 = 2, AGF_F64 = 3 };
@@ -138,19 +138,25 @@ int agf_conv2d_fwd(const void* x, const void* w, void* y,
                    int dtype, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
                    int act, float alpha, float act_gain, void* stream);
 
-/* agf_conv2d_fwd followed, in the same epilogue, by the leaky-ReLU gradient of the layer BELOW -- for data-gradient launches whose
- * result is the gradient w.r.t. that layer's activated output (nn.Conv2d -> nn.LeakyReLU -> nn.Conv2d chains of DBlock,
- * implementations/StyleGAN2/model.py:192-202; autograd runs LeakyReluBackward as a separate pass there):
- *   y = epilogue(...) * (mask_y > 0 ? 1 : mask_alpha),   mask_y [N,H,W,Cout] = the layer-below's lrelu OUTPUT (this conv's forward input)
- *   mask_sum [256][Cout] fp32, nullable, accumulated: sum over its 256 rows = sum_{n,h,w} y[n,h,w,co], the layer-below's bias gradient
+/* agf_conv2d_fwd (linear epilogue) for data-gradient launches, with up to two more autograd nodes folded into the same epilogue:
+ *   t = epilogue(...)                                        as agf_conv2d_fwd
+ *   t += res_scale * res_pooled[n, h/2, w/2, co]             res_pooled [N,H/2,W/2,Cout], nullable: the gradient that reaches this conv's
+ *                                                            input through the OTHER branch of a residual block, AvgPool2d(2) -> 1x1 skip conv
+ *                                                            (implementations/StyleGAN2/model.py:204-212; res_scale = pool gain / 4) -- autograd
+ *                                                            writes that branch's gradient at full resolution and adds the two tensors
+ *   y = t * (mask_y > 0 ? 1 : mask_alpha)                    mask_y [N,H,W,Cout], nullable: the lrelu OUTPUT of the layer below (this conv's
+ *                                                            forward input) -- autograd's separate LeakyReluBackward pass
+ *   mask_sum [256][Cout] fp32, nullable, accumulated: the sum of its 256 rows = sum_{n,h,w} y, the layer-below's bias gradient
  *                (256 slots keep the per-block atomics from piling onto Cout addresses)
- * bf16, Cout % 8 == 0, 16-byte aligned tensors; AGF_ENOKERNEL otherwise (callers then run agf_conv2d_fwd + agf_act_bwd_reduce). */
+ * bf16, Cout % 8 == 0, 16-byte aligned tensors, H and W even for res_pooled; AGF_ENOKERNEL otherwise (callers then compose
+ * agf_conv2d_fwd + agf_upfirdn2d + add + agf_act_bwd_reduce). */
 int agf_conv2d_fwd_mask(const void* x, const void* w, void* y,
                         const float* in_scale, const float* out_scale, const float* bias,
                         const float* noise, const void* residual,
                         int dtype, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
                         int act, float alpha, float act_gain,
-                        const void* mask_y, float mask_alpha, float* mask_sum, void* stream);
+                        const void* mask_y, float mask_alpha, float* mask_sum,
+                        const void* res_pooled, float res_scale, void* stream);
 
 /* weight gradient of the same contraction:
  *   dw[co,kh,kw,ci] += scale * sum_{n,h,w} dy[n,h,w,co] * out_scale[n,co] * x[n,h+kh-p,w+kw-p,ci] * in_scale[n,ci]

@@ -214,21 +214,35 @@ def test_style_demod_vs_composite(shape):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('shape', [(4, 64, 64, 64, 64, None), (3, 128, 136, 32, 64, '2'), (16, 64, 64, 128, 128, None), (5, 512, 512, 8, 8, None),
-                                   (2, 72, 40, 19, 38, None)])
-def test_conv_fwd_mask_vs_composite(shape, monkeypatch):
-    """agf_conv2d_fwd_mask: conv, then the lrelu gradient of the layer below (mask from its activation output) and the channel sums."""
+                                   (2, 72, 40, 19, 38, None), (8, 64, 32, 256, 256, None), (8, 32, 32, 256, 256, None), (8, 32, 64, 256, 256, None)])
+@pytest.mark.parametrize('mode', ['mask', 'pooled', 'both'])
+def test_conv_fwd_mask_vs_composite(shape, mode, monkeypatch):
+    """agf_conv2d_fwd_mask: conv, + the pooled sibling-branch gradient read at half resolution, then the lrelu gradient of the layer below
+    (mask from its activation output) and the channel sums -- on every kernel family (generic, direct-to-LDS, weight-stationary, ping-pong)."""
     from animeface_amd.implementations.StyleGAN2.conv import conv2d_fwd_raw
     N, Cin, Cout, H, W, forced = shape
+    if mode != 'mask' and (H % 2 or W % 2):
+        pytest.skip('pooled residual needs an even map')
     if forced:
         monkeypatch.setenv('AGF_CONV_MT', forced)
     x, w, g = make(N, Cin, Cout, H, W, 3, seed=5)
     a = torch.randn(N, Cout, H, W, generator=g).to(torch.bfloat16).to(DEV).contiguous(memory_format=torch.channels_last)
+    r = torch.randn(N, Cout, H // 2, W // 2, generator=g).to(torch.bfloat16).to(DEV).contiguous(memory_format=torch.channels_last)
     msum = torch.zeros(256, Cout, device=DEV)
-    y = conv2d_fwd_raw(x, w, gain=0.9, mask_y=a, mask_alpha=0.2, mask_sum=msum)
-    ref = F.conv2d(x.float(), w.float(), padding=1) * 0.9
-    ref = ref.to(torch.bfloat16).float() * torch.where(a.float() > 0, 1.0, 0.2)
+    kw = {}
+    if mode != 'pooled':
+        kw.update(mask_y=a, mask_alpha=0.2, mask_sum=msum)
+    if mode != 'mask':
+        kw.update(res_pooled=r, res_scale=0.3)
+    y = conv2d_fwd_raw(x, w, gain=0.9, **kw)
+    ref = (F.conv2d(x.float(), w.float(), padding=1) * 0.9).to(torch.bfloat16).float()
+    if mode != 'mask':
+        ref = ref + r.float().repeat_interleave(2, 2).repeat_interleave(2, 3) * 0.3
+    if mode != 'pooled':
+        ref = ref * torch.where(a.float() > 0, 1.0, 0.2)
     assert rel(y, ref) < 8e-3
-    assert rel(msum.sum(0), ref.sum((0, 2, 3))) < 5e-3
+    if mode != 'pooled':
+        assert rel(msum.sum(0), ref.sum((0, 2, 3))) < 5e-3
 
 
 @pytest.mark.gpu
