@@ -119,7 +119,8 @@ def conv2d_fwd_raw(x, w, in_scale=None, out_scale=None, bias=None, noise=None, r
                                        _lib.ptr(bias), _lib.ptr(noise), _lib.ptr(residual), _lib.dtype_code(x),
                                        N, H, W, Cin, Cout, k, act, float(alpha), float(gain), _lib.stream_ptr(x))
     if timer is not None:
-        timer.stop('conv2d_fwd_kernel', ev0, 2.0 * N * H * W * Cin * Cout * k * k, (N, Cin, Cout, H, W, k, in_scale is not None))
+        timer.stop('conv2d_fwd_kernel', ev0, 2.0 * N * H * W * Cin * Cout * k * k,
+                   (N, Cin, Cout, H, W, k, in_scale is not None, mask_y is not None or res_pooled is not None))
     _lib.check(rc, 'conv2d_fwd')
     return y
 

@@ -176,6 +176,17 @@ def main():
                 alg.setdefault(name, [0, 0])
                 alg[name][0] += len(recs) * (n * h * w * (cin + cout) * 2 + cout * cin * ks * ks * 2)
                 alg[name][1] += len(recs)
+            # conv launches WITHOUT a fused gradient epilogue (agf_conv2d_fwd_mask folds the lrelu-gradient pass, the skip-branch add and
+            # the pooling adjoint of the layer below into the data-gradient launch: those launches do more than their conv flops)
+            plain_ms = plain_fl = fused_n = 0
+            for key, recs in timer.by_shape.items():
+                if key[0] != 'conv2d_fwd_kernel':
+                    continue
+                if len(key) > 8 and key[8]:
+                    fused_n += len(recs)
+                    continue
+                plain_ms += sum(a.elapsed_time(b) for a, b, _ in recs)
+                plain_fl += sum(f for _, _, f in recs)
             if k:
                 out['roofline'] = {'kernel': 'conv2d_fwd* (MFMA implicit-GEMM 3x3/1x1 conv, every instantiation: generic, 8-wave, weight-stationary, ping-pong; forward + data-gradient launches)',
                                    'bound': 'mfma', 'achieved': round(k['tflops'], 2), 'peak': MFMA_BF16_PEAK / 1e12,
@@ -186,7 +197,9 @@ def main():
                                    'algorithmic_bytes_per_launch': round(alg['conv2d_fwd_kernel'][0] / max(alg['conv2d_fwd_kernel'][1], 1))
                                    if 'conv2d_fwd_kernel' in alg else None,
                                    'launches': k['launches'], 'avg_launch_ms': round(k['avg_ms'], 4),
-                                   'share_of_step_time': round(k['total_ms'] / (dt * 1e3), 4)}
+                                   'share_of_step_time': round(k['total_ms'] / (dt * 1e3), 4),
+                                   'launches_with_fused_gradient_epilogue': fused_n,
+                                   'achieved_plain_launches': round(plain_fl / (plain_ms * 1e-3) / 1e12, 2) if plain_ms > 0 else None}
             kw = summ.get('conv2d_wgrad_kernel')
             if kw:
                 out['roofline_wgrad'] = {'kernel': 'conv2d_wgrad_kernel', 'bound': 'mfma', 'achieved': round(kw['tflops'], 2),
