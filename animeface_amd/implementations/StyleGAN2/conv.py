@@ -322,6 +322,13 @@ class cached_weights:
             _prep_cache.clear()
 
 
+def invalidate_cached(params):
+    """Drop the cached preparations of ``params`` (they were just updated by an optimizer step inside a ``cached_weights()`` scope)."""
+    ids = {id(p) for p in params}
+    for key in [k for k in _prep_cache if k[0] in ids]:
+        del _prep_cache[key]
+
+
 def prepared_weights(weight, coef, dtype, need_ft=False):
     import weakref
     cacheable = _prep_cache_on and isinstance(weight, torch.nn.Parameter)

@@ -22,7 +22,7 @@ from ...thirdparty.diffaugment import DiffAugment
 from ... import distributed as dp
 from ... import rng
 from .model import Generator, Discriminator, init_weight_N01
-from .conv import cached_weights
+from .conv import cached_weights, invalidate_cached
 
 
 def pl_penalty(styles, images, pl_mean, scaler=None):
@@ -95,20 +95,22 @@ class TrainStep:
         self._zero(self.optimizer_G, self.reducer_G)
         self._zero(self.optimizer_D, self.reducer_D)
 
-        # ---- discriminator (reference utils.py:60-86) ----
+        # one cache scope for the whole iteration: the generator's prepared weights (bf16 OHWI copies, sum of squares) made for the
+        # D-step's no-grad forward are still valid in the G-step; the discriminator's are dropped when its optimizer steps
         with cached_weights():
+            # ---- discriminator (reference utils.py:60-86) ----
             D_loss = self._d_half(real, it)
-        if self.reducer_D is not None:
-            self.reducer_D.finish()
-        self.optimizer_D.step()
+            if self.reducer_D is not None:
+                self.reducer_D.finish()
+            self.optimizer_D.step()
+            invalidate_cached(D.parameters())
 
-        # ---- generator (reference utils.py:88-113) ----
-        for p in D.parameters():
-            p.requires_grad_(False)
-        with cached_weights():
+            # ---- generator (reference utils.py:88-113) ----
+            for p in D.parameters():
+                p.requires_grad_(False)
             G_loss, fake = self._g_half(real, it)
-        for p in D.parameters():
-            p.requires_grad_(True)
+            for p in D.parameters():
+                p.requires_grad_(True)
         if self.reducer_G is not None:
             self.reducer_G.finish()
         self.optimizer_G.step()
