@@ -581,6 +581,61 @@ __global__ void __launch_bounds__(256) upfirdn2d_fold_border(UpfirdnParams p, in
     }
 }
 
+// channels-last variant: one lane = one 16-byte channel vector of one border pixel, so the (generic, division-heavy) walk over the
+// virtual rows / columns is done once per 8 channels instead of once per element (bf16 128x128x64 maps: 27 -> ~5 us)
+template <class T, int VEC>
+__global__ void __launch_bounds__(256) upfirdn2d_fold_border_cl(UpfirdnParams p, int rx, int ry) {
+    __shared__ float sf[MAX_FILTER_TAPS];
+    stage_filter<256>(p, sf);
+    __syncthreads();
+    const int per = 2 * p.OW + 2 * (p.OH > 2 ? p.OH - 2 : 0);
+    const int CG = p.C / VEC;
+    const int64_t total = (int64_t)p.N * per * CG;
+    for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+        const int cg = (int)(id % CG);
+        const int64_t r = id / CG;
+        const int b = (int)(r % per), n = (int)(r / per);
+        int oy, ox;
+        if (b < p.OW) { oy = 0; ox = b; }
+        else if (b < 2 * p.OW) { oy = p.OH - 1; ox = b - p.OW; }
+        else { int t = b - 2 * p.OW; oy = 1 + (t >> 1); ox = (t & 1) ? p.OW - 1 : 0; }
+        if (p.OH == 1 && b >= p.OW) continue;
+        const T* xb = (const T*)p.x + n * p.xs[0] + cg * VEC;
+        float v[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; e++) v[e] = 0.f;
+        const int y0 = (oy == 0) ? -ry : oy, y1 = (oy == p.OH - 1) ? p.OH - 1 + ry : oy;
+        const int x0 = (ox == 0) ? -rx : ox, x1 = (ox == p.OW - 1) ? p.OW - 1 + rx : ox;
+        for (int vy = y0; vy <= y1; vy++) {
+            if (vy >= 0 && vy <= p.OH - 1 && vy != oy) continue;
+            for (int vx = x0; vx <= x1; vx++) {
+                if (vx >= 0 && vx <= p.OW - 1 && vx != ox) continue;
+                if (vy == oy && vx == ox) continue;
+                int midy = vy * p.downy + p.upy - 1 - p.pady0, midx = vx * p.downx + p.upx - 1 - p.padx0;
+                int iny0 = agf_floor_div(midy, p.upy), inx0 = agf_floor_div(midx, p.upx);
+                int ky0 = (iny0 + 1) * p.upy - midy - 1, kx0 = (inx0 + 1) * p.upx - midx - 1;
+                for (int ky = ky0, iy = iny0; ky < p.fh; ky += p.upy, iy++) {
+                    if (iy < 0 || iy >= p.H) continue;
+                    for (int kx = kx0, ix = inx0; kx < p.fw; kx += p.upx, ix++) {
+                        if (ix < 0 || ix >= p.W) continue;
+                        float xv[VEC];
+                        VecIO<T, VEC>::load(xb + iy * p.xs[2] + ix * p.xs[3], xv);
+                        const float fv = sf[ky * p.fw + kx];
+#pragma unroll
+                        for (int e = 0; e < VEC; e++) v[e] += xv[e] * fv;
+                    }
+                }
+            }
+        }
+        T* yp = (T*)p.y + n * p.ys[0] + oy * p.ys[2] + ox * p.ys[3] + cg * VEC;
+        float yv[VEC];
+        VecIO<T, VEC>::load(yp, yv);
+#pragma unroll
+        for (int e = 0; e < VEC; e++) yv[e] += v[e] * p.gain;
+        VecIO<T, VEC>::store(yp, yv);
+    }
+}
+
 extern "C" int agf_upfirdn2d(const void* x, const float* f, void* y, int dtype,
                              const int32_t in_size[4], const int64_t in_stride[4],
                              const int32_t f_size[2], const int64_t f_stride[2],
@@ -658,6 +713,15 @@ extern "C" int agf_upfirdn2d_fold_border(const void* x, const float* f, void* y,
     int64_t blocks = agf_ceil_div(total, 256);
     if (blocks > 65536) blocks = 65536;
     hipStream_t st = (hipStream_t)stream;
+    if (dtype == AGF_BF16 && p.xs[1] == 1 && p.ys[1] == 1 && p.C % 8 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 &&
+        p.xs[0] % 8 == 0 && p.xs[2] % 8 == 0 && p.xs[3] % 8 == 0 && p.ys[0] % 8 == 0 && p.ys[2] % 8 == 0 && p.ys[3] % 8 == 0) {
+        int64_t nb = agf_ceil_div(total / 8, 256);
+        if (nb < 1) nb = 1;
+        if (nb > 65536) nb = 65536;
+        hipLaunchKernelGGL((upfirdn2d_fold_border_cl<bf16_t, 8>), dim3((unsigned)nb), dim3(256), 0, st, p, rx, ry);
+        AGF_LAUNCH_CHECK();
+        return AGF_OK;
+    }
     switch (dtype) {
         case AGF_F32:  hipLaunchKernelGGL((upfirdn2d_fold_border<float>), dim3((unsigned)blocks), dim3(256), 0, st, p, rx, ry); break;
         case AGF_F16:  hipLaunchKernelGGL((upfirdn2d_fold_border<f16_t>), dim3((unsigned)blocks), dim3(256), 0, st, p, rx, ry); break;
