@@ -434,8 +434,8 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_dl_kernel(ConvPa
     constexpr int WTOT = TAPS * BM * 2;                               // 16-byte vectors of one weight chunk
     constexpr int WV = (WTOT + NTHR - 1) / NTHR;
     constexpr int XV = (PMAX * 2 + NTHR - 1) / NTHR;
-    constexpr int WBUF = WV * NTHR * 8;                               // elements per weight buffer (whole wave-loads)
-    constexpr int XBUF = XV * NTHR * 8;
+    constexpr int WBUF = WTOT * 8;                                    // elements per weight buffer (lanes beyond it issue no load)
+    constexpr int XBUF = PMAX * 2 * 8;                                // 76 KB for both sets of the 4-wave tiling: two blocks per CU
     constexpr int OOB = 0x70000000;                                   // byte offset beyond any buffer: the load returns zeros
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* sW = (bf16_t*)smem_raw;                                  // [2][WBUF]
@@ -517,13 +517,15 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_dl_kernel(ConvPa
         for (int i = 0; i < WV; i++) {
             int off = woff[i] + c0 * 2;
             if (tail && half) off = OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wRes, (lds_ptr)(sW + buf * WBUF + (i * NTHR + wave * 64) * 8), 16, off, 0, 0, 0);
+            if ((i + 1) * NTHR <= WTOT || tid + i * NTHR < WTOT)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wRes, (lds_ptr)(sW + buf * WBUF + (i * NTHR + wave * 64) * 8), 16, off, 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < XV; i++) {
             int off = xoff[i] + c0 * 2;
             if (tail && half) off = OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xRes, (lds_ptr)(sX + buf * XBUF + (i * NTHR + wave * 64) * 8), 16, off, 0, 0, 0);
+            if ((i + 1) * NTHR <= PMAX * 2 || tid + i * NTHR < PMAX * 2)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xRes, (lds_ptr)(sX + buf * XBUF + (i * NTHR + wave * 64) * 8), 16, off, 0, 0, 0);
         }
     };
 
@@ -568,13 +570,13 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_dl_kernel(ConvPa
 template <int KS, int MT, int NWN, int PMAX, int NWM, int NJ>
 static int launch_fwd_dl(const ConvParams& p0, hipStream_t st) {
     constexpr int TAPS = KS * KS, HALO = KS / 2, BM = 32 * NWM * MT, NTHR = 64 * NWM * NWN;
-    constexpr int WV = (TAPS * BM * 2 + NTHR - 1) / NTHR, XV = (PMAX * 2 + NTHR - 1) / NTHR;
     ConvParams p = p0;
     p.tilesCo = (p.Cout + BM - 1) / BM;
     const int P = p.TI * (p.TH + 2 * HALO) * (p.TW + 2 * HALO);
     if (P > PMAX || p.flat || p.in_scale) return AGF_ENOKERNEL;
     if ((int64_t)p.Cout * TAPS * p.Cin * 2 >= 0x60000000ll || (int64_t)p.TI * p.H * p.W * p.Cin * 2 >= 0x60000000ll) return AGF_ENOKERNEL;
-    size_t lds = (size_t)2 * (WV + XV) * NTHR * 16;
+    size_t lds = (size_t)2 * (TAPS * BM * 2 + PMAX * 2) * 16;
+    if (lds < (size_t)(NTHR / 64) * 32 * (64 * MT + 16) + 4096) lds = (size_t)(NTHR / 64) * 32 * (64 * MT + 16) + 4096;     // the epilogue strips
     if (lds > 160 * 1024) return AGF_ENOKERNEL;
     const int slots = ((p.pixTiles + 7) / 8) * p.tilesCo;
     hipError_t e = hipFuncSetAttribute((const void*)conv2d_fwd_dl_kernel<KS, MT, NWN, PMAX, NWM, NJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
