@@ -1317,6 +1317,8 @@ static int launch_fwd(const ConvParams& p, hipStream_t st) {
     static const int w64b = []{ const char* e = getenv("AGF_CONV_W64B"); return e ? atoi(e) : 0; }();
     if (w64b && KS == 3 && MT == 1 && !p.flat && p.TI == 1 && p.TW == 32 && p.TH == 8 && p.Cout > 32 && p.Cout <= 64 && p.Cin >= 32)
         return p.in_scale ? launch_fwd_v<KS, 2, true, 16, 4, 340, 1, 2, 3>(p, st) : launch_fwd_v<KS, 2, false, 16, 4, 340, 1, 2, 3>(p, st);
+    if (KS == 3 && MT == 1 && !p.flat && p.TI * p.TH * p.TW == 64)
+        return p.in_scale ? launch_fwd_v<KS, 1, true, 32, 2, 160, 2, 1>(p, st) : launch_fwd_v<KS, 1, false, 32, 2, 160, 2, 1>(p, st);
     static const int dl = []{ const char* e = getenv("AGF_CONV_DL"); return e ? atoi(e) : 1; }();
     if (dl && KS == 3 && MT == 2 && !p.in_scale && !p.flat) {
         const int rc = p.Cout <= 64 ? launch_fwd_dl<KS, 2, 4, 612, 1, 4>(p, st) : launch_fwd_dl<KS, 2, 4, 612, 2, 4>(p, st);
@@ -1401,6 +1403,13 @@ static int conv2d_fwd_impl(const void* x, const void* w, void* y,
         if (MT == 2 && !(W >= 32 && H >= 16)) MT = 1;
     }
     int blockPix = MT == 2 ? 512 : BLOCK_PIX;
+    // 4x4 / 8x8 maps: 64-pixel tiles (4 waves of 32 co x 32 px).  With 256-pixel tiles such a layer is 32-128 blocks, each a serial
+    // chain of Cin/32 chunks with nothing to overlap its load latency (512 -> 512 @4x4, B=64: 130 us for 2.4 GFLOP); 4x more, 4x
+    // shorter blocks fill the chip.
+    static const bool small_on = []{ const char* e = getenv("AGF_CONV_SMALL"); return !(e && e[0] == '0'); }();
+    const bool smallTile = small_on && MT == 1 && ksize == 3 && H * W <= 64 && H >= 4 && W >= 4 && (int64_t)N * H * W >= 256 &&
+                           (int64_t)N * H * W <= (in_scale ? 8192 : 4096);      // measured: beyond that the 256-pixel tiles fill the chip
+    if (smallTile) blockPix = 64;
     p.TW = pow2_ceil(W) < 32 ? pow2_ceil(W) : 32;
     int th = pow2_ceil(H);
     p.TH = th < blockPix / p.TW ? th : blockPix / p.TW;

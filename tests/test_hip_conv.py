@@ -45,6 +45,9 @@ FWD_CASES = [
     (8, 32, 12, 256, 256, 3, None, 'weight-stationary, direct stores'),
     (8, 32, 8, 256, 256, 1, None, '1x1 weight-stationary (ToImage at 256x256)'),
     (8, 32, 64, 256, 256, 1, None, '1x1 weight-stationary 32->64'),
+    (64, 512, 64, 4, 4, 3, None, '64-pixel tiles (4x4 maps, 4 images per tile)'),
+    (9, 72, 40, 8, 8, 3, None, '64-pixel tiles (8x8 maps), channel tails, odd batch'),
+    (40, 64, 64, 5, 7, 3, None, '64-pixel tiles, ragged 5x7 map'),
     (4, 72, 136, 32, 64, 3, '2', 'direct-to-LDS 8-wave, Cin % 16 == 8, partial co tile'),
     (3, 40, 56, 48, 40, 3, '2', 'direct-to-LDS 4-wave 64 co, ragged map, channel tails'),
 ]
