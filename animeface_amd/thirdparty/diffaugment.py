@@ -4,12 +4,81 @@ policies ``color``, ``translation``, ``cutout``; random draws are made in the re
 
 The translation is a zero-padded integer shift per sample; it is evaluated as one gather along each
 axis on the NCHW tensor instead of the reference's NHWC permute + advanced-index + permute round trip."""
+import os
+
 import torch
 
 from .. import rng
 
 
+_FUSED = os.environ.get('AGF_DIFFAUG_FUSED', '1') != '0'          # A/B switch
+_FUSED_POLICIES = ('color', 'translation', 'color,translation')
+
+
+class _ColorTranslate(torch.autograd.Function):
+    """brightness -> saturation -> contrast -> translation with the draws already made (``prm`` [B,3] = bo, ks, kc; ``shift`` [B,2]
+    int32 or None): one reduction + one apply launch each way (agf_diffaug_sum / agf_diffaug_apply).  First-order only."""
+
+    @staticmethod
+    def forward(ctx, x, prm, shift):
+        from .. import _lib
+        x = x.contiguous()
+        B, C, H, W = x.shape
+        sums = torch.zeros(B, dtype=torch.float32, device=x.device)
+        rc = _lib.lib().agf_diffaug_sum(_lib.ptr(x), _lib.ptr(sums), _lib.ptr(None), _lib.dtype_code(x), B, C, H, W, _lib.stream_ptr(x))
+        _lib.check(rc, 'diffaug_sum')
+        full = torch.cat([prm, (sums / (C * H * W) + prm[:, 0]).unsqueeze(1)], 1).contiguous()
+        y = torch.empty_like(x)
+        rc = _lib.lib().agf_diffaug_apply(_lib.ptr(x), _lib.ptr(y), _lib.ptr(full), _lib.ptr(shift), _lib.dtype_code(x), B, C, H, W, 0,
+                                          _lib.stream_ptr(x))
+        _lib.check(rc, 'diffaug_apply')
+        ctx.save_for_backward(prm, shift)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .. import _lib
+        prm, shift = ctx.saved_tensors
+        if torch.is_grad_enabled() and dy.requires_grad:
+            raise RuntimeError('the fused DiffAugment has no double backward (set AGF_DIFFAUG_FUSED=0)')
+        dy = dy.contiguous()
+        B, C, H, W = dy.shape
+        win = None
+        if shift is not None:
+            tx, ty = shift[:, 0], shift[:, 1]
+            win = torch.stack([(-tx).clamp(min=0), (H - tx).clamp(max=H), (-ty).clamp(min=0), (W - ty).clamp(max=W)], 1).to(torch.int32).contiguous()
+        sums = torch.zeros(B, dtype=torch.float32, device=dy.device)
+        rc = _lib.lib().agf_diffaug_sum(_lib.ptr(dy), _lib.ptr(sums), _lib.ptr(win), _lib.dtype_code(dy), B, C, H, W, _lib.stream_ptr(dy))
+        _lib.check(rc, 'diffaug_sum')
+        full = torch.cat([prm, (sums / (C * H * W)).unsqueeze(1)], 1).contiguous()
+        dx = torch.empty_like(dy)
+        rc = _lib.lib().agf_diffaug_apply(_lib.ptr(dy), _lib.ptr(dx), _lib.ptr(full), _lib.ptr(shift), _lib.dtype_code(dy), B, C, H, W, 1,
+                                          _lib.stream_ptr(dy))
+        _lib.check(rc, 'diffaug_apply')
+        return dx, None, None
+
+
+def _fused(x, policy):
+    """The random draws of the composite path, in its order and with its shapes / dtypes, then the fused op."""
+    B, C, H, W = x.shape
+    one = lambda: rng.rand((B, 1, 1, 1), dtype=x.dtype, device=x.device).reshape(B).float()
+    if 'color' in policy:
+        prm = torch.stack([one() - 0.5, one() * 2, one() + 0.5], 1)
+    else:
+        prm = torch.tensor([0.0, 1.0, 1.0], device=x.device).repeat(B, 1)
+    shift = None
+    if 'translation' in policy:
+        sx, sy = int(H * 0.125 + 0.5), int(W * 0.125 + 0.5)
+        tx = rng.randint(-sx, sx + 1, size=[B, 1, 1], device=x.device)
+        ty = rng.randint(-sy, sy + 1, size=[B, 1, 1], device=x.device)
+        shift = torch.stack([tx.reshape(B), ty.reshape(B)], 1).to(torch.int32).contiguous()
+    return _ColorTranslate.apply(x, prm.contiguous(), shift)
+
+
 def DiffAugment(x, policy='', channels_first=True):
+    if policy in _FUSED_POLICIES and _FUSED and channels_first and x.is_cuda and x.dim() == 4 and x.shape[1] <= 8 \
+            and x.dtype in (torch.float32, torch.bfloat16):
+        return _fused(x, policy)
     if policy:
         if not channels_first:
             x = x.permute(0, 3, 1, 2)

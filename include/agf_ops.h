@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define AGF_ABI_VERSION 6
+#define AGF_ABI_VERSION 7
 
 /* element types of activation tensors */
 enum { AGF_F32 = 0, AGF_F16 = 1, AGF_BF16 = 2, AGF_F64 = 3 };
@@ -220,6 +220,18 @@ int agf_style_demod_fwd(const float* s_raw, const float* wsq_t, float* s, float*
                         int32_t B, int32_t Cin, int32_t Cout, float c2, float eps, void* stream);
 int agf_style_demod_bwd(const float* s, const float* d, const float* dd, const float* ds, const float* wsq, const float* w,
                         float* ds_raw, float* dw, int32_t B, int32_t Cin, int32_t Cout, int32_t taps, float c2, void* stream);
+
+/* DiffAugment 'color' + 'translation' (thirdparty/diffaugment/DiffAugment.py:10-53: rand_brightness, rand_saturation, rand_contrast,
+ * rand_translation -- ~20 elementwise / gather torch launches per call) as one reduction and one apply pass.  NCHW, fp32 or bf16.
+ *   agf_diffaug_sum:   out[b] += sum over c and rows [win[b][0], win[b][1]) x cols [win[b][2], win[b][3]) of x   (win null = whole image)
+ *   agf_diffaug_apply: prm [B][4] fp32, shift [B][2] int32 (nullable = no translation), C <= 8
+ *     forward  (backward = 0), prm = {bo, ks, kc, M}, M = mean_chw(x[b]) + bo:
+ *        y[b,c,i,j] = (i+tx, j+ty) inside ? ((( x + bo - m ) ks + m) - M) kc + M : 0,   m = mean_c(x[b,:,i+tx,j+ty]) + bo
+ *     backward (backward = 1), prm = {-, ks, kc, Dm}, x = dy, Dm = mean_chw(d3[b]), d3 = dy shifted back (zero outside):
+ *        y[b,c,i,j] = ks u_c + (1 - ks) mean_c u,   u_c = kc d3_c + (1 - kc) Dm */
+int agf_diffaug_sum(const void* x, float* out, const int32_t* win, int dtype, int32_t B, int32_t C, int32_t H, int32_t W, void* stream);
+int agf_diffaug_apply(const void* x, void* y, const float* prm, const int32_t* shift, int dtype,
+                      int32_t B, int32_t C, int32_t H, int32_t W, int backward, void* stream);
 
 #ifdef __cplusplus
 }
