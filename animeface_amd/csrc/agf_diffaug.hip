@@ -109,3 +109,37 @@ extern "C" int agf_diffaug_apply(const void* x, void* y, const float* prm, const
     AGF_LAUNCH_CHECK();
     return AGF_OK;
 }
+
+// ADA colour transforms (thirdparty/ada/augment.py: `images = C[:, :3, :3] @ images + C[:, :3, 3:]`): a per-sample 3x4 affine map of the
+// RGB planes.  As a batched [3x3] x [3 x HW] GEMM it ran 0.53 ms per call in a library kernel tuned for anything but M = 3; it is
+// one streaming pass.  transpose = 1 applies the 3x3 part transposed without the offset (the input gradient).
+template <class T>
+__global__ void __launch_bounds__(256) color_affine_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ m,
+                                                           int64_t plane, int transpose) {
+    const int b = blockIdx.y;
+    float a[3][4];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) a[r][c] = transpose ? (c < 3 ? m[b * 12 + c * 4 + r] : 0.f) : m[b * 12 + r * 4 + c];
+    const T* xb = x + (int64_t)b * 3 * plane;
+    T* yb = y + (int64_t)b * 3 * plane;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < plane; i += (int64_t)gridDim.x * 256) {
+        const float v0 = Elem<T>::load(xb + i), v1 = Elem<T>::load(xb + plane + i), v2 = Elem<T>::load(xb + 2 * plane + i);
+#pragma unroll
+        for (int r = 0; r < 3; r++) Elem<T>::store(yb + r * plane + i, a[r][0] * v0 + a[r][1] * v1 + a[r][2] * v2 + a[r][3]);
+    }
+}
+
+extern "C" int agf_color_affine(const void* x, void* y, const float* m, int dtype, int32_t B, int64_t plane, int transpose, void* stream) {
+    AGF_CHECK(x && y && m, "color_affine: null pointer");
+    AGF_CHECK(dtype == AGF_F32 || dtype == AGF_BF16, "color_affine: dtype must be f32 or bf16");
+    AGF_CHECK(B >= 1 && B <= 65535 && plane >= 1, "color_affine: bad shape");
+    int64_t bx = agf_ceil_div(plane, 256 * 4);
+    if (bx > 1024) bx = 1024;
+    dim3 grid((unsigned)bx, (unsigned)B);
+    if (dtype == AGF_F32) hipLaunchKernelGGL((color_affine_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, m, plane, transpose);
+    else hipLaunchKernelGGL((color_affine_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, m, plane, transpose);
+    AGF_LAUNCH_CHECK();
+    return AGF_OK;
+}

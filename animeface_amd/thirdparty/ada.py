@@ -29,6 +29,37 @@ _SYM6 = [0.015404109327027373, 0.0034907120842174702, -0.11799011114819057, -0.0
 # ----------------------------------------------------------------------------------------------------------------------
 # batched homogeneous matrices: every argument is a python number or a [B] tensor; the result is [B,n,n] (or [n,n])
 
+
+class _ColorAffine(torch.autograd.Function):
+    """y[b] = M[b,:,:3] @ x[b] + M[b,:,3:] on [B,3,HW] RGB planes as one streaming pass (agf_color_affine); M carries no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, m):
+        from .. import _lib
+        x = x.contiguous()
+        m = m.detach().float().contiguous()
+        y = torch.empty_like(x)
+        rc = _lib.lib().agf_color_affine(_lib.ptr(x), _lib.ptr(y), _lib.ptr(m), _lib.dtype_code(x), x.shape[0], x.shape[2], 0, _lib.stream_ptr(x))
+        _lib.check(rc, 'color_affine')
+        ctx.save_for_backward(m)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .. import _lib
+        m, = ctx.saved_tensors
+        if torch.is_grad_enabled() and dy.requires_grad:
+            return (m[:, :, :3].transpose(1, 2).to(dy.dtype) @ dy), None
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        rc = _lib.lib().agf_color_affine(_lib.ptr(dy), _lib.ptr(dx), _lib.ptr(m), _lib.dtype_code(dy), dy.shape[0], dy.shape[2], 1, _lib.stream_ptr(dy))
+        _lib.check(rc, 'color_affine')
+        return dx, None
+
+
+def _color_affine(flat, m):
+    return _ColorAffine.apply(flat, m)
+
 def _mat(rows, like=None):
     tensors = [v for row in rows for v in row if isinstance(v, torch.Tensor)]
     if not tensors:
@@ -212,7 +243,8 @@ class AugmentPipe(torch.nn.Module):
         if M is not eye4:
             flat = images.reshape([B, C, H * W])
             if C == 3:
-                flat = M[:, :3, :3] @ flat + M[:, :3, 3:]
+                flat = _color_affine(flat, M[:, :3, :]) if flat.is_cuda and flat.dtype in (torch.float32, torch.bfloat16) and not M.requires_grad \
+                    else M[:, :3, :3] @ flat + M[:, :3, 3:]
             elif C == 1:
                 Mg = M[:, :3, :].mean(dim=1, keepdims=True)
                 flat = flat * Mg[:, :, :3].sum(dim=2, keepdims=True) + Mg[:, :, 3:]

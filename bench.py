@@ -156,7 +156,7 @@ def main():
 
     if rank == 0:
         out = {
-            'metric': 'images/sec (G+D+R1 step) StyleGAN2 256x256 bf16',
+            'metric': f'images/sec (G+D+R1 step) StyleGAN2 {S}x{S} bf16',
             'value': round(args.batch * world * args.steps / dt, 2),
             'unit': 'img/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,

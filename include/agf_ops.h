@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define AGF_ABI_VERSION 7
+#define AGF_ABI_VERSION 8
 
 /* element types of activation tensors */
 enum { AGF_F32 = 0, AGF_F16 = 1, AGF_BF16 = 2, AGF_F64 = 3 };
@@ -232,6 +232,10 @@ int agf_style_demod_bwd(const float* s, const float* d, const float* dd, const f
 int agf_diffaug_sum(const void* x, float* out, const int32_t* win, int dtype, int32_t B, int32_t C, int32_t H, int32_t W, void* stream);
 int agf_diffaug_apply(const void* x, void* y, const float* prm, const int32_t* shift, int dtype,
                       int32_t B, int32_t C, int32_t H, int32_t W, int backward, void* stream);
+
+/* ADA colour transforms (thirdparty/ada/augment.py:  images = C[:, :3, :3] @ images + C[:, :3, 3:]  on [B,3,H*W]): per-sample 3x4 affine
+ * map of the RGB planes, m [B][3][4] fp32; transpose = 1 applies the 3x3 part transposed without the offset (the input gradient). */
+int agf_color_affine(const void* x, void* y, const float* m, int dtype, int32_t B, int64_t plane, int transpose, void* stream);
 
 #ifdef __cplusplus
 }
