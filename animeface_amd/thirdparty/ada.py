@@ -70,12 +70,25 @@ class _ColorAffine(torch.autograd.Function):
 def _color_affine(flat, m):
     return _ColorAffine.apply(flat, m)
 
+_CONSTS = {}
+
+
+def _const_like(ref, value):
+    """A read-only constant tensor shaped like ``ref``, made once per (shape, dtype, device, value): the matrix builders below would
+    otherwise launch one fill per constant entry (~350 per training step)."""
+    key = (tuple(ref.shape), ref.dtype, ref.device, value)
+    t = _CONSTS.get(key)
+    if t is None:
+        t = _CONSTS[key] = torch.full_like(ref, value)
+    return t
+
+
 def _mat(rows, like=None):
     tensors = [v for row in rows for v in row if isinstance(v, torch.Tensor)]
     if not tensors:
         return torch.tensor(rows, dtype=torch.float32, device=None if like is None else like.device)
     ref = tensors[0]
-    cols = [v if isinstance(v, torch.Tensor) else torch.full_like(ref, float(v)) for row in rows for v in row]
+    cols = [v if isinstance(v, torch.Tensor) else _const_like(ref, float(v)) for row in rows for v in row]
     return torch.stack(cols, dim=-1).reshape(ref.shape + (len(rows), len(rows[0])))
 
 
@@ -149,7 +162,7 @@ class AugmentPipe(torch.nn.Module):
     def _gate(self, shape, prob, value, neutral, device):
         """``value`` where a fresh uniform draw of ``shape`` is below ``prob``, else ``neutral`` (draw order: value first)."""
         keep = rng.rand(shape, device) < prob
-        return torch.where(keep, value, torch.full_like(value, neutral))
+        return torch.where(keep, value, neutral)                    # scalar overload: no fill launch for the neutral element
 
     def forward(self, images, debug_percentile=None):
         assert isinstance(images, torch.Tensor) and images.ndim == 4
