@@ -143,3 +143,114 @@ extern "C" int agf_color_affine(const void* x, void* y, const float* m, int dtyp
     AGF_LAUNCH_CHECK();
     return AGF_OK;
 }
+
+// ADA geometric warp (thirdparty/ada/augment.py:275-283: F.affine_grid + F.grid_sample(bilinear, zeros, align_corners=False)) as one
+// kernel each way.  theta [B][2][3] maps normalised OUTPUT coordinates to normalised INPUT coordinates.  In pixel units
+//     ix = A00 j + A01 i + A02,  iy = A10 j + A11 i + A12      (j, i = output column, row)
+// forward:  y[b,c,i,j] = sum over the 2x2 input neighbours of (ix, iy) of (1-|dx|)(1-|dy|) x[b,c,.,.]   (zero outside the image)
+// backward: the exact adjoint as a GATHER (ATen scatters 4 atomics per output sample and also differentiates the grid): an input pixel
+//           (xx, yy) receives w = max(0, 1-|ix-xx|) max(0, 1-|iy-yy|) from the output samples whose (ix, iy) lie within 1 of it; their
+//           (j, i) lie in the pre-image of that square under the affine map, a parallelogram inside the box
+//           |j - jc| <= |Ai00| + |Ai01|, |i - ic| <= |Ai10| + |Ai11| around (jc, ic) = A^-1 (xx, yy)   (Ai = inverse of the 2x2 part).
+struct ResampleParams {
+    const void* x; void* y; const float* theta;
+    int B, C, Hin, Win, Hout, Wout;
+};
+
+static __device__ __forceinline__ void resample_matrix(const ResampleParams& p, int b, float (&A)[6]) {
+    const float* t = p.theta + b * 6;
+    // xn = (2j+1)/Wout - 1, yn = (2i+1)/Hout - 1;  ix = ((gx+1) Win - 1)/2
+    const float sxj = 2.f / p.Wout, sxo = 1.f / p.Wout - 1.f, syi = 2.f / p.Hout, syo = 1.f / p.Hout - 1.f;
+    const float hw = 0.5f * p.Win, hh = 0.5f * p.Hin;
+    A[0] = hw * t[0] * sxj; A[1] = hw * t[1] * syi; A[2] = hw * (t[0] * sxo + t[1] * syo + t[2] + 1.f) - 0.5f;
+    A[3] = hh * t[3] * sxj; A[4] = hh * t[4] * syi; A[5] = hh * (t[3] * sxo + t[4] * syo + t[5] + 1.f) - 0.5f;
+}
+
+template <class T>
+__global__ void __launch_bounds__(256) affine_resample_fwd_kernel(ResampleParams p) {
+    const int b = blockIdx.y;
+    float A[6];
+    resample_matrix(p, b, A);
+    const int64_t oplane = (int64_t)p.Hout * p.Wout, iplane = (int64_t)p.Hin * p.Win;
+    const T* xb = (const T*)p.x + (int64_t)b * p.C * iplane;
+    T* yb = (T*)p.y + (int64_t)b * p.C * oplane;
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < oplane; r += (int64_t)gridDim.x * 256) {
+        const int i = (int)(r / p.Wout), j = (int)(r - (int64_t)i * p.Wout);
+        const float ix = A[0] * j + A[1] * i + A[2], iy = A[3] * j + A[4] * i + A[5];
+        const float fx0 = floorf(ix), fy0 = floorf(iy);
+        const int x0 = (int)fx0, y0 = (int)fy0;
+        const float fx = ix - fx0, fy = iy - fy0;
+        const float w00 = (1.f - fx) * (1.f - fy), w01 = fx * (1.f - fy), w10 = (1.f - fx) * fy, w11 = fx * fy;
+        const bool vx0 = x0 >= 0 && x0 < p.Win, vx1 = x0 + 1 >= 0 && x0 + 1 < p.Win, vy0 = y0 >= 0 && y0 < p.Hin, vy1 = y0 + 1 >= 0 && y0 + 1 < p.Hin;
+        for (int c = 0; c < p.C; c++) {
+            const T* xc = xb + c * iplane;
+            float v = 0.f;
+            if (vy0 && vx0) v += w00 * (float)Elem<T>::load(xc + (int64_t)y0 * p.Win + x0);
+            if (vy0 && vx1) v += w01 * (float)Elem<T>::load(xc + (int64_t)y0 * p.Win + x0 + 1);
+            if (vy1 && vx0) v += w10 * (float)Elem<T>::load(xc + (int64_t)(y0 + 1) * p.Win + x0);
+            if (vy1 && vx1) v += w11 * (float)Elem<T>::load(xc + (int64_t)(y0 + 1) * p.Win + x0 + 1);
+            Elem<T>::store(yb + c * oplane + r, v);
+        }
+    }
+}
+
+// x = dy [B,C,Hout,Wout], y = dx [B,C,Hin,Win]
+template <class T>
+__global__ void __launch_bounds__(256) affine_resample_bwd_kernel(ResampleParams p) {
+    const int b = blockIdx.y;
+    float A[6];
+    resample_matrix(p, b, A);
+    const float det = A[0] * A[4] - A[1] * A[3];
+    const float inv = 1.f / det;
+    const float I00 = A[4] * inv, I01 = -A[1] * inv, I10 = -A[3] * inv, I11 = A[0] * inv;
+    const float rj = fabsf(I00) + fabsf(I01), ri = fabsf(I10) + fabsf(I11);
+    const int64_t oplane = (int64_t)p.Hout * p.Wout, iplane = (int64_t)p.Hin * p.Win;
+    const T* gb = (const T*)p.x + (int64_t)b * p.C * oplane;
+    T* db = (T*)p.y + (int64_t)b * p.C * iplane;
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < iplane; r += (int64_t)gridDim.x * 256) {
+        const int yy = (int)(r / p.Win), xx = (int)(r - (int64_t)yy * p.Win);
+        const float ux = (float)xx - A[2], uy = (float)yy - A[5];
+        const float jc = I00 * ux + I01 * uy, ic = I10 * ux + I11 * uy;
+        int j0 = (int)ceilf(jc - rj), j1 = (int)floorf(jc + rj), i0 = (int)ceilf(ic - ri), i1 = (int)floorf(ic + ri);
+        if (j0 < 0) j0 = 0;
+        if (i0 < 0) i0 = 0;
+        if (j1 > p.Wout - 1) j1 = p.Wout - 1;
+        if (i1 > p.Hout - 1) i1 = p.Hout - 1;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int i = i0; i <= i1; i++) {
+            for (int j = j0; j <= j1; j++) {
+                const float ix = A[0] * j + A[1] * i + A[2], iy = A[3] * j + A[4] * i + A[5];
+                // the forward pass splits (ix, iy) at floor(): weight of pixel xx is 1-|ix-xx| when floor(ix) is xx or xx-1
+                const float dx = ix - (float)xx, dy = iy - (float)yy;
+                const float wx = 1.f - fabsf(dx), wy = 1.f - fabsf(dy);
+                if (wx <= 0.f || wy <= 0.f) continue;
+                const float w = wx * wy;
+                for (int c = 0; c < p.C; c++) acc[c] += w * (float)Elem<T>::load(gb + c * oplane + (int64_t)i * p.Wout + j);
+            }
+        }
+        for (int c = 0; c < p.C; c++) Elem<T>::store(db + c * iplane + r, acc[c]);
+    }
+}
+
+extern "C" int agf_affine_resample(const void* x, void* y, const float* theta, int dtype, int32_t B, int32_t C,
+                                   int32_t Hin, int32_t Win, int32_t Hout, int32_t Wout, int backward, void* stream) {
+    AGF_CHECK(x && y && theta, "affine_resample: null pointer");
+    AGF_CHECK(dtype == AGF_F32 || dtype == AGF_BF16, "affine_resample: dtype must be f32 or bf16");
+    AGF_CHECK(B >= 1 && B <= 65535 && C >= 1 && C <= 4 && Hin >= 1 && Win >= 1 && Hout >= 1 && Wout >= 1, "affine_resample: bad shape (at most 4 channels)");
+    ResampleParams p;
+    p.x = x; p.y = y; p.theta = theta; p.B = B; p.C = C; p.Hin = Hin; p.Win = Win; p.Hout = Hout; p.Wout = Wout;
+    const int64_t n = backward ? (int64_t)Hin * Win : (int64_t)Hout * Wout;
+    int64_t bx = agf_ceil_div(n, 256);
+    if (bx > 4096) bx = 4096;
+    dim3 grid((unsigned)bx, (unsigned)B);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == AGF_F32) {
+        if (backward) hipLaunchKernelGGL((affine_resample_bwd_kernel<float>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((affine_resample_fwd_kernel<float>), grid, dim3(256), 0, st, p);
+    } else {
+        if (backward) hipLaunchKernelGGL((affine_resample_bwd_kernel<bf16_t>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((affine_resample_fwd_kernel<bf16_t>), grid, dim3(256), 0, st, p);
+    }
+    AGF_LAUNCH_CHECK();
+    return AGF_OK;
+}

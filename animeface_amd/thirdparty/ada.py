@@ -12,6 +12,8 @@ the same random stream reproduces the reference's output (``tests/test_hip_ada.p
   * image-space filtering builds a per-sample separable filter from the sym2 filter bank and applies it as two grouped
     1-D convolutions, reference :364-392.
 """
+import os
+
 import numpy as np
 import scipy.signal
 import torch
@@ -39,6 +41,43 @@ def _affine_grid(theta, H, W):
     t = theta[:, :, :, None, None]                                        # [B, 2, 3, 1, 1]
     g = t[:, :, 0] * xs[None, None, None, :] + (t[:, :, 1] * ys[None, None, :, None] + t[:, :, 2])      # [B, 2, H, W]
     return g.permute(0, 2, 3, 1)
+
+
+_RESAMPLE_FUSED = os.environ.get('AGF_ADA_RESAMPLE', '1') != '0'          # A/B switch
+
+
+class _AffineResample(torch.autograd.Function):
+    """``grid_sample(x, affine_grid(theta))`` (bilinear, zero padding, align_corners=False) in one launch each way (agf_affine_resample);
+    theta carries no gradient.  The backward is the exact adjoint evaluated as a gather."""
+
+    @staticmethod
+    def forward(ctx, x, theta, Hout, Wout):
+        from .. import _lib
+        x = x.contiguous()
+        theta = theta.detach().float().contiguous()
+        B, C, Hin, Win = x.shape
+        y = torch.empty((B, C, Hout, Wout), dtype=x.dtype, device=x.device)
+        rc = _lib.lib().agf_affine_resample(_lib.ptr(x), _lib.ptr(y), _lib.ptr(theta), _lib.dtype_code(x), B, C, Hin, Win, Hout, Wout, 0,
+                                            _lib.stream_ptr(x))
+        _lib.check(rc, 'affine_resample')
+        ctx.save_for_backward(theta)
+        ctx.in_shape = (Hin, Win)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .. import _lib
+        theta, = ctx.saved_tensors
+        if torch.is_grad_enabled() and dy.requires_grad:
+            raise RuntimeError('the fused ADA resampling has no double backward (set AGF_ADA_RESAMPLE=0)')
+        dy = dy.contiguous()
+        B, C, Hout, Wout = dy.shape
+        Hin, Win = ctx.in_shape
+        dx = torch.empty((B, C, Hin, Win), dtype=dy.dtype, device=dy.device)
+        rc = _lib.lib().agf_affine_resample(_lib.ptr(dy), _lib.ptr(dx), _lib.ptr(theta), _lib.dtype_code(dy), B, C, Hin, Win, Hout, Wout, 1,
+                                            _lib.stream_ptr(dy))
+        _lib.check(rc, 'affine_resample')
+        return dx, None, None, None
 
 class _ColorAffine(torch.autograd.Function):
     """y[b] = M[b,:,:3] @ x[b] + M[b,:,3:] on [B,3,HW] RGB planes as one streaming pass (agf_color_affine); M carries no gradient."""
@@ -322,8 +361,11 @@ class AugmentPipe(torch.nn.Module):
         # resample
         out_shape = [B, C, (H + taps4 * 2) * 2, (W + taps4 * 2) * 2]
         G = _zoom2(2 / images.shape[3], 2 / images.shape[2], like=images) @ G @ _zoom2(out_shape[3] / 2, out_shape[2] / 2, like=images)
-        grid = _affine_grid(G[:, :2, :], out_shape[2], out_shape[3])
-        images = torch.nn.functional.grid_sample(images, grid, mode='bilinear', padding_mode='zeros', align_corners=False)
+        if _RESAMPLE_FUSED and images.is_cuda and images.dtype in (torch.float32, torch.bfloat16) and C <= 4 and not G.requires_grad:
+            images = _AffineResample.apply(images, G[:, :2, :], out_shape[2], out_shape[3])
+        else:
+            grid = _affine_grid(G[:, :2, :], out_shape[2], out_shape[3])
+            images = torch.nn.functional.grid_sample(images, grid, mode='bilinear', padding_mode='zeros', align_corners=False)
         # /2 with the same low-pass, cropping the filter margins
         return upfirdn2d.downsample2d(x=images, f=self.Hz_geom, down=2, padding=-taps4 * 2, flip_filter=True)
 

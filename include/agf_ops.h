@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define AGF_ABI_VERSION 8
+#define AGF_ABI_VERSION 9
 
 /* element types of activation tensors */
 enum { AGF_F32 = 0, AGF_F16 = 1, AGF_BF16 = 2, AGF_F64 = 3 };
@@ -236,6 +236,13 @@ int agf_diffaug_apply(const void* x, void* y, const float* prm, const int32_t* s
 /* ADA colour transforms (thirdparty/ada/augment.py:  images = C[:, :3, :3] @ images + C[:, :3, 3:]  on [B,3,H*W]): per-sample 3x4 affine
  * map of the RGB planes, m [B][3][4] fp32; transpose = 1 applies the 3x3 part transposed without the offset (the input gradient). */
 int agf_color_affine(const void* x, void* y, const float* m, int dtype, int32_t B, int64_t plane, int transpose, void* stream);
+
+/* ADA geometric warp (thirdparty/ada/augment.py:275-283): F.affine_grid(theta, size, align_corners=False) followed by
+ * F.grid_sample(x, grid, 'bilinear', 'zeros', align_corners=False), one launch.  theta [B][2][3] fp32; x [B,C,Hin,Win], y [B,C,Hout,Wout].
+ * backward = 1: x is the output gradient [B,C,Hout,Wout], y receives the input gradient [B,C,Hin,Win] -- the exact adjoint, evaluated as a
+ * gather over the pre-image of each input pixel's bilinear support (no atomics, no grid gradient).  NCHW, fp32 or bf16, C <= 4. */
+int agf_affine_resample(const void* x, void* y, const float* theta, int dtype, int32_t B, int32_t C,
+                        int32_t Hin, int32_t Win, int32_t Hout, int32_t Wout, int backward, void* stream);
 
 #ifdef __cplusplus
 }

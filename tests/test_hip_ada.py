@@ -102,3 +102,36 @@ def test_ada_training_steps_run_and_adapt_p():
     assert len(hist) == 4 and all(np.isfinite(h[1]) and np.isfinite(h[2]) for h in hist)
     assert float(augment.p) in (0.0, 0.25, 0.5)              # two updates of +-0.25, clamped at 0
     assert augment._num_iter == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(4, 3, 40, 52, 36, 44), (3, 1, 64, 64, 64, 64), (2, 3, 33, 47, 70, 58)])
+def test_fused_affine_resample_matches_grid_sample(shape):
+    """agf_affine_resample (forward gather, exact-adjoint backward gather) against F.affine_grid + F.grid_sample."""
+    import math
+    import torch.nn.functional as F
+    from animeface_amd.thirdparty.ada import _AffineResample
+    B, C, Hin, Win, Hout, Wout = shape
+    dev = torch.device('cuda')
+    g = torch.Generator().manual_seed(5)
+    x0 = torch.randn(B, C, Hin, Win, generator=g).to(dev)
+    gy = torch.randn(B, C, Hout, Wout, generator=g).to(dev)
+    ang = (torch.rand(B, generator=g) * 2 - 1) * math.pi
+    sc = torch.exp2(torch.randn(B, generator=g) * 0.4)
+    an = torch.exp2(torch.randn(B, generator=g) * 0.3)
+    sh = (torch.rand(B, 2, generator=g) - 0.5) * 0.6
+    theta = torch.stack([torch.stack([sc * an * torch.cos(ang), -sc * torch.sin(ang), sh[:, 0]], 1),
+                         torch.stack([sc * an * torch.sin(ang), sc * torch.cos(ang), sh[:, 1]], 1)], 1).to(dev)
+    outs = []
+    for fused in (True, False):
+        x = x0.clone().requires_grad_(True)
+        if fused:
+            y = _AffineResample.apply(x, theta, Hout, Wout)
+        else:
+            y = F.grid_sample(x, F.affine_grid(theta, [B, C, Hout, Wout], align_corners=False), mode='bilinear', padding_mode='zeros',
+                              align_corners=False)
+        (dx,) = torch.autograd.grad(y, x, gy)
+        outs.append((y, dx))
+    for a, b in zip(outs[0], outs[1]):
+        assert a.shape == b.shape
+        assert (a - b).abs().max().item() <= 2e-4 * max(1.0, b.abs().max().item())
