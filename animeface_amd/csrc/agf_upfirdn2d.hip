@@ -488,6 +488,8 @@ static bool launch_nhwc(const UpfirdnParams& p, hipStream_t st) {
     NHWC_CASE(1, 1, 2, 2, 4, 4, 4)   // adjoint of the 2x upsample; StyleGAN3-D downsample
     NHWC_CASE(2, 2, 1, 1, 2, 2, 8)   // adjoint of AvgPool2d(2)
     NHWC_CASE(1, 1, 1, 1, 4, 4, 4)   // StyleGAN3-D filter2d before the strided conv
+    NHWC_CASE(2, 2, 1, 1, 6, 6, 8)   // fused Upsample2x -> Blur2d of the StyleGAN2 generator (composite [1,5,10,10,5,1] filter)
+    NHWC_CASE(1, 1, 2, 2, 6, 6, 4)   // its adjoint
 #undef NHWC_CASE
     hipLaunchKernelGGL((upfirdn2d_nhwc_vec<T, VEC, 0, 0, 0, 0, 0, 0>), g, b, 0, st, pp);
     return true;
@@ -727,6 +729,151 @@ extern "C" int agf_upfirdn2d_fold_border(const void* x, const float* f, void* y,
         case AGF_F16:  hipLaunchKernelGGL((upfirdn2d_fold_border<f16_t>), dim3((unsigned)blocks), dim3(256), 0, st, p, rx, ry); break;
         case AGF_BF16: hipLaunchKernelGGL((upfirdn2d_fold_border<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, st, p, rx, ry); break;
         default:       hipLaunchKernelGGL((upfirdn2d_fold_border<double>), dim3((unsigned)blocks), dim3(256), 0, st, p, rx, ry); break;
+    }
+    AGF_LAUNCH_CHECK();
+    return AGF_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// upblur_border: the border correction of the fused  Upsample(x2, bilinear) -> Blur2d([1,2,1])  of the StyleGAN2 generator
+// (implementations/StyleGAN2/model.py:138-175).  blur(up(x)) with the upsample's clamp-to-edge and the blur's ZERO padding equals the
+// composite 6-tap clamp-mode upfirdn2d  C x  (filter [1,5,10,10,5,1]: one pass instead of two) everywhere except on the outermost
+// ring of the output, where the zero padding removes a quarter of the virtual outer sample:
+//     b = C x - E_v Bc_h u - Bc_v E_h u + E_v E_h u,   u = up(x),  (E u)[0] = u[0] / 4, (E u)[last] = u[last] / 4
+// and on the border rows / columns u is the 1-D upsample of the border row / column of x, so the correction is a 1-D composite of that
+// row / column (taps .3125 .625 .0625 / .0625 .625 .3125 by output parity, clamped) times 1/4, plus x[corner] / 16 at the corners.
+// forward:  y (the composite result, [N,2H,2W,C] channels-last) is corrected in place from x [N,H,W,C]
+// backward: x = dy [N,2H,2W,C]; y = dx [N,H,W,C] (the composite's adjoint) receives the adjoint of the correction in place
+static __device__ __forceinline__ void upblur_taps(int j, int L, int (&idx)[3], float (&w)[3]) {
+    const int i = j >> 1;
+    idx[0] = max(i - 1, 0); idx[1] = i; idx[2] = min(i + 1, L - 1);
+    if (j & 1) { w[0] = 0.0625f; w[1] = 0.625f; w[2] = 0.3125f; } else { w[0] = 0.3125f; w[1] = 0.625f; w[2] = 0.0625f; }
+}
+
+template <class T, int VEC>
+__global__ void __launch_bounds__(256) upblur_border_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int C, int H, int W) {
+    const int OH = 2 * H, OW = 2 * W, CG = C / VEC;
+    const int per = 2 * OW + 2 * (OH - 2);
+    const int64_t total = (int64_t)N * per * CG;
+    for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+        const int cg = (int)(id % CG);
+        const int64_t r = id / CG;
+        const int b = (int)(r % per), n = (int)(r / per);
+        int oy, ox;
+        if (b < OW) { oy = 0; ox = b; }
+        else if (b < 2 * OW) { oy = OH - 1; ox = b - OW; }
+        else { const int t = b - 2 * OW; oy = 1 + (t >> 1); ox = (t & 1) ? OW - 1 : 0; }
+        const T* xb = x + (int64_t)n * H * W * C + cg * VEC;
+        float d[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; e++) d[e] = 0.f;
+        int idx[3]; float w[3]; float v[VEC];
+        if (oy == 0 || oy == OH - 1) {                                   // - Ch(x[row]) / 4
+            const int row = oy == 0 ? 0 : H - 1;
+            upblur_taps(ox, W, idx, w);
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                VecIO<T, VEC>::load(xb + ((int64_t)row * W + idx[k]) * C, v);
+#pragma unroll
+                for (int e = 0; e < VEC; e++) d[e] -= 0.25f * w[k] * v[e];
+            }
+        }
+        if (ox == 0 || ox == OW - 1) {                                   // - Cv(x[:, col]) / 4
+            const int col = ox == 0 ? 0 : W - 1;
+            upblur_taps(oy, H, idx, w);
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                VecIO<T, VEC>::load(xb + ((int64_t)idx[k] * W + col) * C, v);
+#pragma unroll
+                for (int e = 0; e < VEC; e++) d[e] -= 0.25f * w[k] * v[e];
+            }
+            if (oy == 0 || oy == OH - 1) {                               // + x[corner] / 16
+                VecIO<T, VEC>::load(xb + ((int64_t)(oy == 0 ? 0 : H - 1) * W + col) * C, v);
+#pragma unroll
+                for (int e = 0; e < VEC; e++) d[e] += 0.0625f * v[e];
+            }
+        }
+        T* yp = y + (((int64_t)n * OH + oy) * OW + ox) * C + cg * VEC;
+        VecIO<T, VEC>::load(yp, v);
+#pragma unroll
+        for (int e = 0; e < VEC; e++) v[e] += d[e];
+        VecIO<T, VEC>::store(yp, v);
+    }
+}
+
+template <class T, int VEC>
+__global__ void __launch_bounds__(256) upblur_border_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int N, int C, int H, int W) {
+    const int OH = 2 * H, OW = 2 * W, CG = C / VEC;
+    const int per = 2 * W + 2 * (H - 2);                                 // ring of the INPUT
+    const int64_t total = (int64_t)N * per * CG;
+    for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+        const int cg = (int)(id % CG);
+        const int64_t r = id / CG;
+        const int b = (int)(r % per), n = (int)(r / per);
+        int iy, ix;
+        if (b < W) { iy = 0; ix = b; }
+        else if (b < 2 * W) { iy = H - 1; ix = b - W; }
+        else { const int t = b - 2 * W; iy = 1 + (t >> 1); ix = (t & 1) ? W - 1 : 0; }
+        const T* gb = dy + (int64_t)n * OH * OW * C + cg * VEC;
+        float d[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; e++) d[e] = 0.f;
+        int idx[3]; float w[3]; float v[VEC];
+        if (iy == 0 || iy == H - 1) {                                    // adjoint of - Ch(x[row]) / 4: output row 0 / OH-1
+            const int orow = iy == 0 ? 0 : OH - 1;
+            for (int j = max(2 * ix - 2, 0); j <= min(2 * ix + 3, OW - 1); j++) {
+                upblur_taps(j, W, idx, w);
+                float wj = 0.f;
+#pragma unroll
+                for (int k = 0; k < 3; k++) if (idx[k] == ix) wj += w[k];
+                if (wj == 0.f) continue;
+                VecIO<T, VEC>::load(gb + ((int64_t)orow * OW + j) * C, v);
+#pragma unroll
+                for (int e = 0; e < VEC; e++) d[e] -= 0.25f * wj * v[e];
+            }
+        }
+        if (ix == 0 || ix == W - 1) {                                    // adjoint of - Cv(x[:, col]) / 4: output column 0 / OW-1
+            const int ocol = ix == 0 ? 0 : OW - 1;
+            for (int i = max(2 * iy - 2, 0); i <= min(2 * iy + 3, OH - 1); i++) {
+                upblur_taps(i, H, idx, w);
+                float wi = 0.f;
+#pragma unroll
+                for (int k = 0; k < 3; k++) if (idx[k] == iy) wi += w[k];
+                if (wi == 0.f) continue;
+                VecIO<T, VEC>::load(gb + ((int64_t)i * OW + ocol) * C, v);
+#pragma unroll
+                for (int e = 0; e < VEC; e++) d[e] -= 0.25f * wi * v[e];
+            }
+            if (iy == 0 || iy == H - 1) {                                // corner
+                VecIO<T, VEC>::load(gb + ((int64_t)(iy == 0 ? 0 : OH - 1) * OW + ocol) * C, v);
+#pragma unroll
+                for (int e = 0; e < VEC; e++) d[e] += 0.0625f * v[e];
+            }
+        }
+        T* xp = dx + (((int64_t)n * H + iy) * W + ix) * C + cg * VEC;
+        VecIO<T, VEC>::load(xp, v);
+#pragma unroll
+        for (int e = 0; e < VEC; e++) v[e] += d[e];
+        VecIO<T, VEC>::store(xp, v);
+    }
+}
+
+extern "C" int agf_upblur_border(const void* x, void* y, int dtype, int32_t N, int32_t C, int32_t H, int32_t W, int backward, void* stream) {
+    AGF_CHECK(x && y, "upblur_border: null pointer");
+    AGF_CHECK(dtype == AGF_F32 || dtype == AGF_BF16, "upblur_border: dtype must be f32 or bf16");
+    AGF_CHECK(N >= 1 && C >= 1 && H >= 2 && W >= 2, "upblur_border: the map must be at least 2x2");
+    const int vec = dtype == AGF_BF16 ? 8 : 4;
+    AGF_CHECK(C % vec == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0, "upblur_border: C must be a multiple of %d, 16-byte aligned tensors", vec);
+    const int per = backward ? 2 * W + 2 * (H - 2) : 4 * W + 2 * (2 * H - 2);
+    int64_t blocks = agf_ceil_div((int64_t)N * per * (C / vec), 256);
+    if (blocks > 65536) blocks = 65536;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == AGF_BF16) {
+        if (backward) hipLaunchKernelGGL((upblur_border_bwd_kernel<bf16_t, 8>), dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, N, C, H, W);
+        else hipLaunchKernelGGL((upblur_border_fwd_kernel<bf16_t, 8>), dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, N, C, H, W);
+    } else {
+        if (backward) hipLaunchKernelGGL((upblur_border_bwd_kernel<float, 4>), dim3((unsigned)blocks), dim3(256), 0, st, (const float*)x, (float*)y, N, C, H, W);
+        else hipLaunchKernelGGL((upblur_border_fwd_kernel<float, 4>), dim3((unsigned)blocks), dim3(256), 0, st, (const float*)x, (float*)y, N, C, H, W);
     }
     AGF_LAUNCH_CHECK();
     return AGF_OK;

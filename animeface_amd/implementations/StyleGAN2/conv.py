@@ -426,6 +426,48 @@ class PremaskLink:
         self.armed, self.alpha, self.premasked, self.bsum, self.pooled = False, 0.2, False, None, None
 
 
+class _UpBlur(torch.autograd.Function):
+    """``Blur2d([1,2,1])(Upsample(x2, bilinear)(x))`` of the StyleGAN2 generator block (reference model.py:138-175) in ONE pass over the
+    upsampled tensor instead of two: the clamp-mode upfirdn2d with the composite filter [1,5,10,10,5,1] x itself, plus a border-only
+    kernel for the ring where the blur's zero padding differs from the clamp (``agf_upblur_border``).  The backward is the composite's
+    adjoint (decimating FIR + border fold) followed by the adjoint of the border correction.  First-order only."""
+
+    @staticmethod
+    def forward(ctx, x, f6):
+        from ...stylegan3_ops import upfirdn2d as U
+        x = x.contiguous(memory_format=torch.channels_last)
+        N, C, H, W = x.shape
+        y = U._launch(x, f6, 2, 2, 1, 1, 3, 2, 3, 2, False, 4.0, 'clamp')
+        rc = _lib.lib().agf_upblur_border(_lib.ptr(x), _lib.ptr(y), _lib.dtype_code(x), N, C, H, W, 0, _lib.stream_ptr(x))
+        _lib.check(rc, 'upblur_border')
+        ctx.save_for_backward(f6)
+        ctx.x_shape = x.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from ...stylegan3_ops import upfirdn2d as U
+        f6, = ctx.saved_tensors
+        if torch.is_grad_enabled() and dy.requires_grad:
+            raise RuntimeError('the fused upsample + blur has no double backward; build the generator with fused_epilogue=False')
+        N, C, H, W = ctx.x_shape
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        # adjoint of the clamp-mode composite: zero-mode adjoint + fold of the replicate-extension strips (as Upfirdn2dHip.backward)
+        dx = U._launch(dy, f6, 1, 1, 2, 2, 2, 2, 2, 2, True, 4.0, 'zero')
+        rc = _lib.lib().agf_upfirdn2d_fold_border(
+            _lib.ptr(dy), _lib.ptr(f6), _lib.ptr(dx), _lib.dtype_code(dy),
+            _lib.sizes4(dy), _lib.strides4(dy), _lib._i32x2(*f6.shape), _lib._i64x2(*f6.stride()),
+            _lib.sizes4(dx), _lib.strides4(dx), 1, 1, 2, 2, 2, 2, 1, 4.0, 3, 3, _lib.stream_ptr(dy))
+        _lib.check(rc, 'upfirdn2d_fold_border')
+        rc = _lib.lib().agf_upblur_border(_lib.ptr(dy), _lib.ptr(dx), _lib.dtype_code(dy), N, C, H, W, 1, _lib.stream_ptr(dy))
+        _lib.check(rc, 'upblur_border')
+        return dx, None
+
+
+def up_blur(x, f6):
+    return _UpBlur.apply(x, f6)
+
+
 class SkipLink:
     """Handshake between the first conv of a residual block and the 2x2 average of the block's skip branch, which share their input:
     the pool's backward leaves the pooled gradient here (and returns no gradient), the conv's data-gradient launch adds it at half

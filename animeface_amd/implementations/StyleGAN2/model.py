@@ -29,13 +29,14 @@ import torch.nn.functional as F
 
 from ...stylegan3_ops import upfirdn2d, bias_act
 from ... import rng
-from .conv import conv2d, conv2d_act, style_demod, PremaskLink, SkipLink, pool2x_linked, pool2x_skip
+from .conv import conv2d, conv2d_act, style_demod, PremaskLink, SkipLink, pool2x_linked, pool2x_skip, up_blur
 
 
 # bias / noise / leaky-ReLU run in the conv kernel's epilogue (with a fused backward).  The fused modulated conv has
 # no double backward, so the generator falls back to the separately differentiable ops when ``fused_epilogue=False``
 # (needed only for the path-length penalty, pl_lambda > 0).
 FUSED_EPILOGUE = True
+_UPBLUR_FUSED = os.environ.get('AGF_UPBLUR_FUSED', '1') != '0'        # A/B switch: upsample + blur of the generator block as one pass
 _STYLE_FUSED = os.environ.get('AGF_STYLE_FUSED', '1') != '0'      # A/B switch: one-launch style / demodulation scalars
 
 
@@ -234,6 +235,14 @@ class StyleBlock(nn.Module):
     def forward(self, x, y):
         mods = list(self.block)
         i = 0
+        if _UPBLUR_FUSED and FUSED_EPILOGUE and getattr(self, 'fused_epilogue', True) and len(mods) > 1 and isinstance(mods[0], _BilinearUp2x) \
+                and isinstance(mods[1], Blur2d) and x.is_cuda and x.shape[2] >= 2 and x.shape[3] >= 2 \
+                and x.shape[1] % (8 if x.dtype == torch.bfloat16 else 4) == 0 and x.dtype in (torch.bfloat16, torch.float32):
+            # bilinear x2 followed by the [1,2,1] blur: one pass with the composite filter (+ a border-only correction)
+            if getattr(self, '_f6', None) is None or self._f6.device != x.device:
+                self._f6 = upfirdn2d.setup_filter([1, 5, 10, 10, 5, 1], device=x.device)
+            x = up_blur(x, self._f6)
+            i = 2
         while i < len(mods):
             m = mods[i]
             if isinstance(m, ModulatedConv2d) and i + 2 < len(mods) + 0 and isinstance(mods[i + 1], InjectNoise) \

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define AGF_ABI_VERSION 9
+#define AGF_ABI_VERSION 10
 
 /* element types of activation tensors */
 enum { AGF_F32 = 0, AGF_F16 = 1, AGF_BF16 = 2, AGF_F64 = 3 };
@@ -243,6 +243,14 @@ int agf_color_affine(const void* x, void* y, const float* m, int dtype, int32_t 
  * gather over the pre-image of each input pixel's bilinear support (no atomics, no grid gradient).  NCHW, fp32 or bf16, C <= 4. */
 int agf_affine_resample(const void* x, void* y, const float* theta, int dtype, int32_t B, int32_t C,
                         int32_t Hin, int32_t Win, int32_t Hout, int32_t Wout, int backward, void* stream);
+
+/* Border correction of the fused  nn.Upsample(x2, bilinear) -> Blur2d  pair of the StyleGAN2 generator (implementations/StyleGAN2/
+ * model.py:138-175).  blur(up(x)) equals ONE clamp-mode agf_upfirdn2d with the composite filter [1,5,10,10,5,1] x itself except on the
+ * outermost ring of the output, where the blur's zero padding differs from the clamp: this kernel applies that difference (a 1-D
+ * composite of the border row / column of x, divided by 4, and x[corner] / 16).  Channels-last dense tensors.
+ *   backward = 0: x [N,H,W,C] input, y [N,2H,2W,C] = the composite result, corrected in place
+ *   backward = 1: x = dy [N,2H,2W,C], y = dx [N,H,W,C] (the composite's adjoint), receives the correction's adjoint in place */
+int agf_upblur_border(const void* x, void* y, int dtype, int32_t N, int32_t C, int32_t H, int32_t W, int backward, void* stream);
 
 #ifdef __cplusplus
 }
