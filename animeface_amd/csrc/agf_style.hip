@@ -24,16 +24,18 @@ __global__ void __launch_bounds__(256) wsq_kernel(const float* __restrict__ w, f
     if (ci2 < Cin && co2 < Cout) wsq_t[(int64_t)ci2 * Cout + co2] = tile[a][b];
 }
 
-// forward: block = 64 output channels x 4 batch rows; 4 wave-sized slices split the ci sum.  Dynamic LDS: s^2 [4][Cin].
-__global__ void __launch_bounds__(256) style_demod_fwd_kernel(const float* __restrict__ s_raw, const float* __restrict__ wsq_t,
+// forward: block = 64 output channels x 4 batch rows; SL wave-sized slices split the ci sum (16 slices = 1024 threads: the sum is a
+// chain of Cin/SL dependent-latency steps per thread -- with 4 slices a 512-channel layer took 28 us).  Dynamic LDS: s^2 [4][Cin].
+#define STYLE_SL 16
+__global__ void __launch_bounds__(64 * STYLE_SL) style_demod_fwd_kernel(const float* __restrict__ s_raw, const float* __restrict__ wsq_t,
                                                               float* __restrict__ s, float* __restrict__ d,
                                                               int B, int Cin, int Cout, float c2, float eps) {
     extern __shared__ float smem[];
     float* s2 = smem;                                    // [4][Cin]
-    __shared__ float red[4][4][64];
+    __shared__ float red[STYLE_SL][4][64];
     const int tid = threadIdx.x, col = tid & 63, slice = tid >> 6;
     const int co = blockIdx.x * 64 + col, b0 = blockIdx.y * 4;
-    for (int idx = tid; idx < 4 * Cin; idx += 256) {
+    for (int idx = tid; idx < 4 * Cin; idx += 64 * STYLE_SL) {
         const int bt = idx / Cin, ci = idx - bt * Cin, b = b0 + bt;
         float v = 0.f;
         if (b < B) {
@@ -45,7 +47,8 @@ __global__ void __launch_bounds__(256) style_demod_fwd_kernel(const float* __res
     __syncthreads();
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     if (co < Cout) {
-        for (int ci = slice; ci < Cin; ci += 4) {
+#pragma unroll 8
+        for (int ci = slice; ci < Cin; ci += STYLE_SL) {
             const float wv = wsq_t[(int64_t)ci * Cout + co];
 #pragma unroll
             for (int bt = 0; bt < 4; bt++) acc[bt] += s2[bt * Cin + ci] * wv;
@@ -58,23 +61,26 @@ __global__ void __launch_bounds__(256) style_demod_fwd_kernel(const float* __res
 #pragma unroll
         for (int bt = 0; bt < 4; bt++) {
             const int b = b0 + bt;
-            if (b < B) d[(int64_t)b * Cout + co] = rsqrtf(c2 * (red[0][bt][col] + red[1][bt][col] + red[2][bt][col] + red[3][bt][col]) + eps);
+            float sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < STYLE_SL; k++) sum += red[k][bt][col];
+            if (b < B) d[(int64_t)b * Cout + co] = rsqrtf(c2 * sum + eps);
         }
     }
 }
 
 // backward, style part:  g = dd * d' = -0.5 * c2 * d^3 * dd;   ds_raw[b,ci] = ds[b,ci] + 2 s[b,ci] * sum_co g[b,co] wsq[co,ci]
 // Dynamic LDS: g [4][Cout].
-__global__ void __launch_bounds__(256) style_demod_bwd_ds_kernel(const float* __restrict__ s, const float* __restrict__ d,
+__global__ void __launch_bounds__(64 * STYLE_SL) style_demod_bwd_ds_kernel(const float* __restrict__ s, const float* __restrict__ d,
                                                                  const float* __restrict__ dd, const float* __restrict__ ds,
                                                                  const float* __restrict__ wsq, float* __restrict__ ds_raw,
                                                                  int B, int Cin, int Cout, float c2) {
     extern __shared__ float smem[];
     float* g = smem;                                     // [4][Cout]
-    __shared__ float red[4][4][64];
+    __shared__ float red[STYLE_SL][4][64];
     const int tid = threadIdx.x, col = tid & 63, slice = tid >> 6;
     const int ci = blockIdx.x * 64 + col, b0 = blockIdx.y * 4;
-    for (int idx = tid; idx < 4 * Cout; idx += 256) {
+    for (int idx = tid; idx < 4 * Cout; idx += 64 * STYLE_SL) {
         const int bt = idx / Cout, co = idx - bt * Cout, b = b0 + bt;
         float v = 0.f;
         if (b < B) { const float dv = d[(int64_t)b * Cout + co]; v = -0.5f * c2 * dv * dv * dv * dd[(int64_t)b * Cout + co]; }
@@ -83,7 +89,8 @@ __global__ void __launch_bounds__(256) style_demod_bwd_ds_kernel(const float* __
     __syncthreads();
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     if (ci < Cin) {
-        for (int co = slice; co < Cout; co += 4) {
+#pragma unroll 8
+        for (int co = slice; co < Cout; co += STYLE_SL) {
             const float wv = wsq[(int64_t)co * Cin + ci];
 #pragma unroll
             for (int bt = 0; bt < 4; bt++) acc[bt] += g[bt * Cout + co] * wv;
@@ -98,7 +105,9 @@ __global__ void __launch_bounds__(256) style_demod_bwd_ds_kernel(const float* __
             const int b = b0 + bt;
             if (b < B) {
                 const int64_t o = (int64_t)b * Cin + ci;
-                const float sum = red[0][bt][col] + red[1][bt][col] + red[2][bt][col] + red[3][bt][col];
+                float sum = 0.f;
+#pragma unroll
+                for (int k = 0; k < STYLE_SL; k++) sum += red[k][bt][col];
                 ds_raw[o] = (ds ? ds[o] : 0.f) + 2.f * s[o] * sum;
             }
         }
@@ -162,7 +171,7 @@ extern "C" int agf_style_demod_fwd(const float* s_raw, const float* wsq_t, float
     AGF_CHECK(s_raw && wsq_t && s && d, "style_demod_fwd: null pointer");
     AGF_CHECK(B >= 1 && Cin >= 1 && Cout >= 1, "style_demod_fwd: empty tensor");
     AGF_CHECK((size_t)4 * Cin * sizeof(float) <= 48 * 1024, "style_demod_fwd: Cin = %d is too large", Cin);
-    hipLaunchKernelGGL(style_demod_fwd_kernel, dim3((unsigned)agf_ceil_div(Cout, 64), (unsigned)agf_ceil_div(B, 4)), dim3(256),
+    hipLaunchKernelGGL(style_demod_fwd_kernel, dim3((unsigned)agf_ceil_div(Cout, 64), (unsigned)agf_ceil_div(B, 4)), dim3(64 * STYLE_SL),
                        (size_t)4 * Cin * sizeof(float), (hipStream_t)stream, s_raw, wsq_t, s, d, B, Cin, Cout, c2, eps);
     AGF_LAUNCH_CHECK();
     return AGF_OK;
@@ -175,7 +184,7 @@ extern "C" int agf_style_demod_bwd(const float* s, const float* d, const float* 
     AGF_CHECK((size_t)4 * Cout * sizeof(float) <= 48 * 1024, "style_demod_bwd: Cout = %d is too large", Cout);
     AGF_CHECK(!dw || w, "style_demod_bwd: dw needs w");
     if (ds_raw)
-        hipLaunchKernelGGL(style_demod_bwd_ds_kernel, dim3((unsigned)agf_ceil_div(Cin, 64), (unsigned)agf_ceil_div(B, 4)), dim3(256),
+        hipLaunchKernelGGL(style_demod_bwd_ds_kernel, dim3((unsigned)agf_ceil_div(Cin, 64), (unsigned)agf_ceil_div(B, 4)), dim3(64 * STYLE_SL),
                            (size_t)4 * Cout * sizeof(float), (hipStream_t)stream, s, d, dd, ds, wsq, ds_raw, B, Cin, Cout, c2);
     if (dw)
         hipLaunchKernelGGL(style_demod_bwd_dw_kernel, dim3((unsigned)agf_ceil_div(Cin, 64), (unsigned)agf_ceil_div(Cout, 16)), dim3(256),
