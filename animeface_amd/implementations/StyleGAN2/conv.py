@@ -51,6 +51,65 @@ class KernelTimer:
         return out
 
 
+class ZeroArena:
+    """One pre-zeroed fp32 buffer per network half-step that hands out the zero-initialised scratch tensors of a backward pass (weight
+    gradients accumulated by atomics, per-channel sum buffers): ~90 fill launches per half-step become ONE.  ``reset()`` re-zeroes
+    the part used so far and rewinds; it is called when the half-step it serves starts again, i.e. an iteration later -- long after the
+    optimizer consumed (or autograd copied) every tensor handed out.  Requests beyond the capacity fall back to ``torch.zeros`` and
+    grow the buffer at the next reset."""
+
+    def __init__(self):
+        self.buf, self.off, self.want = None, 0, 0
+
+    def reset(self, device):
+        if self.buf is None or self.want > self.buf.numel() or self.buf.device != device:
+            n = max(int(self.want * 1.1) + 4096, 1 << 20)
+            self.buf = torch.zeros(n, dtype=torch.float32, device=device)
+        elif self.off:
+            self.buf[:self.off].zero_()
+        self.off, self.want = 0, 0
+
+    def take(self, shape, device):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        n_al = (n + 63) & ~63                                       # 256-byte granules
+        self.want += n_al
+        if self.buf is None or self.buf.device != device or self.off + n_al > self.buf.numel():
+            return torch.zeros(shape, dtype=torch.float32, device=device)
+        out = self.buf[self.off:self.off + n].view(shape)
+        self.off += n_al
+        return out
+
+
+_zero_arena = None
+_ARENA_ON = os.environ.get('AGF_ZERO_ARENA', '1') != '0'        # A/B switch
+
+
+class zero_arena:
+    """``with zero_arena(arena):`` -- fp32 zero scratch of the backward pass comes from ``arena`` (reset here) inside the block."""
+
+    def __init__(self, arena, device):
+        self.arena, self.device = arena, device
+
+    def __enter__(self):
+        global _zero_arena
+        self.prev = _zero_arena
+        self.arena.reset(self.device)
+        _zero_arena = self.arena
+        return self.arena
+
+    def __exit__(self, *a):
+        global _zero_arena
+        _zero_arena = self.prev
+
+
+def _zeros_f32(shape, device):
+    if _zero_arena is not None and _ARENA_ON:
+        return _zero_arena.take(tuple(shape), device)
+    return torch.zeros(shape, dtype=torch.float32, device=device)
+
+
 def _f32(t):
     return None if t is None else t.contiguous().float()
 
@@ -137,7 +196,7 @@ def conv2d_wgrad_raw(x, dy, ksize, in_scale=None, out_scale=None, scale=1.0):
         raise RuntimeError('conv2d_wgrad: x and dy must both be bfloat16 or both float32')
     x = x.contiguous(memory_format=torch.channels_last)
     dy = dy.contiguous(memory_format=torch.channels_last)
-    dw = torch.zeros((Cout, ksize, ksize, Cin), dtype=torch.float32, device=x.device).permute(0, 3, 1, 2)   # memory OHWI, one fill
+    dw = _zeros_f32((Cout, ksize, ksize, Cin), x.device).permute(0, 3, 1, 2)   # memory OHWI; zeroed by the arena's single fill
     in_scale, out_scale = _f32(in_scale), _f32(out_scale)
     timer = KernelTimer.active
     ev0 = timer.start() if timer is not None else None
@@ -259,7 +318,7 @@ def act_bwd_reduce_raw(dy, y, noise, alpha, want_sums):
     """One ``agf_act_bwd_reduce`` launch: g = dy * lrelu'(y) and (optionally) the three per-(n,c) sums."""
     N, C, H, W = y.shape
     g = torch.empty_like(y)
-    pool = torch.zeros((sum(bool(w) for w in want_sums), N, C), dtype=torch.float32, device=y.device) if any(want_sums) else None
+    pool = _zeros_f32((sum(bool(w) for w in want_sums), N, C), y.device) if any(want_sums) else None
     sums, j = [], 0
     for w in want_sums:                                       # one fill for all requested sum buffers
         sums.append(pool[j] if w else None)
@@ -276,7 +335,7 @@ def act_bwd_reduce_pooled_raw(dy_half, y, alpha, dy_scale, want_sum):
     N, C, H, W = y.shape
     assert dy_half.shape == (N, C, H // 2, W // 2) and dy_half.dtype == y.dtype
     g = torch.empty_like(y)
-    B = torch.zeros((N, C), dtype=torch.float32, device=y.device) if want_sum else None
+    B = _zeros_f32((N, C), y.device) if want_sum else None
     rc = _lib.lib().agf_act_bwd_reduce_pooled(_lib.ptr(dy_half), _lib.ptr(y), _lib.ptr(g), _lib.ptr(B),
                                               _lib.dtype_code(y), N, H, W, C, float(alpha), float(dy_scale), _lib.stream_ptr(y))
     _lib.check(rc, 'act_bwd_reduce_pooled')
@@ -287,7 +346,7 @@ def scale_dot_raw(x, t, s, want_dx=True):
     """One ``agf_scale_dot`` launch: dx = t * s[n,c], ds[n,c] = sum_hw x * t."""
     N, C, H, W = x.shape
     dx = torch.empty_like(t) if want_dx else None
-    ds = torch.zeros((N, C), dtype=torch.float32, device=x.device)
+    ds = _zeros_f32((N, C), x.device)
     rc = _lib.lib().agf_scale_dot(_lib.ptr(x), _lib.ptr(t), _lib.ptr(_f32(s)), _lib.ptr(dx), _lib.ptr(ds),
                                   _lib.dtype_code(x), N, H, W, C, _lib.stream_ptr(x))
     _lib.check(rc, 'scale_dot')
@@ -642,7 +701,7 @@ class _FusedConv(torch.autograd.Function):
             pre = ctx.pre_link
             if pre is not None and pre.armed and s_in is None and need_x and x.dtype == torch.bfloat16 and x.shape[1] % 8 == 0:
                 # x is the lrelu output of the producer this link came from and we are its only consumer: hand it the masked gradient
-                pre.bsum = torch.zeros(256, x.shape[1], dtype=torch.float32, device=x.device)
+                pre.bsum = _zeros_f32((256, x.shape[1]), x.device)
                 t = conv2d_fwd_raw(g, prep.wq_ft, in_scale=s_out, prepared=True, gain=pg, mask_y=x, mask_alpha=pre.alpha, mask_sum=pre.bsum,
                                    res_pooled=res_pooled, res_scale=res_scale)
                 pre.premasked = True

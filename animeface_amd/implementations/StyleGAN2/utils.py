@@ -22,7 +22,7 @@ from ...thirdparty.diffaugment import DiffAugment
 from ... import distributed as dp
 from ... import rng
 from .model import Generator, Discriminator, init_weight_N01
-from .conv import cached_weights, invalidate_cached
+from .conv import cached_weights, invalidate_cached, ZeroArena, zero_arena
 
 
 def pl_penalty(styles, images, pl_mean, scaler=None):
@@ -65,6 +65,7 @@ class TrainStep:
         self.r1_loss = r1_regularizer()
         self.pl_mean = 0.
         self.batches_done = 0
+        self._arena_D, self._arena_G = ZeroArena(), ZeroArena()        # zero-initialised backward scratch of the two half-steps
         import os
         self.merge_d_passes = os.environ.get('AGF_MERGE_D', '1') != '0'
         if hasattr(G, 'set_fused_epilogue'):
@@ -99,7 +100,8 @@ class TrainStep:
         # D-step's no-grad forward are still valid in the G-step; the discriminator's are dropped when its optimizer steps
         with cached_weights():
             # ---- discriminator (reference utils.py:60-86) ----
-            D_loss = self._d_half(real, it)
+            with zero_arena(self._arena_D, real.device):
+                D_loss = self._d_half(real, it)
             if self.reducer_D is not None:
                 self.reducer_D.finish()
             self.optimizer_D.step()
@@ -108,7 +110,8 @@ class TrainStep:
             # ---- generator (reference utils.py:88-113) ----
             for p in D.parameters():
                 p.requires_grad_(False)
-            G_loss, fake = self._g_half(real, it)
+            with zero_arena(self._arena_G, real.device):
+                G_loss, fake = self._g_half(real, it)
             for p in D.parameters():
                 p.requires_grad_(True)
         if self.reducer_G is not None:
