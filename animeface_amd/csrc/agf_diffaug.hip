@@ -15,13 +15,21 @@ __global__ void __launch_bounds__(256) diffaug_sum_kernel(const T* __restrict__ 
     const int b = blockIdx.y;
     int i0 = 0, i1 = H, j0 = 0, j1 = W;
     if (win) { i0 = win[b * 4]; i1 = win[b * 4 + 1]; j0 = win[b * 4 + 2]; j1 = win[b * 4 + 3]; }
-    const int64_t plane = (int64_t)H * W;
+    // a block walks whole image rows (no per-element index arithmetic): rows (c, i) with i inside the window, columns j0 .. j1
+    const int rows = C * (i1 - i0 > 0 ? i1 - i0 : 0);
+    const int hwin = i1 - i0;
     float acc = 0.f;
-    for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < (int64_t)C * plane; id += (int64_t)gridDim.x * 256) {
-        const int c = (int)(id / plane);
-        const int r = (int)(id - c * plane);
-        const int i = r / W, j = r - i * W;
-        if (i >= i0 && i < i1 && j >= j0 && j < j1) acc += Elem<T>::load(x + ((int64_t)b * C + c) * plane + r);
+    // thread = (row slot, 4-column group): 64 column groups x 4 row slots per pass, so a 256-wide row is one 16-byte-per-lane sweep and
+    // four rows are in flight per block
+    const int cg = threadIdx.x & 63, rs = threadIdx.x >> 6;
+#pragma unroll 2
+    for (int rr = blockIdx.x * 4 + rs; rr < rows; rr += gridDim.x * 4) {
+        const int c = rr / hwin, i = i0 + rr - c * hwin;
+        const T* row = x + (((int64_t)b * C + c) * H + i) * W;
+        for (int j = j0 + cg * 4; j < j1; j += 256) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) if (j + e < j1) acc += Elem<T>::load(row + j + e);
+        }
     }
     red[threadIdx.x] = acc;
     __syncthreads();
@@ -29,7 +37,7 @@ __global__ void __launch_bounds__(256) diffaug_sum_kernel(const T* __restrict__ 
         if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
         __syncthreads();
     }
-    if (threadIdx.x == 0) unsafeAtomicAdd(out + b, red[0]);
+    if (threadIdx.x == 0 && rows > 0) unsafeAtomicAdd(out + b, red[0]);
 }
 
 // prm [B][4] = {bo, ks, kc, M} (forward) or {-, ks, kc, Dm} (backward); shift [B][2] = {tx, ty} or null.
@@ -44,7 +52,8 @@ __global__ void __launch_bounds__(256) diffaug_apply_kernel(const T* __restrict_
     const int64_t plane = (int64_t)H * W;
     const float invC = 1.f / (float)C;
     for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < plane; r += (int64_t)gridDim.x * 256) {
-        const int i = (int)(r / W), j = (int)(r - (int64_t)i * W);
+        const int r32 = (int)r;                                        // a plane has < 2^31 pixels
+        const int i = r32 / W, j = r32 - i * W;
         const int si = BACKWARD ? i - tx : i + tx, sj = BACKWARD ? j - ty : j + ty;
         const bool inside = si >= 0 && si < H && sj >= 0 && sj < W;
         float v[8];
@@ -81,8 +90,9 @@ extern "C" int agf_diffaug_sum(const void* x, float* out, const int32_t* win, in
     AGF_CHECK(x && out, "diffaug_sum: null pointer");
     AGF_CHECK(dtype == AGF_F32 || dtype == AGF_BF16, "diffaug_sum: dtype must be f32 or bf16");
     AGF_CHECK(B >= 1 && C >= 1 && H >= 1 && W >= 1 && B <= 65535, "diffaug_sum: bad shape");
-    int64_t bx = agf_ceil_div((int64_t)C * H * W, 256 * 8);
-    if (bx > 64) bx = 64;
+    int64_t bx = agf_ceil_div((int64_t)C * H, 16);                    // ~16 image rows per block, 4 at a time
+    if (bx > 128) bx = 128;
+    if (bx < 1) bx = 1;
     dim3 grid((unsigned)bx, (unsigned)B);
     if (dtype == AGF_F32) hipLaunchKernelGGL((diffaug_sum_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, out, win, C, H, W);
     else hipLaunchKernelGGL((diffaug_sum_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, out, win, C, H, W);
