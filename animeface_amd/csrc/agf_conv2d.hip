@@ -19,61 +19,7 @@
 //
 // Fused on load : per-(n,ci) input scale (the style modulation), fp32 multiply, rounded once to bf16.
 // Fused on store: per-(n,co) output scale (demodulation), bias[co], noise[n,h,w], residual, leaky ReLU, gain.
-#include "agf_common.h"
-#include <stdlib.h>
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-#define BLOCK_PIX 256
-#define XNONE (-2147483647 - 1)     // "no load" marker of the precomputed patch offsets (real offsets can be negative: halo)
-
-static __device__ __forceinline__ u32x4 scale_vec8_reg(u32x4 val, f32x4 s0, f32x4 s1) {
-    float a0, a1;
-    Pack16<bf16_t>::unpack(val.x, a0, a1); val.x = Pack16<bf16_t>::pack(a0 * s0.x, a1 * s0.y);
-    Pack16<bf16_t>::unpack(val.y, a0, a1); val.y = Pack16<bf16_t>::pack(a0 * s0.z, a1 * s0.w);
-    Pack16<bf16_t>::unpack(val.z, a0, a1); val.z = Pack16<bf16_t>::pack(a0 * s1.x, a1 * s1.y);
-    Pack16<bf16_t>::unpack(val.w, a0, a1); val.w = Pack16<bf16_t>::pack(a0 * s1.z, a1 * s1.w);
-    return val;
-}
-
-static __device__ __forceinline__ u32x4 scale_vec8(u32x4 val, const float* sc) {
-    f32x4 s0 = *(const f32x4*)sc, s1 = *(const f32x4*)(sc + 4);
-    float a0, a1;
-    Pack16<bf16_t>::unpack(val.x, a0, a1); val.x = Pack16<bf16_t>::pack(a0 * s0.x, a1 * s0.y);
-    Pack16<bf16_t>::unpack(val.y, a0, a1); val.y = Pack16<bf16_t>::pack(a0 * s0.z, a1 * s0.w);
-    Pack16<bf16_t>::unpack(val.z, a0, a1); val.z = Pack16<bf16_t>::pack(a0 * s1.x, a1 * s1.y);
-    Pack16<bf16_t>::unpack(val.w, a0, a1); val.w = Pack16<bf16_t>::pack(a0 * s1.z, a1 * s1.w);
-    return val;
-}
-
-struct ConvParams {
-    const bf16_t* x;          // [N,H,W,Cin]
-    const bf16_t* w;          // [Cout,KS,KS,Cin]
-    bf16_t* y;                // [N,H,W,Cout]
-    const float* in_scale;    // [N,Cin] or null
-    const float* out_scale;   // [N,Cout] or null
-    const float* bias;        // [Cout] or null
-    const float* noise;       // [N,H,W] or null
-    const bf16_t* residual;   // [N,H,W,Cout] or null
-    int N, H, W, Cin, Cout;
-    int TI, TH, TW;           // pixel tile
-    int tilesW, tilesH, tilesN, tilesCo, pixTiles;
-    int act;                  // 1 linear, 3 lrelu
-    float alpha, gain;
-    const bf16_t* mask_y;     // fused lrelu gradient (agf_conv2d_fwd_mask): y *= mask_y > 0 ? 1 : mask_alpha; null = off
-    float mask_alpha;
-    float* mask_sum;          // [256][Cout] fp32: += sum over pixels of the masked output (nullable)
-    const bf16_t* res_pooled; // [N,H/2,W/2,Cout]: y += res_scale * res_pooled[h/2,w/2] before the mask (the adjoint of a 2x2 average that shares
-    float res_scale;          //   this conv's input: the other branch of a residual block); null = off
-    int vecStore;             // epilogue: transpose through LDS and store 16-byte vectors (needs Cout % 8 == 0, y 16-byte aligned)
-    int hoist;                // A/B switch: hoist the style-scale loads out of the per-vector staging loop
-    int wsSlices;             // ping-pong weight-stationary kernel: blocks per image
-    int twShift, thShift;     // TW = 1 << twShift, TH = 1 << thShift (both are powers of two)
-    uint32_t mPW, mPH;        // magic multipliers for division by PW, PH (operands < 2^16)
-    int flat, flatTiles;      // flat tiling: a tile = 256 consecutive pixels (row-major) of one image; flatTiles = tiles per image
-    uint32_t mW;              // magic multiplier for division by W (flat tiling)
-};
+#include "agf_conv2d_common.h"
 
 // ---- epilogue shared by conv2d_fwd_kernel and conv2d_fwd_dl_kernel.  A lane holds, per accumulator tile, ONE pixel (column) x 4
 //      groups of 4 consecutive channels: written
@@ -218,6 +164,178 @@ static __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16
     }
 }
 
+// ---- register-only epilogue (vecStore == 2).  In the 32x32 MFMA result layout lanes l and l+32 hold the SAME pixel and the channel
+//      groups +0..3 / +4..7 of every 8-channel group, so ONE v_permlane32_swap per packed register pair turns two 8-byte pieces into a
+//      16-byte vector of 8 consecutive channels (lower half-wave: group 2q, upper half-wave: group 2q+1) -- no LDS round trip, no fences,
+//      no per-pixel index headers.  A store instruction then covers 32 pixels x 32 contiguous bytes.  Operands that do not depend on the
+//      accumulators (the lrelu mask of agf_conv2d_fwd_mask, noise) are requested before any arithmetic so that ONE memory latency is
+//      exposed per tile instead of one per 32-pixel strip.
+//      Channel sums of the masked output: 16*MT values per lane, reduced over the 32 lanes of a half-wave with a halving butterfly
+//      (each step a lane keeps the half of the values its lane bit selects: 16*MT - 1 shuffles instead of 5 * 16*MT). ----
+template <int MT, int NJ>
+static __device__ __forceinline__ void conv_epilogue_pl(const ConvParams& p, f32x16 (&acc)[MT][NJ], unsigned char* smem_raw,
+                                                        int wave, int lane, int wm, int wn, int n0, int h0, int w0, int flatP0, int co0,
+                                                        int nwn, int nwaves, int slot) {
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int coW = co0 + wm * 32 * MT;
+    int64_t pixIdx[NJ]; int nimg[NJ]; bool valid[NJ]; float nz[NJ]; int hw2[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+        const int q = wn * (32 * NJ) + j * 32 + l31;
+        int c, r, ti;
+        if (p.flat) { const int pg = flatP0 + q; const int row = (int)__umulhi((uint32_t)pg, p.mW); c = pg - row * p.W; r = row - h0; ti = 0; }
+        else { c = q & (p.TW - 1); r = (q >> p.twShift) & (p.TH - 1); ti = q >> (p.twShift + p.thShift); }
+        const int n = n0 + ti, h = h0 + r, w = w0 + c;
+        hw2[j] = (h >> 1) * (p.W >> 1) + (w >> 1);                        // the pixel's 2x2 cell in a pooled map
+        valid[j] = n < p.N && h < p.H && w < p.W;
+        pixIdx[j] = valid[j] ? ((int64_t)n * p.H + h) * p.W + w : 0;
+        nimg[j] = valid[j] ? n : 0;
+        nz[j] = p.noise ? p.noise[pixIdx[j]] : 0.f;
+    }
+    // the mask operand: this lane's post-swap vectors (pixel j, channel group (i, 2q + lhi))
+    u32x4 mk[NJ][MT][2];
+    if (p.mask_y) {
+#pragma unroll
+        for (int j = 0; j < NJ; j++)
+#pragma unroll
+            for (int i = 0; i < MT; i++)
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const int cb = coW + i * 32 + (2 * q + lhi) * 8;
+                    mk[j][i][q] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+                    if (valid[j] && cb < p.Cout) mk[j][i][q] = *(const u32x4*)(p.mask_y + pixIdx[j] * p.Cout + cb);
+                }
+    }
+    float msum[MT * 16];
+#pragma unroll
+    for (int e = 0; e < MT * 16; e++) msum[e] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+        const int64_t pi = pixIdx[j];
+        const int n = nimg[j];
+        u32x4 rp[MT][2];
+        if (p.res_pooled) {
+            // gradient of the pooled skip branch, read at half resolution (no upsampled tensor, no separate add)
+            const int64_t qi = (int64_t)n * (p.H >> 1) * (p.W >> 1) + hw2[j];
+#pragma unroll
+            for (int i = 0; i < MT; i++)
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const int cb = coW + i * 32 + (2 * q + lhi) * 8;
+                    rp[i][q] = u32x4{0u, 0u, 0u, 0u};
+                    if (valid[j] && cb < p.Cout) rp[i][q] = *(const u32x4*)(p.res_pooled + qi * p.Cout + cb);
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < MT; i++) {
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                uint32_t P[2][2];
+#pragma unroll
+                for (int r2 = 0; r2 < 2; r2++) {
+                    const int rg = 2 * q + r2;
+                    const int co = coW + i * 32 + rg * 8 + lhi * 4;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = acc[i][j][rg * 4 + e];
+                    if (co < p.Cout) {
+                        if (p.out_scale) {
+                            const f32x4 s = *(const f32x4*)(p.out_scale + (int64_t)n * p.Cout + co);
+                            v[0] *= s.x; v[1] *= s.y; v[2] *= s.z; v[3] *= s.w;
+                        }
+                        if (p.bias) {
+                            const f32x4 bb = *(const f32x4*)(p.bias + co);
+                            v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; e++) v[e] += nz[j];
+                        if (p.residual && valid[j]) {
+                            const u32x2 rr = *(const u32x2*)(p.residual + pi * p.Cout + co);
+                            float a0, a1;
+                            Pack16<bf16_t>::unpack(rr.x, a0, a1); v[0] += a0; v[1] += a1;
+                            Pack16<bf16_t>::unpack(rr.y, a0, a1); v[2] += a0; v[3] += a1;
+                        }
+                        if (p.act == 3) {
+#pragma unroll
+                            for (int e = 0; e < 4; e++) v[e] = v[e] > 0.f ? v[e] : v[e] * p.alpha;
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; e++) v[e] *= p.gain;
+                    }
+                    P[r2][0] = Pack16<bf16_t>::pack(v[0], v[1]);
+                    P[r2][1] = Pack16<bf16_t>::pack(v[2], v[3]);
+                }
+                // lanes < 32 end up with channel group 2q (their own +0..3, the partner's +4..7), lanes >= 32 with group 2q+1
+                const auto s0 = __builtin_amdgcn_permlane32_swap(P[0][0], P[1][0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(P[0][1], P[1][1], false, false);
+                u32x4 val = {s0[0], s1[0], s0[1], s1[1]};
+                const int cb = coW + i * 32 + (2 * q + lhi) * 8;
+                if (p.res_pooled || p.mask_y) {
+                    float g[8];
+                    Pack16<bf16_t>::unpack(val.x, g[0], g[1]); Pack16<bf16_t>::unpack(val.y, g[2], g[3]);
+                    Pack16<bf16_t>::unpack(val.z, g[4], g[5]); Pack16<bf16_t>::unpack(val.w, g[6], g[7]);
+                    if (p.res_pooled) {
+                        float rv[8];
+                        Pack16<bf16_t>::unpack(rp[i][q].x, rv[0], rv[1]); Pack16<bf16_t>::unpack(rp[i][q].y, rv[2], rv[3]);
+                        Pack16<bf16_t>::unpack(rp[i][q].z, rv[4], rv[5]); Pack16<bf16_t>::unpack(rp[i][q].w, rv[6], rv[7]);
+#pragma unroll
+                        for (int e = 0; e < 8; e++) g[e] += rv[e] * p.res_scale;
+                    }
+                    if (p.mask_y) {
+                        // the layer below's lrelu gradient, applied where the gradient tensor is produced
+                        float a[8];
+                        Pack16<bf16_t>::unpack(mk[j][i][q].x, a[0], a[1]); Pack16<bf16_t>::unpack(mk[j][i][q].y, a[2], a[3]);
+                        Pack16<bf16_t>::unpack(mk[j][i][q].z, a[4], a[5]); Pack16<bf16_t>::unpack(mk[j][i][q].w, a[6], a[7]);
+                        const bool live = valid[j] && cb < p.Cout;
+#pragma unroll
+                        for (int e = 0; e < 8; e++) {
+                            g[e] = a[e] > 0.f ? g[e] : g[e] * p.mask_alpha;
+                            msum[(i * 2 + q) * 8 + e] += live ? g[e] : 0.f;
+                        }
+                    }
+                    val.x = Pack16<bf16_t>::pack(g[0], g[1]); val.y = Pack16<bf16_t>::pack(g[2], g[3]);
+                    val.z = Pack16<bf16_t>::pack(g[4], g[5]); val.w = Pack16<bf16_t>::pack(g[6], g[7]);
+                }
+                if (valid[j] && cb < p.Cout) *(u32x4*)(p.y + pi * p.Cout + cb) = val;
+            }
+        }
+    }
+    if (p.mask_y && p.mask_sum) {             // block-uniform
+        // halving butterfly over the 32 lanes of each half-wave: after step m a lane keeps the half of the remaining values that its
+        // bit m selects, so lane l ends with the total of value index  bit0*NV/2 + bit1*NV/4 + ...  (NV = 16*MT values per lane)
+        constexpr int NV = MT * 16;
+        int live = NV, idx = 0, m = 1;
+#pragma unroll
+        for (; live > 1; live >>= 1, m <<= 1) {
+            const bool up = (lane & m) != 0;
+            const int half = live >> 1;
+#pragma unroll
+            for (int k = 0; k < NV / 2; k++) {
+                if (k < half) {
+                    const float send = up ? msum[k] : msum[k + half];
+                    const float keep = up ? msum[k + half] : msum[k];
+                    msum[k] = keep + __shfl_xor(send, m);
+                }
+            }
+            idx += up ? half : 0;
+        }
+#pragma unroll
+        for (; m < 32; m <<= 1) msum[0] += __shfl_xor(msum[0], m);          // MT == 1: lane bit 4 is left over
+        // add the waves that share the channels through LDS, then ONE atomic per channel and block into slot (pixel tile % 256)
+        __syncthreads();                                                   // every wave is done reading sW / sX
+        float* red = (float*)smem_raw;                                     // [nwaves][64]
+        red[wave * 64 + lane] = msum[0];
+        __syncthreads();
+        const int ci = idx >> 3, e = idx & 7;                              // value index -> (i * 2 + q, e)
+        const int co = coW + (ci >> 1) * 32 + (2 * (ci & 1) + lhi) * 8 + e;
+        if (wn == 0 && (MT == 2 || l31 < 16) && co < p.Cout) {
+            float v = 0.f;
+            for (int k = 0; k < nwn; k++) v += red[(wm * nwn + k) * 64 + lane];
+            unsafeAtomicAdd(p.mask_sum + (int64_t)slot * p.Cout + co, v);
+        }
+    }
+}
+
 // NWN = waves along the pixel axis (2 or 4): block = 2 x NWN waves, tile = (64*MT) co x (128*NWN) pixels.
 //   <MT=1, NWN=2>: 64 co x 256 px, 4 waves, 73 KB LDS -> two blocks per CU            (default)
 //   <MT=2, NWN=4>: 128 co x 512 px, 8 waves (2 per SIMD), 141 KB LDS, one block per CU: half the staging traffic and
@@ -241,9 +359,11 @@ __global__ void __launch_bounds__(64 * NWM * NWN, OCC) conv2d_fwd_kernel(ConvPar
     // ---- block -> (pixel tile, co tile): co tiles of one pixel tile are consecutive slots of one XCD ----
     const int b = blockIdx.x;
     const int xcd = b & 7, slot = b >> 3;
-    const int pixTile = (slot / p.tilesCo) * 8 + xcd;
+    // xcdBand: XCD x owns the contiguous band of pixel tiles [x * xcdBand, (x+1) * xcdBand) -- tiles that share halo rows run on
+    // the same XCD at about the same time, so its L2 serves the halo re-reads; 0 = tiles interleaved over the XCDs
+    const int pixTile = p.xcdBand ? xcd * p.xcdBand + slot / p.tilesCo : (slot / p.tilesCo) * 8 + xcd;
     const int coTile = slot % p.tilesCo;
-    if (pixTile >= p.pixTiles) return;
+    if (pixTile >= p.pixTiles || (p.xcdBand && slot / p.tilesCo >= p.xcdBand)) return;
     // rectangular tiling: (TI images) x TH x TW pixels.  Flat tiling (maps whose width is not a multiple of the tile: StyleGAN3's
     // 38 / 54 / 66 / 86-wide maps waste up to half of a rectangular tile): 128*NWN consecutive pixels of one image in row-major
     // order; the patch is then the rows they touch plus halo, TW = W and TH = the most rows a tile can span.
@@ -411,7 +531,8 @@ __global__ void __launch_bounds__(64 * NWM * NWN, OCC) conv2d_fwd_kernel(ConvPar
         }
     }
 
-    conv_epilogue<MT, NJ>(p, acc, smem_raw, wave, lane, wm, wn, n0, h0, w0, flatP0, co0, NWN, NWM * NWN, pixTile & 255);
+    if (p.vecStore == 2) conv_epilogue_pl<MT, NJ>(p, acc, smem_raw, wave, lane, wm, wn, n0, h0, w0, flatP0, co0, NWN, NWM * NWN, pixTile & 255);
+    else conv_epilogue<MT, NJ>(p, acc, smem_raw, wave, lane, wm, wn, n0, h0, w0, flatP0, co0, NWN, NWM * NWN, pixTile & 255);
 }
 
 
@@ -443,9 +564,11 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_dl_kernel(ConvPa
 
     const int b = blockIdx.x;
     const int xcd = b & 7, slot = b >> 3;
-    const int pixTile = (slot / p.tilesCo) * 8 + xcd;
+    // xcdBand: XCD x owns the contiguous band of pixel tiles [x * xcdBand, (x+1) * xcdBand) -- tiles that share halo rows run on
+    // the same XCD at about the same time, so its L2 serves the halo re-reads; 0 = tiles interleaved over the XCDs
+    const int pixTile = p.xcdBand ? xcd * p.xcdBand + slot / p.tilesCo : (slot / p.tilesCo) * 8 + xcd;
     const int coTile = slot % p.tilesCo;
-    if (pixTile >= p.pixTiles) return;
+    if (pixTile >= p.pixTiles || (p.xcdBand && slot / p.tilesCo >= p.xcdBand)) return;
     int tq = pixTile;
     const int tw = tq % p.tilesW; tq /= p.tilesW;
     const int th = tq % p.tilesH;
@@ -564,7 +687,8 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_dl_kernel(ConvPa
             __syncthreads();                                          // ... and so have everyone's; everyone is done with `cur`
         }
     }
-    conv_epilogue<MT, NJ>(p, acc, smem_raw, wave, lane, wm, wn, n0, h0, w0, 0, co0, NWN, NWM * NWN, pixTile & 255);
+    if (p.vecStore == 2) conv_epilogue_pl<MT, NJ>(p, acc, smem_raw, wave, lane, wm, wn, n0, h0, w0, 0, co0, NWN, NWM * NWN, pixTile & 255);
+    else conv_epilogue<MT, NJ>(p, acc, smem_raw, wave, lane, wm, wn, n0, h0, w0, 0, co0, NWN, NWM * NWN, pixTile & 255);
 }
 
 template <int KS, int MT, int NWN, int PMAX, int NWM, int NJ>
@@ -1386,8 +1510,15 @@ static int conv2d_fwd_impl(const void* x, const void* w, void* y,
         }
     }
     { static int h = -1; if (h < 0) { const char* e = getenv("AGF_CONV_HOIST"); h = e ? atoi(e) : 1; } p.hoist = h; }
-    { static const int vs = []{ const char* e = getenv("AGF_CONV_VSTORE"); return e ? atoi(e) : 1; }();
-      p.vecStore = (vs || mask_y || res_pooled) && (Cout % 8) == 0 && ((uintptr_t)y % 16) == 0; }
+    p.xcdBand = 0;
+    { static const int vs = []{ const char* e = getenv("AGF_CONV_VSTORE"); return e ? atoi(e) : 2; }();     // 2: register-only (permlane32), 1: through LDS, 0: direct
+      p.vecStore = ((vs || mask_y || res_pooled) && (Cout % 8) == 0 && ((uintptr_t)y % 16) == 0) ? (vs == 2 ? 2 : 1) : 0; }
+    if (ksize == 3) {
+        // high-resolution, few-channel layers: the persistent multi-stage kernel (agf_conv2d_pipe.hip)
+        const int rc = agf_conv2d_pipe_launch(p, (hipStream_t)stream);
+        if (rc == AGF_OK) { AGF_LAUNCH_CHECK(); return AGF_OK; }
+        if (rc != AGF_ENOKERNEL) return rc;
+    }
     // Two tilings.  Large: 128 co x 512 px (16x32 pixel tile), 8 waves -- when the map is at least 16x32, there are at
     // least 128 output channels and the grid still fills the chip (>= 384 blocks).  Default: 64 co x 256 px, 4 waves.
     int MT = 1;
@@ -1435,6 +1566,8 @@ static int conv2d_fwd_impl(const void* x, const void* w, void* y,
         }
     }
     p.tilesCo = (Cout + 64 * MT - 1) / (64 * MT);
+    { static const int band = []{ const char* e = getenv("AGF_CONV_XCDBAND"); return e ? atoi(e) : 1; }();
+      p.xcdBand = (band && p.pixTiles >= 64) ? (p.pixTiles + 7) / 8 : 0; }
     p.twShift = 0; while ((1 << p.twShift) < p.TW) p.twShift++;
     p.thShift = 0; while ((1 << p.thShift) < p.TH) p.thShift++;
     {

@@ -1,0 +1,61 @@
+// Declarations shared by the MFMA convolution translation units (agf_conv2d.hip, agf_conv2d_pipe.hip).
+#pragma once
+#include "agf_common.h"
+#include <stdlib.h>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define BLOCK_PIX 256
+#define XNONE (-2147483647 - 1)     // "no load" marker of the precomputed patch offsets (real offsets can be negative: halo)
+
+static __device__ __forceinline__ u32x4 scale_vec8_reg(u32x4 val, f32x4 s0, f32x4 s1) {
+    float a0, a1;
+    Pack16<bf16_t>::unpack(val.x, a0, a1); val.x = Pack16<bf16_t>::pack(a0 * s0.x, a1 * s0.y);
+    Pack16<bf16_t>::unpack(val.y, a0, a1); val.y = Pack16<bf16_t>::pack(a0 * s0.z, a1 * s0.w);
+    Pack16<bf16_t>::unpack(val.z, a0, a1); val.z = Pack16<bf16_t>::pack(a0 * s1.x, a1 * s1.y);
+    Pack16<bf16_t>::unpack(val.w, a0, a1); val.w = Pack16<bf16_t>::pack(a0 * s1.z, a1 * s1.w);
+    return val;
+}
+
+static __device__ __forceinline__ u32x4 scale_vec8(u32x4 val, const float* sc) {
+    f32x4 s0 = *(const f32x4*)sc, s1 = *(const f32x4*)(sc + 4);
+    float a0, a1;
+    Pack16<bf16_t>::unpack(val.x, a0, a1); val.x = Pack16<bf16_t>::pack(a0 * s0.x, a1 * s0.y);
+    Pack16<bf16_t>::unpack(val.y, a0, a1); val.y = Pack16<bf16_t>::pack(a0 * s0.z, a1 * s0.w);
+    Pack16<bf16_t>::unpack(val.z, a0, a1); val.z = Pack16<bf16_t>::pack(a0 * s1.x, a1 * s1.y);
+    Pack16<bf16_t>::unpack(val.w, a0, a1); val.w = Pack16<bf16_t>::pack(a0 * s1.z, a1 * s1.w);
+    return val;
+}
+
+struct ConvParams {
+    const bf16_t* x;          // [N,H,W,Cin]
+    const bf16_t* w;          // [Cout,KS,KS,Cin]
+    bf16_t* y;                // [N,H,W,Cout]
+    const float* in_scale;    // [N,Cin] or null
+    const float* out_scale;   // [N,Cout] or null
+    const float* bias;        // [Cout] or null
+    const float* noise;       // [N,H,W] or null
+    const bf16_t* residual;   // [N,H,W,Cout] or null
+    int N, H, W, Cin, Cout;
+    int TI, TH, TW;           // pixel tile
+    int tilesW, tilesH, tilesN, tilesCo, pixTiles;
+    int act;                  // 1 linear, 3 lrelu
+    float alpha, gain;
+    const bf16_t* mask_y;     // fused lrelu gradient (agf_conv2d_fwd_mask): y *= mask_y > 0 ? 1 : mask_alpha; null = off
+    float mask_alpha;
+    float* mask_sum;          // [256][Cout] fp32: += sum over pixels of the masked output (nullable)
+    const bf16_t* res_pooled; // [N,H/2,W/2,Cout]: y += res_scale * res_pooled[h/2,w/2] before the mask (the adjoint of a 2x2 average that shares
+    float res_scale;          //   this conv's input: the other branch of a residual block); null = off
+    int vecStore;             // epilogue: transpose through LDS and store 16-byte vectors (needs Cout % 8 == 0, y 16-byte aligned)
+    int hoist;                // A/B switch: hoist the style-scale loads out of the per-vector staging loop
+    int wsSlices;             // ping-pong weight-stationary kernel: blocks per image
+    int twShift, thShift;     // TW = 1 << twShift, TH = 1 << thShift (both are powers of two)
+    uint32_t mPW, mPH;        // magic multipliers for division by PW, PH (operands < 2^16)
+    int flat, flatTiles;      // flat tiling: a tile = 256 consecutive pixels (row-major) of one image; flatTiles = tiles per image
+    uint32_t mW;              // magic multiplier for division by W (flat tiling)
+    int xcdBand;              // pixel tiles per XCD (contiguous bands), 0 = interleaved
+};
+
+// persistent multi-stage direct-to-LDS kernel (agf_conv2d_pipe.hip); AGF_ENOKERNEL = shape not covered, use the other kernels
+int agf_conv2d_pipe_launch(const ConvParams& p, hipStream_t st);

@@ -1,0 +1,446 @@
+// Persistent, multi-stage direct-to-LDS MFMA convolution for the high-resolution, few-channel layers (3x3, stride 1, "same";
+// Cin in {32, 64, 128}, Cout <= 64 per block) -- the layers whose time is set by HBM streaming, not by the matrix pipe.
+//
+// What limited conv2d_fwd_dl_kernel on these shapes (64 -> 64 @256x256: 27 % MFMA busy, 2.2 TB/s): one K chunk of look-ahead against
+// a loaded-memory latency of 2-3 us, a full `vmcnt(0)` drain per chunk, and at every tile boundary a cold prologue (loads issued,
+// then waited for) plus an epilogue during which the block has nothing in flight.  Here
+//   * one block per CU lives for the whole launch and walks its tiles; the (tile, K chunk) stages form ONE continuous pipeline of
+//     NSTAGE LDS buffers filled by `buffer_load ... lds`: the loads of the next tile's first chunks are in flight while the current
+//     tile is contracted and stored -- NSTAGE-1 stages (~3 x 38 KB per CU) of look-ahead everywhere;
+//   * waits are partial: `s_waitcnt vmcnt(N)` with N = the number of vector-memory operations this wave issued AFTER the stage it
+//     needs (memory operations retire in order on gfx9-class hardware, so the N youngest may stay in flight).  For N to be a
+//     compile-time constant every operation is issued unconditionally: DMA beyond the work list, absent epilogue operands and
+//     out-of-image pixels use out-of-range buffer offsets (loads return zeros, stores are dropped); the chunk loop is unrolled
+//     (NCH = Cin / 16 is a template parameter) and `__builtin_amdgcn_sched_barrier` pins the issue order the counts assume;
+//   * epilogue operands (lrelu mask / pooled residual of agf_conv2d_fwd_mask, or demodulation scale + bias + noise) are requested
+//     one or two chunks before the tile's last MFMA, the results leave as 16-byte vectors straight from registers
+//     (v_permlane32_swap, see conv_epilogue_pl in agf_conv2d.hip) -- no LDS round trip, no per-tile block barrier;
+//   * the blocks of one XCD sweep a contiguous band of pixel tiles together, so halo rows are re-read from that XCD's L2.
+// Style-modulated layers use per-image weights (w + n * wImgStride: W * s[n] prepared by agf_prep_weights_mod), so the activation
+// path stays a pure DMA stream.
+#include "agf_conv2d_common.h"
+#include <utility>
+
+typedef __attribute__((address_space(3))) void* lds_ptr;
+
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>) (the chunk index feeds s_waitcnt immediates)
+template <int... I, class F>
+static __device__ __forceinline__ void pipe_static_for(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+
+struct PipeParams {
+    ConvParams c;
+    int tilesWl2, tilesHl2;     // log2(tiles per row), log2(tiles per column) of one image
+    int band;                   // pixel tiles per XCD (contiguous)
+    long long wImgStride;       // elements between per-image weight tensors (0 = one shared tensor)
+};
+
+#define PIPE_OOB 0x7fff0000
+
+template <int V> static __device__ __forceinline__ void pipe_wait_vm() {
+    static_assert(V >= 0 && V <= 63, "vmcnt immediate out of range");
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(V) : "memory");
+}
+
+// vector-memory operations a wave issues after the DMA group of the stage it waits for at chunk c of a tile (steady state):
+// per iteration [P prefetch loads if chunk == PF] [LPW DMA] ... [S stores if chunk == NCH-1]; the group was issued NS-1 iterations ago
+template <int NCH, int NS>
+static constexpr int pipe_younger(int c, int lpw, int P, int S, int PF) {
+    int n = (NS - 2) * lpw;
+    for (int j = 1; j <= NS - 2; j++) if ((((c - j) % NCH) + NCH) % NCH == PF) n += P;
+    for (int j = 1; j <= NS - 1; j++) if ((((c - j) % NCH) + NCH) % NCH == NCH - 1) n += S;
+    return n;
+}
+
+// MT x NWM: 32-channel blocks per wave / waves along co; NWN waves along pixels x NJ 32-pixel sub-tiles each; NCH K chunks of 16.
+// EPI: 0 = forward epilogue (demodulation scale, bias, noise, lrelu, gain), 1 = + lrelu mask of the layer below (agf_conv2d_fwd_mask),
+//      2 = mask + pooled residual.  The per-channel operands of EPI 0 (out_scale[n], bias) travel as two extra 256-byte DMA loads
+//      into a 512-byte tail of every stage buffer and are read from LDS: no registers, no vmcnt entanglement.
+template <int KS, int MT, int NWM, int NWN, int NJ, int NCH, int NSTAGE, int PMAX, int EPI>
+__global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_pipe_kernel(PipeParams pp) {
+    const ConvParams& p = pp.c;
+    constexpr int NW = NWM * NWN;
+    constexpr int TAPS = KS * KS, HALO = KS / 2, BM = 32 * NWM * MT;
+    constexpr int WTOT = TAPS * BM * 2;                  // 16-byte vectors of one weight chunk
+    constexpr int XTOT = PMAX * 2;
+    static_assert(WTOT % 64 == 0, "weight chunk must be whole wave-loads");
+    constexpr int WG = WTOT / 64;                        // wave-loads that carry weights
+    constexpr int NG = WG + (XTOT + 63) / 64;            // 1 KB wave-loads per stage
+    constexpr int SIDE_E = NG * 64 * 8;                  // after the wave-loads (whose last, partial one zero-fills up to here):
+    constexpr int STAGE_E = SIDE_E + 256;                //   float side[2][64] = out_scale[n], bias; elements per stage buffer
+    constexpr int NOPS = NG + 2;                         // DMA operations per stage: the wave-loads + the two side loads
+    constexpr int LPW_HI = (NOPS + NW - 1) / NW, LPW_LO = NOPS / NW;
+    constexpr int KG = LPW_HI;
+    constexpr int PA = MT * NJ * 2;                      // 16-byte vectors of the tile's mask (pooled residual) per lane
+    constexpr int PCNT = EPI == 0 ? NJ : EPI * PA;       // prefetch loads per wave and tile
+    constexpr int SCNT = 2 * MT * NJ;                    // stores per wave and tile
+    constexpr int PF = NCH >= 2 ? NCH - 2 : 0;           // chunk at whose start the epilogue operands are requested
+    constexpr int TCONS = (NSTAGE - 1 + NCH - 1) / NCH;  // first tiles: the conservative wait count (operations of the prologue)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* sS = (bf16_t*)smem_raw;                      // [NSTAGE][STAGE_E]
+    float* red = (float*)(smem_raw + (size_t)NSTAGE * STAGE_E * 2);        // [NW][64]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / NWN, wn = wave % NWN;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int PW = p.TW + 2 * HALO;
+    const int P = (p.TH + 2 * HALO) * PW;
+
+    // ---- this block's tiles: XCD x sweeps the band [x * band, (x+1) * band) with all of its blocks side by side ----
+    const int xcd = blockIdx.x & 7, kx = blockIdx.x >> 3, nPer = gridDim.x >> 3;
+    const int bandEnd = (xcd + 1) * pp.band < p.pixTiles ? (xcd + 1) * pp.band : p.pixTiles;
+    const int tFirst = xcd * pp.band + kx;
+    const int mTiles = tFirst < bandEnd ? (bandEnd - tFirst + nPer - 1) / nPer : 0;
+    if (mTiles == 0) return;
+    const bool hiWave = wave < (NOPS % NW == 0 ? NW : NOPS % NW);   // this wave issues LPW_HI (else LPW_LO) DMA loads per stage
+
+    // ---- chunk-invariant DMA geometry of this lane's wave-loads ----
+    int goff[KG];         // weights: byte offset at chunk 0 (or OOB); activations: byte offset relative to the tile's first pixel
+    int gpos[KG];         // activations: (patch row << 16) | patch column, -1 = beyond the patch
+#pragma unroll
+    for (int k = 0; k < KG; k++) {
+        const int g64 = wave + k * NW;
+        const int v = g64 * 64 + lane;
+        goff[k] = PIPE_OOB; gpos[k] = -1;
+        if (g64 < WG) {
+            const int row = v >> 1, half = (v & 1) ^ ((row >> 3) & 1);
+            const int tap = row / BM, co = row - tap * BM;
+            if (co < p.Cout) goff[k] = ((co * TAPS + tap) * p.Cin + half * 8) * 2;
+        } else if (g64 < NG) {
+            const int vx = v - WTOT;
+            const int pix = vx >> 1, half = (vx & 1) ^ ((pix >> 3) & 1);
+            if (pix < P) {
+                const int pr = pix / PW, pc = pix - pr * PW;
+                gpos[k] = (pr << 16) | pc;
+                goff[k] = (((pr - HALO) * p.W + (pc - HALO)) * p.Cin + half * 8) * 2;
+            }
+        }
+    }
+    const int imgBytes = p.H * p.W * p.Cin * 2;
+    const int wBytes = p.Cout * TAPS * p.Cin * 2;
+
+    auto issue = [&](int ord, int ich, int buf) {
+        const bool live = ord < mTiles;
+        const int pt = tFirst + (live ? ord : 0) * nPer;
+        const int tw = pt & ((1 << pp.tilesWl2) - 1), th = (pt >> pp.tilesWl2) & ((1 << pp.tilesHl2) - 1), n0 = pt >> (pp.tilesWl2 + pp.tilesHl2);
+        const int h0 = th * p.TH, w0 = tw * p.TW;
+        const bool interior = h0 >= HALO && w0 >= HALO && h0 + p.TH + HALO <= p.H && w0 + p.TW + HALO <= p.W;
+        const __amdgpu_buffer_rsrc_t xRes = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (int64_t)n0 * p.H * p.W * p.Cin), 0, live ? imgBytes : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t wRes = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + (int64_t)n0 * pp.wImgStride), 0, live ? wBytes : 0, 0x00020000);
+        // (the chunk's byte offset is made opaque: as a compile-time constant it would be folded into NCH x KG loop-invariant
+        //  per-lane offsets that live in registers across the whole tile loop)
+        int chOff = ich * 32;
+        asm volatile("" : "+s"(chOff));
+        const int tileOrg = (h0 * p.W + w0) * p.Cin * 2 + chOff;
+        bf16_t* dst = sS + buf * STAGE_E;
+#pragma unroll
+        for (int k = 0; k < KG; k++) {
+            const int g64 = wave + k * NW;
+            if (k < LPW_LO || hiWave) {
+                if (g64 >= NG) {
+                    // operation NG: out_scale[n0][lane], operation NG + 1: bias[lane] -> side[g64 - NG][lane] (zeros when absent)
+                    const bool isB = g64 > NG;
+                    const float* src = isB ? p.bias : (p.out_scale ? p.out_scale + (int64_t)n0 * p.Cout : nullptr);
+                    const __amdgpu_buffer_rsrc_t sRes = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (live && src) ? p.Cout * 4 : 0, 0x00020000);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(sRes, (lds_ptr)(dst + SIDE_E + (g64 - NG) * 128), 4, lane * 4, 0, 0, 0);
+                } else if (g64 < WG) {
+                    // (the offset goes through a local: passing an element of a template-sized array straight into the builtin from inside a
+                    //  lambda makes this clang drop the kernel's HOST stub without a diagnostic)
+                    const int off = goff[k] + chOff;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(wRes, (lds_ptr)(dst + g64 * 64 * 8), 16, off, 0, 0, 0);
+                } else {
+                    int off = PIPE_OOB;
+                    if (gpos[k] >= 0) {
+                        const int h = h0 + (gpos[k] >> 16) - HALO, w = w0 + (gpos[k] & 0xffff) - HALO;
+                        if (interior || (h >= 0 && h < p.H && w >= 0 && w < p.W)) off = tileOrg + goff[k];
+                    }
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xRes, (lds_ptr)(dst + g64 * 64 * 8), 16, off, 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    // ---- fragment addresses (tile-invariant): swizzled 32-byte rows as in conv2d_fwd_dl_kernel ----
+    int bPix[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+        const int q = wn * (32 * NJ) + j * 32 + l31;
+        bPix[j] = ((q >> p.twShift) * PW) + (q & (p.TW - 1));
+    }
+    int aBase[MT];
+#pragma unroll
+    for (int i = 0; i < MT; i++) aBase[i] = (wm * 32 * MT + i * 32 + l31) * 16 + ((lhi ^ ((l31 >> 3) & 1)) << 3);
+
+    // ---- epilogue operands that live in registers: the tile's lrelu mask / pooled residual (EPI 1, 2) or its noise (EPI 0) ----
+    const int coW = wm * 32 * MT;
+    u32x4 preA[EPI >= 1 ? PA : 1], preB[EPI == 2 ? PA : 1];
+    float nzv[NJ];
+    int pixOff[NJ];                                                  // byte offset of the lane's pixel j in an image of y (Cout channels), or OOB
+    auto prefetch = [&](int ord) {
+        const int pt = tFirst + ord * nPer;
+        const int tw = pt & ((1 << pp.tilesWl2) - 1), th = (pt >> pp.tilesWl2) & ((1 << pp.tilesHl2) - 1), n0 = pt >> (pp.tilesWl2 + pp.tilesHl2);
+        const int h0 = th * p.TH, w0 = tw * p.TW;
+        const int outImg = p.H * p.W * p.Cout * 2;
+        int hw2[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            const int q = wn * (32 * NJ) + j * 32 + l31;
+            const int h = h0 + (q >> p.twShift), w = w0 + (q & (p.TW - 1));
+            const bool valid = h < p.H && w < p.W;
+            pixOff[j] = valid ? (h * p.W + w) * p.Cout * 2 : PIPE_OOB;
+            hw2[j] = valid ? ((h >> 1) * (p.W >> 1) + (w >> 1)) * p.Cout * 2 : PIPE_OOB;
+            if (EPI == 0) {
+                const __amdgpu_buffer_rsrc_t nRes = __builtin_amdgcn_make_buffer_rsrc((void*)(p.noise + (int64_t)n0 * p.H * p.W), 0, p.noise ? p.H * p.W * 4 : 0, 0x00020000);
+                nzv[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(nRes, valid ? (h * p.W + w) * 4 : PIPE_OOB, 0, 0));
+            }
+        }
+        if (EPI >= 1) {
+            const __amdgpu_buffer_rsrc_t mRes = __builtin_amdgcn_make_buffer_rsrc((void*)(p.mask_y + (int64_t)n0 * p.H * p.W * p.Cout), 0, p.mask_y ? outImg : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rRes = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res_pooled + (int64_t)n0 * (p.H >> 1) * (p.W >> 1) * p.Cout), 0, p.res_pooled ? outImg >> 2 : 0, 0x00020000);
+#pragma unroll
+            for (int s = 0; s < PA; s++) {                           // slot s = (j, i, q): this lane's post-swap vector
+                const int j = s / (MT * 2), i = (s / 2) % MT, q = s & 1;
+                const int cb = coW + i * 32 + (2 * q + lhi) * 8;
+                const int offA = cb < p.Cout ? pixOff[j] + cb * 2 : PIPE_OOB, offB = cb < p.Cout ? hw2[j] + cb * 2 : PIPE_OOB;
+                preA[s] = __builtin_amdgcn_raw_buffer_load_b128(mRes, offA, 0, 0);
+                if (EPI == 2) preB[s] = __builtin_amdgcn_raw_buffer_load_b128(rRes, offB, 0, 0);
+            }
+        }
+    };
+
+    float msumAcc = 0.f;                                             // EPI >= 1: this lane's share of the masked channel sums (see the flush)
+    int msumIdx = 0;
+
+    f32x16 acc[MT][NJ];
+    auto epilogue = [&](int ord, const bf16_t* stage) {
+        const int pt = tFirst + ord * nPer;
+        const int n0 = pt >> (pp.tilesWl2 + pp.tilesHl2);
+        const __amdgpu_buffer_rsrc_t yRes = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (int64_t)n0 * p.H * p.W * p.Cout), 0, p.H * p.W * p.Cout * 2, 0x00020000);
+        const float* side = (const float*)(stage + SIDE_E);         // [2][64]: out_scale[n0], bias (landed with this stage)
+        float msum[EPI >= 1 ? MT * 16 : 1];
+        if (EPI >= 1) {
+#pragma unroll
+            for (int e = 0; e < MT * 16; e++) msum[e] = 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+#pragma unroll
+            for (int i = 0; i < MT; i++) {
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    uint32_t Pk[2][2];
+#pragma unroll
+                    for (int r2 = 0; r2 < 2; r2++) {
+                        const int rg = 2 * q + r2;
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; e++) v[e] = acc[i][j][rg * 4 + e];
+                        if (EPI == 0) {
+                            const int co = coW + i * 32 + rg * 8 + lhi * 4;
+                            const f32x4 bb = *(const f32x4*)(side + 64 + co);
+                            if (p.out_scale) {
+                                const f32x4 os = *(const f32x4*)(side + co);
+                                v[0] *= os.x; v[1] *= os.y; v[2] *= os.z; v[3] *= os.w;
+                            }
+                            v[0] += bb.x + nzv[j]; v[1] += bb.y + nzv[j]; v[2] += bb.z + nzv[j]; v[3] += bb.w + nzv[j];
+                        }
+                        if (p.act == 3) {
+#pragma unroll
+                            for (int e = 0; e < 4; e++) v[e] = v[e] > 0.f ? v[e] : v[e] * p.alpha;
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; e++) v[e] *= p.gain;
+                        Pk[r2][0] = Pack16<bf16_t>::pack(v[0], v[1]);
+                        Pk[r2][1] = Pack16<bf16_t>::pack(v[2], v[3]);
+                    }
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(Pk[0][0], Pk[1][0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(Pk[0][1], Pk[1][1], false, false);
+                    u32x4 val = {s0[0], s1[0], s0[1], s1[1]};
+                    const int cb = coW + i * 32 + (2 * q + lhi) * 8;
+                    if (EPI >= 1) {
+                        const int s = (j * MT + i) * 2 + q;
+                        float g[8];
+                        Pack16<bf16_t>::unpack(val.x, g[0], g[1]); Pack16<bf16_t>::unpack(val.y, g[2], g[3]);
+                        Pack16<bf16_t>::unpack(val.z, g[4], g[5]); Pack16<bf16_t>::unpack(val.w, g[6], g[7]);
+                        if (EPI == 2) {   // pooled residual (zeros when absent)
+                            float rv[8];
+                            Pack16<bf16_t>::unpack(preB[s].x, rv[0], rv[1]); Pack16<bf16_t>::unpack(preB[s].y, rv[2], rv[3]);
+                            Pack16<bf16_t>::unpack(preB[s].z, rv[4], rv[5]); Pack16<bf16_t>::unpack(preB[s].w, rv[6], rv[7]);
+#pragma unroll
+                            for (int e = 0; e < 8; e++) g[e] += rv[e] * p.res_scale;
+                        }
+                        if (p.mask_y) {
+                            float a[8];
+                            Pack16<bf16_t>::unpack(preA[s].x, a[0], a[1]); Pack16<bf16_t>::unpack(preA[s].y, a[2], a[3]);
+                            Pack16<bf16_t>::unpack(preA[s].z, a[4], a[5]); Pack16<bf16_t>::unpack(preA[s].w, a[6], a[7]);
+                            const bool live = pixOff[j] != PIPE_OOB && cb < p.Cout;
+#pragma unroll
+                            for (int e = 0; e < 8; e++) {
+                                g[e] = a[e] > 0.f ? g[e] : g[e] * p.mask_alpha;
+                                msum[(i * 2 + q) * 8 + e] += live ? g[e] : 0.f;
+                            }
+                        }
+                        val.x = Pack16<bf16_t>::pack(g[0], g[1]); val.y = Pack16<bf16_t>::pack(g[2], g[3]);
+                        val.z = Pack16<bf16_t>::pack(g[4], g[5]); val.w = Pack16<bf16_t>::pack(g[6], g[7]);
+                    }
+                    const int offY = cb < p.Cout ? pixOff[j] + cb * 2 : PIPE_OOB;
+                    __builtin_amdgcn_raw_buffer_store_b128(val, yRes, offY, 0, 0);
+                }
+            }
+        }
+        if (EPI >= 1) {
+            // halving butterfly over the 32 lanes of each half-wave (see conv_epilogue_pl): lane l keeps the total of value index
+            // bit0*NV/2 + bit1*NV/4 + ... ; accumulated over the block's tiles in ONE register
+            constexpr int NV = MT * 16;
+            int live = NV, idx = 0, m = 1;
+#pragma unroll
+            for (; live > 1; live >>= 1, m <<= 1) {
+                const bool up = (lane & m) != 0;
+                const int half = live >> 1;
+#pragma unroll
+                for (int k = 0; k < NV / 2; k++) {
+                    if (k < half) {
+                        const float send = up ? msum[k] : msum[k + half];
+                        const float keep = up ? msum[k + half] : msum[k];
+                        msum[k] = keep + __shfl_xor(send, m);
+                    }
+                }
+                idx += up ? half : 0;
+            }
+#pragma unroll
+            for (; m < 32; m <<= 1) msum[0] += __shfl_xor(msum[0], m);
+            msumAcc += msum[0];
+            msumIdx = idx;
+        }
+    };
+
+    // ---- the pipeline ----
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 1; s++) issue(s / NCH, s % NCH, s);
+    __builtin_amdgcn_sched_barrier(0);
+    int buf = 0;
+    for (int t = 0; t < mTiles; t++) {
+        pipe_static_for(std::make_integer_sequence<int, NCH>{}, [&](auto chc) {
+            constexpr int ch = decltype(chc)::value;
+            // wait for this wave's loads of stage (t, ch), then for everyone's; after the barrier buffer (buf - 1) is free again
+            if (t < TCONS) { if (hiWave) pipe_wait_vm<(NSTAGE - 2) * LPW_HI>(); else pipe_wait_vm<(NSTAGE - 2) * LPW_LO>(); }
+            else if (hiWave) pipe_wait_vm<pipe_younger<NCH, NSTAGE>(ch, LPW_HI, PCNT, SCNT, PF)>();
+            else pipe_wait_vm<pipe_younger<NCH, NSTAGE>(ch, LPW_LO, PCNT, SCNT, PF)>();
+            // a bare s_barrier: __syncthreads() adds a workgroup fence that the compiler lowers to `s_waitcnt vmcnt(0)` -- a full drain of
+            // the pipeline.  Nothing more is needed here: a wave's DMA data is in LDS once ITS vmcnt says so (the wait above), its
+            // fragment reads of the previous stage were consumed by MFMAs before it arrived.
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (ch == PF) prefetch(t);
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                constexpr int ahead = NSTAGE - 1;
+                const int nb = buf + ahead >= NSTAGE ? buf + ahead - NSTAGE : buf + ahead;
+                issue(t + (ch + ahead) / NCH, (ch + ahead) % NCH, nb);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (ch == 0) {
+#pragma unroll
+                for (int i = 0; i < MT; i++)
+#pragma unroll
+                    for (int j = 0; j < NJ; j++)
+#pragma unroll
+                        for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+            }
+            const bf16_t* cW = sS + buf * STAGE_E;
+            const bf16_t* cX = cW + WTOT * 8;
+#pragma unroll
+            for (int kh = 0; kh < KS; kh++) {
+#pragma unroll
+                for (int kw = 0; kw < KS; kw++) {
+                    const int tap = kh * KS + kw;
+                    bf16x8 af[MT], bfr[NJ];
+#pragma unroll
+                    for (int i = 0; i < MT; i++) af[i] = *(const bf16x8*)(cW + tap * BM * 16 + aBase[i]);
+#pragma unroll
+                    for (int j = 0; j < NJ; j++) {
+                        const int pix = bPix[j] + kh * PW + kw;
+                        bfr[j] = *(const bf16x8*)(cX + pix * 16 + ((lhi ^ ((pix >> 3) & 1)) << 3));
+                    }
+#pragma unroll
+                    for (int i = 0; i < MT; i++)
+#pragma unroll
+                        for (int j = 0; j < NJ; j++)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                }
+            }
+            buf = buf + 1 == NSTAGE ? 0 : buf + 1;
+            asm volatile("" : "+s"(buf));                 // opaque: keeps the next chunks' LDS addresses from being formed (and held) early
+            __builtin_amdgcn_sched_barrier(0);
+            if (ch == NCH - 1) epilogue(t, cW);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    }
+
+    if (EPI >= 1 && p.mask_y && p.mask_sum) {             // block-uniform
+        // add the waves that share the channels through LDS, then ONE atomic per channel and block
+        red[wave * 64 + lane] = msumAcc;
+        __syncthreads();
+        const int ci = msumIdx >> 3, e = msumIdx & 7;                      // value index -> (i * 2 + q, e)
+        const int co = coW + (ci >> 1) * 32 + (2 * (ci & 1) + lhi) * 8 + e;
+        if (wn == 0 && (MT == 2 || l31 < 16) && co < p.Cout) {
+            float v = 0.f;
+            for (int k = 0; k < NWN; k++) v += red[(wm * NWN + k) * 64 + lane];
+            unsafeAtomicAdd(p.mask_sum + (int64_t)(blockIdx.x & 255) * p.Cout + co, v);
+        }
+    }
+}
+
+template <int KS, int MT, int NWM, int NWN, int NJ, int NCH, int NSTAGE, int PMAX, int EPI>
+static int launch_pipe_e(const PipeParams& pp, int blocksPerCU, hipStream_t st) {
+    constexpr int TAPS = KS * KS, BM = 32 * NWM * MT, NW = NWM * NWN;
+    constexpr int NG = TAPS * BM * 2 / 64 + (PMAX * 2 + 63) / 64;
+    const size_t lds = (size_t)NSTAGE * (NG * 1024 + 512) + NW * 64 * 4;
+    if (lds > 160 * 1024) return AGF_ENOKERNEL;
+    static int cus = 0;
+    if (!cus) { int dev = 0; hipDeviceProp_t prop; if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return AGF_ELAUNCH; cus = prop.multiProcessorCount; }
+    int grid = (cus * blocksPerCU) & ~7;
+    if (grid < 8) grid = 8;
+    hipError_t e = hipFuncSetAttribute((const void*)conv2d_fwd_pipe_kernel<KS, MT, NWM, NWN, NJ, NCH, NSTAGE, PMAX, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { agf_set_error("conv2d_fwd (pipe): cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e)); return AGF_ELAUNCH; }
+    hipLaunchKernelGGL((conv2d_fwd_pipe_kernel<KS, MT, NWM, NWN, NJ, NCH, NSTAGE, PMAX, EPI>), dim3((unsigned)grid), dim3(64 * NW), lds, st, pp);
+    return AGF_OK;
+}
+
+template <int KS, int MT, int NWM, int NWN, int NJ, int NCH, int NSTAGE, int PMAX>
+static int launch_pipe(const PipeParams& pp, int blocksPerCU, hipStream_t st) {
+    if (pp.c.res_pooled) return launch_pipe_e<KS, MT, NWM, NWN, NJ, NCH, NSTAGE, PMAX, 2>(pp, blocksPerCU, st);
+    if (pp.c.mask_y)     return launch_pipe_e<KS, MT, NWM, NWN, NJ, NCH, NSTAGE, PMAX, 1>(pp, blocksPerCU, st);
+    return launch_pipe_e<KS, MT, NWM, NWN, NJ, NCH, NSTAGE, PMAX, 0>(pp, blocksPerCU, st);
+}
+
+int agf_conv2d_pipe_launch(const ConvParams& p0, hipStream_t st) {
+    // covered: 3x3, one co tile (Cout <= 64), Cin in {32, 64, 128}, maps that 16x32 pixel tiles cover with power-of-two tile counts,
+    // no input scale (style-modulated layers come with per-image weights instead), no residual operand
+    static const int mode = []{ const char* e = getenv("AGF_CONV_PIPE"); return e ? atoi(e) : 1; }();
+    if (!mode) return AGF_ENOKERNEL;
+    ConvParams p = p0;
+    if (p.in_scale || p.residual) return AGF_ENOKERNEL;
+    if ((p.mask_y || p.res_pooled) && (p.out_scale || p.bias || p.noise)) return AGF_ENOKERNEL;
+    if (p.Cout > 64 || (p.Cout % 8) || ((uintptr_t)p.y % 16)) return AGF_ENOKERNEL;
+    if (p.Cin != 32 && p.Cin != 64 && p.Cin != 128) return AGF_ENOKERNEL;
+    if (p.H < 16 || p.W < 32) return AGF_ENOKERNEL;
+    p.flat = 0; p.TI = 1; p.TW = 32; p.TH = 16; p.twShift = 5; p.thShift = 4;
+    p.tilesW = (p.W + 31) / 32; p.tilesH = (p.H + 15) / 16; p.tilesN = p.N; p.tilesCo = 1;
+    p.pixTiles = p.tilesW * p.tilesH * p.N;
+    if ((p.tilesW & (p.tilesW - 1)) || (p.tilesH & (p.tilesH - 1)) || p.pixTiles < 512) return AGF_ENOKERNEL;
+    if ((int64_t)p.H * p.W * (p.Cin > p.Cout ? p.Cin : p.Cout) * 2 >= 0x60000000ll) return AGF_ENOKERNEL;
+    PipeParams pp;
+    pp.c = p;
+    pp.tilesWl2 = 0; while ((1 << pp.tilesWl2) < p.tilesW) pp.tilesWl2++;
+    pp.tilesHl2 = 0; while ((1 << pp.tilesHl2) < p.tilesH) pp.tilesHl2++;
+    pp.band = (p.pixTiles + 7) / 8;
+    pp.wImgStride = 0;
+    if (p.Cout > 32) {
+        if (p.Cin == 32)  return launch_pipe<3, 2, 1, 8, 2, 2, 4, 612>(pp, 1, st);
+        if (p.Cin == 64)  return launch_pipe<3, 2, 1, 8, 2, 4, 4, 612>(pp, 1, st);
+        return launch_pipe<3, 2, 1, 8, 2, 8, 4, 612>(pp, 1, st);
+    }
+    if (p.Cin == 32)  return launch_pipe<3, 1, 1, 8, 2, 2, 5, 612>(pp, 1, st);
+    if (p.Cin == 64)  return launch_pipe<3, 1, 1, 8, 2, 4, 5, 612>(pp, 1, st);
+    return launch_pipe<3, 1, 1, 8, 2, 8, 5, 612>(pp, 1, st);
+}

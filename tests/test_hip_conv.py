@@ -86,6 +86,47 @@ def test_conv_fwd_variants_vs_aten(case, scaled, monkeypatch):
     assert rel(y, ref) < (1.2e-2 if scaled else 6e-3)
 
 
+# persistent multi-stage kernel (agf_conv2d_pipe.hip): 3x3, Cin in {32, 64, 128}, Cout <= 64, >= 512 tiles of 16x32 pixels, no input scale
+PIPE_CASES = [
+    (4, 64, 64, 256, 256, 'Cin 64 -> 64 (4 chunks, 4 stages)'),
+    (4, 32, 64, 256, 256, 'Cin 32 -> 64 (2 chunks)'),
+    (16, 128, 64, 128, 128, 'Cin 128 -> 64 (8 chunks)'),
+    (4, 64, 32, 256, 256, '32-channel co tile, 5 stages'),
+    (4, 32, 32, 256, 256, '32 -> 32'),
+    (16, 128, 32, 128, 128, '128 -> 32'),
+    (5, 64, 40, 250, 250, 'ragged map (partial tiles), channel tail, odd batch'),
+    (5, 32, 24, 250, 230, 'ragged map, 24 output channels'),
+    (3, 64, 64, 512, 512, 'large map: 512 tiles per image'),
+]
+
+
+@pytest.mark.parametrize('case', PIPE_CASES, ids=[c[-1] for c in PIPE_CASES])
+@pytest.mark.parametrize('epi', ['bias_lrelu', 'demod_bias_noise_lrelu', 'linear_gain'])
+def test_conv_pipe_kernel_vs_aten(case, epi):
+    from animeface_amd.implementations.StyleGAN2.conv import conv2d_fwd_raw, ACT_LRELU, ACT_LINEAR
+    N, Cin, Cout, H, W, _ = case
+    x, w, g = make(N, Cin, Cout, H, W, 3, seed=11)
+    bias = torch.randn(Cout, generator=g).to(DEV) if epi != 'linear_gain' else None
+    s_out = (torch.rand(N, Cout, generator=g) + 0.5).to(DEV) if epi == 'demod_bias_noise_lrelu' else None
+    noise = torch.randn(N, 1, H, W, generator=g).to(DEV) if epi == 'demod_bias_noise_lrelu' else None
+    act, gain = (ACT_LINEAR, 0.7) if epi == 'linear_gain' else (ACT_LRELU, 1.0)
+    y = conv2d_fwd_raw(x, w, out_scale=s_out, bias=bias, noise=noise, act=act, alpha=0.2, gain=gain)
+    ref = F.conv2d(x.float(), w.float(), padding=1)
+    if s_out is not None:
+        ref = ref * s_out[:, :, None, None]
+    if bias is not None:
+        ref = ref + bias[None, :, None, None]
+    if noise is not None:
+        ref = ref + noise
+    if act == ACT_LRELU:
+        ref = F.leaky_relu(ref, 0.2)
+    ref = ref * gain
+    assert y.shape == ref.shape and y.dtype == torch.bfloat16
+    assert rel(y, ref) < 6e-3
+    # every output element, not only the largest: bf16 rounding of an fp32-accumulated value
+    assert ((y.float() - ref).abs() <= 2 ** -7 * ref.abs() + 1e-2 * ref.abs().max()).all()
+
+
 @pytest.mark.parametrize('shape', [(5, 8, 32, 256, 256), (3, 8, 16, 128, 128), (2, 8, 8, 64, 64), (3, 8, 32, 70, 66),
                                    (3, 32, 8, 256, 256), (3, 8, 128, 64, 64)])
 @pytest.mark.parametrize('scaled', [False, True])
@@ -217,7 +258,8 @@ def test_style_demod_vs_composite(shape):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('shape', [(4, 64, 64, 64, 64, None), (3, 128, 136, 32, 64, '2'), (16, 64, 64, 128, 128, None), (5, 512, 512, 8, 8, None),
-                                   (2, 72, 40, 19, 38, None), (8, 64, 32, 256, 256, None), (8, 32, 32, 256, 256, None), (8, 32, 64, 256, 256, None)])
+                                   (2, 72, 40, 19, 38, None), (8, 64, 32, 256, 256, None), (8, 32, 32, 256, 256, None), (8, 32, 64, 256, 256, None),
+                                   (5, 64, 40, 250, 250, None), (16, 128, 64, 128, 128, None), (4, 64, 64, 256, 256, None)])
 @pytest.mark.parametrize('mode', ['mask', 'pooled', 'both'])
 def test_conv_fwd_mask_vs_composite(shape, mode, monkeypatch):
     """agf_conv2d_fwd_mask: conv, + the pooled sibling-branch gradient read at half resolution, then the lrelu gradient of the layer below

@@ -165,3 +165,20 @@ def test_c_oracle_agrees_with_golden_and_python_oracle(golden):
         assert np.array_equal(y, ref), (i, spec.tolist())
         checked += 1
     assert checked > 200
+
+
+def test_conv2d_resample_oracle_matches_the_reference(golden):
+    """oracle/conv2d_resample.py (definition form) against the reference's conv2d_resample, whose 14 fixture cases take each fast path."""
+    from oracle import conv2d_resample as OC
+    g = golden('conv2d_resample')
+    filt = {0: None, 1: t(g['f4']), 2: t(g['f12'])}
+    for idx, (k, up, down, px0, px1, py0, py1, fi, flip_w, flip_f) in enumerate(g['cases'].tolist()):
+        x = t(g[f'c{idx}_x']).requires_grad_(True)
+        w = t(g[f'c{idx}_w']).requires_grad_(True)
+        y = OC.conv2d_resample(x, w, f=filt[fi], up=up, down=down, padding=[px0, px1, py0, py1], flip_weight=bool(flip_w), flip_filter=bool(flip_f))
+        ref = t(g[f'c{idx}_y'])
+        assert y.shape == ref.shape, (idx, y.shape, ref.shape)
+        torch.testing.assert_close(y, ref, rtol=1e-5, atol=2e-5)
+        dx, dw = torch.autograd.grad(y, [x, w], t(g[f'c{idx}_gy']))
+        torch.testing.assert_close(dx, t(g[f'c{idx}_dx']), rtol=1e-5, atol=2e-5)
+        torch.testing.assert_close(dw, t(g[f'c{idx}_dw']), rtol=1e-4, atol=5e-5)

@@ -654,11 +654,40 @@ def gen_ada():
     save('ada', **arrays)
 
 
+def gen_conv2d_resample():
+    """thirdparty/stylegan3_ops/ops/conv2d_resample.py:40-135 on CPU (its fast paths are ATen convs + the upfirdn2d `_ref` path)."""
+    from thirdparty.stylegan3_ops.ops import conv2d_resample, upfirdn2d
+    g = torch.Generator().manual_seed(21)
+    arrays, cases = {}, []
+    f4 = upfirdn2d.setup_filter([1, 3, 3, 1])
+    f12 = upfirdn2d.setup_filter([1, 2, 5, 9, 14, 17, 17, 14, 9, 5, 2, 1])            # 12 taps -> separable
+    # (k, up, down, padding, filter, flip_weight, flip_filter, H, W)
+    grid = [(1, 1, 1, 0, None, True, False, 9, 11), (3, 1, 1, 1, None, True, False, 9, 11), (3, 1, 1, [2, 0, 1, 3], None, True, False, 9, 11),
+            (3, 1, 1, [-1, 2, 0, 1], None, False, False, 10, 12),
+            (1, 1, 2, 0, 'f4', True, False, 12, 16), (1, 2, 1, 0, 'f4', True, False, 7, 9),
+            (3, 1, 2, 1, 'f4', True, False, 12, 16), (3, 1, 2, 1, 'f4', False, True, 12, 16), (3, 1, 2, [2, 1, 0, 1], 'f12', True, False, 16, 12),
+            (3, 2, 1, 1, 'f4', True, False, 7, 9), (3, 2, 1, 1, 'f4', False, False, 7, 9), (3, 2, 2, 1, 'f4', True, False, 8, 10),
+            (5, 2, 1, 2, 'f12', True, True, 6, 8), (3, 4, 2, 1, 'f4', True, False, 5, 6)]
+    for idx, (k, up, down, pad, fn, fw_, ff, H, W) in enumerate(grid):
+        x = torch.randn(2, 6, H, W, generator=g)
+        w = torch.randn(5, 6, k, k, generator=g) / (6 * k * k) ** 0.5
+        f = {'f4': f4, 'f12': f12, None: None}[fn]
+        x.requires_grad_(True); w.requires_grad_(True)
+        y = conv2d_resample.conv2d_resample(x, w, f=f, up=up, down=down, padding=pad, flip_weight=fw_, flip_filter=ff)
+        gy = torch.randn(y.shape, generator=g)
+        dx, dw = torch.autograd.grad(y, [x, w], gy)
+        arrays.update({f'c{idx}_x': x, f'c{idx}_w': w, f'c{idx}_y': y, f'c{idx}_gy': gy, f'c{idx}_dx': dx, f'c{idx}_dw': dw})
+        cases.append([k, up, down] + list(upfirdn2d._parse_padding(pad)) + [{'f4': 1, 'f12': 2, None: 0}[fn], int(fw_), int(ff)])
+    arrays['cases'] = np.array(cases, dtype=np.int64)
+    arrays['f4'], arrays['f12'] = f4, f12
+    save('conv2d_resample', **arrays)
+
+
 if __name__ == '__main__':
     os.environ.setdefault('PYTHONDONTWRITEBYTECODE', '1')
     torch.set_num_threads(8)
     import_reference()
-    which = sys.argv[1:] or ['upfirdn2d', 'equiv', 'bias_act', 'filtered_lrelu', 'sg2_model', 'train', 'sg3_model', 'sg3_train', 'ada']
+    which = sys.argv[1:] or ['upfirdn2d', 'equiv', 'bias_act', 'filtered_lrelu', 'sg2_model', 'train', 'sg3_model', 'sg3_train', 'ada', 'conv2d_resample']
     if 'upfirdn2d' in which:
         gen_upfirdn2d()
     if 'equiv' in which:
@@ -677,3 +706,5 @@ if __name__ == '__main__':
         gen_sg3_train()
     if 'ada' in which:
         gen_ada()
+    if 'conv2d_resample' in which:
+        gen_conv2d_resample()
