@@ -22,6 +22,7 @@ _DTYPES = {torch.float32: AGF_F32, torch.float16: AGF_F16, torch.bfloat16: AGF_B
 EXPORTS = ['agf_abi_version', 'agf_last_error', 'agf_device_info', 'agf_upfirdn2d', 'agf_upfirdn2d_fold_border', 'agf_bias_act',
            'agf_filtered_lrelu', 'agf_filtered_lrelu_act', 'agf_conv2d_fwd', 'agf_conv2d_fwd_mask', 'agf_conv2d_wgrad',
            'agf_act_bwd_reduce', 'agf_act_bwd_reduce_pooled', 'agf_scale_dot', 'agf_planar_to_cl_pad', 'agf_cl_to_planar_crop', 'agf_prep_weights',
+           'agf_modulate_weights', 'agf_conv2d_fwd_wimg', 'agf_conv2d_fwd_wimg_covers',
            'agf_wsq', 'agf_style_demod_fwd', 'agf_style_demod_bwd', 'agf_diffaug_sum', 'agf_diffaug_apply', 'agf_color_affine', 'agf_affine_resample', 'agf_upblur_border']
 
 _lib = None
@@ -70,6 +71,12 @@ def lib():
         L.agf_conv2d_fwd_mask.restype = ctypes.c_int
         L.agf_conv2d_fwd_mask.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int] + [ctypes.c_int32] * 6 + \
                                          [ctypes.c_int, ctypes.c_float, ctypes.c_float, _vp, ctypes.c_float, _vp, _vp, ctypes.c_float, _vp]
+        L.agf_modulate_weights.restype = ctypes.c_int
+        L.agf_modulate_weights.argtypes = [_vp, _vp, _vp, ctypes.c_int] + [ctypes.c_int32] * 4 + [_vp]
+        L.agf_conv2d_fwd_wimg.restype = ctypes.c_int
+        L.agf_conv2d_fwd_wimg.argtypes = [_vp] * 6 + [ctypes.c_int] + [ctypes.c_int32] * 6 + [ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int64, _vp]
+        L.agf_conv2d_fwd_wimg_covers.restype = ctypes.c_int
+        L.agf_conv2d_fwd_wimg_covers.argtypes = [ctypes.c_int32] * 6
         L.agf_conv2d_wgrad.restype = ctypes.c_int
         L.agf_conv2d_wgrad.argtypes = [_vp, _vp, _vp, _vp, _vp, ctypes.c_int] + [ctypes.c_int32] * 6 + [ctypes.c_float, _vp]
         L.agf_act_bwd_reduce.restype = ctypes.c_int
@@ -99,7 +106,7 @@ def lib():
         L.agf_affine_resample.argtypes = [_vp, _vp, _vp, ctypes.c_int] + [ctypes.c_int32] * 6 + [ctypes.c_int, _vp]
         L.agf_upblur_border.restype = ctypes.c_int
         L.agf_upblur_border.argtypes = [_vp, _vp, ctypes.c_int] + [ctypes.c_int32] * 4 + [ctypes.c_int, _vp]
-        if L.agf_abi_version() != 10:
+        if L.agf_abi_version() != 11:
             raise AgfError('libagf_ops.so ABI version mismatch')
         _lib = L
     return _lib

@@ -413,7 +413,70 @@ static int launch_pipe(const PipeParams& pp, int blocksPerCU, hipStream_t st) {
     return launch_pipe_e<KS, MT, NWM, NWN, NJ, NCH, NSTAGE, PMAX, 0>(pp, blocksPerCU, st);
 }
 
-int agf_conv2d_pipe_launch(const ConvParams& p0, hipStream_t st) {
+static bool pipe_covers(int N, int H, int W, int Cin, int Cout) {
+    if (Cout > 64 || (Cout % 8) || (Cin != 32 && Cin != 64 && Cin != 128) || H < 16 || W < 32) return false;
+    const int tw = (W + 31) / 32, th = (H + 15) / 16;
+    if ((tw & (tw - 1)) || (th & (th - 1)) || (int64_t)tw * th * N < 512) return false;
+    return (int64_t)H * W * (Cin > Cout ? Cin : Cout) * 2 < 0x60000000ll;
+}
+
+static int pipe_launch(const ConvParams& p0, int64_t wImgStride, hipStream_t st);
+
+int agf_conv2d_pipe_launch(const ConvParams& p0, hipStream_t st) { return pipe_launch(p0, 0, st); }
+
+// wmod[n][co][tap][ci] = w[co][tap][ci] * s[n][ci]: the style modulation folded into one weight tensor per image (what the reference
+// materialises as `weight * style`, implementations/StyleGAN2/model.py:115 -- here only for the few-channel layers, a few MB)
+__global__ void __launch_bounds__(256) modulate_weights_kernel(const bf16_t* w, const float* s, bf16_t* out, int N, int rows, int Cin) {
+    const int vpr = Cin >> 3;
+    const int64_t total = (int64_t)N * rows * vpr;
+    for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < total; v += (int64_t)gridDim.x * 256) {
+        const int cv = (int)(v % vpr);
+        const int64_t r = v / vpr;
+        const int row = (int)(r % rows), n = (int)(r / rows);
+        const u32x4 val = *(const u32x4*)(w + ((int64_t)row * Cin + cv * 8));
+        *(u32x4*)(out + (((int64_t)n * rows + row) * Cin + cv * 8)) = scale_vec8(val, s + (int64_t)n * Cin + cv * 8);
+    }
+}
+
+extern "C" int agf_modulate_weights(const void* w, const float* s, void* wmod, int dtype, int32_t N, int32_t Cout, int32_t taps, int32_t Cin, void* stream) {
+    AGF_CHECK(w && s && wmod, "modulate_weights: null pointer");
+    AGF_CHECK(dtype == AGF_BF16, "modulate_weights: bf16 only");
+    AGF_CHECK(N >= 1 && Cout >= 1 && taps >= 1 && Cin >= 8 && Cin % 8 == 0, "modulate_weights: Cin must be a positive multiple of 8");
+    AGF_CHECK(((uintptr_t)w % 16) == 0 && ((uintptr_t)wmod % 16) == 0 && ((uintptr_t)s % 16) == 0, "modulate_weights: misaligned pointer");
+    const int64_t total = (int64_t)N * Cout * taps * (Cin / 8);
+    int64_t blocks = agf_ceil_div(total, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(modulate_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)w, s, (bf16_t*)wmod, N, Cout * taps, Cin);
+    AGF_LAUNCH_CHECK();
+    return AGF_OK;
+}
+
+extern "C" int agf_conv2d_fwd_wimg_covers(int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize) {
+    static const int mode = []{ const char* e = getenv("AGF_CONV_PIPE"); return e ? atoi(e) : 1; }();
+    return (mode && ksize == 3 && pipe_covers(N, H, W, Cin, Cout)) ? 1 : 0;
+}
+
+extern "C" int agf_conv2d_fwd_wimg(const void* x, const void* w, void* y, const float* out_scale, const float* bias, const float* noise,
+                                   int dtype, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
+                                   int act, float alpha, float act_gain, int64_t w_image_stride, void* stream) {
+    AGF_CHECK(x && w && y, "conv2d_fwd_wimg: null pointer");
+    AGF_CHECK(dtype == AGF_BF16, "conv2d_fwd_wimg: bf16 only");
+    AGF_CHECK(act == 1 || act == 3, "conv2d_fwd_wimg: act must be 1 (linear) or 3 (lrelu)");
+    AGF_CHECK(((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0 && ((uintptr_t)y % 16) == 0, "conv2d_fwd_wimg: misaligned pointer");
+    AGF_CHECK(w_image_stride >= (int64_t)Cout * ksize * ksize * Cin && (w_image_stride % 8) == 0, "conv2d_fwd_wimg: bad per-image weight stride");
+    if (ksize != 3 || !pipe_covers(N, H, W, Cin, Cout)) { agf_set_error("conv2d_fwd_wimg: shape not covered by the per-image-weight kernel"); return AGF_ENOKERNEL; }
+    ConvParams p = {};
+    p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.y = (bf16_t*)y;
+    p.out_scale = out_scale; p.bias = bias; p.noise = noise;
+    p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+    p.act = act; p.alpha = alpha; p.gain = act_gain;
+    const int rc = pipe_launch(p, w_image_stride, (hipStream_t)stream);
+    if (rc != AGF_OK) return rc;
+    AGF_LAUNCH_CHECK();
+    return AGF_OK;
+}
+
+static int pipe_launch(const ConvParams& p0, int64_t wImgStride, hipStream_t st) {
     // covered: 3x3, one co tile (Cout <= 64), Cin in {32, 64, 128}, maps that 16x32 pixel tiles cover with power-of-two tile counts,
     // no input scale (style-modulated layers come with per-image weights instead), no residual operand
     static const int mode = []{ const char* e = getenv("AGF_CONV_PIPE"); return e ? atoi(e) : 1; }();
@@ -421,20 +484,16 @@ int agf_conv2d_pipe_launch(const ConvParams& p0, hipStream_t st) {
     ConvParams p = p0;
     if (p.in_scale || p.residual) return AGF_ENOKERNEL;
     if ((p.mask_y || p.res_pooled) && (p.out_scale || p.bias || p.noise)) return AGF_ENOKERNEL;
-    if (p.Cout > 64 || (p.Cout % 8) || ((uintptr_t)p.y % 16)) return AGF_ENOKERNEL;
-    if (p.Cin != 32 && p.Cin != 64 && p.Cin != 128) return AGF_ENOKERNEL;
-    if (p.H < 16 || p.W < 32) return AGF_ENOKERNEL;
+    if (((uintptr_t)p.y % 16) || !pipe_covers(p.N, p.H, p.W, p.Cin, p.Cout)) return AGF_ENOKERNEL;
     p.flat = 0; p.TI = 1; p.TW = 32; p.TH = 16; p.twShift = 5; p.thShift = 4;
     p.tilesW = (p.W + 31) / 32; p.tilesH = (p.H + 15) / 16; p.tilesN = p.N; p.tilesCo = 1;
     p.pixTiles = p.tilesW * p.tilesH * p.N;
-    if ((p.tilesW & (p.tilesW - 1)) || (p.tilesH & (p.tilesH - 1)) || p.pixTiles < 512) return AGF_ENOKERNEL;
-    if ((int64_t)p.H * p.W * (p.Cin > p.Cout ? p.Cin : p.Cout) * 2 >= 0x60000000ll) return AGF_ENOKERNEL;
     PipeParams pp;
     pp.c = p;
     pp.tilesWl2 = 0; while ((1 << pp.tilesWl2) < p.tilesW) pp.tilesWl2++;
     pp.tilesHl2 = 0; while ((1 << pp.tilesHl2) < p.tilesH) pp.tilesHl2++;
     pp.band = (p.pixTiles + 7) / 8;
-    pp.wImgStride = 0;
+    pp.wImgStride = wImgStride;
     if (p.Cout > 32) {
         if (p.Cin == 32)  return launch_pipe<3, 2, 1, 8, 2, 2, 4, 612>(pp, 1, st);
         if (p.Cin == 64)  return launch_pipe<3, 2, 1, 8, 2, 4, 4, 612>(pp, 1, st);

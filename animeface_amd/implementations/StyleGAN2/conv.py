@@ -161,7 +161,18 @@ def conv2d_fwd_raw(x, w, in_scale=None, out_scale=None, bias=None, noise=None, r
         residual = residual.to(x.dtype).contiguous(memory_format=torch.channels_last)
     timer = KernelTimer.active
     ev0 = timer.start() if timer is not None else None
-    if mask_y is not None or res_pooled is not None:
+    L = _lib.lib()
+    if in_scale is not None and x.dtype == torch.bfloat16 and residual is None and mask_y is None and res_pooled is None \
+            and L.agf_conv2d_fwd_wimg_covers(N, H, W, Cin, Cout, k):
+        # few-channel high-resolution layer with a style scale: fold the scale into one weight tensor per image (a few MB) and run the
+        # streaming kernel, whose activation path is a pure DMA stream (``agf_modulate_weights`` + ``agf_conv2d_fwd_wimg``)
+        wmod = torch.empty((N, Cout, k, k, Cin), dtype=x.dtype, device=x.device)
+        rc = L.agf_modulate_weights(_lib.ptr(wq), _lib.ptr(in_scale), _lib.ptr(wmod), _lib.dtype_code(x), N, Cout, k * k, Cin, _lib.stream_ptr(x))
+        _lib.check(rc, 'modulate_weights')
+        rc = L.agf_conv2d_fwd_wimg(_lib.ptr(x), _lib.ptr(wmod), _lib.ptr(y), _lib.ptr(out_scale), _lib.ptr(bias), _lib.ptr(noise),
+                                   _lib.dtype_code(x), N, H, W, Cin, Cout, k, act, float(alpha), float(gain), Cout * k * k * Cin,
+                                   _lib.stream_ptr(x))
+    elif mask_y is not None or res_pooled is not None:
         # ``agf_conv2d_fwd_mask``: + res_scale * res_pooled[h/2, w/2] (the gradient of a pooled sibling branch), then multiplied by the
         # leaky-ReLU derivative taken from ``mask_y`` (same shape as y) with the per-channel sum accumulated into ``mask_sum`` [256, Cout]
         # -- the add and the lrelu backward of the layer below, fused into this data-gradient launch

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define AGF_ABI_VERSION 10
+#define AGF_ABI_VERSION 11
 
 /* element types of activation tensors */
 enum { AGF_F32 = 0, AGF_F16 = 1, AGF_BF16 = 2, AGF_F64 = 3 };
@@ -157,6 +157,20 @@ int agf_conv2d_fwd_mask(const void* x, const void* w, void* y,
                         int act, float alpha, float act_gain,
                         const void* mask_y, float mask_alpha, float* mask_sum,
                         const void* res_pooled, float res_scale, void* stream);
+
+/* Style-modulated layers on the streaming (persistent, direct-to-LDS) kernel: the modulation `weight * style` of the reference
+ * (implementations/StyleGAN2/model.py:115) is folded into ONE weight tensor per image -- only for the few-channel high-resolution
+ * layers, where N such tensors are a few MB -- so that the activation path needs no scaling on load:
+ *   agf_modulate_weights:        wmod[n][co][tap][ci] = w[co][tap][ci] * s[n][ci]          (bf16, w as prepared by agf_prep_weights)
+ *   agf_conv2d_fwd_wimg:         agf_conv2d_fwd with image n using the weights at w + n * w_image_stride (elements); no in_scale,
+ *                                no residual; AGF_ENOKERNEL when the shape is outside the kernel's coverage
+ *   agf_conv2d_fwd_wimg_covers:  1 if agf_conv2d_fwd_wimg takes this shape (3x3, Cin in {32,64,128}, Cout <= 64, Cout % 8 == 0,
+ *                                >= 512 tiles of 16x32 pixels with power-of-two tile counts per image), else 0 */
+int agf_modulate_weights(const void* w, const float* s, void* wmod, int dtype, int32_t N, int32_t Cout, int32_t taps, int32_t Cin, void* stream);
+int agf_conv2d_fwd_wimg(const void* x, const void* w, void* y, const float* out_scale, const float* bias, const float* noise,
+                        int dtype, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
+                        int act, float alpha, float act_gain, int64_t w_image_stride, void* stream);
+int agf_conv2d_fwd_wimg_covers(int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize);
 
 /* weight gradient of the same contraction:
  *   dw[co,kh,kw,ci] += scale * sum_{n,h,w} dy[n,h,w,co] * out_scale[n,co] * x[n,h+kh-p,w+kw-p,ci] * in_scale[n,ci]
