@@ -33,8 +33,26 @@ def state(step):
     return out
 
 
+def _rank_world():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
 def save(step, path):
-    torch.save(state(step), path)
+    """Rank 0 writes the replicated state (networks, optimizers, counters, ADA); under data parallelism every rank also writes its
+    own random-generator state next to it (``path + '.rng<rank>'``), then all ranks meet at a barrier -- no two processes ever write
+    the same file."""
+    rank, world = _rank_world()
+    st = state(step)
+    if world > 1:
+        torch.save(dict(rng_cpu=st['rng_cpu'], rng_cuda=st['rng_cuda']), f'{path}.rng{rank}')
+    if rank == 0:
+        torch.save(st, path)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
 
 
 def load(step, path_or_state, map_location=None):
@@ -50,9 +68,20 @@ def load(step, path_or_state, map_location=None):
     if hasattr(step, 'pl_mean'):
         step.pl_mean = st.get('pl_mean', 0.)
     ada = _ada_of(step)
-    if ada is not None and 'ada' in st:
-        ada.load_state_dict(st['ada']['state'])
-        ada._num_iter = int(st['ada']['num_iter'])
+    if 'ada' in st:
+        if ada is not None:
+            ada.load_state_dict(st['ada']['state'])
+            ada._num_iter = int(st['ada']['num_iter'])
+        elif getattr(step, 'policy', None) == 'ada':
+            # the StyleGAN2 trainer builds its pipe on the first batch (whose size fixes the p step): keep the state for that moment
+            step._pending_ada_state = st['ada']
+        else:
+            raise RuntimeError('the checkpoint carries ADA state (p, sign statistic) but this trainer has no ADA pipe to restore it into')
+    rank, world = _rank_world()
+    if world > 1 and isinstance(path_or_state, str):
+        import os
+        if os.path.exists(f'{path_or_state}.rng{rank}'):
+            st = dict(st, **torch.load(f'{path_or_state}.rng{rank}', map_location='cpu', weights_only=False))
     if st.get('rng_cpu') is not None:
         torch.set_rng_state(st['rng_cpu'].cpu())
     if st.get('rng_cuda') is not None and torch.cuda.is_available():

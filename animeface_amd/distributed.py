@@ -38,14 +38,25 @@ def init_distributed():
 
 
 class GradReducer:
-    def __init__(self, params, bucket_bytes=32 << 20, group=None):
+    def __init__(self, params, bucket_bytes=32 << 20, group=None, never_used=()):
+        """``never_used``: parameters the forward pass is known never to touch (``InjectNoise.scale``, reference F10).  A bucket is
+        launched from the backward hooks once ALL of its parameters have their gradient, so such parameters would hold every bucket
+        they sit in back until ``finish()`` (no overlap at all for the generator); they get a bucket of their own instead."""
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.params = [p for p in params if p.requires_grad]
         self.buckets = []          # each: dict(flat, params, pending, work)
         self._hooks = []
+        self._touched = set()
+        self.stats = dict(steps=0, buckets_from_hooks=0, buckets_at_finish=0, exposed_ms=0.0)
+        self.measure = False             # bench.py: time the compute stream's wait in finish() with events
+        self.early = os.environ.get('AGF_DP_EARLY', '1') != '0'      # A/B switch: launch complete buckets from the backward hooks
+        skip = {id(p) for p in never_used}
+        idle = [p for p in self.params if id(p) in skip]
+        if idle:
+            self._make_bucket(idle)
         # backward produces gradients roughly in reverse parameter order
-        order = list(reversed(self.params))
+        order = [p for p in reversed(self.params) if id(p) not in skip]
         cur, cur_bytes = [], 0
         for p in order:
             nbytes = p.numel() * 4
@@ -61,11 +72,13 @@ class GradReducer:
     def _make_bucket(self, plist):
         n = sum(p.numel() for p in plist)
         flat = torch.zeros(n, dtype=torch.float32, device=plist[0].device)
-        b = dict(flat=flat, params=plist, pending=len(plist), work=None, launched=False)
+        b = dict(flat=flat, params=plist, views=[], pending=len(plist), work=None, launched=False, early=False)
         off = 0
         for p in plist:
             assert p.dtype == torch.float32
-            p.grad = flat[off:off + p.numel()].view_as(p)
+            view = flat[off:off + p.numel()].view_as(p)
+            b['views'].append(view)
+            p.grad = view
             off += p.numel()
             self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(b)))
         self.buckets.append(b)
@@ -74,8 +87,10 @@ class GradReducer:
         def hook(param):
             if not self.enabled:
                 return
+            self._touched.add(id(param))
             bucket['pending'] -= 1
-            if bucket['pending'] == 0:
+            if bucket['pending'] == 0 and self.early:
+                bucket['early'] = True
                 self._launch(bucket)
         return hook
 
@@ -84,31 +99,82 @@ class GradReducer:
             return
         bucket['launched'] = True
         if self.world > 1:
-            bucket['flat'].div_(self.world)
-            bucket['work'] = dist.all_reduce(bucket['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            if dist.get_backend(self.group) == 'nccl':
+                # RCCL averages inside the reduction: no extra pass over the bucket
+                bucket['work'] = dist.all_reduce(bucket['flat'], op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+            else:
+                bucket['flat'].div_(self.world)
+                bucket['work'] = dist.all_reduce(bucket['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def zero_grad(self):
-        """Zero the flat buffers (gradients stay views: ``set_to_none`` must not be used with this reducer)."""
+        """Zero the flat buffers and point every ``param.grad`` at its view again (``finish()`` detaches the gradients of parameters
+        that received none; ``set_to_none`` must not be used with this reducer)."""
         for b in self.buckets:
             b['flat'].zero_()
             b['pending'] = len(b['params'])
             b['work'] = None
             b['launched'] = False
+            b['early'] = False
+            for p, v in zip(b['params'], b['views']):
+                if p.grad is not v:
+                    p.grad = v
+        self._touched.clear()
 
     def finish(self):
-        """Launch incomplete buckets (parameters without gradient this step) and wait for all of them."""
+        """Launch incomplete buckets (parameters without gradient this step), wait for all of them, and give the parameters that
+        received NO gradient ``grad = None`` -- as in the single-process loop (``zero_grad(set_to_none=True)``) Adam then skips them
+        instead of stepping them with g = 0 (their step count and second-moment decay would otherwise differ from the reference:
+        ``InjectNoise.scale`` always, D's last bias on lazy-R1 iterations)."""
+        ev0 = ev1 = None
+        if self.measure and self.buckets and self.buckets[0]['flat'].is_cuda:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
         for b in self.buckets:
+            self.stats['buckets_from_hooks' if b['early'] else 'buckets_at_finish'] += 1
             if not b['launched']:
                 self._launch(b)
         for b in self.buckets:
             if b['work'] is not None:
                 b['work'].wait()
                 b['work'] = None
+        if ev0 is not None:
+            ev1.record()
+            self._pending_events = getattr(self, '_pending_events', []) + [(ev0, ev1)]
+        self.stats['steps'] += 1
+        if self.enabled:
+            for b in self.buckets:
+                for p in b['params']:
+                    if id(p) not in self._touched:
+                        p.grad = None
+
+    def overlap_report(self):
+        """Counters for bench.py: how many buckets were launched from backward hooks (overlappable) vs. only at ``finish()``, and the time
+        the compute stream spent waiting for the exchange in ``finish()`` (the exposed, non-overlapped part)."""
+        ev = getattr(self, '_pending_events', [])
+        if ev:
+            torch.cuda.synchronize()
+            self.stats['exposed_ms'] += sum(a.elapsed_time(b) for a, b in ev)
+            self._pending_events = []
+        s = dict(self.stats)
+        s['buckets'] = len(self.buckets)
+        s['bucket_mib'] = [round(b['flat'].numel() * 4 / 2 ** 20, 1) for b in self.buckets]
+        s['exposed_ms_per_step'] = round(s['exposed_ms'] / max(s['steps'], 1), 4)
+        return s
 
     def remove(self):
         for h in self._hooks:
             h.remove()
         self._hooks = []
+
+
+def never_used_parameters(module):
+    """Parameters that exist only for state_dict parity and never receive a gradient (``InjectNoise.scale``, reference
+    implementations/StyleGAN2/model.py:81-88): pass them to ``GradReducer(never_used=...)``."""
+    out = []
+    for m in module.modules():
+        if type(m).__name__ == 'InjectNoise' and hasattr(m, 'scale'):
+            out.append(m.scale)
+    return out
 
 
 def broadcast_module(module, src=0, group=None):

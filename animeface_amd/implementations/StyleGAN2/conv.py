@@ -538,44 +538,6 @@ def up_blur(x, f6):
     return _UpBlur.apply(x, f6)
 
 
-class SkipLink:
-    """Handshake between the first conv of a residual block and the 2x2 average of the block's skip branch, which share their input:
-    the pool's backward leaves the pooled gradient here (and returns no gradient), the conv's data-gradient launch adds it at half
-    resolution (``agf_conv2d_fwd_mask`` res_pooled).  Whichever of the two backward nodes runs second finds the other's mark, so the
-    result does not depend on autograd's execution order: if the conv ran first the pool simply returns its ordinary gradient."""
-    __slots__ = ('armed', 'pooled', 'consumed')
-
-    def __init__(self):
-        self.armed, self.pooled, self.consumed = False, None, False
-
-
-class _PoolSkip(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, f, gain, link):
-        from ...stylegan3_ops import upfirdn2d
-        ctx.save_for_backward(f)
-        ctx.gain, ctx.link, ctx.x_shape = gain, link, x.shape
-        return upfirdn2d.downsample2d(x.detach(), f, down=2, gain=gain)
-
-    @staticmethod
-    def backward(ctx, dy):
-        from ...stylegan3_ops import upfirdn2d
-        f, = ctx.saved_tensors
-        link, gain = ctx.link, ctx.gain
-        _, _, ih, iw = ctx.x_shape
-        if link is not None and link.armed and not link.consumed and _PREMASK and not torch.is_grad_enabled() \
-                and dy.dtype == torch.bfloat16:
-            link.pooled = (dy.contiguous(memory_format=torch.channels_last), float(gain) * 0.25)
-            return None, None, None, None
-        _, _, oh, ow = dy.shape
-        dx = upfirdn2d.upfirdn2d(dy, f, up=2, padding=[1, iw - 2 * ow, 1, ih - 2 * oh], flip_filter=True, gain=gain)
-        return dx, None, None, None
-
-
-def pool2x_skip(x, f, gain, link):
-    return _PoolSkip.apply(x, f, gain, link)
-
-
 class _PoolLinked(torch.autograd.Function):
     """2x2 box average (``downsample2d`` with the [1,1] filter) as the ONLY consumer of a fused conv's lrelu output: instead of writing
     the full-resolution gradient (an upsampling FIR pass) it hands the pooled gradient to the producer's backward through the link, where
@@ -614,29 +576,39 @@ _PREMASK = os.environ.get('AGF_PREMASK', '1') != '0'       # A/B switch
 
 class _FusedConv(torch.autograd.Function):
     """y = act( s_out * conv(x * s_in, weight * coef) + bias + noise + residual ) * gain   in one launch.
-    act = lrelu (gain must be 1) or linear.  The backward is fused too unless a graph is being recorded."""
+    act = lrelu (gain must be 1) or linear.  The backward is fused too unless a graph is being recorded.
+
+    ``skip_pool = (f, pool_gain)``: the op ALSO returns ``downsample2d(x, f, down=2, gain=pool_gain)`` -- the 2x2 average of a residual
+    block's skip branch, which shares this conv's input.  Both outputs belong to ONE autograd node, so their gradients arrive in the
+    same ``backward`` call and the pooled branch's gradient is added at half resolution inside the data-gradient launch
+    (``agf_conv2d_fwd_mask`` res_pooled) -- by construction, not through a handshake whose outcome would depend on the order in which
+    autograd happens to run two sibling nodes (an earlier ``SkipLink`` object did that; runs could differ by bf16 rounding, and with the
+    producer's lrelu mask folded into the same launch an unlucky order would have masked only one of the two branches)."""
 
     @staticmethod
-    def forward(ctx, x, weight, coef, s_in, s_out, bias, noise, residual, act, alpha, gain, pre_link=None, post_link=None, skip_link=None):
+    def forward(ctx, x, weight, coef, s_in, s_out, bias, noise, residual, act, alpha, gain, pre_link=None, post_link=None, skip_pool=None):
         prep = prepared_weights(weight, coef, x.dtype)
         y = conv2d_fwd_raw(x, prep.wq, in_scale=s_in, out_scale=s_out, bias=bias, noise=noise, residual=residual,
                            act=act, alpha=alpha, gain=gain, prepared=True)
         ctx.save_for_backward(x, weight, s_in, s_out, bias, noise, y if (act == ACT_LRELU or s_out is not None) else None)
         ctx.coef, ctx.act, ctx.alpha, ctx.gain = coef, act, alpha, gain
         ctx.has_residual = residual is not None
-        ctx.pre_link, ctx.post_link, ctx.skip_link = pre_link, None, None
-        if skip_link is not None and _PREMASK and s_in is None and x.dtype == torch.bfloat16 and x.shape[1] % 8 == 0 \
-                and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0:
-            skip_link.armed, skip_link.pooled, skip_link.consumed = True, None, False
-            ctx.skip_link = skip_link
+        ctx.pre_link, ctx.post_link = pre_link, None
+        ctx.pool = None
+        tp = None
+        if skip_pool is not None:
+            from ...stylegan3_ops import upfirdn2d
+            f, pool_gain = skip_pool
+            tp = upfirdn2d.downsample2d(x.detach(), f, down=2, gain=pool_gain)
+            ctx.pool = (f, float(pool_gain))
         if post_link is not None and _PREMASK and act == ACT_LRELU and gain == 1.0 and s_out is None and noise is None \
                 and x.dtype == torch.bfloat16:
             post_link.armed, post_link.alpha, post_link.premasked, post_link.pooled = True, float(alpha), False, None
             ctx.post_link = post_link
-        return y
+        return y if skip_pool is None else (y, tp)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dtp=None):
         x, weight, s_in, s_out, bias, noise, y = ctx.saved_tensors
         coef, act, alpha, gain = ctx.coef, ctx.act, ctx.alpha, ctx.gain
         need_x, need_w, _, need_si, need_so, need_b, _, need_r = ctx.needs_input_grad[:8]
@@ -649,12 +621,20 @@ class _FusedConv(torch.autograd.Function):
             dy = dy.to(x.dtype).contiguous(memory_format=torch.channels_last)
         k = weight.shape[2]
         dx = dw = dsi = dso = db = dres = None
-        skip = ctx.skip_link
-        res_pooled, res_scale = (None, 1.0)
-        if skip is not None:
-            if skip.pooled is not None and not torch.is_grad_enabled():
-                res_pooled, res_scale = skip.pooled
-            skip.pooled, skip.consumed = None, True             # a pool backward that runs after this point returns its own gradient
+        # gradient of the pooled sibling output: folded into the data-gradient launch at half resolution when the kernel takes it
+        # (bf16, even map, channel count a multiple of 8, no graph being recorded), otherwise added as the ordinary adjoint FIR pass
+        res_pooled, res_scale, dx_pool = None, 1.0, None
+        if dtp is not None and ctx.pool is not None:
+            f, pool_gain = ctx.pool
+            can_fold = (not torch.is_grad_enabled()) and _PREMASK and s_in is None and x.dtype == torch.bfloat16 and x.shape[1] % 8 == 0 \
+                and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
+            if can_fold:
+                res_pooled, res_scale = dtp.to(x.dtype).contiguous(memory_format=torch.channels_last), pool_gain * 0.25
+            else:
+                from ...stylegan3_ops import upfirdn2d
+                _, _, ih, iw = x.shape
+                _, _, oh, ow = dtp.shape
+                dx_pool = upfirdn2d.upfirdn2d(dtp.to(x.dtype), f, up=2, padding=[1, iw - 2 * ow, 1, ih - 2 * oh], flip_filter=True, gain=pool_gain)
         if torch.is_grad_enabled():
             # a graph is being recorded (R1 differentiates D twice): compose from differentiable ops
             if s_in is not None or s_out is not None or noise is not None:
@@ -672,6 +652,8 @@ class _FusedConv(torch.autograd.Function):
                 dres = g
             if need_x:
                 dx = _ConvFwd.apply(g, flip_transpose(w), None, None)
+                if dx_pool is not None:
+                    dx = dx + dx_pool
             if need_w:
                 dw = (_ConvWgrad.apply(x, g, None, None, k) * coef).to(weight.dtype)
             return dx, dw, None, None, None, db, None, dres, None, None, None, None, None, None
@@ -710,7 +692,10 @@ class _FusedConv(torch.autograd.Function):
         if need_x or (s_in is not None and need_si):
             prep = prepared_weights(weight, coef, x.dtype, need_ft=True)
             pre = ctx.pre_link
-            if pre is not None and pre.armed and s_in is None and need_x and x.dtype == torch.bfloat16 and x.shape[1] % 8 == 0:
+            # (the producer's lrelu mask may only ride in this launch when this launch carries the WHOLE gradient of x: a pooled
+            #  branch that could not be folded in is added afterwards and would stay unmasked)
+            if pre is not None and pre.armed and s_in is None and need_x and x.dtype == torch.bfloat16 and x.shape[1] % 8 == 0 \
+                    and dx_pool is None:
                 # x is the lrelu output of the producer this link came from and we are its only consumer: hand it the masked gradient
                 pre.bsum = _zeros_f32((256, x.shape[1]), x.device)
                 t = conv2d_fwd_raw(g, prep.wq_ft, in_scale=s_out, prepared=True, gain=pg, mask_y=x, mask_alpha=pre.alpha, mask_sum=pre.bsum,
@@ -722,16 +707,21 @@ class _FusedConv(torch.autograd.Function):
                 dx = t
             else:
                 dx, dsi = scale_dot_raw(x, t, s_in, want_dx=need_x)
+            if dx_pool is not None and dx is not None:
+                dx = dx + dx_pool
+        elif dx_pool is not None and need_x:
+            dx = dx_pool
         if need_w:
             dw = conv2d_wgrad_raw(x, g, k, in_scale=s_in, out_scale=s_out, scale=coef * pg).to(weight.dtype)
         return dx, dw, None, dsi, dso, db, None, dres, None, None, None, None, None, None
 
 
 def conv2d_act(x, weight, bias=None, s_in=None, s_out=None, noise=None, alpha=0.2, fused=True, coef=1.0,
-               act='lrelu', residual=None, gain=1.0, pre_link=None, post_link=None, skip_link=None):
+               act='lrelu', residual=None, gain=1.0, pre_link=None, post_link=None, skip_pool=None):
     """act( s_out * conv(x * s_in, weight * coef) + bias + noise + residual ) * gain; act = 'lrelu' | 'linear'.
     bias [Cout], noise [N,1,H,W] (no gradient), residual like the output.
-    ``fused=False`` evaluates the same expression with the separately differentiable ops (any-order gradients)."""
+    ``fused=False`` evaluates the same expression with the separately differentiable ops (any-order gradients).
+    ``skip_pool = (f, gain)``: also return ``downsample2d(x, f, down=2, gain=gain)`` (see ``_FusedConv``): the result is ``(y, pooled)``."""
     from ...stylegan3_ops import bias_act as _ba
     Cout, Cin = weight.shape[0], weight.shape[1]
     if fused and Cout % 8 == 0 and (act == 'linear' or gain == 1.0 or s_out is None) and not (act == 'linear' and s_out is not None):
@@ -739,12 +729,22 @@ def conv2d_act(x, weight, bias=None, s_in=None, s_out=None, noise=None, alpha=0.
             x = _pad_channels(x, 8, 1).contiguous(memory_format=torch.channels_last)
             weight = _pad_channels(weight, 8, 1)
             s_in = _pad_channels(s_in, 8, 1) if s_in is not None else None
-            pre_link = skip_link = None               # the links describe the UNPADDED input tensor
+            pre_link = None                           # the link describes the UNPADDED input tensor
+            if skip_pool is not None:                 # (not a case the networks produce: pool the unpadded tensor separately)
+                from ...stylegan3_ops import upfirdn2d
+                tp = upfirdn2d.downsample2d(x[:, :Cin], skip_pool[0], down=2, gain=skip_pool[1])
+                return _FusedConv.apply(x, weight, coef, s_in, s_out, bias, noise, residual,
+                                        ACT_LRELU if act == 'lrelu' else ACT_LINEAR, alpha, gain, pre_link, post_link, None), tp
         return _FusedConv.apply(x, weight, coef, s_in, s_out, bias, noise, residual,
-                                ACT_LRELU if act == 'lrelu' else ACT_LINEAR, alpha, gain, pre_link, post_link, skip_link)
+                                ACT_LRELU if act == 'lrelu' else ACT_LINEAR, alpha, gain, pre_link, post_link, skip_pool)
+    x_in = x
     out = conv2d(x, weight * coef if coef != 1.0 else weight, s_in, s_out)
     if noise is not None:
         out = out + noise.to(out.dtype)
     if residual is not None:
         out = out + residual.to(out.dtype)
-    return _ba.bias_act(out, bias.to(out.dtype) if bias is not None else None, act=act, alpha=alpha if act == 'lrelu' else None, gain=gain)
+    out = _ba.bias_act(out, bias.to(out.dtype) if bias is not None else None, act=act, alpha=alpha if act == 'lrelu' else None, gain=gain)
+    if skip_pool is not None:
+        from ...stylegan3_ops import upfirdn2d
+        return out, upfirdn2d.downsample2d(x_in, skip_pool[0], down=2, gain=skip_pool[1])
+    return out

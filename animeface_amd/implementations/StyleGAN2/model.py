@@ -29,7 +29,7 @@ import torch.nn.functional as F
 
 from ...stylegan3_ops import upfirdn2d, bias_act
 from ... import rng
-from .conv import conv2d, conv2d_act, style_demod, PremaskLink, SkipLink, pool2x_linked, pool2x_skip, up_blur
+from .conv import conv2d, conv2d_act, style_demod, PremaskLink, pool2x_linked, up_blur
 
 
 # bias / noise / leaky-ReLU run in the conv kernel's epilogue (with a fused backward).  The fused modulated conv has
@@ -58,7 +58,7 @@ class ELR(nn.Module):
         return F.linear(x * self.coef, self.layer.weight, self.layer.bias)
 
 
-def elr_conv2d(elr, x, act=None, residual=None, gain=1.0, out_gain=1.0, pre_link=None, post_link=None, skip_link=None):
+def elr_conv2d(elr, x, act=None, residual=None, gain=1.0, out_gain=1.0, pre_link=None, post_link=None, skip_pool=None):
     """``ELR(nn.Conv2d)`` on the MFMA conv; coef is folded into the weights; optional fused-order bias + lrelu.
     ``out_gain`` (linear layers only) scales the conv + bias part of the output by a constant for free: it is folded into the
     weight coefficient and the bias instead of being applied to the output tensor (nothing to undo in backward either)."""
@@ -72,7 +72,7 @@ def elr_conv2d(elr, x, act=None, residual=None, gain=1.0, out_gain=1.0, pre_link
         bias = bias * out_gain if bias is not None else None
     return conv2d_act(x, conv.weight, bias, alpha=0.2, fused=FUSED_EPILOGUE, coef=coef,
                       act='lrelu' if act == 'lrelu' else 'linear', residual=residual, gain=gain,
-                      pre_link=pre_link, post_link=post_link, skip_link=skip_link)
+                      pre_link=pre_link, post_link=post_link, skip_pool=skip_pool)
 
 
 def Linear(name, *args, **kwargs):
@@ -107,9 +107,7 @@ class _AvgPool2x(nn.Module):
         super().__init__()
         self.register_buffer('f', upfirdn2d.setup_filter([1, 1]), persistent=False)
 
-    def forward(self, x, gain=1, link=None, skip_link=None):
-        if skip_link is not None:
-            return pool2x_skip(x, self.f, gain, skip_link)    # x is also the input of the block's first conv (SkipLink)
+    def forward(self, x, gain=1, link=None):
         if link is not None:
             return pool2x_linked(x, self.f, gain, link)       # x is a fused conv's lrelu output and this is its only consumer
         return upfirdn2d.downsample2d(x, self.f, down=2, gain=gain)
@@ -281,21 +279,24 @@ class DBlock(nn.Module):
         # conv -> lrelu -> conv chains: the next conv is the only consumer of the activation, so its data-gradient launch applies the
         # lrelu gradient of the layer below (PremaskLink / agf_conv2d_fwd_mask) instead of a separate pass over the tensor
         pooled = isinstance(self.down, _AvgPool2x) and FUSED_EPILOGUE
-        # the block input feeds the first conv AND the pooled skip branch: the skip branch's gradient joins the first conv's
-        # data-gradient launch at half resolution (SkipLink) -- then that launch is the only source of the input's gradient and may
-        # also apply the producer's lrelu gradient (in_link)
-        skip_link = SkipLink() if pooled else None
+        # the block input feeds the first conv AND the pooled skip branch: the first conv's op also returns the pooled input, so the
+        # skip branch's gradient arrives in the same backward call and joins the data-gradient launch at half resolution -- that launch
+        # is then the only source of the input's gradient and may also apply the producer's lrelu gradient (in_link)
         pre = in_link if pooled else None
+        t_pooled = None
         for i in range(0, len(mods), 2):
             post = PremaskLink() if (i + 2 < len(mods) or pooled) else None
-            x = elr_conv2d(mods[i], x, act='lrelu', pre_link=pre, post_link=post, skip_link=skip_link if i == 0 else None)
+            if i == 0 and pooled:
+                x, t_pooled = elr_conv2d(mods[i], x, act='lrelu', pre_link=pre, post_link=post, skip_pool=(self.down.f, 1))
+            else:
+                x = elr_conv2d(mods[i], x, act='lrelu', pre_link=pre, post_link=post)
             pre = post
         c = float(1 / np.sqrt(2))
         if isinstance(self.down, _AvgPool2x):
             # avg-pool commutes with the 1x1 skip conv: pool first (4x less work), identical result
             # (skip(pool(t)) + pool(x)) / sqrt(2): the residual add runs in the 1x1 conv's epilogue; the 1/sqrt(2) costs nothing:
             # it is folded into the skip conv's weight coefficient / bias and into the gain of the pooling FIR of x
-            return elr_conv2d(self.skip, self.down(t, skip_link=skip_link), residual=self.down(x, gain=c, link=pre), out_gain=c)
+            return elr_conv2d(self.skip, t_pooled, residual=self.down(x, gain=c, link=pre), out_gain=c)
         t = self.skip(t)
         return (self.down(x) + self.down(t)) / np.sqrt(2)
 

@@ -58,6 +58,8 @@ class TrainStep:
         # policy 'ada' selects the adaptive pipe of BASELINE config "StyleGAN2 256 + ADA + R1" (built on the first batch, whose size
         # fixes the p step); any other string is a DiffAugment policy as in the reference (utils.py:160)
         self.ada = None
+        self.policy = policy
+        self._pending_ada_state = None
         self.augment = (lambda x: self._ada_pipe(x)(x)) if policy == 'ada' else functools.partial(DiffAugment, policy=policy)
         self.latent_dim, self.sampler = latent_dim, sampler
         self.reducer_G, self.reducer_D = reducer_G, reducer_D
@@ -82,6 +84,10 @@ class TrainStep:
         if self.ada is None:
             from ...nnutils.ada import ADA
             self.ada = ADA(x.size(0)).to(x.device)
+            if self._pending_ada_state is not None:          # a resumed run: checkpoint.load() ran before the pipe existed
+                self.ada.load_state_dict(self._pending_ada_state['state'])
+                self.ada._num_iter = int(self._pending_ada_state['num_iter'])
+                self._pending_ada_state = None
         return self.ada
 
     def _zero(self, opt, reducer):
@@ -170,7 +176,13 @@ class TrainStep:
         if it % self.g_k == 0 and self.pl_lambda > 0 and it != 0:
             pl = pl_penalty(style, fake, self.pl_mean, None)
             G_loss = pl * self.pl_lambda * self.g_k
-            self.pl_mean = update_pl_mean(self.pl_mean, float(pl.detach()))
+            pl_now = pl.detach().float().clone()
+            if self.reducer_G is not None and dp.dist.is_initialized() and dp.dist.get_world_size() > 1:
+                # the running path-length mean is a statistic of the GLOBAL batch: average it over the replicas so that every rank keeps
+                # the same pl_mean (otherwise their penalties, hence their losses, drift apart)
+                dp.dist.all_reduce(pl_now)
+                pl_now /= dp.dist.get_world_size()
+            self.pl_mean = update_pl_mean(self.pl_mean, float(pl_now))
         else:
             G_loss = self.loss.g_loss(fake_prob)
         G_loss.backward()
@@ -269,7 +281,7 @@ def main(parser, dataset=None):
     G, G_ema, D = build_models(args, device, compute_dtype)
     dp.broadcast_module(G), dp.broadcast_module(G_ema), dp.broadcast_module(D)
     optimizer_G, optimizer_D = build_optimizers(G, D, args.lr, (args.beta1, args.beta2), args.r1_lambda, args.pl_lambda, args.d_k, args.g_k)
-    reducer_G = dp.GradReducer(G.parameters()) if world > 1 else None
+    reducer_G = dp.GradReducer(G.parameters(), never_used=dp.never_used_parameters(G)) if world > 1 else None
     reducer_D = dp.GradReducer(D.parameters()) if world > 1 else None
     if dataset is None:
         gen = torch.Generator(device='cpu').manual_seed(rank)

@@ -22,6 +22,8 @@ for name, pred in [('conv2d_fwd', lambda k: 'conv2d_fwd' in k), ('conv2d_wgrad',
     out[name] = {'launches': nf, 'fetch_bytes_per_launch': 2 * f * 1024 / max(nf, 1), 'write_bytes_per_launch': w * 1024 / max(nw, 1),
                  'traffic_bytes_per_launch': (2 * f * 1024 / max(nf, 1)) + (w * 1024 / max(nw, 1)),
                  'note': 'FETCH_SIZE (KB) x2 gfx950 correction + WRITE_SIZE (KB), averaged over every launch of 3 bench.py steps (B=64, 256x256)'}
+import os
+out['commit'] = os.environ.get('AGF_COMMIT', 'unknown')      # the GPU box has no .git: pass AGF_COMMIT=$(git rev-parse --short HEAD)
 json.dump(out, open('gpurun_out/conv_traffic.json', 'w'), indent=1)
 print(json.dumps(out, indent=1))
 PY
