@@ -54,6 +54,32 @@ class Config:
 
 
 # ---------------------------------------------------------------------------------------------
+# bf16-storage emulation.  The product keeps activations and the prepared weights in bf16 and accumulates in fp32; inside
+# ``with bf16_storage():`` this restatement rounds to bf16 at the SAME points (conv operands: x * style and W * coef; every tensor
+# a kernel writes: conv + epilogue output, FIR output, RGB skip sums), so the MFMA network path can be compared with it at a few bf16
+# ulps instead of the ~6e-2 that separates bf16 from the fp32 reference.  Gradients flow through the rounding unchanged (straight
+# through), i.e. they are the fp32 gradients of the rounded forward pass.  Off by default: the fp32 restatement of the reference.
+
+_BF16_STORAGE = False
+
+
+class bf16_storage:
+    def __enter__(self):
+        global _BF16_STORAGE
+        self.prev, _BF16_STORAGE = _BF16_STORAGE, True
+
+    def __exit__(self, *a):
+        global _BF16_STORAGE
+        _BF16_STORAGE = self.prev
+
+
+def q(x):
+    if not _BF16_STORAGE:
+        return x
+    return x + (x.to(torch.bfloat16).to(x.dtype) - x).detach()
+
+
+# ---------------------------------------------------------------------------------------------
 # layers
 
 def elr_linear(sd, prefix, x, gain=1.0):
@@ -67,6 +93,8 @@ def elr_conv(sd, prefix, x, padding):
     """ELR(nn.Conv2d) (model.py:29-37,50-53)."""
     w, b = sd[prefix + '.layer.weight'], sd[prefix + '.layer.bias']
     coef = 1.0 / math.sqrt(w[0].numel())
+    if _BF16_STORAGE:                                   # the product folds coef into the prepared (bf16) weights
+        return F.conv2d(q(x), q(w * coef), b, padding=padding)
     return F.conv2d(x * coef, w, b, padding=padding)
 
 
@@ -78,9 +106,16 @@ def modulated_conv2d(sd, prefix, x, y, demod=True, gain=1.0):
     s = elr_linear(sd, prefix + '.affine', y) + 1                                   # :110
     coef = gain / math.sqrt(weight[0].numel())                                      # :105
     w = weight[None] * s[:, None, :, None, None] * coef                             # :115
+    pad = (k - 1) // 2                                                              # :134-135 with stride 1
+    if _BF16_STORAGE:
+        # the product's factorisation: d * conv(bf16(x * s), bf16(W * coef)) with d from the unrounded fp32 weights
+        d = torch.rsqrt(w.pow(2).sum([2, 3, 4]) + 1e-4) if demod else None
+        out = F.conv2d(q(x * s[:, :, None, None]), q(weight * coef), padding=pad)
+        if d is not None:
+            out = out * d[:, :, None, None]
+        return out + bias
     if demod:
         w = w * torch.rsqrt(w.pow(2).sum([2, 3, 4], keepdim=True) + 1e-4)           # :118-120
-    pad = (k - 1) // 2                                                              # :134-135 with stride 1
     out = F.conv2d(x.reshape(1, B * cin, H, W), w.reshape(B * cout, cin, k, k), padding=pad, groups=B)   # :123-129
     return out.reshape(B, cout, H, W) + bias                                        # :132
 
@@ -145,28 +180,32 @@ class NoiseSource:
         return n
 
 
-def synthesis(sd, cfg, x, styles, noise, prefix='synthesis'):
-    """Synthesis.forward (model.py:312-332) with ``styles`` already a per-layer list."""
+def synthesis(sd, cfg, x, styles, noise, prefix='synthesis', collect=None):
+    """Synthesis.forward (model.py:312-332) with ``styles`` already a per-layer list.  ``collect``: optional list that receives the
+    feature map after the input layer and after every StyleBlock."""
     _, blocks = cfg.synthesis_channels()
-    x = modulated_conv2d(sd, f'{prefix}.input', x, styles[0])                                   # :324
-    pre = upsample2x(modulated_conv2d(sd, f'{prefix}.input_to_image.conv', x, styles[0], demod=False))   # :325, ToImage :244-250
+    keep = (lambda v: collect.append(v.detach())) if collect is not None else (lambda v: None)
+    x = q(modulated_conv2d(sd, f'{prefix}.input', q(x), styles[0]))                             # :324
+    keep(x)
+    pre = q(upsample2x(q(modulated_conv2d(sd, f'{prefix}.input_to_image.conv', x, styles[0], demod=False))))   # :325, ToImage :244-250
     image = pre
     for i, (resl, _ic, _oc) in enumerate(blocks):
         y = styles[i + 1]
         # StyleBlock (model.py:154-180): up, blur, [modconv, noise, lrelu] * num_conv
-        x = blur2d(upsample2x(x))
+        x = q(blur2d(upsample2x(x)))                      # (the product runs the pair as one FIR pass: one rounding)
         for j in range(cfg.block_num_conv):
             x = modulated_conv2d(sd, f'{prefix}.blocks.{i}.block.{2 + 3 * j}', x, y)
             x = x + noise(x.shape[0], x.shape[2], x.shape[3], x.device, x.dtype)              # InjectNoise: unscaled (F10)
-            x = F.leaky_relu(x, 0.2)
-        image = modulated_conv2d(sd, f'{prefix}.to_images.{i}.conv', x, y, demod=False) + pre  # ToImage :245-247
+            x = q(F.leaky_relu(x, 0.2))
+        keep(x)
+        image = q(q(modulated_conv2d(sd, f'{prefix}.to_images.{i}.conv', x, y, demod=False)) + pre)  # ToImage :245-247
         if resl < cfg.image_size:
-            image = upsample2x(image)                                                          # :248-249
+            image = q(upsample2x(image))                                                       # :248-249
         pre = image
     return torch.tanh(image)                                                                    # :332
 
 
-def generator(sd, cfg, z, noise=None, injection=None):
+def generator(sd, cfg, z, noise=None, injection=None, collect=None):
     """Generator.forward (model.py:351-363).  Returns (image, style)."""
     noise = noise if noise is not None else NoiseSource()
     n_layers = len(cfg.synthesis_channels()[1]) + 1
@@ -180,29 +219,41 @@ def generator(sd, cfg, z, noise=None, injection=None):
         B = z.shape[0]
         styles = [style] * n_layers
     x = sd['const'].expand(B, -1, -1, -1)
-    return synthesis(sd, cfg, x, styles, noise), style
+    return synthesis(sd, cfg, x, styles, noise, collect=collect), style
 
 
 def d_block(sd, prefix, x, num_conv):
     """DBlock.forward (model.py:204-212)."""
     t = x
     for j in range(num_conv):
-        x = F.leaky_relu(elr_conv(sd, f'{prefix}.block.{2 * j}', x, 1), 0.2)
+        x = q(F.leaky_relu(elr_conv(sd, f'{prefix}.block.{2 * j}', x, 1), 0.2))
+    if _BF16_STORAGE:
+        # the product's order: pool the block input first (it commutes with the 1x1 conv), 1/sqrt(2) folded into the skip weights and
+        # the pooling gain, the sum formed in the skip conv's epilogue
+        c = 1 / np.sqrt(2)
+        w, b = sd[f'{prefix}.skip.layer.weight'], sd[f'{prefix}.skip.layer.bias']
+        coef = c / math.sqrt(w[0].numel())
+        return q(F.conv2d(q(F.avg_pool2d(t, 2)), q(w * coef), b * c) + q(F.avg_pool2d(x, 2) * c))
     t = elr_conv(sd, f'{prefix}.skip', t, 0)
     x = F.avg_pool2d(x, 2)
     t = F.avg_pool2d(t, 2)
     return (x + t) / np.sqrt(2)
 
 
-def discriminator(sd, cfg, x):
-    """Discriminator.forward (model.py:398-401) over the nn.Sequential of :375-397."""
+def discriminator(sd, cfg, x, collect=None):
+    """Discriminator.forward (model.py:398-401) over the nn.Sequential of :375-397.  ``collect``: optional list that receives the
+    activation after from_rgb, after every DBlock and after the last conv (layer-wise parity tests)."""
     dblocks, oc, resl = cfg.discriminator_channels()
-    x = F.leaky_relu(elr_conv(sd, 'from_rgb.0', x, 0), 0.2)
+    keep = (lambda v: collect.append(v.detach())) if collect is not None else (lambda v: None)
+    x = q(F.leaky_relu(elr_conv(sd, 'from_rgb.0', q(x), 0), 0.2))
+    keep(x)
     for i in range(len(dblocks)):
         x = d_block(sd, f'blocks.{i}', x, cfg.block_num_conv)
+        keep(x)
     n = len(dblocks)
-    x = minibatch_stddev(x, cfg.mbsd_groups)                                    # blocks.{n}
-    x = F.leaky_relu(elr_conv(sd, f'blocks.{n + 1}', x, 1), 0.2)                # blocks.{n+1}, {n+2}
+    x = q(minibatch_stddev(x, cfg.mbsd_groups))                                 # blocks.{n}
+    x = q(F.leaky_relu(elr_conv(sd, f'blocks.{n + 1}', x, 1), 0.2))             # blocks.{n+1}, {n+2}
+    keep(x)
     x = x.reshape(x.shape[0], -1)                                               # Flatten blocks.{n+3}
     x = F.leaky_relu(elr_linear(sd, f'blocks.{n + 4}', x), 0.2)                 # blocks.{n+4}, {n+5}
     return elr_linear(sd, f'blocks.{n + 6}', x)                                 # blocks.{n+6}

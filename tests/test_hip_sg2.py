@@ -231,3 +231,39 @@ def test_checkpoint_resume_continues_the_run(tmp_path):
         torch.testing.assert_close(v, w, rtol=1e-4, atol=1e-5, msg=lambda m, k=k: f'{k}: {m}')
     for (k, v), (_, w) in zip(a.G_ema.state_dict().items(), b.G_ema.state_dict().items()):
         torch.testing.assert_close(v, w, rtol=1e-4, atol=1e-5, msg=lambda m, k=k: f'{k}: {m}')
+
+
+def test_checkpoint_resume_restores_the_ada_state_of_a_lazily_built_pipe(tmp_path):
+    """policy='ada': the trainer builds its pipe on the first batch, i.e. AFTER checkpoint.load() ran on a fresh TrainStep -- the saved
+    probability / sign statistic / iteration count must still arrive (they used to be dropped silently: p restarted at 0)."""
+    import functools
+    from animeface_amd.implementations.StyleGAN2 import utils as U
+    from animeface_amd.nnutils import sample_nnoise, update_ema
+    from animeface_amd import checkpoint
+
+    def make(seed, policy='ada'):
+        torch.manual_seed(seed)
+        M, G, D = build(torch.float32)
+        _, G_ema, _ = build(torch.float32)
+        G.init_weight(functools.partial(M.init_weight_N01, lr=0.01), M.init_weight_N01)
+        D.apply(M.init_weight_N01)
+        G_ema.eval()
+        update_ema(G, G_ema, decay=0)
+        oG, oD = U.build_optimizers(G, D, 0.001, (0., 0.99), 10., 0., 16, 8)
+        return U.TrainStep(G, G_ema, D, oG, oD, 10., 0., 16, 8, policy, TINY['style_dim'], functools.partial(sample_nnoise, device=DEV))
+    real = torch.rand(4, 3, 16, 16, device=DEV) * 2 - 1
+    a = make(1)
+    for _ in range(5):                              # the ADA interval is 4 iterations: p has been updated once
+        a(real)
+    a.ada.p.fill_(0.37)                             # a value the controller would not reach by itself in five iterations
+    path = str(tmp_path / 'ada.pt')
+    checkpoint.save(a, path)
+    b = checkpoint.load(make(2), path)
+    assert b.ada is None and b._pending_ada_state is not None     # nothing to load into yet ...
+    b(real)
+    assert b.ada is not None and b._pending_ada_state is None      # ... applied when the pipe was built
+    a(real)
+    assert float(b.ada.p) == pytest.approx(float(a.ada.p), abs=1e-6) and float(b.ada.p) > 0.3
+    assert b.ada._num_iter == a.ada._num_iter
+    with pytest.raises(RuntimeError, match='ADA state'):
+        checkpoint.load(make(3, policy='color,translation'), path)
