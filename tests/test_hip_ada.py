@@ -107,7 +107,8 @@ def test_ada_training_steps_run_and_adapt_p():
 @pytest.mark.gpu
 @pytest.mark.parametrize('shape', [(4, 3, 40, 52, 36, 44), (3, 1, 64, 64, 64, 64), (2, 3, 33, 47, 70, 58)])
 def test_fused_affine_resample_matches_grid_sample(shape):
-    """agf_affine_resample (forward gather, exact-adjoint backward gather) against F.affine_grid + F.grid_sample."""
+    """agf_affine_resample (forward gather, exact-adjoint backward gather) against F.affine_grid + F.grid_sample evaluated on the CPU
+    (the calls the reference makes, thirdparty/ada/augment.py:275-283, on the reference's own substrate -- not a GPU composite of the product)."""
     import math
     import torch.nn.functional as F
     from animeface_amd.thirdparty.ada import _AffineResample
@@ -127,11 +128,13 @@ def test_fused_affine_resample_matches_grid_sample(shape):
         x = x0.clone().requires_grad_(True)
         if fused:
             y = _AffineResample.apply(x, theta, Hout, Wout)
+            (dx,) = torch.autograd.grad(y, x, gy)
         else:
-            y = F.grid_sample(x, F.affine_grid(theta, [B, C, Hout, Wout], align_corners=False), mode='bilinear', padding_mode='zeros',
+            x = x0.cpu().clone().requires_grad_(True)
+            y = F.grid_sample(x, F.affine_grid(theta.cpu(), [B, C, Hout, Wout], align_corners=False), mode='bilinear', padding_mode='zeros',
                               align_corners=False)
-        (dx,) = torch.autograd.grad(y, x, gy)
-        outs.append((y, dx))
+            (dx,) = torch.autograd.grad(y, x, gy.cpu())
+        outs.append((y.detach().cpu(), dx.cpu()))
     for a, b in zip(outs[0], outs[1]):
         assert a.shape == b.shape
         assert (a - b).abs().max().item() <= 2e-4 * max(1.0, b.abs().max().item())

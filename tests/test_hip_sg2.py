@@ -267,3 +267,58 @@ def test_checkpoint_resume_restores_the_ada_state_of_a_lazily_built_pipe(tmp_pat
     assert b.ada._num_iter == a.ada._num_iter
     with pytest.raises(RuntimeError, match='ADA state'):
         checkpoint.load(make(3, policy='color,translation'), path)
+
+
+def test_full_size_step_properties():
+    """One GAN-loss iteration and one lazy-R1 iteration of the BENCHMARK configuration (256x256, batch 64, bf16, DiffAugment): everything
+    finite, the discriminator receives no gradient in the generator half-step (it is frozen there), parameters that never get a
+    gradient are never stepped, and a replay with the same seeds reproduces the losses (the property checks a 64 x 256 x 256 run admits;
+    element-wise parity at this size is covered layer by layer in tests/test_hip_parity_bf16.py and test_hip_conv_bench_shapes.py)."""
+    import functools
+    from animeface_amd.implementations.StyleGAN2 import model as M, utils as U
+    from animeface_amd.nnutils import sample_nnoise, update_ema
+    from animeface_amd import rng
+
+    def run():
+        torch.manual_seed(0)
+        G, G_ema, D = M.Generator(256).to(DEV), M.Generator(256).to(DEV), M.Discriminator(256).to(DEV)
+        G.init_weight(functools.partial(M.init_weight_N01, lr=0.01), M.init_weight_N01)
+        D.apply(M.init_weight_N01)
+        G_ema.eval()
+        update_ema(G, G_ema, decay=0)
+        oG, oD = U.build_optimizers(G, D, 0.001, (0., 0.99), 10., 0., 16, 8)
+        step = U.TrainStep(G, G_ema, D, oG, oD, 10., 0., 16, 8, 'color,translation', 512, functools.partial(sample_nnoise, device=DEV))
+        gen = torch.Generator().manual_seed(3)
+        real = (torch.rand(64, 3, 256, 256, generator=gen) * 2 - 1).to(DEV)
+        seen = {}
+        orig = step._g_half
+
+        def g_half(real, it):
+            out = orig(real, it)
+            seen['d_frozen'] = all(not p.requires_grad for p in D.parameters())
+            return out
+        step._g_half = g_half
+        losses = []
+        with rng.cpu_stream():
+            torch.manual_seed(77)
+            losses.append([float(v) for v in step(real)[:2]])
+            d_after_first = {n: p.detach().clone() for n, p in D.named_parameters()}
+            step.batches_done = 16                                   # lazy R1: the penalty replaces the GAN loss
+            dl, gl, fake = step(real)
+            losses.append([float(dl), float(gl)])
+        assert seen['d_frozen']
+        assert torch.isfinite(fake).all() and tuple(fake.shape) == (64, 3, 256, 256)
+        for net in (G, D, G_ema):
+            for n, p in net.named_parameters():
+                assert torch.isfinite(p).all(), n
+        # D moved in both iterations (its optimizer stepped), InjectNoise.scale never did
+        assert any(not torch.equal(p.detach(), d_after_first[n]) for n, p in D.named_parameters())
+        for n, p in G.named_parameters():
+            if n.endswith('.scale'):
+                assert float(p.detach().abs().max()) == 0.0 and not oG.state.get(p), n
+        return losses
+    a = run()
+    b = run()
+    assert all(abs(x) < 1e4 for pair in a for x in pair), a
+    for (d0, g0), (d1, g1) in zip(a, b):
+        assert d0 == pytest.approx(d1, rel=2e-3, abs=1e-5) and g0 == pytest.approx(g1, rel=2e-3, abs=1e-5), (a, b)
