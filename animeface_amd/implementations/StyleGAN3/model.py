@@ -12,7 +12,11 @@ reference's ``implementations/StyleGAN3/model.py``; the arithmetic runs on this 
   ConvAct: conv2d_resample + bias_act (model.py:410-417)       stride-1 convs on the MFMA conv; 1x1+down = HIP upfirdn2d(down) then
                                                                 MFMA conv; 3x3+down = MFMA conv at stride 1 then HIP upfirdn2d(down)
                                                                 (FIR and conv commute, see ConvAct.forward); HIP bias_act
-Filter design (``design_filter``, ``get_layer_params``) is scipy / numpy arithmetic exactly as in model.py:76-115.
+The band-limit schedule (``get_layer_params``), the Kaiser filter design (``design_filter``), the resampling plan of a layer and
+the Fourier-feature input are written here from their definitions (alias-free GAN: geometric cutoff / stopband progressions,
+power-of-two sampling rates, windowed sinc / jinc low-pass filters, a rotated + translated sine basis); the values they produce --
+layer tables, filter taps, padding, buffers -- are pinned to the reference's by tests (tests/test_oracle_sg3.py,
+tests/test_hip_sg3.py::test_layer_params_and_filters_match_the_reference).
 """
 import math
 
@@ -23,12 +27,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ...stylegan3_ops import bias_act, filtered_lrelu, conv2d_resample, upfirdn2d, layout
+from ...stylegan3_ops import bias_act, filtered_lrelu, upfirdn2d, layout
 from ..StyleGAN2.conv import conv2d, conv2d_act
-
-
-def _native(x):
-    return x.is_cuda
 
 
 class _ZeroPadCL(torch.autograd.Function):
@@ -111,38 +111,81 @@ class ModulatedConv(nn.Module):
         return layout.channels_last_to_planar(y, 0, cout)  # planar for filtered_lrelu; its gradient returns channels-last
 
 
+def _kaiser_taper(numtaps, transition_width, fs):
+    """1-D Kaiser window whose side-lobe attenuation suits a transition band of ``transition_width`` at sampling rate ``fs``."""
+    attenuation = scipy.signal.kaiser_atten(numtaps, transition_width / (fs / 2))
+    return np.kaiser(numtaps, scipy.signal.kaiser_beta(attenuation))
+
+
+def _jinc_lowpass(numtaps, cutoff, transition_width, fs):
+    """Radially symmetric low-pass on a numtaps x numtaps lattice: the ideal circular response J1(2 pi fc r) / (pi r) sampled at the tap
+    positions (numtaps is even here, so no tap sits at r = 0), tapered by the separable Kaiser window, normalised to unit DC gain."""
+    pos = (np.arange(numtaps) - 0.5 * (numtaps - 1)) / fs
+    radius = np.sqrt(pos[None, :] ** 2 + pos[:, None] ** 2)
+    ideal = scipy.special.j1(2 * np.pi * cutoff * radius) / (np.pi * radius)
+    taper = _kaiser_taper(numtaps, transition_width, fs)
+    taps = ideal * taper[:, None] * taper[None, :]
+    return taps / taps.sum()
+
+
 def design_filter(numtaps, cutoff, width, fs, radial=False):
-    """Kaiser low-pass design of the reference (model.py:76-93): separable firwin, or the radially symmetric jinc."""
-    assert numtaps >= 1
+    """Low-pass FIR of ``numtaps`` taps (None for a single tap = no filtering): cutoff frequency ``cutoff``, transition band ``width``,
+    sampling rate ``fs``; separable windowed sinc (scipy's Kaiser ``firwin``) or, with ``radial``, the 2-D jinc design above
+    (the reference's ``design_filter``, model.py:76-93, produces the same taps)."""
+    if numtaps < 1:
+        raise ValueError('a filter needs at least one tap')
     if numtaps == 1:
         return None
-    if not radial:
-        return torch.as_tensor(scipy.signal.firwin(numtaps=numtaps, cutoff=cutoff, width=width, fs=fs), dtype=torch.float32)
-    x = (np.arange(numtaps) - (numtaps - 1) / 2) / fs
-    r = np.hypot(*np.meshgrid(x, x))
-    f = scipy.special.j1(2 * cutoff * (np.pi * r)) / (np.pi * r)
-    beta = scipy.signal.kaiser_beta(scipy.signal.kaiser_atten(numtaps, width / (fs / 2)))
-    w = np.kaiser(numtaps, beta)
-    f *= np.outer(w, w)
-    f /= np.sum(f)
-    return torch.as_tensor(f, dtype=torch.float32)
+    taps = _jinc_lowpass(numtaps, cutoff, width, fs) if radial else scipy.signal.firwin(numtaps=numtaps, cutoff=cutoff, width=width, fs=fs)
+    return torch.as_tensor(taps, dtype=torch.float32)
 
 
 def get_layer_params(image_size, num_layers, channels, max_channels=512, image_channels=3, margin_size=10,
                      first_cutoff=2, first_stopband=2 ** 2.1, last_stopband_rel=2 ** 0.3, num_critical=2):
-    """Per-layer channels / sizes / sampling rates / cutoffs / half widths (reference model.py:95-115)."""
-    last_cutoff = image_size / 2
-    last_stopband = last_cutoff * last_stopband_rel
-    exponents = np.minimum(np.arange(num_layers + 1) / (num_layers - num_critical), 1)
-    cutoffs = first_cutoff * (last_cutoff / first_cutoff) ** exponents
-    stopbands = first_stopband * (last_stopband / first_stopband) ** exponents
+    """Band-limit schedule of the num_layers + 1 layers (the last one is the RGB layer); returns five arrays
+    (channels, sizes, sampling_rates, cutoffs, half_widths) like the reference's ``get_layer_params`` (model.py:95-115).
+
+    Cutoff and stopband grow geometrically from their first-layer values to the output's Nyquist frequency (image_size / 2, resp. that times
+    ``last_stopband_rel``) and stay there for the last ``num_critical`` layers.  A layer is sampled at the next power of two above
+    twice its stopband (never above the output resolution); its transition band reaches from the cutoff to the stopband, or to the
+    layer's own Nyquist frequency where that is larger; feature maps carry ``margin_size`` extra samples per side except the last two;
+    the channel count is inversely proportional to the cutoff."""
+    depth = np.arange(num_layers + 1)
+    progress = np.minimum(depth / (num_layers - num_critical), 1)
+    nyquist_out = image_size / 2
+    cutoffs = first_cutoff * (nyquist_out / first_cutoff) ** progress
+    stop_last = nyquist_out * last_stopband_rel
+    stopbands = first_stopband * (stop_last / first_stopband) ** progress
     sampling_rates = np.exp2(np.ceil(np.log2(np.minimum(stopbands * 2, image_size))))
     half_widths = np.maximum(stopbands, sampling_rates / 2) - cutoffs
-    sizes = sampling_rates + margin_size * 2
+    sizes = sampling_rates + 2 * margin_size
     sizes[-2:] = image_size
-    channels = np.rint(np.minimum((channels / 2) / cutoffs, max_channels))
-    channels[-1] = image_channels
-    return channels, sizes, sampling_rates, cutoffs, half_widths
+    widths = np.rint(np.minimum((channels / 2) / cutoffs, max_channels))
+    widths[-1] = image_channels
+    return widths, sizes, sampling_rates, cutoffs, half_widths
+
+
+def _resampling_plan(in_rate, out_rate, in_size, out_size, kernel_size, filter_size, lrelu_sampling, is_rgb):
+    """Up / down factors, filter lengths and padding of one layer's ``filtered_lrelu``.
+
+    The non-linearity runs at a working rate of ``lrelu_sampling`` x the larger of the layer's input / output rates (the RGB layer has no
+    non-linearity: factor 1, no filters).  Per axis, at the working rate: the conv output has (in + k - 1) * up samples, the two FIRs
+    shorten it by (up_taps - 1) + (down_taps - 1), and (out - 1) * down + 1 samples must remain for the decimation to deliver ``out``
+    samples -- the difference is the padding, split so that the up-filter stays centred on the input lattice."""
+    work_rate = max(in_rate, out_rate) * (1 if is_rgb else lrelu_sampling)
+    up, down = int(round(work_rate / in_rate)), int(round(work_rate / out_rate))
+    if in_rate * up != work_rate or out_rate * down != work_rate:
+        raise ValueError('sampling rates must divide the working rate')
+    up_taps = filter_size * up if (up > 1 and not is_rgb) else 1
+    down_taps = filter_size * down if (down > 1 and not is_rgb) else 1
+    in_size = np.broadcast_to(np.asarray(in_size), [2])
+    out_size = np.broadcast_to(np.asarray(out_size), [2])
+    needed = (out_size - 1) * down + 1
+    available = (in_size + kernel_size - 1) * up - (up_taps - 1) - (down_taps - 1)
+    total = needed - available
+    lo = (total + up) // 2
+    hi = total - lo
+    return work_rate, up, down, up_taps, down_taps, [int(lo[0]), int(hi[0]), int(lo[1]), int(hi[1])]
 
 
 class StyleLayer(nn.Module):
@@ -152,34 +195,18 @@ class StyleLayer(nn.Module):
                  in_sampling_rate, out_sampling_rate, in_cutoff, out_cutoff, in_half_width, out_half_width,
                  is_rgb, is_critical_sampled, lrelu_sampling=2, filter_size=6, conv_clamp=256, ema_decay=0.999) -> None:
         super().__init__()
-        self.conv_clamp = conv_clamp
-        self.ema_decay = ema_decay
-        self.is_rgb = is_rgb
-        self.gain = 1. if is_rgb else 2 ** 0.5
-        self.negative_slope = 1. if is_rgb else 0.2
+        self.conv_clamp, self.ema_decay, self.is_rgb = conv_clamp, ema_decay, is_rgb
+        self.gain, self.negative_slope = (1., 1.) if is_rgb else (2 ** 0.5, 0.2)          # the RGB layer is linear
         self.affine = Linear(style_dim, in_channels, True)
-        self.affine.bias.data.fill_(1.)
-        self.register_buffer('ema', torch.ones([]))
-
-        tmp_srate = max(in_sampling_rate, out_sampling_rate) * (1 if is_rgb else lrelu_sampling)
-        self.up_factor = int(np.rint(tmp_srate / in_sampling_rate))
-        assert in_sampling_rate * self.up_factor == tmp_srate
-        up_taps = filter_size * self.up_factor if self.up_factor > 1 and not is_rgb else 1
-        self.register_buffer('up_filter', design_filter(up_taps, in_cutoff, in_half_width * 2, tmp_srate))
-        self.down_factor = int(np.rint(tmp_srate / out_sampling_rate))
-        assert out_sampling_rate * self.down_factor == tmp_srate
-        down_taps = filter_size * self.down_factor if self.down_factor > 1 and not is_rgb else 1
-        self.register_buffer('down_filter', design_filter(down_taps, out_cutoff, out_half_width * 2, tmp_srate,
-                                                          not is_critical_sampled))
-        in_size = np.broadcast_to(np.asarray(in_size), [2])
-        out_size = np.broadcast_to(np.asarray(out_size), [2])
-        pad_total = (out_size - 1) * self.down_factor + 1
-        pad_total -= (in_size + kernel_size - 1) * self.up_factor
-        pad_total += up_taps + down_taps - 2
-        pad_lo = (pad_total + self.up_factor) // 2
-        pad_hi = pad_total - pad_lo
-        self.padding = [int(pad_lo[0]), int(pad_hi[0]), int(pad_lo[1]), int(pad_hi[1])]
-        self.conv = ModulatedConv(in_channels, out_channels, kernel_size, kernel_size - 1, not is_rgb)
+        nn.init.ones_(self.affine.bias)
+        self.register_buffer('ema', torch.ones([]))                                       # running mean of x^2 (input magnitude)
+        work_rate, self.up_factor, self.down_factor, up_taps, down_taps, self.padding = _resampling_plan(
+            in_sampling_rate, out_sampling_rate, in_size, out_size, kernel_size, filter_size, lrelu_sampling, is_rgb)
+        # interpolation filter: band limit of the INPUT; decimation filter: band limit of the OUTPUT, radially symmetric unless the
+        # layer is critically sampled; both designed at the working rate, transition band = twice the half width
+        self.register_buffer('up_filter', design_filter(up_taps, in_cutoff, in_half_width * 2, work_rate))
+        self.register_buffer('down_filter', design_filter(down_taps, out_cutoff, out_half_width * 2, work_rate, radial=not is_critical_sampled))
+        self.conv = ModulatedConv(in_channels, out_channels, kernel_size, kernel_size - 1, demod=not is_rgb)
         self.bias = nn.Parameter(torch.zeros(out_channels))
 
     def forward(self, x, w):
@@ -197,54 +224,51 @@ class StyleLayer(nn.Module):
 
 
 class SynthesisInput(nn.Module):
-    """Fourier-feature input with a learned rotation / translation (reference model.py:193-267); small fp32 torch math."""
+    """Fourier-feature input: ``channels`` plane waves with random frequencies inside the band limit, rotated and translated by a
+    learned function of the style, mixed by a learned matrix (the reference's ``SynthesisInput``, model.py:193-267; parameters and
+    buffers carry the same names).  Small fp32 torch math."""
 
     def __init__(self, style_dim, channels, size, sampling_rate, bandwidth) -> None:
         super().__init__()
-        self.channels = channels
-        self.bandwidth = bandwidth
-        self.sampling_rate = sampling_rate
-        self.size = list(map(int, (np.broadcast_to(np.asarray(size), [2]))))
+        self.channels, self.bandwidth, self.sampling_rate = channels, bandwidth, sampling_rate
+        self.size = [int(v) for v in np.broadcast_to(np.asarray(size), [2])]             # [width, height]
+        # directions ~ N(0, I), radii reshaped so that |f| <= bandwidth with the reference's radial density: f / (|f| * exp(|f|^2 / 4))
         freqs = torch.randn(channels, 2)
-        radii = freqs.square().sum(1, keepdim=True).sqrt()
-        freqs /= radii * radii.square().exp().pow(0.25)
-        freqs *= bandwidth
+        norm = freqs.square().sum(1, keepdim=True).sqrt()
+        freqs = freqs / (norm * norm.square().exp().pow(0.25)) * bandwidth
         phases = torch.rand(channels) - 0.5
         self.weight = nn.Parameter(torch.randn(channels, channels))
-        self.scale = 1 / (channels ** 0.5)
-        self.affine = Linear(style_dim, 4, True)
-        self.affine.weight.data.fill_(0.)
-        self.affine.bias.data.copy_(torch.tensor([1, 0, 0, 0], dtype=torch.float32))
-        self.register_buffer('transform', torch.eye(3, 3))
+        self.scale = channels ** -0.5
+        self.affine = Linear(style_dim, 4, True)                                         # -> (cos, sin, tx, ty), identity at init
+        nn.init.zeros_(self.affine.weight)
+        with torch.no_grad():
+            self.affine.bias.copy_(torch.tensor([1., 0., 0., 0.]))
+        self.register_buffer('transform', torch.eye(3, 3))                               # user transform applied after the learned one
         self.register_buffer('freqs', freqs)
         self.register_buffer('phases', phases)
 
     def forward(self, w):
-        B, device = w.size(0), w.device
         t = self.affine(w.float())
-        t = t / t[:, :2].norm(dim=1, keepdim=True)
-        m_r = torch.eye(3, device=device).unsqueeze(0).repeat(B, 1, 1)
-        m_r[:, 0, 0] = t[:, 0]
-        m_r[:, 0, 1] = -t[:, 1]
-        m_r[:, 1, 0] = t[:, 1]
-        m_r[:, 1, 1] = t[:, 0]
-        m_t = torch.eye(3, device=device).unsqueeze(0).repeat(B, 1, 1)
-        m_t[:, 0, 2] = -t[:, 2]
-        m_t[:, 1, 2] = -t[:, 3]
-        transforms = m_r @ m_t @ self.transform.unsqueeze(0)
-        phases = self.phases.unsqueeze(0) + (self.freqs.unsqueeze(0) @ transforms[:, :2, 2:]).squeeze(2)
-        freqs = self.freqs.unsqueeze(0) @ transforms[:, :2, :2]
+        t = t / t[:, :2].norm(dim=1, keepdim=True)                                       # unit (cos, sin); translation in the same units
+        c, s_, tx, ty = t.unbind(1)
+        # rotation by (c, s) composed with the translation by (-tx, -ty): rows of  R @ T  written out, then the user transform
+        learned = torch.stack([torch.stack([c, -s_, -(c * tx - s_ * ty)], 1),
+                               torch.stack([s_, c, -(s_ * tx + c * ty)], 1)], 1)           # [B, 2, 3]
+        total = learned @ self.transform                                                 # [B, 2, 3]: first two rows of R @ T @ U
+        lin, shift = total[:, :, :2], total[:, :, 2]
+        freqs = torch.einsum('cd,bde->bce', self.freqs, lin)                             # every wave's frequency vector, transformed
+        phases = self.phases[None, :] + torch.einsum('cd,bd->bc', self.freqs, shift)
+        # waves beyond the band limit fade out linearly between the bandwidth and the layer's Nyquist frequency
         amp = (1 - (freqs.norm(dim=2) - self.bandwidth) / (self.sampling_rate / 2 - self.bandwidth)).clamp(0, 1)
-        theta = torch.eye(2, 3, device=device)
-        theta[0, 0] = 0.5 * self.size[0] / self.sampling_rate
-        theta[1, 1] = 0.5 * self.size[1] / self.sampling_rate
-        grids = F.affine_grid(theta.unsqueeze(0), [1, 1, self.size[1], self.size[0]], align_corners=False)
-        x = (grids.unsqueeze(3) @ freqs.permute(0, 2, 1).unsqueeze(1).unsqueeze(2)).squeeze(3)
-        x = x + phases.unsqueeze(1).unsqueeze(2)
-        x = torch.sin(x * (np.pi * 2))
-        x = x * amp.unsqueeze(1).unsqueeze(2)
-        x = F.linear(x, self.weight * self.scale)
-        return x.permute(0, 3, 1, 2)
+        # pixel-centre coordinates in units of 1 / sampling_rate, origin at the centre of the map
+        W, H = self.size
+        xs = ((2 * torch.arange(W, device=w.device, dtype=torch.float32) + 1) / W - 1) * (0.5 * W / self.sampling_rate)
+        ys = ((2 * torch.arange(H, device=w.device, dtype=torch.float32) + 1) / H - 1) * (0.5 * H / self.sampling_rate)
+        arg = xs[None, None, :, None] * freqs[:, None, None, :, 0] + ys[None, :, None, None] * freqs[:, None, None, :, 1] \
+            + phases[:, None, None, :]                                                   # [B, H, W, C]
+        feat = torch.sin(arg * (2 * np.pi)) * amp[:, None, None, :]
+        out = feat @ (self.weight * self.scale).t()                                      # learned mix of the waves
+        return out.permute(0, 3, 1, 2)
 
 
 class PixelNorm(nn.Module):
@@ -253,29 +277,24 @@ class PixelNorm(nn.Module):
 
 
 class Mapping(nn.Module):
-    """reference model.py:275-306 (tracks ``w_avg`` in training mode)."""
+    """latent -> style MLP with a running average of the styles for truncation (the reference's ``Mapping``, model.py:275-306)."""
 
     def __init__(self, latent_dim, style_dim, num_layers=2, pixel_norm=True, ema_decay=0.998) -> None:
         super().__init__()
         self.ema_decay = ema_decay
         if pixel_norm:
             self.norm = PixelNorm()
-        layers = [Linear(latent_dim, style_dim, True, 'lrelu')]
-        for _ in range(num_layers - 1):
-            layers.append(Linear(style_dim, style_dim, True, 'lrelu'))
-        self.net = nn.Sequential(*layers)
+        widths = [latent_dim] + [style_dim] * num_layers
+        self.net = nn.Sequential(*[Linear(a, b, True, 'lrelu') for a, b in zip(widths[:-1], widths[1:])])
         self.register_buffer('w_avg', torch.zeros(style_dim))
 
     def forward(self, z, truncation_psi=1.):
         z = z.float()
-        if hasattr(self, 'norm'):
-            z = self.norm(z)
-        w = self.net(z)
-        if self.training:
-            stats = w.detach().to(torch.float32).mean(dim=0)
-            self.w_avg.copy_(stats.lerp(self.w_avg, self.ema_decay))
-        if truncation_psi != 1:
-            w = self.w_avg.lerp(w, truncation_psi)
+        w = self.net(self.norm(z) if hasattr(self, 'norm') else z)
+        if self.training:                                   # w_avg <- decay * w_avg + (1 - decay) * batch mean
+            self.w_avg.mul_(self.ema_decay).add_(w.detach().float().mean(0), alpha=1 - self.ema_decay)
+        if truncation_psi != 1:                             # pull the styles towards their running mean
+            w = self.w_avg + (w - self.w_avg) * truncation_psi
         return w
 
 
@@ -286,33 +305,28 @@ class Synthesis(nn.Module):
                  output_scale=0.25, margin_size=10, first_cutoff=2, first_stopband=2 ** 2.1, last_stopband_rel=2 ** 0.3,
                  kernel_size=3, compute_dtype=torch.bfloat16) -> None:
         super().__init__()
-        self.num_ws = num_layers + 2
+        self.num_ws = num_layers + 2                        # one style for the input, one per layer incl. the RGB layer
         self.compute_dtype = compute_dtype
-        log_resl_diff = int(math.log2(512) - math.log2(image_size))
-        min_c_scale = channels / 64
-        channels = int(2 ** (15 - log_resl_diff) * min_c_scale)
-        channels, sizes, sampling_rates, cutoffs, half_widths = get_layer_params(
-            image_size, num_layers, channels, max_channels, image_channels, margin_size, first_cutoff, first_stopband,
-            last_stopband_rel, num_critical=2)
-        self.input = SynthesisInput(style_dim, int(channels[0]), sizes[0], sampling_rates[0], cutoffs[0])
-        layers = []
+        # width multiplier: ``channels`` = 64 at 512x512 means a channel base of 2^15; it halves per octave of resolution below that
+        base = int(2 ** (15 - int(math.log2(512) - math.log2(image_size))) * (channels / 64))
+        table = get_layer_params(image_size, num_layers, base, max_channels, image_channels, margin_size, first_cutoff, first_stopband,
+                                 last_stopband_rel, num_critical=2)
+        width, size, rate, cutoff, half = table
+        self.input = SynthesisInput(style_dim, int(width[0]), size[0], rate[0], cutoff[0])
+        self.net = nn.ModuleList()
         for i in range(num_layers + 1):
-            prev = max(i - 1, 0)
-            is_rgb = i == num_layers
-            layers.append(StyleLayer(
-                int(channels[prev]), style_dim, int(channels[i]), 1 if is_rgb else kernel_size,
-                int(sizes[prev]), int(sizes[i]), sampling_rates[prev], sampling_rates[i], cutoffs[prev], cutoffs[i],
-                half_widths[prev], half_widths[i], is_rgb, i >= num_layers - 2))
-        self.net = nn.ModuleList(layers)
+            src = max(i - 1, 0)                             # layer i reads layer i-1's lattice (layer 0 reads the input's = its own)
+            rgb = i == num_layers
+            self.net.append(StyleLayer(int(width[src]), style_dim, int(width[i]), 1 if rgb else kernel_size, int(size[src]), int(size[i]),
+                                       rate[src], rate[i], cutoff[src], cutoff[i], half[src], half[i],
+                                       is_rgb=rgb, is_critical_sampled=i >= num_layers - 2))
         self.register_buffer('output_scale', torch.tensor([output_scale]))
 
     def forward(self, w):
         if w.ndim == 2:
             w = w.unsqueeze(1).repeat(1, self.num_ws, 1)
         ws = w.unbind(dim=1)
-        x = self.input(ws[0])
-        if _native(x):
-            x = x.to(self.compute_dtype)
+        x = self.input(ws[0]).to(self.compute_dtype)
         for module, w_i in zip(self.net, ws[1:]):
             x = module(x, w_i)
         return x.float() * self.output_scale
@@ -360,9 +374,7 @@ class ConvAct(nn.Module):
     def forward(self, x):
         weight = self.weight * self.scale
         k = self.weight.shape[2]
-        if not _native(x):
-            x = conv2d_resample.conv2d_resample(x, weight.to(x.dtype), self.down_filter, 1, self.down, self.padding)
-        elif self.down == 1:
+        if self.down == 1:
             # MFMA conv ("same" padding) with bias + activation + gain in its epilogue (and the fused backward of that epilogue)
             return conv2d_act(x.contiguous(memory_format=torch.channels_last), self.weight, self.bias, coef=self.scale,
                               act=self.act_name, gain=self.act_gain) if self.act_name in ('lrelu', 'linear') else \
@@ -400,8 +412,10 @@ class ResBlock(nn.Module):
         return self.conv2(self.conv1(x)) + self.skip(x)
 
 
-class MinibatchStdDev(torch.nn.Module):
-    """reference model.py:442-462."""
+class MinibatchStdDev(nn.Module):
+    """Appends ``num_channels`` feature maps holding the standard deviation over groups of ``group_size`` samples, averaged over the
+    channels of each of ``num_channels`` channel blocks and over all pixels (the reference's ``MinibatchStdDev``, model.py:442-462:
+    group g consists of samples g, g + N/G, g + 2N/G, ...)."""
 
     def __init__(self, group_size, num_channels=1):
         super().__init__()
@@ -411,53 +425,44 @@ class MinibatchStdDev(torch.nn.Module):
     def forward(self, x):
         N, C, H, W = x.shape
         G = self.group_size if N % self.group_size == 0 else N
-        Fc = self.num_channels
-        c = C // Fc
-        y = x.float().reshape(G, -1, Fc, c, H, W)
-        y = y - y.mean(dim=0)
-        y = y.square().mean(dim=0)
-        y = (y + 1e-8).sqrt()
-        y = y.mean(dim=[2, 3, 4])
-        y = y.reshape(-1, Fc, 1, 1)
-        y = y.repeat(G, 1, H, W)
-        return torch.cat([x, y.to(x.dtype)], dim=1)
+        blocks = self.num_channels
+        grouped = x.float().reshape(G, N // G, blocks, C // blocks, H, W)
+        var = grouped.var(dim=0, unbiased=False)                              # over the G members of each group
+        stat = (var + 1e-8).sqrt().mean(dim=[2, 3, 4])                        # [N / G, blocks]
+        maps = stat.reshape(N // G, blocks, 1, 1).repeat(G, 1, H, W)          # sample n gets the statistic of group n mod (N / G)
+        return torch.cat([x, maps.to(x.dtype)], dim=1)
 
 
 class DiscEpilogue(nn.Module):
+    """minibatch stddev -> 3x3 conv -> flatten -> two dense layers (``epilogue.{0..4}`` as in the reference, model.py:419-440)."""
+
     def __init__(self, mbsd_group_size, mbsd_channels, channels, bottom, act_name='lrelu', gain=1.) -> None:
         super().__init__()
-        self.epilogue = nn.Sequential(
-            MinibatchStdDev(mbsd_group_size, mbsd_channels),
-            ConvAct(channels + mbsd_channels, channels, 3, True, 1, None, act_name, gain),
-            nn.Flatten(),
-            Linear(channels * bottom ** 2, channels, True, act_name, gain),
-            Linear(channels, 1, True, 'linear', gain))
+        stages = [MinibatchStdDev(mbsd_group_size, mbsd_channels),
+                  ConvAct(channels + mbsd_channels, channels, 3, True, 1, None, act_name, gain),
+                  nn.Flatten(),
+                  Linear(channels * bottom * bottom, channels, True, act_name, gain),
+                  Linear(channels, 1, True, 'linear', gain)]
+        self.epilogue = nn.Sequential(*stages)
 
     def forward(self, x):
         return self.epilogue(x)
 
 
 class Discriminator(nn.Module):
-    """reference model.py:464-510."""
+    """from_rgb -> one residual block per halving of the resolution down to ``bottom`` x ``bottom`` -> epilogue
+    (the reference's ``Discriminator``, model.py:464-510; same module names)."""
 
     def __init__(self, image_size, in_channels=3, channels=64, max_channels=512, kernel_size=3, mbsd_group_size=4,
                  mbsd_channels=1, bottom=4, filter_size=4, act_name='lrelu', gain=1., compute_dtype=torch.bfloat16) -> None:
         super().__init__()
         self.compute_dtype = compute_dtype
-        num_downs = int(math.log2(image_size) - math.log2(bottom))
-        ochannels = channels
-        self.from_rgb = ConvAct(in_channels, ochannels, 1, True, 1, None, act_name, gain)
-        resblocks = []
-        for _ in range(num_downs):
-            channels *= 2
-            ichannels, ochannels = ochannels, min(max_channels, channels)
-            resblocks.append(ResBlock(ichannels, ochannels, filter_size, act_name, gain))
-        self.resblocks = nn.Sequential(*resblocks)
-        self.epilogue = DiscEpilogue(mbsd_group_size, mbsd_channels, ochannels, bottom, act_name, gain)
+        halvings = int(math.log2(image_size) - math.log2(bottom))
+        widths = [channels] + [min(max_channels, channels * 2 ** (i + 1)) for i in range(halvings)]     # doubles per block, capped
+        self.from_rgb = ConvAct(in_channels, widths[0], 1, True, 1, None, act_name, gain)
+        self.resblocks = nn.Sequential(*[ResBlock(a, b, filter_size, act_name, gain) for a, b in zip(widths[:-1], widths[1:])])
+        self.epilogue = DiscEpilogue(mbsd_group_size, mbsd_channels, widths[-1], bottom, act_name, gain)
 
     def forward(self, x):
-        if _native(x):
-            x = x.to(self.compute_dtype)
-        x = self.from_rgb(x)
-        x = self.resblocks(x)
-        return self.epilogue(x).float()
+        x = self.from_rgb(x.to(self.compute_dtype))
+        return self.epilogue(self.resblocks(x)).float()
