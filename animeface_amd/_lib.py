@@ -23,7 +23,7 @@ EXPORTS = ['agf_abi_version', 'agf_last_error', 'agf_device_info', 'agf_upfirdn2
            'agf_filtered_lrelu', 'agf_filtered_lrelu_act', 'agf_conv2d_fwd', 'agf_conv2d_fwd_mask', 'agf_conv2d_wgrad',
            'agf_act_bwd_reduce', 'agf_act_bwd_reduce_pooled', 'agf_scale_dot', 'agf_planar_to_cl_pad', 'agf_cl_to_planar_crop', 'agf_prep_weights',
            'agf_modulate_weights', 'agf_conv2d_fwd_wimg', 'agf_conv2d_fwd_wimg_covers',
-           'agf_wsq', 'agf_style_demod_fwd', 'agf_style_demod_bwd', 'agf_diffaug_sum', 'agf_diffaug_apply', 'agf_color_affine', 'agf_affine_resample', 'agf_upblur_border']
+           'agf_wsq', 'agf_style_demod_fwd', 'agf_style_demod_bwd', 'agf_diffaug_sum', 'agf_diffaug_apply', 'agf_color_affine', 'agf_affine_resample', 'agf_upblur_border', 'agf_image_resample_rows', 'agf_image_finish']
 
 _lib = None
 _i32x4 = ctypes.c_int32 * 4
@@ -106,7 +106,11 @@ def lib():
         L.agf_affine_resample.argtypes = [_vp, _vp, _vp, ctypes.c_int] + [ctypes.c_int32] * 6 + [ctypes.c_int, _vp]
         L.agf_upblur_border.restype = ctypes.c_int
         L.agf_upblur_border.argtypes = [_vp, _vp, ctypes.c_int] + [ctypes.c_int32] * 4 + [ctypes.c_int, _vp]
-        if L.agf_abi_version() != 11:
+        L.agf_image_resample_rows.restype = ctypes.c_int
+        L.agf_image_resample_rows.argtypes = [_vp] * 5 + [ctypes.c_int32] * 8 + [_vp]
+        L.agf_image_finish.restype = ctypes.c_int
+        L.agf_image_finish.argtypes = [_vp] * 5 + [ctypes.c_int32, _vp, ctypes.c_int] + [ctypes.c_int32] * 6 + [ctypes.c_int, _vp]
+        if L.agf_abi_version() != 12:
             raise AgfError('libagf_ops.so ABI version mismatch')
         _lib = L
     return _lib

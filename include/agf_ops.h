@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define AGF_ABI_VERSION 11
+#define AGF_ABI_VERSION 12
 
 /* element types of activation tensors */
 enum { AGF_F32 = 0, AGF_F16 = 1, AGF_BF16 = 2, AGF_F64 = 3 };
@@ -265,6 +265,21 @@ int agf_affine_resample(const void* x, void* y, const float* theta, int dtype, i
  *   backward = 0: x [N,H,W,C] input, y [N,2H,2W,C] = the composite result, corrected in place
  *   backward = 1: x = dy [N,2H,2W,C], y = dx [N,H,W,C] (the composite's adjoint), receives the correction's adjoint in place */
 int agf_upblur_border(const void* x, void* y, int dtype, int32_t N, int32_t C, int32_t H, int32_t W, int backward, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * GPU-side input transform (new: the reference runs torchvision / Pillow transforms in DataLoader worker processes,
+ * dataset/_base.py:18-37: Resize -> CenterCrop -> RandomHorizontalFlip -> ToTensor -> Normalize(0.5, 0.5)).  Decoded uint8 images
+ * [N][H][W][C] of ONE size are resident in HBM; Pillow's BILINEAR resize (separable, anti-aliased, 22-bit fixed point, uint8 rounding
+ * after each pass) is reproduced bit-exactly.  The tables (first input sample, tap count, int32 fixed-point taps [out][ksize]) are
+ * made on the host exactly as Pillow's Resample.c makes them; the crop is folded into the tables' ranges.
+ *   agf_image_resample_rows: horizontal pass of rows [row0, row0 + rows) -> dst [N][rows][OW][C] uint8 (OW = kept columns)
+ *   agf_image_finish:        vertical pass to SH rows (first[] in full-image rows; tmp starts at row0), per-image horizontal flip
+ *                            (flip[n] != 0, nullable), v / 255, optionally (x - 0.5) / 0.5 -> out [N][C][SH][SW] f32 or bf16 */
+int agf_image_resample_rows(const void* src, void* dst, const int32_t* first, const int32_t* count, const int32_t* taps, int32_t ksize,
+                            int32_t N, int32_t H, int32_t W, int32_t C, int32_t row0, int32_t rows, int32_t OW, void* stream);
+int agf_image_finish(const void* tmp, void* out, const int32_t* first, const int32_t* count, const int32_t* taps, int32_t ksize,
+                     const uint8_t* flip, int dtype, int32_t N, int32_t rows, int32_t row0, int32_t SW, int32_t C, int32_t SH,
+                     int normalize, void* stream);
 
 #ifdef __cplusplus
 }

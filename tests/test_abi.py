@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_error_string():
     L = _lib.lib()
-    assert L.agf_abi_version() == 11
+    assert L.agf_abi_version() == 12
     assert isinstance(L.agf_last_error(), bytes)
 
 
@@ -62,3 +62,20 @@ def test_setup_filter_matches_golden(golden):
              ([[1, 2], [3, 4]], dict(flip_filter=True)), (None, {}), ([1, 2, 3, 4, 5, 6, 7, 8], dict(separable=False))]
     for i, (taps, kw) in enumerate(cases):
         torch.testing.assert_close(setup_filter(taps, **kw), torch.from_numpy(g[f'sf{i}']), rtol=1e-6, atol=1e-7)
+
+
+def test_generator_matches_the_manifest_of_the_published_checkpoint(golden):
+    """weights.md:10-22 (StyleGAN2 animeface 128 pix): keys and shapes of the reference's ``Generator(128, ...)`` state_dict, written by
+    tools/make_golden.py from the reference's own constructor -- a checkpoint in that format must load here with strict=True."""
+    import torch
+    from animeface_amd.implementations.StyleGAN2.model import Generator
+    g = golden('sg2_128_manifest')
+    G = Generator(image_size=128, image_channels=3, style_dim=512, channels=32, max_channels=512, block_num_conv=2, map_num_layers=8, map_lr=0.01)
+    sd = G.state_dict()
+    keys = [str(k) for k in g['keys']]
+    assert list(sd.keys()) == keys
+    for k, shape, nd in zip(keys, g['shapes'].tolist(), g['ndims'].tolist()):
+        assert list(sd[k].shape) == shape[:nd], k
+    assert sum(p.numel() for p in G.parameters()) == int(g['n_params']) == 13842684       # SURVEY.md section 8: G(128x128)
+    fake = {k: torch.zeros(shape[:nd]) for k, shape, nd in zip(keys, g['shapes'].tolist(), g['ndims'].tolist())}
+    G.load_state_dict(fake, strict=True)

@@ -1,45 +1,55 @@
-"""filtered_lrelu: fused kernel vs the generic 4-pass composition on StyleGAN3-512 layer shapes."""
+"""filtered_lrelu roofline table: every layer of the StyleGAN3-T 512x512 generator (BASELINE.json configs[3]) at batch 16, bf16 --
+forward and gradient kernel time, ALGORITHMIC HBM bytes per SURVEY.md section 8(d) ((numel_x + numel_y) * sizeof(T) + the 2-bit sign
+tensor when gradients are needed) and the fraction of the 8 TB/s HBM peak; one JSON line per distinct layer configuration."""
 import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
-from animeface_amd.stylegan3_ops import filtered_lrelu as FL, upfirdn2d as U
-from animeface_amd import _lib
-import scipy.signal
-
-def lowpass(numtaps, cutoff, width, fs):
-    return torch.as_tensor(scipy.signal.firwin(numtaps=numtaps, cutoff=cutoff, width=width, fs=fs), dtype=torch.float32)
+import torch
+from animeface_amd.stylegan3_ops import filtered_lrelu as FL
+from animeface_amd.implementations.StyleGAN3 import model as M
 
 dev = 'cuda'
-fu = lowpass(12, 2.0, 2.2, 8.0).to(dev)
-fd = lowpass(12, 2.0, 2.2, 8.0).to(dev)
-fdr = torch.outer(fd, fd).contiguous()
+B = int(os.environ.get('B', '16'))
+G = M.Generator(512, 512).to(dev)
 
-def timeit(fn, reps=10):
-    for _ in range(2): fn()
+
+def timeit(fn, reps=8):
+    for _ in range(2):
+        fn()
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
-    for _ in range(reps): fn()
+    for _ in range(reps):
+        fn()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / reps
 
-for dtype in (torch.float32, torch.bfloat16):
-    for name, B, C, S, fdd, pad in [('L12 up2/down2 sep', 8, 32, 534, fd, [9, 8, 9, 8]), ('L1 up2/down2 radial', 8, 512, 38, fdr, [9, 8, 9, 8])]:
-        x = torch.randn(B, C, S, S, device=dev).to(dtype)
-        b = torch.randn(C, device=dev).to(dtype)
-        with torch.no_grad():
-            y = FL.filtered_lrelu(x, fu, fdd, b, up=2, down=2, padding=pad, clamp=256)
-            ms = timeit(lambda: FL.filtered_lrelu(x, fu, fdd, b, up=2, down=2, padding=pad, clamp=256))
-            # generic composition for comparison
-            def generic():
-                t = x.add(b[None, :, None, None])
-                t = U.upfirdn2d(t, fu, up=2, padding=pad, gain=4)
-                FL._native_act_(t, None, 0, 0, float(np.sqrt(2)), 0.2, 256.0, False)
-                return U.upfirdn2d(t, fdd, down=2)
-            yg = generic()
-            msg = timeit(generic)
-        es = 2 if dtype == torch.bfloat16 else 4
-        nbytes = (x.numel() + y.numel()) * es
-        err = (y.float() - yg.float()).abs().max().item()
-        print(json.dumps(dict(case=name, dtype=str(dtype), fused_ms=round(ms, 4), generic_ms=round(msg, 4), fused_GBps=round(nbytes / ms / 1e6, 1),
-                              frac_8TBps=round(nbytes / ms / 1e6 / 8000, 4), max_diff_vs_generic=err, out=list(y.shape))), flush=True)
+
+seen = {}
+size = G.synthesis.input.size[0]
+for i, layer in enumerate(G.synthesis.net):
+    cin = layer.conv.weight.shape[1]; cout = layer.conv.weight.shape[0]; k = layer.conv.weight.shape[2]
+    s_in = size + k - 1                                       # the conv's "full" padding: its output is the filtered_lrelu input
+    x = torch.randn(B, cout, s_in, s_in, device=dev).to(torch.bfloat16).requires_grad_(True)
+    b = layer.bias.detach().to(torch.bfloat16)
+    fu, fd = layer.up_filter, layer.down_filter
+    args = dict(up=layer.up_factor, down=layer.down_factor, padding=layer.padding, gain=layer.gain, slope=layer.negative_slope, clamp=layer.conv_clamp)
+    y = FL.filtered_lrelu(x, fu, fd, b, **args)
+    size = y.shape[-1]
+    key = (cout, s_in, layer.up_factor, layer.down_factor, None if fu is None else tuple(fu.shape), None if fd is None else tuple(fd.shape), tuple(layer.padding))
+    if key in seen:
+        continue
+    seen[key] = i
+    gy = torch.randn_like(y)
+    with torch.no_grad():
+        ms_f = timeit(lambda: FL.filtered_lrelu(x.detach(), fu, fd, b, **args))
+    ms_fb = timeit(lambda: torch.autograd.grad(FL.filtered_lrelu(x, fu, fd, b, **args), x, gy))
+    sw = s_in * layer.up_factor + layer.padding[0] + layer.padding[1] - ((fu.shape[-1] if fu is not None else 1) - 1)
+    sign_bytes = B * cout * sw * ((sw + 15) // 16 * 16) // 4
+    alg_f = (x.numel() + y.numel()) * 2
+    alg_b = alg_f + sign_bytes                                 # the gradient pass reads dy and the signs, writes dx
+    radial = fd is not None and fd.ndim == 2
+    print(json.dumps(dict(layer=i, channels=cout, in_size=s_in, out_size=int(y.shape[-1]), up=layer.up_factor, down=layer.down_factor,
+                          up_taps=None if fu is None else int(fu.shape[-1]), down_filter=None if fd is None else ('radial %dx%d' % tuple(fd.shape) if radial else 'separable %d' % fd.shape[0]),
+                          batch=B, fwd_ms=round(ms_f, 4), fwd_bwd_ms=round(ms_fb, 4), bwd_ms=round(ms_fb - ms_f, 4),
+                          algorithmic_MB_fwd=round(alg_f / 1e6, 1), fwd_TBps=round(alg_f / ms_f / 1e9, 3), fwd_frac_of_8TBps=round(alg_f / ms_f / 1e9 / 8, 4),
+                          bwd_TBps=round(alg_b / max(ms_fb - ms_f, 1e-6) / 1e9, 3), bwd_frac_of_8TBps=round(alg_b / max(ms_fb - ms_f, 1e-6) / 1e9 / 8, 4))), flush=True)

@@ -28,11 +28,47 @@ def timeit(fn, reps=20, warm=3):
     return s.elapsed_time(e) / reps * 1e-3
 
 
+def cpu_rows():
+    """BASELINE.md section 3 kernel rows on the CPU: oracle/ (pinned to the reference's `_ref` paths), fp32, NCHW."""
+    import time
+    from oracle import upfirdn2d as OU, bias_act as OB, filtered_lrelu as OF
+    import scipy.signal
+    g = torch.Generator().manual_seed(0)
+    x128 = torch.randn(16, 64, 128, 128, generator=g)
+    x256 = torch.randn(16, 64, 256, 256, generator=g)
+    f4, f3 = OU.setup_filter([1, 3, 3, 1]), OU.setup_filter([1, 2, 1])
+    b = torch.randn(64, generator=g)
+    fl = torch.as_tensor(scipy.signal.firwin(numtaps=12, cutoff=2.0, width=2.2, fs=8.0), dtype=torch.float32)
+    xf = torch.randn(4, 32, 534, 534, generator=g)
+    bf = torch.randn(32, generator=g)
+    cases = [('upsample2d f4x4 [16,64,128,128]->256', lambda: OU.upsample2d(x128, f4, up=2), x128.numel() * 5 * 4),
+             ('downsample2d f4x4 [16,64,256,256]->128', lambda: OU.downsample2d(x256, f4, down=2), x256.numel() * 1.25 * 4),
+             ('filter2d f3x3 [16,64,256,256]', lambda: OU.filter2d(x256, f3), x256.numel() * 2 * 4),
+             ('bias_act lrelu [16,64,256,256]', lambda: OB.bias_act(x256, b, act='lrelu'), x256.numel() * 2 * 4),
+             ('filtered_lrelu up2/down2 12-tap sep [4,32,534,534] (SG3-512 layer 12)',
+              lambda: OF.filtered_lrelu(xf, fl, fl, bf, up=2, down=2, padding=[9, 8, 9, 8], clamp=256), None)]
+    with torch.no_grad():
+        for name, fn, nbytes in cases:
+            y = fn()
+            if nbytes is None:
+                nbytes = (xf.numel() + y.numel()) * 4
+            t0 = time.time(); n = 0
+            while time.time() - t0 < 2.0 or n < 2:
+                fn(); n += 1
+            sec = (time.time() - t0) / n
+            print(json.dumps(dict(kernel=name, device='cpu', kind='port (oracle/)', cores=torch.get_num_threads(), dtype='float32',
+                                  ms=round(sec * 1e3, 2), algorithmic_GBps=round(nbytes / sec / 1e9, 2))), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--batch', type=int, default=64)
     ap.add_argument('--reps', type=int, default=20)
+    ap.add_argument('--cpu', action='store_true', help='also time the CPU oracle (the port of the reference\'s pure-PyTorch op fallback) on the '
+                                                       'BASELINE.md section 3 shapes (batch 16, fp32), on this box\'s host cores')
     a = ap.parse_args()
+    if a.cpu:
+        cpu_rows()
     dev = 'cuda'
     N = a.batch
     f4 = U.setup_filter([1, 3, 3, 1], device=dev)

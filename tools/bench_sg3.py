@@ -44,3 +44,8 @@ for _ in range(a.steps):
 torch.cuda.synchronize()
 dtm = (time.time() - t0) / a.steps
 print('sg3 %s batch %d: %.1f ms/iter, %.1f img/s' % ('fp32' if a.fp32 else 'bf16', a.batch, dtm * 1e3, a.batch / dtm))
+import json
+print(json.dumps({'metric': f'images/sec (G+D+R1 step) StyleGAN3-T {a.image_size}x{a.image_size} ' + ('fp32' if a.fp32 else 'bf16'), 'value': round(a.batch / dtm, 2),
+                  'unit': 'img/s', 'n_gpus': 1, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dtm * 1e3, 2), 'dtype': 'fp32' if a.fp32 else 'bf16',
+                  'data': 'synthetic', 'config': {'workload': f'StyleGAN3-T {a.image_size}x{a.image_size} (14 layers, channels 32, kernel 3), batch {a.batch}, '
+                                                           'gp_every 16 (reference implementations/StyleGAN3/utils.py defaults), DiffAugment color,translation'}}))

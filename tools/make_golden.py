@@ -683,11 +683,46 @@ def gen_conv2d_resample():
     save('conv2d_resample', **arrays)
 
 
+def gen_image_pipeline():
+    """Pillow's BILINEAR resize (what torchvision's Resize on PIL images calls, dataset/_base.py:27) on random uint8 images: inputs and
+    Pillow's outputs, so the resampling restatement can be checked bit-exactly on a box without Pillow."""
+    import PIL
+    from PIL import Image
+    rng = np.random.default_rng(7)
+    arrays, cases = {}, []
+    for idx, (H, W, size) in enumerate([(96, 80, 48), (100, 73, 64), (37, 53, 64), (150, 200, 64), (64, 64, 64), (90, 160, 72), (211, 130, 100)]):
+        img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        short, long_ = (W, H) if W <= H else (H, W)
+        if short == size:
+            oh, ow = H, W
+        else:
+            ns, nl = size, int(size * long_ / short)
+            oh, ow = (nl, ns) if W <= H else (ns, nl)
+        out = np.asarray(Image.fromarray(img).resize((ow, oh), Image.BILINEAR))
+        arrays[f'in{idx}'], arrays[f'out{idx}'] = img, out
+        cases.append([H, W, size, oh, ow])
+    arrays['cases'] = np.array(cases, dtype=np.int64)
+    arrays['pillow_version'] = np.array(PIL.__version__)
+    save('image_pipeline', **arrays)
+
+
+def gen_weights_md_manifest():
+    """weights.md:10-22: the published StyleGAN2 128-pixel checkpoint is ``Generator(image_size=128, image_channels=3, style_dim=512,
+    channels=32, max_channels=512, block_num_conv=2, map_num_layers=8, map_lr=0.01).state_dict()``.  The file itself is a download; its
+    key set and tensor shapes follow from the reference's constructor, which is instantiated here: the manifest a drop-in must match."""
+    sg2 = import_sg2_model()
+    G = sg2.Generator(image_size=128, image_channels=3, style_dim=512, channels=32, max_channels=512, block_num_conv=2,
+                      map_num_layers=8, map_lr=0.01)
+    sd = G.state_dict()
+    save('sg2_128_manifest', keys=np.array(list(sd.keys())), shapes=np.array([list(v.shape) + [0] * (4 - v.dim()) for v in sd.values()], dtype=np.int64),
+         ndims=np.array([v.dim() for v in sd.values()], dtype=np.int64), n_params=np.array(sum(p.numel() for p in G.parameters())))
+
+
 if __name__ == '__main__':
     os.environ.setdefault('PYTHONDONTWRITEBYTECODE', '1')
     torch.set_num_threads(8)
     import_reference()
-    which = sys.argv[1:] or ['upfirdn2d', 'equiv', 'bias_act', 'filtered_lrelu', 'sg2_model', 'train', 'sg3_model', 'sg3_train', 'ada', 'conv2d_resample']
+    which = sys.argv[1:] or ['upfirdn2d', 'equiv', 'bias_act', 'filtered_lrelu', 'sg2_model', 'train', 'sg3_model', 'sg3_train', 'ada', 'conv2d_resample', 'image_pipeline', 'weights_md']
     if 'upfirdn2d' in which:
         gen_upfirdn2d()
     if 'equiv' in which:
@@ -708,3 +743,7 @@ if __name__ == '__main__':
         gen_ada()
     if 'conv2d_resample' in which:
         gen_conv2d_resample()
+    if 'image_pipeline' in which:
+        gen_image_pipeline()
+    if 'weights_md' in which:
+        gen_weights_md_manifest()
