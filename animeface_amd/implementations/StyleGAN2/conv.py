@@ -59,14 +59,19 @@ class ZeroArena:
     grow the buffer at the next reset."""
 
     def __init__(self):
-        self.buf, self.off, self.want = None, 0, 0
+        self.buf, self.off, self.want, self.high = None, 0, 0, 0
 
     def reset(self, device):
         if self.buf is None or self.want > self.buf.numel() or self.buf.device != device:
             n = max(int(self.want * 1.1) + 4096, 1 << 20)
             self.buf = torch.zeros(n, dtype=torch.float32, device=device)
-        elif self.off:
-            self.buf[:self.off].zero_()
+            self.high = 0
+        else:
+            # everything ever handed out from this buffer, not only the previous pass's share: the passes that alternate on one arena
+            # (GAN-loss and lazy-R1 iterations) use different amounts, and a captured graph replays the extent it was recorded with
+            self.high = max(self.high, self.off)
+            if self.high:
+                self.buf[:self.high].zero_()
         self.off, self.want = 0, 0
 
     def take(self, shape, device):

@@ -189,20 +189,72 @@ class TrainStep:
         return G_loss, fake
 
 
-def build_optimizers(G, D, lr, betas, r1_lambda, pl_lambda, d_k, g_k):
+class GraphedTrainStep:
+    """The iteration replayed from HIP graphs: the whole body of ``TrainStep.__call__`` -- both half-steps with
+    their backward passes, both fused Adam steps, EMA -- is captured once per iteration kind (GAN-loss iteration, lazy-R1 iteration) with
+    ``torch.cuda.graph`` and replayed with ONE host call per iteration, so the ~1 400 launches of an iteration no longer cost host time
+    (the 128x128 / batch-32 configuration is launch-bound in eager mode).  The kernels, their order and their arithmetic are those of the
+    eager step; random draws come from torch's graph-safe generator state.  Needs: one process (no gradient exchange inside a graph),
+    no path-length penalty (its running mean lives on the host), a DiffAugment policy (the ADA pipe synchronises with the host), capturable
+    optimizers (``build_optimizers(..., capturable=True)``), and input batches of one fixed shape."""
+
+    def __init__(self, step, real, warmup=3):
+        if step.reducer_G is not None or step.reducer_D is not None:
+            raise RuntimeError('graph capture covers the single-process step only')
+        if step.pl_lambda > 0 or step.policy == 'ada':
+            raise RuntimeError('graph capture needs pl_lambda == 0 and a DiffAugment policy')
+        self.step, self.graphs = step, {}
+        self.static_real = real.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                      # eager iterations first: optimizer state, arenas and caches reach their final size
+            for _ in range(warmup):
+                step(self.static_real)
+        torch.cuda.current_stream().wait_stream(side)
+
+    @property
+    def batches_done(self):
+        return self.step.batches_done
+
+    def _kind(self, it):
+        st = self.step
+        return 'r1' if (it % st.d_k == 0 and st.r1_lambda > 0 and it != 0) else 'gan'
+
+    def __call__(self, real):
+        st = self.step
+        it = st.batches_done
+        kind = self._kind(it)
+        self.static_real.copy_(real)
+        if kind not in self.graphs:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):                  # records; the Python body runs once and leaves batches_done advanced
+                out = st(self.static_real)
+            st.batches_done = it
+            self.graphs[kind] = (graph, out)
+        graph, out = self.graphs[kind]
+        graph.replay()
+        st.batches_done = it + 1
+        return out
+
+
+def build_optimizers(G, D, lr, betas, r1_lambda, pl_lambda, d_k, g_k, capturable=False):
     g_lr, g_betas = lazy_adam_hparams(lr, betas, g_k, pl_lambda)
     d_lr, d_betas = lazy_adam_hparams(lr, betas, d_k, r1_lambda)
     fused = all(p.is_cuda for p in G.parameters())
-    optimizer_G = optim.Adam(G.parameters(), lr=g_lr, betas=g_betas, fused=fused)
-    optimizer_D = optim.Adam(D.parameters(), lr=d_lr, betas=d_betas, fused=fused)
+    kw = dict(capturable=True) if capturable else {}
+    optimizer_G = optim.Adam(G.parameters(), lr=g_lr, betas=g_betas, fused=fused, **kw)
+    optimizer_D = optim.Adam(D.parameters(), lr=d_lr, betas=d_betas, fused=fused, **kw)
     return optimizer_G, optimizer_D
 
 
 def train(max_iter, dataset, sampler, const_z, latent_dim,
           G, G_ema, D, optimizer_G, optimizer_D,
           r1_lambda, pl_lambda, d_k, g_k, policy,
-          device, amp, save=1000, log_every=50, on_save=None, reducer_G=None, reducer_D=None, resume=None, checkpoint_path=None):
-    """Same positional signature as the reference's ``train`` (utils.py:35-41)."""
+          device, amp, save=1000, log_every=50, on_save=None, reducer_G=None, reducer_D=None, resume=None, checkpoint_path=None,
+          graphs=False, log=print):
+    """Same positional signature as the reference's ``train`` (utils.py:35-41).  ``graphs``: replay the iteration from HIP graphs
+    (``GraphedTrainStep``; single process, pl_lambda == 0, DiffAugment policy, capturable optimizers).  Every ``log_every`` iterations one
+    line with the losses and the throughput since the previous line goes to ``log`` (the reference's ``Status`` shows losses only)."""
     if G_ema is not None:
         G_ema.eval()
     step = TrainStep(G, G_ema, D, optimizer_G, optimizer_D, r1_lambda, pl_lambda, d_k, g_k, policy,
@@ -211,11 +263,20 @@ def train(max_iter, dataset, sampler, const_z, latent_dim,
         from ... import checkpoint
         checkpoint.load(step, resume, map_location=device)
     history = []
+    import time
+    runner = None
+    t_last, it_last = time.perf_counter(), step.batches_done
+    if log is not None:
+        log(f'training on {torch.cuda.get_device_name(device) if torch.cuda.is_available() else device} | '
+            f'{"bf16" if amp else "fp32"} | {"HIP-graph replay" if graphs else "eager"} | world size {dp.dist.get_world_size() if dp.dist.is_initialized() else 1}')
     while step.batches_done < max_iter:
         for real in dataset:
             real = real.to(device, non_blocking=True)
             it = step.batches_done
-            D_loss, G_loss, fake = step(real)
+            if graphs and runner is None:
+                runner = GraphedTrainStep(step, real)
+                it = step.batches_done
+            D_loss, G_loss, fake = (runner or step)(real)
             if it % save == 0 and checkpoint_path is not None and it > 0:
                 from ... import checkpoint
                 checkpoint.save(step, checkpoint_path)
@@ -224,8 +285,14 @@ def train(max_iter, dataset, sampler, const_z, latent_dim,
                     images, _ = G_ema(const_z)
                 on_save(it, images, G_ema)
             if log_every and it % log_every == 0:
-                d, g = D_loss.item(), G_loss.item()
+                d, g = D_loss.item(), G_loss.item()                 # the one host sync per log interval
                 history.append((it, 0 if d != d else d, 0 if g != g else g))
+                now = time.perf_counter()
+                if log is not None and step.batches_done > it_last:
+                    world = dp.dist.get_world_size() if dp.dist.is_initialized() else 1
+                    rate = (step.batches_done - it_last) * real.size(0) * world / (now - t_last)
+                    log(f'iter {it:7d} | D_loss {d:9.4f} | G_loss {g:9.4f} | {rate:8.1f} img/s')
+                t_last, it_last = now, step.batches_done
             if step.batches_done == max_iter:
                 break
     return history
@@ -262,7 +329,9 @@ SG2_ARGS = dict(
     d_k=[16, 'for lazy regularization. calculate gradient penalty each d_k iters'],
     r1_lambda=[10, 'lambda for r1'],
     pl_lambda=[0., 'lambda for perceptual path length loss'],
-    policy=['color,translation', 'policy for DiffAugment'])
+    policy=['color,translation', 'policy for DiffAugment'],
+    hip_graphs=[False, 'replay the training iteration from HIP graphs (single GPU)'],
+    log_every=[50, 'iterations between log lines (losses, img/s)'])
 
 
 def main(parser, dataset=None):
@@ -280,7 +349,9 @@ def main(parser, dataset=None):
     const_z = sample_nnoise((16, args.style_dim), device=device)
     G, G_ema, D = build_models(args, device, compute_dtype)
     dp.broadcast_module(G), dp.broadcast_module(G_ema), dp.broadcast_module(D)
-    optimizer_G, optimizer_D = build_optimizers(G, D, args.lr, (args.beta1, args.beta2), args.r1_lambda, args.pl_lambda, args.d_k, args.g_k)
+    graphs = bool(args.hip_graphs) and world == 1 and args.pl_lambda == 0 and args.policy != 'ada'
+    optimizer_G, optimizer_D = build_optimizers(G, D, args.lr, (args.beta1, args.beta2), args.r1_lambda, args.pl_lambda, args.d_k, args.g_k,
+                                                capturable=graphs)
     reducer_G = dp.GradReducer(G.parameters(), never_used=dp.never_used_parameters(G)) if world > 1 else None
     reducer_D = dp.GradReducer(D.parameters()) if world > 1 else None
     if dataset is None:
@@ -290,5 +361,5 @@ def main(parser, dataset=None):
     if args.max_iters < 0:
         args.max_iters = len(dataset) * args.default_epochs
     return train(args.max_iters, dataset, sampler, const_z, args.style_dim, G, G_ema, D, optimizer_G, optimizer_D,
-                 args.r1_lambda, args.pl_lambda, args.d_k, args.g_k, args.policy, device, amp, args.save,
-                 reducer_G=reducer_G, reducer_D=reducer_D)
+                 args.r1_lambda, args.pl_lambda, args.d_k, args.g_k, args.policy, device, amp, args.save, log_every=args.log_every,
+                 reducer_G=reducer_G, reducer_D=reducer_D, graphs=graphs, log=print if rank == 0 else None)

@@ -97,13 +97,20 @@ def train(max_iters, dataset, latent_dim, const_input,
           G, G_ema, D, optimizer_G, optimizer_D,
           gp_lambda, gp_every, augment,
           device, amp, save=1000, log_file=None, log_every=50, on_save=None, reducer_G=None, reducer_D=None, resume=None,
-          checkpoint_path=None):
-    """Same positional signature as the reference's ``train`` (utils.py:15-20)."""
+          checkpoint_path=None, log=print):
+    """Same positional signature as the reference's ``train`` (utils.py:15-20).  Every ``log_every`` iterations one line with the losses
+    and the throughput since the previous line goes to ``log``."""
+    import time
+    from ... import distributed as _dp
     step = TrainStep(G, G_ema, D, optimizer_G, optimizer_D, gp_lambda, gp_every, augment, latent_dim, reducer_G, reducer_D)
     if resume is not None:                                  # full resume state (animeface_amd/checkpoint.py), not just G_ema
         from ... import checkpoint
         checkpoint.load(step, resume, map_location=device)
     history = []
+    t_last, it_last = time.perf_counter(), step.batches_done
+    world = _dp.dist.get_world_size() if _dp.dist.is_initialized() else 1
+    if log is not None:
+        log(f'training on {torch.cuda.get_device_name(device) if torch.cuda.is_available() else device} | {"bf16" if amp else "fp32"} | world size {world}')
     while step.batches_done < max_iters:
         for real in dataset:
             real = real.to(device, non_blocking=True)
@@ -116,7 +123,12 @@ def train(max_iters, dataset, latent_dim, const_input,
                 with torch.no_grad():
                     on_save(it, G_ema(const_input), G_ema)
             if log_every and it % log_every == 0:
-                history.append((it, D_loss.item(), G_loss.item()))
+                d, g = D_loss.item(), G_loss.item()
+                history.append((it, d, g))
+                now = time.perf_counter()
+                if log is not None and step.batches_done > it_last:
+                    log(f'iter {it:7d} | D_loss {d:9.4f} | G_loss {g:9.4f} | {(step.batches_done - it_last) * real.size(0) * world / (now - t_last):8.1f} img/s')
+                t_last, it_last = now, step.batches_done
             if step.batches_done == max_iters:
                 break
     return history

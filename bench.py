@@ -76,6 +76,10 @@ def main():
     ap.add_argument('--batch', type=int, default=64, help='per-GPU batch')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timer', action='store_true')
+    ap.add_argument('--eager', action='store_true', help='launch every kernel from the host.  Default on ONE GPU: the iteration is replayed from HIP '
+                                                         'graphs (GraphedTrainStep: same kernels, one host call per iteration); the steps sampled for the '
+                                                         'per-launch roofline timing always run eagerly.  With several GPUs the step is eager (the gradient '
+                                                         'exchange is issued from backward hooks)')
     ap.add_argument('--no-r1-every-step', action='store_true', help='skip the side measurement with the R1 penalty on every iteration')
     ap.add_argument('--augment', default='color,translation', help="DiffAugment policy (the reference's SG2 default) or 'ada'")
     args = ap.parse_args()
@@ -103,7 +107,8 @@ def main():
     G_ema.eval()
     update_ema(G, G_ema, decay=0)
     dp.broadcast_module(G), dp.broadcast_module(G_ema), dp.broadcast_module(D)
-    opt_G, opt_D = U.build_optimizers(G, D, 0.001, (0., 0.99), 10., 0., 16, 8)
+    use_graphs = (not args.eager) and world == 1 and args.augment != 'ada'
+    opt_G, opt_D = U.build_optimizers(G, D, 0.001, (0., 0.99), 10., 0., 16, 8, capturable=use_graphs)
     red_G = dp.GradReducer(G.parameters(), never_used=dp.never_used_parameters(G)) if world > 1 else None
     red_D = dp.GradReducer(D.parameters()) if world > 1 else None
     for red in (red_G, red_D):
@@ -136,6 +141,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    eager_step = step
+    if use_graphs:
+        # capture both iteration kinds before anything is timed (a capture records, it does not execute), then restore the counter
+        step = U.GraphedTrainStep(eager_step, real, warmup=1)
+        for it0 in (1, 16):
+            eager_step.batches_done = it0
+            step(real)
+        eager_step.batches_done = 0
     for _ in range(args.warmup):
         step(real)
     # per-launch HIP events on the MFMA kernels for the roofline numbers: two events around each of ~200 launches per step cost 2.6 %
@@ -151,7 +164,7 @@ def main():
         sample = timer is not None and (i % 4 == 0 or (it % 16 == 0 and it != 0))
         C.KernelTimer.active = timer if sample else None
         sampled_steps += int(sample)
-        step(real)
+        (eager_step if sample else step)(real)
     barrier()
     dt = time.perf_counter() - t0
     C.KernelTimer.active = None
@@ -163,8 +176,10 @@ def main():
 
     # the worst case "G+D+R1 step" literally names: the R1 penalty on EVERY iteration; a few extra steps after the
     # timed window, forced onto the lazy-R1 branch, rank-local timing is enough for this side figure
+    step = eager_step if not use_graphs else step
     r1_ms = None
     if not args.no_r1_every_step:
+        step = eager_step
         saved = step.batches_done
         n_r1 = 4
         step.batches_done = 16
@@ -186,7 +201,7 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'bf16', 'data': 'synthetic',
+            'dtype': 'bf16', 'data': 'synthetic', 'execution': 'hip-graph replay (eager on the event-timed steps)' if use_graphs else 'eager launches',
             'config': {'workload': f'StyleGAN2 {S}x{S} G+D+lazy-R1 training step, batch {args.batch}/GPU '
                                    f'(BASELINE.json configs[2]: channels 32, max 512, style 512, d_k 16, r1_lambda 10, '
                                    + ('ADA pipe (12 augmentations, adaptive p)' if args.augment == 'ada' else f'DiffAugment {args.augment} = the reference SG2 default; --augment ada selects the ADA pipe') + ', Adam, EMA)',

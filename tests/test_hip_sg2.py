@@ -322,3 +322,52 @@ def test_full_size_step_properties():
     assert all(abs(x) < 1e4 for pair in a for x in pair), a
     for (d0, g0), (d1, g1) in zip(a, b):
         assert d0 == pytest.approx(d1, rel=2e-3, abs=1e-5) and g0 == pytest.approx(g1, rel=2e-3, abs=1e-5), (a, b)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['fp32', 'bf16'])
+def test_graph_replayed_step_equals_the_eager_step(dtype):
+    """GraphedTrainStep (the iteration captured into HIP graphs, one per iteration kind) against the eager TrainStep from the same seeds:
+    the captured kernels, their order and torch's graph-safe random offsets are those of the eager run, so losses and weights agree --
+    to fp32 summation noise in fp32 mode; in bf16 the losses agree and the weights are compared statistically (see tests/test_hip_dp.py
+    for why bf16 + Adam cannot be held element-wise)."""
+    import functools
+    from animeface_amd.implementations.StyleGAN2 import utils as U
+    from animeface_amd.nnutils import sample_nnoise, update_ema
+
+    def run(graphed, iters=6):
+        torch.manual_seed(5)
+        M, G, D = build(dtype)
+        _, G_ema, _ = build(dtype)
+        G.init_weight(functools.partial(M.init_weight_N01, lr=0.01), M.init_weight_N01)
+        D.apply(M.init_weight_N01)
+        G_ema.eval()
+        update_ema(G, G_ema, decay=0)
+        oG, oD = U.build_optimizers(G, D, 0.001, (0., 0.99), 10., 0., 2, 8, capturable=True)
+        step = U.TrainStep(G, G_ema, D, oG, oD, 10., 0., 2, 8, 'color,translation', TINY['style_dim'], functools.partial(sample_nnoise, device=DEV))
+        gen = torch.Generator().manual_seed(9)
+        real = (torch.rand(8, 3, 16, 16, generator=gen) * 2 - 1).to(DEV)
+        torch.manual_seed(123)
+        for _ in range(2):                                   # the warm-up GraphedTrainStep runs eagerly, in both arms
+            step(real)
+        runner = U.GraphedTrainStep(step, real, warmup=0) if graphed else step
+        losses = []
+        for _ in range(iters):                               # d_k = 2: GAN-loss and lazy-R1 iterations alternate
+            dl, gl, fake = runner(real)
+            losses.append((float(dl), float(gl)))
+        assert step.batches_done == 2 + iters
+        if graphed:
+            assert set(runner.graphs) == {'gan', 'r1'}
+        return losses, {k: v.detach().clone() for k, v in list(G.state_dict().items()) + [('D.' + k, v) for k, v in D.state_dict().items()]}
+    le, we = run(False)
+    lg, wg = run(True)
+    tol = 1e-4 if dtype == torch.float32 else 2e-2
+    for (d0, g0), (d1, g1) in zip(le, lg):
+        assert d0 == pytest.approx(d1, rel=tol, abs=tol * 1e-1) and g0 == pytest.approx(g1, rel=tol, abs=tol * 1e-1), (le, lg)
+    far = total = 0
+    for k in we:
+        d = (we[k].float() - wg[k].float()).abs()
+        if dtype == torch.float32:
+            assert float(d.max()) < 2e-5, (k, float(d.max()))
+        far += int((d > 1e-4).sum())
+        total += d.numel()
+    assert far <= 0.2 * total, (far, total)
