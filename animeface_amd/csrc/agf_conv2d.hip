@@ -1935,11 +1935,17 @@ static int launch_wgrad(const WgradParams& p, size_t lds, hipStream_t st) {
     return AGF_OK;
 }
 
-extern "C" int agf_conv2d_wgrad(const void* x, const void* dy, float* dw,
-                                const float* in_scale, const float* out_scale,
-                                int dtype, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
-                                float scale, void* stream) {
+static int conv2d_wgrad_impl(const void* x, const void* dy, float* dw,
+                             const float* in_scale, const float* out_scale,
+                             int dtype, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
+                             float scale, void* workspace, int64_t workspace_bytes, void* stream) {
     AGF_CHECK(x && dy && dw, "conv2d_wgrad: null pointer");
+    AGF_CHECK(N >= 1 && H >= 1 && W >= 1 && Cin >= 1 && Cout >= 1, "conv2d_wgrad: empty tensor");
+    AGF_CHECK(ksize == 1 || ksize == 3, "conv2d_wgrad: kernel size must be 1 or 3 (got %d)", ksize);
+    if (workspace_bytes < 0) {                            // overwriting mode (agf_conv2d_wgrad_ws) on a shape that accumulates with atomics
+        hipError_t e = hipMemsetAsync(dw, 0, (size_t)Cout * ksize * ksize * Cin * sizeof(float), (hipStream_t)stream);
+        if (e != hipSuccess) { agf_set_error("conv2d_wgrad: memset failed: %s", hipGetErrorString(e)); return AGF_ELAUNCH; }
+    }
     AGF_CHECK(dtype == AGF_BF16 || dtype == AGF_F32, "conv2d_wgrad: dtype must be bf16 or f32");
     if (dtype == AGF_F32) {
         AGF_CHECK(N >= 1 && H >= 1 && W >= 1 && Cin >= 1 && Cout >= 1, "conv2d_wgrad: empty tensor");
@@ -1957,6 +1963,13 @@ extern "C" int agf_conv2d_wgrad(const void* x, const void* dy, float* dw,
     AGF_CHECK(ksize == 1 || ksize == 3, "conv2d_wgrad: kernel size must be 1 or 3 (got %d)", ksize);
     AGF_CHECK(Cin % 8 == 0 && Cout % 8 == 0, "conv2d_wgrad: Cin and Cout must be multiples of 8 (pad the channel axis)");
     AGF_CHECK(((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0 && ((uintptr_t)dw % 4) == 0, "conv2d_wgrad: misaligned pointer");
+    if (ksize == 3) {
+        const int rc = agf_conv2d_wgrad_ring_launch(x, dy, dw, in_scale, out_scale, N, H, W, Cin, Cout, scale, (float*)workspace, workspace_bytes,
+                                                    (hipStream_t)stream);
+        if (rc == AGF_OK) { AGF_LAUNCH_CHECK(); return AGF_OK; }
+        if (rc != AGF_ENOKERNEL) return rc;
+    }
+
     WgradParams p;
     p.x = (const bf16_t*)x; p.dy = (const bf16_t*)dy; p.dw = dw; p.in_scale = in_scale; p.out_scale = out_scale; p.scale = scale;
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
@@ -2025,4 +2038,27 @@ extern "C" int agf_conv2d_wgrad(const void* x, const void* dy, float* dw,
     if (rc != AGF_OK) return rc;
     AGF_LAUNCH_CHECK();
     return AGF_OK;
+}
+
+extern "C" int agf_conv2d_wgrad(const void* x, const void* dy, float* dw,
+                                const float* in_scale, const float* out_scale,
+                                int dtype, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
+                                float scale, void* stream) {
+    return conv2d_wgrad_impl(x, dy, dw, in_scale, out_scale, dtype, N, H, W, Cin, Cout, ksize, scale, nullptr, 0, stream);
+}
+
+extern "C" int64_t agf_conv2d_wgrad_workspace_bytes(int dtype, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize, int has_scales) {
+    if (dtype != AGF_BF16 || ksize != 3 || N < 1 || H < 1 || W < 1 || Cin < 8 || Cout < 8 || Cin % 8 || Cout % 8) return 0;
+    return agf_conv2d_wgrad_ring_workspace(has_scales != 0, N, H, W, Cin, Cout);
+}
+
+extern "C" int agf_conv2d_wgrad_ws(const void* x, const void* dy, float* dw,
+                                   const float* in_scale, const float* out_scale,
+                                   int dtype, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
+                                   float scale, void* workspace, int64_t workspace_bytes, void* stream) {
+    AGF_CHECK(workspace_bytes >= 0 && (workspace || workspace_bytes == 0), "conv2d_wgrad_ws: bad workspace");
+    const int64_t need = agf_conv2d_wgrad_workspace_bytes(dtype, N, H, W, Cin, Cout, ksize, (in_scale || out_scale) ? 1 : 0);
+    if (need > 0 && workspace && workspace_bytes >= need)
+        return conv2d_wgrad_impl(x, dy, dw, in_scale, out_scale, dtype, N, H, W, Cin, Cout, ksize, scale, workspace, workspace_bytes, stream);
+    return conv2d_wgrad_impl(x, dy, dw, in_scale, out_scale, dtype, N, H, W, Cin, Cout, ksize, scale, nullptr, -1, stream);
 }

@@ -12,6 +12,8 @@ the discriminator twice, the path-length penalty the generator) compose from thr
 """
 import os
 
+import functools
+
 import torch
 
 from ... import _lib
@@ -200,6 +202,29 @@ def conv2d_fwd_raw(x, w, in_scale=None, out_scale=None, bias=None, noise=None, r
     return y
 
 
+@functools.lru_cache(maxsize=None)
+def _wgrad_workspace_bytes(dtype_code, N, H, W, Cin, Cout, ksize, scaled):
+    return int(_lib.lib().agf_conv2d_wgrad_workspace_bytes(dtype_code, N, H, W, Cin, Cout, ksize, int(scaled)))
+
+
+_WGRAD_WS = {}
+
+
+def _wgrad_workspace(device, nbytes):
+    """Scratch of the two-stage split-K combine: ONE buffer per device, grown to the largest request (every launch writes ~256 blocks x
+    64x64x9 fp32 = 38-45 MB whatever the layer) and reused by every launch -- the trainers issue all compute on one stream, where
+    launches are ordered (a second compute stream would need its own buffer: AGF_WGRAD_TWOSTAGE=0 falls back to atomics).  The buffer
+    exists before a HIP-graph capture starts (GraphedTrainStep warms up eagerly), so it is a static address inside the graph and stays
+    resident in the 256 MB Infinity Cache between the launch that writes it and the one that sums it."""
+    ws = _WGRAD_WS.get(device.index)
+    if ws is None or ws.numel() < nbytes:
+        if torch.cuda.is_current_stream_capturing():
+            return torch.empty(nbytes, dtype=torch.uint8, device=device)      # capture started cold: the graph's own pool holds it
+        ws = torch.empty(max(nbytes, 48 << 20), dtype=torch.uint8, device=device)
+        _WGRAD_WS[device.index] = ws
+    return ws
+
+
 def conv2d_wgrad_raw(x, dy, ksize, in_scale=None, out_scale=None, scale=1.0):
     """One ``agf_conv2d_wgrad`` launch.  x: [N,Cin,H,W], dy: [N,Cout,H,W], both bf16 channels_last.
     Returns dw fp32 in the logical [Cout,Cin,k,k] shape (memory OHWI)."""
@@ -212,12 +237,22 @@ def conv2d_wgrad_raw(x, dy, ksize, in_scale=None, out_scale=None, scale=1.0):
         raise RuntimeError('conv2d_wgrad: x and dy must both be bfloat16 or both float32')
     x = x.contiguous(memory_format=torch.channels_last)
     dy = dy.contiguous(memory_format=torch.channels_last)
-    dw = _zeros_f32((Cout, ksize, ksize, Cin), x.device).permute(0, 3, 1, 2)   # memory OHWI; zeroed by the arena's single fill
     in_scale, out_scale = _f32(in_scale), _f32(out_scale)
+    scaled = in_scale is not None or out_scale is not None
+    ws_bytes = _wgrad_workspace_bytes(_lib.dtype_code(x), N, H, W, Cin, Cout, ksize, scaled)
     timer = KernelTimer.active
-    ev0 = timer.start() if timer is not None else None
-    rc = _lib.lib().agf_conv2d_wgrad(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(in_scale), _lib.ptr(out_scale),
-                                     _lib.dtype_code(x), N, H, W, Cin, Cout, ksize, float(scale), _lib.stream_ptr(x))
+    if ws_bytes:
+        # two-stage split-K combine: partial tiles to a scratch buffer, summed by a second launch; dw is overwritten (no zero fill)
+        dw = torch.empty((Cout, ksize, ksize, Cin), dtype=torch.float32, device=x.device).permute(0, 3, 1, 2)
+        ws = _wgrad_workspace(x.device, ws_bytes)
+        ev0 = timer.start() if timer is not None else None
+        rc = _lib.lib().agf_conv2d_wgrad_ws(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(in_scale), _lib.ptr(out_scale),
+                                            _lib.dtype_code(x), N, H, W, Cin, Cout, ksize, float(scale), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(x))
+    else:
+        dw = _zeros_f32((Cout, ksize, ksize, Cin), x.device).permute(0, 3, 1, 2)   # memory OHWI; zeroed by the arena's single fill
+        ev0 = timer.start() if timer is not None else None
+        rc = _lib.lib().agf_conv2d_wgrad(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(in_scale), _lib.ptr(out_scale),
+                                         _lib.dtype_code(x), N, H, W, Cin, Cout, ksize, float(scale), _lib.stream_ptr(x))
     if timer is not None:
         timer.stop('conv2d_wgrad_kernel', ev0, 2.0 * N * H * W * Cin * Cout * ksize * ksize, (N, Cin, Cout, H, W, ksize, in_scale is not None))
     _lib.check(rc, 'conv2d_wgrad')

@@ -151,22 +151,29 @@ def main():
         eager_step.batches_done = 0
     for _ in range(args.warmup):
         step(real)
-    # per-launch HIP events on the MFMA kernels for the roofline numbers: two events around each of ~200 launches per step cost 2.6 %
-    # of the step, so they are recorded on every 4th timed step and on the lazy-R1 step(s) only (the launches of the other steps
-    # are identical)
+    # per-launch HIP events on the MFMA kernels for the roofline numbers.  A graph replay has no host-side launch points to bracket, so a
+    # sampled step runs eagerly -- ~48 ms instead of ~40 (it is bound by the host issuing ~2 100 launches and ~800 event records).  They
+    # are therefore recorded on the FIRST timed step and on the lazy-R1 step(s) only; the launches of the other steps are identical.
+    # (Round 1 sampled every 4th step: with graph replay in between that cost 3-5 ms per step of the headline number.)
     timer = None if args.no_kernel_timer else C.KernelTimer()
     first_timed = step.batches_done
     sampled_steps = 0
+    step_times = [] if os.environ.get('AGF_BENCH_STEP_TIMES') == '1' else None
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         it = first_timed + i
-        sample = timer is not None and (i % 4 == 0 or (it % 16 == 0 and it != 0))
+        sample = timer is not None and (i == 0 or (it % 16 == 0 and it != 0))
         C.KernelTimer.active = timer if sample else None
         sampled_steps += int(sample)
         (eager_step if sample else step)(real)
+        if step_times is not None:                  # diagnosis only (AGF_BENCH_STEP_TIMES=1): a sync per step
+            torch.cuda.synchronize()
+            step_times.append((round((time.perf_counter() - t0) * 1e3, 1), 'sampled' if sample else 'plain'))
     barrier()
     dt = time.perf_counter() - t0
+    if step_times:
+        print('cumulative ms after each step:', step_times, file=sys.stderr)
     C.KernelTimer.active = None
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define AGF_ABI_VERSION 12
+#define AGF_ABI_VERSION 13
 
 /* element types of activation tensors */
 enum { AGF_F32 = 0, AGF_F16 = 1, AGF_BF16 = 2, AGF_F64 = 3 };
@@ -180,6 +180,18 @@ int agf_conv2d_wgrad(const void* x, const void* dy, float* dw,
                      const float* in_scale, const float* out_scale,
                      int dtype, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
                      float scale, void* stream);
+
+/* The same weight gradient with dw OVERWRITTEN (no zero-initialisation) and, when the caller passes a scratch buffer of
+ * agf_conv2d_wgrad_workspace_bytes() bytes, a two-stage split-K combine: the blocks write their fp32 partial tiles to the workspace with
+ * plain stores and a second launch sums them into dw -- deterministic, and 3x cheaper than the atomics of agf_conv2d_wgrad (which ran at
+ * 0.5 TB/s: 76 us of a 190 us launch).  agf_conv2d_wgrad_workspace_bytes returns 0 for shapes that take the one-stage path (1x1, fp32,
+ * maps below 16x16 or not a multiple of the 128-pixel tile); agf_conv2d_wgrad_ws then zeroes dw itself and accumulates with atomics.
+ * (ABI v13; no reference counterpart: ATen / cuDNN own this in the reference, implementations/StyleGAN2/model.py:123-129.) */
+int64_t agf_conv2d_wgrad_workspace_bytes(int dtype, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize, int has_scales);
+int agf_conv2d_wgrad_ws(const void* x, const void* dy, float* dw,
+                        const float* in_scale, const float* out_scale,
+                        int dtype, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
+                        float scale, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Backward halves of the fused conv epilogues (new: the reference has no counterpart -- it runs these as separate
