@@ -141,9 +141,53 @@ extern "C" int agf_cl_to_planar_crop(const void* x, void* y, int dtype, int32_t 
 //   wq  [Cout][kh][kw][Cin]   = w * coef                                   (forward)
 //   wft [Cin][kh][kw][Cout]   = w[co][ci][k-1-kh][k-1-kw] * coef           (data gradient: flipped taps, swapped channel axes)
 // in the activation dtype.  Replaces 3 + 5 ATen launches (mul, cast, layout copy / flip, transpose, ...) per layer and half-step.
+// One block = a 32 co x 32 ci tile with all taps: the fp32 rows are read coalesced into LDS (row pitch odd: conflict-free both ways) and
+// written out twice, ci-fastest for wq and co-fastest for wft, so both outputs leave as contiguous runs (the first version wrote one
+// 2-byte element per thread with a stride of Cin / Cout elements: 7.6 us per layer, 125 launches per training iteration).  The same
+// kernel serves a whole LIST of weight tensors (agf_prep_weights_multi): blockIdx -> tensor by binary search of the descriptors' first
+// block index.
+struct PrepDesc {            // = AgfPrepDesc (include/agf_ops.h)
+    const float* w; void* wq; void* wft;
+    int32_t Cout, Cin, ksize; float coef;
+    int32_t block_start, reserved;
+};
+
+template <class T>
+static __device__ __forceinline__ void prep_tile(const float* __restrict__ w, T* __restrict__ wq, T* __restrict__ wft,
+                                                 int Cout, int Cin, int kk, float coef, int tile, float* sm) {
+    const int tilesCi = (Cin + 31) >> 5;
+    const int co0 = (tile / tilesCi) * 32, ci0 = (tile % tilesCi) * 32;
+    const int nco = min(32, Cout - co0), nci = min(32, Cin - ci0);
+    const int rowLen = nci * kk, pitch = 32 * kk + 1 - ((32 * kk) & 1);             // odd pitch
+    for (int e = threadIdx.x; e < nco * rowLen; e += 256) {
+        const int co = e / rowLen, r = e - co * rowLen;
+        sm[co * pitch + r] = w[((int64_t)(co0 + co) * Cin + ci0) * kk + r] * coef;
+    }
+    __syncthreads();
+    if (wq) {
+        for (int e = threadIdx.x; e < nco * kk * nci; e += 256) {                   // (co, tap, ci): ci fastest
+            const int ci = e % nci, t2 = e / nci, tap = t2 % kk, co = t2 / kk;
+            Elem<T>::store(wq + ((int64_t)(co0 + co) * kk + tap) * Cin + ci0 + ci, sm[co * pitch + ci * kk + tap]);
+        }
+    }
+    if (wft) {
+        for (int e = threadIdx.x; e < nci * kk * nco; e += 256) {                   // (ci, flipped tap, co): co fastest
+            const int co = e % nco, t2 = e / nco, tap = t2 % kk, ci = t2 / kk;
+            Elem<T>::store(wft + ((int64_t)(ci0 + ci) * kk + (kk - 1 - tap)) * Cout + co0 + co, sm[co * pitch + ci * kk + tap]);
+        }
+    }
+}
+
 template <class T>
 __global__ void __launch_bounds__(256) prep_weights_kernel(const float* __restrict__ w, T* __restrict__ wq, T* __restrict__ wft,
                                                            int Cout, int Cin, int kk, float coef) {
+    extern __shared__ float prep_sm[];
+    prep_tile<T>(w, wq, wft, Cout, Cin, kk, coef, blockIdx.x, prep_sm);
+}
+
+template <class T>      // any kernel size: one element per thread, scattered stores
+__global__ void __launch_bounds__(256) prep_weights_generic_kernel(const float* __restrict__ w, T* __restrict__ wq, T* __restrict__ wft,
+                                                                   int Cout, int Cin, int kk, float coef) {
     const int64_t total = (int64_t)Cout * Cin * kk;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int tap = (int)(i % kk);
@@ -155,19 +199,56 @@ __global__ void __launch_bounds__(256) prep_weights_kernel(const float* __restri
     }
 }
 
+template <class T>
+__global__ void __launch_bounds__(256) prep_weights_multi_kernel(const PrepDesc* __restrict__ descs, int count) {
+    extern __shared__ float prep_sm[];
+    int lo = 0, hi = count - 1;
+    while (lo < hi) {                                                                // last descriptor with block_start <= blockIdx.x
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].block_start <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const PrepDesc d = descs[lo];
+    prep_tile<T>(d.w, (T*)d.wq, (T*)d.wft, d.Cout, d.Cin, d.ksize * d.ksize, d.coef, blockIdx.x - d.block_start, prep_sm);
+}
+
 extern "C" int agf_prep_weights(const float* w, void* wq, void* wft, int dtype, int32_t Cout, int32_t Cin, int32_t ksize,
                                 float coef, void* stream) {
     AGF_CHECK(w && (wq || wft), "prep_weights: null pointer");
     AGF_CHECK(dtype == AGF_F32 || dtype == AGF_F16 || dtype == AGF_BF16, "prep_weights: dtype must be float16, bfloat16 or float32");
     AGF_CHECK(Cout >= 1 && Cin >= 1 && ksize >= 1, "prep_weights: bad shape");
     const int kk = ksize * ksize;
-    const int64_t total = (int64_t)Cout * Cin * kk;
-    int64_t blocks = (total + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == AGF_F32) hipLaunchKernelGGL((prep_weights_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st, w, (float*)wq, (float*)wft, Cout, Cin, kk, coef);
-    else if (dtype == AGF_F16) hipLaunchKernelGGL((prep_weights_kernel<f16_t>), dim3((unsigned)blocks), dim3(256), 0, st, w, (f16_t*)wq, (f16_t*)wft, Cout, Cin, kk, coef);
-    else hipLaunchKernelGGL((prep_weights_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, st, w, (bf16_t*)wq, (bf16_t*)wft, Cout, Cin, kk, coef);
+    if (ksize > 3) {
+        int64_t gb = ((int64_t)Cout * Cin * kk + 255) / 256;
+        if (gb > 4096) gb = 4096;
+        if (dtype == AGF_F32) hipLaunchKernelGGL((prep_weights_generic_kernel<float>), dim3((unsigned)gb), dim3(256), 0, st, w, (float*)wq, (float*)wft, Cout, Cin, kk, coef);
+        else if (dtype == AGF_F16) hipLaunchKernelGGL((prep_weights_generic_kernel<f16_t>), dim3((unsigned)gb), dim3(256), 0, st, w, (f16_t*)wq, (f16_t*)wft, Cout, Cin, kk, coef);
+        else hipLaunchKernelGGL((prep_weights_generic_kernel<bf16_t>), dim3((unsigned)gb), dim3(256), 0, st, w, (bf16_t*)wq, (bf16_t*)wft, Cout, Cin, kk, coef);
+        AGF_LAUNCH_CHECK();
+        return AGF_OK;
+    }
+    const unsigned blocks = (unsigned)(((Cout + 31) / 32) * ((Cin + 31) / 32));
+    const size_t lds = (size_t)32 * (32 * kk + 1) * sizeof(float);
+    if (dtype == AGF_F32) hipLaunchKernelGGL((prep_weights_kernel<float>), dim3(blocks), dim3(256), lds, st, w, (float*)wq, (float*)wft, Cout, Cin, kk, coef);
+    else if (dtype == AGF_F16) hipLaunchKernelGGL((prep_weights_kernel<f16_t>), dim3(blocks), dim3(256), lds, st, w, (f16_t*)wq, (f16_t*)wft, Cout, Cin, kk, coef);
+    else hipLaunchKernelGGL((prep_weights_kernel<bf16_t>), dim3(blocks), dim3(256), lds, st, w, (bf16_t*)wq, (bf16_t*)wft, Cout, Cin, kk, coef);
+    AGF_LAUNCH_CHECK();
+    return AGF_OK;
+}
+
+extern "C" int32_t agf_prep_weights_blocks(int32_t Cout, int32_t Cin) { return ((Cout + 31) / 32) * ((Cin + 31) / 32); }
+
+extern "C" int agf_prep_weights_multi(const void* descs_device, int32_t count, int32_t total_blocks, int32_t max_ksize, int dtype, void* stream) {
+    AGF_CHECK(descs_device && count >= 1 && total_blocks >= 1, "prep_weights_multi: empty list");
+    AGF_CHECK(dtype == AGF_F32 || dtype == AGF_F16 || dtype == AGF_BF16, "prep_weights_multi: dtype must be float16, bfloat16 or float32");
+    AGF_CHECK(max_ksize >= 1 && max_ksize <= 3, "prep_weights_multi: kernel sizes 1 ... 3 (larger ones go through agf_prep_weights)");
+    static_assert(sizeof(PrepDesc) == 48, "AgfPrepDesc layout");
+    const size_t lds = (size_t)32 * (32 * max_ksize * max_ksize + 1) * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    const PrepDesc* d = (const PrepDesc*)descs_device;
+    if (dtype == AGF_F32) hipLaunchKernelGGL((prep_weights_multi_kernel<float>), dim3((unsigned)total_blocks), dim3(256), lds, st, d, count);
+    else if (dtype == AGF_F16) hipLaunchKernelGGL((prep_weights_multi_kernel<f16_t>), dim3((unsigned)total_blocks), dim3(256), lds, st, d, count);
+    else hipLaunchKernelGGL((prep_weights_multi_kernel<bf16_t>), dim3((unsigned)total_blocks), dim3(256), lds, st, d, count);
     AGF_LAUNCH_CHECK();
     return AGF_OK;
 }

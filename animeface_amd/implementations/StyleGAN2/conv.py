@@ -439,6 +439,92 @@ def invalidate_cached(params):
         del _prep_cache[key]
 
 
+class PrepPlan:
+    """All conv weights of one network prepared by ONE ``agf_prep_weights_multi`` launch (instead of one launch per layer: ~125 launches
+    of 5-15 us per training iteration).  The (weight, coef, dtype) requests of a network are not a static property of its modules -- call
+    sites fold gains into ``coef`` -- so the plan RECORDS them while the first iteration runs through the per-layer path, then owns
+    persistent output buffers (both layouts: forward and data-gradient) and a device-resident descriptor table; ``run()`` refreshes
+    every buffer and installs them in the prepared-weight cache of the enclosing ``cached_weights()`` scope.  A request that does not
+    match what was recorded (other coef / dtype) simply misses the cache and is prepared on its own, as before."""
+
+    def __init__(self, parameters):
+        self.ids = {id(p) for p in parameters}
+        self.requests = {}             # id(weight) -> (weight, coef, dtype)
+        self.entries = None
+
+    def note(self, weight, coef, dtype):
+        if self.entries is None and id(weight) in self.ids and weight.dim() == 4 and weight.shape[2] == weight.shape[3] <= 3:
+            self.requests.setdefault(id(weight), (weight, coef, dtype))
+
+    def build(self):
+        """End of the recorded iteration: allocate the persistent buffers and upload the descriptor table (not inside a graph capture:
+        a capture that starts cold keeps the per-layer path)."""
+        import numpy as np
+        if self.entries is not None:
+            return
+        if not self.requests or torch.cuda.is_current_stream_capturing():
+            if torch.cuda.is_current_stream_capturing():
+                self.entries, self.requests = [], {}
+            return
+        reqs = [r for r in self.requests.values() if r[0].dtype == torch.float32 and r[0].is_contiguous()]
+        dtypes = {r[2] for r in reqs}
+        if not reqs or len(dtypes) != 1:
+            self.entries = []
+            return
+        self.dtype = dtypes.pop()
+        L = _lib.lib()
+        desc = np.zeros(len(reqs), dtype=np.dtype([('w', '<u8'), ('wq', '<u8'), ('wft', '<u8'), ('Cout', '<i4'), ('Cin', '<i4'), ('ksize', '<i4'),
+                                                  ('coef', '<f4'), ('block_start', '<i4'), ('reserved', '<i4')]))
+        assert desc.dtype.itemsize == 48
+        self.entries, blocks = [], 0
+        for i, (w, coef, dtype) in enumerate(reqs):
+            Cout, Cin, k, _ = w.shape
+            wq, wft = _empty_ohwi(Cout, Cin, k, dtype, w.device), _empty_ohwi(Cin, Cout, k, dtype, w.device)
+            desc[i] = (w.data_ptr(), wq.data_ptr(), wft.data_ptr(), Cout, Cin, k, coef, blocks, 0)
+            blocks += int(L.agf_prep_weights_blocks(Cout, Cin))
+            self.entries.append((w, float(coef), wq, wft))
+        self.blocks, self.kmax = blocks, max(int(w.shape[2]) for w, _, _ in reqs)
+        self.table = torch.from_numpy(desc.view(np.uint8).copy()).to(reqs[0][0].device)
+        self.ptrs = [w.data_ptr() for w, _, _ in reqs]
+        self.requests = {}
+
+    def run(self):
+        """Prepare everything (call inside a ``cached_weights()`` scope, after the parameters changed)."""
+        import weakref
+        if not self.entries:                        # still recording (first iteration), or nothing to batch
+            return
+        if any(w.data_ptr() != p for (w, _, _, _), p in zip(self.entries, self.ptrs)):     # a parameter was re-allocated (load_state_dict
+            self.entries, self.requests = None, {}                                         # copies in place; .to() / .data = ... do not):
+            return                                                                         # record again during this iteration
+        w0 = self.entries[0][0]
+        rc = _lib.lib().agf_prep_weights_multi(_lib.ptr(self.table), len(self.entries), self.blocks, self.kmax, _lib._DTYPES[self.dtype],
+                                               _lib.stream_ptr(w0))
+        _lib.check(rc, 'prep_weights_multi')
+        if _prep_cache_on:
+            for w, coef, wq, wft in self.entries:
+                ent = _Prepared()
+                ent.ref, ent.coef, ent.wq, ent.wq_ft = weakref.ref(w), coef, wq, wft
+                _prep_cache[(id(w), self.dtype)] = ent
+
+
+_prep_plans = []          # plans that are recording (TrainStep registers its two while an iteration runs)
+
+
+class recording_plans:
+    def __init__(self, *plans):
+        self.plans = [p for p in plans if p is not None]
+
+    def __enter__(self):
+        global _prep_plans
+        self.prev = _prep_plans
+        _prep_plans = self.plans
+        return self
+
+    def __exit__(self, *a):
+        global _prep_plans
+        _prep_plans = self.prev
+
+
 def prepared_weights(weight, coef, dtype, need_ft=False):
     import weakref
     cacheable = _prep_cache_on and isinstance(weight, torch.nn.Parameter)
@@ -447,6 +533,9 @@ def prepared_weights(weight, coef, dtype, need_ft=False):
         ent = _prep_cache.get((id(weight), dtype))
         if ent is not None and (ent.ref() is not weight or ent.coef != coef):
             ent = None
+        if ent is None:
+            for plan in _prep_plans:
+                plan.note(weight, float(coef), dtype)
     if ent is None:
         ent = _Prepared()
         ent.coef, ent.wq_ft = coef, None

@@ -13,6 +13,8 @@ rescale (:208-218).  Differences, all outside the arithmetic of a step:
 import functools
 
 import numpy as np
+import os
+
 import torch
 import torch.optim as optim
 
@@ -22,7 +24,7 @@ from ...thirdparty.diffaugment import DiffAugment
 from ... import distributed as dp
 from ... import rng
 from .model import Generator, Discriminator, init_weight_N01
-from .conv import cached_weights, invalidate_cached, ZeroArena, zero_arena
+from .conv import cached_weights, invalidate_cached, ZeroArena, zero_arena, PrepPlan, recording_plans
 
 
 def pl_penalty(styles, images, pl_mean, scaler=None):
@@ -68,7 +70,9 @@ class TrainStep:
         self.pl_mean = 0.
         self.batches_done = 0
         self._arena_D, self._arena_G = ZeroArena(), ZeroArena()        # zero-initialised backward scratch of the two half-steps
-        import os
+        # batched weight preparation (one launch per network and optimizer step); AGF_PREP_PLAN=0: one launch per layer
+        on = os.environ.get('AGF_PREP_PLAN', '1') != '0'
+        self._plan_G, self._plan_D = (PrepPlan(G.parameters()), PrepPlan(D.parameters())) if on else (None, None)
         self.merge_d_passes = os.environ.get('AGF_MERGE_D', '1') != '0'
         if hasattr(G, 'set_fused_epilogue'):
             G.set_fused_epilogue(pl_lambda == 0)     # the fused modulated conv has no double backward (path length needs it)
@@ -104,7 +108,11 @@ class TrainStep:
 
         # one cache scope for the whole iteration: the generator's prepared weights (bf16 OHWI copies, sum of squares) made for the
         # D-step's no-grad forward are still valid in the G-step; the discriminator's are dropped when its optimizer steps
-        with cached_weights():
+        # (from the second iteration on every conv weight of a network is prepared by one launch: PrepPlan)
+        with cached_weights(), recording_plans(self._plan_G, self._plan_D):
+            if self._plan_G is not None:
+                self._plan_G.run()
+                self._plan_D.run()
             # ---- discriminator (reference utils.py:60-86) ----
             with zero_arena(self._arena_D, real.device):
                 D_loss = self._d_half(real, it)
@@ -112,6 +120,8 @@ class TrainStep:
                 self.reducer_D.finish()
             self.optimizer_D.step()
             invalidate_cached(D.parameters())
+            if self._plan_D is not None:
+                self._plan_D.run()
 
             # ---- generator (reference utils.py:88-113) ----
             for p in D.parameters():
@@ -120,6 +130,8 @@ class TrainStep:
                 G_loss, fake = self._g_half(real, it)
             for p in D.parameters():
                 p.requires_grad_(True)
+        if self._plan_G is not None:
+            self._plan_G.build(), self._plan_D.build()          # no-ops after the first iteration
         if self.reducer_G is not None:
             self.reducer_G.finish()
         self.optimizer_G.step()

@@ -234,6 +234,18 @@ int agf_cl_to_planar_crop(const void* x, void* y, int dtype, int32_t N, int32_t 
 int agf_prep_weights(const float* w, void* wq, void* wft, int dtype, int32_t Cout, int32_t Cin, int32_t ksize,
                      float coef, void* stream);
 
+/* agf_prep_weights for a LIST of weight tensors in one launch (ABI v13): `descs_device` is a device array of `count` descriptors sorted by
+ * block_start, where block_start[i] = sum of agf_prep_weights_blocks(Cout, Cin) over the tensors before i and total_blocks the sum over
+ * all of them; wq / wft may be null per tensor; max_ksize = the largest ksize in the list (sizes the LDS tile).  A training iteration
+ * prepares every conv weight of a network with one launch instead of ~60. */
+typedef struct AgfPrepDesc {
+    const float* w; void* wq; void* wft;
+    int32_t Cout, Cin, ksize; float coef;
+    int32_t block_start, reserved;
+} AgfPrepDesc;
+int32_t agf_prep_weights_blocks(int32_t Cout, int32_t Cin);
+int agf_prep_weights_multi(const void* descs_device, int32_t count, int32_t total_blocks, int32_t max_ksize, int dtype, void* stream);
+
 /* Style / demodulation scalars of ModulatedConv2d (implementations/StyleGAN2/model.py:105-121; the reference scales a per-sample
  * copy of the weights by the style and reduces it: `weight * style`, `rsqrt(weight.pow(2).sum([2,3,4]) + 1e-4)`).  Evaluated here
  * through wsq[co][ci] = sum_taps W[co][ci][kh][kw]^2 without materialising scaled weights; everything fp32.
