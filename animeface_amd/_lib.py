@@ -23,7 +23,7 @@ EXPORTS = ['agf_abi_version', 'agf_last_error', 'agf_device_info', 'agf_upfirdn2
            'agf_filtered_lrelu', 'agf_filtered_lrelu_act', 'agf_conv2d_fwd', 'agf_conv2d_fwd_mask', 'agf_conv2d_wgrad', 'agf_conv2d_wgrad_ws', 'agf_conv2d_wgrad_workspace_bytes',
            'agf_act_bwd_reduce', 'agf_act_bwd_reduce_pooled', 'agf_scale_dot', 'agf_planar_to_cl_pad', 'agf_cl_to_planar_crop', 'agf_prep_weights', 'agf_prep_weights_multi', 'agf_prep_weights_blocks',
            'agf_modulate_weights', 'agf_conv2d_fwd_wimg', 'agf_conv2d_fwd_wimg_covers',
-           'agf_wsq', 'agf_style_demod_fwd', 'agf_style_demod_bwd', 'agf_diffaug_sum', 'agf_diffaug_apply', 'agf_color_affine', 'agf_affine_resample', 'agf_upblur_border', 'agf_image_resample_rows', 'agf_image_finish']
+           'agf_wsq', 'agf_style_demod_fwd', 'agf_style_demod_fwd_ld', 'agf_style_demod_bwd', 'agf_diffaug_sum', 'agf_diffaug_apply', 'agf_color_affine', 'agf_affine_resample', 'agf_upblur_border', 'agf_image_resample_rows', 'agf_image_finish']
 
 _lib = None
 _i32x4 = ctypes.c_int32 * 4
@@ -102,6 +102,8 @@ def lib():
         L.agf_wsq.argtypes = [_vp, _vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp]
         L.agf_style_demod_fwd.restype = ctypes.c_int
         L.agf_style_demod_fwd.argtypes = [_vp] * 4 + [ctypes.c_int32] * 3 + [ctypes.c_float, ctypes.c_float, _vp]
+        L.agf_style_demod_fwd_ld.restype = ctypes.c_int
+        L.agf_style_demod_fwd_ld.argtypes = [_vp, ctypes.c_int64] + [_vp] * 3 + [ctypes.c_int32] * 3 + [ctypes.c_float, ctypes.c_float, _vp]
         L.agf_style_demod_bwd.restype = ctypes.c_int
         L.agf_style_demod_bwd.argtypes = [_vp] * 8 + [ctypes.c_int32] * 4 + [ctypes.c_float, _vp]
         L.agf_diffaug_sum.restype = ctypes.c_int

@@ -29,7 +29,7 @@ __global__ void __launch_bounds__(256) wsq_kernel(const float* __restrict__ w, f
 #define STYLE_SL 16
 __global__ void __launch_bounds__(64 * STYLE_SL) style_demod_fwd_kernel(const float* __restrict__ s_raw, const float* __restrict__ wsq_t,
                                                               float* __restrict__ s, float* __restrict__ d,
-                                                              int B, int Cin, int Cout, float c2, float eps) {
+                                                              int B, int Cin, int Cout, float c2, float eps, int64_t ldRaw) {
     extern __shared__ float smem[];
     float* s2 = smem;                                    // [4][Cin]
     __shared__ float red[STYLE_SL][4][64];
@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(64 * STYLE_SL) style_demod_fwd_kernel(const fl
         const int bt = idx / Cin, ci = idx - bt * Cin, b = b0 + bt;
         float v = 0.f;
         if (b < B) {
-            v = s_raw[(int64_t)b * Cin + ci] + 1.f;
+            v = s_raw[(int64_t)b * ldRaw + ci] + 1.f;
             if (blockIdx.x == 0) s[(int64_t)b * Cin + ci] = v;
         }
         s2[idx] = v * v;
@@ -166,13 +166,21 @@ extern "C" int agf_wsq(const float* w, float* wsq, float* wsq_t, int32_t Cout, i
     return AGF_OK;
 }
 
+extern "C" int agf_style_demod_fwd_ld(const float* s_raw, int64_t s_raw_stride, const float* wsq_t, float* s, float* d,
+                                      int32_t B, int32_t Cin, int32_t Cout, float c2, float eps, void* stream);
 extern "C" int agf_style_demod_fwd(const float* s_raw, const float* wsq_t, float* s, float* d,
                                    int32_t B, int32_t Cin, int32_t Cout, float c2, float eps, void* stream) {
+    return agf_style_demod_fwd_ld(s_raw, Cin, wsq_t, s, d, B, Cin, Cout, c2, eps, stream);
+}
+
+extern "C" int agf_style_demod_fwd_ld(const float* s_raw, int64_t s_raw_stride, const float* wsq_t, float* s, float* d,
+                                      int32_t B, int32_t Cin, int32_t Cout, float c2, float eps, void* stream) {
     AGF_CHECK(s_raw && wsq_t && s && d, "style_demod_fwd: null pointer");
+    AGF_CHECK(s_raw_stride >= Cin, "style_demod_fwd: row stride %lld below Cin = %d", (long long)s_raw_stride, Cin);
     AGF_CHECK(B >= 1 && Cin >= 1 && Cout >= 1, "style_demod_fwd: empty tensor");
     AGF_CHECK((size_t)4 * Cin * sizeof(float) <= 48 * 1024, "style_demod_fwd: Cin = %d is too large", Cin);
     hipLaunchKernelGGL(style_demod_fwd_kernel, dim3((unsigned)agf_ceil_div(Cout, 64), (unsigned)agf_ceil_div(B, 4)), dim3(64 * STYLE_SL),
-                       (size_t)4 * Cin * sizeof(float), (hipStream_t)stream, s_raw, wsq_t, s, d, B, Cin, Cout, c2, eps);
+                       (size_t)4 * Cin * sizeof(float), (hipStream_t)stream, s_raw, wsq_t, s, d, B, Cin, Cout, c2, eps, s_raw_stride);
     AGF_LAUNCH_CHECK();
     return AGF_OK;
 }

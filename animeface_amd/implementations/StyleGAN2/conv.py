@@ -575,14 +575,15 @@ class _StyleDemod(torch.autograd.Function):
     @staticmethod
     def forward(ctx, s_raw, weight, coef, eps):
         _lib.require_gpu(s_raw, 'style_demod')
-        s_raw = _f32(s_raw)
+        if not (s_raw.dtype == torch.float32 and s_raw.dim() == 2 and s_raw.stride(1) == 1 and s_raw.stride(0) >= s_raw.shape[1]):
+            s_raw = _f32(s_raw)                              # (a column block of the batched style GEMM is read in place: row stride)
         B, Cin = s_raw.shape
         Cout = weight.shape[0]
         wsq, wsq_t = _wsq_pair(weight)
-        s = torch.empty_like(s_raw)
+        s = torch.empty((B, Cin), dtype=torch.float32, device=s_raw.device)
         d = torch.empty(B, Cout, dtype=torch.float32, device=s_raw.device)
-        rc = _lib.lib().agf_style_demod_fwd(_lib.ptr(s_raw), _lib.ptr(wsq_t), _lib.ptr(s), _lib.ptr(d), B, Cin, Cout,
-                                            float(coef * coef), float(eps), _lib.stream_ptr(s_raw))
+        rc = _lib.lib().agf_style_demod_fwd_ld(_lib.ptr(s_raw), s_raw.stride(0), _lib.ptr(wsq_t), _lib.ptr(s), _lib.ptr(d), B, Cin, Cout,
+                                               float(coef * coef), float(eps), _lib.stream_ptr(s_raw))
         _lib.check(rc, 'style_demod_fwd')
         ctx.save_for_backward(s, d, weight, wsq)
         ctx.c2 = float(coef * coef)

@@ -38,6 +38,7 @@ from .conv import conv2d, conv2d_act, style_demod, PremaskLink, pool2x_linked, u
 FUSED_EPILOGUE = True
 _UPBLUR_FUSED = os.environ.get('AGF_UPBLUR_FUSED', '1') != '0'        # A/B switch: upsample + blur of the generator block as one pass
 _STYLE_FUSED = os.environ.get('AGF_STYLE_FUSED', '1') != '0'      # A/B switch: one-launch style / demodulation scalars
+_AFFINE_BATCHED = os.environ.get('AGF_AFFINE_BATCHED', '1') != '0'  # A/B switch: the style affines of all layers as one GEMM
 
 
 class ELR(nn.Module):
@@ -141,6 +142,10 @@ class MapLinear(nn.Module):
         self.lr = lr
 
     def forward(self, x):
+        elr = self.linear
+        if isinstance(elr, ELR) and isinstance(elr.layer, nn.Linear) and elr.layer.bias is not None and x.dim() == 2:
+            # ((x * coef) @ W^T + b) * lr as ONE GEMM launch: alpha = coef * lr on the product, beta = lr on the bias
+            return torch.addmm(elr.layer.bias, x.float(), elr.layer.weight.t(), alpha=elr.coef * self.lr, beta=self.lr)
         return self.linear(x) * self.lr
 
 
@@ -180,9 +185,12 @@ class ModulatedConv2d(nn.Module):
     def scales(self, y):
         """style scale s [B,Cin] and demodulation d [B,Cout] (fp32).
         sum_{ci,kh,kw} (W*coef*s)^2  ==  coef^2 * (s^2 @ (sum_{kh,kw} W^2)^T): no scaled copy of the weights is made."""
+        raw = self.__dict__.pop('_s_raw', None)          # left here by Synthesis._batched_affines for exactly this call
+        if raw is None:
+            raw = self.affine(y)
         if self.demod and FUSED_EPILOGUE and _STYLE_FUSED and getattr(self, 'fused_epilogue', True) and y.is_cuda:
-            return style_demod(self.affine(y), self.weight, self.coef, 1e-4)
-        s = self.affine(y) + 1
+            return style_demod(raw, self.weight, self.coef, 1e-4)
+        s = raw + 1
         d = None
         if self.demod:
             wsq = self.weight.square().sum((2, 3))
@@ -384,6 +392,32 @@ class Synthesis(nn.Module):
             self.num_layers += 1
         self.tanh = nn.Tanh()
 
+    def _batched_affines(self, ys):
+        """The style affines of all modulated convs (reference model.py:105: ``self.affine(y)`` inside each layer) as ONE GEMM per distinct
+        style tensor: every layer multiplies the same [B, style_dim] input, so the weights are concatenated along the output axis
+        (26 launches of a 64 x 512 x Cin GEMM -> cat + addmm; backward 78 -> 3).  The per-layer slices are handed to
+        ``ModulatedConv2d.scales`` through a transient attribute.  state_dict and parameters are untouched."""
+        if not (_AFFINE_BATCHED and ys[0].is_cuda and ys[0].dim() == 2):
+            return
+        if getattr(self, '_affine_groups', None) is None:
+            convs = [(self.input, 0), (self.input_to_image.conv, 0)]
+            for i, (block, to_image) in enumerate(zip(self.blocks, self.to_images)):
+                convs += [(m, i + 1) for m in block.block if isinstance(m, ModulatedConv2d)] + [(to_image.conv, i + 1)]
+            ok = all(isinstance(m.affine, ELR) and isinstance(m.affine.layer, nn.Linear) and m.affine.layer.bias is not None
+                     and m.affine.coef == convs[0][0].affine.coef for m, _ in convs)
+            self._affine_groups = convs if ok else []
+        if not self._affine_groups:
+            return
+        groups = {}
+        for m, level in self._affine_groups:
+            groups.setdefault(id(ys[level]), (ys[level], []))[1].append(m)
+        for y, mods in groups.values():
+            w = torch.cat([m.affine.layer.weight for m in mods], 0)
+            b = torch.cat([m.affine.layer.bias for m in mods], 0)
+            raw = torch.addmm(b, y.float(), w.t(), alpha=mods[0].affine.coef)
+            for m, sl in zip(mods, raw.split([m.affine.layer.out_features for m in mods], 1)):
+                m.__dict__['_s_raw'] = sl
+
     def forward(self, x, y, injection=None):
         if isinstance(y, (list, tuple)):          # style mixing
             assert len(y) == 2
@@ -392,6 +426,7 @@ class Synthesis(nn.Module):
             y = [y[0] for _ in range(injection)] + [y[1] for _ in range(self.num_layers - injection)]
         else:
             y = [y for _ in range(self.num_layers)]
+        self._batched_affines(y)
         x = self.input(x, y[0])
         pre = self.input_to_image(x, y[0])
         image = pre

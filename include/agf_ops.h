@@ -256,6 +256,10 @@ int agf_prep_weights_multi(const void* descs_device, int32_t count, int32_t tota
 int agf_wsq(const float* w, float* wsq, float* wsq_t, int32_t Cout, int32_t Cin, int32_t taps, void* stream);
 int agf_style_demod_fwd(const float* s_raw, const float* wsq_t, float* s, float* d,
                         int32_t B, int32_t Cin, int32_t Cout, float c2, float eps, void* stream);
+/* the same with s_raw rows `s_raw_stride` floats apart: a column block of the [B, sum Cin] result of ONE GEMM that evaluates the style
+ * affines of every layer (ABI v13) */
+int agf_style_demod_fwd_ld(const float* s_raw, int64_t s_raw_stride, const float* wsq_t, float* s, float* d,
+                           int32_t B, int32_t Cin, int32_t Cout, float c2, float eps, void* stream);
 int agf_style_demod_bwd(const float* s, const float* d, const float* dd, const float* ds, const float* wsq, const float* w,
                         float* ds_raw, float* dw, int32_t B, int32_t Cin, int32_t Cout, int32_t taps, float c2, void* stream);
 
