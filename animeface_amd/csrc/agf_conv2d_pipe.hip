@@ -32,9 +32,11 @@ struct PipeParams {
     int tilesWl2, tilesHl2;     // log2(tiles per row), log2(tiles per column) of one image
     int band;                   // pixel tiles per XCD (contiguous)
     long long wImgStride;       // elements between per-image weight tensors (0 = one shared tensor)
+    int dbg;                    // timing experiments (AGF_PIPE_DBG): bits 0-1: 1 = no epilogue at all, 2 = stores of zeros without the epilogue arithmetic; +4: weight DMA out of range (zero fill, no memory traffic); +8: the same for the activations
 };
 
 #define PIPE_OOB 0x7fff0000
+#define PIPE_ISSUE_TAP 1          // the tap of a chunk after whose MFMAs the next DMA group is issued
 
 template <int V> static __device__ __forceinline__ void pipe_wait_vm() {
     static_assert(V >= 0 && V <= 63, "vmcnt immediate out of range");
@@ -55,7 +57,11 @@ static constexpr int pipe_younger(int c, int lpw, int P, int S, int PF) {
 // EPI: 0 = forward epilogue (demodulation scale, bias, noise, lrelu, gain), 1 = + lrelu mask of the layer below (agf_conv2d_fwd_mask),
 //      2 = mask + pooled residual.  The per-channel operands of EPI 0 (out_scale[n], bias) travel as two extra 256-byte DMA loads
 //      into a 512-byte tail of every stage buffer and are read from LDS: no registers, no vmcnt entanglement.
-template <int KS, int MT, int NWM, int NWN, int NJ, int NCH, int NSTAGE, int PMAX, int EPI>
+// WS (weights stationary; shared weights that fit: Cin <= 64): the whole Cout x 9 x Cin tensor is loaded ONCE per block into a fixed LDS
+//      region and only the activation chunks stream through the ring.  Measured on 64 -> 64 @256x256, B = 128 with the epilogue off:
+//      0.73 ms with the 74 KB of weights re-streamed from L2 for every tile, 0.58 ms without that traffic -- and the two streams cost
+//      more together than the sum of each alone.
+template <int KS, int MT, int NWM, int NWN, int NJ, int NCH, int NSTAGE, int PMAX, int EPI, bool WS>
 __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_pipe_kernel(PipeParams pp) {
     const ConvParams& p = pp.c;
     constexpr int NW = NWM * NWN;
@@ -63,8 +69,9 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_pipe_kernel(Pipe
     constexpr int WTOT = TAPS * BM * 2;                  // 16-byte vectors of one weight chunk
     constexpr int XTOT = PMAX * 2;
     static_assert(WTOT % 64 == 0, "weight chunk must be whole wave-loads");
-    constexpr int WG = WTOT / 64;                        // wave-loads that carry weights
-    constexpr int NG = WG + (XTOT + 63) / 64;            // 1 KB wave-loads per stage
+    constexpr int WG = WTOT / 64;                        // wave-loads of one weight chunk
+    constexpr int WGS = WS ? 0 : WG;                     // ... that travel with every stage
+    constexpr int NG = WGS + (XTOT + 63) / 64;           // 1 KB wave-loads per stage
     constexpr int SIDE_E = NG * 64 * 8;                  // after the wave-loads (whose last, partial one zero-fills up to here):
     constexpr int STAGE_E = SIDE_E + 256;                //   float side[2][64] = out_scale[n], bias; elements per stage buffer
     constexpr int NOPS = NG + 2;                         // DMA operations per stage: the wave-loads + the two side loads
@@ -76,8 +83,9 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_pipe_kernel(Pipe
     constexpr int PF = NCH >= 2 ? NCH - 2 : 0;           // chunk at whose start the epilogue operands are requested
     constexpr int TCONS = (NSTAGE - 1 + NCH - 1) / NCH;  // first tiles: the conservative wait count (operations of the prologue)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    bf16_t* sS = (bf16_t*)smem_raw;                      // [NSTAGE][STAGE_E]
-    float* red = (float*)(smem_raw + (size_t)NSTAGE * STAGE_E * 2);        // [NW][64]
+    bf16_t* sWfix = (bf16_t*)smem_raw;                   // WS: [NCH][WTOT * 8]
+    bf16_t* sS = sWfix + (WS ? NCH * WTOT * 8 : 0);      // [NSTAGE][STAGE_E]
+    float* red = (float*)(sS + (size_t)NSTAGE * STAGE_E);                  // [NW][64]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / NWN, wn = wave % NWN;
@@ -101,12 +109,12 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_pipe_kernel(Pipe
         const int g64 = wave + k * NW;
         const int v = g64 * 64 + lane;
         goff[k] = PIPE_OOB; gpos[k] = -1;
-        if (g64 < WG) {
+        if (g64 < WGS) {
             const int row = v >> 1, half = (v & 1) ^ ((row >> 3) & 1);
             const int tap = row / BM, co = row - tap * BM;
             if (co < p.Cout) goff[k] = ((co * TAPS + tap) * p.Cin + half * 8) * 2;
         } else if (g64 < NG) {
-            const int vx = v - WTOT;
+            const int vx = v - WGS * 64;
             const int pix = vx >> 1, half = (vx & 1) ^ ((pix >> 3) & 1);
             if (pix < P) {
                 const int pr = pix / PW, pc = pix - pr * PW;
@@ -142,16 +150,16 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_pipe_kernel(Pipe
                     const float* src = isB ? p.bias : (p.out_scale ? p.out_scale + (int64_t)n0 * p.Cout : nullptr);
                     const __amdgpu_buffer_rsrc_t sRes = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (live && src) ? p.Cout * 4 : 0, 0x00020000);
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(sRes, (lds_ptr)(dst + SIDE_E + (g64 - NG) * 128), 4, lane * 4, 0, 0, 0);
-                } else if (g64 < WG) {
+                } else if (g64 < WGS) {
                     // (the offset goes through a local: passing an element of a template-sized array straight into the builtin from inside a
                     //  lambda makes this clang drop the kernel's HOST stub without a diagnostic)
-                    const int off = goff[k] + chOff;
+                    const int off = (pp.dbg & 4) ? PIPE_OOB : goff[k] + chOff;
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(wRes, (lds_ptr)(dst + g64 * 64 * 8), 16, off, 0, 0, 0);
                 } else {
                     int off = PIPE_OOB;
                     if (gpos[k] >= 0) {
                         const int h = h0 + (gpos[k] >> 16) - HALO, w = w0 + (gpos[k] & 0xffff) - HALO;
-                        if (interior || (h >= 0 && h < p.H && w >= 0 && w < p.W)) off = tileOrg + goff[k];
+                        if ((interior || (h >= 0 && h < p.H && w >= 0 && w < p.W)) && !(pp.dbg & 8)) off = tileOrg + goff[k];
                     }
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(xRes, (lds_ptr)(dst + g64 * 64 * 8), 16, off, 0, 0, 0);
                 }
@@ -216,6 +224,21 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_pipe_kernel(Pipe
         const int n0 = pt >> (pp.tilesWl2 + pp.tilesHl2);
         const __amdgpu_buffer_rsrc_t yRes = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (int64_t)n0 * p.H * p.W * p.Cout), 0, p.H * p.W * p.Cout * 2, 0x00020000);
         const float* side = (const float*)(stage + SIDE_E);         // [2][64]: out_scale[n0], bias (landed with this stage)
+        if ((pp.dbg & 3) == 1) return;
+        if ((pp.dbg & 3) == 2) {
+#pragma unroll
+            for (int j = 0; j < NJ; j++)
+#pragma unroll
+                for (int i = 0; i < MT; i++)
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        const int cb = coW + i * 32 + (2 * q + lhi) * 8;
+                        const int offY = cb < p.Cout ? pixOff[j] + cb * 2 : PIPE_OOB;
+                        u32x4 val = {0u, 0u, 0u, 0u};
+                        __builtin_amdgcn_raw_buffer_store_b128(val, yRes, offY, 0, 0);
+                    }
+            return;
+        }
         float msum[EPI >= 1 ? MT * 16 : 1];
         if (EPI >= 1) {
 #pragma unroll
@@ -313,6 +336,21 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_pipe_kernel(Pipe
         }
     };
 
+    if (WS) {
+        // the whole weight tensor, chunk-major, in the stage layout of a weight chunk (swizzled 32-byte rows)
+        const __amdgpu_buffer_rsrc_t wAll = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, wBytes, 0x00020000);
+        for (int g = wave; g < WG * NCH; g += NW) {
+            const int chunk = g / WG, gg = g - chunk * WG;
+            const int v = gg * 64 + lane;
+            const int row = v >> 1, half = (v & 1) ^ ((row >> 3) & 1);
+            const int tap = row / BM, co = row - tap * BM;
+            const int off = co < p.Cout ? ((co * TAPS + tap) * p.Cin + half * 8) * 2 + chunk * 32 : PIPE_OOB;
+            bf16_t* dst = sWfix + (chunk * WTOT + gg * 64) * 8;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wAll, (lds_ptr)dst, 16, off, 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
     // ---- the pipeline ----
 #pragma unroll
     for (int s = 0; s < NSTAGE - 1; s++) issue(s / NCH, s % NCH, s);
@@ -330,14 +368,6 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_pipe_kernel(Pipe
             // fragment reads of the previous stage were consumed by MFMAs before it arrived.
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            if (ch == PF) prefetch(t);
-            __builtin_amdgcn_sched_barrier(0);
-            {
-                constexpr int ahead = NSTAGE - 1;
-                const int nb = buf + ahead >= NSTAGE ? buf + ahead - NSTAGE : buf + ahead;
-                issue(t + (ch + ahead) / NCH, (ch + ahead) % NCH, nb);
-            }
-            __builtin_amdgcn_sched_barrier(0);
             if (ch == 0) {
 #pragma unroll
                 for (int i = 0; i < MT; i++)
@@ -346,8 +376,9 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_pipe_kernel(Pipe
 #pragma unroll
                         for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
             }
-            const bf16_t* cW = sS + buf * STAGE_E;
-            const bf16_t* cX = cW + WTOT * 8;
+            const bf16_t* stageBase = sS + buf * STAGE_E;
+            const bf16_t* cW = WS ? sWfix + ch * WTOT * 8 : stageBase;
+            const bf16_t* cX = stageBase + WGS * 64 * 8;
 #pragma unroll
             for (int kh = 0; kh < KS; kh++) {
 #pragma unroll
@@ -366,12 +397,24 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_pipe_kernel(Pipe
 #pragma unroll
                         for (int j = 0; j < NJ; j++)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    if (tap == PIPE_ISSUE_TAP) {
+                        // the address arithmetic of the epilogue-operand requests and of the next DMA group rides in the shadow of this
+                        // chunk's MFMAs (issued in one piece right after the barrier, all eight waves spent it in lock step with the
+                        // matrix pipe idle); the order [prefetch][DMA] within the iteration is what pipe_younger counts on
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (ch == PF) prefetch(t);
+                        __builtin_amdgcn_sched_barrier(0);
+                        constexpr int ahead = NSTAGE - 1;
+                        const int nb = buf + ahead >= NSTAGE ? buf + ahead - NSTAGE : buf + ahead;
+                        issue(t + (ch + ahead) / NCH, (ch + ahead) % NCH, nb);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
             }
             buf = buf + 1 == NSTAGE ? 0 : buf + 1;
             asm volatile("" : "+s"(buf));                 // opaque: keeps the next chunks' LDS addresses from being formed (and held) early
             __builtin_amdgcn_sched_barrier(0);
-            if (ch == NCH - 1) epilogue(t, cW);
+            if (ch == NCH - 1) epilogue(t, stageBase);
             __builtin_amdgcn_sched_barrier(0);
         });
     }
@@ -390,27 +433,28 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_pipe_kernel(Pipe
     }
 }
 
-template <int KS, int MT, int NWM, int NWN, int NJ, int NCH, int NSTAGE, int PMAX, int EPI>
+template <int KS, int MT, int NWM, int NWN, int NJ, int NCH, int NSTAGE, int PMAX, int EPI, bool WS>
 static int launch_pipe_e(const PipeParams& pp, int blocksPerCU, hipStream_t st) {
     constexpr int TAPS = KS * KS, BM = 32 * NWM * MT, NW = NWM * NWN;
-    constexpr int NG = TAPS * BM * 2 / 64 + (PMAX * 2 + 63) / 64;
-    const size_t lds = (size_t)NSTAGE * (NG * 1024 + 512) + NW * 64 * 4;
+    constexpr int WG = TAPS * BM * 2 / 64;
+    constexpr int NG = (WS ? 0 : WG) + (PMAX * 2 + 63) / 64;
+    const size_t lds = (size_t)(WS ? NCH * WG * 1024 : 0) + (size_t)NSTAGE * (NG * 1024 + 512) + NW * 64 * 4;
     if (lds > 160 * 1024) return AGF_ENOKERNEL;
     static int cus = 0;
     if (!cus) { int dev = 0; hipDeviceProp_t prop; if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return AGF_ELAUNCH; cus = prop.multiProcessorCount; }
     int grid = (cus * blocksPerCU) & ~7;
     if (grid < 8) grid = 8;
-    hipError_t e = hipFuncSetAttribute((const void*)conv2d_fwd_pipe_kernel<KS, MT, NWM, NWN, NJ, NCH, NSTAGE, PMAX, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)conv2d_fwd_pipe_kernel<KS, MT, NWM, NWN, NJ, NCH, NSTAGE, PMAX, EPI, WS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { agf_set_error("conv2d_fwd (pipe): cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e)); return AGF_ELAUNCH; }
-    hipLaunchKernelGGL((conv2d_fwd_pipe_kernel<KS, MT, NWM, NWN, NJ, NCH, NSTAGE, PMAX, EPI>), dim3((unsigned)grid), dim3(64 * NW), lds, st, pp);
+    hipLaunchKernelGGL((conv2d_fwd_pipe_kernel<KS, MT, NWM, NWN, NJ, NCH, NSTAGE, PMAX, EPI, WS>), dim3((unsigned)grid), dim3(64 * NW), lds, st, pp);
     return AGF_OK;
 }
 
-template <int KS, int MT, int NWM, int NWN, int NJ, int NCH, int NSTAGE, int PMAX>
+template <int KS, int MT, int NWM, int NWN, int NJ, int NCH, int NSTAGE, int PMAX, bool WS = false>
 static int launch_pipe(const PipeParams& pp, int blocksPerCU, hipStream_t st) {
-    if (pp.c.res_pooled) return launch_pipe_e<KS, MT, NWM, NWN, NJ, NCH, NSTAGE, PMAX, 2>(pp, blocksPerCU, st);
-    if (pp.c.mask_y)     return launch_pipe_e<KS, MT, NWM, NWN, NJ, NCH, NSTAGE, PMAX, 1>(pp, blocksPerCU, st);
-    return launch_pipe_e<KS, MT, NWM, NWN, NJ, NCH, NSTAGE, PMAX, 0>(pp, blocksPerCU, st);
+    if (pp.c.res_pooled) return launch_pipe_e<KS, MT, NWM, NWN, NJ, NCH, NSTAGE, PMAX, 2, WS>(pp, blocksPerCU, st);
+    if (pp.c.mask_y)     return launch_pipe_e<KS, MT, NWM, NWN, NJ, NCH, NSTAGE, PMAX, 1, WS>(pp, blocksPerCU, st);
+    return launch_pipe_e<KS, MT, NWM, NWN, NJ, NCH, NSTAGE, PMAX, 0, WS>(pp, blocksPerCU, st);
 }
 
 static bool pipe_covers(int N, int H, int W, int Cin, int Cout) {
@@ -494,6 +538,25 @@ static int pipe_launch(const ConvParams& p0, int64_t wImgStride, hipStream_t st)
     pp.tilesHl2 = 0; while ((1 << pp.tilesHl2) < p.tilesH) pp.tilesHl2++;
     pp.band = (p.pixTiles + 7) / 8;
     pp.wImgStride = wImgStride;
+    static const int pipe_dbg = []{ const char* e = getenv("AGF_PIPE_DBG"); return e ? atoi(e) : 0; }();
+    pp.dbg = pipe_dbg;
+    static const int ws_on = []{ const char* e = getenv("AGF_PIPE_WS"); return e ? atoi(e) : 1; }();
+    if (ws_on && wImgStride == 0 && p.Cin <= 64) {       // shared weights that fit next to the activation ring: loaded once per block
+        if (p.Cout > 32) {
+            if (p.Cin == 32) return launch_pipe<3, 2, 1, 8, 2, 2, 5, 612, true>(pp, 1, st);
+            return launch_pipe<3, 2, 1, 8, 2, 4, 4, 612, true>(pp, 1, st);
+        }
+        if (p.Cin == 32) return launch_pipe<3, 1, 1, 8, 2, 2, 6, 612, true>(pp, 1, st);
+        return launch_pipe<3, 1, 1, 8, 2, 4, 5, 612, true>(pp, 1, st);
+    }
+    if (wImgStride == 0 && p.Cin <= 64) {                // (A/B: AGF_PIPE_WS=0)
+        if (p.Cout > 32) {
+            if (p.Cin == 32)  return launch_pipe<3, 2, 1, 8, 2, 2, 4, 612>(pp, 1, st);
+            return launch_pipe<3, 2, 1, 8, 2, 4, 4, 612>(pp, 1, st);
+        }
+        if (p.Cin == 32)  return launch_pipe<3, 1, 1, 8, 2, 2, 5, 612>(pp, 1, st);
+        return launch_pipe<3, 1, 1, 8, 2, 4, 5, 612>(pp, 1, st);
+    }
     if (p.Cout > 32) {
         if (p.Cin == 32)  return launch_pipe<3, 2, 1, 8, 2, 2, 4, 612>(pp, 1, st);
         if (p.Cin == 64)  return launch_pipe<3, 2, 1, 8, 2, 4, 4, 612>(pp, 1, st);

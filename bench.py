@@ -261,6 +261,14 @@ def main():
                                    'event_timed_steps': sampled_steps,
                                    'launches_with_fused_gradient_epilogue': fused_n,
                                    'achieved_plain_launches': round(plain_fl / (plain_ms * 1e-3) / 1e12, 2) if plain_ms > 0 else None}
+            if os.environ.get('AGF_BENCH_SHAPES') == '1':        # per-shape table of the sampled launches (diagnosis)
+                rows = []
+                for key, recs in timer.by_shape.items():
+                    ms = sum(a.elapsed_time(b) for a, b, _ in recs)
+                    fl = sum(f for _, _, f in recs)
+                    rows.append((ms, len(recs), fl / max(ms, 1e-9) / 1e9, key))
+                for ms, n, tf, key in sorted(rows, reverse=True)[:45]:
+                    print('%8.3f ms %3d launches %7.1f TFLOP/s  %s' % (ms, n, tf, key), file=sys.stderr)
             kw = summ.get('conv2d_wgrad_kernel')
             if kw:
                 out['roofline_wgrad'] = {'kernel': 'conv2d_wgrad_kernel', 'bound': 'mfma', 'achieved': round(kw['tflops'], 2),

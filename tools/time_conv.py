@@ -1,21 +1,23 @@
+"""Time one 3x3 forward / data-gradient conv launch: python tools/time_conv.py N Cin Cout H W [mask]"""
 import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from animeface_amd.implementations.StyleGAN2.conv import conv2d_fwd_raw
+from animeface_amd.implementations.StyleGAN2.conv import conv2d_fwd_raw, prep_weights_raw
 N, Cin, Cout, H, W = [int(v) for v in sys.argv[1:6]]
-KS = int(sys.argv[6]) if len(sys.argv) > 6 else 3
+mask = len(sys.argv) > 6 and sys.argv[6] == 'mask'
 x = torch.randn(N, Cin, H, W, device='cuda').to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-w = (torch.randn(Cout, Cin, KS, KS, device='cuda') / (Cin * KS * KS) ** 0.5).to(torch.bfloat16)
-sc = (torch.rand(N, Cin, device='cuda') + 0.5) if os.environ.get('SCALED') == '1' else None
-for _ in range(3):
-    conv2d_fwd_raw(x, w, in_scale=sc)
+w = torch.randn(Cout, Cin, 3, 3, device='cuda') / (Cin * 9) ** 0.5
+wq = prep_weights_raw(w, 1.0, torch.bfloat16)[0]
+my = torch.randn(N, Cout, H, W, device='cuda').to(torch.bfloat16).contiguous(memory_format=torch.channels_last) if mask else None
+ms_ = torch.zeros(256, Cout, device='cuda') if mask else None
+def run():
+    return conv2d_fwd_raw(x, wq, prepared=True, mask_y=my, mask_sum=ms_)
+for _ in range(3): run()
 torch.cuda.synchronize()
 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 s.record()
-for _ in range(20):
-    conv2d_fwd_raw(x, w, in_scale=sc)
+for _ in range(20): run()
 e.record(); torch.cuda.synchronize()
 ms = s.elapsed_time(e) / 20
-print(json.dumps(dict(variant=os.environ.get('AGF_CONV_VARIANT'), MT=os.environ.get('AGF_CONV_MT'), shape=[N, Cin, Cout, H, W], ms=round(ms, 4),
-                      TFLOPs=round(2.0 * N * H * W * Cin * Cout * KS * KS / ms / 1e9, 1),
-                      GBps=round(2.0 * N * H * W * (Cin + Cout) / ms / 1e6, 1))))
+gb = (N * H * W * (Cin + Cout * (2 if mask else 1)) * 2 + Cout * Cin * 18) / 1e9
+print(json.dumps(dict(shape=[N, Cin, Cout, H, W], mask=mask, dbg=os.environ.get('AGF_PIPE_DBG'), ms=round(ms, 4), TFLOPs=round(2.0 * N * H * W * Cin * Cout * 9 / ms / 1e9, 1), TBps=round(gb / ms, 2))))
