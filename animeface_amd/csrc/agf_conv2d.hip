@@ -1968,6 +1968,10 @@ static int conv2d_wgrad_impl(const void* x, const void* dy, float* dw,
                                                     (hipStream_t)stream);
         if (rc == AGF_OK) { AGF_LAUNCH_CHECK(); return AGF_OK; }
         if (rc != AGF_ENOKERNEL) return rc;
+        if (workspace) {                                  // overwriting mode, but this launch accumulates with atomics after all
+            hipError_t e = hipMemsetAsync(dw, 0, (size_t)Cout * ksize * ksize * Cin * sizeof(float), (hipStream_t)stream);
+            if (e != hipSuccess) { agf_set_error("conv2d_wgrad: memset failed: %s", hipGetErrorString(e)); return AGF_ELAUNCH; }
+        }
     }
 
     WgradParams p;

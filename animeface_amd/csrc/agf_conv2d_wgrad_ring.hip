@@ -43,9 +43,14 @@ static __device__ __forceinline__ bf16x8 ring_tr_frag(const bf16_t* base) {
 #define RING_XRMAX 208         // x rows of a tile incl. halo, rounded to 16: 6 x 34 = 204 -> 208 (TW = 32), 10 x 18 = 180 -> 192 (TW = 16)
 
 // NK = k-steps per wave and tile = 8 / (k subsets): 4 when the block has four 32 x 32 quadrants, 2 with two (Cin <= 32 or Cout <= 32), 1 with one.
-// DBG (timing experiments only, wrong results): 3 = no global loads, 4 = no epilogue (k-subset reduction + atomics), 5 = no atomics.
+// SC: per-image operand scales applied to the fragments in registers (a wave's lane holds ONE channel of each operand: one scalar per
+//     lane and tile, fetched a tile ahead) -- for the launches whose blocks cannot stay inside one image (small maps with many images),
+//     where the scales cannot ride on the partial sums; ~230 VALU operations per tile in the shadow of its 36 MFMAs.
 typedef uint32_t uint2_t __attribute__((ext_vector_type(2)));
-template <int NS, int NK, int DBG = 0>
+static __device__ __forceinline__ uint32_t ring_scale2(uint32_t v, float s) {
+    return Pack16<bf16_t>::pack(__uint_as_float(v << 16) * s, __uint_as_float(v & 0xffff0000u) * s);
+}
+template <int NS, int NK, bool SC = false>
 __global__ void __launch_bounds__(512, 2) conv2d_wgrad_ring_kernel(WgradRingParams p) {
     constexpr int TAPS = 9;
     constexpr int DYR = RING_DYR;
@@ -152,9 +157,19 @@ __global__ void __launch_bounds__(512, 2) conv2d_wgrad_ring_kernel(WgradRingPara
 
     int ptIssue = ptBegin, stIssue = 0;
 #pragma unroll
-    for (int s = 0; s < NS - 1 && DBG < 3; s++) {
+    for (int s = 0; s < NS - 1; s++) {
         issue_tile(ptIssue, ptIssue < ptEnd, stIssue);
         ptIssue += ptStep; stIssue = stIssue + 1 == NS ? 0 : stIssue + 1;
+    }
+    // SC: this lane's channel of the A operand (dy: co) and of the B operand (x: ci), and their scales for the first tile's image
+    const int lgImg = p.lgTilesW + p.lgTilesH;
+    const int chA = co0 + wa * 32 + (lane & 31), chB = ci0 + wb * 32 + (lane & 31);
+    float scA = 1.f, scB = 1.f;
+    const int chAc = chA < p.Cout ? chA : p.Cout - 1, chBc = chB < p.Cin ? chB : p.Cin - 1;     // (tail lanes hold zero fragments: any finite scale)
+    if (SC && ptBegin < ptEnd) {
+        const int n = ptBegin >> lgImg;
+        scA = p.out_scale[(int64_t)n * p.Cout + chAc];
+        scB = p.in_scale[(int64_t)n * p.Cin + chBc];
     }
     int cur = 0;
     for (int pt = ptBegin; pt < ptEnd; pt += ptStep) {
@@ -180,6 +195,19 @@ __global__ void __launch_bounds__(512, 2) conv2d_wgrad_ring_kernel(WgradRingPara
             rowE[j] = __builtin_bit_cast(uint2_t, e).x;
             if (j < NK) aF[j] = ring_tr_frag(aCur + j * p.TW * 32);
         }
+        if (SC) {
+#pragma unroll
+            for (int j = 0; j < NK + 2; j++) {
+                rowF[j].x = ring_scale2(rowF[j].x, scB); rowF[j].y = ring_scale2(rowF[j].y, scB);
+                rowF[j].z = ring_scale2(rowF[j].z, scB); rowF[j].w = ring_scale2(rowF[j].w, scB);
+                rowE[j] = ring_scale2(rowE[j], scB);
+                if (j < NK) {
+                    u32x4 a = __builtin_bit_cast(u32x4, aF[j]);
+                    a.x = ring_scale2(a.x, scA); a.y = ring_scale2(a.y, scA); a.z = ring_scale2(a.z, scA); a.w = ring_scale2(a.w, scA);
+                    aF[j] = __builtin_bit_cast(bf16x8, a);
+                }
+            }
+        }
 #pragma unroll
         for (int j = 0; j < NK; j++) {
 #pragma unroll
@@ -195,14 +223,24 @@ __global__ void __launch_bounds__(512, 2) conv2d_wgrad_ring_kernel(WgradRingPara
                 acc[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aF[j], __builtin_bit_cast(bf16x8, s2), acc[kh * 3 + 2], 0, 0, 0);
             }
             if (j == 0) {                                                 // the DMA of tile pt + (NS - 1) steps, into the stage tile pt - 1 occupied
-                if (DBG < 3) issue_tile(ptIssue, ptIssue < ptEnd, stIssue);
+                if (SC) {
+                    // the next tile's scales, requested BEFORE this iteration's DMA group: the partial wait at the top of the next
+                    // iteration (everything but the youngest LPW operations) then covers them
+                    // (inline asm: a compiler-visible load into a loop-carried register gets an `s_waitcnt vmcnt(0)` right behind it --
+                    //  a full drain of the ring.  The explicit wait at the top of the loop is what orders these two loads.)
+                    const int nn = (pt + ptStep < ptEnd ? pt + ptStep : pt) >> lgImg;
+                    const float* pa = p.out_scale + (int64_t)nn * p.Cout + chAc;
+                    const float* pb = p.in_scale + (int64_t)nn * p.Cin + chBc;
+                    asm volatile("global_load_dword %0, %1, off" : "=v"(scA) : "v"(pa) : "memory");
+                    asm volatile("global_load_dword %0, %1, off" : "=v"(scB) : "v"(pb) : "memory");
+                }
+                issue_tile(ptIssue, ptIssue < ptEnd, stIssue);
                 ptIssue += ptStep; stIssue = stIssue + 1 == NS ? 0 : stIssue + 1;
             }
         }
         cur = cur + 1 == NS ? 0 : cur + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the trailing (empty) loads still target LDS
-    if (DBG == 4) { if (acc[0][0] + acc[4][3] + acc[8][15] == 123.456f) p.dw[tid] = 1.f; return; }
     // k-step subsets hold partial sums of the same quadrants: add them through LDS, then one wave per quadrant issues the atomics
     {
         float* sRed = (float*)smem_raw;
@@ -223,7 +261,6 @@ __global__ void __launch_bounds__(512, 2) conv2d_wgrad_ring_kernel(WgradRingPara
         }
     }
     if (kidx != 0) return;
-    if (DBG == 5) { if (acc[0][0] + acc[4][3] + acc[8][15] == 123.456f) p.dw[tid] = 1.f; return; }
     const int ci = ci0 + wb * 32 + (lane & 31);
     if (ci >= p.Cin) return;
     float si = p.scale;
@@ -273,7 +310,7 @@ __global__ void __launch_bounds__(256) conv2d_wgrad_reduce_kernel(const float* _
 static int ring_pow2_floor_log2(int v) { int s = 0; while ((2 << s) <= v) s++; return s; }
 
 // Tile geometry, split and scale mode of a launch; false: shape not covered (the caller falls through to conv2d_wgrad_kernel)
-static bool ring_plan(WgradRingParams& p, bool scales, int N, int H, int W, int Cin, int Cout) {
+static bool ring_plan(WgradRingParams& p, bool scales, bool both, int N, int H, int W, int Cin, int Cout) {
     static const int on = []{ const char* e = getenv("AGF_WGRAD_RING"); return e ? atoi(e) : 1; }();
     if (!on) return false;
     p.TW = W >= 32 ? 32 : 16;
@@ -299,8 +336,11 @@ static bool ring_plan(WgradRingParams& p, bool scales, int N, int H, int W, int 
         int m = (want + N - 1) / N;
         if (m > tpi / 8) m = tpi / 8;
         if (m < 1) m = 1;
-        if ((N * m > want + want / 2 && tpi / m < 24) || tpi < 8) return false;
-        p.epiScale = 1; p.perImage = m; p.splitK = N * m;
+        static const int sc_on = []{ const char* e = getenv("AGF_WGRAD_RING_SC"); return e ? atoi(e) : 1; }();
+        if ((N * m > want + want / 2 && tpi / m < 24) || tpi < 8) {
+            if (!sc_on || !both) return false;
+            p.epiScale = 0;                                  // blocks span images: scales on the operands (SC kernel), split as without scales
+        } else { p.epiScale = 1; p.perImage = m; p.splitK = N * m; }
     }
     p.dwNumel = (int64_t)Cout * 9 * Cin;
     const int XR = ((p.TH + 2) * (p.TW + 2) + 15) & ~15;
@@ -311,7 +351,7 @@ static bool ring_plan(WgradRingParams& p, bool scales, int N, int H, int W, int 
 int64_t agf_conv2d_wgrad_ring_workspace(bool scales, int N, int H, int W, int Cin, int Cout) {
     static const int two = []{ const char* e = getenv("AGF_WGRAD_TWOSTAGE"); return e ? atoi(e) : 1; }();
     WgradRingParams p;
-    if (!two || !ring_plan(p, scales, N, H, W, Cin, Cout) || p.splitK < 2) return 0;
+    if (!two || !ring_plan(p, scales, scales, N, H, W, Cin, Cout) || p.splitK < 2) return 0;
     return (int64_t)p.splitK * p.dwNumel * 4;
 }
 
@@ -321,20 +361,20 @@ int64_t agf_conv2d_wgrad_ring_workspace(bool scales, int N, int H, int W, int Ci
 int agf_conv2d_wgrad_ring_launch(const void* x, const void* dy, float* dw, const float* in_scale, const float* out_scale,
                                  int N, int H, int W, int Cin, int Cout, float scale, float* workspace, int64_t workspaceBytes, hipStream_t st) {
     WgradRingParams p;
-    if (!ring_plan(p, in_scale || out_scale, N, H, W, Cin, Cout)) return AGF_ENOKERNEL;
+    if (!ring_plan(p, in_scale || out_scale, in_scale && out_scale, N, H, W, Cin, Cout)) return AGF_ENOKERNEL;
     p.x = (const bf16_t*)x; p.dy = (const bf16_t*)dy; p.dw = dw; p.in_scale = in_scale; p.out_scale = out_scale; p.scale = scale;
     p.part = (workspace && p.splitK >= 2 && workspaceBytes >= (int64_t)p.splitK * p.dwNumel * 4) ? workspace : nullptr;
     const int base = p.tilesCo * p.tilesCi;
     constexpr int NS = 3;
     const int XR = ((p.TH + 2) * (p.TW + 2) + 15) & ~15;
     const size_t lds = (size_t)NS * (2 * RING_DYR + 2 * XR) * 32 * sizeof(bf16_t) + 1024;
-    static const int dbg = []{ const char* e = getenv("AGF_WGRAD_RING_DBG"); return e ? atoi(e) : 0; }();
     const int realQ = (Cout > 32 ? 2 : 1) * (Cin > 32 ? 2 : 1);
-    void (*kern)(WgradRingParams) = realQ == 4 ? (dbg == 3 ? conv2d_wgrad_ring_kernel<NS, 4, 3> : dbg == 4 ? conv2d_wgrad_ring_kernel<NS, 4, 4> : dbg == 5 ? conv2d_wgrad_ring_kernel<NS, 4, 5> : conv2d_wgrad_ring_kernel<NS, 4, 0>)
-                                  : realQ == 2 ? (dbg == 3 ? conv2d_wgrad_ring_kernel<NS, 2, 3> : conv2d_wgrad_ring_kernel<NS, 2, 0>)
-                                               : (dbg == 3 ? conv2d_wgrad_ring_kernel<NS, 1, 3> : conv2d_wgrad_ring_kernel<NS, 1, 0>);
-    static bool attr[3] = {false, false, false};
-    const int slot = realQ == 4 ? 0 : realQ == 2 ? 1 : 2;
+    const bool sc = (in_scale || out_scale) && !p.epiScale;
+    void (*kern)(WgradRingParams) = realQ == 4 ? (sc ? conv2d_wgrad_ring_kernel<NS, 4, true> : conv2d_wgrad_ring_kernel<NS, 4, false>)
+                                  : realQ == 2 ? (sc ? conv2d_wgrad_ring_kernel<NS, 2, true> : conv2d_wgrad_ring_kernel<NS, 2, false>)
+                                               : (sc ? conv2d_wgrad_ring_kernel<NS, 1, true> : conv2d_wgrad_ring_kernel<NS, 1, false>);
+    static bool attr[6] = {false, false, false, false, false, false};
+    const int slot = (realQ == 4 ? 0 : realQ == 2 ? 1 : 2) + (sc ? 3 : 0);
     if (!attr[slot]) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) { agf_set_error("conv2d_wgrad ring: cannot reserve LDS: %s", hipGetErrorString(e)); return AGF_ELAUNCH; }

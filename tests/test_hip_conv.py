@@ -165,6 +165,8 @@ WGRAD_CASES = [
     (2, 128, 72, 16, 16, 3, 'ring: 8x16 tiles, output-channel tail'),
     (5, 64, 32, 128, 128, 3, 'ring: odd batch, blocks inside one image when scaled'),
     (2, 40, 136, 32, 64, 3, 'ring: channel tails on both sides'),
+    (24, 256, 128, 32, 32, 3, 'ring: scales on the operands (blocks span images)'),
+    (40, 128, 64, 16, 16, 3, 'ring: scales on the operands, 8x16 tiles'),
 ]
 
 
