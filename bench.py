@@ -153,7 +153,8 @@ def main():
         step(real)
     # per-launch HIP events on the MFMA kernels for the roofline numbers.  A graph replay has no host-side launch points to bracket, so a
     # sampled step runs eagerly -- ~48 ms instead of ~40 (it is bound by the host issuing ~2 100 launches and ~800 event records).  They
-    # are therefore recorded on the FIRST timed step and on the lazy-R1 step(s) only; the launches of the other steps are identical.
+    # are therefore recorded on the FIRST timed step only (the launches of the other GAN-loss steps are identical); the launches of a
+    # lazy-R1 iteration are sampled on the first of the R1 iterations that follow the timed window (`roofline.r1_iteration`).
     # (Round 1 sampled every 4th step: with graph replay in between that cost 3-5 ms per step of the headline number.)
     timer = None if args.no_kernel_timer else C.KernelTimer()
     first_timed = step.batches_done
@@ -163,7 +164,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         it = first_timed + i
-        sample = timer is not None and (i == 0 or (it % 16 == 0 and it != 0))
+        sample = timer is not None and i == 0
         C.KernelTimer.active = timer if sample else None
         sampled_steps += int(sample)
         (eager_step if sample else step)(real)
@@ -184,13 +185,16 @@ def main():
     # the worst case "G+D+R1 step" literally names: the R1 penalty on EVERY iteration; a few extra steps after the
     # timed window, forced onto the lazy-R1 branch, rank-local timing is enough for this side figure
     step = eager_step if not use_graphs else step
-    r1_ms = None
+    r1_ms, timer_r1 = None, None
     if not args.no_r1_every_step:
         step = eager_step
         saved = step.batches_done
         n_r1 = 4
         step.batches_done = 16
+        timer_r1 = None if timer is None else C.KernelTimer()
+        C.KernelTimer.active = timer_r1
         step(real)
+        C.KernelTimer.active = None
         barrier()
         t1 = time.perf_counter()
         for _ in range(n_r1):
@@ -259,6 +263,9 @@ def main():
                                    'launches': k['launches'], 'avg_launch_ms': round(k['avg_ms'], 4),
                                    'share_of_step_time': round(k['total_ms'] / (dt * 1e3 * sampled_steps / args.steps), 4),
                                    'event_timed_steps': sampled_steps,
+                                   'r1_iteration': (lambda q: None if not q else {'achieved': round(q['tflops'], 2), 'launches': q['launches'],
+                                                                                    'note': 'conv launches of one lazy-R1 iteration (double backward), sampled after the timed window'})(
+                                       timer_r1.summary().get('conv2d_fwd_kernel') if timer_r1 is not None else None),
                                    'launches_with_fused_gradient_epilogue': fused_n,
                                    'achieved_plain_launches': round(plain_fl / (plain_ms * 1e-3) / 1e12, 2) if plain_ms > 0 else None}
             if os.environ.get('AGF_BENCH_SHAPES') == '1':        # per-shape table of the sampled launches (diagnosis)
