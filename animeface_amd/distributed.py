@@ -147,6 +147,35 @@ class GradReducer:
                     if id(p) not in self._touched:
                         p.grad = None
 
+    def exchange_all(self):
+        """Graph-replayed training (``GraphedTrainStep`` with reducers): the backward pass ran inside a HIP graph, where no hook fires, so
+        every bucket is all-reduced here, between two graph launches, and waited for.  Which parameters received a gradient is a static
+        property of the captured iteration kind (``detach_untouched`` ran when it was captured)."""
+        ev0 = ev1 = None
+        if self.measure and self.buckets and self.buckets[0]['flat'].is_cuda:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        for b in self.buckets:
+            b['launched'] = False
+            self._launch(b)
+        for b in self.buckets:
+            if b['work'] is not None:
+                b['work'].wait()
+                b['work'] = None
+        if ev0 is not None:
+            ev1.record()
+            self._pending_events = getattr(self, '_pending_events', []) + [(ev0, ev1)]
+        self.stats['steps'] += 1
+        self.stats['buckets_at_finish'] += len(self.buckets)
+
+    def detach_untouched(self):
+        """``grad = None`` for the parameters whose hook did not fire since ``zero_grad()`` (second half of ``finish()``)."""
+        if self.enabled:
+            for b in self.buckets:
+                for p in b['params']:
+                    if id(p) not in self._touched:
+                        p.grad = None
+
     def overlap_report(self):
         """Counters for bench.py: how many buckets were launched from backward hooks (overlappable) vs. only at ``finish()``, and the time
         the compute stream spent waiting for the exchange in ``finish()`` (the exposed, non-overlapped part)."""

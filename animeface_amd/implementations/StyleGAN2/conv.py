@@ -500,7 +500,12 @@ class PrepPlan:
         rc = _lib.lib().agf_prep_weights_multi(_lib.ptr(self.table), len(self.entries), self.blocks, self.kmax, _lib._DTYPES[self.dtype],
                                                _lib.stream_ptr(w0))
         _lib.check(rc, 'prep_weights_multi')
-        if _prep_cache_on:
+        self.install()
+
+    def install(self):
+        """Put the (already refreshed) buffers into the prepared-weight cache of the enclosing ``cached_weights()`` scope, no launch."""
+        import weakref
+        if self.entries and _prep_cache_on:
             for w, coef, wq, wft in self.entries:
                 ent = _Prepared()
                 ent.ref, ent.coef, ent.wq, ent.wq_ft = weakref.ref(w), coef, wq, wft

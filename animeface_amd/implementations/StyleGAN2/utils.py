@@ -143,6 +143,39 @@ class TrainStep:
         self.batches_done += 1
         return D_loss.detach(), G_loss.detach(), fake
 
+    # ---- the same iteration cut at the two gradient exchanges (GraphedTrainStep under data parallelism: one HIP graph per segment, the
+    #      all-reduce of the bucket buffers issued between two graph launches) ----
+    def _seg1(self, real, it):
+        self._zero(self.optimizer_G, self.reducer_G)
+        self._zero(self.optimizer_D, self.reducer_D)
+        with cached_weights(), recording_plans(self._plan_G, self._plan_D):
+            if self._plan_G is not None:
+                self._plan_G.run()
+                self._plan_D.run()
+            with zero_arena(self._arena_D, real.device):
+                D_loss = self._d_half(real, it)
+        return D_loss.detach()
+
+    def _seg2(self, real, it):
+        D = self.D
+        self.optimizer_D.step()
+        with cached_weights(), recording_plans(self._plan_G, self._plan_D):
+            if self._plan_G is not None:
+                self._plan_G.install()              # refreshed in segment 1, unchanged since
+                self._plan_D.run()
+            for p in D.parameters():
+                p.requires_grad_(False)
+            with zero_arena(self._arena_G, real.device):
+                G_loss, fake = self._g_half(real, it)
+            for p in D.parameters():
+                p.requires_grad_(True)
+        return G_loss.detach(), fake
+
+    def _seg3(self):
+        self.optimizer_G.step()
+        if self.G_ema is not None:
+            update_ema(self.G, self.G_ema)
+
     def _d_half(self, real, it):
         G, D = self.G, self.D
         z = self.sampler((real.size(0), self.latent_dim))
@@ -206,16 +239,24 @@ class GraphedTrainStep:
     their backward passes, both fused Adam steps, EMA -- is captured once per iteration kind (GAN-loss iteration, lazy-R1 iteration) with
     ``torch.cuda.graph`` and replayed with ONE host call per iteration, so the ~1 400 launches of an iteration no longer cost host time
     (the 128x128 / batch-32 configuration is launch-bound in eager mode).  The kernels, their order and their arithmetic are those of the
-    eager step; random draws come from torch's graph-safe generator state.  Needs: one process (no gradient exchange inside a graph),
+    eager step; random draws come from torch's graph-safe generator state.  Needs (a gradient exchange never sits inside a graph: with
+    reducers the iteration becomes three graphs, see ``__init__``):
     no path-length penalty (its running mean lives on the host), a DiffAugment policy (the ADA pipe synchronises with the host), capturable
     optimizers (``build_optimizers(..., capturable=True)``), and input batches of one fixed shape."""
 
     def __init__(self, step, real, warmup=3):
-        if step.reducer_G is not None or step.reducer_D is not None:
-            raise RuntimeError('graph capture covers the single-process step only')
+        if (step.reducer_G is None) != (step.reducer_D is None):
+            raise RuntimeError('graph capture: both networks or neither must have a gradient reducer')
         if step.pl_lambda > 0 or step.policy == 'ada':
             raise RuntimeError('graph capture needs pl_lambda == 0 and a DiffAugment policy')
         self.step, self.graphs = step, {}
+        # Data parallel: no collective inside a graph.  The iteration is captured as THREE graphs cut at the two gradient exchanges; the
+        # bucket buffers are all-reduced between the launches (``GradReducer.exchange_all``).  The overlap of the exchange with the
+        # backward pass is given up (~1 ms per network over xGMI) for the ~6 ms of host / launch time a replayed iteration saves.
+        self.segmented = step.reducer_G is not None
+        if self.segmented:
+            step.reducer_G.early = step.reducer_D.early = False
+            self.pool = torch.cuda.graph_pool_handle()
         self.static_real = real.clone()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -232,19 +273,61 @@ class GraphedTrainStep:
         st = self.step
         return 'r1' if (it % st.d_k == 0 and st.r1_lambda > 0 and it != 0) else 'gan'
 
+    def _capture_segments(self, it):
+        """Record the three segments of one iteration kind.  Nothing executes here; the hooks of the reducers fire while the backward
+        passes are recorded, which tells which parameters this kind of iteration gives a gradient (the others get ``grad = None`` before
+        the optimizer step is recorded, as ``GradReducer.finish()`` does in the eager loop)."""
+        st = self.step
+        g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1, pool=self.pool):
+            d_loss = st._seg1(self.static_real, it)
+        st.reducer_D.detach_untouched()
+        with torch.cuda.graph(g2, pool=self.pool):
+            g_loss, fake = st._seg2(self.static_real, it)
+        st.reducer_G.detach_untouched()
+        with torch.cuda.graph(g3, pool=self.pool):
+            st._seg3()
+        return (g1, g2, g3), (d_loss, g_loss, fake)
+
+    def _capture(self, it):
+        st = self.step
+        kind = self._kind(it)
+        if kind in self.graphs:
+            return
+        saved = st.batches_done
+        if self.segmented:
+            self.graphs[kind] = self._capture_segments(it)
+        else:
+            st.batches_done = it
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):                  # records; the Python body runs once and leaves batches_done advanced
+                out = st(self.static_real)
+            self.graphs[kind] = (graph, out)
+        st.batches_done = saved
+
+    def capture_all(self):
+        """Record both iteration kinds now (nothing executes, no collective is issued): lets a multi-process caller agree on success
+        before the first replay."""
+        st = self.step
+        self._capture(1)
+        if st.r1_lambda > 0:
+            self._capture(st.d_k)
+
     def __call__(self, real):
         st = self.step
         it = st.batches_done
         kind = self._kind(it)
         self.static_real.copy_(real)
-        if kind not in self.graphs:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):                  # records; the Python body runs once and leaves batches_done advanced
-                out = st(self.static_real)
-            st.batches_done = it
-            self.graphs[kind] = (graph, out)
+        self._capture(it)
         graph, out = self.graphs[kind]
-        graph.replay()
+        if self.segmented:
+            graph[0].replay()
+            st.reducer_D.exchange_all()
+            graph[1].replay()
+            st.reducer_G.exchange_all()
+            graph[2].replay()
+        else:
+            graph.replay()
         st.batches_done = it + 1
         return out
 
@@ -361,7 +444,7 @@ def main(parser, dataset=None):
     const_z = sample_nnoise((16, args.style_dim), device=device)
     G, G_ema, D = build_models(args, device, compute_dtype)
     dp.broadcast_module(G), dp.broadcast_module(G_ema), dp.broadcast_module(D)
-    graphs = bool(args.hip_graphs) and world == 1 and args.pl_lambda == 0 and args.policy != 'ada'
+    graphs = bool(args.hip_graphs) and args.pl_lambda == 0 and args.policy != 'ada'      # (several ranks: three graphs per iteration)
     optimizer_G, optimizer_D = build_optimizers(G, D, args.lr, (args.beta1, args.beta2), args.r1_lambda, args.pl_lambda, args.d_k, args.g_k,
                                                 capturable=graphs)
     reducer_G = dp.GradReducer(G.parameters(), never_used=dp.never_used_parameters(G)) if world > 1 else None

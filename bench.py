@@ -107,7 +107,10 @@ def main():
     G_ema.eval()
     update_ema(G, G_ema, decay=0)
     dp.broadcast_module(G), dp.broadcast_module(G_ema), dp.broadcast_module(D)
-    use_graphs = (not args.eager) and world == 1 and args.augment != 'ada'
+    use_graphs = (not args.eager) and args.augment != 'ada' and (world == 1 or os.environ.get('AGF_DP_GRAPHS', '0') == '1')
+    # (several ranks: AGF_DP_GRAPHS=1 replays three graphs per iteration with the gradient all-reduce between the launches -- tested with two
+    #  ranks on one GPU over gloo (tests/test_hip_dp.py), never yet on RCCL hardware, hence opt-in; the default there is the eager loop whose
+    #  all-reduce overlaps the backward pass)
     opt_G, opt_D = U.build_optimizers(G, D, 0.001, (0., 0.99), 10., 0., 16, 8, capturable=use_graphs)
     red_G = dp.GradReducer(G.parameters(), never_used=dp.never_used_parameters(G)) if world > 1 else None
     red_D = dp.GradReducer(D.parameters()) if world > 1 else None
@@ -143,11 +146,25 @@ def main():
 
     eager_step = step
     if use_graphs:
-        # capture both iteration kinds before anything is timed (a capture records, it does not execute), then restore the counter
-        step = U.GraphedTrainStep(eager_step, real, warmup=1)
-        for it0 in (1, 16):
-            eager_step.batches_done = it0
-            step(real)
+        # capture both iteration kinds before anything is timed (a capture records, it does not execute).  With several ranks the
+        # iteration is three graphs cut at the two gradient exchanges; every rank must have captured before any rank replays (the
+        # replay issues collectives), so success is agreed on first and the eager loop is the fallback.
+        ok = 1
+        try:
+            step = U.GraphedTrainStep(eager_step, real, warmup=1)
+            step.capture_all()
+        except Exception as exc:                   # noqa: BLE001 -- any capture failure means: run eagerly
+            print(f'[bench] rank {rank}: graph capture failed ({type(exc).__name__}: {exc}); eager launches', file=sys.stderr)
+            ok = 0
+        if world > 1:
+            flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag.item())
+        if not ok:
+            use_graphs, step = False, eager_step
+            for red in (red_G, red_D):
+                if red is not None:
+                    red.early = os.environ.get('AGF_DP_EARLY', '1') != '0'
         eager_step.batches_done = 0
     for _ in range(args.warmup):
         step(real)
@@ -212,7 +229,7 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'bf16', 'data': 'synthetic', 'execution': 'hip-graph replay (eager on the event-timed steps)' if use_graphs else 'eager launches',
+            'dtype': 'bf16', 'data': 'synthetic', 'execution': ('hip-graph replay (eager on the event-timed steps)' + (': three graphs per iteration, gradient all-reduce between the launches' if world > 1 else '')) if use_graphs else 'eager launches',
             'config': {'workload': f'StyleGAN2 {S}x{S} G+D+lazy-R1 training step, batch {args.batch}/GPU '
                                    f'(BASELINE.json configs[2]: channels 32, max 512, style 512, d_k 16, r1_lambda 10, '
                                    + ('ADA pipe (12 augmentations, adaptive p)' if args.augment == 'ada' else f'DiffAugment {args.augment} = the reference SG2 default; --augment ada selects the ADA pipe') + ', Adam, EMA)',

@@ -193,3 +193,74 @@ def test_two_ranks_on_one_gpu_match_the_accumulated_single_process_run(tmp_path,
           + (f'; {n_far} of {n_all} weights differ by more than 0.1 lr' if n_all else ''))
     if n_all:
         assert n_far <= 0.2 * n_all, (n_far, n_all)
+
+
+def _worker_graphs(rank, world, port, out, graphed):
+    """Two ranks on GPU 0; fp32; the device generator drives every draw (graph-safe).  ``graphed``: iterations 2.. replayed from three
+    HIP graphs per iteration kind with the bucket all-reduce between the launches; else the eager loop with ``GradReducer.finish()``."""
+    import sys
+    import functools
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      AGF_SINGLE_DEVICE='1', AGF_DIST_BACKEND='gloo')
+    from animeface_amd import distributed as dp
+    from animeface_amd.implementations.StyleGAN2 import model as M, utils as U
+    from animeface_amd.nnutils import sample_nnoise, update_ema
+    dp.init_distributed()
+    dev = torch.device('cuda', 0)
+    torch.manual_seed(0)
+    mk = lambda: M.Generator(CFG['image_size'], 3, CFG['style_dim'], CFG['channels'], CFG['max_channels'], 2, CFG['map_num_layers'], True, 0.01,
+                             compute_dtype=torch.float32)
+    G, G_ema = mk().to(dev), mk().to(dev)
+    D = M.Discriminator(CFG['image_size'], 3, CFG['channels'], CFG['max_channels'], 2, 4, compute_dtype=torch.float32).to(dev)
+    G.init_weight(functools.partial(M.init_weight_N01, lr=0.01), M.init_weight_N01)
+    D.apply(M.init_weight_N01)
+    G_ema.eval()
+    update_ema(G, G_ema, decay=0)
+    dp.broadcast_module(G), dp.broadcast_module(G_ema), dp.broadcast_module(D)
+    opt_G, opt_D = U.build_optimizers(G, D, 0.001, (0., 0.99), 10., 0., D_K, 8, capturable=True)
+    red_G = dp.GradReducer(G.parameters(), bucket_bytes=1 << 18, never_used=dp.never_used_parameters(G))
+    red_D = dp.GradReducer(D.parameters(), bucket_bytes=1 << 18)
+    step = U.TrainStep(G, G_ema, D, opt_G, opt_D, 10., 0., D_K, 8, 'color,translation', CFG['style_dim'],
+                       functools.partial(sample_nnoise, device=dev), red_G, red_D)
+    real = _shard(rank, dev)
+    torch.manual_seed(1000 + rank)
+    for _ in range(2):
+        step(real)
+    runner = U.GraphedTrainStep(step, real, warmup=0) if graphed else step
+    losses = []
+    for _ in range(4):                                     # d_k = 2: both iteration kinds, each captured once and replayed once
+        dl, gl, _ = runner(real)
+        losses.append((float(dl), float(gl)))
+    torch.cuda.synchronize()
+    if graphed:
+        assert runner.segmented and set(runner.graphs) == {'gan', 'r1'}
+    for m in (G, G_ema, D):
+        dp.check_replica_consistency(m)
+    scale = dp.never_used_parameters(G)[0]
+    assert not opt_G.state.get(scale), 'Adam stepped a parameter that never received a gradient'
+    torch.save(dict(G={k: v.cpu() for k, v in G.state_dict().items()}, D={k: v.cpu() for k, v in D.state_dict().items()},
+                    G_ema={k: v.cpu() for k, v in G_ema.state_dict().items()}, losses=losses), f'{out}.{int(graphed)}.{rank}')
+    dp.dist.barrier()
+    dp.dist.destroy_process_group()
+
+
+def test_graph_replay_under_data_parallelism_equals_the_eager_exchange(tmp_path):
+    """GraphedTrainStep with reducers: three graphs per iteration kind, all-reduce of the bucket buffers between the launches -- against
+    the eager two-rank loop from the same seeds (fp32: weights to summation noise)."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / 'dpg')
+    for graphed in (False, True):
+        mp.start_processes(_worker_graphs, args=(2, _free_port(), out, graphed), nprocs=2, join=True, start_method='spawn')
+    eager, graph = torch.load(f'{out}.0.0'), torch.load(f'{out}.1.0')
+    print('losses eager :', eager['losses'])
+    print('losses graphs:', graph['losses'])
+    for (d0, g0), (d1, g1) in zip(eager['losses'], graph['losses']):
+        assert abs(d0 - d1) <= 1e-4 * max(1.0, abs(d0)) and abs(g0 - g1) <= 1e-4 * max(1.0, abs(g0))
+    worst = 0.0
+    for name in ('G', 'D', 'G_ema'):
+        for k in eager[name]:
+            d = float((eager[name][k].float() - graph[name][k].float()).abs().max())
+            worst = max(worst, d)
+            assert d <= 1e-4, (name, k, d)          # six Adam steps of lr 1e-3; a flipped update would show as ~1e-3
+    print(f'largest weight difference graph-replayed vs eager two-rank run: {worst:.3g}')
