@@ -80,7 +80,7 @@ def lib():
         L.agf_conv2d_wgrad.restype = ctypes.c_int
         L.agf_conv2d_wgrad.argtypes = [_vp, _vp, _vp, _vp, _vp, ctypes.c_int] + [ctypes.c_int32] * 6 + [ctypes.c_float, _vp]
         L.agf_conv2d_wgrad_ws.restype = ctypes.c_int
-        L.agf_conv2d_wgrad_ws.argtypes = [_vp, _vp, _vp, _vp, _vp, ctypes.c_int] + [ctypes.c_int32] * 6 + [ctypes.c_float, _vp, ctypes.c_int64, _vp]
+        L.agf_conv2d_wgrad_ws.argtypes = [_vp, _vp, _vp, _vp, _vp, ctypes.c_int] + [ctypes.c_int32] * 6 + [ctypes.c_float, _vp, ctypes.c_int64, _vp, _vp]
         L.agf_conv2d_wgrad_workspace_bytes.restype = ctypes.c_int64
         L.agf_conv2d_wgrad_workspace_bytes.argtypes = [ctypes.c_int] + [ctypes.c_int32] * 6 + [ctypes.c_int]
         L.agf_act_bwd_reduce.restype = ctypes.c_int

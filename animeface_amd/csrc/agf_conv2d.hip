@@ -1938,7 +1938,7 @@ static int launch_wgrad(const WgradParams& p, size_t lds, hipStream_t st) {
 static int conv2d_wgrad_impl(const void* x, const void* dy, float* dw,
                              const float* in_scale, const float* out_scale,
                              int dtype, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
-                             float scale, void* workspace, int64_t workspace_bytes, void* stream) {
+                             float scale, void* workspace, int64_t workspace_bytes, void* stream, int32_t* dw_layout_out = nullptr) {
     AGF_CHECK(x && dy && dw, "conv2d_wgrad: null pointer");
     AGF_CHECK(N >= 1 && H >= 1 && W >= 1 && Cin >= 1 && Cout >= 1, "conv2d_wgrad: empty tensor");
     AGF_CHECK(ksize == 1 || ksize == 3, "conv2d_wgrad: kernel size must be 1 or 3 (got %d)", ksize);
@@ -1965,8 +1965,8 @@ static int conv2d_wgrad_impl(const void* x, const void* dy, float* dw,
     AGF_CHECK(((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0 && ((uintptr_t)dw % 4) == 0, "conv2d_wgrad: misaligned pointer");
     if (ksize == 3) {
         const int rc = agf_conv2d_wgrad_ring_launch(x, dy, dw, in_scale, out_scale, N, H, W, Cin, Cout, scale, (float*)workspace, workspace_bytes,
-                                                    (hipStream_t)stream);
-        if (rc == AGF_OK) { AGF_LAUNCH_CHECK(); return AGF_OK; }
+                                                    (workspace && dw_layout_out) ? 1 : 0, (hipStream_t)stream);
+        if (rc == AGF_OK) { if (workspace && dw_layout_out) *dw_layout_out = 1; AGF_LAUNCH_CHECK(); return AGF_OK; }
         if (rc != AGF_ENOKERNEL) return rc;
         if (workspace) {                                  // overwriting mode, but this launch accumulates with atomics after all
             hipError_t e = hipMemsetAsync(dw, 0, (size_t)Cout * ksize * ksize * Cin * sizeof(float), (hipStream_t)stream);
@@ -2059,10 +2059,11 @@ extern "C" int64_t agf_conv2d_wgrad_workspace_bytes(int dtype, int32_t N, int32_
 extern "C" int agf_conv2d_wgrad_ws(const void* x, const void* dy, float* dw,
                                    const float* in_scale, const float* out_scale,
                                    int dtype, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
-                                   float scale, void* workspace, int64_t workspace_bytes, void* stream) {
+                                   float scale, void* workspace, int64_t workspace_bytes, int32_t* dw_layout_out, void* stream) {
+    if (dw_layout_out) *dw_layout_out = 0;
     AGF_CHECK(workspace_bytes >= 0 && (workspace || workspace_bytes == 0), "conv2d_wgrad_ws: bad workspace");
     const int64_t need = agf_conv2d_wgrad_workspace_bytes(dtype, N, H, W, Cin, Cout, ksize, (in_scale || out_scale) ? 1 : 0);
     if (need > 0 && workspace && workspace_bytes >= need)
-        return conv2d_wgrad_impl(x, dy, dw, in_scale, out_scale, dtype, N, H, W, Cin, Cout, ksize, scale, workspace, workspace_bytes, stream);
+        return conv2d_wgrad_impl(x, dy, dw, in_scale, out_scale, dtype, N, H, W, Cin, Cout, ksize, scale, workspace, workspace_bytes, stream, dw_layout_out);
     return conv2d_wgrad_impl(x, dy, dw, in_scale, out_scale, dtype, N, H, W, Cin, Cout, ksize, scale, nullptr, -1, stream);
 }

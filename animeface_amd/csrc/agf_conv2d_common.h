@@ -63,5 +63,5 @@ int agf_conv2d_pipe_launch(const ConvParams& p, hipStream_t st);
 // multi-stage ring variant of the 3x3 weight gradient (agf_conv2d_wgrad_ring.hip); AGF_ENOKERNEL = shape not covered.
 // workspace (optional): scratch of agf_conv2d_wgrad_ring_workspace() bytes -> two-stage combine, dw is overwritten instead of accumulated into
 int agf_conv2d_wgrad_ring_launch(const void* x, const void* dy, float* dw, const float* in_scale, const float* out_scale,
-                                 int N, int H, int W, int Cin, int Cout, float scale, float* workspace, int64_t workspaceBytes, hipStream_t st);
+                                 int N, int H, int W, int Cin, int Cout, float scale, float* workspace, int64_t workspaceBytes, int oihw, hipStream_t st);
 int64_t agf_conv2d_wgrad_ring_workspace(bool scales, int N, int H, int W, int Cin, int Cout);

@@ -283,7 +283,10 @@ __global__ void __launch_bounds__(512, 2) conv2d_wgrad_ring_kernel(WgradRingPara
 }
 
 // second stage of the two-stage combine: dw[i] = sum_ks part[ks][i].  256 threads = 64 float4 lanes x 4 interleaved subsets of ks.
-__global__ void __launch_bounds__(256) conv2d_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int64_t numel, int splitK) {
+// oihwCin > 0: dw is written in the parameter's own [Cout][Cin][3][3] order (the partial sums are [Cout][3][3][Cin]), so that autograd can
+// hand the tensor to the optimizer without a layout copy.
+__global__ void __launch_bounds__(256) conv2d_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int64_t numel, int splitK,
+                                                                  int oihwCin) {
     __shared__ f32x4 red[3][64];
     const int l = threadIdx.x & 63, kp = threadIdx.x >> 6;
     const int64_t i4 = (int64_t)blockIdx.x * 64 + l;
@@ -303,7 +306,14 @@ __global__ void __launch_bounds__(256) conv2d_wgrad_reduce_kernel(const float* _
     __syncthreads();
     if (kp == 0 && live) {
         a += red[0][l]; a += red[1][l]; a += red[2][l];
-        *(f32x4*)(dw + i4 * 4) = a;
+        if (oihwCin > 0) {
+            const int64_t i = i4 * 4;                            // = (co * 9 + t) * Cin + ci, four consecutive ci
+            const int ci = (int)(i % oihwCin);
+            const int64_t r = i / oihwCin;
+            const int t = (int)(r % 9);
+            float* dst = dw + ((r / 9) * oihwCin + ci) * 9 + t;
+            dst[0] = a.x; dst[9] = a.y; dst[18] = a.z; dst[27] = a.w;
+        } else *(f32x4*)(dw + i4 * 4) = a;
     }
 }
 
@@ -359,7 +369,7 @@ int64_t agf_conv2d_wgrad_ring_workspace(bool scales, int N, int H, int W, int Ci
 // there with plain stores and a second launch adds them into dw (which is then OVERWRITTEN, no zero-initialisation needed): the fp32
 // atomics of the one-stage combine ran at 0.5 TB/s -- 76 us of a 190 us launch for the 37 MB that 256 blocks x 64x64x9 produce.
 int agf_conv2d_wgrad_ring_launch(const void* x, const void* dy, float* dw, const float* in_scale, const float* out_scale,
-                                 int N, int H, int W, int Cin, int Cout, float scale, float* workspace, int64_t workspaceBytes, hipStream_t st) {
+                                 int N, int H, int W, int Cin, int Cout, float scale, float* workspace, int64_t workspaceBytes, int oihw, hipStream_t st) {
     WgradRingParams p;
     if (!ring_plan(p, in_scale || out_scale, in_scale && out_scale, N, H, W, Cin, Cout)) return AGF_ENOKERNEL;
     p.x = (const bf16_t*)x; p.dy = (const bf16_t*)dy; p.dw = dw; p.in_scale = in_scale; p.out_scale = out_scale; p.scale = scale;
@@ -382,7 +392,7 @@ int agf_conv2d_wgrad_ring_launch(const void* x, const void* dy, float* dw, const
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)(base * p.splitK)), dim3(512), lds, st, p);
     if (p.part)
-        hipLaunchKernelGGL(conv2d_wgrad_reduce_kernel, dim3((unsigned)((p.dwNumel / 4 + 63) / 64)), dim3(256), 0, st, p.part, dw, p.dwNumel, p.splitK);
+        hipLaunchKernelGGL(conv2d_wgrad_reduce_kernel, dim3((unsigned)((p.dwNumel / 4 + 63) / 64)), dim3(256), 0, st, p.part, dw, p.dwNumel, p.splitK, oihw ? Cin : 0);
     else if (workspace) return AGF_EINVAL;               // the caller asked for the overwriting mode but the plan changed: cannot happen
     return AGF_OK;
 }

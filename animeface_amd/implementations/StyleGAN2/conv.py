@@ -12,6 +12,7 @@ the discriminator twice, the path-length penalty the generator) compose from thr
 """
 import os
 
+import ctypes
 import functools
 
 import torch
@@ -243,11 +244,15 @@ def conv2d_wgrad_raw(x, dy, ksize, in_scale=None, out_scale=None, scale=1.0):
     timer = KernelTimer.active
     if ws_bytes:
         # two-stage split-K combine: partial tiles to a scratch buffer, summed by a second launch; dw is overwritten (no zero fill)
-        dw = torch.empty((Cout, ksize, ksize, Cin), dtype=torch.float32, device=x.device).permute(0, 3, 1, 2)
+        buf = torch.empty(Cout * ksize * ksize * Cin, dtype=torch.float32, device=x.device)
         ws = _wgrad_workspace(x.device, ws_bytes)
+        layout = ctypes.c_int32(0)
         ev0 = timer.start() if timer is not None else None
-        rc = _lib.lib().agf_conv2d_wgrad_ws(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(in_scale), _lib.ptr(out_scale),
-                                            _lib.dtype_code(x), N, H, W, Cin, Cout, ksize, float(scale), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(x))
+        rc = _lib.lib().agf_conv2d_wgrad_ws(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(buf), _lib.ptr(in_scale), _lib.ptr(out_scale),
+                                            _lib.dtype_code(x), N, H, W, Cin, Cout, ksize, float(scale), _lib.ptr(ws), ws_bytes,
+                                            ctypes.byref(layout), _lib.stream_ptr(x))
+        # the combine launch may have written the parameter's own [Cout, Cin, k, k] order: autograd then needs no layout copy
+        dw = buf.view(Cout, Cin, ksize, ksize) if layout.value == 1 else buf.view(Cout, ksize, ksize, Cin).permute(0, 3, 1, 2)
     else:
         dw = _zeros_f32((Cout, ksize, ksize, Cin), x.device).permute(0, 3, 1, 2)   # memory OHWI; zeroed by the arena's single fill
         ev0 = timer.start() if timer is not None else None

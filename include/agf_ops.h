@@ -186,12 +186,15 @@ int agf_conv2d_wgrad(const void* x, const void* dy, float* dw,
  * plain stores and a second launch sums them into dw -- deterministic, and 3x cheaper than the atomics of agf_conv2d_wgrad (which ran at
  * 0.5 TB/s: 76 us of a 190 us launch).  agf_conv2d_wgrad_workspace_bytes returns 0 for shapes that take the one-stage path (1x1, fp32,
  * maps below 16x16 or not a multiple of the 128-pixel tile); agf_conv2d_wgrad_ws then zeroes dw itself and accumulates with atomics.
+ * dw_layout_out (nullable): a caller that passes it accepts dw in EITHER order and is told which one was written -- 0: [Cout][kh][kw][Cin]
+ * as everywhere else, 1: [Cout][Cin][kh][kw], the parameter's own order (the combine launch writes it for free; saves the layout copy
+ * that autograd's gradient accumulation would otherwise make).
  * (ABI v13; no reference counterpart: ATen / cuDNN own this in the reference, implementations/StyleGAN2/model.py:123-129.) */
 int64_t agf_conv2d_wgrad_workspace_bytes(int dtype, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize, int has_scales);
 int agf_conv2d_wgrad_ws(const void* x, const void* dy, float* dw,
                         const float* in_scale, const float* out_scale,
                         int dtype, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
-                        float scale, void* workspace, int64_t workspace_bytes, void* stream);
+                        float scale, void* workspace, int64_t workspace_bytes, int32_t* dw_layout_out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Backward halves of the fused conv epilogues (new: the reference has no counterpart -- it runs these as separate
