@@ -106,7 +106,7 @@ class ModulatedConv(nn.Module):
             w = F.pad(w, [0, 0, 0, 0, 0, cin_p - cin, 0, cout_p - cout])
             s_in = F.pad(s_in, [0, cin_p - cin])
             if d is not None:
-                d = F.pad(d, [0, cout_p - cout])
+                d = F.pad(d, [0, cout_p - cout], value=1.0)      # (not 0: its gradient divides by it; the padded weights are zero anyway)
         y = conv2d(x, w, s_in, d)
         return layout.channels_last_to_planar(y, 0, cout)  # planar for filtered_lrelu; its gradient returns channels-last
 
