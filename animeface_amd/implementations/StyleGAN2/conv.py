@@ -866,7 +866,12 @@ def conv2d_act(x, weight, bias=None, s_in=None, s_out=None, noise=None, alpha=0.
     Cout, Cin = weight.shape[0], weight.shape[1]
     if fused and Cout % 8 == 0 and (act == 'linear' or gain == 1.0 or s_out is None) and not (act == 'linear' and s_out is not None):
         if x.dtype == torch.bfloat16 and Cin % 8:
-            x = _pad_channels(x, 8, 1).contiguous(memory_format=torch.channels_last)
+            if x.is_cuda and x.is_contiguous():
+                # planar RGB -> channels-last with the channel axis zero-padded to 8, one launch (its adjoint crops the gradient)
+                from ...stylegan3_ops import layout
+                x = layout.planar_to_channels_last(x, 0, (Cin + 7) // 8 * 8)
+            else:
+                x = _pad_channels(x, 8, 1).contiguous(memory_format=torch.channels_last)
             weight = _pad_channels(weight, 8, 1)
             s_in = _pad_channels(s_in, 8, 1) if s_in is not None else None
             pre_link = None                           # the link describes the UNPADDED input tensor
