@@ -458,8 +458,12 @@ class Generator(nn.Module):
 
     def forward(self, z, injection=None):
         if isinstance(z, (list, tuple)):
-            style = [self.map(z[0]), self.map(z[1])]
             B = z[0].size(0)
+            if z[0].shape == z[1].shape and z[0].is_cuda:
+                # style mixing: both latents through the mapping network as ONE batch (every op in it is row-wise): half the launches
+                style = list(self.map(torch.cat([z[0], z[1]], 0)).split(B, 0))
+            else:
+                style = [self.map(z[0]), self.map(z[1])]
         else:
             style = self.map(z)
             B = z.size(0)
