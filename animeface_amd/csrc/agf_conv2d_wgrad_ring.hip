@@ -22,7 +22,8 @@ struct WgradRingParams {
     const float* out_scale;   // [N,Cout] or null
     int N, H, W, Cin, Cout;
     int TH, TW, twShift;      // pixel tile: TH x TW = 128, TW in {16, 32}
-    int tilesW, tilesH, pixTiles, lgTilesW, lgTilesH;   // tiles per row / column of an image: powers of two
+    int tilesW, tilesH, pixTiles, lgTilesW, lgTilesH;   // tiles per row / column of an image; lg* >= 0: powers of two (shift decode)
+    int cutX, cutY;           // first patch column / row (halo included) that lies beyond the image in the LAST tile column / row
     int tilesCo, tilesCi, splitK;
     float scale;
     int epiScale, perImage;
@@ -92,7 +93,8 @@ __global__ void __launch_bounds__(512, 2) conv2d_wgrad_ring_kernel(WgradRingPara
 
     // Addressing.  Everything that does not depend on the tile is computed once: per wave-load slot v = (i * 8 + wave) * 64 + lane (LDS-
     // linear order [32-channel block][row][16-byte chunk]) the byte offset of the lane's vector relative to the tile origin and a flag
-    // word -- bit 0..3: the vector lies in the top / bottom / left / right halo ring, bit 4: never loaded (channel tail, slot padding),
+    // word -- bit 0..3: the vector lies in the top halo row / at or below the row that leaves the image in the last tile row / in the left halo
+    // column / at or beyond the column that leaves the image in the last tile column (for maps that are whole tiles: the halo ring), bit 4: never loaded (channel tail, slot padding),
     // bit 5: always set.  A tile contributes one scalar mask (which halo sides fall outside the image, bit 4, bit 5 for tiles beyond
     // the work list): offset = (flags & mask) ? out of range : origin + relative -- four vector instructions per load, placed between
     // the MFMAs of the tile being contracted (when this block was issued in one piece right after the barrier, with a division-based
@@ -106,7 +108,7 @@ __global__ void __launch_bounds__(512, 2) conv2d_wgrad_ring_kernel(WgradRingPara
         const int q = rem >> 2, ch = (blk * 4 + (rem & 3)) * 8;
         const int r = q >> p.twShift, c = q & (p.TW - 1);
         dRel[i] = ((r * p.W + c) * p.Cout + co0 + ch) * 2;
-        dFlag[i] = 32 | (co0 + ch < p.Cout ? 0 : 16);
+        dFlag[i] = 32 | (co0 + ch < p.Cout ? 0 : 16) | (r >= p.cutY - 1 ? 2 : 0) | (c >= p.cutX - 1 ? 8 : 0);
         dLds[i] = (i * 8 + wave) * 512;
     }
 #pragma unroll
@@ -118,7 +120,7 @@ __global__ void __launch_bounds__(512, 2) conv2d_wgrad_ring_kernel(WgradRingPara
         const int q = rem >> 2, ch = (blk * 4 + (rem & 3)) * 8;
         const int pr = q / PW, pc = q - pr * PW;
         xRel[i] = (((pr - 1) * p.W + pc - 1) * p.Cin + ci0 + ch) * 2;
-        xFlag[i] = 32 | ((slot && q < P && ci0 + ch < p.Cin) ? 0 : 16) | (pr == 0 ? 1 : 0) | (pr == PH - 1 ? 2 : 0) | (pc == 0 ? 4 : 0) | (pc == PW - 1 ? 8 : 0);
+        xFlag[i] = 32 | ((slot && q < P && ci0 + ch < p.Cin) ? 0 : 16) | (pr == 0 ? 1 : 0) | (pr >= p.cutY ? 2 : 0) | (pc == 0 ? 4 : 0) | (pc >= p.cutX ? 8 : 0);
         xLds[i] = slot ? 2 * DYR * 32 + wl * 512 : -1;
     }
 
@@ -127,7 +129,9 @@ __global__ void __launch_bounds__(512, 2) conv2d_wgrad_ring_kernel(WgradRingPara
     const __amdgpu_buffer_rsrc_t dRes = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, RING_OOB, 0x00020000);
     const __amdgpu_buffer_rsrc_t xRes = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, RING_OOB, 0x00020000);
     auto issue_tile = [&](int pt, bool live, int stage) {
-        const int tw = pt & (p.tilesW - 1), th = (pt >> p.lgTilesW) & (p.tilesH - 1), n = pt >> (p.lgTilesW + p.lgTilesH);
+        int tw, th, n;
+        if (p.lgTilesW >= 0) { tw = pt & (p.tilesW - 1); th = (pt >> p.lgTilesW) & (p.tilesH - 1); n = pt >> (p.lgTilesW + p.lgTilesH); }
+        else { n = pt / tilesPerImage; const int rem = pt - n * tilesPerImage; th = rem / p.tilesW; tw = rem - th * p.tilesW; }
         const int pix = (n * p.H + th * p.TH) * p.W + tw * p.TW;
         const int dOrigin = pix * p.Cout * 2, xOrigin = pix * p.Cin * 2;
         const int mask = !live ? 63 : 16 | (th == 0 ? 1 : 0) | (th == p.tilesH - 1 ? 2 : 0) | (tw == 0 ? 4 : 0) | (tw == p.tilesW - 1 ? 8 : 0);
@@ -162,12 +166,11 @@ __global__ void __launch_bounds__(512, 2) conv2d_wgrad_ring_kernel(WgradRingPara
         ptIssue += ptStep; stIssue = stIssue + 1 == NS ? 0 : stIssue + 1;
     }
     // SC: this lane's channel of the A operand (dy: co) and of the B operand (x: ci), and their scales for the first tile's image
-    const int lgImg = p.lgTilesW + p.lgTilesH;
     const int chA = co0 + wa * 32 + (lane & 31), chB = ci0 + wb * 32 + (lane & 31);
     float scA = 1.f, scB = 1.f;
     const int chAc = chA < p.Cout ? chA : p.Cout - 1, chBc = chB < p.Cin ? chB : p.Cin - 1;     // (tail lanes hold zero fragments: any finite scale)
     if (SC && ptBegin < ptEnd) {
-        const int n = ptBegin >> lgImg;
+        const int n = ptBegin / tilesPerImage;
         scA = p.out_scale[(int64_t)n * p.Cout + chAc];
         scB = p.in_scale[(int64_t)n * p.Cin + chBc];
     }
@@ -228,7 +231,7 @@ __global__ void __launch_bounds__(512, 2) conv2d_wgrad_ring_kernel(WgradRingPara
                     // iteration (everything but the youngest LPW operations) then covers them
                     // (inline asm: a compiler-visible load into a loop-carried register gets an `s_waitcnt vmcnt(0)` right behind it --
                     //  a full drain of the ring.  The explicit wait at the top of the loop is what orders these two loads.)
-                    const int nn = (pt + ptStep < ptEnd ? pt + ptStep : pt) >> lgImg;
+                    const int nn = (pt + ptStep < ptEnd ? pt + ptStep : pt) / tilesPerImage;
                     const float* pa = p.out_scale + (int64_t)nn * p.Cout + chAc;
                     const float* pb = p.in_scale + (int64_t)nn * p.Cin + chBc;
                     asm volatile("global_load_dword %0, %1, off" : "=v"(scA) : "v"(pa) : "memory");
@@ -323,15 +326,24 @@ static int ring_pow2_floor_log2(int v) { int s = 0; while ((2 << s) <= v) s++; r
 static bool ring_plan(WgradRingParams& p, bool scales, bool both, int N, int H, int W, int Cin, int Cout) {
     static const int on = []{ const char* e = getenv("AGF_WGRAD_RING"); return e ? atoi(e) : 1; }();
     if (!on) return false;
-    p.TW = W >= 32 ? 32 : 16;
+    if (W < 16 || H < 4) return false;
+    {   // 4 x 32 or 8 x 16 pixel tiles: whichever wastes less of its area on this map
+        auto cover = [&](int tw) { const int th = RING_DYR / tw; return (double)H * W / ((double)((W + tw - 1) / tw) * tw * ((H + th - 1) / th) * th); };
+        p.TW = (W >= 32 && cover(32) >= cover(16)) ? 32 : 16;
+    }
     p.TH = RING_DYR / p.TW;
-    if (W < 16 || W % p.TW || H % p.TH) return false;
     if ((int64_t)N * H * W * (Cin > Cout ? Cin : Cout) * 2 >= 0x7fff0000ll) return false;     // 32-bit byte offsets into the whole tensor
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
     p.twShift = ring_pow2_floor_log2(p.TW);
-    p.tilesW = W / p.TW; p.tilesH = H / p.TH;
+    p.tilesW = (W + p.TW - 1) / p.TW; p.tilesH = (H + p.TH - 1) / p.TH;
     p.lgTilesW = ring_pow2_floor_log2(p.tilesW); p.lgTilesH = ring_pow2_floor_log2(p.tilesH);
-    if ((1 << p.lgTilesW) != p.tilesW || (1 << p.lgTilesH) != p.tilesH) return false;
+    if ((1 << p.lgTilesW) != p.tilesW || (1 << p.lgTilesH) != p.tilesH) p.lgTilesW = p.lgTilesH = -1;      // ragged maps: division decode
+    p.cutX = W - (p.tilesW - 1) * p.TW + 1; p.cutY = H - (p.tilesH - 1) * p.TH + 1;
+    {   // tiles that hang over the image contract zeros: not worth it when more than ~30 % of the tile area is padding
+        static const int ragged = []{ const char* e = getenv("AGF_WGRAD_RING_RAGGED"); return e ? atoi(e) : 1; }();
+        const double cover = (double)H * W / ((double)p.tilesW * p.TW * p.tilesH * p.TH);
+        if ((W % p.TW || H % p.TH) && (!ragged || cover < 0.7)) return false;
+    }
     const int tpi = p.tilesW * p.tilesH;
     p.pixTiles = tpi * N;
     p.tilesCo = (Cout + 63) / 64; p.tilesCi = (Cin + 63) / 64;

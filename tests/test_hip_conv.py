@@ -166,6 +166,8 @@ WGRAD_CASES = [
     (5, 64, 32, 128, 128, 3, 'ring: odd batch, blocks inside one image when scaled'),
     (2, 40, 136, 32, 64, 3, 'ring: channel tails on both sides'),
     (24, 256, 128, 32, 32, 3, 'ring: scales on the operands (blocks span images)'),
+    (3, 64, 72, 38, 54, 3, 'ring: ragged map (tiles hang over the right and bottom edges)'),
+    (2, 32, 64, 150, 86, 3, 'ring: ragged map, 4x32 tiles, division decode'),
     (40, 128, 64, 16, 16, 3, 'ring: scales on the operands, 8x16 tiles'),
 ]
 
