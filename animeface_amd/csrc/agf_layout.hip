@@ -137,6 +137,47 @@ extern "C" int agf_cl_to_planar_crop(const void* x, void* y, int dtype, int32_t 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// agf_cl_pad: zero border of `pad` pixels around a dense channels-last tensor (crop = 0: [N][H][W][C] -> [N][H+2p][W+2p][C]) and its
+// adjoint, the crop (crop = 1: the other way), one pass of 16-byte vectors (a pixel row is a run of W * C elements).  torch needs a
+// fill plus a strided copy for the first (0.83 ms on a 1 GB activation of the StyleGAN3 discriminator) and a strided copy for the second.
+__global__ void __launch_bounds__(256) cl_pad_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, int N, int H, int W, int rowV, int padV,
+                                                     int pad, int crop) {
+    // rowV = 16-byte vectors of an unpadded pixel row (W * C * esize / 16), padV = vectors of `pad` pixels
+    const int Hp = H + 2 * pad, rowVp = rowV + 2 * padV;
+    const int64_t total = crop ? (int64_t)N * H * rowV : (int64_t)N * Hp * rowVp;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        if (crop) {
+            const int v = (int)(i % rowV); const int64_t r = i / rowV;
+            const int yy = (int)(r % H); const int64_t n = r / H;
+            y[i] = x[((n * Hp + yy + pad) * rowVp) + padV + v];
+        } else {
+            const int v = (int)(i % rowVp); const int64_t r = i / rowVp;
+            const int yp = (int)(r % Hp); const int64_t n = r / Hp;
+            uint4 val = {0u, 0u, 0u, 0u};
+            if (yp >= pad && yp < H + pad && v >= padV && v < rowV + padV) val = x[((n * H + yp - pad) * rowV) + v - padV];
+            y[i] = val;
+        }
+    }
+}
+
+extern "C" int agf_cl_pad(const void* x, void* y, int32_t elem_bytes, int32_t N, int32_t H, int32_t W, int32_t C, int32_t pad, int32_t crop,
+                          void* stream) {
+    AGF_CHECK(x && y, "cl_pad: null pointer");
+    AGF_CHECK(N >= 1 && H >= 1 && W >= 1 && C >= 1 && pad >= 0 && (elem_bytes == 2 || elem_bytes == 4), "cl_pad: bad shape");
+    AGF_CHECK(((int64_t)C * elem_bytes) % 16 == 0, "cl_pad: a pixel (C = %d elements of %d bytes) must be a whole number of 16-byte vectors", C, elem_bytes);
+    AGF_CHECK(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0, "cl_pad: misaligned pointer");
+    const int pixV = C * elem_bytes / 16;
+    const int64_t total = crop ? (int64_t)N * H * W * pixV : (int64_t)N * (H + 2 * pad) * (W + 2 * pad) * pixV;
+    AGF_CHECK((int64_t)W * pixV < (1ll << 30), "cl_pad: row too long");
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 65536 * 8) blocks = 65536 * 8;
+    hipLaunchKernelGGL(cl_pad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, (uint4*)y, N, H, W, W * pixV, pad * pixV,
+                       pad, crop);
+    AGF_LAUNCH_CHECK();
+    return AGF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // agf_prep_weights: fp32 master weights [Cout][Cin][k][k]  ->  the conv kernels' operand layouts in ONE launch:
 //   wq  [Cout][kh][kw][Cin]   = w * coef                                   (forward)
 //   wft [Cin][kh][kw][Cout]   = w[co][ci][k-1-kh][k-1-kw] * coef           (data gradient: flipped taps, swapped channel axes)

@@ -31,17 +31,32 @@ from ...stylegan3_ops import bias_act, filtered_lrelu, upfirdn2d, layout
 from ..StyleGAN2.conv import conv2d, conv2d_act
 
 
+def _cl_pad_raw(x, pad, crop):
+    """``agf_cl_pad``: one pass.  x logical [N,C,H,W] in channels-last memory; falls back to torch for layouts the kernel does not take."""
+    N, C, H, W = x.shape
+    es = x.element_size()
+    if x.is_cuda and es in (2, 4) and (C * es) % 16 == 0 and x.is_contiguous(memory_format=torch.channels_last):
+        from ... import _lib
+        Ho, Wo = (H - 2 * pad, W - 2 * pad) if crop else (H + 2 * pad, W + 2 * pad)
+        y = torch.empty((N, C, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        _lib.check(_lib.lib().agf_cl_pad(_lib.ptr(x), _lib.ptr(y), es, N, Ho if crop else H, Wo if crop else W, C, pad, int(crop),
+                                         _lib.stream_ptr(x)), 'cl_pad')
+        return y
+    if crop:
+        return x[:, :, pad:-pad, pad:-pad].contiguous(memory_format=torch.channels_last)
+    y = torch.empty((N, C, H + 2 * pad, W + 2 * pad), dtype=x.dtype, device=x.device, memory_format=torch.channels_last).zero_()
+    y[:, :, pad:-pad, pad:-pad].copy_(x)
+    return y
+
+
 class _ZeroPadCL(torch.autograd.Function):
-    """Zero-pad H and W of a (channels-last) tensor into a dense channels-last tensor with one copy; differentiable to any
+    """Zero-pad H and W of a (channels-last) tensor into a dense channels-last tensor in one pass; differentiable to any
     order (its adjoint is the crop below)."""
 
     @staticmethod
     def forward(ctx, x, pad):
         ctx.pad = pad
-        N, C, H, W = x.shape
-        y = torch.empty((N, C, H + 2 * pad, W + 2 * pad), dtype=x.dtype, device=x.device, memory_format=torch.channels_last).zero_()
-        y[:, :, pad:-pad, pad:-pad].copy_(x)
-        return y
+        return _cl_pad_raw(x, pad, False)
 
     @staticmethod
     def backward(ctx, g):
@@ -52,7 +67,7 @@ class _CropCL(torch.autograd.Function):
     @staticmethod
     def forward(ctx, g, pad):
         ctx.pad = pad
-        return g[:, :, pad:-pad, pad:-pad].contiguous(memory_format=torch.channels_last)
+        return _cl_pad_raw(g, pad, True)
 
     @staticmethod
     def backward(ctx, gg):

@@ -230,6 +230,12 @@ int agf_planar_to_cl_pad(const void* x, void* y, int dtype, int32_t N, int32_t C
 int agf_cl_to_planar_crop(const void* x, void* y, int dtype, int32_t N, int32_t C, int32_t H, int32_t W,
                           int32_t pad, int32_t Cp, void* stream);
 
+/* Zero border of `pad` pixels around a dense channels-last tensor x [N][H][W][C] -> y [N][H+2p][W+2p][C] (crop = 0), or the adjoint:
+ * crop the border of x [N][H+2p][W+2p][C] -> y [N][H][W][C] (crop = 1).  C * elem_bytes must be a multiple of 16.  (ABI v13; the
+ * StyleGAN3 discriminator's FIR + stride-2 conv runs as a stride-1 conv over the input padded by one more pixel:
+ * implementations/StyleGAN3/model.py ConvAct, reference conv2d_resample.py:100-103.) */
+int agf_cl_pad(const void* x, void* y, int32_t elem_bytes, int32_t N, int32_t H, int32_t W, int32_t C, int32_t pad, int32_t crop, void* stream);
+
 /* fp32 master weights [Cout][Cin][k][k] -> operand layouts of agf_conv2d_fwd in the activation dtype, one launch:
  *   wq [Cout][kh][kw][Cin] = w * coef (nullable);   wft [Cin][kh][kw][Cout] = w[co][ci][k-1-kh][k-1-kw] * coef (nullable; the
  *   weights of the data-gradient convolution).  coef is the equalised-learning-rate constant of ELR / ModulatedConv2d

@@ -212,3 +212,22 @@ def test_hip_model_vs_cpu_oracle_on_a_second_configuration():
     torch.testing.assert_close(G.map.w_avg.cpu(), stats['w_avg'], rtol=1e-4, atol=1e-6)
     for i, e in stats['ema'].items():
         torch.testing.assert_close(G.synthesis.net[i].ema.cpu(), e, rtol=1e-3, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize('shape,pad', [((3, 16, 9, 13), 1), ((2, 64, 32, 32), 1), ((1, 8, 5, 7), 2)])
+def test_channels_last_zero_pad_and_crop_one_pass(dtype, shape, pad):
+    """``agf_cl_pad`` behind ``_ZeroPadCL`` / ``_CropCL`` (the discriminator's FIR + stride-2 conv pads its input by one more pixel):
+    equal to F.pad / slicing, and each other's adjoint."""
+    import torch.nn.functional as F
+    from animeface_amd.implementations.StyleGAN3.model import _ZeroPadCL, _CropCL
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(shape, generator=g).to(dtype).to('cuda').contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = _ZeroPadCL.apply(x, pad)
+    assert y.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(y, F.pad(x.detach(), [pad] * 4))
+    gy = torch.randn(y.shape, generator=g).to(dtype).to('cuda').contiguous(memory_format=torch.channels_last)
+    (gx,) = torch.autograd.grad(y, x, gy)
+    assert torch.equal(gx, gy[:, :, pad:-pad, pad:-pad])
+    assert torch.equal(_CropCL.apply(y, pad), x.detach())
