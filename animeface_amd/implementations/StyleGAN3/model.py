@@ -387,8 +387,9 @@ class ConvAct(nn.Module):
             self.down_filter = None
 
     def forward(self, x):
-        weight = self.weight * self.scale
         k = self.weight.shape[2]
+        fused = self.act_name in ('lrelu', 'linear')
+        weight = None if (fused and (self.down == 1 or k == 1)) else self.weight * self.scale      # (the fused op folds the scale itself)
         if self.down == 1:
             # MFMA conv ("same" padding) with bias + activation + gain in its epilogue (and the fused backward of that epilogue)
             return conv2d_act(x.contiguous(memory_format=torch.channels_last), self.weight, self.bias, coef=self.scale,
