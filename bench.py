@@ -70,8 +70,8 @@ def measured_traffic():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=16)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=32)
+    ap.add_argument('--warmup', type=int, default=4)
     ap.add_argument('--image-size', type=int, default=256)
     ap.add_argument('--batch', type=int, default=64, help='per-GPU batch')
     ap.add_argument('--no-cpu-baseline', action='store_true')
