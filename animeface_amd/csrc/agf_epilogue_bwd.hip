@@ -20,19 +20,25 @@ struct ActBwdParams {
     float alpha, inv_alpha;
     int pooled, W;            // pooled: dy is [N,H/2,W/2,C], the gradient of a 2x2 box average: every input pixel of a 2x2 cell gets dy * dy_scale
     float dy_scale;
+    const float* dscale;      // [N,C] or null: the incoming gradient is dy * dscale[n,c] (agf_act_bwd_reduce_scaled: dy = the data gradient t of
+    float* sumD;              //   the consumer's modulated conv, dscale = its style scale s); sumD[n,c] += sum_p y * dy  (= that conv's d s)
 };
 
-template <class T, int VEC>
+template <class T, int VEC, bool SCALED = false>
 __global__ void __launch_bounds__(256) act_bwd_reduce_kernel(ActBwdParams p) {
-    __shared__ float red[3][256][VEC + 1];
+    __shared__ float red[SCALED ? 4 : 3][256][VEC + 1];
     const int tid = threadIdx.x;
     const int cg = tid % p.CG, pl = tid / p.CG;
     const int n = blockIdx.y, chunk = blockIdx.x;
     const int p0 = chunk * p.pixPerBlock;
     const int p1 = min(p0 + p.pixPerBlock, p.HW);
-    float a[VEC], b[VEC], c[VEC];
+    float a[VEC], b[VEC], c[VEC], d[SCALED ? VEC : 1], sc[SCALED ? VEC : 1];
 #pragma unroll
     for (int i = 0; i < VEC; i++) a[i] = b[i] = c[i] = 0.f;
+    if (SCALED) {
+#pragma unroll
+        for (int i = 0; i < VEC; i++) { d[i] = 0.f; sc[i] = p.dscale[(int64_t)n * p.C + cg * VEC + i]; }
+    }
     const bool active = pl < p.pixLanes;
     if (active) {
         const int64_t base = (int64_t)n * p.HW * p.C + cg * VEC;
@@ -68,6 +74,7 @@ __global__ void __launch_bounds__(256) act_bwd_reduce_kernel(ActBwdParams p) {
 #pragma unroll
                 for (int i = 0; i < VEC; i++) {
                     const bool pos = y[u][i] > 0.f;
+                    if (SCALED) { d[i] += y[u][i] * dy[u][i]; dy[u][i] *= sc[i]; }
                     g[i] = pos ? dy[u][i] : dy[u][i] * p.alpha;
                     const float y0 = pos ? y[u][i] : y[u][i] * p.inv_alpha;
                     a[i] += g[i] * y0; b[i] += g[i]; c[i] += g[i] * nz;
@@ -77,13 +84,14 @@ __global__ void __launch_bounds__(256) act_bwd_reduce_kernel(ActBwdParams p) {
         }
     }
 #pragma unroll
-    for (int i = 0; i < VEC; i++) { red[0][tid][i] = a[i]; red[1][tid][i] = b[i]; red[2][tid][i] = c[i]; }
+    for (int i = 0; i < VEC; i++) { red[0][tid][i] = a[i]; red[1][tid][i] = b[i]; red[2][tid][i] = c[i]; if (SCALED) red[3][tid][i] = d[i]; }
     __syncthreads();
     if (pl == 0) {
         for (int l = 1; l < p.pixLanes; l++) {
 #pragma unroll
             for (int i = 0; i < VEC; i++) {
                 a[i] += red[0][l * p.CG + cg][i]; b[i] += red[1][l * p.CG + cg][i]; c[i] += red[2][l * p.CG + cg][i];
+                if (SCALED) d[i] += red[3][l * p.CG + cg][i];
             }
         }
         const int64_t o = (int64_t)n * p.C + cg * VEC;
@@ -92,6 +100,7 @@ __global__ void __launch_bounds__(256) act_bwd_reduce_kernel(ActBwdParams p) {
             if (p.sumA) unsafeAtomicAdd(p.sumA + o + i, a[i]);
             if (p.sumB) unsafeAtomicAdd(p.sumB + o + i, b[i]);
             if (p.sumC) unsafeAtomicAdd(p.sumC + o + i, c[i]);
+            if (SCALED && p.sumD) unsafeAtomicAdd(p.sumD + o + i, d[i]);
         }
     }
 }
@@ -166,7 +175,8 @@ static int plan(int C, int vec, int HW, int N, int* CG, int* pixLanes, int* pixP
 
 static int act_bwd_reduce_impl(const void* dy, const void* y, const float* noise, void* g,
                                float* sum_gy0, float* sum_g, float* sum_gnoise,
-                               int dtype, int32_t N, int32_t H, int32_t W, int32_t C, float alpha, int pooled, float dy_scale, void* stream) {
+                               int dtype, int32_t N, int32_t H, int32_t W, int32_t C, float alpha, int pooled, float dy_scale, void* stream,
+                               const float* dscale = nullptr, float* sum_ydy = nullptr) {
     AGF_CHECK(dy && y && g, "act_bwd_reduce: null pointer");
     AGF_CHECK(dtype == AGF_BF16 || dtype == AGF_F32, "act_bwd_reduce: dtype must be bf16 or f32");
     AGF_CHECK(alpha > 0.f, "act_bwd_reduce: the leaky slope must be positive");
@@ -174,14 +184,17 @@ static int act_bwd_reduce_impl(const void* dy, const void* y, const float* noise
     ActBwdParams p;
     p.dy = dy; p.y = y; p.noise = noise; p.g = g; p.sumA = sum_gy0; p.sumB = sum_g; p.sumC = sum_gnoise;
     p.N = N; p.HW = H * W; p.C = C; p.alpha = alpha; p.inv_alpha = 1.f / alpha;
-    p.pooled = pooled; p.W = W; p.dy_scale = dy_scale;
+    p.pooled = pooled; p.W = W; p.dy_scale = dy_scale; p.dscale = dscale; p.sumD = sum_ydy;
     const int vec = dtype == AGF_BF16 ? 8 : 4;
     if (!plan(C, vec, p.HW, N, &p.CG, &p.pixLanes, &p.pixPerBlock, &p.chunks)) {
         agf_set_error("act_bwd_reduce: C=%d is not a multiple of %d (or too wide)", C, vec);
         return AGF_ENOKERNEL;
     }
     dim3 grid((unsigned)p.chunks, (unsigned)N), block(256);
-    if (dtype == AGF_BF16) hipLaunchKernelGGL((act_bwd_reduce_kernel<bf16_t, 8>), grid, block, 0, (hipStream_t)stream, p);
+    if (dscale) {
+        if (dtype == AGF_BF16) hipLaunchKernelGGL((act_bwd_reduce_kernel<bf16_t, 8, true>), grid, block, 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((act_bwd_reduce_kernel<float, 4, true>), grid, block, 0, (hipStream_t)stream, p);
+    } else if (dtype == AGF_BF16) hipLaunchKernelGGL((act_bwd_reduce_kernel<bf16_t, 8>), grid, block, 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((act_bwd_reduce_kernel<float, 4>), grid, block, 0, (hipStream_t)stream, p);
     AGF_LAUNCH_CHECK();
     return AGF_OK;
@@ -191,6 +204,13 @@ extern "C" int agf_act_bwd_reduce(const void* dy, const void* y, const float* no
                                   float* sum_gy0, float* sum_g, float* sum_gnoise,
                                   int dtype, int32_t N, int32_t H, int32_t W, int32_t C, float alpha, void* stream) {
     return act_bwd_reduce_impl(dy, y, noise, g, sum_gy0, sum_g, sum_gnoise, dtype, N, H, W, C, alpha, 0, 1.f, stream);
+}
+
+extern "C" int agf_act_bwd_reduce_scaled(const void* t, const void* y, const float* noise, const float* t_scale, void* g,
+                                         float* sum_gy0, float* sum_g, float* sum_gnoise, float* sum_yt,
+                                         int dtype, int32_t N, int32_t H, int32_t W, int32_t C, float alpha, void* stream) {
+    AGF_CHECK(t_scale && sum_yt, "act_bwd_reduce_scaled: null pointer");
+    return act_bwd_reduce_impl(t, y, noise, g, sum_gy0, sum_g, sum_gnoise, dtype, N, H, W, C, alpha, 0, 1.f, stream, t_scale, sum_yt);
 }
 
 extern "C" int agf_act_bwd_reduce_pooled(const void* dy_half, const void* y, void* g, float* sum_g,

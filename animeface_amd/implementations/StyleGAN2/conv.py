@@ -386,6 +386,21 @@ def act_bwd_reduce_raw(dy, y, noise, alpha, want_sums):
     return g, sums
 
 
+def act_bwd_reduce_scaled_raw(t, y, noise, t_scale, alpha):
+    """One ``agf_act_bwd_reduce_scaled`` launch: g = (t * t_scale[n,c]) * lrelu'(y), the producer's three sums and the consumer's
+    ds[n,c] = sum_hw y * t.  Returns g, (A, B, Cn), ds."""
+    N, C, H, W = y.shape
+    g = torch.empty_like(y)
+    pool = _zeros_f32((4 if noise is not None else 3, N, C), y.device)
+    A, B, ds = pool[0], pool[1], pool[2]
+    Cn = pool[3] if noise is not None else None
+    rc = _lib.lib().agf_act_bwd_reduce_scaled(_lib.ptr(t), _lib.ptr(y), _lib.ptr(_f32(noise)), _lib.ptr(_f32(t_scale)), _lib.ptr(g),
+                                              _lib.ptr(A), _lib.ptr(B), _lib.ptr(Cn), _lib.ptr(ds),
+                                              _lib.dtype_code(y), N, H, W, C, float(alpha), _lib.stream_ptr(y))
+    _lib.check(rc, 'act_bwd_reduce_scaled')
+    return g, (A, B, Cn), ds
+
+
 def act_bwd_reduce_pooled_raw(dy_half, y, alpha, dy_scale, want_sum):
     """One ``agf_act_bwd_reduce_pooled`` launch: g = dy_scale * dy_half[h/2, w/2] * lrelu'(y) and its per-(n,c) sum."""
     N, C, H, W = y.shape
@@ -630,10 +645,13 @@ class PremaskLink:
     """Handshake between two chained fused convs  y1 = lrelu(conv1(x) + b1);  y2 = conv2(y1)  where conv2 is the ONLY consumer of y1
     (the caller guarantees that: DBlock).  conv2's backward then produces the gradient of y1 already multiplied by lrelu'(y1) and its
     per-channel sums (``agf_conv2d_fwd_mask``), and conv1's backward skips its own pass over the tensor (``agf_act_bwd_reduce``)."""
-    __slots__ = ('armed', 'alpha', 'premasked', 'bsum', 'pooled')
+    __slots__ = ('armed', 'alpha', 'premasked', 'bsum', 'pooled', 'armed_mod', 'noise', 'sums')
 
     def __init__(self):
         self.armed, self.alpha, self.premasked, self.bsum, self.pooled = False, 0.2, False, None, None
+        # modulated producer -> modulated consumer (generator block): the consumer's backward runs agf_act_bwd_reduce_scaled, which
+        # turns its unscaled data gradient t straight into the producer's masked gradient and leaves the producer's sums here
+        self.armed_mod, self.noise, self.sums = False, None, None
 
 
 class _UpBlur(torch.autograd.Function):
@@ -712,6 +730,7 @@ def pool2x_linked(x, f, gain, link):
 
 
 _PREMASK = os.environ.get('AGF_PREMASK', '1') != '0'       # A/B switch
+_PREMASK_MOD = os.environ.get('AGF_PREMASK_MOD', '1') != '0'   # A/B switch: scale_dot + act_bwd_reduce of a modulated chain as one pass
 
 
 class _FusedConv(torch.autograd.Function):
@@ -744,6 +763,10 @@ class _FusedConv(torch.autograd.Function):
         if post_link is not None and _PREMASK and act == ACT_LRELU and gain == 1.0 and s_out is None and noise is None \
                 and x.dtype == torch.bfloat16:
             post_link.armed, post_link.alpha, post_link.premasked, post_link.pooled = True, float(alpha), False, None
+            ctx.post_link = post_link
+        elif post_link is not None and _PREMASK and _PREMASK_MOD and act == ACT_LRELU and gain == 1.0 and x.dtype == torch.bfloat16 \
+                and s_out is not None:
+            post_link.armed_mod, post_link.alpha, post_link.premasked, post_link.noise, post_link.sums = True, float(alpha), False, noise, None
             ctx.post_link = post_link
         return y if skip_pool is None else (y, tp)
 
@@ -804,6 +827,17 @@ class _FusedConv(torch.autograd.Function):
             g, B = act_bwd_reduce_pooled_raw(pooled[0], y, alpha, pooled[1], need_b and bias is not None)
             if need_b and bias is not None:
                 db = B.sum(0).to(bias.dtype)
+        elif link is not None and link.premasked and link.sums is not None:
+            # modulated chain: the consumer's backward already produced g = dy * lrelu'(y) and this layer's three sums
+            # (agf_act_bwd_reduce_scaled)
+            link.premasked = False
+            g = dy
+            (A, B, Cn), link.sums = link.sums, None
+            if need_b and bias is not None:
+                db = B.sum(0).to(bias.dtype)
+            if s_out is not None and need_so:
+                num = A - (bias.float()[None, :] * B if bias is not None else 0) - (Cn if Cn is not None else 0)
+                dso = num / s_out
         elif link is not None and link.premasked:
             # the consumer's data-gradient launch already applied lrelu'(y) and summed the channels (agf_conv2d_fwd_mask)
             link.premasked = False
@@ -845,6 +879,11 @@ class _FusedConv(torch.autograd.Function):
                 t = conv2d_fwd_raw(g, prep.wq_ft, in_scale=s_out, prepared=True, gain=pg, res_pooled=res_pooled, res_scale=res_scale)
             if s_in is None:
                 dx = t
+            elif pre is not None and pre.armed_mod and need_x and x.dtype == torch.bfloat16 and x.shape[1] % 8 == 0 and dx_pool is None:
+                # x is the lrelu output of the modulated producer this link came from and this conv is its only consumer: one pass gives
+                # this conv's ds and the producer's masked gradient and sums (instead of scale_dot here + act_bwd_reduce there)
+                dx, pre.sums, dsi = act_bwd_reduce_scaled_raw(t, x, pre.noise, s_in, pre.alpha)
+                pre.premasked, pre.noise = True, None
             else:
                 dx, dsi = scale_dot_raw(x, t, s_in, want_dx=need_x)
             if dx_pool is not None and dx is not None:

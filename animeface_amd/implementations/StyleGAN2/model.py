@@ -249,6 +249,7 @@ class StyleBlock(nn.Module):
                 self._f6 = upfirdn2d.setup_filter([1, 5, 10, 10, 5, 1], device=x.device)
             x = up_blur(x, self._f6)
             i = 2
+        link = None          # between consecutive modulated convs of the block: the first one's output has the second as its only consumer
         while i < len(mods):
             m = mods[i]
             if isinstance(m, ModulatedConv2d) and i + 2 < len(mods) + 0 and isinstance(mods[i + 1], InjectNoise) \
@@ -256,8 +257,12 @@ class StyleBlock(nn.Module):
                 # modconv -> +bias -> +noise -> lrelu, noise drawn exactly where the reference draws it
                 s, d = m.scales(y)
                 noise = InjectNoise.draw(x[:, :1])
+                fused = FUSED_EPILOGUE and getattr(self, 'fused_epilogue', True)
+                chained = fused and i + 3 < len(mods) and isinstance(mods[i + 3], ModulatedConv2d)
+                nxt = PremaskLink() if chained else None
                 x = conv2d_act(x, m.weight, m.bias.reshape(-1), s, d, noise, alpha=mods[i + 2].negative_slope,
-                               fused=FUSED_EPILOGUE and getattr(self, 'fused_epilogue', True), coef=m.coef)
+                               fused=fused, coef=m.coef, pre_link=link, post_link=nxt)
+                link = nxt
                 i += 3
             elif isinstance(m, ModulatedConv2d):
                 x = m(x, y)

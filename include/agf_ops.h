@@ -207,6 +207,15 @@ int agf_act_bwd_reduce(const void* dy, const void* y, const float* noise, void* 
                        float* sum_gy0, float* sum_g, float* sum_gnoise,
                        int dtype, int32_t N, int32_t H, int32_t W, int32_t C, float alpha, void* stream);
 
+/* agf_act_bwd_reduce fused with agf_scale_dot (ABI v13): y is the lrelu output of a modulated layer whose ONLY consumer is the next
+ * modulated conv; t is that conv's unscaled data gradient and t_scale [N,C] its style scale.  One pass gives
+ *   sum_yt[n,c] = sum_p y * t            (the consumer's gradient w.r.t. its style scale: what agf_scale_dot returns as ds)
+ *   g           = (t * t_scale[n,c]) * lrelu'(y)   and sum_gy0 / sum_g / sum_gnoise of agf_act_bwd_reduce for the producer,
+ * instead of writing dx = t * t_scale, reading it back and reading y a second time (6 tensor passes -> 3). */
+int agf_act_bwd_reduce_scaled(const void* t, const void* y, const float* noise, const float* t_scale, void* g,
+                              float* sum_gy0, float* sum_g, float* sum_gnoise, float* sum_yt,
+                              int dtype, int32_t N, int32_t H, int32_t W, int32_t C, float alpha, void* stream);
+
 /* agf_act_bwd_reduce for an activation whose only consumer is a 2x2 box average (nn.AvgPool2d(2) after the last LeakyReLU of a DBlock,
  * implementations/StyleGAN2/model.py:204-212): dy_half [N,H/2,W/2,C] is the gradient of the POOLED tensor; every pixel of a 2x2 cell
  * receives dy_half * dy_scale (dy_scale = gain / 4), so g = dy_scale * dy_half[h/2,w/2] * lrelu'(y) and sum_g[n,c] = sum_p g --
