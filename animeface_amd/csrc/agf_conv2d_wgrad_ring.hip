@@ -56,7 +56,7 @@ __global__ void __launch_bounds__(512, 2) conv2d_wgrad_ring_kernel(WgradRingPara
     constexpr int TAPS = 9;
     constexpr int DYR = RING_DYR;
     constexpr int DV = 2, XV = 4;                                        // wave-loads per wave and tile (8 waves: 16 dy, up to 32 x slots)
-    constexpr int LPW = DV + XV;
+    constexpr int LPW = DV + XV + (SC ? 2 : 0);                           // SC: + the two scale vectors of the tile's image
     static_assert(LPW * (NS - 2) <= 63, "vmcnt immediate");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int PW = p.TW + 2, PH = p.TH + 2;
@@ -65,6 +65,7 @@ __global__ void __launch_bounds__(512, 2) conv2d_wgrad_ring_kernel(WgradRingPara
     const int STAGE_E = (2 * DYR + 2 * XR) * 32;                          // elements of one stage: dy [2][DYR][32], x [2][XR][32]
     bf16_t* sBase = (bf16_t*)smem_raw;
     bf16_t* sDummy = sBase + NS * STAGE_E;                                // 1 KB: target of the wave-loads that carry nothing
+    float* sSide = (float*)(sDummy + 512);                                // SC: [NS][2][8 waves][64 lanes] per-lane operand scales of a stage's tile
 
     int bid = blockIdx.x;
     const int ks = bid % p.splitK; bid /= p.splitK;
@@ -128,6 +129,11 @@ __global__ void __launch_bounds__(512, 2) conv2d_wgrad_ring_kernel(WgradRingPara
     // one buffer resource per tensor (the launcher checks that both are below 2 GB)
     const __amdgpu_buffer_rsrc_t dRes = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, RING_OOB, 0x00020000);
     const __amdgpu_buffer_rsrc_t xRes = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, RING_OOB, 0x00020000);
+    // SC: this lane's channel of the A operand (dy: co) and of the B operand (x: ci); tail lanes hold zero fragments: any finite scale
+    const int chA = co0 + wa * 32 + (lane & 31), chB = ci0 + wb * 32 + (lane & 31);
+    const int chAc = chA < p.Cout ? chA : p.Cout - 1, chBc = chB < p.Cin ? chB : p.Cin - 1;
+    const __amdgpu_buffer_rsrc_t aScRes = __builtin_amdgcn_make_buffer_rsrc((void*)p.out_scale, 0, SC ? p.N * p.Cout * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t bScRes = __builtin_amdgcn_make_buffer_rsrc((void*)p.in_scale, 0, SC ? p.N * p.Cin * 4 : 0, 0x00020000);
     auto issue_tile = [&](int pt, bool live, int stage) {
         int tw, th, n;
         if (p.lgTilesW >= 0) { tw = pt & (p.tilesW - 1); th = (pt >> p.lgTilesW) & (p.tilesH - 1); n = pt >> (p.lgTilesW + p.lgTilesH); }
@@ -148,6 +154,16 @@ __global__ void __launch_bounds__(512, 2) conv2d_wgrad_ring_kernel(WgradRingPara
             bf16_t* dst = xLds[i] >= 0 ? sS + xLds[i] : sDummy;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xRes, (lds_ptr)dst, 16, off, 0, 0, 0);
         }
+        if (SC) {
+            // this lane's scale of each operand for the tile's image, as two more DMA operations of the same group: they land with the tile
+            // (a register-carried asynchronous load cannot be made safe here: the compiler may copy the destination register before the
+            //  data has arrived -- it does not know the inline-asm load is one)
+            const int offA = live ? (n * p.Cout + chAc) * 4 : RING_OOB, offB = live ? (n * p.Cin + chBc) * 4 : RING_OOB;
+            float* dA = sSide + ((stage * 2 + 0) * 8 + wave) * 64;
+            float* dB = sSide + ((stage * 2 + 1) * 8 + wave) * 64;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(aScRes, (lds_ptr)dA, 4, offA, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(bScRes, (lds_ptr)dB, 4, offB, 0, 0, 0);
+        }
     };
 
     // work list of this block: with per-image scales a contiguous run of tiles of ONE image, otherwise every splitK-th tile
@@ -165,20 +181,16 @@ __global__ void __launch_bounds__(512, 2) conv2d_wgrad_ring_kernel(WgradRingPara
         issue_tile(ptIssue, ptIssue < ptEnd, stIssue);
         ptIssue += ptStep; stIssue = stIssue + 1 == NS ? 0 : stIssue + 1;
     }
-    // SC: this lane's channel of the A operand (dy: co) and of the B operand (x: ci), and their scales for the first tile's image
-    const int chA = co0 + wa * 32 + (lane & 31), chB = ci0 + wb * 32 + (lane & 31);
-    float scA = 1.f, scB = 1.f;
-    const int chAc = chA < p.Cout ? chA : p.Cout - 1, chBc = chB < p.Cin ? chB : p.Cin - 1;     // (tail lanes hold zero fragments: any finite scale)
-    if (SC && ptBegin < ptEnd) {
-        const int n = ptBegin / tilesPerImage;
-        scA = p.out_scale[(int64_t)n * p.Cout + chAc];
-        scB = p.in_scale[(int64_t)n * p.Cin + chBc];
-    }
     int cur = 0;
     for (int pt = ptBegin; pt < ptEnd; pt += ptStep) {
         asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LPW * (NS - 2)) : "memory");   // this wave's part of tile pt has landed ...
         __builtin_amdgcn_s_barrier();                                            // ... everyone's has, and everyone has left tile pt - 1
         __builtin_amdgcn_sched_barrier(0);
+        float scA = 1.f, scB = 1.f;
+        if (SC) {
+            scA = sSide[((cur * 2 + 0) * 8 + wave) * 64 + lane];
+            scB = sSide[((cur * 2 + 1) * 8 + wave) * 64 + lane];
+        }
         const bf16_t* aCur = sBase + cur * STAGE_E + aOff + (rowStart * p.TW + colHalf * 16) * 32;
         const bf16_t* bCur = sBase + cur * STAGE_E + bOff + (rowStart * PW + colHalf * 16) * 32;
         // Fragment reads: this wave contracts NK k-steps = 16-pixel runs of NK consecutive tile rows at one column offset.  The three
@@ -226,17 +238,6 @@ __global__ void __launch_bounds__(512, 2) conv2d_wgrad_ring_kernel(WgradRingPara
                 acc[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aF[j], __builtin_bit_cast(bf16x8, s2), acc[kh * 3 + 2], 0, 0, 0);
             }
             if (j == 0) {                                                 // the DMA of tile pt + (NS - 1) steps, into the stage tile pt - 1 occupied
-                if (SC) {
-                    // the next tile's scales, requested BEFORE this iteration's DMA group: the partial wait at the top of the next
-                    // iteration (everything but the youngest LPW operations) then covers them
-                    // (inline asm: a compiler-visible load into a loop-carried register gets an `s_waitcnt vmcnt(0)` right behind it --
-                    //  a full drain of the ring.  The explicit wait at the top of the loop is what orders these two loads.)
-                    const int nn = (pt + ptStep < ptEnd ? pt + ptStep : pt) / tilesPerImage;
-                    const float* pa = p.out_scale + (int64_t)nn * p.Cout + chAc;
-                    const float* pb = p.in_scale + (int64_t)nn * p.Cin + chBc;
-                    asm volatile("global_load_dword %0, %1, off" : "=v"(scA) : "v"(pa) : "memory");
-                    asm volatile("global_load_dword %0, %1, off" : "=v"(scB) : "v"(pb) : "memory");
-                }
                 issue_tile(ptIssue, ptIssue < ptEnd, stIssue);
                 ptIssue += ptStep; stIssue = stIssue + 1 == NS ? 0 : stIssue + 1;
             }
@@ -366,7 +367,7 @@ static bool ring_plan(WgradRingParams& p, bool scales, bool both, int N, int H, 
     }
     p.dwNumel = (int64_t)Cout * 9 * Cin;
     const int XR = ((p.TH + 2) * (p.TW + 2) + 15) & ~15;
-    return (size_t)3 * (2 * RING_DYR + 2 * XR) * 32 * sizeof(bf16_t) + 1024 <= 160 * 1024;
+    return (size_t)3 * (2 * RING_DYR + 2 * XR) * 32 * sizeof(bf16_t) + 1024 + 3 * 2 * 8 * 64 * 4 <= 160 * 1024;
 }
 
 // bytes of the [splitK][Cout,3,3,Cin] fp32 scratch of the two-stage combine, 0 = shape not covered
@@ -389,7 +390,7 @@ int agf_conv2d_wgrad_ring_launch(const void* x, const void* dy, float* dw, const
     const int base = p.tilesCo * p.tilesCi;
     constexpr int NS = 3;
     const int XR = ((p.TH + 2) * (p.TW + 2) + 15) & ~15;
-    const size_t lds = (size_t)NS * (2 * RING_DYR + 2 * XR) * 32 * sizeof(bf16_t) + 1024;
+    const size_t lds = (size_t)NS * (2 * RING_DYR + 2 * XR) * 32 * sizeof(bf16_t) + 1024 + (size_t)NS * 2 * 8 * 64 * sizeof(float);
     const int realQ = (Cout > 32 ? 2 : 1) * (Cin > 32 ? 2 : 1);
     const bool sc = (in_scale || out_scale) && !p.epiScale;
     void (*kern)(WgradRingParams) = realQ == 4 ? (sc ? conv2d_wgrad_ring_kernel<NS, 4, true> : conv2d_wgrad_ring_kernel<NS, 4, false>)

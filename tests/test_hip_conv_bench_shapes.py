@@ -70,3 +70,30 @@ def test_conv_weight_gradient_at_bench_shapes_vs_cpu(shape):
         ref += gw
     err = (dw.float().cpu() - ref).abs().max() / ref.abs().max()
     assert float(err) < 2e-3, float(err)                                 # fp32 accumulation of exact bf16 products: summation order only
+
+
+@pytest.mark.parametrize('shape', [(64, 512, 512, 16, 16), (64, 512, 256, 32, 32), (64, 64, 32, 256, 256)],
+                         ids=lambda s: f'N{s[0]}_{s[1]}to{s[2]}_{s[3]}x{s[4]}')
+def test_modulated_weight_gradient_at_bench_shapes_vs_cpu_and_bitwise_reproducible(shape):
+    """The generator's weight gradients carry per-image scales on both operands: blocks that stay inside one image scale their partial
+    sums (256x256 maps), blocks that span images scale the fragments in registers (16x16 / 32x32 maps at batch 64).  The two-stage
+    split-K combine has no atomics: two launches give the same bits."""
+    from animeface_amd.implementations.StyleGAN2.conv import conv2d_wgrad_raw
+    N, Cin, Cout, H, W = shape
+    x, _, _ = _mk(N, Cin, Cout, H, W, 5)
+    g = torch.Generator().manual_seed(6)
+    dy = torch.randn(N, Cout, H, W, generator=g).to(torch.bfloat16)
+    s_in, s_out = torch.rand(N, Cin, generator=g) + 0.5, torch.rand(N, Cout, generator=g) + 0.5
+    xd, dyd = x.to(DEV).contiguous(memory_format=torch.channels_last), dy.to(DEV).contiguous(memory_format=torch.channels_last)
+    dw = conv2d_wgrad_raw(xd, dyd, 3, in_scale=s_in.to(DEV), out_scale=s_out.to(DEV))
+    dw2 = conv2d_wgrad_raw(xd, dyd, 3, in_scale=s_in.to(DEV), out_scale=s_out.to(DEV))
+    assert torch.equal(dw, dw2)
+    wz = torch.zeros(Cout, Cin, 3, 3, requires_grad=True)
+    ref = torch.zeros(Cout, Cin, 3, 3)
+    for n0 in range(0, N, 8):
+        xs = x[n0:n0 + 8].float() * s_in[n0:n0 + 8, :, None, None]
+        ds = dy[n0:n0 + 8].float() * s_out[n0:n0 + 8, :, None, None]
+        (gw,) = torch.autograd.grad(F.conv2d(xs, wz, padding=1), wz, ds)
+        ref += gw
+    err = (dw.float().cpu() - ref).abs().max() / ref.abs().max()
+    assert float(err) < 8e-3, float(err)             # the in-register path rounds the scaled operands to bf16, as the forward conv does
