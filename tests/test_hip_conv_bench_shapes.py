@@ -36,6 +36,12 @@ def test_conv_forward_at_bench_shapes_vs_cpu(shape, modulated):
     y = conv2d_fwd_raw(x.to(DEV).contiguous(memory_format=torch.channels_last), w.to(DEV), in_scale=None if s_in is None else s_in.to(DEV),
                        out_scale=None if s_out is None else s_out.to(DEV), bias=b.to(DEV), noise=None if nz is None else nz.to(DEV),
                        act=ACT_LRELU, alpha=0.2)
+    # no atomics on this path: a second launch must give the same bits (a race in the hand-counted vmcnt / barrier protocol of the
+    # streaming kernels would show up here long before it shows up in a tolerance)
+    y2 = conv2d_fwd_raw(x.to(DEV).contiguous(memory_format=torch.channels_last), w.to(DEV), in_scale=None if s_in is None else s_in.to(DEV),
+                        out_scale=None if s_out is None else s_out.to(DEV), bias=b.to(DEV), noise=None if nz is None else nz.to(DEV),
+                        act=ACT_LRELU, alpha=0.2)
+    assert torch.equal(y, y2)
     torch.cuda.synchronize()
     sample = sorted({0, 1, N // 2, N - 1})
     xs = x[sample].float()
@@ -63,6 +69,8 @@ def test_conv_weight_gradient_at_bench_shapes_vs_cpu(shape):
     g = torch.Generator().manual_seed(4)
     dy = torch.randn(N, Cout, H, W, generator=g).to(torch.bfloat16)
     dw = conv2d_wgrad_raw(x.to(DEV).contiguous(memory_format=torch.channels_last), dy.to(DEV).contiguous(memory_format=torch.channels_last), 3)
+    assert torch.equal(dw, conv2d_wgrad_raw(x.to(DEV).contiguous(memory_format=torch.channels_last),
+                                            dy.to(DEV).contiguous(memory_format=torch.channels_last), 3))       # two-stage combine: no atomics
     wz = torch.zeros(Cout, Cin, 3, 3, requires_grad=True)
     ref = torch.zeros(Cout, Cin, 3, 3)
     for n0 in range(0, N, 8):                                            # in chunks: bounded host memory
