@@ -335,3 +335,25 @@ def test_dblock_linked_backward_matches_unlinked(monkeypatch):
     assert rel(outs[0][0], outs[1][0]) == 0
     for a, b in zip(outs[0][1], outs[1][1]):
         assert rel(a, b) < 2e-2, (a.shape, rel(a, b))
+
+
+@pytest.mark.parametrize('seed', range(10))
+def test_conv_wgrad_random_shapes_vs_aten(seed):
+    """Random map sizes / channel counts / scales through whichever weight-gradient kernel the launcher picks (ring with whole or ragged
+    tiles, 4x32 or 8x16 tile shape, shift or division tile decode, scales on the partial sums or on the fragments, padded small-map
+    scheme): every edge flag and tail path sees odd numbers."""
+    from animeface_amd.implementations.StyleGAN2.conv import conv2d_wgrad_raw
+    rs = torch.Generator().manual_seed(100 + seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=rs))
+    N, Cin, Cout, H, W = ri(1, 6), 8 * ri(1, 17), 8 * ri(1, 17), ri(5, 70), ri(5, 70)
+    scaled = seed % 2 == 1
+    x = torch.randn(N, Cin, H, W, generator=rs).to(torch.bfloat16).to(DEV).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(N, Cout, H, W, generator=rs).to(torch.bfloat16).to(DEV).contiguous(memory_format=torch.channels_last)
+    s_in = (torch.rand(N, Cin, generator=rs) + 0.5).to(DEV) if scaled else None
+    s_out = (torch.rand(N, Cout, generator=rs) + 0.5).to(DEV) if scaled else None
+    dw = conv2d_wgrad_raw(x, dy, 3, in_scale=s_in, out_scale=s_out, scale=1.5)
+    xf = x.float() * (s_in[:, :, None, None] if scaled else 1.0)
+    dyf = dy.float() * (s_out[:, :, None, None] if scaled else 1.0)
+    wz = torch.zeros(Cout, Cin, 3, 3, device=DEV, requires_grad=True)
+    (ref,) = torch.autograd.grad(F.conv2d(xf, wz, padding=1), wz, dyf)
+    assert rel(dw, ref * 1.5) < (8e-3 if scaled else 1e-3), (N, Cin, Cout, H, W, scaled, rel(dw, ref * 1.5))
