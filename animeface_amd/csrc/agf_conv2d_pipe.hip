@@ -8,7 +8,9 @@
 //     NSTAGE LDS buffers filled by `buffer_load ... lds`: the loads of the next tile's first chunks are in flight while the current
 //     tile is contracted and stored -- NSTAGE-1 stages (~3 x 38 KB per CU) of look-ahead everywhere;
 //   * waits are partial: `s_waitcnt vmcnt(N)` with N = the number of vector-memory operations this wave issued AFTER the stage it
-//     needs (memory operations retire in order on gfx9-class hardware, so the N youngest may stay in flight).  For N to be a
+//     needs (LOADS retire in order among themselves, so the N youngest loads may stay in flight; the tile's stores are not counted
+//     among those N -- a store may be acknowledged before an older load returns -- which makes the wait exact when no store is pending
+//     and early otherwise: measured cost 0-4 % per launch).  For N to be a
 //     compile-time constant every operation is issued unconditionally: DMA beyond the work list, absent epilogue operands and
 //     out-of-image pixels use out-of-range buffer offsets (loads return zeros, stores are dropped); the chunk loop is unrolled
 //     (NCH = Cin / 16 is a template parameter) and `__builtin_amdgcn_sched_barrier` pins the issue order the counts assume;
@@ -32,6 +34,7 @@ struct PipeParams {
     int tilesWl2, tilesHl2;     // log2(tiles per row), log2(tiles per column) of one image
     int band;                   // pixel tiles per XCD (contiguous)
     long long wImgStride;       // elements between per-image weight tensors (0 = one shared tensor)
+    int countStores;            // A/B: count a tile's stores among the operations a partial wait leaves in flight (see the wait)
     int dbg;                    // timing experiments (AGF_PIPE_DBG): bits 0-1: 1 = no epilogue at all, 2 = stores of zeros without the epilogue arithmetic; +4: weight DMA out of range (zero fill, no memory traffic); +8: the same for the activations
 };
 
@@ -361,8 +364,15 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_pipe_kernel(Pipe
             constexpr int ch = decltype(chc)::value;
             // wait for this wave's loads of stage (t, ch), then for everyone's; after the barrier buffer (buf - 1) is free again
             if (t < TCONS) { if (hiWave) pipe_wait_vm<(NSTAGE - 2) * LPW_HI>(); else pipe_wait_vm<(NSTAGE - 2) * LPW_LO>(); }
-            else if (hiWave) pipe_wait_vm<pipe_younger<NCH, NSTAGE>(ch, LPW_HI, PCNT, SCNT, PF)>();
-            else pipe_wait_vm<pipe_younger<NCH, NSTAGE>(ch, LPW_LO, PCNT, SCNT, PF)>();
+            // (stores are NOT counted among the operations that may stay in flight: loads retire in order among themselves, but the ISA does
+            //  not promise that a younger store cannot be acknowledged before an older load returns -- counting the tile's 2*MT*NJ stores as
+            //  "still outstanding" would let the wait pass with the stage's loads pending.  With S = 0 the wait is exact when no store is
+            //  pending and merely earlier-than-needed (it also drains the stores) otherwise.  AGF_PIPE_COUNT_STORES=1: the old count, A/B.)
+            else if (pp.countStores) {
+                if (hiWave) pipe_wait_vm<pipe_younger<NCH, NSTAGE>(ch, LPW_HI, PCNT, SCNT, PF)>();
+                else pipe_wait_vm<pipe_younger<NCH, NSTAGE>(ch, LPW_LO, PCNT, SCNT, PF)>();
+            } else if (hiWave) pipe_wait_vm<pipe_younger<NCH, NSTAGE>(ch, LPW_HI, PCNT, 0, PF)>();
+            else pipe_wait_vm<pipe_younger<NCH, NSTAGE>(ch, LPW_LO, PCNT, 0, PF)>();
             // a bare s_barrier: __syncthreads() adds a workgroup fence that the compiler lowers to `s_waitcnt vmcnt(0)` -- a full drain of
             // the pipeline.  Nothing more is needed here: a wave's DMA data is in LDS once ITS vmcnt says so (the wait above), its
             // fragment reads of the previous stage were consumed by MFMAs before it arrived.
@@ -540,6 +550,8 @@ static int pipe_launch(const ConvParams& p0, int64_t wImgStride, hipStream_t st)
     pp.wImgStride = wImgStride;
     static const int pipe_dbg = []{ const char* e = getenv("AGF_PIPE_DBG"); return e ? atoi(e) : 0; }();
     pp.dbg = pipe_dbg;
+    static const int cnt_st = []{ const char* e = getenv("AGF_PIPE_COUNT_STORES"); return e ? atoi(e) : 0; }();
+    pp.countStores = cnt_st;
     static const int ws_on = []{ const char* e = getenv("AGF_PIPE_WS"); return e ? atoi(e) : 1; }();
     if (ws_on && wImgStride == 0 && p.Cin <= 64) {       // shared weights that fit next to the activation ring: loaded once per block
         if (p.Cout > 32) {
