@@ -1935,6 +1935,58 @@ static int launch_wgrad(const WgradParams& p, size_t lds, hipStream_t st) {
     return AGF_OK;
 }
 
+// Weight gradient of the pointwise conv from 8 input channels (FromRGB: RGB padded to 8 -> 32 channels at 256x256, batch 128):
+// dw[co][ci] = sum_pixels dy[p][co] * x[p][ci] is a streaming reduction (704 MB read for 256 results); the MFMA kernel ran it at 2 TB/s
+// (0.34 ms).  A lane owns one group of 8 output channels and walks pixels with four 16-byte loads of each operand in flight, an 8 x 8
+// block of accumulators in registers; the block's pixel lanes are reduced through LDS and one atomic per (co, ci) and block is issued.
+__global__ void __launch_bounds__(256) conv2d_wgrad_pw8_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, float* __restrict__ dw,
+                                                               int Cout, int G, int64_t pixels, float scale) {
+    __shared__ float red[256][65];
+    const int64_t t0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int g = (int)(t0 % G);
+    const int64_t pstride = ((int64_t)gridDim.x * 256) / G;
+    float acc[8][8];
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+#pragma unroll
+        for (int c = 0; c < 8; c++) acc[j][c] = 0.f;
+    constexpr int U = 4;
+    for (int64_t pix0 = t0 / G; pix0 < pixels; pix0 += U * pstride) {
+        u32x4 rx[U], rd[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int64_t pix = pix0 + u * pstride;
+            rx[u] = rd[u] = u32x4{0u, 0u, 0u, 0u};
+            if (pix < pixels) { rx[u] = *(const u32x4*)(x + pix * 8); rd[u] = *(const u32x4*)(dy + pix * Cout + 8 * g); }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            float xv[8], dv[8];
+            Pack16<bf16_t>::unpack(rx[u].x, xv[0], xv[1]); Pack16<bf16_t>::unpack(rx[u].y, xv[2], xv[3]);
+            Pack16<bf16_t>::unpack(rx[u].z, xv[4], xv[5]); Pack16<bf16_t>::unpack(rx[u].w, xv[6], xv[7]);
+            Pack16<bf16_t>::unpack(rd[u].x, dv[0], dv[1]); Pack16<bf16_t>::unpack(rd[u].y, dv[2], dv[3]);
+            Pack16<bf16_t>::unpack(rd[u].z, dv[4], dv[5]); Pack16<bf16_t>::unpack(rd[u].w, dv[6], dv[7]);
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+#pragma unroll
+                for (int c = 0; c < 8; c++) acc[j][c] = fmaf(dv[j], xv[c], acc[j][c]);
+        }
+    }
+    // threads tid, tid + G, tid + 2G ... hold the same channel group: 256 / G pixel lanes per group
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+#pragma unroll
+        for (int c = 0; c < 8; c++) red[threadIdx.x][j * 8 + c] = acc[j][c];
+    __syncthreads();
+    // 64 * G results per block: thread r = (group, j, c) sums its group's pixel lanes
+    for (int r = threadIdx.x; r < 64 * G; r += 256) {
+        const int gg = r >> 6, e = r & 63;
+        float v = 0.f;
+        for (int l = gg; l < 256; l += G) v += red[l][e];
+        unsafeAtomicAdd(dw + (8 * gg + (e >> 3)) * 8 + (e & 7), v * scale);
+    }
+}
+
 static int conv2d_wgrad_impl(const void* x, const void* dy, float* dw,
                              const float* in_scale, const float* out_scale,
                              int dtype, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
@@ -1963,6 +2015,19 @@ static int conv2d_wgrad_impl(const void* x, const void* dy, float* dw,
     AGF_CHECK(ksize == 1 || ksize == 3, "conv2d_wgrad: kernel size must be 1 or 3 (got %d)", ksize);
     AGF_CHECK(Cin % 8 == 0 && Cout % 8 == 0, "conv2d_wgrad: Cin and Cout must be multiples of 8 (pad the channel axis)");
     AGF_CHECK(((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0 && ((uintptr_t)dw % 4) == 0, "conv2d_wgrad: misaligned pointer");
+    {
+        // pointwise conv from 8 input channels on a large map without scales: the streaming reduction (see conv2d_wgrad_pw8_kernel)
+        static const bool pw8 = []{ const char* e = getenv("AGF_WGRAD_PW8"); return !(e && e[0] == '0'); }();
+        if (pw8 && dtype == AGF_BF16 && ksize == 1 && Cin == 8 && Cout >= 8 && Cout <= 64 && Cout % 8 == 0 && (256 % (Cout / 8)) == 0 && !in_scale && !out_scale &&
+            (int64_t)N * H * W >= 65536 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0) {
+            const int G = Cout / 8;
+            const int64_t pixels = (int64_t)N * H * W;
+            hipLaunchKernelGGL(conv2d_wgrad_pw8_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)dy, dw, Cout, G,
+                               pixels, scale);
+            AGF_LAUNCH_CHECK();
+            return AGF_OK;
+        }
+    }
     if (ksize == 3) {
         const int rc = agf_conv2d_wgrad_ring_launch(x, dy, dw, in_scale, out_scale, N, H, W, Cin, Cout, scale, (float*)workspace, workspace_bytes,
                                                     (workspace && dw_layout_out) ? 1 : 0, (hipStream_t)stream);

@@ -161,6 +161,8 @@ WGRAD_CASES = [
     (16, 512, 512, 4, 4, 3, 'padded staging (4x4 maps)'),
     (6, 256, 128, 8, 8, 3, 'padded staging (8x8 maps)'),
     (4, 64, 8, 64, 64, 1, '1x1'),
+    (5, 8, 32, 128, 128, 1, '1x1 from 8 channels (streaming reduction)'),
+    (3, 8, 64, 160, 144, 1, '1x1 from 8 channels, 64 outputs'),
     (3, 32, 32, 64, 64, 3, 'ring: one quadrant, k split over the eight waves'),
     (2, 128, 72, 16, 16, 3, 'ring: 8x16 tiles, output-channel tail'),
     (5, 64, 32, 128, 128, 3, 'ring: odd batch, blocks inside one image when scaled'),
