@@ -279,13 +279,16 @@ class GraphedTrainStep:
         the optimizer step is recorded, as ``GradReducer.finish()`` does in the eager loop)."""
         st = self.step
         g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g1, pool=self.pool):
+        # (thread_local: the process group's watchdog thread polls the events of earlier collectives; under the default global capture
+        #  mode such a call from another thread invalidates the capture)
+        mode = dict(pool=self.pool, capture_error_mode='thread_local')
+        with torch.cuda.graph(g1, **mode):
             d_loss = st._seg1(self.static_real, it)
         st.reducer_D.detach_untouched()
-        with torch.cuda.graph(g2, pool=self.pool):
+        with torch.cuda.graph(g2, **mode):
             g_loss, fake = st._seg2(self.static_real, it)
         st.reducer_G.detach_untouched()
-        with torch.cuda.graph(g3, pool=self.pool):
+        with torch.cuda.graph(g3, **mode):
             st._seg3()
         return (g1, g2, g3), (d_loss, g_loss, fake)
 
