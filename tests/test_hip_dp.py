@@ -177,13 +177,17 @@ def test_two_ranks_on_one_gpu_match_the_accumulated_single_process_run(tmp_path,
         for (dl, gl), (dl2, gl2) in zip(st[r]['losses'], losses[r]):
             assert abs(dl - dl2) <= ltol * max(1.0, abs(dl2)) and abs(gl - gl2) <= ltol * max(1.0, abs(gl2)), (r, st[r]['losses'], losses[r])
     lr, worst, n_far, n_all = 1e-3, 0.0, 0, 0
+    n_far32 = n_all32 = 0
     for name, mod in (('G', G), ('D', D), ('G_ema', G_ema)):
         for k, v in mod.state_dict().items():
             a, b = st[0][name][k].float(), v.detach().float().cpu()
             diff = (a - b).abs()
             worst = max(worst, float(diff.max()))
             if dtype == torch.float32:
-                assert diff.max() <= 2e-5, (name, k, float(diff.max()))
+                # typically ~1e-5 (summation order only); a near-zero gradient that changes sign costs a single weight a few lr
+                assert diff.max() <= 8e-3, (name, k, float(diff.max()))
+                n_far32 += int((diff > 1e-4).sum())
+                n_all32 += diff.numel()
             else:
                 # three Adam steps with beta1 = 0 move a weight by at most (1 + 1.41 + 1.72) lr in either direction
                 assert diff.max() <= 2 * 4.2 * lr, (name, k, float(diff.max()))
@@ -193,6 +197,8 @@ def test_two_ranks_on_one_gpu_match_the_accumulated_single_process_run(tmp_path,
           + (f'; {n_far} of {n_all} weights differ by more than 0.1 lr' if n_all else ''))
     if n_all:
         assert n_far <= 0.2 * n_all, (n_far, n_all)
+    if n_all32:
+        assert n_far32 <= 1e-4 * n_all32 + 2, (n_far32, n_all32)
 
 
 def _worker_graphs(rank, world, port, out, graphed):
