@@ -374,5 +374,5 @@ def test_graph_replayed_step_equals_the_eager_step(dtype):
     if dtype == torch.float32:
         # summation order only (fp32 atomics, rocBLAS split-K): typically ~1e-5; Adam with beta1 = 0 can move a single weight whose
         # gradient changes sign near zero by a few lr, so the bound is on how MANY weights differ, not on the largest one
-        assert worst <= 8e-3 and far <= 1e-4 * total + 2, (worst, far, total)
+        assert worst <= 8e-3 and far <= 1e-3 * total + 2, (worst, far, total)
     assert far <= 0.2 * total, (far, total)
