@@ -34,6 +34,7 @@ struct PipeParams {
     int tilesWl2, tilesHl2;     // log2(tiles per row), log2(tiles per column) of one image
     int band;                   // pixel tiles per XCD (contiguous)
     long long wImgStride;       // elements between per-image weight tensors (0 = one shared tensor)
+    int yPix;                   // elements per pixel of y (= Cout unless this launch writes a channel slice of a wider tensor: EPI 0 only)
     int countStores;            // A/B: count a tile's stores among the operations a partial wait leaves in flight (see the wait)
     int dbg;                    // timing experiments (AGF_PIPE_DBG): bits 0-1: 1 = no epilogue at all, 2 = stores of zeros without the epilogue arithmetic; +4: weight DMA out of range (zero fill, no memory traffic); +8: the same for the activations
 };
@@ -197,7 +198,7 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_pipe_kernel(Pipe
             const int q = wn * (32 * NJ) + j * 32 + l31;
             const int h = h0 + (q >> p.twShift), w = w0 + (q & (p.TW - 1));
             const bool valid = h < p.H && w < p.W;
-            pixOff[j] = valid ? (h * p.W + w) * p.Cout * 2 : PIPE_OOB;
+            pixOff[j] = valid ? (h * p.W + w) * pp.yPix * 2 : PIPE_OOB;
             hw2[j] = valid ? ((h >> 1) * (p.W >> 1) + (w >> 1)) * p.Cout * 2 : PIPE_OOB;
             if (EPI == 0) {
                 const __amdgpu_buffer_rsrc_t nRes = __builtin_amdgcn_make_buffer_rsrc((void*)(p.noise + (int64_t)n0 * p.H * p.W), 0, p.noise ? p.H * p.W * 4 : 0, 0x00020000);
@@ -225,7 +226,7 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_pipe_kernel(Pipe
     auto epilogue = [&](int ord, const bf16_t* stage) {
         const int pt = tFirst + ord * nPer;
         const int n0 = pt >> (pp.tilesWl2 + pp.tilesHl2);
-        const __amdgpu_buffer_rsrc_t yRes = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (int64_t)n0 * p.H * p.W * p.Cout), 0, p.H * p.W * p.Cout * 2, 0x00020000);
+        const __amdgpu_buffer_rsrc_t yRes = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (int64_t)n0 * p.H * p.W * pp.yPix), 0, p.H * p.W * pp.yPix * 2, 0x00020000);
         const float* side = (const float*)(stage + SIDE_E);         // [2][64]: out_scale[n0], bias (landed with this stage)
         if ((pp.dbg & 3) == 1) return;
         if ((pp.dbg & 3) == 2) {
@@ -474,9 +475,28 @@ static bool pipe_covers(int N, int H, int W, int Cin, int Cout) {
     return (int64_t)H * W * (Cin > Cout ? Cin : Cout) * 2 < 0x60000000ll;
 }
 
-static int pipe_launch(const ConvParams& p0, int64_t wImgStride, hipStream_t st);
+static int pipe_launch(const ConvParams& p0, int64_t wImgStride, hipStream_t st, int yPix = 0);
 
-int agf_conv2d_pipe_launch(const ConvParams& p0, hipStream_t st) { return pipe_launch(p0, 0, st); }
+int agf_conv2d_pipe_launch(const ConvParams& p0, hipStream_t st) {
+    // 128 output channels from 32 / 64 inputs on a streaming-size map (the discriminator's 64 -> 128 conv at 128x128): the 8-wave
+    // 128-channel kernel has only 2-4 K chunks per tile to amortise its prologue and epilogue over (590 TFLOP/s); two launches of this
+    // kernel, one per 64-channel half of the weights, each writing its channel slice of y, are faster (the second reads x from L2 / MALL)
+    static const int split = []{ const char* e = getenv("AGF_PIPE_SPLIT128"); return e ? atoi(e) : 1; }();
+    if (split && p0.Cout == 128 && (p0.Cin == 32 || p0.Cin == 64) && !p0.mask_y && !p0.res_pooled && !p0.out_scale && !p0.in_scale && !p0.residual &&
+        !p0.noise && ((uintptr_t)p0.y % 16) == 0 && pipe_covers(p0.N, p0.H, p0.W, p0.Cin, 64)) {
+        for (int half = 0; half < 2; half++) {
+            ConvParams q = p0;
+            q.Cout = 64;
+            q.w = p0.w + (int64_t)half * 64 * 9 * p0.Cin;
+            q.y = p0.y + half * 64;
+            q.bias = p0.bias ? p0.bias + half * 64 : nullptr;
+            const int rc = pipe_launch(q, 0, st, 128);
+            if (rc != AGF_OK) return half == 0 ? rc : AGF_ELAUNCH;
+        }
+        return AGF_OK;
+    }
+    return pipe_launch(p0, 0, st);
+}
 
 // wmod[n][co][tap][ci] = w[co][tap][ci] * s[n][ci]: the style modulation folded into one weight tensor per image (what the reference
 // materialises as `weight * style`, implementations/StyleGAN2/model.py:115 -- here only for the few-channel layers, a few MB)
@@ -530,7 +550,7 @@ extern "C" int agf_conv2d_fwd_wimg(const void* x, const void* w, void* y, const 
     return AGF_OK;
 }
 
-static int pipe_launch(const ConvParams& p0, int64_t wImgStride, hipStream_t st) {
+static int pipe_launch(const ConvParams& p0, int64_t wImgStride, hipStream_t st, int yPix) {
     // covered: 3x3, one co tile (Cout <= 64), Cin in {32, 64, 128}, maps that 16x32 pixel tiles cover with power-of-two tile counts,
     // no input scale (style-modulated layers come with per-image weights instead), no residual operand
     static const int mode = []{ const char* e = getenv("AGF_CONV_PIPE"); return e ? atoi(e) : 1; }();
@@ -548,6 +568,8 @@ static int pipe_launch(const ConvParams& p0, int64_t wImgStride, hipStream_t st)
     pp.tilesHl2 = 0; while ((1 << pp.tilesHl2) < p.tilesH) pp.tilesHl2++;
     pp.band = (p.pixTiles + 7) / 8;
     pp.wImgStride = wImgStride;
+    pp.yPix = yPix ? yPix : p.Cout;
+    if (pp.yPix != p.Cout && (p.mask_y || p.res_pooled || p.out_scale || wImgStride)) return AGF_ENOKERNEL;
     static const int pipe_dbg = []{ const char* e = getenv("AGF_PIPE_DBG"); return e ? atoi(e) : 0; }();
     pp.dbg = pipe_dbg;
     static const int cnt_st = []{ const char* e = getenv("AGF_PIPE_COUNT_STORES"); return e ? atoi(e) : 0; }();

@@ -12,7 +12,8 @@ DEV = 'cuda'
 
 # (N, Cin, Cout, H, W): forward / data-gradient shapes of the 256x256 step
 FWD_SHAPES = [(64, 512, 512, 32, 32), (128, 512, 512, 16, 16), (64, 256, 256, 64, 64), (64, 128, 128, 128, 128), (128, 64, 64, 256, 256),
-              (64, 64, 32, 256, 256), (64, 32, 32, 256, 256), (128, 32, 64, 256, 256), (64, 512, 512, 4, 4), (128, 256, 512, 32, 32)]
+              (64, 64, 32, 256, 256), (64, 32, 32, 256, 256), (128, 32, 64, 256, 256), (64, 512, 512, 4, 4), (128, 256, 512, 32, 32),
+              (128, 64, 128, 128, 128)]
 
 
 def _mk(N, Cin, Cout, H, W, seed):
