@@ -24,6 +24,9 @@ struct ActBwdParams {
     float* sumD;              //   the consumer's modulated conv, dscale = its style scale s); sumD[n,c] += sum_p y * dy  (= that conv's d s)
 };
 
+#ifndef ACTBWD_U
+#define ACTBWD_U 2          // (4 measured the same: the kernel is not short of loads in flight)
+#endif
 template <class T, int VEC, bool SCALED = false>
 __global__ void __launch_bounds__(256) act_bwd_reduce_kernel(ActBwdParams p) {
     __shared__ float red[SCALED ? 4 : 3][256][VEC + 1];
@@ -42,35 +45,34 @@ __global__ void __launch_bounds__(256) act_bwd_reduce_kernel(ActBwdParams p) {
     const bool active = pl < p.pixLanes;
     if (active) {
         const int64_t base = (int64_t)n * p.HW * p.C + cg * VEC;
-        // two pixels per iteration: four independent 16-byte loads in flight per lane (the single-pixel loop ran at 51-64 % of HBM)
-        for (int px = p0 + pl; px < p1; px += 2 * p.pixLanes) {
-            const int px2 = px + p.pixLanes;
-            const bool two = px2 < p1;
-            float dy[2][VEC], y[2][VEC], g[VEC];
-            if (p.pooled) {
-                // the adjoint of the 2x2 average fused in: no full-resolution gradient tensor is ever written / re-read
-                const int h = px / p.W, w = px - h * p.W;
-                VecIO<T, VEC>::load((const T*)p.dy + ((int64_t)n * (p.HW >> 2) + (h >> 1) * (p.W >> 1) + (w >> 1)) * p.C + cg * VEC, dy[0]);
-                if (two) {
-                    const int h2 = px2 / p.W, w2 = px2 - h2 * p.W;
-                    VecIO<T, VEC>::load((const T*)p.dy + ((int64_t)n * (p.HW >> 2) + (h2 >> 1) * (p.W >> 1) + (w2 >> 1)) * p.C + cg * VEC, dy[1]);
+        // U pixels per iteration: 2 U independent 16-byte loads in flight per lane (the single-pixel loop ran at 51-64 % of HBM)
+        constexpr int U = ACTBWD_U;
+        for (int px0 = p0 + pl; px0 < p1; px0 += U * p.pixLanes) {
+            float dy[U][VEC], y[U][VEC], g[VEC];
+            float nzv[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int px = px0 + u * p.pixLanes;
+                if (px >= p1) break;
+                if (p.pooled) {
+                    // the adjoint of the 2x2 average fused in: no full-resolution gradient tensor is ever written / re-read
+                    const int h = px / p.W, w = px - h * p.W;
+                    VecIO<T, VEC>::load((const T*)p.dy + ((int64_t)n * (p.HW >> 2) + (h >> 1) * (p.W >> 1) + (w >> 1)) * p.C + cg * VEC, dy[u]);
+                } else {
+                    VecIO<T, VEC>::load((const T*)p.dy + base + (int64_t)px * p.C, dy[u]);
                 }
-            } else {
-                VecIO<T, VEC>::load((const T*)p.dy + base + (int64_t)px * p.C, dy[0]);
-                if (two) VecIO<T, VEC>::load((const T*)p.dy + base + (int64_t)px2 * p.C, dy[1]);
+                VecIO<T, VEC>::load((const T*)p.y + base + (int64_t)px * p.C, y[u]);
+                nzv[u] = p.noise ? p.noise[(int64_t)n * p.HW + px] : 0.f;
             }
-            VecIO<T, VEC>::load((const T*)p.y + base + (int64_t)px * p.C, y[0]);
-            if (two) VecIO<T, VEC>::load((const T*)p.y + base + (int64_t)px2 * p.C, y[1]);
-            if (p.pooled) {
 #pragma unroll
-                for (int i = 0; i < VEC; i++) { dy[0][i] *= p.dy_scale; dy[1][i] *= p.dy_scale; }
-            }
-            const float nz0 = p.noise ? p.noise[(int64_t)n * p.HW + px] : 0.f;
-            const float nz1 = (p.noise && two) ? p.noise[(int64_t)n * p.HW + px2] : 0.f;
+            for (int u = 0; u < U; u++) {
+                const int px = px0 + u * p.pixLanes;
+                if (px >= p1) break;
+                if (p.pooled) {
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
-                if (u == 1 && !two) break;
-                const float nz = u ? nz1 : nz0;
+                    for (int i = 0; i < VEC; i++) dy[u][i] *= p.dy_scale;
+                }
+                const float nz = nzv[u];
 #pragma unroll
                 for (int i = 0; i < VEC; i++) {
                     const bool pos = y[u][i] > 0.f;
@@ -79,7 +81,7 @@ __global__ void __launch_bounds__(256) act_bwd_reduce_kernel(ActBwdParams p) {
                     const float y0 = pos ? y[u][i] : y[u][i] * p.inv_alpha;
                     a[i] += g[i] * y0; b[i] += g[i]; c[i] += g[i] * nz;
                 }
-                VecIO<T, VEC>::store((T*)p.g + base + (int64_t)(u ? px2 : px) * p.C, g);
+                VecIO<T, VEC>::store((T*)p.g + base + (int64_t)px * p.C, g);
             }
         }
     }
