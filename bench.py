@@ -268,6 +268,13 @@ def main():
                     continue
                 plain_ms += sum(a.elapsed_time(b) for a, b, _ in recs)
                 plain_fl += sum(f for _, _, f in recs)
+            # the launches that are MFMA-bound by arithmetic intensity (3x3, >= 128 channels on both sides: > 500 flop per HBM byte) --
+            # the average over ALL conv launches also contains the 1x1 and few-channel launches, which are HBM-bound
+            big_ms = big_fl = 0.0
+            for key, recs in timer.by_shape.items():
+                if key[0] == 'conv2d_fwd_kernel' and key[6] == 3 and min(key[2], key[3]) >= 128:
+                    big_ms += sum(a.elapsed_time(b) for a, b, _ in recs)
+                    big_fl += sum(f for _, _, f in recs)
             if k:
                 out['roofline'] = {'kernel': 'conv2d_fwd* (MFMA implicit-GEMM 3x3/1x1 conv, every instantiation: generic, 8-wave, weight-stationary, ping-pong; forward + data-gradient launches)',
                                    'bound': 'mfma', 'achieved': round(k['tflops'], 2), 'peak': MFMA_BF16_PEAK / 1e12,
@@ -284,7 +291,9 @@ def main():
                                                                                     'note': 'conv launches of one lazy-R1 iteration (double backward), sampled after the timed window'})(
                                        timer_r1.summary().get('conv2d_fwd_kernel') if timer_r1 is not None else None),
                                    'launches_with_fused_gradient_epilogue': fused_n,
-                                   'achieved_plain_launches': round(plain_fl / (plain_ms * 1e-3) / 1e12, 2) if plain_ms > 0 else None}
+                                   'achieved_plain_launches': round(plain_fl / (plain_ms * 1e-3) / 1e12, 2) if plain_ms > 0 else None,
+                                   'achieved_3x3_ge128_channels': round(big_fl / (big_ms * 1e-3) / 1e12, 2) if big_ms > 0 else None,
+                                   'share_3x3_ge128_channels': round(big_ms / max(k['total_ms'], 1e-9), 3) if big_ms > 0 else None}
             if os.environ.get('AGF_BENCH_SHAPES') == '1':        # per-shape table of the sampled launches (diagnosis)
                 rows = []
                 for key, recs in timer.by_shape.items():
