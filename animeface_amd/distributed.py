@@ -28,11 +28,15 @@ def init_distributed():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if os.environ.get('AGF_SINGLE_DEVICE') == '1':
         local_rank = 0                      # test hook: several ranks share GPU 0 (needs the gloo backend)
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get('AGF_FORCE_DP') == '1'   # test hook: a ONE-rank process group, so that the RCCL path (process group, watchdog
+    #                                                  thread, exchange between graph launches) can be exercised on a single-GPU box
+    if (world > 1 or force) and not dist.is_initialized():
         backend = os.environ.get('AGF_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         if torch.cuda.is_available():
             torch.cuda.set_device(local_rank)
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if force:
+            os.environ.setdefault('MASTER_PORT', '29531')
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local_rank
 
@@ -44,6 +48,7 @@ class GradReducer:
         they sit in back until ``finish()`` (no overlap at all for the generator); they get a bucket of their own instead."""
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.collectives = self.world > 1 or (dist.is_initialized() and os.environ.get('AGF_FORCE_DP') == '1')
         self.params = [p for p in params if p.requires_grad]
         self.buckets = []          # each: dict(flat, params, pending, work)
         self._hooks = []
@@ -72,7 +77,7 @@ class GradReducer:
     def _make_bucket(self, plist):
         n = sum(p.numel() for p in plist)
         flat = torch.zeros(n, dtype=torch.float32, device=plist[0].device)
-        b = dict(flat=flat, params=plist, views=[], pending=len(plist), work=None, launched=False, early=False)
+        b = dict(flat=flat, params=plist, views=[], pending=len(plist), work=None, launched=False, early=False, packed=False)
         off = 0
         for p in plist:
             assert p.dtype == torch.float32
@@ -91,6 +96,7 @@ class GradReducer:
             bucket['pending'] -= 1
             if bucket['pending'] == 0 and self.early:
                 bucket['early'] = True
+                self._pack(bucket)
                 self._launch(bucket)
         return hook
 
@@ -98,7 +104,7 @@ class GradReducer:
         if bucket['launched']:
             return
         bucket['launched'] = True
-        if self.world > 1:
+        if self.collectives:
             if dist.get_backend(self.group) == 'nccl':
                 # RCCL averages inside the reduction: no extra pass over the bucket
                 bucket['work'] = dist.all_reduce(bucket['flat'], op=dist.ReduceOp.AVG, group=self.group, async_op=True)
@@ -107,18 +113,40 @@ class GradReducer:
                 bucket['work'] = dist.all_reduce(bucket['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def zero_grad(self):
-        """Zero the flat buffers and point every ``param.grad`` at its view again (``finish()`` detaches the gradients of parameters
-        that received none; ``set_to_none`` must not be used with this reducer)."""
+        """``grad = None`` for every parameter: the backward pass then hands each gradient tensor over as it is (no accumulation launch
+        per parameter into the bucket -- ~500 small adds per iteration for the two StyleGAN2 networks); ``_pack`` moves the gradients
+        of a complete bucket into its flat buffer with ONE multi-tensor copy and re-points ``param.grad`` at the bucket views.  The slice
+        of a parameter that receives no gradient keeps stale (finite) values; it is all-reduced and never read (``grad`` stays None)."""
         for b in self.buckets:
-            b['flat'].zero_()
             b['pending'] = len(b['params'])
             b['work'] = None
             b['launched'] = False
             b['early'] = False
-            for p, v in zip(b['params'], b['views']):
-                if p.grad is not v:
-                    p.grad = v
+            b['packed'] = False
+            for p in b['params']:
+                p.grad = None
         self._touched.clear()
+
+    def _pack(self, bucket):
+        if bucket['packed']:
+            return
+        bucket['packed'] = True
+        src, dst = [], []
+        for p, v in zip(bucket['params'], bucket['views']):
+            g = p.grad
+            if g is None or g is v:
+                continue
+            src.append(g.detach())
+            dst.append(v)
+            p.grad = v
+        if src:
+            torch._foreach_copy_(dst, src)
+
+    def pack_all(self):
+        """Graph-replayed training: called at the end of the captured backward segment, so the copies into the buckets are part of the
+        graph and the optimizer step recorded later reads the bucket views."""
+        for b in self.buckets:
+            self._pack(b)
 
     def finish(self):
         """Launch incomplete buckets (parameters without gradient this step), wait for all of them, and give the parameters that
@@ -132,6 +160,7 @@ class GradReducer:
         for b in self.buckets:
             self.stats['buckets_from_hooks' if b['early'] else 'buckets_at_finish'] += 1
             if not b['launched']:
+                self._pack(b)
                 self._launch(b)
         for b in self.buckets:
             if b['work'] is not None:

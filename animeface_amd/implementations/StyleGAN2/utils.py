@@ -154,6 +154,8 @@ class TrainStep:
                 self._plan_D.run()
             with zero_arena(self._arena_D, real.device):
                 D_loss = self._d_half(real, it)
+        if self.reducer_D is not None:
+            self.reducer_D.pack_all()               # gradients -> bucket buffers (one multi-tensor copy per bucket, inside the graph)
         return D_loss.detach()
 
     def _seg2(self, real, it):
@@ -169,6 +171,8 @@ class TrainStep:
                 G_loss, fake = self._g_half(real, it)
             for p in D.parameters():
                 p.requires_grad_(True)
+        if self.reducer_G is not None:
+            self.reducer_G.pack_all()
         return G_loss.detach(), fake
 
     def _seg3(self):

@@ -107,13 +107,14 @@ def main():
     G_ema.eval()
     update_ema(G, G_ema, decay=0)
     dp.broadcast_module(G), dp.broadcast_module(G_ema), dp.broadcast_module(D)
-    use_graphs = (not args.eager) and args.augment != 'ada' and (world == 1 or os.environ.get('AGF_DP_GRAPHS', '0') == '1')
+    dp_on = world > 1 or dist.is_initialized()           # (AGF_FORCE_DP=1: a one-rank RCCL group, to exercise the path on a single-GPU box)
+    use_graphs = (not args.eager) and args.augment != 'ada' and (not dp_on or os.environ.get('AGF_DP_GRAPHS', '0') == '1')
     # (several ranks: AGF_DP_GRAPHS=1 replays three graphs per iteration with the gradient all-reduce between the launches -- tested with two
     #  ranks on one GPU over gloo (tests/test_hip_dp.py), never yet on RCCL hardware, hence opt-in; the default there is the eager loop whose
     #  all-reduce overlaps the backward pass)
     opt_G, opt_D = U.build_optimizers(G, D, 0.001, (0., 0.99), 10., 0., 16, 8, capturable=use_graphs)
-    red_G = dp.GradReducer(G.parameters(), never_used=dp.never_used_parameters(G)) if world > 1 else None
-    red_D = dp.GradReducer(D.parameters()) if world > 1 else None
+    red_G = dp.GradReducer(G.parameters(), never_used=dp.never_used_parameters(G)) if dp_on else None
+    red_D = dp.GradReducer(D.parameters()) if dp_on else None
     for red in (red_G, red_D):
         if red is not None:
             red.measure = True
@@ -140,7 +141,7 @@ def main():
     torch.manual_seed(1234 + rank)
 
     def barrier():
-        if world > 1:
+        if dp_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -156,7 +157,7 @@ def main():
         except Exception as exc:                   # noqa: BLE001 -- any capture failure means: run eagerly
             print(f'[bench] rank {rank}: graph capture failed ({type(exc).__name__}: {exc}); eager launches', file=sys.stderr)
             ok = 0
-        if world > 1:
+        if dp_on:
             flag = torch.tensor([ok], device=dev, dtype=torch.int32)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             ok = int(flag.item())
@@ -193,7 +194,7 @@ def main():
     if step_times:
         print('cumulative ms after each step:', step_times, file=sys.stderr)
     C.KernelTimer.active = None
-    if world > 1:
+    if dp_on:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -229,7 +230,7 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'bf16', 'data': 'synthetic', 'execution': ('hip-graph replay (eager on the event-timed steps)' + (': three graphs per iteration, gradient all-reduce between the launches' if world > 1 else '')) if use_graphs else 'eager launches',
+            'dtype': 'bf16', 'data': 'synthetic', 'execution': ('hip-graph replay (eager on the event-timed steps)' + (': three graphs per iteration, gradient all-reduce between the launches' if dp_on else '')) if use_graphs else 'eager launches',
             'config': {'workload': f'StyleGAN2 {S}x{S} G+D+lazy-R1 training step, batch {args.batch}/GPU '
                                    f'(BASELINE.json configs[2]: channels 32, max 512, style 512, d_k 16, r1_lambda 10, '
                                    + ('ADA pipe (12 augmentations, adaptive p)' if args.augment == 'ada' else f'DiffAugment {args.augment} = the reference SG2 default; --augment ada selects the ADA pipe') + ', Adam, EMA)',
@@ -240,7 +241,7 @@ def main():
         if r1_ms is not None:
             out['r1_every_step'] = {'value': round(args.batch * world / (r1_ms * 1e-3), 2), 'unit': 'img/s', 'ms_per_step': round(r1_ms, 3),
                                     'note': 'the lazy-R1 iteration (penalty replaces the GAN loss) on every step: 4 steps after the timed window'}
-        if world > 1:
+        if dp_on:
             # what the exchange looked like: RCCL ranks, buckets launched from backward hooks (overlappable) vs. at finish(), and the time
             # the compute stream waited for the exchange (exposed); hidden = the rest of the all-reduce time
             out['rccl'] = {'rccl_ranks': world, 'backend': dist.get_backend(),
@@ -310,8 +311,13 @@ def main():
                                          'share_of_step_time': round(kw['total_ms'] / (dt * 1e3 * sampled_steps / args.steps), 4)}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(S)
+        if dp_on:
+            # RCCL writes its version banner through C stdio, which is flushed at exit -- after Python's line.  Flush it now so that the
+            # JSON line is the LAST line of stdout
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dp_on:
         dist.barrier()
         dist.destroy_process_group()
 
