@@ -450,7 +450,7 @@ static void launch_planar(UpfirdnParams p, hipStream_t st) {
 // peak in bf16.
 constexpr int pv_floor_div(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 
-template <class T, int UP, int DN, int FW, int FH, int PAD0, int ROWS, int PM>
+template <class T, int UP, int DN, int FW, int FH, int PAD0, int ROWS, int PM, int PF>
 static __device__ __forceinline__ void planar_vec_body(const UpfirdnParams& p, const float* sf, const T* xb, T* yb, int g, int oy0, int iyBase) {
     constexpr int VEC = 16 / sizeof(T);
     constexpr int OV = UP > 1 ? VEC * UP : VEC;                       // output columns of a lane
@@ -470,7 +470,7 @@ static __device__ __forceinline__ void planar_vec_body(const UpfirdnParams& p, c
 #pragma unroll
         for (int o = 0; o < OV; o++) acc[e][o] = 0.f;
     typedef u32x4 raw_t;
-    raw_t nxt[NV];
+    raw_t buf[PF][NV];                                                // PF input rows in flight per lane (bytes in flight per CU bound the rate)
     auto fetch = [&](int r, raw_t (&dst)[NV]) {
         int iy = iyBase + r;
         const bool rowOk = p.clamp_edge || (iy >= 0 && iy < p.H);
@@ -485,10 +485,13 @@ static __device__ __forceinline__ void planar_vec_body(const UpfirdnParams& p, c
             dst[d] = t;
         }
     };
-    fetch(0, nxt);
+#pragma unroll
+    for (int r = 0; r < PF; r++)
+        if (r < NR) fetch(r, buf[r]);
 #pragma unroll
     for (int r = 0; r < NR; r++) {
         float row[NV * VEC];
+        raw_t (&nxt)[NV] = buf[r % PF];
 #pragma unroll
         for (int d = 0; d < NV; d++) {
             if constexpr (sizeof(T) == 4) {
@@ -509,7 +512,7 @@ static __device__ __forceinline__ void planar_vec_body(const UpfirdnParams& p, c
                 }
             }
         }
-        if (r + 1 < NR) fetch(r + 1, nxt);
+        if (r + PF < NR) fetch(r + PF, nxt);
 #pragma unroll
         for (int e = 0; e < ROWS; e++) {
             constexpr int dummy = 0; (void)dummy;
@@ -546,7 +549,7 @@ static __device__ __forceinline__ void planar_vec_body(const UpfirdnParams& p, c
     }
 }
 
-template <class T, int UP, int DN, int FW, int FH, int PAD0, int ROWS>
+template <class T, int UP, int DN, int FW, int FH, int PAD0, int ROWS, int PF>
 __global__ void __launch_bounds__(256) upfirdn2d_planar_vec(UpfirdnParams p, int groups, int strips) {
     __shared__ float sf[FH * FW];
     stage_filter<256>(p, sf);
@@ -565,8 +568,8 @@ __global__ void __launch_bounds__(256) upfirdn2d_planar_vec(UpfirdnParams p, int
     const int pm = midy0 - iyBase * UP;
     const T* xb = (const T*)p.x + plane * p.H * p.W;
     T* yb = (T*)p.y + plane * p.OH * p.OW;
-    if (UP == 1 || pm == 0) planar_vec_body<T, UP, DN, FW, FH, PAD0, ROWS, 0>(p, sf, xb, yb, g, oy0, iyBase);
-    else planar_vec_body<T, UP, DN, FW, FH, PAD0, ROWS, (UP >= 2 ? 1 : 0)>(p, sf, xb, yb, g, oy0, iyBase);
+    if (UP == 1 || pm == 0) planar_vec_body<T, UP, DN, FW, FH, PAD0, ROWS, 0, PF>(p, sf, xb, yb, g, oy0, iyBase);
+    else planar_vec_body<T, UP, DN, FW, FH, PAD0, ROWS, (UP >= 2 ? 1 : 0), PF>(p, sf, xb, yb, g, oy0, iyBase);
 }
 
 template <class T>
@@ -575,29 +578,33 @@ static bool launch_planar_vec_cases(const UpfirdnParams& p, hipStream_t st) {
     constexpr int VEC = 16 / sizeof(T);
     if (!on || p.upx != p.upy || p.downx != p.downy || p.fw != p.fh || p.upx > 2) return false;
     if (p.W % VEC || ((uintptr_t)p.x % 16) || ((uintptr_t)p.y % 16)) return false;
-#define PVEC_CASE(U_, D_, F_, P_, R_)                                                                                          \
+#define PVEC_CASE(U_, D_, F_, P_, R_, PF_)                                                                                        \
     if (p.upx == U_ && p.downx == D_ && p.fw == F_ && p.padx0 == P_) {                                                          \
         constexpr int OV = U_ > 1 ? VEC * U_ : VEC;                                                                             \
         if (p.OW % OV) return false;                                                                                            \
         const int groups = p.OW / OV, strips = (p.OH + R_ - 1) / R_;                                                            \
         const int64_t threads = (int64_t)groups * strips * p.N * p.C;                                                           \
         if (threads >= (1ll << 38)) return false;                                                                               \
-        hipLaunchKernelGGL((upfirdn2d_planar_vec<T, U_, D_, F_, F_, P_, R_>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, \
+        hipLaunchKernelGGL((upfirdn2d_planar_vec<T, U_, D_, F_, F_, P_, R_, PF_>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, \
                            p, groups, strips);                                                                                  \
         return true; }
-    static const int rowsSel = []{ const char* e = getenv("AGF_PVEC_ROWS"); return e ? atoi(e) : 0; }();     // A/B: rows per lane
-    if (rowsSel == 2) {
-        PVEC_CASE(2, 1, 4, 2, 2) PVEC_CASE(1, 1, 3, 1, 2) PVEC_CASE(1, 2, 2, 0, 2) PVEC_CASE(1, 2, 4, 1, 2) PVEC_CASE(2, 1, 2, 1, 2)
-    } else if (rowsSel == 8) {
-        PVEC_CASE(2, 1, 4, 2, 8) PVEC_CASE(1, 1, 3, 1, 8) PVEC_CASE(1, 2, 2, 0, 8) PVEC_CASE(1, 2, 4, 1, 4) PVEC_CASE(2, 1, 2, 1, 8)
-    } else if (rowsSel == 1) {
-        PVEC_CASE(2, 1, 4, 2, 2) PVEC_CASE(1, 1, 3, 1, 1) PVEC_CASE(1, 2, 2, 0, 1) PVEC_CASE(1, 2, 4, 1, 1) PVEC_CASE(2, 1, 2, 1, 2)
+    static const int pfSel = []{ const char* e = getenv("AGF_PVEC_PF"); return e ? atoi(e) : 0; }();         // A/B: input rows in flight per lane
+    if (pfSel == 1) {
+        PVEC_CASE(2, 1, 4, 2, 4, 1) PVEC_CASE(1, 1, 3, 1, 4, 1) PVEC_CASE(1, 2, 2, 0, 4, 1) PVEC_CASE(1, 2, 4, 1, 2, 1) PVEC_CASE(2, 1, 2, 1, 4, 1)
+    } else if (pfSel == 2) {
+        PVEC_CASE(2, 1, 4, 2, 4, 2) PVEC_CASE(1, 1, 3, 1, 4, 2) PVEC_CASE(1, 2, 2, 0, 4, 2) PVEC_CASE(1, 2, 4, 1, 2, 2) PVEC_CASE(2, 1, 2, 1, 4, 2)
+    } else if (pfSel == 3) {
+        PVEC_CASE(2, 1, 4, 2, 4, 3) PVEC_CASE(1, 1, 3, 1, 4, 3) PVEC_CASE(1, 2, 2, 0, 4, 3) PVEC_CASE(1, 2, 4, 1, 2, 3) PVEC_CASE(2, 1, 2, 1, 4, 3)
+    } else if (pfSel == 4) {
+        PVEC_CASE(2, 1, 4, 2, 4, 4) PVEC_CASE(1, 1, 3, 1, 4, 4) PVEC_CASE(1, 2, 2, 0, 4, 4) PVEC_CASE(1, 2, 4, 1, 2, 4) PVEC_CASE(2, 1, 2, 1, 4, 4)
     }
-    PVEC_CASE(2, 1, 4, 2, 4)      // 2x upsample [1,3,3,1]
-    PVEC_CASE(1, 1, 3, 1, 4)      // blur [1,2,1]
-    PVEC_CASE(1, 2, 2, 0, 4)      // 2x2 average pooling
-    PVEC_CASE(1, 2, 4, 1, 2)      // 2x downsample [1,3,3,1]
-    PVEC_CASE(2, 1, 2, 1, 4)      // adjoint of the average pooling
+    // (rows in flight: measured per case with tools/bench_planar.py -- bf16 up2 0.49 -> 0.53 of the HBM peak with 2, down2 f4 0.42 -> 0.48
+    //  with 4; the blur and the pooling are best with 1)
+    PVEC_CASE(2, 1, 4, 2, 4, 2)      // 2x upsample [1,3,3,1]
+    PVEC_CASE(1, 1, 3, 1, 4, 1)      // blur [1,2,1]
+    PVEC_CASE(1, 2, 2, 0, 4, 1)      // 2x2 average pooling
+    PVEC_CASE(1, 2, 4, 1, 2, 4)      // 2x downsample [1,3,3,1]
+    PVEC_CASE(2, 1, 2, 1, 4, 1)      // adjoint of the average pooling
 #undef PVEC_CASE
     return false;
 }
