@@ -159,7 +159,8 @@ WGRAD_CASES = [
     (2, 72, 40, 19, 38, 3, 'ragged map, channel tails'),
     (8, 32, 64, 256, 256, 3, 'large map: blocks inside one image'),
     (16, 512, 512, 4, 4, 3, 'padded staging (4x4 maps)'),
-    (6, 256, 128, 8, 8, 3, 'padded staging (8x8 maps)'),
+    (6, 256, 128, 8, 8, 3, 'ring: 8x8 maps, one half-empty tile per image'),
+    (24, 128, 192, 8, 8, 3, 'ring: 8x8 maps, split over the images'),
     (4, 64, 8, 64, 64, 1, '1x1'),
     (5, 8, 32, 128, 128, 1, '1x1 from 8 channels (streaming reduction)'),
     (3, 8, 64, 160, 144, 1, '1x1 from 8 channels, 64 outputs'),
