@@ -129,15 +129,19 @@ def main():
     # final size before anything is timed.  Without it the first R1 iteration of a fresh process costs 150-350 ms instead of 84 ms
     # (tools/step_times.py) and, with W < 16, lands inside the timed window.  The real models / optimizers are untouched.
     import copy
-    sG, sGe, sD = copy.deepcopy(G), copy.deepcopy(G_ema), copy.deepcopy(D)
-    soG, soD = U.build_optimizers(sG, sD, 0.001, (0., 0.99), 10., 0., 16, 8)
-    scratch = U.TrainStep(sG, sGe, sD, soG, soD, 10., 0., 16, 8, args.augment, 512, functools.partial(sample_nnoise, device=dev))
-    scratch(real)
-    scratch.batches_done = 16
-    scratch(real)
-    scratch(real)
-    torch.cuda.synchronize()
-    del scratch, sG, sGe, sD, soG, soD
+    if os.environ.get('AGF_BENCH_NO_LOAD_PHASE') == '1':     # tools/pmc_bench_traffic.sh: only GAN-loss iterations under the counters
+        copy = None
+    sG, sGe, sD = (copy.deepcopy(G), copy.deepcopy(G_ema), copy.deepcopy(D)) if copy else (None, None, None)
+    if copy:
+        soG, soD = U.build_optimizers(sG, sD, 0.001, (0., 0.99), 10., 0., 16, 8)
+        scratch = U.TrainStep(sG, sGe, sD, soG, soD, 10., 0., 16, 8, args.augment, 512, functools.partial(sample_nnoise, device=dev))
+        scratch(real)
+        scratch.batches_done = 16
+        scratch(real)
+        scratch(real)
+        torch.cuda.synchronize()
+        del scratch, soG, soD
+    del sG, sGe, sD
     torch.manual_seed(1234 + rank)
 
     def barrier():
