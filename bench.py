@@ -255,12 +255,14 @@ def main():
             summ = timer.summary()
             k = summ.get('conv2d_fwd_kernel')
             traffic = measured_traffic()
-            # algorithmic HBM bytes of a launch: activations in + out, weights once (bf16)
+            # algorithmic HBM bytes of a launch: activations in + out, weights once (bf16); a launch with the fused gradient epilogue also reads its
+            # lrelu mask once (the pass it replaces would read it too)
             alg = {}
             for key, recs in timer.by_shape.items():
                 name, n, cin, cout, h, w, ks = key[:7]
                 alg.setdefault(name, [0, 0])
-                alg[name][0] += len(recs) * (n * h * w * (cin + cout) * 2 + cout * cin * ks * ks * 2)
+                fused = name == 'conv2d_fwd_kernel' and len(key) > 8 and key[8]      # + the lrelu mask the fused gradient epilogue reads (as large as y)
+                alg[name][0] += len(recs) * (n * h * w * (cin + cout + (cout if fused else 0)) * 2 + cout * cin * ks * ks * 2)
                 alg[name][1] += len(recs)
             # conv launches WITHOUT a fused gradient epilogue (agf_conv2d_fwd_mask folds the lrelu-gradient pass, the skip-branch add and
             # the pooling adjoint of the layer below into the data-gradient launch: those launches do more than their conv flops)
