@@ -226,6 +226,13 @@ def main():
         r1_ms = (time.perf_counter() - t1) / n_r1 * 1e3
         step.batches_done = saved
 
+    if dp_on:
+        # RCCL writes its version banner through C stdio, which a process flushes at exit -- after rank 0's JSON line.  Every rank flushes
+        # now, before rank 0 prints, so that the JSON line is the LAST line of the job's stdout
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        sys.stdout.flush()
+        dist.barrier()
     if rank == 0:
         out = {
             'metric': f'images/sec (G+D+R1 step) StyleGAN2 {S}x{S} bf16',
@@ -317,11 +324,6 @@ def main():
                                          'share_of_step_time': round(kw['total_ms'] / (dt * 1e3 * sampled_steps / args.steps), 4)}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(S)
-        if dp_on:
-            # RCCL writes its version banner through C stdio, which is flushed at exit -- after Python's line.  Flush it now so that the
-            # JSON line is the LAST line of stdout
-            import ctypes
-            ctypes.CDLL(None).fflush(None)
         print(json.dumps(out), flush=True)
     if dp_on:
         dist.barrier()
