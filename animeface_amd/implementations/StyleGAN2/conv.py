@@ -342,13 +342,13 @@ class _ConvWgrad(torch.autograd.Function):
         return gx, gdy, gsi, gso, None
 
 
-def _pad_channels(t, mult, dim):
+def _pad_channels(t, mult, dim, value=0.0):
     c = t.shape[dim]
     extra = (-c) % mult
     if extra == 0:
         return t
     pad = [0, 0] * (t.dim() - dim - 1) + [0, extra]
-    return torch.nn.functional.pad(t, pad)
+    return torch.nn.functional.pad(t, pad, value=value)
 
 
 def conv2d(x, w, s_in=None, s_out=None):
@@ -362,7 +362,9 @@ def conv2d(x, w, s_in=None, s_out=None):
         xp = _pad_channels(x, 8, 1)
         wp = _pad_channels(_pad_channels(w, 8, 1), 8, 0)
         si = _pad_channels(s_in, 8, 1) if s_in is not None else None
-        so = _pad_channels(s_out, 8, 1) if s_out is not None else None
+        # (output scale of the padded channels: 1, not 0 -- its gradient is  sum(dy * y) / s_out,  and in a double backward pass the 0 / 0 of
+        #  a zero pad turns into NaNs that the zero weights of the padded channels do not stop: NaN * 0 inside the MFMA)
+        so = _pad_channels(s_out, 8, 1, value=1.0) if s_out is not None else None
         return _ConvFwd.apply(xp.contiguous(memory_format=torch.channels_last), wp, si, so)[:, :Cout]
     return _ConvFwd.apply(x, w, s_in, s_out)
 

@@ -122,19 +122,21 @@ def test_r1_and_path_length_double_backward_vs_reference(golden, dtype, tol):
     grads = torch.autograd.grad(r1, [pd[k] for k in names])
     for k, gr in zip(names, grads):
         assert relerr(gr, t(g['r1grad/' + k])) < tol * 2, k
-    if dtype == torch.float32:
-        G.set_fused_epilogue(False)          # the path-length penalty differentiates G twice
-        with ReplayNoise(M, [t(g[f'pl_noise{i}']) for i in range(4)]):
-            fake, style = G(t(g['pl_z']).to(DEV))
-        with rng.cpu_stream():
-            torch.manual_seed(11)
-            pl = U.pl_penalty(style, fake, 0.3, None)
-        assert abs(pl.item() - float(g['pl'])) < 2e-3 * abs(float(g['pl']))
-        names = [k[len('plgrad/'):] for k in g if k.startswith('plgrad/')]
-        pg = dict(G.named_parameters())
-        grads = torch.autograd.grad(pl, [pg[k] for k in names])
-        for k, gr in zip(names, grads):
-            assert relerr(gr, t(g['plgrad/' + k])) < 5e-3, k
+    # the path-length penalty differentiates G twice: the generator runs its unfused composite (MFMA convs in bf16, differentiable to any
+    # order); bf16 activations bound the agreement with the fp32 reference
+    G.set_fused_epilogue(False)
+    with ReplayNoise(M, [t(g[f'pl_noise{i}']) for i in range(4)]):
+        fake, style = G(t(g['pl_z']).to(DEV))
+    with rng.cpu_stream():
+        torch.manual_seed(11)
+        pl = U.pl_penalty(style, fake, 0.3, None)
+    pl_tol, grad_tol = (2e-3, 5e-3) if dtype == torch.float32 else (0.05, 0.3)        # measured in bf16: 0.8 % / 0.18
+    assert abs(pl.item() - float(g['pl'])) < pl_tol * abs(float(g['pl']))
+    names = [k[len('plgrad/'):] for k in g if k.startswith('plgrad/')]
+    pg = dict(G.named_parameters())
+    grads = torch.autograd.grad(pl, [pg[k] for k in names])
+    for k, gr in zip(names, grads):
+        assert relerr(gr, t(g['plgrad/' + k])) < grad_tol, k
 
 
 def test_train_loop_replays_the_references_train(golden):
@@ -193,6 +195,30 @@ def test_bf16_training_step_runs_and_stays_finite():
         dl, gl, fake = step(real)
         assert torch.isfinite(dl) and torch.isfinite(gl) and torch.isfinite(fake).all()
     assert all(torch.isfinite(p).all() for p in list(G.parameters()) + list(D.parameters()))
+
+
+def test_bf16_training_with_path_length_regularisation_stays_finite():
+    """The lazy path-length iterations in the bf16 training path (second-order terms through the MFMA convs, channel counts padded to
+    8: a zero pad of the demodulation scale once turned its 0 / 0 gradient into NaNs in every generator gradient)."""
+    import functools
+    from animeface_amd.implementations.StyleGAN2 import utils as U
+    from animeface_amd.nnutils import sample_nnoise, update_ema
+    torch.manual_seed(0)
+    M, G, D = build(torch.bfloat16)
+    _, G_ema, _ = build(torch.bfloat16)
+    G.init_weight(functools.partial(M.init_weight_N01, lr=0.01), M.init_weight_N01)
+    D.apply(M.init_weight_N01)
+    update_ema(G, G_ema, decay=0)
+    opt_G, opt_D = U.build_optimizers(G, D, 0.001, (0., 0.99), 10., 2., 2, 2)
+    step = U.TrainStep(G, G_ema, D, opt_G, opt_D, 10., 2., 2, 2, 'color,translation', TINY['style_dim'],
+                       functools.partial(sample_nnoise, device=DEV))
+    real = (torch.rand(8, 3, 16, 16) * 2 - 1).to(DEV)
+    for _ in range(5):                                   # iterations 2 and 4 carry the R1 and the path-length penalties
+        d_loss, g_loss, _ = step(real)
+        assert torch.isfinite(d_loss).all() and torch.isfinite(g_loss).all()
+    for name, p in list(G.named_parameters()) + list(D.named_parameters()):
+        assert torch.isfinite(p).all(), name
+    assert np.isfinite(step.pl_mean) and step.pl_mean > 0
 
 
 def test_checkpoint_resume_continues_the_run(tmp_path):
