@@ -111,18 +111,25 @@ def test_bf16_backward_tracks_the_fp32_reference(golden):
         assert cos > 0.97, (k, cos)
 
 
-def test_r1_double_backward_vs_reference(golden):
+@pytest.mark.parametrize('dtype,tol,gtol', [(torch.float32, 1e-3, 1e-3), (torch.bfloat16, 0.1, 0.3)])
+def test_r1_double_backward_vs_reference(golden, dtype, tol, gtol):
     from animeface_amd.nnutils.loss import r1_regularizer
     g = golden('sg3_model')
-    M, G, D = build(torch.float32)
+    M, G, D = build(dtype)
     D.load_state_dict(sub(g, 'D/'))
     r1 = r1_regularizer()(t(g['real']).to(DEV), D, None)
-    assert abs(r1.item() - float(g['r1'])) < 1e-3 * abs(float(g['r1']))
+    assert abs(r1.item() - float(g['r1'])) < tol * abs(float(g['r1']))
     r1.backward()
     pd = dict(D.named_parameters())
+    # (bf16: 2-13 % on the weights; gradients 100x below the others -- one bias at 3e-7 -- are rounding noise and only bounded absolutely)
+    top = max(float(t(g[k]).abs().max()) for k in g if k.startswith('r1grad/'))
     for k in g:
         if k.startswith('r1grad/'):
-            assert relerr(pd[k[len('r1grad/'):]].grad, t(g[k])) < 1e-3, k
+            got, ref = pd[k[len('r1grad/'):]].grad, t(g[k])
+            if dtype == torch.float32 or float(ref.abs().max()) > 0.02 * top:
+                assert relerr(got, ref) < gtol, k
+            else:
+                assert float((got.float().cpu() - ref).abs().max()) < 0.02 * top, k
 
 
 def test_train_loop_replays_the_references_train(golden):
