@@ -42,5 +42,5 @@ def main(parser, dataset=None):
     if args.max_iters < 0:
         args.max_iters = len(dataset) * args.default_epochs
     return train(args.max_iters, dataset, args.latent_dim, const_input, G, G_ema, D, optimizer_G, optimizer_D,
-                 args.gp_lambda, args.gp_every, augment, device, amp, args.save, args.logfile,
+                 args.gp_lambda, args.gp_every, augment, device, amp, args.save, args.logfile, log_every=args.log_every,
                  reducer_G=reducer_G, reducer_D=reducer_D)

@@ -184,6 +184,7 @@ SG3_ARGS = dict(
     gp_lambda=[3., 'lambda for r1'],
     gp_every=[16, 'calc penalty every'],
     policy=['color,translation', 'policy for DiffAugment'],
+    log_every=[50, 'iterations between log lines (losses, img/s); not a flag of the reference'],
     logfile=[str, 'log file'])
 
 
@@ -212,5 +213,5 @@ def main(parser, dataset=None):
         args.max_iters = len(dataset) * args.default_epochs
     augment = functools.partial(DiffAugment, policy=args.policy)
     return train(args.max_iters, dataset, args.latent_dim, const_input, G, G_ema, D, optimizer_G, optimizer_D,
-                 args.gp_lambda, args.gp_every, augment, device, amp, args.save, args.logfile,
+                 args.gp_lambda, args.gp_every, augment, device, amp, args.save, args.logfile, log_every=args.log_every,
                  reducer_G=reducer_G, reducer_D=reducer_D)
