@@ -63,9 +63,14 @@ class ZeroArena:
 
     def __init__(self):
         self.buf, self.off, self.want, self.high = None, 0, 0, 0
+        self._in_graphs = []          # buffers whose address a captured graph replays: never returned to the allocator
 
     def reset(self, device):
-        if self.buf is None or self.want > self.buf.numel() or self.buf.device != device:
+        capturing = torch.cuda.is_current_stream_capturing()
+        if capturing and self.buf is not None and not any(b is self.buf for b in self._in_graphs):
+            self._in_graphs.append(self.buf)
+        if self.buf is None or (self.want > self.buf.numel() and not capturing) or self.buf.device != device:
+            # (never re-allocated while a graph is being recorded: requests beyond the capacity become recorded fills of the graph's pool)
             n = max(int(self.want * 1.1) + 4096, 1 << 20)
             self.buf = torch.zeros(n, dtype=torch.float32, device=device)
             self.high = 0
@@ -73,6 +78,10 @@ class ZeroArena:
             # everything ever handed out from this buffer, not only the previous pass's share: the passes that alternate on one arena
             # (GAN-loss and lazy-R1 iterations) use different amounts, and a captured graph replays the extent it was recorded with
             self.high = max(self.high, self.off)
+            if capturing:
+                # a recorded memset must cover whatever ANY pass recorded later takes from this buffer (the lazy-R1 pass takes more
+                # than the GAN-loss pass captured before it, and Python's reset() never runs again under replay): the whole buffer
+                self.high = self.buf.numel()
             if self.high:
                 self.buf[:self.high].zero_()
         self.off, self.want = 0, 0

@@ -7,7 +7,8 @@ One "step" = one iteration of the reference loop (implementations/StyleGAN2/util
 d_k = 16 iterations, replacing the GAN loss) + G-step + EMA, DiffAugment 'color,translation', batch 64 per GPU,
 synthetic uniform [-1,1] images resident in HBM, random-init weights of the exact 256x256 architecture.
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline     -- the dominant kernel (the MFMA conv) timed per launch with HIP events inside the timed region
+  roofline     -- the dominant kernel (the MFMA conv) timed per launch with HIP events on one eager iteration right after the timed window
+  step_ms      -- per-iteration GPU time inside the window (p50 / max / all)
   cpu_baseline -- the CPU oracle (a port of the reference's pure-PyTorch path) timed on this box's host cores
 """
 import argparse
@@ -171,37 +172,53 @@ def main():
                 if red is not None:
                     red.early = os.environ.get('AGF_DP_EARLY', '1') != '0'
         eager_step.batches_done = 0
+    if use_graphs:
+        # one untimed replay of EACH captured graph: the first launch of a graph uploads its ~1 500 nodes to the device, a one-off cost that
+        # would otherwise sit inside the timed window for the lazy-R1 graph (first replayed at iteration 16).  The replays are ordinary
+        # training iterations of the (synthetic) run; the iteration counter is rewound so the timed window keeps its place in the schedule.
+        for it in (1, 16):
+            step.step.batches_done = it
+            step(real)
+        torch.cuda.synchronize()
+        eager_step.batches_done = 0
     for _ in range(args.warmup):
         step(real)
-    # per-launch HIP events on the MFMA kernels for the roofline numbers.  A graph replay has no host-side launch points to bracket, so a
-    # sampled step runs eagerly -- ~48 ms instead of ~40 (it is bound by the host issuing ~2 100 launches and ~800 event records).  They
-    # are therefore recorded on the FIRST timed step only (the launches of the other GAN-loss steps are identical); the launches of a
-    # lazy-R1 iteration are sampled on the first of the R1 iterations that follow the timed window (`roofline.r1_iteration`).
-    # (Round 1 sampled every 4th step: with graph replay in between that cost 3-5 ms per step of the headline number.)
-    timer = None if args.no_kernel_timer else C.KernelTimer()
+    # The timed window holds NOTHING but the K iterations: one host call per iteration under graph replay, plus one event record between
+    # iterations (free: no synchronisation) from which the per-step distribution (`step_ms`) is read after the window -- a one-off stall of
+    # the box shows up there as max >> p50 instead of silently inflating the mean.  The per-launch event timing of the MFMA kernels
+    # (roofline numbers) needs eager launches (a graph replay has no host-side launch points to bracket) and therefore runs on sampled
+    # iterations AFTER the window: one GAN-loss iteration and one lazy-R1 iteration.
     first_timed = step.batches_done
-    sampled_steps = 0
-    step_times = [] if os.environ.get('AGF_BENCH_STEP_TIMES') == '1' else None
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     barrier()
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(args.steps):
-        it = first_timed + i
-        sample = timer is not None and i == 0
-        C.KernelTimer.active = timer if sample else None
-        sampled_steps += int(sample)
-        (eager_step if sample else step)(real)
-        if step_times is not None:                  # diagnosis only (AGF_BENCH_STEP_TIMES=1): a sync per step
-            torch.cuda.synchronize()
-            step_times.append((round((time.perf_counter() - t0) * 1e3, 1), 'sampled' if sample else 'plain'))
+        step(real)
+        marks[i + 1].record()
     barrier()
     dt = time.perf_counter() - t0
-    if step_times:
-        print('cumulative ms after each step:', step_times, file=sys.stderr)
-    C.KernelTimer.active = None
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
     if dp_on:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    # sampled eager GAN-loss iteration(s) for the per-launch roofline numbers (after the window)
+    timer = None if args.no_kernel_timer else C.KernelTimer()
+    sampled_steps, sampled_ms = 0, 0.0
+    if timer is not None:
+        eager_step.batches_done = 1
+        eager_step(real)                                     # untimed: the eager path's own caches after a stretch of replays
+        barrier()
+        C.KernelTimer.active = timer
+        ts = time.perf_counter()
+        eager_step.batches_done = 1
+        eager_step(real)
+        torch.cuda.synchronize()
+        sampled_ms = (time.perf_counter() - ts) * 1e3
+        C.KernelTimer.active = None
+        sampled_steps = 1
+        eager_step.batches_done = first_timed + args.steps
     r1_steps = sum(1 for it in range(first_timed, first_timed + args.steps) if it % 16 == 0 and it != 0)
 
     # the worst case "G+D+R1 step" literally names: the R1 penalty on EVERY iteration; a few extra steps after the
@@ -241,7 +258,7 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'bf16', 'data': 'synthetic', 'execution': ('hip-graph replay (eager on the event-timed steps)' + (': three graphs per iteration, gradient all-reduce between the launches' if dp_on else '')) if use_graphs else 'eager launches',
+            'dtype': 'bf16', 'data': 'synthetic', 'execution': ('hip-graph replay (the event-timed roofline sample is one eager iteration after the window)' + (': three graphs per iteration, gradient all-reduce between the launches' if dp_on else '')) if use_graphs else 'eager launches',
             'config': {'workload': f'StyleGAN2 {S}x{S} G+D+lazy-R1 training step, batch {args.batch}/GPU '
                                    f'(BASELINE.json configs[2]: channels 32, max 512, style 512, d_k 16, r1_lambda 10, '
                                    + ('ADA pipe (12 augmentations, adaptive p)' if args.augment == 'ada' else f'DiffAugment {args.augment} = the reference SG2 default; --augment ada selects the ADA pipe') + ', Adam, EMA)',
@@ -249,6 +266,11 @@ def main():
                        'r1_steps_in_window': r1_steps, 'params_G': sum(p.numel() for p in G.parameters()),
                        'params_D': sum(p.numel() for p in D.parameters())},
         }
+        srt = sorted(step_ms)
+        out['step_ms'] = {'p50': round(srt[len(srt) // 2], 3), 'min': round(srt[0], 3), 'max': round(srt[-1], 3),
+                          'max_without_r1_steps': round(max([m for i, m in enumerate(step_ms) if not ((first_timed + i) % 16 == 0 and first_timed + i != 0)] or [0.0]), 3),
+                          'all': [round(m, 2) for m in step_ms],
+                          'note': 'GPU time between event records placed after each iteration of the timed window (no sync); the lazy-R1 iterations are the long ones'}
         if r1_ms is not None:
             out['r1_every_step'] = {'value': round(args.batch * world / (r1_ms * 1e-3), 2), 'unit': 'img/s', 'ms_per_step': round(r1_ms, 3),
                                     'note': 'the lazy-R1 iteration (penalty replaces the GAN loss) on every step: 4 steps after the timed window'}
@@ -299,7 +321,7 @@ def main():
                                    'algorithmic_bytes_per_launch': round(alg['conv2d_fwd_kernel'][0] / max(alg['conv2d_fwd_kernel'][1], 1))
                                    if 'conv2d_fwd_kernel' in alg else None,
                                    'launches': k['launches'], 'avg_launch_ms': round(k['avg_ms'], 4),
-                                   'share_of_step_time': round(k['total_ms'] / (dt * 1e3 * sampled_steps / args.steps), 4),
+                                   'share_of_step_time': round(k['total_ms'] / max(dt * 1e3 / args.steps, 1e-9), 4),
                                    'event_timed_steps': sampled_steps,
                                    'r1_iteration': (lambda q: None if not q else {'achieved': round(q['tflops'], 2), 'launches': q['launches'],
                                                                                     'note': 'conv launches of one lazy-R1 iteration (double backward), sampled after the timed window'})(
@@ -321,7 +343,7 @@ def main():
                 out['roofline_wgrad'] = {'kernel': 'conv2d_wgrad_kernel', 'bound': 'mfma', 'achieved': round(kw['tflops'], 2),
                                          'peak': MFMA_BF16_PEAK / 1e12, 'unit': 'TFLOP/s',
                                          'frac': round(kw['tflops'] * 1e12 / MFMA_BF16_PEAK, 4), 'launches': kw['launches'],
-                                         'share_of_step_time': round(kw['total_ms'] / (dt * 1e3 * sampled_steps / args.steps), 4)}
+                                         'share_of_step_time': round(kw['total_ms'] / max(dt * 1e3 / args.steps, 1e-9), 4)}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(S)
         print(json.dumps(out), flush=True)
