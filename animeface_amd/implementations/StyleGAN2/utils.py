@@ -141,7 +141,9 @@ class TrainStep:
         if self.ada is not None:
             self.ada.update_p(self._real_prob)
         self.batches_done += 1
-        return D_loss.detach(), G_loss.detach(), fake
+        # (detached: a caller that keeps the returned images would keep the iteration's autograd nodes -- and their stream -- alive into the
+        #  next iteration, which a HIP-graph capture does not survive)
+        return D_loss.detach(), G_loss.detach(), fake.detach()
 
     # ---- the same iteration cut at the two gradient exchanges (GraphedTrainStep under data parallelism: one HIP graph per segment, the
     #      all-reduce of the bucket buffers issued between two graph launches) ----
@@ -173,7 +175,7 @@ class TrainStep:
                 p.requires_grad_(True)
         if self.reducer_G is not None:
             self.reducer_G.pack_all()
-        return G_loss.detach(), fake
+        return G_loss.detach(), fake.detach()
 
     def _seg3(self):
         self.optimizer_G.step()
@@ -349,6 +351,9 @@ def build_optimizers(G, D, lr, betas, r1_lambda, pl_lambda, d_k, g_k, capturable
     return optimizer_G, optimizer_D
 
 
+GRAPH_AFTER = 3        # eager iterations at the start of train(graphs=True) before the iteration is recorded into HIP graphs
+
+
 def train(max_iter, dataset, sampler, const_z, latent_dim,
           G, G_ema, D, optimizer_G, optimizer_D,
           r1_lambda, pl_lambda, d_k, g_k, policy,
@@ -368,6 +373,7 @@ def train(max_iter, dataset, sampler, const_z, latent_dim,
     import time
     runner = None
     t_last, it_last = time.perf_counter(), step.batches_done
+    it_start = step.batches_done
     if log is not None:
         log(f'training on {torch.cuda.get_device_name(device) if torch.cuda.is_available() else device} | '
             f'{"bf16" if amp else "fp32"} | {"HIP-graph replay" if graphs else "eager"} | world size {dp.dist.get_world_size() if dp.dist.is_initialized() else 1}')
@@ -375,9 +381,11 @@ def train(max_iter, dataset, sampler, const_z, latent_dim,
         for real in dataset:
             real = real.to(device, non_blocking=True)
             it = step.batches_done
-            if graphs and runner is None:
-                runner = GraphedTrainStep(step, real)
-                it = step.batches_done
+            if graphs and runner is None and step.batches_done - it_start >= GRAPH_AFTER:
+                # the first iterations of a run (or of a resumed run) are ordinary eager iterations -- fresh batches, logged and saved like
+                # any other -- after which optimizer state, arenas and caches have their final size and the iteration is recorded; the
+                # recording itself executes nothing, so no iteration is consumed and no batch is trained on twice
+                runner = GraphedTrainStep(step, real, warmup=0)
             D_loss, G_loss, fake = (runner or step)(real)
             if it % save == 0 and checkpoint_path is not None and it > 0:
                 from ... import checkpoint

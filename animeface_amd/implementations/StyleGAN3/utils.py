@@ -90,7 +90,7 @@ class TrainStep:
         if hasattr(self.augment, 'update_p'):                 # ADA pipe (reference implementations/ADA/utils.py:73)
             self.augment.update_p(real_prob.detach())
         self.batches_done += 1
-        return D_loss.detach(), G_loss.detach(), fake
+        return D_loss.detach(), G_loss.detach(), fake.detach()
 
 
 def train(max_iters, dataset, latent_dim, const_input,
