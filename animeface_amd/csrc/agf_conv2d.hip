@@ -581,15 +581,20 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_dl_kernel(ConvPa
     const int wm = wave / NWN, wn = wave % NWN;
     const int l31 = lane & 31, lhi = lane >> 5;
 
-    // Swizzle: row r keeps its two 16-byte halves swapped when bit 3 of r is set.  A 16-lane pass of a ds_read_b128 then covers 16
-    // distinct 16-byte bank groups for ANY run of 16 consecutive rows (rows r and r+8 hit the two different halves of a 32-byte
-    // bank column); the plain [row][2] order is a 2-way conflict on every fragment read (PMC: half of the LDS-active cycles).
-    int bPix[NJ];
+    // LDS layout of the activation patch: TWO PLANES, plane h = channels [8h, 8h + 8) of every patch pixel as 16-byte rows
+    // ([2][PMAX][8]).  A lane (pixel column l31, k-half lhi) of a B fragment reads plane lhi at row bPix + tap shift: the shift is a
+    // constant BYTE OFFSET for every lane (an immediate of the ds_read), 16 consecutive pixels are 256 contiguous bytes (every bank
+    // once: conflict-free for any shift).  The earlier [pixel][2 halves] rows needed a swizzle that depended on bit 3 of the SHIFTED
+    // pixel index, so every (tap, j) pair had its own pair of address registers -- 72 VGPRs, which left the compiler no room to fetch
+    // the next tap's fragments under the current tap's MFMAs (it spilled, and every tap exposed its LDS latency).
+    // Weights keep 32-byte rows with the row-bit-3 swizzle (their tap offset is a multiple of BM rows: already an immediate).
+    int bRow[NJ][KS];
 #pragma unroll
     for (int j = 0; j < NJ; j++) {
         const int q = wn * (32 * NJ) + j * 32 + l31;
         const int c = q & (p.TW - 1), r = (q >> p.twShift) & (p.TH - 1), ti = q >> (p.twShift + p.thShift);
-        bPix[j] = (ti * PH + r) * PW + c;
+#pragma unroll
+        for (int kh = 0; kh < KS; kh++) bRow[j][kh] = (lhi * PMAX + (ti * PH + r + kh) * PW + c) * 8;      // element offset inside one X buffer
     }
     int aBase[MT];
 #pragma unroll
@@ -611,17 +616,20 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_dl_kernel(ConvPa
     const __amdgpu_buffer_rsrc_t wRes = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.Cout * TAPS * p.Cin * 2, 0x00020000);
     // chunk-invariant byte offsets of this thread's vectors (channel 0 of the chunk), OOB for halo pixels outside the image / co tails
     int xoff[XV], woff[WV];
-    const int half = (tid & 1) ^ ((tid >> 4) & 1);                    // which 8-channel half this lane's LDS slot holds (swizzle above)
+    const int half = (tid & 1) ^ ((tid >> 4) & 1);                    // which 8-channel half this lane's WEIGHT slot holds (swizzle above)
+    unsigned xHalf = 0;                                               // bit i: this lane's activation slot of piece i lies in plane 1
 #pragma unroll
     for (int i = 0; i < XV; i++) {
-        const int v = tid + i * NTHR;
-        const int pix = v >> 1;
+        const int v = tid + i * NTHR;                                 // slot: plane v / PMAX, patch pixel v % PMAX
+        const int hx = v >= PMAX ? 1 : 0;
+        const int pix = v - hx * PMAX;
+        xHalf |= (unsigned)hx << i;
         xoff[i] = OOB;
         if (pix < P) {
             const int t2 = PW == 1 ? pix : (int)__umulhi((uint32_t)pix, p.mPW); const int pc = pix - t2 * PW;
             const int ti = PH == 1 ? t2 : (int)__umulhi((uint32_t)t2, p.mPH); const int pr = t2 - ti * PH;
             const int n = n0 + ti, h = h0 + pr - HALO, w = w0 + pc - HALO;
-            if (n < p.N && h >= 0 && h < p.H && w >= 0 && w < p.W) xoff[i] = (((ti * p.H + h) * p.W + w) * p.Cin + half * 8) * 2;
+            if (n < p.N && h >= 0 && h < p.H && w >= 0 && w < p.W) xoff[i] = (((ti * p.H + h) * p.W + w) * p.Cin + hx * 8) * 2;
         }
     }
 #pragma unroll
@@ -633,11 +641,13 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_dl_kernel(ConvPa
         if (v < WTOT && co0 + co < p.Cout) woff[i] = (((co0 + co) * TAPS + tap) * p.Cin + half * 8) * 2;
     }
     typedef __attribute__((address_space(3))) void* lds_ptr;
-    auto issue = [&](int c0, int buf) {
+    // one DMA piece = one wave-load (1 KB per wave): pieces [0, WV) carry the weight chunk, [WV, WV + XV) the activation patch
+    auto issue_range = [&](int c0, int buf, int lo, int hi) {
         // lanes of a wave write consecutive 16-byte slots from the (wave-uniform) base: slot index = v
         const bool tail = c0 + 8 >= p.Cin;                            // Cin % 16 == 8: the chunk's second half does not exist
 #pragma unroll
         for (int i = 0; i < WV; i++) {
+            if (i < lo || i >= hi) continue;
             int off = woff[i] + c0 * 2;
             if (tail && half) off = OOB;
             if ((i + 1) * NTHR <= WTOT || tid + i * NTHR < WTOT)
@@ -645,12 +655,15 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_dl_kernel(ConvPa
         }
 #pragma unroll
         for (int i = 0; i < XV; i++) {
+            if (i + WV < lo || i + WV >= hi) continue;
             int off = xoff[i] + c0 * 2;
-            if (tail && half) off = OOB;
+            if (tail && ((xHalf >> i) & 1)) off = OOB;
             if ((i + 1) * NTHR <= PMAX * 2 || tid + i * NTHR < PMAX * 2)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(xRes, (lds_ptr)(sX + buf * XBUF + (i * NTHR + wave * 64) * 8), 16, off, 0, 0, 0);
         }
     };
+    auto issue = [&](int c0, int buf) { issue_range(c0, buf, 0, WV + XV); };
+    constexpr int NP = WV + XV;
 
     const int nChunks = (p.Cin + KC - 1) / KC;
     issue(0, 0);
@@ -658,28 +671,37 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_dl_kernel(ConvPa
     __syncthreads();
     for (int ch = 0; ch < nChunks; ch++) {
         const int cur = ch & 1;
-        if (ch + 1 < nChunks) issue((ch + 1) * KC, cur ^ 1);
+        const bool more = ch + 1 < nChunks;
         const bf16_t* cW = sW + cur * WBUF;
         const bf16_t* cX = sX + cur * XBUF;
-        // (explicitly double-buffering the fragment registers across taps -- there is room for it here -- measured no gain)
+        // fragments are fetched ONE TAP AHEAD: the ds_reads of tap t + 1 are in flight under the MFMAs of tap t
+        bf16x8 af[2][MT], bfr[2][NJ];
+        auto fetch = [&](int tap, int kh, int kw, int slot) {
+#pragma unroll
+            for (int i = 0; i < MT; i++) af[slot][i] = *(const bf16x8*)(cW + tap * BM * KC + aBase[i]);
+#pragma unroll
+            for (int j = 0; j < NJ; j++) bfr[slot][j] = *(const bf16x8*)(cX + bRow[j][kh] + kw * 8);
+        };
+        fetch(0, 0, 0, 0);
 #pragma unroll
         for (int kh = 0; kh < KS; kh++) {
 #pragma unroll
             for (int kw = 0; kw < KS; kw++) {
                 const int tap = kh * KS + kw;
-                bf16x8 af[MT], bfr[NJ];
-#pragma unroll
-                for (int i = 0; i < MT; i++) af[i] = *(const bf16x8*)(cW + tap * BM * KC + aBase[i]);
-#pragma unroll
-                for (int j = 0; j < NJ; j++) {
-                    const int pix = bPix[j] + kh * PW + kw;
-                    bfr[j] = *(const bf16x8*)(cX + pix * KC + ((lhi ^ ((pix >> 3) & 1)) << 3));
-                }
+                const int slot = tap & 1;
+                if (tap + 1 < TAPS) fetch(tap + 1, (tap + 1) / KS, (tap + 1) % KS, slot ^ 1);
 #pragma unroll
                 for (int i = 0; i < MT; i++)
 #pragma unroll
                     for (int j = 0; j < NJ; j++)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[slot][i], bfr[slot][j], acc[i][j], 0, 0, 0);
+                if (more) {
+                    // the next chunk's DMA pieces go out BETWEEN the taps' MFMA groups (one or two per tap over the first TAPS - 1 taps; the last
+                    // tap covers the youngest pieces' flight): issued in one burst at the top of the chunk they cost every wave ~1 000 cycles in
+                    // lock step, during which the matrix pipe idles (+6-11 % on the >= 128-channel layers, tools/ab_dl.sh)
+                    constexpr int T1 = TAPS > 1 ? TAPS - 1 : 1;
+                    if (tap < T1) issue_range((ch + 1) * KC, cur ^ 1, tap * NP / T1, (tap + 1) * NP / T1);
+                }
             }
         }
         if (ch + 1 < nChunks) {
