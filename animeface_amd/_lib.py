@@ -20,7 +20,7 @@ EDGE_ZERO, EDGE_CLAMP = 0, 1
 _DTYPES = {torch.float32: AGF_F32, torch.float16: AGF_F16, torch.bfloat16: AGF_BF16, torch.float64: AGF_F64}
 
 EXPORTS = ['agf_abi_version', 'agf_last_error', 'agf_device_info', 'agf_upfirdn2d', 'agf_upfirdn2d_fold_border', 'agf_bias_act',
-           'agf_filtered_lrelu', 'agf_filtered_lrelu_act', 'agf_conv2d_fwd', 'agf_conv2d_fwd_mask', 'agf_conv2d_wgrad', 'agf_conv2d_wgrad_ws', 'agf_conv2d_wgrad_workspace_bytes',
+           'agf_filtered_lrelu', 'agf_filtered_lrelu_act', 'agf_conv2d_fwd', 'agf_conv2d_fwd_mask', 'agf_conv2d_s2_fwd', 'agf_conv2d_s2_dgrad', 'agf_conv2d_wgrad', 'agf_conv2d_wgrad_ws', 'agf_conv2d_wgrad_workspace_bytes',
            'agf_act_bwd_reduce', 'agf_act_bwd_reduce_pooled', 'agf_act_bwd_reduce_scaled', 'agf_scale_dot', 'agf_planar_to_cl_pad', 'agf_cl_to_planar_crop', 'agf_cl_pad', 'agf_prep_weights', 'agf_prep_weights_multi', 'agf_prep_weights_blocks',
            'agf_modulate_weights', 'agf_conv2d_fwd_wimg', 'agf_conv2d_fwd_wimg_covers',
            'agf_wsq', 'agf_style_demod_fwd', 'agf_style_demod_fwd_ld', 'agf_style_demod_bwd', 'agf_diffaug_sum', 'agf_diffaug_apply', 'agf_color_affine', 'agf_affine_resample', 'agf_upblur_border', 'agf_image_resample_rows', 'agf_image_finish']
@@ -71,6 +71,10 @@ def lib():
         L.agf_conv2d_fwd_mask.restype = ctypes.c_int
         L.agf_conv2d_fwd_mask.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int] + [ctypes.c_int32] * 6 + \
                                          [ctypes.c_int, ctypes.c_float, ctypes.c_float, _vp, ctypes.c_float, _vp, _vp, ctypes.c_float, _vp]
+        L.agf_conv2d_s2_fwd.restype = ctypes.c_int
+        L.agf_conv2d_s2_fwd.argtypes = [_vp] * 4 + [ctypes.c_int] + [ctypes.c_int32] * 7 + [ctypes.c_int, ctypes.c_float, ctypes.c_float, _vp]
+        L.agf_conv2d_s2_dgrad.restype = ctypes.c_int
+        L.agf_conv2d_s2_dgrad.argtypes = [_vp] * 3 + [ctypes.c_int] + [ctypes.c_int32] * 7 + [ctypes.c_float, _vp]
         L.agf_modulate_weights.restype = ctypes.c_int
         L.agf_modulate_weights.argtypes = [_vp, _vp, _vp, ctypes.c_int] + [ctypes.c_int32] * 4 + [_vp]
         L.agf_conv2d_fwd_wimg.restype = ctypes.c_int
@@ -124,7 +128,7 @@ def lib():
         L.agf_image_resample_rows.argtypes = [_vp] * 5 + [ctypes.c_int32] * 8 + [_vp]
         L.agf_image_finish.restype = ctypes.c_int
         L.agf_image_finish.argtypes = [_vp] * 5 + [ctypes.c_int32, _vp, ctypes.c_int] + [ctypes.c_int32] * 6 + [ctypes.c_int, _vp]
-        if L.agf_abi_version() != 13:
+        if L.agf_abi_version() != 14:
             raise AgfError('libagf_ops.so ABI version mismatch')
         _lib = L
     return _lib

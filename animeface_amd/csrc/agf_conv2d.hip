@@ -47,7 +47,10 @@ static __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16
         int n = n0 + ti, h = h0 + r, w = w0 + c;
         const bool valid = n < p.N && h < p.H && w < p.W;
         if (!vecStore && !valid) continue;
-        const int64_t pixIdx = valid ? ((int64_t)n * p.H + h) * p.W + w : 0;
+        // (yMul: the output pixel (h, w) of this launch is pixel (yMul * h + yOffH, yMul * w + yOffW) of a [N, yH, yW, Cout] tensor -- one
+        //  phase of a transposed stride-2 conv, conv2d_fwd_taps_kernel)
+        const int64_t pixIdx = !valid ? 0 : p.yMul ? ((int64_t)n * p.yH + h * p.yMul + p.yOffH) * p.yW + w * p.yMul + p.yOffW
+                                                   : ((int64_t)n * p.H + h) * p.W + w;
         if (!valid) n = 0;
         const float nz = p.noise ? p.noise[pixIdx] : 0.f;
         if (vecStore && lhi == 0) *(int64_t*)(sE + l31 * EROW + 64 * MT) = valid ? pixIdx : (int64_t)-1;
@@ -729,6 +732,199 @@ static int launch_fwd_dl(const ConvParams& p0, hipStream_t st) {
     if (e != hipSuccess) { agf_set_error("conv2d_fwd: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e)); return AGF_ELAUNCH; }
     hipLaunchKernelGGL((conv2d_fwd_dl_kernel<KS, MT, NWN, PMAX, NWM, NJ>), dim3((unsigned)(slots * 8)), dim3(NTHR), lds, st, p);
     return AGF_OK;
+}
+
+// =================================================================================================
+// Tap-list variant of conv2d_fwd_dl_kernel: the same double-buffered direct-to-LDS MFMA contraction, but the set of taps, the geometry
+// of the staged patch and the output lattice are PARAMETERS.  It serves the stride-2 3x3 convolution of the StyleGAN3 discriminator
+// (conv2d_resample.py:100-103: the conv evaluated on the kept lattice only) and its data gradient at the strided flop count:
+//   mode 1 (forward):  y[n,i,j,:] = sum_{ky,kx} W[:,ky,kx,:] x[n, 2i+ky, 2j+kx, :].  The patch of a TH x TW output tile is the
+//       (2TH+1) x (2TW+1) input window, staged as FOUR planes (k-half x column parity) of 16-byte rows, so that the 32 pixels of a B
+//       fragment -- input columns 2c + kx, a stride of two -- are again 16 consecutive rows of ONE plane (column parity kx & 1, start
+//       c + (kx >> 1)): conflict-free, and a tap is one wave-uniform offset.  Nine taps per 16-channel chunk, as in the 3x3 kernel.
+//   mode 0 (one output phase of the transposed conv): dz[n, 2a+pu, 2b+pv, :] = sum over the taps of that parity of
+//       W^T[:,ky,kx,:] dy[n, a-(ky>>1)..., b-...]: a 2x2 / 2x1 / 1x2 / 1x1 tap grid over a patch with halo rows above / left of the tile,
+//       the result stored with pixel stride 2 (ConvParams::yMul, yOffH, yOffW: the epilogue's strided store).
+// Weights are read from the ordinary [M][9][K] (OHWI) tensor; tapW picks the taps.  8 waves, 128 co x 256 px, one block per CU.
+struct TapParams {
+    ConvParams c;              // c.H, c.W: OUTPUT tile lattice; c.Cin = K; c.Cout = M
+    int mode;
+    int xH, xW;                // input lattice (bounds and pitches of x)
+    int PHp, PWp, PL;          // patch rows, columns per plane, rows per plane = TI * PHp * PWp
+    int HY, HX;                // mode 0: halo rows above / columns left of the tile
+    int ntaps, wTaps;          // taps contracted; taps per (m, k) row of the weight tensor (9)
+    int tapX[9], tapW[9];      // element offset of a tap inside an X buffer; its index in the weight tensor
+    int KM, tapK[9];           // mode 0: a chunk holds KM groups of 16 channels (2 * KM planes); tapK = the group a (virtual) tap contracts.
+                               //   A phase with one or two real taps would otherwise run 4-8 MFMAs per wave between two block barriers
+    uint32_t mPWp, mPHp;
+};
+
+template <int MT, int NWN, int XROWS, int NWM, int NJ>
+__global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_taps_kernel(TapParams tp) {
+    const ConvParams& p = tp.c;
+    constexpr int NTHR = 64 * NWM * NWN;
+    constexpr int KC = 16, MAXT = 9;
+    constexpr int BM = 32 * NWM * MT;
+    constexpr int WTOT = MAXT * BM * 2;
+    constexpr int WV = (WTOT + NTHR - 1) / NTHR;
+    constexpr int XV = (XROWS + NTHR - 1) / NTHR;
+    constexpr int WBUF = WTOT * 8;                                    // (lanes of the last piece beyond it issue no load)
+    constexpr int XBUF = XV * NTHR * 8;
+    constexpr int OOB = 0x70000000;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* sW = (bf16_t*)smem_raw;                                  // [2][WBUF]
+    bf16_t* sX = sW + 2 * WBUF;                                      // [2][XBUF]
+
+    const int b = blockIdx.x;
+    const int xcd = b & 7, slot = b >> 3;
+    const int pixTile = p.xcdBand ? xcd * p.xcdBand + slot / p.tilesCo : (slot / p.tilesCo) * 8 + xcd;
+    const int coTile = slot % p.tilesCo;
+    if (pixTile >= p.pixTiles || (p.xcdBand && slot / p.tilesCo >= p.xcdBand)) return;
+    int tq = pixTile;
+    const int tw = tq % p.tilesW; tq /= p.tilesW;
+    const int th = tq % p.tilesH;
+    const int tn = tq / p.tilesH;
+    const int n0 = tn * p.TI, h0 = th * p.TH, w0 = tw * p.TW;
+    const int co0 = coTile * BM;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / NWN, wn = wave % NWN;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int PL = tp.PL, PWp = tp.PWp, PHp = tp.PHp;
+    const int planes = tp.mode ? 4 : 2 * tp.KM;
+    const int ntaps = tp.ntaps;
+    const int KCH = tp.mode ? KC : KC * tp.KM;                        // channels per chunk
+
+    int bBase[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+        const int q = wn * (32 * NJ) + j * 32 + l31;
+        const int c = q & (p.TW - 1), r = (q >> p.twShift) & (p.TH - 1), ti = q >> (p.twShift + p.thShift);
+        bBase[j] = tp.mode ? (lhi * 2 * PL + (ti * PHp + 2 * r) * PWp + c) * 8 : (lhi * PL + (ti * PHp + r) * PWp + c) * 8;
+    }
+    int aBase[MT];
+#pragma unroll
+    for (int i = 0; i < MT; i++) aBase[i] = (wm * 32 * MT + i * 32 + l31) * KC + ((lhi ^ ((l31 >> 3) & 1)) << 3);
+
+    f32x16 acc[MT][NJ];
+#pragma unroll
+    for (int i = 0; i < MT; i++)
+#pragma unroll
+        for (int j = 0; j < NJ; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    const int64_t imgBytes = (int64_t)tp.xH * tp.xW * p.Cin * 2;
+    int64_t xBytes = imgBytes * (n0 + p.TI <= p.N ? p.TI : p.N - n0);
+    if (xBytes > 0x60000000) xBytes = 0x60000000;
+    const __amdgpu_buffer_rsrc_t xRes = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (int64_t)n0 * tp.xH * tp.xW * p.Cin), 0, (int)xBytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wRes = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.Cout * tp.wTaps * p.Cin * 2, 0x00020000);
+    int xoff[XV], woff[WV];
+    const int half = (tid & 1) ^ ((tid >> 4) & 1);
+    unsigned xHalf = 0;
+#pragma unroll
+    for (int i = 0; i < XV; i++) {
+        const int v = tid + i * NTHR;
+        int plane = 0;
+#pragma unroll
+        for (int q = 1; q < 8; q++) if (v >= q * PL) plane = q;
+        const int rem = v - plane * PL;
+        xoff[i] = OOB;
+        const int hx = tp.mode ? (plane >> 1) : (plane & 1);           // k-half of the 16-channel group
+        const int kg = tp.mode ? 0 : (plane >> 1);                     // mode 0: which 16-channel group of the chunk
+        xHalf |= (unsigned)(hx & 1) << i;
+        if (plane < planes) {
+            const int t2 = PWp == 1 ? rem : (int)__umulhi((uint32_t)rem, tp.mPWp); const int cc = rem - t2 * PWp;
+            const int ti = PHp == 1 ? t2 : (int)__umulhi((uint32_t)t2, tp.mPHp); const int pr = t2 - ti * PHp;
+            const int n = n0 + ti;
+            int gy, gx; bool ok = n < p.N;
+            if (tp.mode) {
+                const int col = 2 * cc + (plane & 1);
+                gy = 2 * h0 + pr; gx = 2 * w0 + col;
+                ok = ok && col <= 2 * p.TW;
+            } else {
+                gy = h0 + pr - tp.HY; gx = w0 + cc - tp.HX;
+            }
+            if (ok && gy >= 0 && gy < tp.xH && gx >= 0 && gx < tp.xW) xoff[i] = (((ti * tp.xH + gy) * tp.xW + gx) * p.Cin + kg * 16 + hx * 8) * 2;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < WV; i++) {
+        const int v = tid + i * NTHR;
+        const int row = v >> 1;
+        const int t = row / BM, co = row - t * BM;
+        woff[i] = OOB;
+        if (t < ntaps && co0 + co < p.Cout) woff[i] = (((co0 + co) * tp.wTaps + tp.tapW[t]) * p.Cin + tp.tapK[t] * 16 + half * 8) * 2;
+    }
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const int wPieces = (ntaps * BM * 2 + NTHR - 1) / NTHR;           // weight pieces that carry anything
+    const int xPieces = (planes * PL + NTHR - 1) / NTHR;
+    // channel tails (Cin not a multiple of the chunk depth): a vector whose first channel lies beyond Cin is fetched out of range (zeros)
+    int wch[WV], xch[XV];
+#pragma unroll
+    for (int i = 0; i < WV; i++) { const int t = ((tid + i * NTHR) >> 1) / BM; wch[i] = (t < ntaps ? tp.tapK[t] * 16 : 0) + half * 8; }
+#pragma unroll
+    for (int i = 0; i < XV; i++) {
+        int plane = 0;
+#pragma unroll
+        for (int q = 1; q < 8; q++) if (tid + i * NTHR >= q * PL) plane = q;
+        xch[i] = tp.mode ? (plane >> 1) * 8 : (plane >> 1) * 16 + (plane & 1) * 8;
+    }
+    auto issue_range = [&](int c0, int buf, int lo, int hi) {
+#pragma unroll
+        for (int i = 0; i < WV; i++) {
+            if (i < lo || i >= hi || i >= wPieces) continue;
+            int off = woff[i] + c0 * 2;
+            if (c0 + wch[i] >= p.Cin) off = OOB;
+            if ((i + 1) * NTHR <= WTOT || tid + i * NTHR < WTOT)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wRes, (lds_ptr)(sW + buf * WBUF + (i * NTHR + wave * 64) * 8), 16, off, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < XV; i++) {
+            if (i + WV < lo || i + WV >= hi || i >= xPieces) continue;
+            int off = xoff[i] + c0 * 2;
+            if (c0 + xch[i] >= p.Cin) off = OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xRes, (lds_ptr)(sX + buf * XBUF + (i * NTHR + wave * 64) * 8), 16, off, 0, 0, 0);
+        }
+    };
+    constexpr int NP = WV + XV;
+
+    const int nChunks = (p.Cin + KCH - 1) / KCH;
+    issue_range(0, 0, 0, NP);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int ch = 0; ch < nChunks; ch++) {
+        const int cur = ch & 1;
+        const bool more = ch + 1 < nChunks;
+        const bf16_t* cW = sW + cur * WBUF;
+        const bf16_t* cX = sX + cur * XBUF;
+#pragma unroll
+        for (int t = 0; t < MAXT; t++) {
+            if (t < ntaps) {
+                bf16x8 af[MT], bfr[NJ];
+                const int tx = tp.tapX[t];
+#pragma unroll
+                for (int i = 0; i < MT; i++) af[i] = *(const bf16x8*)(cW + t * BM * KC + aBase[i]);
+#pragma unroll
+                for (int j = 0; j < NJ; j++) bfr[j] = *(const bf16x8*)(cX + bBase[j] + tx);
+#pragma unroll
+                for (int i = 0; i < MT; i++)
+#pragma unroll
+                    for (int j = 0; j < NJ; j++)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+            // the next chunk's DMA pieces between the taps' MFMA groups (nine taps: spread over the first eight; fewer: after the first)
+            if (more) {
+                if (ntaps == MAXT) { if (t < MAXT - 1) issue_range((ch + 1) * KCH, cur ^ 1, t * NP / (MAXT - 1), (t + 1) * NP / (MAXT - 1)); }
+                else if (ntaps == 8) { if (t < 5) issue_range((ch + 1) * KCH, cur ^ 1, t * NP / 5, (t + 1) * NP / 5); }
+                else if (t == 0) issue_range((ch + 1) * KCH, cur ^ 1, 0, NP);
+            }
+        }
+        if (more) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+    conv_epilogue<MT, NJ>(p, acc, smem_raw, wave, lane, wm, wn, n0, h0, w0, 0, co0, NWN, NWM * NWN, pixTile & 255);
 }
 
 // Second half of the LDS-transposed epilogue of the weight-stationary kernels (see conv2d_fwd_kernel): the wave's strip holds
@@ -1510,7 +1706,7 @@ static int conv2d_fwd_impl(const void* x, const void* w, void* y,
     AGF_CHECK(act == 1 || act == 3, "conv2d_fwd: act must be 1 (linear) or 3 (lrelu)");
     AGF_CHECK(((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0 && ((uintptr_t)y % 8) == 0, "conv2d_fwd: misaligned pointer");
     AGF_CHECK((int64_t)N * H * W * (int64_t)(Cin > Cout ? Cin : Cout) < (1ll << 40), "conv2d_fwd: tensor too large");
-    ConvParams p;
+    ConvParams p = {};
     p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.y = (bf16_t*)y;
     p.in_scale = in_scale; p.out_scale = out_scale; p.bias = bias; p.noise = noise; p.residual = (const bf16_t*)residual;
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
@@ -1626,6 +1822,124 @@ extern "C" int agf_conv2d_fwd_mask(const void* x, const void* w, void* y,
     AGF_CHECK(mask_y || res_pooled, "conv2d_fwd_mask: neither a mask nor a pooled residual");
     return conv2d_fwd_impl(x, w, y, in_scale, out_scale, bias, noise, residual, dtype, N, H, W, Cin, Cout, ksize, act, alpha, act_gain,
                            mask_y, mask_alpha, mask_sum, res_pooled, res_scale, stream);
+}
+
+// ---- stride-2 3x3 convolution and its data gradient on conv2d_fwd_taps_kernel ----
+static int taps_launch(TapParams& tp, hipStream_t st) {
+    constexpr int MT = 2, NWN = 4, XROWS = 2496, NWM = 2, NJ = 2, NTHR = 512, BM = 128;
+    ConvParams& p = tp.c;
+    p.TW = pow2_ceil(p.W) < 32 ? pow2_ceil(p.W) : 32;
+    const int th = pow2_ceil(p.H);
+    p.TH = th < 256 / p.TW ? th : 256 / p.TW;
+    p.TI = 256 / (p.TW * p.TH);
+    p.tilesW = (p.W + p.TW - 1) / p.TW; p.tilesH = (p.H + p.TH - 1) / p.TH; p.tilesN = (p.N + p.TI - 1) / p.TI;
+    p.pixTiles = p.tilesW * p.tilesH * p.tilesN;
+    p.tilesCo = (p.Cout + BM - 1) / BM;
+    p.twShift = 0; while ((1 << p.twShift) < p.TW) p.twShift++;
+    p.thShift = 0; while ((1 << p.thShift) < p.TH) p.thShift++;
+    p.flat = 0; p.vecStore = 1;
+    p.xcdBand = p.pixTiles >= 64 ? (p.pixTiles + 7) / 8 : 0;
+    if (tp.mode) { tp.PHp = 2 * p.TH + 1; tp.PWp = p.TW + 1; }
+    else { tp.PHp = p.TH + tp.HY; tp.PWp = p.TW + tp.HX; }
+    tp.PL = p.TI * tp.PHp * tp.PWp;
+    if ((tp.mode ? 4 : 2 * tp.KM) * tp.PL > XROWS) return AGF_ENOKERNEL;
+    tp.mPWp = tp.PWp <= 1 ? 0u : (uint32_t)(0xFFFFFFFFull / (uint32_t)tp.PWp) + 1u;
+    tp.mPHp = tp.PHp <= 1 ? 0u : (uint32_t)(0xFFFFFFFFull / (uint32_t)tp.PHp) + 1u;
+    if ((int64_t)p.Cout * tp.wTaps * p.Cin * 2 >= 0x60000000ll || (int64_t)p.TI * tp.xH * tp.xW * p.Cin * 2 >= 0x60000000ll) return AGF_ENOKERNEL;
+    constexpr size_t lds = (size_t)2 * (9 * BM * 2 + ((XROWS + NTHR - 1) / NTHR) * NTHR) * 16;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    auto kern = conv2d_fwd_taps_kernel<MT, NWN, XROWS, NWM, NJ>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { agf_set_error("conv2d_s2: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e)); return AGF_ELAUNCH; }
+    const int slots = ((p.pixTiles + 7) / 8) * p.tilesCo;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(slots * 8)), dim3(NTHR), lds, st, tp);
+    return AGF_OK;
+}
+
+extern "C" int agf_conv2d_s2_fwd(const void* x, const void* w, void* y, const float* bias, int dtype,
+                                 int32_t N, int32_t xH, int32_t xW, int32_t Cin, int32_t Cout, int32_t Ho, int32_t Wo,
+                                 int act, float alpha, float act_gain, void* stream) {
+    AGF_CHECK(x && w && y, "conv2d_s2_fwd: null pointer");
+    AGF_CHECK(dtype == AGF_BF16, "conv2d_s2_fwd: bf16 only");
+    AGF_CHECK(N >= 1 && xH >= 1 && xW >= 1 && Ho >= 1 && Wo >= 1 && Cin >= 8 && Cout >= 8, "conv2d_s2_fwd: empty tensor");
+    AGF_CHECK(Cin % 8 == 0 && Cout % 8 == 0, "conv2d_s2_fwd: channel counts must be multiples of 8");
+    AGF_CHECK(act == 1 || act == 3, "conv2d_s2_fwd: act must be 1 (linear) or 3 (lrelu)");
+    AGF_CHECK(((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0 && ((uintptr_t)y % 16) == 0, "conv2d_s2_fwd: misaligned pointer");
+    TapParams tp = {};
+    ConvParams& p = tp.c;
+    p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.y = (bf16_t*)y; p.bias = bias;
+    p.N = N; p.H = Ho; p.W = Wo; p.Cin = Cin; p.Cout = Cout;
+    p.act = act; p.alpha = alpha; p.gain = act_gain;
+    tp.mode = 1; tp.xH = xH; tp.xW = xW; tp.ntaps = 9; tp.wTaps = 9; tp.KM = 1;
+    const int rc0 = AGF_OK; (void)rc0;
+    // tap offsets need the patch pitch: fixed by the tiling, which taps_launch derives -- replicate its choice here
+    {
+        const int TW = pow2_ceil(Wo) < 32 ? pow2_ceil(Wo) : 32;
+        const int th = pow2_ceil(Ho);
+        const int TH = th < 256 / TW ? th : 256 / TW;
+        const int TI = 256 / (TW * TH);
+        const int PWp = TW + 1, PL = TI * (2 * TH + 1) * PWp;
+        for (int ky = 0; ky < 3; ky++)
+            for (int kx = 0; kx < 3; kx++) {
+                tp.tapX[ky * 3 + kx] = ((kx & 1) * PL + ky * PWp + (kx >> 1)) * 8;
+                tp.tapW[ky * 3 + kx] = ky * 3 + kx;
+            }
+    }
+    const int rc = taps_launch(tp, (hipStream_t)stream);
+    if (rc != AGF_OK) { if (rc == AGF_ENOKERNEL) agf_set_error("conv2d_s2_fwd: shape not covered (output map smaller than 8x8?)"); return rc; }
+    AGF_LAUNCH_CHECK();
+    return AGF_OK;
+}
+
+extern "C" int agf_conv2d_s2_dgrad(const void* dy, const void* wt, void* dz, int dtype,
+                                   int32_t N, int32_t Ho, int32_t Wo, int32_t Cout, int32_t Cin, int32_t zH, int32_t zW,
+                                   float gain, void* stream) {
+    AGF_CHECK(dy && wt && dz, "conv2d_s2_dgrad: null pointer");
+    AGF_CHECK(dtype == AGF_BF16, "conv2d_s2_dgrad: bf16 only");
+    AGF_CHECK(N >= 1 && zH >= 1 && zW >= 1 && Ho >= 1 && Wo >= 1, "conv2d_s2_dgrad: empty tensor");
+    AGF_CHECK(Cin % 8 == 0 && Cout % 8 == 0, "conv2d_s2_dgrad: channel counts must be multiples of 8");
+    AGF_CHECK(((uintptr_t)dy % 16) == 0 && ((uintptr_t)wt % 16) == 0 && ((uintptr_t)dz % 16) == 0, "conv2d_s2_dgrad: misaligned pointer");
+    for (int pu = 0; pu < 2; pu++)
+        for (int pv = 0; pv < 2; pv++) {
+            const int A = (zH - pu + 1) / 2, B = (zW - pv + 1) / 2;
+            if (A <= 0 || B <= 0) continue;
+            TapParams tp = {};
+            ConvParams& p = tp.c;
+            p.x = (const bf16_t*)dy; p.w = (const bf16_t*)wt; p.y = (bf16_t*)dz;
+            p.N = N; p.H = A; p.W = B; p.Cin = Cout; p.Cout = Cin;
+            p.act = 1; p.alpha = 0.f; p.gain = gain;
+            p.yMul = 2; p.yOffH = pu; p.yOffW = pv; p.yH = zH; p.yW = zW;
+            tp.mode = 0; tp.xH = Ho; tp.xW = Wo; tp.wTaps = 9;
+            tp.HY = pu == 0 ? 1 : 0; tp.HX = pv == 0 ? 1 : 0;
+            const int TW = pow2_ceil(B) < 32 ? pow2_ceil(B) : 32;
+            const int thp = pow2_ceil(A);
+            const int TH = thp < 256 / TW ? thp : 256 / TW;
+            const int TI = 256 / (TW * TH);
+            const int PWp = TW + tp.HX, PL = TI * (TH + tp.HY) * PWp;
+            int kys[2], kxs[2], ny = 0, nx = 0;
+            for (int ky = pu; ky < 3; ky += 2) kys[ny++] = ky;
+            for (int kx = pv; kx < 3; kx += 2) kxs[nx++] = kx;
+            const int real = ny * nx;                                    // 4, 2, 2 or 1 taps
+            int KM = 8 / real;                                           // virtual taps = KM channel groups x real taps: 8 per chunk
+            while (KM > 1 && (2 * KM * PL > 2496 || KM * 16 > ((Cout + 15) / 16) * 16)) KM >>= 1;
+            tp.KM = KM;
+            int nt = 0;
+            for (int kg = 0; kg < KM; kg++)
+                for (int a = 0; a < ny; a++)
+                    for (int c = 0; c < nx; c++) {
+                        const int ky = kys[a], kx = kxs[c];
+                        const int ty = tp.HY - (ky >> 1), tx = tp.HX - (kx >> 1);
+                        tp.tapX[nt] = (kg * 2 * PL + ty * PWp + tx) * 8;
+                        tp.tapW[nt] = ky * 3 + kx;
+                        tp.tapK[nt] = kg;
+                        nt++;
+                    }
+            tp.ntaps = nt;
+            const int rc = taps_launch(tp, (hipStream_t)stream);
+            if (rc != AGF_OK) { if (rc == AGF_ENOKERNEL) agf_set_error("conv2d_s2_dgrad: shape not covered"); return rc; }
+        }
+    AGF_LAUNCH_CHECK();
+    return AGF_OK;
 }
 
 // =================================================================================================

@@ -351,6 +351,102 @@ class _ConvWgrad(torch.autograd.Function):
         return gx, gdy, gsi, gso, None
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# stride-2 3x3 convolution (the StyleGAN3 discriminator's downsampling conv, conv2d_resample.py:100-103) on the kept lattice only
+
+def _s2_covers(x, w):
+    if x.dtype != torch.bfloat16 or not x.is_cuda or tuple(w.shape[2:]) != (3, 3):
+        return False
+    N, Cin, ZH, ZW = x.shape
+    Ho, Wo = (ZH - 3) // 2 + 1, (ZW - 3) // 2 + 1
+    return Cin % 8 == 0 and w.shape[0] % 8 == 0 and ZH >= 3 and ZW >= 3 and Ho >= 8 and Wo >= 8
+
+
+def _zero_upsample_odd(dy, ZH, ZW):
+    """dy [N,C,Ho,Wo] -> [N,C,ZH,ZW] with dy at the odd positions (2i+1, 2j+1), zeros elsewhere: on that lattice the stride-2 conv's weight
+    gradient is the ordinary 3x3 "same" weight gradient (tap ky reads z[2i + 1 + ky - 1])."""
+    N, C, Ho, Wo = dy.shape
+    up = torch.zeros((N, C, ZH, ZW), dtype=dy.dtype, device=dy.device).contiguous(memory_format=torch.channels_last)
+    up[:, :, 1:2 * Ho:2, 1:2 * Wo:2] = dy
+    return up
+
+
+class _ConvS2Fwd(torch.autograd.Function):
+    """y[n,co,i,j] = sum_{ky,kx,ci} z[n,ci,2i+ky,2j+kx] w[co,ci,ky,kx]  (no padding).  One ``agf_conv2d_s2_fwd`` launch."""
+
+    @staticmethod
+    def forward(ctx, z, w):
+        _lib.require_gpu(z, 'conv2d_s2')
+        z = z.contiguous(memory_format=torch.channels_last)
+        N, Cin, ZH, ZW = z.shape
+        Cout = w.shape[0]
+        Ho, Wo = (ZH - 3) // 2 + 1, (ZW - 3) // 2 + 1
+        wq = prep_weights_raw(w, 1.0, z.dtype)[0]
+        y = torch.empty((N, Cout, Ho, Wo), dtype=z.dtype, device=z.device, memory_format=torch.channels_last)
+        timer = KernelTimer.active
+        ev0 = timer.start() if timer is not None else None
+        rc = _lib.lib().agf_conv2d_s2_fwd(_lib.ptr(z), _lib.ptr(wq), _lib.ptr(y), None, _lib.dtype_code(z), N, ZH, ZW, Cin, Cout, Ho, Wo,
+                                          ACT_LINEAR, 0.0, 1.0, _lib.stream_ptr(z))
+        if timer is not None:
+            timer.stop('conv2d_fwd_kernel', ev0, 2.0 * N * Ho * Wo * Cin * Cout * 9, (N, Cin, Cout, Ho, Wo, 3, False, False, 's2'))
+        _lib.check(rc, 'conv2d_s2_fwd')
+        ctx.save_for_backward(z, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        z, w = ctx.saved_tensors
+        dz = dw = None
+        dy = dy.to(z.dtype).contiguous(memory_format=torch.channels_last)
+        if ctx.needs_input_grad[0]:
+            dz = _ConvS2Dgrad.apply(dy, w, z.shape[2], z.shape[3])
+        if ctx.needs_input_grad[1]:
+            dw = _ConvWgrad.apply(z, _zero_upsample_odd(dy, z.shape[2], z.shape[3]), None, None, 3).to(w.dtype)
+        return dz, dw
+
+
+class _ConvS2Dgrad(torch.autograd.Function):
+    """dz[n,ci,u,v] = sum_{co,ky,kx} dy[n,co,(u-ky)/2,(v-kx)/2] w[co,ci,ky,kx] over the taps of u's / v's parity: the transposed conv, four
+    phase launches inside ``agf_conv2d_s2_dgrad``."""
+
+    @staticmethod
+    def forward(ctx, dy, w, ZH, ZW):
+        _lib.require_gpu(dy, 'conv2d_s2_dgrad')
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        N, Cout, Ho, Wo = dy.shape
+        Cin = w.shape[1]
+        wt = prep_weights_raw(w.detach().transpose(0, 1).contiguous(), 1.0, dy.dtype)[0]          # [Cin][3][3][Cout], taps not flipped
+        dz = torch.empty((N, Cin, ZH, ZW), dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last)
+        timer = KernelTimer.active
+        ev0 = timer.start() if timer is not None else None
+        rc = _lib.lib().agf_conv2d_s2_dgrad(_lib.ptr(dy), _lib.ptr(wt), _lib.ptr(dz), _lib.dtype_code(dy), N, Ho, Wo, Cout, Cin, ZH, ZW, 1.0,
+                                            _lib.stream_ptr(dy))
+        if timer is not None:
+            timer.stop('conv2d_fwd_kernel', ev0, 2.0 * N * Ho * Wo * Cin * Cout * 9, (N, Cout, Cin, Ho, Wo, 3, False, False, 's2t'))
+        _lib.check(rc, 'conv2d_s2_dgrad')
+        ctx.save_for_backward(dy, w)
+        return dz
+
+    @staticmethod
+    def backward(ctx, g):
+        dy, w = ctx.saved_tensors
+        ddy = dw = None
+        g = g.to(dy.dtype).contiguous(memory_format=torch.channels_last)
+        if ctx.needs_input_grad[0]:
+            ddy = _ConvS2Fwd.apply(g, w)
+        if ctx.needs_input_grad[1]:
+            dw = _ConvWgrad.apply(g, _zero_upsample_odd(dy, g.shape[2], g.shape[3]), None, None, 3).to(w.dtype)
+        return ddy, dw, None, None
+
+
+def conv2d_s2(z, w):
+    """Stride-2 3x3 convolution without padding, differentiable to any order; ``None`` when the MFMA path does not take the shape
+    (fp32 reference-precision runs, output maps below 8x8, odd channel counts): the caller then uses its generic formulation."""
+    if not _s2_covers(z, w):
+        return None
+    return _ConvS2Fwd.apply(z, w)
+
+
 def _pad_channels(t, mult, dim, value=0.0):
     c = t.shape[dim]
     extra = (-c) % mult

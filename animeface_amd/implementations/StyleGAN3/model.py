@@ -28,7 +28,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ...stylegan3_ops import bias_act, filtered_lrelu, upfirdn2d, layout
-from ..StyleGAN2.conv import conv2d, conv2d_act
+from ..StyleGAN2.conv import conv2d, conv2d_act, conv2d_s2
 
 
 def _cl_pad_raw(x, pad, crop):
@@ -406,15 +406,33 @@ class ConvAct(nn.Module):
                                   act=self.act_name, gain=self.act_gain)
             x = conv2d(x.contiguous(memory_format=torch.channels_last), weight)
         else:
-            # FIR + stride-2 conv of conv2d_resample.py:100-103.  The FIR and the (channel-mixing) conv commute, so the conv
-            # runs first, at stride 1 on the MFMA kernel over the input zero-padded by one more pixel, and ONE upfirdn2d then
-            # filters and decimates: same linear map, every piece double-differentiable on this package's kernels (MIOpen's
-            # double backward of a strided conv lands on its "naive" kernels: 12 s per R1 iteration at 256x256).
+            # FIR + stride-2 conv of conv2d_resample.py:100-103, at the strided conv's own cost class (see ``fir_strided_conv3x3``)
             assert self.down == 2 and k == 3 and self.padding == 1
-            x = conv2d(_ZeroPadCL.apply(x, 1), weight)
-            x = upfirdn2d.upfirdn2d(x, self.down_filter, down=self.down, padding=0)
+            x = fir_strided_conv3x3(x, weight, self.down_filter)
         b = self.bias.to(x.dtype) if self.bias is not None else None
         return bias_act.bias_act(x, b, act=self.act_name, gain=self.act_gain)
+
+
+S2_MIN_CHANNELS = 128
+
+
+def fir_strided_conv3x3(x, weight, f):
+    """``conv2d_resample(x, w, f, down=2, padding=1)`` for a 3x3 ``w`` and a 4-tap ``f`` (reference conv2d_resample.py:100-103): the FIR at the
+    full rate, then the 3x3 conv evaluated on the kept lattice only (``conv2d_s2``: the MFMA stride-2 kernel, 9 taps per OUTPUT pixel,
+    with its transposed-conv data gradient; any-order differentiable).  Where that kernel does not take the shape (fp32 runs, maps
+    below 8x8) the same linear map is evaluated as: 3x3 conv at stride 1 over the zero-padded input, then ONE filtering + decimating
+    ``upfirdn2d`` (FIR and channel mix commute) -- 4x the conv flops, but every piece on this package's own kernels."""
+    N, C, H, W = x.shape
+    # (below 128 channels the layer is bound by HBM streaming, not by the matrix pipe: there the stride-1 formulation on the persistent
+    #  streaming kernel is the faster one -- tools/time_s2.py: 64 -> 64 @512x512 0.45 ms strided vs 0.33 ms)
+    if x.is_cuda and x.dtype == torch.bfloat16 and H % 2 == 0 and W % 2 == 0 and min(H, W) >= 16 and C % 8 == 0 and weight.shape[0] % 8 == 0 \
+            and min(C, weight.shape[0]) >= S2_MIN_CHANNELS:
+        z = upfirdn2d.upfirdn2d(x, f, padding=[2, 2, 2, 2])                               # [N, Cin, H + 1, W + 1]: the reference's FIR output
+        y = conv2d_s2(z, weight)
+        if y is not None:
+            return y
+    x = conv2d(_ZeroPadCL.apply(x, 1), weight)
+    return upfirdn2d.upfirdn2d(x, f, down=2, padding=0)
 
 
 class ResBlock(nn.Module):

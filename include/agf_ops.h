@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define AGF_ABI_VERSION 13
+#define AGF_ABI_VERSION 14
 
 /* element types of activation tensors */
 enum { AGF_F32 = 0, AGF_F16 = 1, AGF_BF16 = 2, AGF_F64 = 3 };
@@ -157,6 +157,23 @@ int agf_conv2d_fwd_mask(const void* x, const void* w, void* y,
                         int act, float alpha, float act_gain,
                         const void* mask_y, float mask_alpha, float* mask_sum,
                         const void* res_pooled, float res_scale, void* stream);
+
+/* The stride-2 3x3 convolution of the StyleGAN3 discriminator's downsampling blocks (thirdparty/stylegan3_ops/ops/conv2d_resample.py:100-103:
+ * `_conv2d_wrapper(x, w, stride=down)` after the FIR; implementations/StyleGAN3/model.py:410-417) and its data gradient, evaluated on the
+ * kept lattice only (9 taps per OUTPUT pixel; the round-2 formulation ran the 3x3 conv at every input pixel and decimated: 4x the flops).
+ *   agf_conv2d_s2_fwd:    y[n,i,j,co] = act( sum_{ky,kx,ci} x[n, 2i+ky, 2j+kx, ci] * w[co,ky,kx,ci] + bias[co] ) * act_gain
+ *                         x [N,xH,xW,Cin] (no padding: the FIR before it already padded; reads beyond xH / xW give 0), w [Cout,3,3,Cin],
+ *                         y [N,Ho,Wo,Cout]; the caller passes Ho = (xH - 3) / 2 + 1, Wo likewise
+ *   agf_conv2d_s2_dgrad:  dz[n,u,v,ci] = gain * sum_{ky = u mod 2 (+2), kx likewise} dy[n, (u-ky)/2, (v-kx)/2, co] * wt[ci,ky,kx,co]
+ *                         (the transposed conv, conv2d_gradfix.py's `conv_transpose2d(stride=2)` path); dy [N,Ho,Wo,Cout],
+ *                         wt [Cin,3,3,Cout] = w with the channel axes swapped (taps NOT flipped), dz [N,zH,zW,Cin] written completely
+ * bf16 channels-last, channel counts multiples of 8, 16-byte aligned; AGF_ENOKERNEL when a patch does not fit (output maps below 8x8). */
+int agf_conv2d_s2_fwd(const void* x, const void* w, void* y, const float* bias, int dtype,
+                      int32_t N, int32_t xH, int32_t xW, int32_t Cin, int32_t Cout, int32_t Ho, int32_t Wo,
+                      int act, float alpha, float act_gain, void* stream);
+int agf_conv2d_s2_dgrad(const void* dy, const void* wt, void* dz, int dtype,
+                        int32_t N, int32_t Ho, int32_t Wo, int32_t Cout, int32_t Cin, int32_t zH, int32_t zW,
+                        float gain, void* stream);
 
 /* Style-modulated layers on the streaming (persistent, direct-to-LDS) kernel: the modulation `weight * style` of the reference
  * (implementations/StyleGAN2/model.py:115) is folded into ONE weight tensor per image -- only for the few-channel high-resolution

@@ -360,3 +360,36 @@ def test_conv_wgrad_random_shapes_vs_aten(seed):
     wz = torch.zeros(Cout, Cin, 3, 3, device=DEV, requires_grad=True)
     (ref,) = torch.autograd.grad(F.conv2d(xf, wz, padding=1), wz, dyf)
     assert rel(dw, ref * 1.5) < (8e-3 if scaled else 1e-3), (N, Cin, Cout, H, W, scaled, rel(dw, ref * 1.5))
+
+
+@pytest.mark.parametrize('N,Cin,Cout,H', [(2, 16, 24, 16), (1, 64, 128, 34), (3, 136, 8, 20), (16, 32, 32, 16)],
+                         ids=['16ch-16x16', '64-128ch-34x34', '136-8ch-20x20', 'sixteen-images'])
+def test_stride2_conv_and_its_gradients_of_first_and_second_order(N, Cin, Cout, H):
+    """``conv2d_s2`` (agf_conv2d_s2_fwd / agf_conv2d_s2_dgrad: the StyleGAN3 discriminator's downsampling conv on the kept lattice) against
+    ATen's strided convolution on the CPU in fp32, from the same bf16-rounded operands: forward, data gradient (the transposed conv, four
+    phase launches with the strided store), weight gradient, and a second-order term (R1 differentiates the discriminator twice)."""
+    import torch.nn.functional as F
+    from animeface_amd.implementations.StyleGAN2.conv import conv2d_s2
+    g = torch.Generator().manual_seed(N * 1000 + Cin + H)
+    ZH, ZW = H + 1, H + 3                                       # odd and unequal: the reference's FIR output is (H + 1) wide
+    z = torch.randn(N, Cin, ZH, ZW, generator=g).bfloat16().float()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).bfloat16().float()
+    zr, wr = z.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = F.conv2d(zr, wr, stride=2)
+    gy = torch.randn(yr.shape, generator=g).bfloat16().float()
+    dzr, dwr = torch.autograd.grad(yr, [zr, wr], gy, create_graph=True)
+    s2r = (dzr.square().sum() * 0.5 + dwr.square().sum() * 0.5)
+    ddwr, = torch.autograd.grad(s2r, [wr])
+
+    zd = z.to('cuda', torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wd = w.to('cuda').requires_grad_(True)
+    y = conv2d_s2(zd, wd)
+    assert y is not None and y.shape == yr.shape
+    tol = dict(rtol=2e-2, atol=2e-2 * float(yr.detach().abs().max()))
+    torch.testing.assert_close(y.float().cpu(), yr.detach(), **tol)
+    dz, dw = torch.autograd.grad(y, [zd, wd], gy.to('cuda', torch.bfloat16), create_graph=True)
+    torch.testing.assert_close(dz.float().cpu(), dzr.detach(), rtol=2e-2, atol=2e-2 * float(dzr.detach().abs().max()))
+    torch.testing.assert_close(dw.float().cpu(), dwr.detach(), rtol=2e-2, atol=2e-2 * float(dwr.detach().abs().max()))
+    s2 = (dz.float().square().sum() * 0.5 + dw.float().square().sum() * 0.5)
+    ddw, = torch.autograd.grad(s2, [wd])
+    torch.testing.assert_close(ddw.float().cpu(), ddwr.detach(), rtol=5e-2, atol=5e-2 * float(ddwr.abs().max()))
