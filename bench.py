@@ -37,7 +37,7 @@ def cpu_baseline(image_size, seconds_budget=30.0):
     D = S.init_state(S.discriminator_state_shapes(cfg), cfg, which='D')
     E = {k: v.clone() for k, v in G.items()}
     st = T.StepState(cfg, G, E, D)
-    B = 2
+    B = 4                                                    # batch 4
     real = torch.rand(B, 3, image_size, image_size) * 2 - 1
     sampler = lambda size: torch.empty(size).normal_()
     t0 = time.time()
@@ -53,6 +53,38 @@ def cpu_baseline(image_size, seconds_budget=30.0):
                 gan_iteration_s=round(t_gan, 2), r1_iteration_s=round(t_r1, 2),
                 sample=f'1 GAN-loss iteration + 1 lazy-R1 iteration of the same {image_size}x{image_size} step at batch {B} in fp32, '
                        f'weighted {k - 1}:1 as in the loop (oracle/training.py, torch {torch.__version__} CPU)')
+
+
+def upfirdn2d_roofline(dev, batch=64, reps=20):
+    """The three SURVEY.md section 8(d) upfirdn2d rows at 256x256 (north_star: >= 60 % of the HBM roofline), timed in this process with HIP
+    events on the launch stream: algorithmic bytes = (numel_in + numel_out) * sizeof(T) over the launch time, as a fraction of 8 TB/s.
+    bf16, both layouts: channels-last (what the training step runs) and planar NCHW (what a drop-in caller of the reference op passes)."""
+    from animeface_amd.stylegan3_ops import upfirdn2d as U
+    f4, f3 = U.setup_filter([1, 3, 3, 1], device=dev), U.setup_filter([1, 2, 1], device=dev)
+    rows = []
+    for layout, mf in (('nhwc', torch.channels_last), ('nchw', torch.contiguous_format)):
+        x128 = torch.randn(batch, 64, 128, 128, device=dev).to(torch.bfloat16).contiguous(memory_format=mf)
+        x256 = torch.randn(batch, 64, 256, 256, device=dev).to(torch.bfloat16).contiguous(memory_format=mf)
+        cases = [('up2 f=4x4 [%d,64,128,128]->256x256' % batch, lambda: U.upsample2d(x128, f4, up=2), x128.numel() * 5 * 2),
+                 ('blur f=3x3 [%d,64,256,256]' % batch, lambda: U.filter2d(x256, f3), x256.numel() * 2 * 2),
+                 ('down2 f=4x4 [%d,64,256,256]->128x128' % batch, lambda: U.downsample2d(x256, f4, down=2), x256.numel() * 1.25 * 2)]
+        with torch.no_grad():
+            for name, fn, nbytes in cases:
+                for _ in range(3):
+                    fn()
+                torch.cuda.synchronize()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(reps):
+                    fn()
+                b.record()
+                torch.cuda.synchronize()
+                sec = a.elapsed_time(b) / reps * 1e-3
+                rows.append({'kernel': name, 'layout': layout, 'dtype': 'bf16', 'ms': round(sec * 1e3, 4), 'algorithmic_bytes': int(nbytes),
+                             'achieved': round(nbytes / sec / 1e9, 1), 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': round(nbytes / sec / HBM_PEAK, 4)})
+        del x128, x256
+    return {'bound': 'hbm', 'rows': rows, 'target': 'north_star: >= 0.60 on upfirdn2d at 256x256',
+            'traffic': 'PMC passes (FETCH_SIZE x2 + WRITE_SIZE): profiles/r03_upfirdn_hbm_pmc.txt'}
 
 
 def measured_traffic():
@@ -82,6 +114,8 @@ def main():
                                                          'per-launch roofline timing always run eagerly.  With several GPUs the step is eager (the gradient '
                                                          'exchange is issued from backward hooks)')
     ap.add_argument('--no-r1-every-step', action='store_true', help='skip the side measurement with the R1 penalty on every iteration')
+    ap.add_argument('--no-ada-variant', action='store_true', help='skip the side measurement with the ADA pipe (BASELINE configs[2] "+ ADA")')
+    ap.add_argument('--no-upfirdn2d-rows', action='store_true', help='skip the three upfirdn2d roofline rows (SURVEY.md section 8d)')
     ap.add_argument('--augment', default='color,translation', help="DiffAugment policy (the reference's SG2 default) or 'ada'")
     args = ap.parse_args()
 
@@ -243,6 +277,29 @@ def main():
         r1_ms = (time.perf_counter() - t1) / n_r1 * 1e3
         step.batches_done = saved
 
+    # BASELINE.json configs[2] literally reads "StyleGAN2 256x256 + ADA + R1": the same iteration with the adaptive augmentation pipe
+    # (thirdparty/ada.py, 12 augmentations, p adapted from sign(D(real))) instead of DiffAugment -- a side figure measured after the window on
+    # the same networks; the pipe synchronises with the host once per iteration (its p update), so these iterations are launched eagerly
+    ada_out = None
+    if not args.no_ada_variant and args.augment != 'ada' and not dp_on:
+        ada_step = U.TrainStep(G, G_ema, D, opt_G, opt_D, 10., 0., 16, 8, 'ada', 512, functools.partial(sample_nnoise, device=dev))
+        ada_step.batches_done = 1
+        for _ in range(3):
+            ada_step(real)
+        barrier()
+        n_ada = 8
+        ta = time.perf_counter()
+        for _ in range(n_ada):
+            ada_step(real)
+        barrier()
+        ada_ms = (time.perf_counter() - ta) / n_ada * 1e3
+        ada_out = {'value': round(args.batch * world / (ada_ms * 1e-3), 2), 'unit': 'img/s', 'ms_per_step': round(ada_ms, 3), 'steps': n_ada,
+                   'p': round(float(ada_step.ada.p) if hasattr(ada_step.ada, 'p') else -1.0, 4),
+                   'note': 'configs[2] "+ ADA": GAN-loss iterations with the ADA pipe in place of DiffAugment, eager launches, after the timed window'}
+    fir_out = None
+    if rank == 0 and not args.no_upfirdn2d_rows:
+        fir_out = upfirdn2d_roofline(dev, args.batch)
+
     if dp_on:
         # RCCL writes its version banner through C stdio, which a process flushes at exit -- after rank 0's JSON line.  Every rank flushes
         # now, before rank 0 prints, so that the JSON line is the LAST line of the job's stdout
@@ -263,7 +320,7 @@ def main():
                                    f'(BASELINE.json configs[2]: channels 32, max 512, style 512, d_k 16, r1_lambda 10, '
                                    + ('ADA pipe (12 augmentations, adaptive p)' if args.augment == 'ada' else f'DiffAugment {args.augment} = the reference SG2 default; --augment ada selects the ADA pipe') + ', Adam, EMA)',
                        'global_batch': args.batch * world, 'parallelism': f'dp{world}',
-                       'r1_steps_in_window': r1_steps, 'params_G': sum(p.numel() for p in G.parameters()),
+                       'r1_steps_in_window': r1_steps, 'window': f'{args.steps} iterations of which {r1_steps} lazy-R1 (iterations {first_timed}..{first_timed + args.steps - 1}, d_k = 16)', 'params_G': sum(p.numel() for p in G.parameters()),
                        'params_D': sum(p.numel() for p in D.parameters())},
         }
         srt = sorted(step_ms)
@@ -274,6 +331,10 @@ def main():
         if r1_ms is not None:
             out['r1_every_step'] = {'value': round(args.batch * world / (r1_ms * 1e-3), 2), 'unit': 'img/s', 'ms_per_step': round(r1_ms, 3),
                                     'note': 'the lazy-R1 iteration (penalty replaces the GAN loss) on every step: 4 steps after the timed window'}
+        if ada_out is not None:
+            out['ada_variant'] = ada_out
+        if fir_out is not None:
+            out['roofline_upfirdn2d'] = fir_out
         if dp_on:
             # what the exchange looked like: RCCL ranks, buckets launched from backward hooks (overlappable) vs. at finish(), and the time
             # the compute stream waited for the exchange (exposed); hidden = the rest of the all-reduce time
