@@ -450,8 +450,13 @@ static void launch_planar(UpfirdnParams p, hipStream_t st) {
 // peak in bf16.
 constexpr int pv_floor_div(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 
-template <class T, int UP, int DN, int FW, int FH, int PAD0, int ROWS, int PM, int PF>
-static __device__ __forceinline__ void planar_vec_body(const UpfirdnParams& p, const float* sf, const T* xb, T* yb, int g, int oy0, int iyBase) {
+// SHF: the halo samples left / right of a lane's own vectors come from the neighbouring LANES (one dword each way per input row) instead of
+// from memory.  Lanes of a wave are consecutive column groups; when the groups of a row divide the wave (a power of two <= 64) a row's
+// first / last group sits on a wave edge or next to another row, where the halo is the image border anyway.  The loaded bytes per lane
+// drop from NV to IV / VEC vectors per input row (3 -> 1 for the blur): the L1 / address path, not HBM, was what held the planar bf16
+// cases at 0.43-0.56 of the peak.
+template <class T, int UP, int DN, int FW, int FH, int PAD0, int ROWS, int PM, int PF, bool SHF>
+static __device__ __forceinline__ void planar_vec_body(const UpfirdnParams& p, const float* sf, const T* xb, T* yb, int g, int oy0, int iyBase, int groups) {
     constexpr int VEC = 16 / sizeof(T);
     constexpr int OV = UP > 1 ? VEC * UP : VEC;                       // output columns of a lane
     constexpr int IV = OV * DN / UP;                                  // input columns they map to (a whole number of vectors)
@@ -462,6 +467,9 @@ static __device__ __forceinline__ void planar_vec_body(const UpfirdnParams& p, c
     constexpr int NV = DHI - DLO + 1;
     constexpr int NR = ((ROWS - 1) * DN + PM) / UP + NTY;             // input rows of the strip
     static_assert(IV % VEC == 0 && NV <= 5, "planar_vec geometry");
+    constexpr int EPD = 4 / sizeof(T);                                // elements per dword
+    constexpr int HL = -REL_MIN > 0 ? -REL_MIN : 0, HR = REL_MAX - (IV - 1) > 0 ? REL_MAX - (IV - 1) : 0;     // halo samples used left / right
+    static_assert(!SHF || (HL <= EPD && HR <= EPD && DLO >= -1 && DHI <= IV / VEC), "planar_vec: the shuffled halo is one dword per side");
     const int nvec = p.W / VEC;
     const int v0 = g * (IV / VEC) + DLO;
     float acc[ROWS][OV];
@@ -481,7 +489,8 @@ static __device__ __forceinline__ void planar_vec_body(const UpfirdnParams& p, c
             const int vi = v0 + d;
             const int vc = min(max(vi, 0), nvec - 1);
             raw_t t = {0u, 0u, 0u, 0u};
-            if (rowOk && (p.clamp_edge || vi == vc)) t = *(const raw_t*)(row + (int64_t)vc * VEC);
+            const bool own = d + DLO >= 0 && d + DLO < IV / VEC;       // (compile-time per d)
+            if ((!SHF || own) && rowOk && (p.clamp_edge || vi == vc)) t = *(const raw_t*)(row + (int64_t)vc * VEC);
             dst[d] = t;
         }
     };
@@ -492,6 +501,15 @@ static __device__ __forceinline__ void planar_vec_body(const UpfirdnParams& p, c
     for (int r = 0; r < NR; r++) {
         float row[NV * VEC];
         raw_t (&nxt)[NV] = buf[r % PF];
+        if constexpr (SHF) {
+            // left halo: the LAST dword of the left neighbour's last own vector; right halo: the FIRST dword of the right neighbour's first
+            constexpr int FIRST = -DLO, LAST = -DLO + IV / VEC - 1;     // indices of this lane's own vectors in nxt[]
+            uint32_t fromLeft = (uint32_t)__shfl_up((int)nxt[LAST].w, 1), fromRight = (uint32_t)__shfl_down((int)nxt[FIRST].x, 1);
+            if (g == 0) fromLeft = p.clamp_edge ? (sizeof(T) == 4 ? nxt[FIRST].x : ((nxt[FIRST].x & 0xffffu) | (nxt[FIRST].x << 16))) : 0u;
+            if (g == groups - 1) fromRight = p.clamp_edge ? (sizeof(T) == 4 ? nxt[LAST].w : ((nxt[LAST].w >> 16) | (nxt[LAST].w & 0xffff0000u))) : 0u;
+            if constexpr (DLO < 0) { nxt[0].x = 0u; nxt[0].y = 0u; nxt[0].z = 0u; nxt[0].w = fromLeft; }
+            if constexpr (DHI >= IV / VEC) { nxt[NV - 1].x = fromRight; nxt[NV - 1].y = 0u; nxt[NV - 1].z = 0u; nxt[NV - 1].w = 0u; }
+        }
 #pragma unroll
         for (int d = 0; d < NV; d++) {
             if constexpr (sizeof(T) == 4) {
@@ -501,7 +519,7 @@ static __device__ __forceinline__ void planar_vec_body(const UpfirdnParams& p, c
                 Pack16<T>::unpack(nxt[d].x, row[d * VEC + 0], row[d * VEC + 1]); Pack16<T>::unpack(nxt[d].y, row[d * VEC + 2], row[d * VEC + 3]);
                 Pack16<T>::unpack(nxt[d].z, row[d * VEC + 4], row[d * VEC + 5]); Pack16<T>::unpack(nxt[d].w, row[d * VEC + 6], row[d * VEC + 7]);
             }
-            if (p.clamp_edge) {                                        // a vector beyond the row replicates the row's edge sample
+            if (!SHF && p.clamp_edge) {                                // a vector beyond the row replicates the row's edge sample
                 const int vi = v0 + d;
                 if (vi < 0) {
 #pragma unroll
@@ -549,7 +567,7 @@ static __device__ __forceinline__ void planar_vec_body(const UpfirdnParams& p, c
     }
 }
 
-template <class T, int UP, int DN, int FW, int FH, int PAD0, int ROWS, int PF>
+template <class T, int UP, int DN, int FW, int FH, int PAD0, int ROWS, int PF, bool SHF>
 __global__ void __launch_bounds__(256) upfirdn2d_planar_vec(UpfirdnParams p, int groups, int strips) {
     __shared__ float sf[FH * FW];
     stage_filter<256>(p, sf);
@@ -568,15 +586,14 @@ __global__ void __launch_bounds__(256) upfirdn2d_planar_vec(UpfirdnParams p, int
     const int pm = midy0 - iyBase * UP;
     const T* xb = (const T*)p.x + plane * p.H * p.W;
     T* yb = (T*)p.y + plane * p.OH * p.OW;
-    if (UP == 1 || pm == 0) planar_vec_body<T, UP, DN, FW, FH, PAD0, ROWS, 0, PF>(p, sf, xb, yb, g, oy0, iyBase);
-    else planar_vec_body<T, UP, DN, FW, FH, PAD0, ROWS, (UP >= 2 ? 1 : 0), PF>(p, sf, xb, yb, g, oy0, iyBase);
+    if (UP == 1 || pm == 0) planar_vec_body<T, UP, DN, FW, FH, PAD0, ROWS, 0, PF, SHF>(p, sf, xb, yb, g, oy0, iyBase, groups);
+    else planar_vec_body<T, UP, DN, FW, FH, PAD0, ROWS, (UP >= 2 ? 1 : 0), PF, SHF>(p, sf, xb, yb, g, oy0, iyBase, groups);
 }
 
 template <class T>
 static bool launch_planar_vec_cases(const UpfirdnParams& p, hipStream_t st) {
-    static const bool on = []{ const char* e = getenv("AGF_UPFIRDN_PLANAR_VEC"); return !(e && e[0] == '0'); }();
     constexpr int VEC = 16 / sizeof(T);
-    if (!on || p.upx != p.upy || p.downx != p.downy || p.fw != p.fh || p.upx > 2) return false;
+    if (p.upx != p.upy || p.downx != p.downy || p.fw != p.fh || p.upx > 2) return false;
     if (p.W % VEC || ((uintptr_t)p.x % 16) || ((uintptr_t)p.y % 16)) return false;
 #define PVEC_CASE(U_, D_, F_, P_, R_, PF_)                                                                                        \
     if (p.upx == U_ && p.downx == D_ && p.fw == F_ && p.padx0 == P_) {                                                          \
@@ -585,25 +602,22 @@ static bool launch_planar_vec_cases(const UpfirdnParams& p, hipStream_t st) {
         const int groups = p.OW / OV, strips = (p.OH + R_ - 1) / R_;                                                            \
         const int64_t threads = (int64_t)groups * strips * p.N * p.C;                                                           \
         if (threads >= (1ll << 38)) return false;                                                                               \
-        hipLaunchKernelGGL((upfirdn2d_planar_vec<T, U_, D_, F_, F_, P_, R_, PF_>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, \
-                           p, groups, strips);                                                                                  \
+        if (groups <= 64 && (groups & (groups - 1)) == 0)                                                                       \
+            hipLaunchKernelGGL((upfirdn2d_planar_vec<T, U_, D_, F_, F_, P_, R_, PF_, true>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, \
+                               p, groups, strips);                                                                              \
+        else                                                                                                                    \
+            hipLaunchKernelGGL((upfirdn2d_planar_vec<T, U_, D_, F_, F_, P_, R_, PF_, false>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, \
+                               p, groups, strips);                                                                              \
         return true; }
-    static const int pfSel = []{ const char* e = getenv("AGF_PVEC_PF"); return e ? atoi(e) : 0; }();         // A/B: input rows in flight per lane
-    if (pfSel == 1) {
-        PVEC_CASE(2, 1, 4, 2, 4, 1) PVEC_CASE(1, 1, 3, 1, 4, 1) PVEC_CASE(1, 2, 2, 0, 4, 1) PVEC_CASE(1, 2, 4, 1, 2, 1) PVEC_CASE(2, 1, 2, 1, 4, 1)
-    } else if (pfSel == 2) {
-        PVEC_CASE(2, 1, 4, 2, 4, 2) PVEC_CASE(1, 1, 3, 1, 4, 2) PVEC_CASE(1, 2, 2, 0, 4, 2) PVEC_CASE(1, 2, 4, 1, 2, 2) PVEC_CASE(2, 1, 2, 1, 4, 2)
-    } else if (pfSel == 3) {
-        PVEC_CASE(2, 1, 4, 2, 4, 3) PVEC_CASE(1, 1, 3, 1, 4, 3) PVEC_CASE(1, 2, 2, 0, 4, 3) PVEC_CASE(1, 2, 4, 1, 2, 3) PVEC_CASE(2, 1, 2, 1, 4, 3)
-    } else if (pfSel == 4) {
-        PVEC_CASE(2, 1, 4, 2, 4, 4) PVEC_CASE(1, 1, 3, 1, 4, 4) PVEC_CASE(1, 2, 2, 0, 4, 4) PVEC_CASE(1, 2, 4, 1, 2, 4) PVEC_CASE(2, 1, 2, 1, 4, 4)
-    }
     // (rows in flight: measured per case with tools/bench_planar.py -- bf16 up2 0.49 -> 0.53 of the HBM peak with 2, down2 f4 0.42 -> 0.48
     //  with 4; the blur and the pooling are best with 1)
-    PVEC_CASE(2, 1, 4, 2, 4, 2)      // 2x upsample [1,3,3,1]
-    PVEC_CASE(1, 1, 3, 1, 4, 1)      // blur [1,2,1]
-    PVEC_CASE(1, 2, 2, 0, 4, 1)      // 2x2 average pooling
-    PVEC_CASE(1, 2, 4, 1, 2, 4)      // 2x downsample [1,3,3,1]
+    // (output rows per lane, input rows in flight: measured per case with tools/bench_planar.py after the halo moved to lane shuffles --
+    //  with a third of the loads per row, MORE rows in flight pay: bf16 up2 0.53 -> 0.60-0.62 of the HBM peak, blur 0.44 -> 0.62,
+    //  2x2 pooling 0.68, down2 f4 0.47 -> 0.68; the fp32 blur keeps its 4-row strips (0.72))
+    PVEC_CASE(2, 1, 4, 2, 2, 3)      // 2x upsample [1,3,3,1]
+    if constexpr (sizeof(T) == 4) { PVEC_CASE(1, 1, 3, 1, 4, 1) } else { PVEC_CASE(1, 1, 3, 1, 8, 3) }      // blur [1,2,1]
+    PVEC_CASE(1, 2, 2, 0, 4, 2)      // 2x2 average pooling
+    PVEC_CASE(1, 2, 4, 1, 2, 6)      // 2x downsample [1,3,3,1]
     PVEC_CASE(2, 1, 2, 1, 4, 1)      // adjoint of the average pooling
 #undef PVEC_CASE
     return false;

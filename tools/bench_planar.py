@@ -1,5 +1,5 @@
 """Planar (NCHW) upfirdn2d cases of tools/bench_kernels.py only: fraction of the 8 TB/s HBM peak per case (A/B of the planar_vec kernel:
-AGF_PVEC_PF = input rows in flight per lane, AGF_PVEC_ROWS = output rows per lane)."""
+per-case rows per lane and rows in flight are compile-time choices in launch_planar_vec_cases)."""
 import json, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -38,7 +38,7 @@ def main():
             for name, fn, nbytes in cases:
                 out[f'{name}_{"bf16" if es == 2 else "f32"}'] = round(nbytes / timeit(fn) / HBM_PEAK, 3)
         del x128, x256
-    print(os.environ.get('AGF_PVEC_PF', '-'), os.environ.get('AGF_PVEC_ROWS', '-'), json.dumps(out))
+    print(json.dumps(out))
 
 
 if __name__ == '__main__':
