@@ -42,7 +42,7 @@ def init_distributed():
 
 
 class GradReducer:
-    def __init__(self, params, bucket_bytes=32 << 20, group=None, never_used=()):
+    def __init__(self, params, bucket_bytes=32 << 20, group=None, never_used=(), tail_bytes=8 << 20):
         """``never_used``: parameters the forward pass is known never to touch (``InjectNoise.scale``, reference F10).  A bucket is
         launched from the backward hooks once ALL of its parameters have their gradient, so such parameters would hold every bucket
         they sit in back until ``finish()`` (no overlap at all for the generator); they get a bucket of their own instead."""
@@ -60,18 +60,22 @@ class GradReducer:
         idle = [p for p in self.params if id(p) in skip]
         if idle:
             self._make_bucket(idle)
-        # backward produces gradients roughly in reverse parameter order
-        order = [p for p in reversed(self.params) if id(p) not in skip]
-        cur, cur_bytes = [], 0
+        # backward produces gradients roughly in reverse parameter order.  The bucket that completes LAST cannot overlap anything -- its
+        # all-reduce is the exposed tail of the exchange -- so it is kept small (``tail_bytes``); the buckets before it are large
+        # (xGMI ring: per-link bound, latency amortised over 32 MiB).  Built from the tail end: walk the parameters in FORWARD order.
+        order = [p for p in self.params if id(p) not in skip]
+        groups, cur, cur_bytes, cap = [], [], 0, min(tail_bytes, bucket_bytes)
         for p in order:
             nbytes = p.numel() * 4
-            if cur and cur_bytes + nbytes > bucket_bytes:
-                self._make_bucket(cur)
-                cur, cur_bytes = [], 0
+            if cur and cur_bytes + nbytes > cap:
+                groups.append(cur)
+                cur, cur_bytes, cap = [], 0, bucket_bytes
             cur.append(p)
             cur_bytes += nbytes
         if cur:
-            self._make_bucket(cur)
+            groups.append(cur)
+        for grp in reversed(groups):                     # bucket order = completion order in backward
+            self._make_bucket(list(reversed(grp)))
         self.enabled = True
 
     def _make_bucket(self, plist):
@@ -94,6 +98,11 @@ class GradReducer:
                 return
             self._touched.add(id(param))
             bucket['pending'] -= 1
+            # one backward per parameter between zero_grad() and finish(): a second one would launch the bucket with a partial gradient
+            # and then accumulate into a buffer whose all-reduce is in flight
+            if bucket['pending'] < 0 or bucket['launched']:
+                raise RuntimeError('GradReducer: a parameter received a second gradient before finish() / zero_grad() '
+                                   '(accumulating several backward passes needs reducer.enabled = False until the last one)')
             if bucket['pending'] == 0 and self.early:
                 bucket['early'] = True
                 self._pack(bucket)

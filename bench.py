@@ -109,10 +109,10 @@ def main():
     ap.add_argument('--batch', type=int, default=64, help='per-GPU batch')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timer', action='store_true')
-    ap.add_argument('--eager', action='store_true', help='launch every kernel from the host.  Default on ONE GPU: the iteration is replayed from HIP '
-                                                         'graphs (GraphedTrainStep: same kernels, one host call per iteration); the steps sampled for the '
-                                                         'per-launch roofline timing always run eagerly.  With several GPUs the step is eager (the gradient '
-                                                         'exchange is issued from backward hooks)')
+    ap.add_argument('--eager', action='store_true', help='launch every kernel from the host (several GPUs: the gradient all-reduce is then issued from '
+                                                         'backward hooks and overlaps the backward pass).  Default for every N: the iteration is replayed '
+                                                         'from HIP graphs (GraphedTrainStep: same kernels, one host call per iteration and graph segment); '
+                                                         'the iterations sampled for the per-launch roofline timing always run eagerly')
     ap.add_argument('--no-r1-every-step', action='store_true', help='skip the side measurement with the R1 penalty on every iteration')
     ap.add_argument('--no-ada-variant', action='store_true', help='skip the side measurement with the ADA pipe (BASELINE configs[2] "+ ADA")')
     ap.add_argument('--no-upfirdn2d-rows', action='store_true', help='skip the three upfirdn2d roofline rows (SURVEY.md section 8d)')
@@ -143,10 +143,11 @@ def main():
     update_ema(G, G_ema, decay=0)
     dp.broadcast_module(G), dp.broadcast_module(G_ema), dp.broadcast_module(D)
     dp_on = world > 1 or dist.is_initialized()           # (AGF_FORCE_DP=1: a one-rank RCCL group, to exercise the path on a single-GPU box)
-    use_graphs = (not args.eager) and args.augment != 'ada' and (not dp_on or os.environ.get('AGF_DP_GRAPHS', '0') == '1')
-    # (several ranks: AGF_DP_GRAPHS=1 replays three graphs per iteration with the gradient all-reduce between the launches -- tested with two
-    #  ranks on one GPU over gloo (tests/test_hip_dp.py), never yet on RCCL hardware, hence opt-in; the default there is the eager loop whose
-    #  all-reduce overlaps the backward pass)
+    use_graphs = (not args.eager) and args.augment != 'ada'
+    # ONE execution mode for every N: HIP-graph replay.  With several ranks the iteration is three graphs cut at the two gradient exchanges,
+    # the all-reduce of the bucket buffers issued between the launches (tests/test_hip_dp.py: two ranks on one GPU over gloo, and a one-rank
+    # RCCL group via AGF_FORCE_DP=1).  If ANY rank fails to capture, every rank falls back to the eager loop (all-reduce from backward hooks,
+    # overlapped with the backward pass); --eager selects that loop outright.
     opt_G, opt_D = U.build_optimizers(G, D, 0.001, (0., 0.99), 10., 0., 16, 8, capturable=use_graphs)
     red_G = dp.GradReducer(G.parameters(), never_used=dp.never_used_parameters(G)) if dp_on else None
     red_D = dp.GradReducer(D.parameters()) if dp_on else None
@@ -227,9 +228,11 @@ def main():
     barrier()
     t0 = time.perf_counter()
     marks[0].record()
+    host_t = [t0]
     for i in range(args.steps):
         step(real)
         marks[i + 1].record()
+        host_t.append(time.perf_counter())              # host time to ISSUE the iteration (no synchronisation): >= the GPU time means host-bound
     barrier()
     dt = time.perf_counter() - t0
     step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
@@ -324,7 +327,8 @@ def main():
                        'params_D': sum(p.numel() for p in D.parameters())},
         }
         srt = sorted(step_ms)
-        out['step_ms'] = {'p50': round(srt[len(srt) // 2], 3), 'min': round(srt[0], 3), 'max': round(srt[-1], 3),
+        hsrt = sorted((host_t[i + 1] - host_t[i]) * 1e3 for i in range(args.steps))
+        out['step_ms'] = {'p50': round(srt[len(srt) // 2], 3), 'host_issue_p50': round(hsrt[len(hsrt) // 2], 3), 'min': round(srt[0], 3), 'max': round(srt[-1], 3),
                           'max_without_r1_steps': round(max([m for i, m in enumerate(step_ms) if not ((first_timed + i) % 16 == 0 and first_timed + i != 0)] or [0.0]), 3),
                           'all': [round(m, 2) for m in step_ms],
                           'note': 'GPU time between event records placed after each iteration of the timed window (no sync); the lazy-R1 iterations are the long ones'}

@@ -1,7 +1,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for mode in single dp; do
-  if [ $mode = dp ]; then export AGF_FORCE_DP=1 AGF_DP_GRAPHS=${DP_GRAPHS:-1}; fi
-  rm -rf /tmp/gap_$mode; rocprofv3 --kernel-trace --output-format csv -d /tmp/gap_$mode -o g -- python bench.py --steps 12 --warmup 2 --no-cpu-baseline --no-kernel-timer --no-r1-every-step > /tmp/gap_$mode.log 2>&1
+  if [ $mode = dp ]; then export AGF_FORCE_DP=1; fi
+  rm -rf /tmp/gap_$mode; rocprofv3 --kernel-trace --output-format csv -d /tmp/gap_$mode -o g -- python bench.py --steps 12 --warmup 2 --no-cpu-baseline --no-kernel-timer --no-r1-every-step --no-ada-variant --no-upfirdn2d-rows > /tmp/gap_$mode.log 2>&1
   grep '"metric"' /tmp/gap_$mode.log | cut -c100-260
 done
 python - <<'PY'

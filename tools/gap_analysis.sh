@@ -1,7 +1,7 @@
 #!/bin/bash
 # kernel trace of graph-replayed steps: busy time vs wall span, gap statistics, per-kernel totals inside one steady-state iteration
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rm -rf /tmp/gap; rocprofv3 --kernel-trace --output-format csv -d /tmp/gap -o g -- python bench.py --steps 12 --warmup 2 --no-cpu-baseline --no-kernel-timer --no-r1-every-step "$@" > /tmp/gap_bench.log 2>&1
+rm -rf /tmp/gap; rocprofv3 --kernel-trace --output-format csv -d /tmp/gap -o g -- python bench.py --steps 12 --warmup 2 --no-cpu-baseline --no-kernel-timer --no-r1-every-step --no-ada-variant --no-upfirdn2d-rows "$@" > /tmp/gap_bench.log 2>&1
 tail -1 /tmp/gap_bench.log | cut -c1-200
 python - <<'PY'
 import csv, glob, collections

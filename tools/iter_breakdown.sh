@@ -5,7 +5,7 @@
 out=${1:-gpurun_out/iter_breakdown.txt}; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p $(dirname $out)
-rm -rf /tmp/itb; rocprofv3 --kernel-trace --output-format csv -d /tmp/itb -o g -- python bench.py --steps 12 --warmup 2 --no-cpu-baseline --no-kernel-timer --no-r1-every-step "$@" > /tmp/itb_bench.log 2>&1
+rm -rf /tmp/itb; rocprofv3 --kernel-trace --output-format csv -d /tmp/itb -o g -- python bench.py --steps 12 --warmup 2 --no-cpu-baseline --no-kernel-timer --no-r1-every-step --no-ada-variant --no-upfirdn2d-rows "$@" > /tmp/itb_bench.log 2>&1
 tail -1 /tmp/itb_bench.log | cut -c1-260 > $out
 python - >> $out <<'PY'
 import csv, glob, collections, re

@@ -16,7 +16,7 @@ python tools/bench_kernels.py --cpu > gpurun_out/${tag}_kernel_microbench.jsonl 
 python tools/bench_flrelu.py > gpurun_out/${tag}_flrelu_roofline.jsonl 2>/dev/null
 cat gpurun_out/${tag}_flrelu_roofline.jsonl | cut -c1-400
 bash tools/pmc_bench_traffic.sh > /dev/null 2>&1; cp gpurun_out/conv_traffic.json gpurun_out/${tag}_conv_fwd_traffic.json
-rm -rf /tmp/prof_s; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_s -o p -- python bench.py --steps 16 --warmup 2 --no-cpu-baseline --no-kernel-timer --no-r1-every-step > gpurun_out/${tag}_bench_step_prof.log 2>&1
+rm -rf /tmp/prof_s; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_s -o p -- python bench.py --steps 16 --warmup 2 --no-cpu-baseline --no-kernel-timer --no-r1-every-step --no-ada-variant --no-upfirdn2d-rows > gpurun_out/${tag}_bench_step_prof.log 2>&1
 find /tmp/prof_s -name "*kernel_stats.csv" -exec cp {} gpurun_out/${tag}_bench_step_kernel_stats.csv \;
 rm -rf /tmp/prof_3; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_3 -o p -- python tools/bench_sg3.py --image-size 512 --batch 16 --steps 4 --warmup 2 > /dev/null 2>&1
 find /tmp/prof_3 -name "*kernel_stats.csv" -exec cp {} gpurun_out/${tag}_sg3_512_kernel_stats.csv \;
