@@ -1,0 +1,110 @@
+"""BASELINE.json configurations 2 and 4 at FULL size under ``-m gpu`` (configuration 3, StyleGAN2 256x256 batch 64, is
+tests/test_hip_sg2.py::test_full_size_step_properties): the size-independent properties a full-size run admits -- everything finite, the
+discriminator frozen in the generator half-step, never-used parameters never stepped, a replay from the same seeds reproduces the
+losses, and (StyleGAN2) the HIP-graph replay agrees with the eager iteration.  Element-wise parity lives in the layer-wise tests."""
+import functools
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def test_stylegan2_128_batch_32_full_size_step_properties():
+    """configs[1]: "StyleGAN2 128x128 bf16, batch 32, 1xMI355X (upfirdn2d + bias_act HIP path)"."""
+    from animeface_amd.implementations.StyleGAN2 import model as M, utils as U
+    from animeface_amd.nnutils import sample_nnoise, update_ema
+
+    def run(graphed):
+        torch.manual_seed(0)
+        G, G_ema, D = M.Generator(128).to(DEV), M.Generator(128).to(DEV), M.Discriminator(128).to(DEV)
+        G.init_weight(functools.partial(M.init_weight_N01, lr=0.01), M.init_weight_N01)
+        D.apply(M.init_weight_N01)
+        G_ema.eval()
+        update_ema(G, G_ema, decay=0)
+        oG, oD = U.build_optimizers(G, D, 0.001, (0., 0.99), 10., 0., 4, 8, capturable=True)
+        step = U.TrainStep(G, G_ema, D, oG, oD, 10., 0., 4, 8, 'color,translation', 512, functools.partial(sample_nnoise, device=DEV))
+        gen = torch.Generator().manual_seed(3)
+        real = (torch.rand(32, 3, 128, 128, generator=gen) * 2 - 1).to(DEV)
+        seen = {}
+        orig = step._g_half
+
+        def g_half(real, it):
+            out = orig(real, it)
+            seen['d_frozen'] = all(not p.requires_grad for p in D.parameters())
+            return out
+        step._g_half = g_half
+        torch.manual_seed(77)
+        losses = []
+        for _ in range(2):
+            step(real)
+        runner = U.GraphedTrainStep(step, real, warmup=0) if graphed else step
+        for _ in range(7):                                               # iterations 2..8: lazy R1 at 4 and 8 (d_k = 4)
+            dl, gl, fake = runner(real)
+            losses.append((float(dl), float(gl)))
+        assert seen['d_frozen']
+        assert torch.isfinite(fake).all() and tuple(fake.shape) == (32, 3, 128, 128)
+        for net in (G, D, G_ema):
+            for n, p in net.named_parameters():
+                assert torch.isfinite(p).all(), n
+        for n, p in G.named_parameters():
+            if n.endswith('.scale'):
+                assert float(p.detach().abs().max()) == 0.0, n
+        return losses
+    a, b, c = run(False), run(False), run(True)
+    assert all(abs(x) < 1e4 for pair in a for x in pair), a
+    for (d0, g0), (d1, g1), (d2, g2) in zip(a, b, c):
+        assert d0 == pytest.approx(d1, rel=5e-3, abs=1e-4) and g0 == pytest.approx(g1, rel=5e-3, abs=1e-4), (a, b)      # same seeds, eager twice
+    # graph replay vs eager in bf16: same kernels and random offsets; after a few optimizer steps roundings have flipped, so the losses
+    # are compared loosely and only over the first iterations
+    for (d0, g0), (d2, g2) in list(zip(a, c))[:3]:
+        assert d0 == pytest.approx(d2, rel=5e-2, abs=5e-2) and g0 == pytest.approx(g2, rel=5e-2, abs=5e-2), (a, c)
+
+
+def test_stylegan3_t_512_batch_16_full_size_step_properties():
+    """configs[3]: "StyleGAN3-T 512x512 (filtered_lrelu HIP kernel)": three iterations (R1 on the first), batch 16, bf16."""
+    from animeface_amd.implementations.StyleGAN3 import model as M, utils as U
+    from animeface_amd.nnutils import update_ema, freeze
+    from animeface_amd.thirdparty.diffaugment import DiffAugment
+
+    def run():
+        torch.manual_seed(0)
+        G = M.Generator(512, 512).to(DEV)
+        G_ema = M.Generator(512, 512).to(DEV)
+        freeze(G_ema)
+        update_ema(G, G_ema, 0., copy_buffers=True)
+        D = M.Discriminator(512, 3, 32, 512).to(DEV)
+        oG, oD = U.build_optimizers(G, D, 0.0025, 0.01, (0., 0.99))
+        step = U.TrainStep(G, G_ema, D, oG, oD, 3., 16, functools.partial(DiffAugment, policy='color,translation'), 512)
+        gen = torch.Generator().manual_seed(3)
+        real = (torch.rand(16, 3, 512, 512, generator=gen) * 2 - 1).to(DEV)
+        frozen = []
+        orig_g_loss = step.adv_fn.g_loss
+
+        def g_loss(prob):
+            frozen.append(all(not p.requires_grad for p in D.parameters()))
+            return orig_g_loss(prob)
+        step.adv_fn.g_loss = g_loss
+        torch.manual_seed(77)
+        d_before = {n: p.detach().clone() for n, p in D.named_parameters()}
+        losses = []
+        for _ in range(3):
+            dl, gl, fake = step(real)
+            losses.append((float(dl), float(gl)))
+        assert frozen and all(frozen)
+        assert torch.isfinite(fake).all() and tuple(fake.shape) == (16, 3, 512, 512)
+        for net in (G, D, G_ema):
+            for n, p in list(net.named_parameters()) + list(net.named_buffers()):
+                assert torch.isfinite(p).all(), n
+        assert any(not torch.equal(p.detach(), d_before[n]) for n, p in D.named_parameters())
+        for i, layer in enumerate(G.synthesis.net):                      # the running input-magnitude statistics moved off their initial 1
+            assert float(layer.ema) != 1.0, i
+        return losses
+    a = run()
+    b = run()
+    assert all(abs(x) < 1e4 for pair in a for x in pair), a
+    (d0, g0), (d1, g1) = a[0], b[0]
+    assert d0 == pytest.approx(d1, rel=2e-3, abs=1e-4) and g0 == pytest.approx(g1, rel=2e-3, abs=1e-4), (a, b)
+    for (d0, g0), (d1, g1) in zip(a, b):                                 # later iterations: bf16 + Adam decorrelate a few weights
+        assert d0 == pytest.approx(d1, rel=5e-2, abs=5e-2) and g0 == pytest.approx(g1, rel=5e-2, abs=5e-2), (a, b)

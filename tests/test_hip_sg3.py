@@ -238,3 +238,75 @@ def test_channels_last_zero_pad_and_crop_one_pass(dtype, shape, pad):
     (gx,) = torch.autograd.grad(y, x, gy)
     assert torch.equal(gx, gy[:, :, pad:-pad, pad:-pad])
     assert torch.equal(_CropCL.apply(y, pad), x.detach())
+
+
+@pytest.mark.parametrize('config', ['fixture', 'second'])
+def test_bf16_networks_layer_by_layer_vs_the_bf16_emulating_oracle(golden, config):
+    """The bf16 (training) path held tightly: the oracle evaluated with bf16 storage emulation (``oracle.stylegan3.bf16_storage``: conv
+    operands x * s * gain and W * scale, every tensor a kernel stores) instead of the fp32 reference -- every synthesis layer and every
+    residual block within 2e-2 of the largest value (the fp32 comparison above needs 8e-2), the image and the logits likewise, and the
+    gradients of the generator loss by relative rms error instead of a cosine."""
+    from animeface_amd.implementations.StyleGAN3 import model as M
+    from oracle import stylegan3 as S3
+    if config == 'fixture':
+        g = golden('sg3_model')
+        _, G, D = build(torch.bfloat16)
+        G.load_state_dict(sub(g, 'G/'), strict=True)
+        D.load_state_dict(sub(g, 'D/'), strict=True)
+        cfg = S3.Config(**CFG)
+        z = t(g['z'])
+    else:
+        torch.manual_seed(5)
+        kw = dict(image_size=64, latent_dim=24, num_layers=8, map_num_layers=2, channels=16, max_channels=24, style_dim=24, margin_size=6)
+        G = M.Generator(kw['image_size'], kw['latent_dim'], kw['num_layers'], kw['map_num_layers'], kw['channels'], kw['max_channels'],
+                        kw['style_dim'], margin_size=kw['margin_size'], compute_dtype=torch.bfloat16).to(DEV)
+        D = M.Discriminator(64, 3, 8, 24, compute_dtype=torch.bfloat16).to(DEV)
+        with torch.no_grad():
+            for n, p in list(G.named_parameters()) + list(D.named_parameters()):
+                if n.endswith('bias') and 'affine' not in n:
+                    p.normal_(0, 0.2)
+        cfg = S3.Config(d_channels=8, d_max_channels=24, **kw)
+        z = torch.randn(3, 24)
+    sdG = {k: v.detach().float().cpu().clone() for k, v in G.state_dict().items()}
+    sdD = {k: v.detach().float().cpu().clone() for k, v in D.state_dict().items()}
+    for sd in (sdG, sdD):
+        for k, v in sd.items():
+            if v.is_floating_point() and not k.endswith(('filter', 'ema', 'w_avg', 'freqs', 'phases', 'transform', 'output_scale')):
+                v.requires_grad_(True)
+    G.train()
+    taps_g, taps_d = [], []
+    hooks = [m.register_forward_hook(lambda mod, i, o: taps_g.append(o.detach())) for m in G.synthesis.net]
+    hooks += [m.register_forward_hook(lambda mod, i, o: taps_d.append(o.detach())) for m in D.resblocks]
+    image = G(z.to(DEV))
+    logits = D(image)
+    loss = torch.nn.functional.softplus(-logits).mean()
+    names_g = [k for k in ('synthesis.net.0.conv.weight', 'synthesis.net.2.conv.weight', 'synthesis.net.3.affine.weight', 'synthesis.net.4.bias',
+                           'synthesis.input.weight', 'map.net.1.weight') if k in dict(G.named_parameters())]
+    names_d = [k for k in ('from_rgb.weight', 'resblocks.0.conv1.weight', 'resblocks.0.conv2.weight', 'resblocks.1.skip.weight',
+                           'resblocks.1.conv2.bias', 'epilogue.epilogue.3.weight') if k in dict(D.named_parameters())]
+    pg, pd = dict(G.named_parameters()), dict(D.named_parameters())
+    grads = torch.autograd.grad(loss, [pg[k] for k in names_g] + [pd[k] for k in names_d])
+    for h in hooks:
+        h.remove()
+    ref_g, ref_d = [], []
+    with S3.bf16_storage():
+        ref_img, _ = S3.generator(sdG, cfg, z, training=True, collect=ref_g)
+        ref_logits = S3.discriminator(sdD, cfg, ref_img, collect=ref_d)
+        ref_loss = torch.nn.functional.softplus(-ref_logits).mean()
+    ref_grads = torch.autograd.grad(ref_loss, [sdG[k] for k in names_g] + [sdD[k] for k in names_d])
+    assert len(taps_g) == len(ref_g) and len(taps_d) == len(ref_d)
+    for i, (a, b) in enumerate(zip(taps_g, ref_g)):
+        r = relerr(a, b)
+        print(f'   G layer {i} {tuple(a.shape)}: max rel {r:.4f}')
+        assert r < 2e-2, ('G layer', i, r)
+    for i, (a, b) in enumerate(zip(taps_d, ref_d)):
+        r = relerr(a, b)
+        print(f'   D block {i} {tuple(a.shape)}: max rel {r:.4f}')
+        assert r < 2e-2, ('D block', i, r)
+    assert relerr(image, ref_img.detach()) < 2e-2
+    assert relerr(logits, ref_logits.detach()) < 2e-2
+    for k, a, b in zip(names_g + names_d, grads, ref_grads):
+        af, bf = a.detach().float().cpu(), b.detach().float()
+        rms = float((af - bf).square().mean().sqrt() / bf.square().mean().sqrt().clamp_min(1e-12))
+        print(f'   grad {k}: rms rel {rms:.4f}')
+        assert rms < 0.08, (k, rms)
