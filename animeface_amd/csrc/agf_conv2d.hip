@@ -1624,14 +1624,13 @@ static int launch_fwd_ws(const ConvParams& p0, hipStream_t st) {
     return AGF_OK;
 }
 
-static int g_ws_enable = -1;       // AGF_CONV_WS=0 disables the weight-stationary variant (A/B)
+constexpr int g_ws_enable = 1;     // (2 would also send 64 -> 64 layers to the weight-stationary kernel: measured slower than the streaming kernel)
 
 template <int KS, int MT>
 static int launch_fwd(const ConvParams& p, hipStream_t st) {
-    if (g_ws_enable < 0) { const char* e = getenv("AGF_CONV_WS"); g_ws_enable = e ? atoi(e) : 1; }
     // weight-stationary kernel: Cin <= 32 (two blocks per CU), or Cin <= 64 with Cout <= 32 (32-channel co tile: the
     // generic 64-channel tile would waste half of its MFMAs there); measured per layer in tools/ab_ws.sh
-    static const int ws1 = []{ const char* e = getenv("AGF_CONV_WS1"); return e ? atoi(e) : 1; }();
+    constexpr int ws1 = 1;
     if (g_ws_enable && ws1 && (ws1 == 2 || p.in_scale) && KS == 1 && MT == 1 && p.pixTiles >= 2048 && p.TW == 32 && p.TH == 8 && p.TI == 1 && p.Cin <= 32 && p.Cout <= 64) {
         // 1x1 convs with few channels (FromRGB / ToRGB / the 32 -> 64 skip): pure streaming work.  One 256-pixel tile per block left
         // them at ~2 TB/s (block prologue per 20 KB of traffic); the persistent kernel keeps the weights in LDS and streams tiles.
@@ -1643,7 +1642,7 @@ static int launch_fwd(const ConvParams& p, hipStream_t st) {
     if (g_ws_enable && KS == 3 && MT == 1 && p.pixTiles >= 2048 && p.TW == 32 && p.TH == 8 && p.TI == 1 &&
         (p.Cin <= 32 || (p.Cin <= 64 && p.Cout <= 32) || (g_ws_enable >= 2 && p.Cin <= 64 && p.Cout <= 64))) {
         int rc;
-        static const int ws2 = []{ const char* e = getenv("AGF_CONV_WS2"); return e ? atoi(e) : 1; }();
+        constexpr int ws2 = 1;
         if ((ws2 == 1 && !(p.Cin <= 32 && p.Cout <= 32) && !(p.Cin > 32 && p.Cout > 32)) || (ws2 == 2 && !(p.Cin > 32 && p.Cout > 32))) {
             if (p.Cin <= 32 && p.Cout <= 32) rc = p.in_scale ? launch_fwd_ws2<3, true, 32, 32>(p, st) : launch_fwd_ws2<3, false, 32, 32>(p, st);
             else if (p.Cin <= 32)            rc = p.in_scale ? launch_fwd_ws2<3, true, 32, 64>(p, st) : launch_fwd_ws2<3, false, 32, 64>(p, st);
@@ -1656,12 +1655,12 @@ static int launch_fwd(const ConvParams& p, hipStream_t st) {
         else                             rc = p.in_scale ? launch_fwd_ws<3, true, 64, 32>(p, st) : launch_fwd_ws<3, false, 64, 32>(p, st);
         if (rc != AGF_ENOKERNEL) return rc;
     }
-    static const int w64b = []{ const char* e = getenv("AGF_CONV_W64B"); return e ? atoi(e) : 0; }();
+    constexpr int w64b = 0;
     if (w64b && KS == 3 && MT == 1 && !p.flat && p.TI == 1 && p.TW == 32 && p.TH == 8 && p.Cout > 32 && p.Cout <= 64 && p.Cin >= 32)
         return p.in_scale ? launch_fwd_v<KS, 2, true, 16, 4, 340, 1, 2, 3>(p, st) : launch_fwd_v<KS, 2, false, 16, 4, 340, 1, 2, 3>(p, st);
     if (KS == 3 && MT == 1 && !p.flat && p.TI * p.TH * p.TW == 64)
         return p.in_scale ? launch_fwd_v<KS, 1, true, 32, 2, 160, 2, 1>(p, st) : launch_fwd_v<KS, 1, false, 32, 2, 160, 2, 1>(p, st);
-    static const int dl = []{ const char* e = getenv("AGF_CONV_DL"); return e ? atoi(e) : 1; }();
+    constexpr int dl = 1;
     if (dl && KS == 3 && MT == 2 && !p.in_scale && !p.flat) {
         const int rc = p.Cout <= 64 ? launch_fwd_dl<KS, 2, 4, 612, 1, 4>(p, st) : launch_fwd_dl<KS, 2, 4, 612, 2, 4>(p, st);
         if (rc != AGF_ENOKERNEL) return rc;
@@ -1715,7 +1714,7 @@ static int conv2d_fwd_impl(const void* x, const void* w, void* y,
     p.res_pooled = (const bf16_t*)res_pooled; p.res_scale = res_scale;
     {
         // 1x1 conv from 8 input channels to <= 32 outputs on a large map: the streaming kernel (see conv2d_pw8_kernel)
-        static const bool pw8 = []{ const char* e = getenv("AGF_CONV_PW8"); return !(e && e[0] == '0'); }();
+        constexpr bool pw8 = true;
         const bool pow2 = (Cout & (Cout - 1)) == 0;
         if (pw8 && !mask_y && !res_pooled && ksize == 1 && !noise && !residual && Cin == 8 && Cout >= 8 && Cout <= 32 && pow2 && H * W >= 4096 && ((uintptr_t)y % 16) == 0) {
             const int G = Cout / 8;
@@ -1727,9 +1726,9 @@ static int conv2d_fwd_impl(const void* x, const void* w, void* y,
             return AGF_OK;
         }
     }
-    { static int h = -1; if (h < 0) { const char* e = getenv("AGF_CONV_HOIST"); h = e ? atoi(e) : 1; } p.hoist = h; }
+    p.hoist = 1;
     p.xcdBand = 0;
-    { static const int vs = []{ const char* e = getenv("AGF_CONV_VSTORE"); return e ? atoi(e) : 2; }();     // 2: register-only (permlane32), 1: through LDS, 0: direct
+    { constexpr int vs = 2;     // 2: register-only (permlane32), 1: through LDS, 0: direct
       p.vecStore = ((vs || mask_y || res_pooled) && (Cout % 8) == 0 && ((uintptr_t)y % 16) == 0) ? (vs == 2 ? 2 : 1) : 0; }
     if (ksize == 3) {
         // high-resolution, few-channel layers: the persistent multi-stage kernel (agf_conv2d_pipe.hip)
@@ -1741,12 +1740,11 @@ static int conv2d_fwd_impl(const void* x, const void* w, void* y,
     // least 128 output channels and the grid still fills the chip (>= 384 blocks).  Default: 64 co x 256 px, 4 waves.
     int MT = 1;
     {
-        const char* e = getenv("AGF_CONV_MT");
-        int forced = e ? atoi(e) : 0;
+        constexpr int forced = 0;
         int64_t bigBlocks = (int64_t)N * ((H + 15) / 16) * ((W + 31) / 32) * ((Cout + 127) / 128);
         if (forced == 2 || (forced != 1 && ksize == 3 && W >= 32 && H >= 16 && Cout >= 128 && Cin >= 64 && bigBlocks >= 384)) MT = 2;
         // 64 output channels: the 64 co x 512 px tile of four 64 co x 128 px waves (see the kernel comment)
-        static const int w64 = []{ const char* e = getenv("AGF_CONV_W64"); return e ? atoi(e) : 2; }();      // 1: only Cin >= 64
+        constexpr int w64 = 2;      // 1: only Cin >= 64
         if (w64 && forced != 1 && ksize == 3 && W >= 32 && H >= 16 && Cout > 32 && Cout <= 64 && Cin >= (w64 == 2 ? 32 : 64) &&
             (int64_t)N * ((H + 15) / 16) * ((W + 31) / 32) >= 512) MT = 2;
         if (MT == 2 && !(W >= 32 && H >= 16)) MT = 1;
@@ -1755,7 +1753,7 @@ static int conv2d_fwd_impl(const void* x, const void* w, void* y,
     // 4x4 / 8x8 maps: 64-pixel tiles (4 waves of 32 co x 32 px).  With 256-pixel tiles such a layer is 32-128 blocks, each a serial
     // chain of Cin/32 chunks with nothing to overlap its load latency (512 -> 512 @4x4, B=64: 130 us for 2.4 GFLOP); 4x more, 4x
     // shorter blocks fill the chip.
-    static const bool small_on = []{ const char* e = getenv("AGF_CONV_SMALL"); return !(e && e[0] == '0'); }();
+    constexpr bool small_on = true;
     const bool smallTile = small_on && MT == 1 && ksize == 3 && H * W <= 64 && H >= 4 && W >= 4 && (int64_t)N * H * W >= 256 &&
                            (int64_t)N * H * W <= (in_scale ? 8192 : 4096);      // measured: beyond that the 256-pixel tiles fill the chip
     if (smallTile) blockPix = 64;
@@ -1769,7 +1767,7 @@ static int conv2d_fwd_impl(const void* x, const void* w, void* y,
     {
         // flat tiling when the rectangular tiles would waste more than ~30 % of their pixels and the row patch stays small (wide
         // maps stage too many halo pixels per output: 86x86 ran 2x slower flat, 38x38 1.45x faster -- tools/time_conv.py)
-        static const bool flat_on = []{ const char* e = getenv("AGF_CONV_FLAT"); return !(e && e[0] == '0'); }();
+        constexpr bool flat_on = true;
         const int halo = ksize / 2;
         const int span = (BLOCK_PIX + W - 2) / W + 1;                  // most rows 256 consecutive pixels can touch
         const int Pflat = (span + 2 * halo) * (W + 2 * halo);
@@ -1784,7 +1782,7 @@ static int conv2d_fwd_impl(const void* x, const void* w, void* y,
         }
     }
     p.tilesCo = (Cout + 64 * MT - 1) / (64 * MT);
-    { static const int band = []{ const char* e = getenv("AGF_CONV_XCDBAND"); return e ? atoi(e) : 1; }();
+    { constexpr int band = 1;
       p.xcdBand = (band && p.pixTiles >= 64) ? (p.pixTiles + 7) / 8 : 0; }
     p.twShift = 0; while ((1 << p.twShift) < p.TW) p.twShift++;
     p.thShift = 0; while ((1 << p.thShift) < p.TH) p.thShift++;
@@ -2353,7 +2351,7 @@ static int conv2d_wgrad_impl(const void* x, const void* dy, float* dw,
     AGF_CHECK(((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0 && ((uintptr_t)dw % 4) == 0, "conv2d_wgrad: misaligned pointer");
     {
         // pointwise conv from 8 input channels on a large map without scales: the streaming reduction (see conv2d_wgrad_pw8_kernel)
-        static const bool pw8 = []{ const char* e = getenv("AGF_WGRAD_PW8"); return !(e && e[0] == '0'); }();
+        constexpr bool pw8 = true;
         if (pw8 && dtype == AGF_BF16 && ksize == 1 && Cin == 8 && Cout >= 8 && Cout <= 64 && Cout % 8 == 0 && (256 % (Cout / 8)) == 0 && !in_scale && !out_scale &&
             (int64_t)N * H * W >= 65536 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0) {
             const int G = Cout / 8;
@@ -2407,12 +2405,12 @@ static int conv2d_wgrad_impl(const void* x, const void* dy, float* dw,
     // 256 instead of 512 blocks: 770 -> 830 TFLOP/s on the large layers, 550 -> 670 on the 16x16 maps.  1x1 (128 registers, two
     // blocks per CU, pure streaming) keeps 512.  (A two-stage combine -- partial tiles to scratch with plain stores + a reduce
     // kernel -- was measured slower than these atomics.)
-    static const int wantBlocks = []{ const char* e = getenv("AGF_WGRAD_BLOCKS"); return e ? atoi(e) : 0; }();
+    constexpr int wantBlocks = 0;
     int want = ((wantBlocks ? wantBlocks : (ksize == 3 ? 256 : 512)) + base - 1) / base;
     int cap = p.pixTiles / 4 < 1 ? 1 : p.pixTiles / 4;
     p.splitK = want < 1 ? 1 : (want > cap ? cap : want);
     {
-        static const bool epi_on = []{ const char* e = getenv("AGF_WGRAD_EPI"); return !(e && e[0] == '0'); }();
+        constexpr bool epi_on = true;
         p.epiScale = (epi_on && p.TI == 1 && (in_scale || out_scale)) ? 1 : 0;
         p.perImage = 1;
         if (p.epiScale) {
@@ -2434,7 +2432,7 @@ static int conv2d_wgrad_impl(const void* x, const void* dy, float* dw,
     if (lds > 160 * 1024) { agf_set_error("conv2d_wgrad: tile needs %zu bytes of LDS", lds); return AGF_ENOKERNEL; }
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    static const bool dl_on = []{ const char* e = getenv("AGF_WGRAD_DL"); return !(e && e[0] == '0'); }();
+    constexpr bool dl_on = true;
     const bool dl = dl_on && ksize == 3 && compact && 2 * lds <= 160 * 1024 && !((in_scale || out_scale) && !p.epiScale) &&
                     (int64_t)p.TI * H * W * (Cin > Cout ? Cin : Cout) * 2 < 0x60000000ll;
     if (dl) rc = launch_wgrad<3, true, true>(p, 2 * lds, st);

@@ -481,7 +481,7 @@ int agf_conv2d_pipe_launch(const ConvParams& p0, hipStream_t st) {
     // 128 output channels from 32 / 64 inputs on a streaming-size map (the discriminator's 64 -> 128 conv at 128x128): the 8-wave
     // 128-channel kernel has only 2-4 K chunks per tile to amortise its prologue and epilogue over (590 TFLOP/s); two launches of this
     // kernel, one per 64-channel half of the weights, each writing its channel slice of y, are faster (the second reads x from L2 / MALL)
-    static const int split = []{ const char* e = getenv("AGF_PIPE_SPLIT128"); return e ? atoi(e) : 1; }();
+    constexpr int split = 1;
     if (split && p0.Cout == 128 && (p0.Cin == 32 || p0.Cin == 64) && !p0.mask_y && !p0.res_pooled && !p0.out_scale && !p0.in_scale && !p0.residual &&
         !p0.noise && ((uintptr_t)p0.y % 16) == 0 && pipe_covers(p0.N, p0.H, p0.W, p0.Cin, 64)) {
         for (int half = 0; half < 2; half++) {
@@ -526,7 +526,7 @@ extern "C" int agf_modulate_weights(const void* w, const float* s, void* wmod, i
 }
 
 extern "C" int agf_conv2d_fwd_wimg_covers(int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize) {
-    static const int mode = []{ const char* e = getenv("AGF_CONV_PIPE"); return e ? atoi(e) : 1; }();
+    constexpr int mode = 1;
     return (mode && ksize == 3 && pipe_covers(N, H, W, Cin, Cout)) ? 1 : 0;
 }
 
@@ -553,7 +553,7 @@ extern "C" int agf_conv2d_fwd_wimg(const void* x, const void* w, void* y, const 
 static int pipe_launch(const ConvParams& p0, int64_t wImgStride, hipStream_t st, int yPix) {
     // covered: 3x3, one co tile (Cout <= 64), Cin in {32, 64, 128}, maps that 16x32 pixel tiles cover with power-of-two tile counts,
     // no input scale (style-modulated layers come with per-image weights instead), no residual operand
-    static const int mode = []{ const char* e = getenv("AGF_CONV_PIPE"); return e ? atoi(e) : 1; }();
+    constexpr int mode = 1;
     if (!mode) return AGF_ENOKERNEL;
     ConvParams p = p0;
     if (p.in_scale || p.residual) return AGF_ENOKERNEL;
@@ -570,11 +570,11 @@ static int pipe_launch(const ConvParams& p0, int64_t wImgStride, hipStream_t st,
     pp.wImgStride = wImgStride;
     pp.yPix = yPix ? yPix : p.Cout;
     if (pp.yPix != p.Cout && (p.mask_y || p.res_pooled || p.out_scale || wImgStride)) return AGF_ENOKERNEL;
-    static const int pipe_dbg = []{ const char* e = getenv("AGF_PIPE_DBG"); return e ? atoi(e) : 0; }();
+    constexpr int pipe_dbg = 0;
     pp.dbg = pipe_dbg;
-    static const int cnt_st = []{ const char* e = getenv("AGF_PIPE_COUNT_STORES"); return e ? atoi(e) : 0; }();
+    constexpr int cnt_st = 0;
     pp.countStores = cnt_st;
-    static const int ws_on = []{ const char* e = getenv("AGF_PIPE_WS"); return e ? atoi(e) : 1; }();
+    constexpr int ws_on = 1;
     if (ws_on && wImgStride == 0 && p.Cin <= 64) {       // shared weights that fit next to the activation ring: loaded once per block
         if (p.Cout > 32) {
             if (p.Cin == 32) return launch_pipe<3, 2, 1, 8, 2, 2, 5, 612, true>(pp, 1, st);

@@ -325,7 +325,7 @@ static int ring_pow2_floor_log2(int v) { int s = 0; while ((2 << s) <= v) s++; r
 
 // Tile geometry, split and scale mode of a launch; false: shape not covered (the caller falls through to conv2d_wgrad_kernel)
 static bool ring_plan(WgradRingParams& p, bool scales, bool both, int N, int H, int W, int Cin, int Cout) {
-    static const int on = []{ const char* e = getenv("AGF_WGRAD_RING"); return e ? atoi(e) : 1; }();
+    constexpr int on = 1;
     if (!on) return false;
     if (W < 8 || H < 4) return false;
     {   // 4 x 32 or 8 x 16 pixel tiles: whichever wastes less of its area on this map
@@ -341,8 +341,8 @@ static bool ring_plan(WgradRingParams& p, bool scales, bool both, int N, int H, 
     if ((1 << p.lgTilesW) != p.tilesW || (1 << p.lgTilesH) != p.tilesH) p.lgTilesW = p.lgTilesH = -1;      // ragged maps: division decode
     p.cutX = W - (p.tilesW - 1) * p.TW + 1; p.cutY = H - (p.tilesH - 1) * p.TH + 1;
     {   // tiles that hang over the image contract zeros: not worth it when more than ~30 % of the tile area is padding
-        static const int ragged = []{ const char* e = getenv("AGF_WGRAD_RING_RAGGED"); return e ? atoi(e) : 1; }();
-        static const double minCover = []{ const char* e = getenv("AGF_WGRAD_RING_MINCOVER"); return e ? atof(e) : 0.7; }();
+        constexpr int ragged = 1;
+        constexpr double minCover = 0.7;
         const double cover = (double)H * W / ((double)p.tilesW * p.TW * p.tilesH * p.TH);
         // (8x8 maps are ONE half-empty 8x16 tile per image: still 75 -> 60 us for 512 -> 512 channels at batch 64 against the staging kernel)
         const double need = (p.tilesW * p.tilesH == 1 && minCover > 0.45) ? 0.45 : minCover;
@@ -352,7 +352,7 @@ static bool ring_plan(WgradRingParams& p, bool scales, bool both, int N, int H, 
     p.pixTiles = tpi * N;
     p.tilesCo = (Cout + 63) / 64; p.tilesCi = (Cin + 63) / 64;
     const int base = p.tilesCo * p.tilesCi;
-    static const int wantBlocks = []{ const char* e = getenv("AGF_WGRAD_BLOCKS"); return e ? atoi(e) : 0; }();
+    constexpr int wantBlocks = 0;
     const int want = ((wantBlocks ? wantBlocks : 256) + base - 1) / base;
     const int cap = p.pixTiles / 8 < 1 ? 1 : p.pixTiles / 8;          // >= 8 tiles of 128 pixels per block (its 64x64x9 partial sums must stay cheap)
     p.splitK = want < 1 ? 1 : (want > cap ? cap : want);
@@ -362,7 +362,7 @@ static bool ring_plan(WgradRingParams& p, bool scales, bool both, int N, int H, 
         int m = (want + N - 1) / N;
         if (m > tpi / 8) m = tpi / 8;
         if (m < 1) m = 1;
-        static const int sc_on = []{ const char* e = getenv("AGF_WGRAD_RING_SC"); return e ? atoi(e) : 1; }();
+        constexpr int sc_on = 1;
         if ((N * m > want + want / 2 && tpi / m < 24) || tpi < 8) {
             if (!sc_on || !both) return false;
             p.epiScale = 0;                                  // blocks span images: scales on the operands (SC kernel), split as without scales
@@ -375,7 +375,7 @@ static bool ring_plan(WgradRingParams& p, bool scales, bool both, int N, int H, 
 
 // bytes of the [splitK][Cout,3,3,Cin] fp32 scratch of the two-stage combine, 0 = shape not covered
 int64_t agf_conv2d_wgrad_ring_workspace(bool scales, int N, int H, int W, int Cin, int Cout) {
-    static const int two = []{ const char* e = getenv("AGF_WGRAD_TWOSTAGE"); return e ? atoi(e) : 1; }();
+    constexpr int two = 1;
     WgradRingParams p;
     if (!two || !ring_plan(p, scales, scales, N, H, W, Cin, Cout) || p.splitK < 2) return 0;
     return (int64_t)p.splitK * p.dwNumel * 4;

@@ -922,7 +922,7 @@ static bool flr_rb_launch(FlrParams p, hipStream_t st, int* status) {
     P.mG = flr_magic(SU == 1 ? P.TVWa >> 3 : 1); P.mTUW = flr_magic(p.TUW); P.mMW = flr_magic(P.MW ? P.MW : 1);
     P.mQ4 = flr_magic(P.UPC >> 2); P.mTOW = flr_magic(p.TOW); P.mXP = flr_magic(P.XP);
 #ifdef AGF_PROFILE_PHASES      // build with -DAGF_PROFILE_PHASES for tools/flr_phases.sh; a product build cannot leave phases out
-    { static const int sk = []{ const char* e = getenv("AGF_FLR_SKIP"); return e ? atoi(e) : 0; }(); P.skip = sk; }
+    { constexpr int sk = 0; P.skip = sk; }
 #else
     P.skip = 0;
 #endif
@@ -950,7 +950,7 @@ static bool flr_rb_dispatch_nt(const FlrParams& p, hipStream_t st, int* status) 
 
 template <class T>
 static bool flr_rb_dispatch(const FlrParams& p, hipStream_t st, int* status) {
-    static const int nt = []{ const char* e = getenv("AGF_FLR_NT"); return e ? atoi(e) : 512; }();
+    constexpr int nt = 512;
     return nt == 512 ? flr_rb_dispatch_nt<T, 512>(p, st, status) : flr_rb_dispatch_nt<T, 256>(p, st, status);
 }
 
@@ -986,7 +986,7 @@ extern "C" int agf_filtered_lrelu(const void* x, const float* fu, const float* f
     // logical upsampled size implied by the output size (filtered_lrelu.cpp:57-73): yw = (uw - (fdw-1) + down-1)/down
     p.UW = (p.YW - 1) * down + p.fdw; p.UH = (p.YH - 1) * down + fdH;
     {
-        static const bool rb_on = []{ const char* e = getenv("AGF_FLR_RB"); return !(e && e[0] == '0'); }();
+        constexpr bool rb_on = true;
         int status = AGF_OK;
         bool done = false;
         if (rb_on) {

@@ -688,7 +688,7 @@ static int launch_typed(UpfirdnParams& p, bool dense_nchw, bool dense_nhwc, int 
         if (ok) return AGF_OK;
     }
     if (dense_nchw && sizeof(T) <= 4 && p.OW >= 64) {
-        static const bool planar_on = []{ const char* e = getenv("AGF_UPFIRDN_PLANAR"); return !(e && e[0] == '0'); }();
+        constexpr bool planar_on = true;
         if constexpr (sizeof(T) <= 4) { if (planar_on && launch_planar_vec_cases<T>(p, st)) return AGF_OK; }
         if (planar_on && launch_planar_cases<T>(p, st)) return AGF_OK;
     }

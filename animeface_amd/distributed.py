@@ -55,7 +55,7 @@ class GradReducer:
         self._touched = set()
         self.stats = dict(steps=0, buckets_from_hooks=0, buckets_at_finish=0, exposed_ms=0.0)
         self.measure = False             # bench.py: time the compute stream's wait in finish() with events
-        self.early = os.environ.get('AGF_DP_EARLY', '1') != '0'      # A/B switch: launch complete buckets from the backward hooks
+        self.early = True                # launch complete buckets from the backward hooks (False: all at finish(); the graph-segmented loop)
         skip = {id(p) for p in never_used}
         idle = [p for p in self.params if id(p) in skip]
         if idle:

@@ -10,7 +10,6 @@ the discriminator twice, the path-length penalty the generator) compose from thr
     fwd(x, w)            -> dx = fwd(dy, flipT(w)),  dw = wgrad(x, dy)
     wgrad(x, dy)         -> dx = fwd(dy, flipT(ddw)),  d(dy) = fwd(x, ddw)
 """
-import os
 
 import ctypes
 import functools
@@ -100,7 +99,6 @@ class ZeroArena:
 
 
 _zero_arena = None
-_ARENA_ON = os.environ.get('AGF_ZERO_ARENA', '1') != '0'        # A/B switch
 
 
 class zero_arena:
@@ -122,7 +120,7 @@ class zero_arena:
 
 
 def _zeros_f32(shape, device):
-    if _zero_arena is not None and _ARENA_ON:
+    if _zero_arena is not None:
         return _zero_arena.take(tuple(shape), device)
     return torch.zeros(shape, dtype=torch.float32, device=device)
 
@@ -223,7 +221,7 @@ _WGRAD_WS = {}
 def _wgrad_workspace(device, nbytes):
     """Scratch of the two-stage split-K combine: ONE buffer per device, grown to the largest request (every launch writes ~256 blocks x
     64x64x9 fp32 = 38-45 MB whatever the layer) and reused by every launch -- the trainers issue all compute on one stream, where
-    launches are ordered (a second compute stream would need its own buffer: AGF_WGRAD_TWOSTAGE=0 falls back to atomics).  The buffer
+    launches are ordered (a second compute stream would need its own buffer).  The buffer
     exists before a HIP-graph capture starts (GraphedTrainStep warms up eagerly), so it is a static address inside the graph and stays
     resident in the 256 MB Infinity Cache between the launch that writes it and the one that sums it."""
     ws = _WGRAD_WS.get(device.index)
@@ -836,8 +834,7 @@ def pool2x_linked(x, f, gain, link):
     return _PoolLinked.apply(x, f, gain, link)
 
 
-_PREMASK = os.environ.get('AGF_PREMASK', '1') != '0'       # A/B switch
-_PREMASK_MOD = os.environ.get('AGF_PREMASK_MOD', '1') != '0'   # A/B switch: scale_dot + act_bwd_reduce of a modulated chain as one pass
+_PREMASK = True        # tests/test_hip_conv.py::test_dblock_linked_backward_matches_unlinked runs the block with the fused hand-offs off
 
 
 class _FusedConv(torch.autograd.Function):
@@ -871,7 +868,7 @@ class _FusedConv(torch.autograd.Function):
                 and x.dtype == torch.bfloat16:
             post_link.armed, post_link.alpha, post_link.premasked, post_link.pooled = True, float(alpha), False, None
             ctx.post_link = post_link
-        elif post_link is not None and _PREMASK and _PREMASK_MOD and act == ACT_LRELU and gain == 1.0 and x.dtype == torch.bfloat16 \
+        elif post_link is not None and _PREMASK and act == ACT_LRELU and gain == 1.0 and x.dtype == torch.bfloat16 \
                 and s_out is not None:
             post_link.armed_mod, post_link.alpha, post_link.premasked, post_link.noise, post_link.sums = True, float(alpha), False, noise, None
             ctx.post_link = post_link

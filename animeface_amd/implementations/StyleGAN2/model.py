@@ -20,7 +20,6 @@ Activations run channels-last in ``compute_dtype`` (bf16 for training, fp32 for 
 parameters stay fp32.  The skip path of ``DBlock`` pools before its 1x1 conv (the two commute exactly).
 """
 import functools
-import os
 
 import numpy as np
 import torch
@@ -36,9 +35,6 @@ from .conv import conv2d, conv2d_act, style_demod, PremaskLink, pool2x_linked, u
 # no double backward, so the generator falls back to the separately differentiable ops when ``fused_epilogue=False``
 # (needed only for the path-length penalty, pl_lambda > 0).
 FUSED_EPILOGUE = True
-_UPBLUR_FUSED = os.environ.get('AGF_UPBLUR_FUSED', '1') != '0'        # A/B switch: upsample + blur of the generator block as one pass
-_STYLE_FUSED = os.environ.get('AGF_STYLE_FUSED', '1') != '0'      # A/B switch: one-launch style / demodulation scalars
-_AFFINE_BATCHED = os.environ.get('AGF_AFFINE_BATCHED', '1') != '0'  # A/B switch: the style affines of all layers as one GEMM
 
 
 class ELR(nn.Module):
@@ -188,7 +184,7 @@ class ModulatedConv2d(nn.Module):
         raw = self.__dict__.pop('_s_raw', None)          # left here by Synthesis._batched_affines for exactly this call
         if raw is None:
             raw = self.affine(y)
-        if self.demod and FUSED_EPILOGUE and _STYLE_FUSED and getattr(self, 'fused_epilogue', True) and y.is_cuda:
+        if self.demod and FUSED_EPILOGUE and getattr(self, 'fused_epilogue', True) and y.is_cuda:
             return style_demod(raw, self.weight, self.coef, 1e-4)
         s = raw + 1
         d = None
@@ -241,7 +237,7 @@ class StyleBlock(nn.Module):
     def forward(self, x, y):
         mods = list(self.block)
         i = 0
-        if _UPBLUR_FUSED and FUSED_EPILOGUE and getattr(self, 'fused_epilogue', True) and len(mods) > 1 and isinstance(mods[0], _BilinearUp2x) \
+        if FUSED_EPILOGUE and getattr(self, 'fused_epilogue', True) and len(mods) > 1 and isinstance(mods[0], _BilinearUp2x) \
                 and isinstance(mods[1], Blur2d) and x.is_cuda and x.shape[2] >= 2 and x.shape[3] >= 2 \
                 and x.shape[1] % (8 if x.dtype == torch.bfloat16 else 4) == 0 and x.dtype in (torch.bfloat16, torch.float32):
             # bilinear x2 followed by the [1,2,1] blur: one pass with the composite filter (+ a border-only correction)
@@ -402,7 +398,7 @@ class Synthesis(nn.Module):
         style tensor: every layer multiplies the same [B, style_dim] input, so the weights are concatenated along the output axis
         (26 launches of a 64 x 512 x Cin GEMM -> cat + addmm; backward 78 -> 3).  The per-layer slices are handed to
         ``ModulatedConv2d.scales`` through a transient attribute.  state_dict and parameters are untouched."""
-        if not (_AFFINE_BATCHED and ys[0].is_cuda and ys[0].dim() == 2):
+        if not (ys[0].is_cuda and ys[0].dim() == 2):
             return
         if getattr(self, '_affine_groups', None) is None:
             convs = [(self.input, 0), (self.input_to_image.conv, 0)]

@@ -13,7 +13,6 @@ rescale (:208-218).  Differences, all outside the arithmetic of a step:
 import functools
 
 import numpy as np
-import os
 
 import torch
 import torch.optim as optim
@@ -70,10 +69,9 @@ class TrainStep:
         self.pl_mean = 0.
         self.batches_done = 0
         self._arena_D, self._arena_G = ZeroArena(), ZeroArena()        # zero-initialised backward scratch of the two half-steps
-        # batched weight preparation (one launch per network and optimizer step); AGF_PREP_PLAN=0: one launch per layer
-        on = os.environ.get('AGF_PREP_PLAN', '1') != '0'
-        self._plan_G, self._plan_D = (PrepPlan(G.parameters()), PrepPlan(D.parameters())) if on else (None, None)
-        self.merge_d_passes = os.environ.get('AGF_MERGE_D', '1') != '0'
+        # batched weight preparation (one launch per network and optimizer step)
+        self._plan_G, self._plan_D = PrepPlan(G.parameters()), PrepPlan(D.parameters())
+        self.merge_d_passes = True                      # D(real) and D(fake) of the D-step as one batch-2B pass
         if hasattr(G, 'set_fused_epilogue'):
             G.set_fused_epilogue(pl_lambda == 0)     # the fused modulated conv has no double backward (path length needs it)
 

@@ -12,7 +12,6 @@ the same random stream reproduces the reference's output (``tests/test_hip_ada.p
   * image-space filtering builds a per-sample separable filter from the sym2 filter bank and applies it as two grouped
     1-D convolutions, reference :364-392.
 """
-import os
 
 import numpy as np
 import scipy.signal
@@ -43,7 +42,6 @@ def _affine_grid(theta, H, W):
     return g.permute(0, 2, 3, 1)
 
 
-_RESAMPLE_FUSED = os.environ.get('AGF_ADA_RESAMPLE', '1') != '0'          # A/B switch
 
 
 class _AffineResample(torch.autograd.Function):
@@ -361,7 +359,7 @@ class AugmentPipe(torch.nn.Module):
         # resample
         out_shape = [B, C, (H + taps4 * 2) * 2, (W + taps4 * 2) * 2]
         G = _zoom2(2 / images.shape[3], 2 / images.shape[2], like=images) @ G @ _zoom2(out_shape[3] / 2, out_shape[2] / 2, like=images)
-        if _RESAMPLE_FUSED and images.is_cuda and images.dtype in (torch.float32, torch.bfloat16) and C <= 4 and not G.requires_grad:
+        if images.is_cuda and images.dtype in (torch.float32, torch.bfloat16) and C <= 4 and not G.requires_grad:
             images = _AffineResample.apply(images, G[:, :2, :], out_shape[2], out_shape[3])
         else:
             grid = _affine_grid(G[:, :2, :], out_shape[2], out_shape[3])

@@ -4,14 +4,13 @@ policies ``color``, ``translation``, ``cutout``; random draws are made in the re
 
 The translation is a zero-padded integer shift per sample; it is evaluated as one gather along each
 axis on the NCHW tensor instead of the reference's NHWC permute + advanced-index + permute round trip."""
-import os
 
 import torch
 
 from .. import rng
 
 
-_FUSED = os.environ.get('AGF_DIFFAUG_FUSED', '1') != '0'          # A/B switch
+_FUSED = True          # tests/test_hip_ops.py::test_fused_diffaugment_matches_the_composite compares with the op-by-op composite
 _FUSED_POLICIES = ('color', 'translation', 'color,translation')
 
 

@@ -205,7 +205,7 @@ def main():
             use_graphs, step = False, eager_step
             for red in (red_G, red_D):
                 if red is not None:
-                    red.early = os.environ.get('AGF_DP_EARLY', '1') != '0'
+                    red.early = True
         eager_step.batches_done = 0
     if use_graphs:
         # one untimed replay of EACH captured graph: the first launch of a graph uploads its ~1 500 nodes to the device, a one-off cost that

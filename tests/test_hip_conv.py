@@ -48,8 +48,8 @@ FWD_CASES = [
     (64, 512, 64, 4, 4, 3, None, '64-pixel tiles (4x4 maps, 4 images per tile)'),
     (9, 72, 40, 8, 8, 3, None, '64-pixel tiles (8x8 maps), channel tails, odd batch'),
     (40, 64, 64, 5, 7, 3, None, '64-pixel tiles, ragged 5x7 map'),
-    (4, 72, 136, 32, 64, 3, '2', 'direct-to-LDS 8-wave, Cin % 16 == 8, partial co tile'),
-    (3, 40, 56, 48, 40, 3, '2', 'direct-to-LDS 4-wave 64 co, ragged map, channel tails'),
+    (48, 72, 136, 32, 64, 3, None, 'direct-to-LDS 8-wave (>= 384 tiles of 128 co x 512 px), Cin % 16 == 8, partial co tile'),
+    (86, 40, 56, 48, 40, 3, None, '64 co on >= 512 tiles, ragged map, channel tails'),
 ]
 
 
@@ -58,8 +58,6 @@ FWD_CASES = [
 def test_conv_fwd_variants_vs_aten(case, scaled, monkeypatch):
     from animeface_amd.implementations.StyleGAN2.conv import conv2d_fwd_raw, ACT_LRELU, ACT_LINEAR
     N, Cin, Cout, H, W, k, forced, _ = case
-    if forced:
-        monkeypatch.setenv('AGF_CONV_MT', forced)
     x, w, g = make(N, Cin, Cout, H, W, k)
     s_in = (torch.rand(N, Cin, generator=g) + 0.5).to(DEV) if scaled else None
     s_out = (torch.rand(N, Cout, generator=g) + 0.5).to(DEV) if scaled else None
@@ -271,7 +269,7 @@ def test_style_demod_vs_composite(shape):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('shape', [(4, 64, 64, 64, 64, None), (3, 128, 136, 32, 64, '2'), (16, 64, 64, 128, 128, None), (5, 512, 512, 8, 8, None),
+@pytest.mark.parametrize('shape', [(4, 64, 64, 64, 64, None), (48, 128, 136, 32, 64, None), (16, 64, 64, 128, 128, None), (5, 512, 512, 8, 8, None),
                                    (2, 72, 40, 19, 38, None), (8, 64, 32, 256, 256, None), (8, 32, 32, 256, 256, None), (8, 32, 64, 256, 256, None),
                                    (5, 64, 40, 250, 250, None), (16, 128, 64, 128, 128, None), (4, 64, 64, 256, 256, None)])
 @pytest.mark.parametrize('mode', ['mask', 'pooled', 'both'])
@@ -282,8 +280,6 @@ def test_conv_fwd_mask_vs_composite(shape, mode, monkeypatch):
     N, Cin, Cout, H, W, forced = shape
     if mode != 'mask' and (H % 2 or W % 2):
         pytest.skip('pooled residual needs an even map')
-    if forced:
-        monkeypatch.setenv('AGF_CONV_MT', forced)
     x, w, g = make(N, Cin, Cout, H, W, 3, seed=5)
     a = torch.randn(N, Cout, H, W, generator=g).to(torch.bfloat16).to(DEV).contiguous(memory_format=torch.channels_last)
     r = torch.randn(N, Cout, H // 2, W // 2, generator=g).to(torch.bfloat16).to(DEV).contiguous(memory_format=torch.channels_last)

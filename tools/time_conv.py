@@ -20,4 +20,4 @@ for _ in range(20): run()
 e.record(); torch.cuda.synchronize()
 ms = s.elapsed_time(e) / 20
 gb = (N * H * W * (Cin + Cout * (2 if mask else 1)) * 2 + Cout * Cin * 18) / 1e9
-print(json.dumps(dict(shape=[N, Cin, Cout, H, W], mask=mask, dbg=os.environ.get('AGF_PIPE_DBG'), ms=round(ms, 4), TFLOPs=round(2.0 * N * H * W * Cin * Cout * 9 / ms / 1e9, 1), TBps=round(gb / ms, 2))))
+print(json.dumps(dict(shape=[N, Cin, Cout, H, W], mask=mask, ms=round(ms, 4), TFLOPs=round(2.0 * N * H * W * Cin * Cout * 9 / ms / 1e9, 1), TBps=round(gb / ms, 2))))
