@@ -46,8 +46,19 @@ def save(step, path):
     the same file."""
     rank, world = _rank_world()
     st = state(step)
+    st['world_size'] = world
+    if world > 1 and 'ada' in st and 'signsum' in st['ada']['state']:
+        # the ADA sign statistic is accumulated per rank between two p updates and all-reduced at the update (nnutils/ada.py): store the
+        # mean over the ranks, so that every rank resuming from rank 0's file carries 1 / world of the total (every rank calls save())
+        import torch.distributed as dist
+        tot = st['ada']['state']['signsum'].detach().clone()
+        dist.all_reduce(tot)
+        st['ada']['state'] = dict(st['ada']['state'], signsum=tot / world)
     if world > 1:
-        torch.save(dict(rng_cpu=st['rng_cpu'], rng_cuda=st['rng_cuda']), f'{path}.rng{rank}')
+        # tagged with the iteration and the world size: load() refuses a side file of another save (a crash between the two writes would
+        # otherwise pair a stale generator state with a new checkpoint)
+        torch.save(dict(rng_cpu=st['rng_cpu'], rng_cuda=st['rng_cuda'], batches_done=st['batches_done'], world_size=world, rank=rank),
+                   f'{path}.rng{rank}')
     if rank == 0:
         torch.save(st, path)
     if world > 1:
@@ -78,10 +89,23 @@ def load(step, path_or_state, map_location=None):
         else:
             raise RuntimeError('the checkpoint carries ADA state (p, sign statistic) but this trainer has no ADA pipe to restore it into')
     rank, world = _rank_world()
-    if world > 1 and isinstance(path_or_state, str):
+    if world > 1:
         import os
-        if os.path.exists(f'{path_or_state}.rng{rank}'):
-            st = dict(st, **torch.load(f'{path_or_state}.rng{rank}', map_location='cpu', weights_only=False))
+        import warnings
+        side = f'{path_or_state}.rng{rank}' if isinstance(path_or_state, str) else None
+        own = None
+        if side is not None and os.path.exists(side):
+            own = torch.load(side, map_location='cpu', weights_only=False)
+            if int(own.get('batches_done', -1)) != int(st['batches_done']) or int(own.get('world_size', -1)) != world:
+                own = None                                   # written by another save, or for another world size
+        if own is not None:
+            st = dict(st, rng_cpu=own['rng_cpu'], rng_cuda=own['rng_cuda'])
+        elif rank != 0 or int(st.get('world_size', world)) != world:
+            # no generator state of THIS rank for THIS checkpoint: restoring rank 0's state on every rank would give all replicas the same
+            # noise and augmentation draws.  Re-seed deterministically per rank instead, and say so.
+            warnings.warn(f'checkpoint: no matching random-generator state for rank {rank} (world size {world}); re-seeding this rank')
+            torch.manual_seed(1234 + 1000003 * int(st['batches_done']) + rank)
+            st = dict(st, rng_cpu=None, rng_cuda=None)
     if st.get('rng_cpu') is not None:
         torch.set_rng_state(st['rng_cpu'].cpu())
     if st.get('rng_cuda') is not None and torch.cuda.is_available():

@@ -1685,7 +1685,7 @@ static int conv2d_fwd_impl(const void* x, const void* w, void* y,
     }
     if (dtype == AGF_F32) {
         AGF_CHECK(N >= 1 && H >= 1 && W >= 1 && Cin >= 1 && Cout >= 1, "conv2d_fwd: empty tensor");
-        AGF_CHECK(ksize == 1 || ksize == 3, "conv2d_fwd: kernel size must be 1 or 3 (got %d)", ksize);
+        AGF_CHECK(ksize >= 1 && ksize <= 7 && (ksize & 1), "conv2d_fwd: fp32 kernel size must be odd and <= 7 (got %d)", ksize);
         AGF_CHECK(act == 1 || act == 3, "conv2d_fwd: act must be 1 (linear) or 3 (lrelu)");
         ConvF32Params q;
         q.x = (const float*)x; q.w = (const float*)w; q.y = (float*)y;
@@ -2327,7 +2327,7 @@ static int conv2d_wgrad_impl(const void* x, const void* dy, float* dw,
                              float scale, void* workspace, int64_t workspace_bytes, void* stream, int32_t* dw_layout_out = nullptr) {
     AGF_CHECK(x && dy && dw, "conv2d_wgrad: null pointer");
     AGF_CHECK(N >= 1 && H >= 1 && W >= 1 && Cin >= 1 && Cout >= 1, "conv2d_wgrad: empty tensor");
-    AGF_CHECK(ksize == 1 || ksize == 3, "conv2d_wgrad: kernel size must be 1 or 3 (got %d)", ksize);
+    AGF_CHECK(ksize == 1 || ksize == 3 || (dtype == AGF_F32 && ksize <= 7 && (ksize & 1)), "conv2d_wgrad: kernel size must be 1 or 3 (fp32: odd, <= 7; got %d)", ksize);
     if (workspace_bytes < 0) {                            // overwriting mode (agf_conv2d_wgrad_ws) on a shape that accumulates with atomics
         hipError_t e = hipMemsetAsync(dw, 0, (size_t)Cout * ksize * ksize * Cin * sizeof(float), (hipStream_t)stream);
         if (e != hipSuccess) { agf_set_error("conv2d_wgrad: memset failed: %s", hipGetErrorString(e)); return AGF_ELAUNCH; }
@@ -2335,7 +2335,6 @@ static int conv2d_wgrad_impl(const void* x, const void* dy, float* dw,
     AGF_CHECK(dtype == AGF_BF16 || dtype == AGF_F32, "conv2d_wgrad: dtype must be bf16 or f32");
     if (dtype == AGF_F32) {
         AGF_CHECK(N >= 1 && H >= 1 && W >= 1 && Cin >= 1 && Cout >= 1, "conv2d_wgrad: empty tensor");
-        AGF_CHECK(ksize == 1 || ksize == 3, "conv2d_wgrad: kernel size must be 1 or 3 (got %d)", ksize);
         WgradF32Params q;
         q.x = (const float*)x; q.dy = (const float*)dy; q.dw = dw; q.in_scale = in_scale; q.out_scale = out_scale;
         q.N = N; q.H = H; q.W = W; q.Cin = Cin; q.Cout = Cout; q.KS = ksize; q.scale = scale;

@@ -200,3 +200,33 @@ extern "C" int agf_style_demod_bwd(const float* s, const float* d, const float* 
     AGF_LAUNCH_CHECK();
     return AGF_OK;
 }
+
+// ---- finish of a fused modulated layer's epilogue gradients from the three per-(n, c) sums of agf_act_bwd_reduce:
+//        dso[n,c] = (A[n,c] - bias[c] * B[n,c] - Cn[n,c]) / s_out[n,c]        (gradient of the demodulation scale)
+//        db[c]    = gain * sum_n B[n,c]                                       (bias gradient)
+//      one launch instead of the six small ATen kernels (mul, sub, sub, div, sum, mul) per layer and backward pass ----
+__global__ void __launch_bounds__(256) demod_grad_finish_kernel(const float* A, const float* Bs, const float* Cn, const float* bias, const float* s_out,
+                                                                float* dso, float* db, int N, int C, float gain) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float b = bias ? bias[c] : 0.f;
+    float acc = 0.f;
+    for (int n = 0; n < N; n++) {
+        const int64_t i = (int64_t)n * C + c;
+        const float bv = Bs[i];
+        acc += bv;
+        if (dso) dso[i] = (A[i] - b * bv - (Cn ? Cn[i] : 0.f)) / s_out[i];
+    }
+    if (db) db[c] = acc * gain;
+}
+
+extern "C" int agf_demod_grad_finish(const float* A, const float* Bs, const float* Cn, const float* bias, const float* s_out,
+                                     float* dso, float* db, int32_t N, int32_t C, float gain, void* stream) {
+    AGF_CHECK(Bs && (dso || db), "demod_grad_finish: null pointer");
+    AGF_CHECK(!dso || (A && s_out), "demod_grad_finish: dso needs A and s_out");
+    AGF_CHECK(N >= 1 && C >= 1, "demod_grad_finish: empty tensor");
+    hipLaunchKernelGGL(demod_grad_finish_kernel, dim3((unsigned)agf_ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream,
+                       A, Bs, Cn, bias, s_out, dso, db, N, C, gain);
+    AGF_LAUNCH_CHECK();
+    return AGF_OK;
+}

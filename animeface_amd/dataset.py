@@ -54,12 +54,15 @@ def _resized_shape(h, w, size):
 
 
 class GpuTransform:
-    """``transform(batch)``: uint8 [N, H, W, C] on the GPU -> float [N, C, S, S]; the flip decision of every image is drawn with
-    ``torch.rand(1) < 0.5`` in batch order, the draws torchvision's RandomHorizontalFlip makes for the same images in the same order."""
+    """``transform(batch)``: uint8 [N, H, W, C] on the GPU -> float [N, C, S, S].  The flip decisions of a batch are ONE device-side draw
+    (``rand(N) < 0.5`` from the package's generator, no host synchronisation); torchvision's RandomHorizontalFlip draws one CPU number per
+    image instead -- same distribution, a different stream (pass ``flips`` to replay given decisions).  The resampling tables of an input
+    size are built once and stay on the device."""
 
     def __init__(self, image_size, resize_scale=1., hflip=True, normalize=True, dtype=torch.float32):
         self.image_size, self.resize_to = int(image_size), int(image_size * resize_scale)
         self.hflip, self.normalize, self.dtype = hflip, normalize, dtype
+        self._tables = {}          # (H, W, device) -> uploaded tap tables and the geometry derived from them
 
     def __call__(self, batch, flips=None):
         _lib.require_gpu(batch, 'image transform')
@@ -72,16 +75,20 @@ class GpuTransform:
         top, left = int(round((oh - S) / 2.0)), int(round((ow - S) / 2.0))
         if top < 0 or left < 0:
             raise RuntimeError(f'image transform: {H}x{W} images resize to {oh}x{ow}, smaller than the {S}x{S} crop')
-        hf, hc, ht, hk = _tables(W, ow, left, left + S)              # horizontal pass: only the columns the crop keeps
-        vf, vc, vt, vk = _tables(H, oh, top, top + S)                # vertical pass: only the rows the crop keeps
-        row0 = int(vf.min())
-        rows = int((vf + vc).max()) - row0
         dev = batch.device
-        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-        hf, hc, ht, vf, vc, vt = up(hf), up(hc), up(ht), up(vf), up(vc), up(vt)
+        key = (H, W, str(dev))
+        if key not in self._tables:
+            hf, hc, ht, hk = _tables(W, ow, left, left + S)          # horizontal pass: only the columns the crop keeps
+            vf, vc, vt, vk = _tables(H, oh, top, top + S)            # vertical pass: only the rows the crop keeps
+            row0 = int(vf.min())
+            rows = int((vf + vc).max()) - row0
+            up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+            self._tables[key] = (up(hf), up(hc), up(ht), hk, up(vf), up(vc), up(vt), vk, row0, rows)
+        hf, hc, ht, hk, vf, vc, vt, vk, row0, rows = self._tables[key]
         if flips is None:
-            flips = [bool(rng.rand((1,), device=dev) < 0.5) for _ in range(N)] if self.hflip else [False] * N
-        flip = torch.tensor([int(bool(f)) for f in flips], dtype=torch.uint8, device=dev)
+            flip = (rng.rand((N,), device=dev) < 0.5).to(torch.uint8) if self.hflip else torch.zeros(N, dtype=torch.uint8, device=dev)
+        else:
+            flip = torch.as_tensor([int(bool(f)) for f in flips], dtype=torch.uint8).to(dev)
         tmp = torch.empty((N, rows, S, C), dtype=torch.uint8, device=dev)
         out = torch.empty((N, C, S, S), dtype=self.dtype, device=dev)
         L = _lib.lib()

@@ -518,6 +518,33 @@ def act_bwd_reduce_pooled_raw(dy_half, y, alpha, dy_scale, want_sum):
     return g, B
 
 
+def demod_grad_finish_raw(A, B, Cn, bias, s_out, want_dso, want_db, gain=1.0):
+    """One ``agf_demod_grad_finish`` launch: (dso [N,C] or None, db [C] or None) from the sums of ``act_bwd_reduce``."""
+    N, C = B.shape
+    dso = torch.empty((N, C), dtype=torch.float32, device=B.device) if want_dso else None
+    db = torch.empty((C,), dtype=torch.float32, device=B.device) if want_db else None
+    rc = _lib.lib().agf_demod_grad_finish(_lib.ptr(A if want_dso else None), _lib.ptr(B), _lib.ptr(Cn if want_dso else None),
+                                          _lib.ptr(_f32(bias) if (bias is not None and want_dso) else None), _lib.ptr(_f32(s_out) if want_dso else None),
+                                          _lib.ptr(dso), _lib.ptr(db), N, C, float(gain), _lib.stream_ptr(B))
+    _lib.check(rc, 'demod_grad_finish')
+    return dso, db
+
+
+def channel_sum_raw(x, scale=1.0):
+    """scale * x.sum((0, 2, 3)) in fp32 -- one ``agf_channel_sum`` launch for channels-last bf16 / fp32 tensors whose channel count fills
+    16-byte vectors, ATen's reduction otherwise."""
+    N, C, H, W = x.shape
+    vec = 8 if x.dtype == torch.bfloat16 else 4
+    if not (x.is_cuda and x.dtype in (torch.bfloat16, torch.float32) and C % vec == 0 and C // vec <= 256
+            and x.is_contiguous(memory_format=torch.channels_last)):
+        out = x.sum((0, 2, 3), dtype=torch.float32)
+        return out * scale if scale != 1.0 else out
+    out = _zeros_f32((C,), x.device)
+    rc = _lib.lib().agf_channel_sum(_lib.ptr(x), _lib.ptr(out), _lib.dtype_code(x), N, H, W, C, float(scale), _lib.stream_ptr(x))
+    _lib.check(rc, 'channel_sum')
+    return out
+
+
 def scale_dot_raw(x, t, s, want_dx=True):
     """One ``agf_scale_dot`` launch: dx = t * s[n,c], ds[n,c] = sum_hw x * t."""
     N, C, H, W = x.shape
@@ -930,18 +957,15 @@ class _FusedConv(torch.autograd.Function):
         if pooled is not None:
             g, B = act_bwd_reduce_pooled_raw(pooled[0], y, alpha, pooled[1], need_b and bias is not None)
             if need_b and bias is not None:
-                db = B.sum(0).to(bias.dtype)
+                db = demod_grad_finish_raw(None, B, None, None, None, False, True)[1].to(bias.dtype)
         elif link is not None and link.premasked and link.sums is not None:
             # modulated chain: the consumer's backward already produced g = dy * lrelu'(y) and this layer's three sums
             # (agf_act_bwd_reduce_scaled)
             link.premasked = False
             g = dy
             (A, B, Cn), link.sums = link.sums, None
-            if need_b and bias is not None:
-                db = B.sum(0).to(bias.dtype)
-            if s_out is not None and need_so:
-                num = A - (bias.float()[None, :] * B if bias is not None else 0) - (Cn if Cn is not None else 0)
-                dso = num / s_out
+            dso, db = demod_grad_finish_raw(A, B, Cn, bias, s_out, s_out is not None and need_so, need_b and bias is not None)
+            db = db.to(bias.dtype) if db is not None else None
         elif link is not None and link.premasked:
             # the consumer's data-gradient launch already applied lrelu'(y) and summed the channels (agf_conv2d_fwd_mask)
             link.premasked = False
@@ -954,17 +978,14 @@ class _FusedConv(torch.autograd.Function):
             want_so = s_out is not None and need_so
             g, (A, B, Cn) = act_bwd_reduce_raw(dy, y, noise, alpha,
                                                (want_so, want_so or (need_b and bias is not None), want_so and noise is not None))
-            if need_b and bias is not None:
-                db = (B.sum(0) * pg if pg != 1.0 else B.sum(0)).to(bias.dtype)
-            if want_so:
-                num = A - (bias.float()[None, :] * B if bias is not None else 0) - (Cn if Cn is not None else 0)
-                dso = num / s_out
+            if B is not None:
+                dso, db = demod_grad_finish_raw(A, B, Cn, bias, s_out, want_so, need_b and bias is not None, pg)
+                db = db.to(bias.dtype) if db is not None else None
         else:
             assert s_out is None, 'linear epilogue with a demodulation scale is not used by the networks'
             g = dy
             if need_b and bias is not None:
-                db = g.sum((0, 2, 3), dtype=torch.float32)
-                db = (db * pg if pg != 1.0 else db).to(bias.dtype)
+                db = channel_sum_raw(g, pg).to(bias.dtype)
         if need_r:
             dres = g * pg if pg != 1.0 else g
         if need_x or (s_in is not None and need_si):

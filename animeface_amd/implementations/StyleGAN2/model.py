@@ -163,6 +163,9 @@ class InjectNoise(nn.Module):
         return x + noise.to(x.dtype)
 
 
+_DEFAULT_NOISE_DRAW = InjectNoise.__dict__['draw'].__func__          # (tests replay captured noise by replacing ``InjectNoise.draw``)
+
+
 class ModulatedConv2d(nn.Module):
     """reference model.py:91-135, evaluated with shared weights and per-sample scales (see module docstring)."""
 
@@ -252,7 +255,8 @@ class StyleBlock(nn.Module):
                     and isinstance(mods[i + 2], nn.LeakyReLU):
                 # modconv -> +bias -> +noise -> lrelu, noise drawn exactly where the reference draws it
                 s, d = m.scales(y)
-                noise = InjectNoise.draw(x[:, :1])
+                pre = self.__dict__.get('_noise')
+                noise = pre.pop(0) if pre else InjectNoise.draw(x[:, :1])
                 fused = FUSED_EPILOGUE and getattr(self, 'fused_epilogue', True)
                 chained = fused and i + 3 < len(mods) and isinstance(mods[i + 3], ModulatedConv2d)
                 nxt = PremaskLink() if chained else None
@@ -419,6 +423,30 @@ class Synthesis(nn.Module):
             for m, sl in zip(mods, raw.split([m.affine.layer.out_features for m in mods], 1)):
                 m.__dict__['_s_raw'] = sl
 
+    def _batched_noise(self, x):
+        """The ``randn(B, 1, H, W)`` of every noise injection of one forward pass (reference model.py:81-88, drawn inside each layer) as ONE
+        draw, sliced per layer in the order the layers consume it: 14 generator launches -> 1 (the draws of a pass are consecutive in
+        the reference's stream too; with torch's device generator one large draw is not the concatenation of the small ones, so a replay
+        of captured noise (``InjectNoise.draw`` replaced) and the CPU-stream replay of the reference's train() keep the per-layer draws)."""
+        for block in self.blocks:
+            block.__dict__.pop('_noise', None)
+        cur = InjectNoise.__dict__['draw']
+        if not x.is_cuda or rng._cpu or getattr(cur, '__func__', cur) is not _DEFAULT_NOISE_DRAW:
+            return
+        B, res, shapes = x.shape[0], x.shape[2], []
+        for block in self.blocks:
+            res *= 2
+            n = sum(1 for m in block.block if isinstance(m, InjectNoise))
+            shapes.append((n, res))
+        total = sum(n * B * r * r for n, r in shapes)
+        buf = rng.randn((total,), device=x.device)
+        off = 0
+        for block, (n, r) in zip(self.blocks, shapes):
+            block.__dict__['_noise'] = []
+            for _ in range(n):
+                block.__dict__['_noise'].append(buf[off:off + B * r * r].view(B, 1, r, r))
+                off += B * r * r
+
     def forward(self, x, y, injection=None):
         if isinstance(y, (list, tuple)):          # style mixing
             assert len(y) == 2
@@ -428,6 +456,7 @@ class Synthesis(nn.Module):
         else:
             y = [y for _ in range(self.num_layers)]
         self._batched_affines(y)
+        self._batched_noise(x)
         x = self.input(x, y[0])
         pre = self.input_to_image(x, y[0])
         image = pre

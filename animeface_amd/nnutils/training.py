@@ -1,5 +1,5 @@
-"""reference nnutils/training.py:7-40 -- same signatures; ``update_ema`` runs as two multi-tensor
-(foreach) launches instead of ~200 per-parameter kernel pairs."""
+"""reference nnutils/training.py:7-40 -- same signatures; ``update_ema`` runs as one multi-tensor
+(foreach) pass instead of ~200 per-parameter kernel pairs."""
 from __future__ import annotations
 
 from typing import Union
@@ -29,8 +29,9 @@ def update_ema(model: torch.nn.Module, model_ema: torch.nn.Module, decay: float 
         # plain copy: ``mul_(0)`` would keep NaNs of a freshly constructed (torch.empty) model_ema
         torch._foreach_copy_(ema_list, src_list)
     else:
-        torch._foreach_mul_(ema_list, decay)
-        torch._foreach_add_(ema_list, src_list, alpha=(1 - decay))
+        # ema * decay + p * (1 - decay) as ONE multi-tensor pass: ema + (1 - decay) * (p - ema)  (the reference's mul_ / add_ pair reads and
+        # writes every EMA tensor twice; the two forms differ by an fp32 rounding)
+        torch._foreach_lerp_(ema_list, src_list, 1 - decay)
     if copy_buffers:
         buffer_ema = dict(model_ema.named_buffers())
         buffer = dict(model.named_buffers())
