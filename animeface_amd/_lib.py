@@ -21,7 +21,7 @@ _DTYPES = {torch.float32: AGF_F32, torch.float16: AGF_F16, torch.bfloat16: AGF_B
 
 EXPORTS = ['agf_abi_version', 'agf_last_error', 'agf_device_info', 'agf_upfirdn2d', 'agf_upfirdn2d_fold_border', 'agf_bias_act',
            'agf_filtered_lrelu', 'agf_filtered_lrelu_act', 'agf_conv2d_fwd', 'agf_conv2d_fwd_mask', 'agf_conv2d_s2_fwd', 'agf_conv2d_s2_dgrad', 'agf_conv2d_wgrad', 'agf_conv2d_wgrad_ws', 'agf_conv2d_wgrad_workspace_bytes',
-           'agf_act_bwd_reduce', 'agf_act_bwd_reduce_pooled', 'agf_act_bwd_reduce_scaled', 'agf_scale_dot', 'agf_channel_sum', 'agf_demod_grad_finish', 'agf_planar_to_cl_pad', 'agf_cl_to_planar_crop', 'agf_cl_pad', 'agf_prep_weights', 'agf_prep_weights_multi', 'agf_prep_weights_blocks',
+           'agf_act_bwd_reduce', 'agf_act_bwd_reduce_pooled', 'agf_act_bwd_reduce_scaled', 'agf_scale_dot', 'agf_demod_grad_finish', 'agf_planar_to_cl_pad', 'agf_cl_to_planar_crop', 'agf_cl_pad', 'agf_prep_weights', 'agf_prep_weights_multi', 'agf_prep_weights_blocks',
            'agf_modulate_weights', 'agf_conv2d_fwd_wimg', 'agf_conv2d_fwd_wimg_covers',
            'agf_wsq', 'agf_style_demod_fwd', 'agf_style_demod_fwd_ld', 'agf_style_demod_bwd', 'agf_diffaug_sum', 'agf_diffaug_apply', 'agf_color_affine', 'agf_affine_resample', 'agf_upblur_border', 'agf_image_resample_rows', 'agf_image_finish']
 
@@ -97,8 +97,6 @@ def lib():
         L.agf_scale_dot.argtypes = [_vp] * 5 + [ctypes.c_int] + [ctypes.c_int32] * 4 + [_vp]
         L.agf_demod_grad_finish.restype = ctypes.c_int
         L.agf_demod_grad_finish.argtypes = [_vp] * 7 + [ctypes.c_int32, ctypes.c_int32, ctypes.c_float, _vp]
-        L.agf_channel_sum.restype = ctypes.c_int
-        L.agf_channel_sum.argtypes = [_vp, _vp, ctypes.c_int] + [ctypes.c_int32] * 4 + [ctypes.c_float, _vp]
         for fn in (L.agf_planar_to_cl_pad, L.agf_cl_to_planar_crop):
             fn.restype = ctypes.c_int
             fn.argtypes = [_vp, _vp, ctypes.c_int] + [ctypes.c_int32] * 6 + [_vp]

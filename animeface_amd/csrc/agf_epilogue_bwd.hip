@@ -241,72 +241,3 @@ extern "C" int agf_scale_dot(const void* x, const void* t, const float* s, void*
     return AGF_OK;
 }
 
-// ---- per-channel sum of a channels-last tensor: out[c] += scale * sum_{n,h,w} x[n,h,w,c]  (the bias gradient of a conv with a linear
-//      epilogue: `dy.sum((0, 2, 3))` -- ATen's generic reduction ran these at 2-3 TB/s in two launches each) ----
-struct ChannelSumParams {
-    const void* x; float* out;
-    int N, HW, C, CG, pixLanes, pixPerBlock;
-    float scale;
-};
-
-template <class T, int VEC>
-__global__ void __launch_bounds__(256) channel_sum_kernel(ChannelSumParams p) {
-    __shared__ float red[256][VEC + 1];
-    const int tid = threadIdx.x;
-    const int cg = tid % p.CG, pl = tid / p.CG;
-    const int n = blockIdx.y;
-    const int p0 = blockIdx.x * p.pixPerBlock;
-    const int p1 = min(p0 + p.pixPerBlock, p.HW);
-    float acc[VEC];
-#pragma unroll
-    for (int i = 0; i < VEC; i++) acc[i] = 0.f;
-    if (pl < p.pixLanes) {
-        const int64_t base = (int64_t)n * p.HW * p.C + cg * VEC;
-        constexpr int U = 4;                                            // independent 16-byte loads in flight per lane
-        for (int px0 = p0 + pl; px0 < p1; px0 += U * p.pixLanes) {
-            float v[U][VEC];
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int px = px0 + u * p.pixLanes;
-                if (px < p1) VecIO<T, VEC>::load((const T*)p.x + base + (int64_t)px * p.C, v[u]);
-                else {
-#pragma unroll
-                    for (int i = 0; i < VEC; i++) v[u][i] = 0.f;
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; u++)
-#pragma unroll
-                for (int i = 0; i < VEC; i++) acc[i] += v[u][i];
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < VEC; i++) red[tid][i] = acc[i];
-    __syncthreads();
-    if (pl == 0) {
-        for (int l = 1; l < p.pixLanes; l++)
-#pragma unroll
-            for (int i = 0; i < VEC; i++) acc[i] += red[l * p.CG + cg][i];
-#pragma unroll
-        for (int i = 0; i < VEC; i++) unsafeAtomicAdd(p.out + cg * VEC + i, acc[i] * p.scale);
-    }
-}
-
-extern "C" int agf_channel_sum(const void* x, float* out, int dtype, int32_t N, int32_t H, int32_t W, int32_t C, float scale, void* stream) {
-    AGF_CHECK(x && out, "channel_sum: null pointer");
-    AGF_CHECK(dtype == AGF_BF16 || dtype == AGF_F32, "channel_sum: dtype must be bf16 or f32");
-    AGF_CHECK(N >= 1 && N <= 65535 && H >= 1 && W >= 1, "channel_sum: bad shape");
-    ChannelSumParams p;
-    p.x = x; p.out = out; p.N = N; p.HW = H * W; p.C = C; p.scale = scale;
-    const int vec = dtype == AGF_BF16 ? 8 : 4;
-    int chunks;
-    if (!plan(C, vec, p.HW, N, &p.CG, &p.pixLanes, &p.pixPerBlock, &chunks)) {
-        agf_set_error("channel_sum: C=%d is not a multiple of %d (or too wide)", C, vec);
-        return AGF_ENOKERNEL;
-    }
-    dim3 grid((unsigned)chunks, (unsigned)N), block(256);
-    if (dtype == AGF_BF16) hipLaunchKernelGGL((channel_sum_kernel<bf16_t, 8>), grid, block, 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((channel_sum_kernel<float, 4>), grid, block, 0, (hipStream_t)stream, p);
-    AGF_LAUNCH_CHECK();
-    return AGF_OK;
-}

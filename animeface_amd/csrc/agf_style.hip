@@ -207,17 +207,29 @@ extern "C" int agf_style_demod_bwd(const float* s, const float* d, const float* 
 //      one launch instead of the six small ATen kernels (mul, sub, sub, div, sum, mul) per layer and backward pass ----
 __global__ void __launch_bounds__(256) demod_grad_finish_kernel(const float* A, const float* Bs, const float* Cn, const float* bias, const float* s_out,
                                                                 float* dso, float* db, int N, int C, float gain) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    const float b = bias ? bias[c] : 0.f;
+    // block = 16 channels x 16 row lanes: the rows of a column are read by 16 lanes in parallel (a single lane walking a column of 64-128
+    // rows is a chain of dependent-latency loads: 38 us for a 64 x 512 matrix)
+    __shared__ float red[16][17];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     float acc = 0.f;
-    for (int n = 0; n < N; n++) {
-        const int64_t i = (int64_t)n * C + c;
-        const float bv = Bs[i];
-        acc += bv;
-        if (dso) dso[i] = (A[i] - b * bv - (Cn ? Cn[i] : 0.f)) / s_out[i];
+    if (c < C) {
+        const float b = bias ? bias[c] : 0.f;
+        for (int n = rl; n < N; n += 16) {
+            const int64_t i = (int64_t)n * C + c;
+            const float bv = Bs[i];
+            acc += bv;
+            if (dso) dso[i] = (A[i] - b * bv - (Cn ? Cn[i] : 0.f)) / s_out[i];
+        }
     }
-    if (db) db[c] = acc * gain;
+    red[rl][cl] = acc;
+    __syncthreads();
+    if (rl == 0 && c < C && db) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) t += red[r][cl];
+        db[c] = t * gain;
+    }
 }
 
 extern "C" int agf_demod_grad_finish(const float* A, const float* Bs, const float* Cn, const float* bias, const float* s_out,
@@ -225,7 +237,7 @@ extern "C" int agf_demod_grad_finish(const float* A, const float* Bs, const floa
     AGF_CHECK(Bs && (dso || db), "demod_grad_finish: null pointer");
     AGF_CHECK(!dso || (A && s_out), "demod_grad_finish: dso needs A and s_out");
     AGF_CHECK(N >= 1 && C >= 1, "demod_grad_finish: empty tensor");
-    hipLaunchKernelGGL(demod_grad_finish_kernel, dim3((unsigned)agf_ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(demod_grad_finish_kernel, dim3((unsigned)agf_ceil_div(C, 16)), dim3(256), 0, (hipStream_t)stream,
                        A, Bs, Cn, bias, s_out, dso, db, N, C, gain);
     AGF_LAUNCH_CHECK();
     return AGF_OK;

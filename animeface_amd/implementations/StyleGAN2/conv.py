@@ -531,18 +531,12 @@ def demod_grad_finish_raw(A, B, Cn, bias, s_out, want_dso, want_db, gain=1.0):
 
 
 def channel_sum_raw(x, scale=1.0):
-    """scale * x.sum((0, 2, 3)) in fp32 -- one ``agf_channel_sum`` launch for channels-last bf16 / fp32 tensors whose channel count fills
-    16-byte vectors, ATen's reduction otherwise."""
-    N, C, H, W = x.shape
-    vec = 8 if x.dtype == torch.bfloat16 else 4
-    if not (x.is_cuda and x.dtype in (torch.bfloat16, torch.float32) and C % vec == 0 and C // vec <= 256
-            and x.is_contiguous(memory_format=torch.channels_last)):
-        out = x.sum((0, 2, 3), dtype=torch.float32)
-        return out * scale if scale != 1.0 else out
-    out = _zeros_f32((C,), x.device)
-    rc = _lib.lib().agf_channel_sum(_lib.ptr(x), _lib.ptr(out), _lib.dtype_code(x), N, H, W, C, float(scale), _lib.stream_ptr(x))
-    _lib.check(rc, 'channel_sum')
-    return out
+    """scale * x.sum((0, 2, 3)) in fp32: the bias gradient of a conv with a linear epilogue.  ATen's reduction (31 us per launch on the
+    step's shapes).  A dedicated streaming kernel (per-image partial sums with fp32 atomics, 17 us per launch) was measured and
+    REMOVED in round 3: with it in the iteration the chip settled at ~2.08 GHz / 1.10 kW instead of ~2.37 GHz / 0.96 kW and every MFMA
+    kernel of the step ran 12 % slower (36.0 -> 39.0 ms per iteration, same box, tools/_ab in profiles/r03_channel_sum_regression.txt)."""
+    out = x.sum((0, 2, 3), dtype=torch.float32)
+    return out * scale if scale != 1.0 else out
 
 
 def scale_dot_raw(x, t, s, want_dx=True):

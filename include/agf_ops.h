@@ -244,10 +244,6 @@ int agf_act_bwd_reduce_pooled(const void* dy_half, const void* y, void* g, float
 int agf_scale_dot(const void* x, const void* t, const float* s, void* dx, float* ds,
                   int dtype, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
 
-/* out[c] += scale * sum_{n,h,w} x[n,h,w,c]: the bias gradient of a conv whose epilogue is linear (autograd's `dy.sum((0, 2, 3))` for the
- * 1x1 skip conv of implementations/StyleGAN2/model.py:204-212 and the ToRGB conv :239-250) as one streaming pass.  x channels-last
- * bf16 / fp32, C a multiple of 8 / 4; out [C] fp32, accumulated into (zero it first). */
-int agf_channel_sum(const void* x, float* out, int dtype, int32_t N, int32_t H, int32_t W, int32_t C, float scale, void* stream);
 
 /* Finish of a fused modulated layer's epilogue gradients from the per-(n, c) sums agf_act_bwd_reduce leaves (implementations/StyleGAN2/model.py:
  * 118-121 demodulation, :132 bias): dso[n,c] = (A - bias[c] * B - Cn) / s_out (nullable, with A, Cn, s_out), db[c] = gain * sum_n B[n,c] (nullable).
