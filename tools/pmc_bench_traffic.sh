@@ -6,8 +6,8 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 export AGF_BENCH_NO_LOAD_PHASE=1      # GAN-loss iterations only: the same launches as the event-timed step whose algorithmic bytes bench.py reports
 rm -rf /tmp/pf /tmp/pw
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pf -o p -- python bench.py --steps 2 --warmup 1 --eager --no-r1-every-step --no-cpu-baseline --no-kernel-timer > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pw -o p -- python bench.py --steps 2 --warmup 1 --eager --no-r1-every-step --no-cpu-baseline --no-kernel-timer > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pf -o p -- python bench.py --steps 2 --warmup 1 --eager --no-r1-every-step --no-cpu-baseline --no-kernel-timer --no-ada-variant --no-upfirdn2d-rows > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pw -o p -- python bench.py --steps 2 --warmup 1 --eager --no-r1-every-step --no-cpu-baseline --no-kernel-timer --no-ada-variant --no-upfirdn2d-rows > /dev/null 2>&1
 python - <<'PY'
 import csv, json
 def tot(path, counter, pred):
