@@ -820,7 +820,6 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_taps_kernel(TapP
     const __amdgpu_buffer_rsrc_t wRes = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.Cout * tp.wTaps * p.Cin * 2, 0x00020000);
     int xoff[XV], woff[WV];
     const int half = (tid & 1) ^ ((tid >> 4) & 1);
-    unsigned xHalf = 0;
 #pragma unroll
     for (int i = 0; i < XV; i++) {
         const int v = tid + i * NTHR;
@@ -831,7 +830,6 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_taps_kernel(TapP
         xoff[i] = OOB;
         const int hx = tp.mode ? (plane >> 1) : (plane & 1);           // k-half of the 16-channel group
         const int kg = tp.mode ? 0 : (plane >> 1);                     // mode 0: which 16-channel group of the chunk
-        xHalf |= (unsigned)(hx & 1) << i;
         if (plane < planes) {
             const int t2 = PWp == 1 ? rem : (int)__umulhi((uint32_t)rem, tp.mPWp); const int cc = rem - t2 * PWp;
             const int ti = PHp == 1 ? t2 : (int)__umulhi((uint32_t)t2, tp.mPHp); const int pr = t2 - ti * PHp;
@@ -1631,7 +1629,7 @@ static int launch_fwd(const ConvParams& p, hipStream_t st) {
     // weight-stationary kernel: Cin <= 32 (two blocks per CU), or Cin <= 64 with Cout <= 32 (32-channel co tile: the
     // generic 64-channel tile would waste half of its MFMAs there); measured per layer in tools/ab_ws.sh
     constexpr int ws1 = 1;
-    if (g_ws_enable && ws1 && (ws1 == 2 || p.in_scale) && KS == 1 && MT == 1 && p.pixTiles >= 2048 && p.TW == 32 && p.TH == 8 && p.TI == 1 && p.Cin <= 32 && p.Cout <= 64) {
+    if (g_ws_enable != 0 && ws1 != 0 && (ws1 == 2 || p.in_scale) && KS == 1 && MT == 1 && p.pixTiles >= 2048 && p.TW == 32 && p.TH == 8 && p.TI == 1 && p.Cin <= 32 && p.Cout <= 64) {
         // 1x1 convs with few channels (FromRGB / ToRGB / the 32 -> 64 skip): pure streaming work.  One 256-pixel tile per block left
         // them at ~2 TB/s (block prologue per 20 KB of traffic); the persistent kernel keeps the weights in LDS and streams tiles.
         int rc;
