@@ -189,10 +189,10 @@ class GradReducer:
         """Graph-replayed training (``GraphedTrainStep`` with reducers): the backward pass ran inside a HIP graph, where no hook fires, so
         every bucket is all-reduced here, between two graph launches, and waited for.  Which parameters received a gradient is a static
         property of the captured iteration kind (``detach_untouched`` ran when it was captured)."""
+        # (no event timing here: an event recorded right after a graph launch is not ordered against the graph's kernels the way a
+        #  stream-ordered launch is -- the pair read 110 ms for the discriminator's exchange; the exposed time of this mode is the whole
+        #  exchange by construction, and bench.py's step_ms carries it)
         ev0 = ev1 = None
-        if self.measure and self.buckets and self.buckets[0]['flat'].is_cuda:
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            ev0.record()
         for b in self.buckets:
             b['launched'] = False
             self._launch(b)
@@ -225,7 +225,7 @@ class GradReducer:
         s = dict(self.stats)
         s['buckets'] = len(self.buckets)
         s['bucket_mib'] = [round(b['flat'].numel() * 4 / 2 ** 20, 1) for b in self.buckets]
-        s['exposed_ms_per_step'] = round(s['exposed_ms'] / max(s['steps'], 1), 4)
+        s['exposed_ms_per_step'] = round(s['exposed_ms'] / max(s['steps'], 1), 4) if s['exposed_ms'] > 0 else None
         return s
 
     def remove(self):
