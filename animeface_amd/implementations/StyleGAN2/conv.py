@@ -362,11 +362,11 @@ def _s2_covers(x, w):
 
 def _zero_upsample_odd(dy, ZH, ZW):
     """dy [N,C,Ho,Wo] -> [N,C,ZH,ZW] with dy at the odd positions (2i+1, 2j+1), zeros elsewhere: on that lattice the stride-2 conv's weight
-    gradient is the ordinary 3x3 "same" weight gradient (tap ky reads z[2i + 1 + ky - 1])."""
+    gradient is the ordinary 3x3 "same" weight gradient (tap ky reads z[2i + 1 + ky - 1]).  Zero insertion is ``upfirdn2d`` with the unit
+    impulse (one launch, differentiable): sample (i, j) lands on (2i, 2j) of the polyphase grid, one leading pad shifts it to the odd lattice."""
+    from ...stylegan3_ops import upfirdn2d as _fir
     N, C, Ho, Wo = dy.shape
-    up = torch.zeros((N, C, ZH, ZW), dtype=dy.dtype, device=dy.device).contiguous(memory_format=torch.channels_last)
-    up[:, :, 1:2 * Ho:2, 1:2 * Wo:2] = dy
-    return up
+    return _fir.upfirdn2d(dy, None, up=2, padding=[1, ZW - 2 * Wo - 1, 1, ZH - 2 * Ho - 1])
 
 
 class _ConvS2Fwd(torch.autograd.Function):
