@@ -403,6 +403,10 @@ struct FlrRbParams {
     int ofsU, ofsX, ofsH, ofsV, ofsS;   // LDS offsets (floats) after the filters; sS = staged sign words of the gradient pass
     int nDw;                         // sign dwords (16 samples each) staged per up-resolution row
     uint32_t mG, mTUW, mMW, mQ4, mTOW, mXP;   // magic numbers for division by nG, TUW, MW, UPC/4, TOW, XP
+    int ldw;                         // 16-bit x whose rows start on dwords: the tile is fetched as dwords (two samples per load)
+    int NW, dRy, dW;                 // dwords per tile row (XP / 2 + 1); the step of (row, dword) when a lane moves on by NT items
+    uint32_t mNW, mHW;               // ... by NW, TOW / 2
+    int sdw;                         // 16-bit y whose rows start on dwords: the two columns of a lane leave as one dword
     int skip;                        // profiling only (AGF_FLR_SKIP bit mask: 1 load, 2 up-FIR, 4 act, 8 down-FIR): phases left out, results wrong
 };
 
@@ -457,12 +461,50 @@ __global__ void __launch_bounds__(NT, NT == 256 ? 2 : 4) flr_rb_kernel(FlrRbPara
     const int tix0 = agf_floor_div(midx0, UP), tiy0 = agf_floor_div(midy0, UP);
     const int dx = midx0 - tix0 * UP, dy = midy0 - tiy0 * UP;          // 0 .. UP-1
 
-    // ---- 1. input tile + bias (zero outside the image).  Eight independent loads in flight per lane: with two
-    //      workgroups per CU a load -> wait -> store loop would leave the phase bound by one HBM latency per row ----
+    // ---- 1. input tile + bias (zero outside the image).  Independent loads in flight per lane: with two workgroups per
+    //      CU a load -> wait -> store loop would leave the phase bound by one HBM latency per row ----
     {
         const T* xb = (const T*)p.x + n * p.xs[0] + c * p.xs[1];
         const float bias = p.b ? (float)Elem<T>::load((const T*)p.b + c) : 0.f;
-        const int total = (P.skip & 1) ? 0 : p.TXH * P.XP;
+        bool done = false;
+        if constexpr (sizeof(T) == 2) {
+            if (P.ldw) {
+                // dword path (16-bit x, even width and row pitch): aligned pairs (ix0, ix0 + 1), ix0 even -- inside or outside
+                // the image together.  Half the loads and index arithmetic of the element-wise loop below (which cost ~40 VALU
+                // instructions per sample: the phase was as much instruction-bound as latency-bound); the (row, dword) index of a
+                // lane advances by NT items without a division
+                done = true;
+                const int a0 = tix0 & ~1, off = tix0 - a0;
+                const uint32_t* xw = (const uint32_t*)xb;
+                const int xs2 = (int)p.xs[2];
+                const int total = (P.skip & 1) ? 0 : p.TXH * P.NW;
+                int ry = (int)FLR_DIV(tid, P.NW, P.mNW), w = tid - ry * P.NW;
+                for (int i0 = tid; i0 < total; i0 += NT * 4) {
+                    uint32_t v[4]; int rys[4], ws[4]; bool ok[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        rys[u] = ry; ws[u] = w;
+                        const int iy = tiy0 + ry, ix0 = a0 + 2 * w;
+                        ok[u] = ry < p.TXH && (uint32_t)iy < (uint32_t)p.XH && (uint32_t)ix0 < (uint32_t)p.XW;
+                        v[u] = 0u;
+                        if (ok[u]) v[u] = xw[(iy * xs2 + ix0) >> 1];
+                        w += P.dW; ry += P.dRy;
+                        if (w >= P.NW) { w -= P.NW; ry++; }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        if (rys[u] >= p.TXH) continue;
+                        float lo, hi;
+                        Pack16<T>::unpack(v[u], lo, hi);
+                        lo = ok[u] ? lo + bias : 0.f; hi = ok[u] ? hi + bias : 0.f;
+                        float* dst = sX + rys[u] * P.XP + 2 * ws[u] - off;
+                        if (off == 0) { if (2 * ws[u] < P.XP) *(float2*)dst = make_float2(lo, hi); }
+                        else { if (ws[u] > 0) dst[0] = lo; if (2 * ws[u] < P.XP) dst[1] = hi; }
+                    }
+                }
+            }
+        }
+        const int total = (done || (P.skip & 1)) ? 0 : p.TXH * P.XP;      // element-wise path: fp32, odd widths, strided x
         for (int i0 = tid; i0 < total; i0 += NT * 8) {
             float v[8];
 #pragma unroll
@@ -737,30 +779,39 @@ __global__ void __launch_bounds__(NT, NT == 256 ? 2 : 4) flr_rb_kernel(FlrRbPara
     T* yb = (T*)p.y + n * p.ys[0] + c * p.ys[1];
     float ysum_local = 0.f;
     if (SD == 2) {
-        // ---- 4. 2-D down-FIR (DOWN == 2, 12x12): output column rox, strip of R4 rows, sliding window over tap rows ----
+        // ---- 4. 2-D down-FIR (DOWN == 2, 12x12): TWO adjacent output columns per lane (floats 4c .. 4c + 13 of an up-resolution
+        //      row: three b128 reads and one b64, lanes 16 bytes apart), strip of R4 rows, sliding window over tap rows.  The phase
+        //      is bound by LDS bandwidth, not by its FMAs (PMC: LDS busy 100 %, one column per lane: 108 b64 row reads for 288
+        //      packed FMAs); two columns share 5/6 of a row window: 0.58x the LDS cycles per output ----
         const int strips = p.TOH / R4;
-        const int items = (P.skip & 8) ? 0 : strips * p.TOW;
+        const int halfW = p.TOW >> 1;
+        const int items = (P.skip & 8) ? 0 : strips * halfW;
         for (int it = tid; it < items; it += NT) {
-            const int strip = (int)FLR_DIV(it, p.TOW, P.mTOW), rox = it - strip * p.TOW;
-            const float* ubase = sU + (strip * R4 * 2) * P.UPC + 2 * rox;
-            // acc2[o] = (sum over even kx, sum over odd kx): packed fp32 FMAs on the b64 pairs exactly as they come from LDS
-            v2f acc2[R4];
+            const int strip = (int)FLR_DIV(it, halfW, P.mHW), cx = it - strip * halfW;
+            const float* ubase = sU + (strip * R4 * 2) * P.UPC + 4 * cx;
+            // acc2[o][col] = (sum over even kx, sum over odd kx): packed fp32 FMAs on the pairs exactly as they come from LDS
+            v2f acc2[R4][2];
 #pragma unroll
-            for (int o = 0; o < R4; o++) acc2[o] = (v2f)(0.f);
+            for (int o = 0; o < R4; o++) { acc2[o][0] = (v2f)(0.f); acc2[o][1] = (v2f)(0.f); }
 #pragma unroll
             for (int par = 0; par < 2; par++) {
                 // rows of parity `par`; at step j (tap row par + 2j) output o reads row o + j of this list
 #pragma unroll
-                for (int o = 0; o < R4; o++) FLR_PIN(acc2[o]);
-                v2f rows[R4 + 5][6];
+                for (int o = 0; o < R4; o++) { FLR_PIN(acc2[o][0]); FLR_PIN(acc2[o][1]); }
+                v2f rows[R4 + 5][7];
                 v2f t[7][6];
                 const float* hb = ubase + par * P.UPC;
+                auto load_row = [&](int m) {
+                    const float4* rp = (const float4*)(hb + (2 * m) * P.UPC);
+                    const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
+                    const v2f r3 = *(const v2f*)(rp + 3);
+                    rows[m][0] = (v2f){r0.x, r0.y}; rows[m][1] = (v2f){r0.z, r0.w};
+                    rows[m][2] = (v2f){r1.x, r1.y}; rows[m][3] = (v2f){r1.z, r1.w};
+                    rows[m][4] = (v2f){r2.x, r2.y}; rows[m][5] = (v2f){r2.z, r2.w};
+                    rows[m][6] = r3;
+                };
 #pragma unroll
-                for (int mrow = 0; mrow < R4; mrow++) {
-                    const v2f* rp = (const v2f*)(hb + (2 * mrow) * P.UPC);
-#pragma unroll
-                    for (int q = 0; q < 6; q++) rows[mrow][q] = rp[q];
-                }
+                for (int mrow = 0; mrow < R4; mrow++) load_row(mrow);
                 {
                     const v2f* tp = (const v2f*)(sFd + par * 12);
 #pragma unroll
@@ -769,11 +820,9 @@ __global__ void __launch_bounds__(NT, NT == 256 ? 2 : 4) flr_rb_kernel(FlrRbPara
 #pragma unroll
                 for (int j = 0; j < 6; j++) {
 #pragma unroll
-                    for (int o = 0; o < R4; o++) FLR_PIN(acc2[o]);
+                    for (int o = 0; o < R4; o++) { FLR_PIN(acc2[o][0]); FLR_PIN(acc2[o][1]); }
                     if (j < 5) {                                   // fetch the next step's row and taps under this step's FMAs
-                        const v2f* rp = (const v2f*)(hb + (2 * (R4 + j)) * P.UPC);
-#pragma unroll
-                        for (int q = 0; q < 6; q++) rows[R4 + j][q] = rp[q];
+                        load_row(R4 + j);
                         const v2f* tp = (const v2f*)(sFd + (par + 2 * (j + 1)) * 12);
 #pragma unroll
                         for (int q = 0; q < 6; q++) t[j + 1][q] = tp[q];
@@ -781,18 +830,26 @@ __global__ void __launch_bounds__(NT, NT == 256 ? 2 : 4) flr_rb_kernel(FlrRbPara
 #pragma unroll
                     for (int o = 0; o < R4; o++)
 #pragma unroll
-                        for (int q = 0; q < 6; q++) acc2[o] = __builtin_elementwise_fma(rows[o + j][q], t[j][q], acc2[o]);
+                        for (int q = 0; q < 6; q++) {
+                            acc2[o][0] = __builtin_elementwise_fma(rows[o + j][q], t[j][q], acc2[o][0]);
+                            acc2[o][1] = __builtin_elementwise_fma(rows[o + j][q + 1], t[j][q], acc2[o][1]);
+                        }
                 }
             }
-            float acc[R4];
+            const int ox = ox0 + 2 * cx;
 #pragma unroll
-            for (int o = 0; o < R4; o++) acc[o] = acc2[o].x + acc2[o].y;
-            const int ox = ox0 + rox;
-            if (ox < p.YW) {
-#pragma unroll
-                for (int o = 0; o < R4; o++) {
-                    const int oy = oy0 + strip * R4 + o;
-                    if (oy < p.YH) { Elem<T>::store(yb + oy * p.ys[2] + ox * p.ys[3], acc[o]); ysum_local += acc[o]; }
+            for (int o = 0; o < R4; o++) {
+                const int oy = oy0 + strip * R4 + o;
+                const float a0 = acc2[o][0].x + acc2[o][0].y, a1 = acc2[o][1].x + acc2[o][1].y;
+                if (oy >= p.YH) continue;
+                T* dst = yb + oy * p.ys[2] + ox * p.ys[3];
+                bool packed = false;
+                if constexpr (sizeof(T) == 2) {
+                    if (P.sdw && ox + 1 < p.YW) { *(uint32_t*)dst = Pack16<T>::pack(a0, a1); ysum_local += a0 + a1; packed = true; }
+                }
+                if (!packed) {
+                    if (ox < p.YW) { Elem<T>::store(dst, a0); ysum_local += a0; }
+                    if (ox + 1 < p.YW) { Elem<T>::store(dst + p.ys[3], a1); ysum_local += a1; }
                 }
             }
         }
@@ -921,8 +978,13 @@ static bool flr_rb_launch(FlrParams p, hipStream_t st, int* status) {
     P.b = p;
     P.mG = flr_magic(SU == 1 ? P.TVWa >> 3 : 1); P.mTUW = flr_magic(p.TUW); P.mMW = flr_magic(P.MW ? P.MW : 1);
     P.mQ4 = flr_magic(P.UPC >> 2); P.mTOW = flr_magic(p.TOW); P.mXP = flr_magic(P.XP);
-#ifdef AGF_PROFILE_PHASES      // build with -DAGF_PROFILE_PHASES for tools/flr_phases.sh; a product build cannot leave phases out
-    { constexpr int sk = 0; P.skip = sk; }
+    P.mHW = flr_magic(p.TOW >> 1);
+    P.sdw = sizeof(T) == 2 && p.ys[3] == 1 && !(p.ys[2] & 1) && !(p.ys[1] & 1) && !(p.ys[0] & 1) && !((uintptr_t)p.y & 3);
+    P.NW = (P.XP >> 1) + 1; P.dRy = NT / P.NW; P.dW = NT - P.dRy * P.NW; P.mNW = flr_magic(P.NW);
+    P.ldw = sizeof(T) == 2 && p.xs[3] == 1 && !(p.xs[2] & 1) && !(p.xs[1] & 1) && !(p.xs[0] & 1) && !(p.XW & 1) && !((uintptr_t)p.x & 3)
+            && (int64_t)p.XH * p.xs[2] < (1ll << 31);
+#ifdef AGF_PROFILE_PHASES      // build with -DAGF_PROFILE_PHASES=<mask> (tools/flr_phases.sh); a product build cannot leave phases out
+    P.skip = AGF_PROFILE_PHASES;
 #else
     P.skip = 0;
 #endif
