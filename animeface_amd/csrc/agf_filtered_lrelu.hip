@@ -9,6 +9,7 @@
 // __shfl_xor_sync masks (filtered_lrelu.cu:1143-1150); on a 64-lane wavefront the packing is two __ballot()s
 // (one per code bit) whose 16-bit quarters are bit-interleaved by the quarter's first lane: 4 uint32 stores per wave.
 #include "agf_common.h"
+#include <type_traits>
 
 struct ActParams {
     void* x;
@@ -580,64 +581,94 @@ __global__ void __launch_bounds__(NT, NT == 256 ? 2 : 4) flr_rb_kernel(FlrRbPara
         __syncthreads();
         // ---- 3. vertical up-FIR + activation: column rux (v = rux + dx), rows vy = 8s .. 8s+7 -> sU[vy - dy][rux].
         //      The up-resolution values are in registers here, so gain / leaky ReLU / clamp and the sign bits are applied before
-        //      the store: no separate pass over sU.  Lanes 4q .. 4q+3 hold the four samples of one sign byte (columns are padded
-        //      to a multiple of 4 so that lane & 3 == rux & 3); the byte is assembled with two quad-permute DPP steps ----
-        {
+        //      the store: no separate pass over sU.  This pass is VALU-issue-bound (PMC: VALU busy 100 %), and what it issues is
+        //      mostly not the 6 FMAs of a sample: so the sign mode is resolved outside the item loop, samples beyond the logical
+        //      image are masked only in tiles that reach it, a lane keeps the 2-bit codes of its 8 rows in one register and the
+        //      quad (lanes 4q .. 4q+3 = the four samples of a sign byte; columns are padded to a multiple of 4 so that
+        //      lane & 3 == rux & 3) transposes them once per item: lane l then stores the bytes of rows l and l + 4 ----
+        auto vert = [&](auto modeTag) {
+            constexpr int MODE = decltype(modeTag)::value;
             const int64_t plane64 = (int64_t)plane;
             const int coreW = (tx == p.tilesX - 1) ? p.TUW : p.TOW * DOWN;
             const int coreH = (ty == p.tilesY - 1) ? p.TUH : p.TOH * DOWN;
+            const bool edgeTile = ux0 + p.TUW > p.UW || uy0 + p.TUH > p.UH;
             const int items = (P.skip & 2) ? 0 : P.runsV * P.UPC;
             const int q4 = P.UPC >> 2;
+            const float slope = p.slope, clampv = p.clamp;
             for (int it = tid; it < items; it += NT) {
                 const int sr = (int)FLR_DIV(it >> 2, q4, P.mQ4), rux = it - sr * P.UPC;
                 const bool colok = rux < p.TUW;
                 const int ux = ux0 + rux;
                 constexpr int NROW = UP == 2 ? 9 : 7;
                 const float* src = sH + (UP == 2 ? 4 * sr : 2 * sr) * P.HP + (colok ? rux : 0) + dx;
+                const int ruy0 = 8 * sr - dy;
                 uint32_t scode[8];
-                if (p.signMode == 2) {
+                if (MODE == 2) {
 #pragma unroll
-                    for (int e = 0; e < 8; e++) scode[e] = colok ? sign_code(8 * sr + e - dy, rux) : 0u;
+                    for (int e = 0; e < 8; e++) scode[e] = colok ? sign_code(ruy0 + e, rux) : 0u;
                 }
                 float h[NROW];
 #pragma unroll
                 for (int j = 0; j < NROW; j++) h[j] = src[j * P.HP];
+                const uint32_t rowLimit = colok ? (uint32_t)p.TUH : 0u;     // rows this lane stores: 0 <= ruy < rowLimit
+                const bool colin = colok && ux < p.UW;
+                float* dst = sU + ruy0 * P.UPC + rux;
+                uint32_t codes = 0;                                         // 2 bits per row
 #pragma unroll
                 for (int e = 0; e < 8; e++) {
                     const int k0 = UP - 1 - (e % UP), b0 = e / UP;
                     float a = 0.f;
 #pragma unroll
                     for (int j = 0; j < 6; j++) a = fmaf(h[b0 + j], fu[k0 + j * UP], a);
-                    const int ruy = 8 * sr + e - dy;
-                    const int uy = uy0 + ruy;
-                    const bool rowok = ruy >= 0 && ruy < p.TUH;
                     float v = a * upGain;
                     uint32_t code = 0;
-                    const bool inimg = colok && ux < p.UW && uy < p.UH;
-                    if (p.signMode == 2) {                       // uniform branch; everything below is select / med3, no divergence
-                        float mul = (scode[e] & 1) ? p.slope : 1.f;
+                    if (MODE == 2) {
+                        float mul = (scode[e] & 1) ? slope : 1.f;
                         mul = (scode[e] & 2) ? 0.f : mul;
                         v *= mul;
                     } else {
                         const bool neg = v < 0.f;
-                        v *= neg ? p.slope : 1.f;
-                        const bool cl = fabsf(v) > p.clamp;
-                        v = __builtin_amdgcn_fmed3f(v, -p.clamp, p.clamp);
-                        code = cl ? 2u : (neg ? 1u : 0u);
+                        v *= neg ? slope : 1.f;
+                        const bool cl = fabsf(v) > clampv;
+                        v = __builtin_amdgcn_fmed3f(v, -clampv, clampv);
+                        if (MODE == 1) code = cl ? (2u << (2 * e)) : (neg ? (1u << (2 * e)) : 0u);
                     }
-                    v = inimg ? v : 0.f;
-                    code = inimg ? code : 0u;
-                    if (rowok && colok) sU[ruy * P.UPC + rux] = v;
-                    if (p.signMode == 1) {
-                        uint32_t c4 = code << ((rux & 3) << 1);
-                        c4 |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c4, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
-                        c4 |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c4, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
-                        if ((rux & 3) == 0 && rowok && rux < coreW && ruy < coreH && uy < p.SH && (ux >> 2) < p.SWB)
-                            p.s[(ux >> 2) + (int64_t)p.SWB * (uy + (int64_t)p.SH * plane64)] = (uint8_t)c4;
+                    if (edgeTile) {                              // uniform
+                        const bool inimg = colin && uy0 + ruy0 + e < p.UH;
+                        v = inimg ? v : 0.f;
+                        code = inimg ? code : 0u;
+                    }
+                    codes |= code;
+                    if ((uint32_t)(ruy0 + e) < rowLimit) dst[e * P.UPC] = v;
+                }
+                if (MODE == 1) {
+                    codes = colok ? codes : 0u;                  // padding columns of the tile carry no sample
+                    // quad transpose: A[m] = codes of lane m of the quad; byte of row r = sum over m of (A[m] >> 2r & 3) << 2m
+                    const int l = rux & 3;
+                    uint32_t A[4];
+                    A[0] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)codes, 0x00, 0xF, 0xF, true);   // quad_perm [0,0,0,0]
+                    A[1] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)codes, 0x55, 0xF, 0xF, true);   // [1,1,1,1]
+                    A[2] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)codes, 0xAA, 0xF, 0xF, true);   // [2,2,2,2]
+                    A[3] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)codes, 0xFF, 0xF, 0xF, true);   // [3,3,3,3]
+                    uint32_t b0 = 0, b1 = 0;
+#pragma unroll
+                    for (int m = 0; m < 4; m++) {
+                        b0 |= __builtin_amdgcn_ubfe(A[m], (uint32_t)(2 * l), 2u) << (2 * m);
+                        b1 |= __builtin_amdgcn_ubfe(A[m], (uint32_t)(2 * l + 8), 2u) << (2 * m);
+                    }
+                    const int qx = rux - l, sx = (ux0 + qx) >> 2;
+                    if (qx < coreW && sx < p.SWB) {
+                        const int r0 = ruy0 + l, r1 = r0 + 4;
+                        uint8_t* sp = p.s + sx + (int64_t)p.SWB * (uy0 + (int64_t)p.SH * plane64);
+                        if ((uint32_t)r0 < (uint32_t)coreH && uy0 + r0 < p.SH) sp[(int64_t)p.SWB * r0] = (uint8_t)b0;
+                        if ((uint32_t)r1 < (uint32_t)coreH && uy0 + r1 < p.SH) sp[(int64_t)p.SWB * r1] = (uint8_t)b1;
                     }
                 }
             }
-        }
+        };
+        if (p.signMode == 1) vert(std::integral_constant<int, 1>{});
+        else if (p.signMode == 2) vert(std::integral_constant<int, 2>{});
+        else vert(std::integral_constant<int, 0>{});
     } else {
         // ---- 3'. 2-D up-FIR (UP == 2, 12x12): input column m -> output columns v = 2m, 2m+1; RN input rows per run.
         //      acc[i][a] = (column phase 0, column phase 1) of output row 2(n0+i)+a, updated with packed fp32 FMAs:
