@@ -413,6 +413,7 @@ struct FlrRbParams {
 
 // Scheduling fence: the value must be materialised here, and no memory access moves across.  Without tying the accumulators
 // to the fence the compiler sinks every FMA below all the loads of an unrolled phase (everything live at once -> spills).
+#define FLR_RV 4                     // rows per item of the two-column vertical pass (8: fewer, longer items; the last round of a tile is then a third full)
 #define FLR_PIN(v) asm volatile("" : "+v"(v) :: "memory")
 typedef float v2f __attribute__((ext_vector_type(2)));
 static __device__ __forceinline__ uint32_t flr_div(uint32_t a, uint32_t magic) { return __umulhi(a, magic); }
@@ -420,7 +421,7 @@ static inline uint32_t flr_magic(uint32_t d) { return d <= 1 ? 0u : (uint32_t)(0
 #define FLR_DIV(a, d, magic) ((d) <= 1 ? (uint32_t)(a) : flr_div((uint32_t)(a), (magic)))
 
 template <class T, int UP, int DOWN, int SU, int SD, int RN, int R4, int NT>
-__global__ void __launch_bounds__(NT, NT == 256 ? 2 : 4) flr_rb_kernel(FlrRbParams P) {
+__global__ void __launch_bounds__(NT, 4) flr_rb_kernel(FlrRbParams P) {
     constexpr int FU = 6 * UP, FD = 6 * DOWN;
     static_assert(SU == 1 || UP == 2, "2-D up filter: factor 2 only");
     static_assert(SD == 1 || DOWN == 2, "2-D down filter: factor 2 only");
@@ -437,6 +438,44 @@ __global__ void __launch_bounds__(NT, NT == 256 ? 2 : 4) flr_rb_kernel(FlrRbPara
     uint32_t* sS = (uint32_t*)(base + P.ofsS);                  // [TUH][nDw], only when signs are read
     const int tid = threadIdx.x;
 
+    int bid = blockIdx.x;
+    const int tx = bid % p.tilesX; bid /= p.tilesX;
+    const int ty = bid % p.tilesY;
+    const int plane = bid / p.tilesY;
+    const int n = plane / p.C, c = plane - n * p.C;
+    const int oy0 = ty * p.TOH, ox0 = tx * p.TOW;
+    const int uy0 = oy0 * DOWN, ux0 = ox0 * DOWN;
+    const int midx0 = ux0 + UP - 1 - p.px0, midy0 = uy0 + UP - 1 - p.py0;
+    const int tix0 = agf_floor_div(midx0, UP), tiy0 = agf_floor_div(midy0, UP);
+    const int dx = midx0 - tix0 * UP, dy = midy0 - tiy0 * UP;          // 0 .. UP-1
+
+    // 16-bit x, dword path (P.ldw): aligned pairs (ix0, ix0 + 1), ix0 even -- inside or outside the image together.  Half the loads and
+    // index arithmetic of the element-wise loop (which cost ~40 VALU instructions per sample: the phase was as much instruction-bound
+    // as latency-bound); the (row, dword) index of a lane advances by NT items without a division.  When the whole tile is one pass
+    // (P.ldw == 2: at most four dwords per lane) the loads are issued here, ahead of the filter taps, so that the two global
+    // round trips of a workgroup's prologue overlap.
+    uint32_t xv[4] = {0u, 0u, 0u, 0u};
+    int xry[4], xw_[4];
+    bool xok[4];
+    const T* xb = (const T*)p.x + n * p.xs[0] + c * p.xs[1];
+    const int xa0 = tix0 & ~1, xoff = tix0 - xa0;
+    int xr = (int)FLR_DIV(tid, P.NW, P.mNW), xc = tid - xr * P.NW;
+    auto x_issue = [&]() {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            xry[u] = xr; xw_[u] = xc;
+            const int iy = tiy0 + xr, ix0 = xa0 + 2 * xc;
+            xok[u] = xr < p.TXH && (uint32_t)iy < (uint32_t)p.XH && (uint32_t)ix0 < (uint32_t)p.XW;
+            xv[u] = 0u;
+            if (xok[u]) xv[u] = ((const uint32_t*)xb)[(iy * (int)p.xs[2] + ix0) >> 1];
+            xc += P.dW; xr += P.dRy;
+            if (xc >= P.NW) { xc -= P.NW; xr++; }
+        }
+    };
+    const float bias = p.b ? (float)Elem<T>::load((const T*)p.b + c) : 0.f;
+    const bool xpre = sizeof(T) == 2 && P.ldw == 2 && !(P.skip & 1);
+    if constexpr (sizeof(T) == 2) { if (xpre) x_issue(); }
+
     // ---- filters.  F(k) = f[size-1-k] unless flip.  2-D up taps are stored in the order the polyphase loop consumes them:
     //      sFu[((a*6 + jy)*6 + jx)*2 + b] = F(1-a+2jy, 1-b+2jx) ----
     if (SU == 1) { for (int i = tid; i < FU; i += NT) sFu[i] = p.fu[(p.flip ? i : FU - 1 - i) * p.fus0]; }
@@ -451,56 +490,25 @@ __global__ void __launch_bounds__(NT, NT == 256 ? 2 : 4) flr_rb_kernel(FlrRbPara
     else { for (int i = tid; i < FD * FD; i += NT) { int ky = i / FD, kx = i - ky * FD;
             sFd[i] = p.fd[(p.flip ? ky : FD - 1 - ky) * p.fds0 + (p.flip ? kx : FD - 1 - kx) * p.fds1]; } }
 
-    int bid = blockIdx.x;
-    const int tx = bid % p.tilesX; bid /= p.tilesX;
-    const int ty = bid % p.tilesY;
-    const int plane = bid / p.tilesY;
-    const int n = plane / p.C, c = plane - n * p.C;
-    const int oy0 = ty * p.TOH, ox0 = tx * p.TOW;
-    const int uy0 = oy0 * DOWN, ux0 = ox0 * DOWN;
-    const int midx0 = ux0 + UP - 1 - p.px0, midy0 = uy0 + UP - 1 - p.py0;
-    const int tix0 = agf_floor_div(midx0, UP), tiy0 = agf_floor_div(midy0, UP);
-    const int dx = midx0 - tix0 * UP, dy = midy0 - tiy0 * UP;          // 0 .. UP-1
-
     // ---- 1. input tile + bias (zero outside the image).  Independent loads in flight per lane: with two workgroups per
     //      CU a load -> wait -> store loop would leave the phase bound by one HBM latency per row ----
     {
-        const T* xb = (const T*)p.x + n * p.xs[0] + c * p.xs[1];
-        const float bias = p.b ? (float)Elem<T>::load((const T*)p.b + c) : 0.f;
         bool done = false;
         if constexpr (sizeof(T) == 2) {
             if (P.ldw) {
-                // dword path (16-bit x, even width and row pitch): aligned pairs (ix0, ix0 + 1), ix0 even -- inside or outside
-                // the image together.  Half the loads and index arithmetic of the element-wise loop below (which cost ~40 VALU
-                // instructions per sample: the phase was as much instruction-bound as latency-bound); the (row, dword) index of a
-                // lane advances by NT items without a division
                 done = true;
-                const int a0 = tix0 & ~1, off = tix0 - a0;
-                const uint32_t* xw = (const uint32_t*)xb;
-                const int xs2 = (int)p.xs[2];
                 const int total = (P.skip & 1) ? 0 : p.TXH * P.NW;
-                int ry = (int)FLR_DIV(tid, P.NW, P.mNW), w = tid - ry * P.NW;
                 for (int i0 = tid; i0 < total; i0 += NT * 4) {
-                    uint32_t v[4]; int rys[4], ws[4]; bool ok[4];
+                    if (!xpre) x_issue();
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
-                        rys[u] = ry; ws[u] = w;
-                        const int iy = tiy0 + ry, ix0 = a0 + 2 * w;
-                        ok[u] = ry < p.TXH && (uint32_t)iy < (uint32_t)p.XH && (uint32_t)ix0 < (uint32_t)p.XW;
-                        v[u] = 0u;
-                        if (ok[u]) v[u] = xw[(iy * xs2 + ix0) >> 1];
-                        w += P.dW; ry += P.dRy;
-                        if (w >= P.NW) { w -= P.NW; ry++; }
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        if (rys[u] >= p.TXH) continue;
+                        if (xry[u] >= p.TXH) continue;
                         float lo, hi;
-                        Pack16<T>::unpack(v[u], lo, hi);
-                        lo = ok[u] ? lo + bias : 0.f; hi = ok[u] ? hi + bias : 0.f;
-                        float* dst = sX + rys[u] * P.XP + 2 * ws[u] - off;
-                        if (off == 0) { if (2 * ws[u] < P.XP) *(float2*)dst = make_float2(lo, hi); }
-                        else { if (ws[u] > 0) dst[0] = lo; if (2 * ws[u] < P.XP) dst[1] = hi; }
+                        Pack16<T>::unpack(xv[u], lo, hi);
+                        lo = xok[u] ? lo + bias : 0.f; hi = xok[u] ? hi + bias : 0.f;
+                        float* dst = sX + xry[u] * P.XP + 2 * xw_[u] - xoff;
+                        if (xoff == 0) { if (2 * xw_[u] < P.XP) *(float2*)dst = make_float2(lo, hi); }
+                        else { if (xw_[u] > 0) dst[0] = lo; if (2 * xw_[u] < P.XP) dst[1] = hi; }
                     }
                 }
             }
@@ -666,9 +674,80 @@ __global__ void __launch_bounds__(NT, NT == 256 ? 2 : 4) flr_rb_kernel(FlrRbPara
                 }
             }
         };
-        if (p.signMode == 1) vert(std::integral_constant<int, 1>{});
+        // The same pass with TWO adjacent columns per lane (sign modes 0 and 1): the FIR, the gain and the slope become packed fp32
+        // instructions (one per two samples), a row leaves as one b64 store, and a sign byte is the nibbles of two lanes.
+        auto vert2 = [&](auto modeTag) {
+            constexpr int MODE = decltype(modeTag)::value;
+            constexpr int RV = FLR_RV;                                      // rows per item
+            const int64_t plane64 = (int64_t)plane;
+            const int coreW = (tx == p.tilesX - 1) ? p.TUW : p.TOW * DOWN;
+            const int coreH = (ty == p.tilesY - 1) ? p.TUH : p.TOH * DOWN;
+            const bool edgeTile = ux0 + p.TUW > p.UW || uy0 + p.TUH > p.UH;
+            const int half = P.UPC >> 1, q4 = P.UPC >> 2;
+            const int items = (P.skip & 2) ? 0 : (P.runsV * 8 / RV) * half;
+            const float slope = p.slope, clampv = p.clamp;
+            uint8_t* splane = p.s + (int64_t)p.SWB * p.SH * plane64;
+            for (int it = tid; it < items; it += NT) {
+                const int sr = (int)FLR_DIV(it >> 1, q4, P.mQ4), c2 = it - sr * half, rux = 2 * c2;
+                const bool colok = rux < p.TUW;                             // TUW is even: both columns or neither
+                const int ux = ux0 + rux;
+                constexpr int NROW = RV / UP + 5;
+                const float* src = sH + (RV / UP * sr) * P.HP + (colok ? rux : 0) + dx;
+                const int ruy0 = RV * sr - dy;
+                v2f h[NROW];
+#pragma unroll
+                for (int j = 0; j < NROW; j++) h[j] = (v2f){src[j * P.HP], src[j * P.HP + 1]};
+                const uint32_t rowLimit = colok ? (uint32_t)p.TUH : 0u;     // rows this lane stores: 0 <= ruy < rowLimit
+                float* dst = sU + ruy0 * P.UPC + rux;
+                uint32_t codes = 0;                                         // 4 bits per row: (column 0, column 1) x 2 bits
+#pragma unroll
+                for (int e = 0; e < RV; e++) {
+                    const int k0 = UP - 1 - (e % UP), b0 = e / UP;
+                    v2f a = (v2f)(0.f);
+#pragma unroll
+                    for (int j = 0; j < 6; j++) a = __builtin_elementwise_fma(h[b0 + j], (v2f)(fu[k0 + j * UP]), a);
+                    v2f v = a * (v2f)(upGain);
+                    const bool n0 = v.x < 0.f, n1 = v.y < 0.f;
+                    v = v * (v2f){n0 ? slope : 1.f, n1 ? slope : 1.f};
+                    const bool c0 = fabsf(v.x) > clampv, c1 = fabsf(v.y) > clampv;
+                    v.x = __builtin_amdgcn_fmed3f(v.x, -clampv, clampv);
+                    v.y = __builtin_amdgcn_fmed3f(v.y, -clampv, clampv);
+                    uint32_t code = 0;
+                    if (MODE == 1) code = (c0 ? (2u << (4 * e)) : (n0 ? (1u << (4 * e)) : 0u)) | (c1 ? (8u << (4 * e)) : (n1 ? (4u << (4 * e)) : 0u));
+                    if (edgeTile) {                              // uniform
+                        const bool rowin = uy0 + ruy0 + e < p.UH;
+                        const bool i0 = rowin && ux < p.UW, i1 = rowin && ux + 1 < p.UW;
+                        v.x = i0 ? v.x : 0.f; v.y = i1 ? v.y : 0.f;
+                        code = (i0 ? code & (3u << (4 * e)) : 0u) | (i1 ? code & (12u << (4 * e)) : 0u);
+                    }
+                    codes |= code;
+                    if ((uint32_t)(ruy0 + e) < rowLimit) *(v2f*)(dst + e * P.UPC) = v;
+                }
+                if (MODE == 1) {
+                    codes = colok ? codes : 0u;                  // padding columns of the tile carry no sample
+                    // lane pair (2q, 2q + 1) = the four columns of a sign byte: the even lane assembles the bytes of the first RV / 2
+                    // rows of the run, the odd lane those of the other half
+                    const uint32_t other = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)codes, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+                    const bool odd = c2 & 1;
+                    uint32_t lo = odd ? other : codes, hi = odd ? codes : other;
+                    lo = odd ? lo >> (2 * RV) : lo & ((1u << (2 * RV)) - 1u); hi = odd ? hi >> (2 * RV) : hi & ((1u << (2 * RV)) - 1u);
+                    lo = (lo | (lo << 8)) & 0x00FF00FFu; lo = (lo | (lo << 4)) & 0x0F0F0F0Fu;
+                    hi = (hi | (hi << 8)) & 0x00FF00FFu; hi = (hi | (hi << 4)) & 0x0F0F0F0Fu;
+                    const uint32_t W = lo | (hi << 4);
+                    const int qx = rux & ~3, sx = (ux0 + qx) >> 2;
+                    if (qx < coreW && sx < p.SWB) {
+                        const int r = ruy0 + (odd ? RV / 2 : 0);
+                        uint8_t* sp = splane + (uint32_t)sx;
+#pragma unroll
+                        for (int k = 0; k < RV / 2; k++)
+                            if ((uint32_t)(r + k) < (uint32_t)coreH && uy0 + r + k < p.SH) sp[(uint32_t)(p.SWB * (uy0 + r + k))] = (uint8_t)(W >> (8 * k));
+                    }
+                }
+            }
+        };
+        if (p.signMode == 1) vert2(std::integral_constant<int, 1>{});
         else if (p.signMode == 2) vert(std::integral_constant<int, 2>{});
-        else vert(std::integral_constant<int, 0>{});
+        else vert2(std::integral_constant<int, 0>{});
     } else {
         // ---- 3'. 2-D up-FIR (UP == 2, 12x12): input column m -> output columns v = 2m, 2m+1; RN input rows per run.
         //      acc[i][a] = (column phase 0, column phase 1) of output row 2(n0+i)+a, updated with packed fp32 FMAs:
@@ -942,7 +1021,7 @@ __global__ void __launch_bounds__(NT, NT == 256 ? 2 : 4) flr_rb_kernel(FlrRbPara
 // instantiations (the caller then uses filtered_lrelu_kernel).
 template <class T, int UP, int DOWN, int SU, int SD, int NT>
 static bool flr_rb_launch(FlrParams p, hipStream_t st, int* status) {
-    constexpr int FU = 6 * UP, FD = 6 * DOWN, RN = 4, R4 = NT == 256 ? 8 : 4;
+    constexpr int FU = 6 * UP, FD = 6 * DOWN, RN = 4, R4 = 4;
     constexpr int RD = DOWN == 2 ? 8 : 4;
     constexpr int ROUT = SD == 2 ? R4 : RD;                   // TOH is a multiple of this
     const int maxW = (SD == 2) ? 64 : (DOWN == 2 ? 64 : 32);
@@ -997,7 +1076,7 @@ static bool flr_rb_launch(FlrParams p, hipStream_t st, int* status) {
         P.ofsS = szU + szR2;
         const size_t fl = (size_t)(SU == 1 ? FU : FU * FU) + (size_t)(SD == 1 ? FD : FD * FD) + szU + szR2 + szS;
         lds = fl * sizeof(float);
-        if (lds <= 78 * 1024) break;                             // two workgroups per CU
+        if (lds <= 78 * 1024) break;                             // two workgroups per CU (256 threads x 4, 3 x 512 with smaller tiles: all slower)
         if (strips == 1 && lds <= 150 * 1024) break;
     }
     // the filter block must keep sU 16-byte aligned
@@ -1014,6 +1093,7 @@ static bool flr_rb_launch(FlrParams p, hipStream_t st, int* status) {
     P.NW = (P.XP >> 1) + 1; P.dRy = NT / P.NW; P.dW = NT - P.dRy * P.NW; P.mNW = flr_magic(P.NW);
     P.ldw = sizeof(T) == 2 && p.xs[3] == 1 && !(p.xs[2] & 1) && !(p.xs[1] & 1) && !(p.xs[0] & 1) && !(p.XW & 1) && !((uintptr_t)p.x & 3)
             && (int64_t)p.XH * p.xs[2] < (1ll << 31);
+    if (P.ldw && p.TXH * P.NW <= 4 * NT) P.ldw = 2;
 #ifdef AGF_PROFILE_PHASES      // build with -DAGF_PROFILE_PHASES=<mask> (tools/flr_phases.sh); a product build cannot leave phases out
     P.skip = AGF_PROFILE_PHASES;
 #else
