@@ -406,7 +406,7 @@ struct FlrRbParams {
     uint32_t mG, mTUW, mMW, mQ4, mTOW, mXP;   // magic numbers for division by nG, TUW, MW, UPC/4, TOW, XP
     int ldw;                         // 16-bit x whose rows start on dwords: the tile is fetched as dwords (two samples per load)
     int NW, dRy, dW;                 // dwords per tile row (XP / 2 + 1); the step of (row, dword) when a lane moves on by NT items
-    uint32_t mNW, mHW;               // ... by NW, TOW / 2
+    uint32_t mNW, mHW, mDw;               // ... by NW, TOW / 2
     int sdw;                         // 16-bit y whose rows start on dwords: the two columns of a lane leave as one dword
     int skip;                        // profiling only (AGF_FLR_SKIP bit mask: 1 load, 2 up-FIR, 4 act, 8 down-FIR): phases left out, results wrong
 };
@@ -476,6 +476,21 @@ __global__ void __launch_bounds__(NT, 4) flr_rb_kernel(FlrRbParams P) {
     const bool xpre = sizeof(T) == 2 && P.ldw == 2 && !(P.skip & 1);
     if constexpr (sizeof(T) == 2) { if (xpre) x_issue(); }
 
+    if (p.signMode == 2) {
+        // gradient pass: the tile's sign bits (2 per sample, 16 samples per aligned dword) are staged once, coalesced;
+        // the FIR phases then pick their codes from LDS instead of issuing scattered byte loads
+        const uint32_t* splane = (const uint32_t*)(p.s + (int64_t)p.SWB * p.SH * (int64_t)plane);
+        const int dw0 = (ux0 + p.sofsx) >> 4, rowDw = p.SWB >> 2;
+        const int n = p.TUH * P.nDw;                          // a row = one zero dword (samples -16 .. -1), then the tile's dwords
+        for (int i = tid; i < n; i += NT) {
+            const int ruy = (int)FLR_DIV(i, P.nDw, P.mDw), d = i - ruy * P.nDw - 1;
+            const int sy = uy0 + ruy + p.sofsy, sd = dw0 + d;
+            uint32_t v = 0;
+            if (d >= 0 && (uint32_t)sy < (uint32_t)p.SH && (uint32_t)sd < (uint32_t)rowDw) v = splane[(int64_t)rowDw * sy + sd];
+            sS[i] = v;
+        }
+    }
+
     // ---- filters.  F(k) = f[size-1-k] unless flip.  2-D up taps are stored in the order the polyphase loop consumes them:
     //      sFu[((a*6 + jy)*6 + jx)*2 + b] = F(1-a+2jy, 1-b+2jx) ----
     if (SU == 1) { for (int i = tid; i < FU; i += NT) sFu[i] = p.fu[(p.flip ? i : FU - 1 - i) * p.fus0]; }
@@ -527,26 +542,12 @@ __global__ void __launch_bounds__(NT, 4) flr_rb_kernel(FlrRbParams P) {
 #pragma unroll
             for (int u = 0; u < 8; u++) { const int i = i0 + u * NT; if (i < total) sX[i] = v[u]; }
         }
-        if (p.signMode == 2) {
-            // gradient pass: the tile's sign bits (2 per sample, 16 samples per aligned dword) are staged once, coalesced;
-            // the FIR phases then pick their codes from LDS instead of issuing scattered byte loads
-            const uint32_t* splane = (const uint32_t*)(p.s + (int64_t)p.SWB * p.SH * (int64_t)plane);
-            const int dw0 = (ux0 + p.sofsx) >> 4, rowDw = p.SWB >> 2;
-            const int n = p.TUH * P.nDw;
-            for (int i = tid; i < n; i += NT) {
-                const int ruy = i / P.nDw, d = i - ruy * P.nDw;
-                const int sy = uy0 + ruy + p.sofsy, sd = dw0 + d;
-                uint32_t v = 0;
-                if ((uint32_t)sy < (uint32_t)p.SH && (uint32_t)sd < (uint32_t)rowDw) v = splane[(int64_t)rowDw * sy + sd];
-                sS[i] = v;
-            }
-        }
     }
     __syncthreads();
     const int sxo = (ux0 + p.sofsx) - (((ux0 + p.sofsx) >> 4) << 4);       // sample offset of the tile inside its first sign dword
     auto sign_code = [&](int ruy, int rux) -> uint32_t {                     // 2-bit code of tile sample (ruy, rux), rows outside -> 0
         if ((uint32_t)ruy >= (uint32_t)p.TUH) return 0u;
-        const int pos = sxo + rux;
+        const int pos = sxo + rux + 16;
         return (sS[ruy * P.nDw + (pos >> 4)] >> ((pos & 15) << 1)) & 3u;
     };
 
@@ -752,81 +753,101 @@ __global__ void __launch_bounds__(NT, 4) flr_rb_kernel(FlrRbParams P) {
         // ---- 3'. 2-D up-FIR (UP == 2, 12x12): input column m -> output columns v = 2m, 2m+1; RN input rows per run.
         //      acc[i][a] = (column phase 0, column phase 1) of output row 2(n0+i)+a, updated with packed fp32 FMAs:
         //      (acc.x, acc.y) += (w, w) * (tap of phase 0, tap of phase 1); the taps of step s+1 are fetched during step s ----
-        const int items = (P.skip & 2) ? 0 : P.NR * P.MW;
-        for (int it = tid; it < items; it += NT) {
-            const int run = (int)FLR_DIV(it, P.MW, P.mMW), m = it - run * P.MW;
-            const int n0 = run * RN;
-            const float* src = sX + n0 * P.XP + m;
-            uint32_t scode[2 * RN];                              // per output row: codes of the lane's two columns (bits 0-1, 2-3)
-            if (p.signMode == 2) {
-                const int rx = 2 * m - dx;
+        //      This pass too is bound by the VALU instructions around its FMAs: the sign mode is resolved outside the item loop; in
+        //      the gradient pass a row's two 2-bit codes come out of the staged dwords as one 4-bit field (v_alignbit over the dword
+        //      pair: rows carry a leading zero dword so that column -1 of a tile exists), the multipliers 1 / slope / 0 are picked with
+        //      bit-field masks instead of compares, gain and multiplier are packed multiplies, and a row leaves as one b64 store when
+        //      the tile's column phase is even
+        auto up2d = [&](auto modeTag) {
+            constexpr int MODE = decltype(modeTag)::value;
+            const bool edgeTile = ux0 + p.TUW > p.UW || uy0 + p.TUH > p.UH;
+            const float slope = p.slope, clampv = p.clamp;
+            const int items = (P.skip & 2) ? 0 : P.NR * P.MW;
+            for (int it = tid; it < items; it += NT) {
+                const int run = (int)FLR_DIV(it, P.MW, P.mMW), m = it - run * P.MW;
+                const int n0 = run * RN;
+                const float* src = sX + n0 * P.XP + m;
+                const int rux0 = 2 * m - dx;
+                float w[RN + 5][6];
 #pragma unroll
-                for (int r = 0; r < 2 * RN; r++) {
-                    const int ry = 2 * n0 + r - dy;
-                    scode[r] = (rx >= 0 ? sign_code(ry, rx) : 0u) | (sign_code(ry, rx + 1) << 2);
+                for (int r = 0; r < RN + 5; r++)
+#pragma unroll
+                    for (int q = 0; q < 6; q++) w[r][q] = src[r * P.XP + q];
+                v2f acc[RN][2];
+#pragma unroll
+                for (int i = 0; i < RN; i++) { acc[i][0] = (v2f)(0.f); acc[i][1] = (v2f)(0.f); }
+                v2f t[13][6];
+                {
+                    const float4* tp = (const float4*)sFu;
+#pragma unroll
+                    for (int q = 0; q < 3; q++) { float4 v4 = tp[q]; t[0][2*q] = (v2f){v4.x, v4.y}; t[0][2*q+1] = (v2f){v4.z, v4.w}; }
                 }
-            } else {
 #pragma unroll
-                for (int r = 0; r < 2 * RN; r++) scode[r] = 0;
-            }
-            float w[RN + 5][6];
+                for (int st = 0; st < 12; st++) {
+                    const int a = st / 6, jy = st % 6;
 #pragma unroll
-            for (int r = 0; r < RN + 5; r++)
+                    for (int i = 0; i < RN; i++) FLR_PIN(acc[i][a]);
+                    if (st < 11) {
+                        const float4* tp = (const float4*)(sFu + (st + 1) * 12);
 #pragma unroll
-                for (int q = 0; q < 6; q++) w[r][q] = src[r * P.XP + q];
-            v2f acc[RN][2];
+                        for (int q = 0; q < 3; q++) { float4 v4 = tp[q]; t[st + 1][2*q] = (v2f){v4.x, v4.y}; t[st + 1][2*q+1] = (v2f){v4.z, v4.w}; }
+                    }
 #pragma unroll
-            for (int i = 0; i < RN; i++) { acc[i][0] = (v2f)(0.f); acc[i][1] = (v2f)(0.f); }
-            v2f t[13][6];
-            {
-                const float4* tp = (const float4*)sFu;
+                    for (int i = 0; i < RN; i++)
 #pragma unroll
-                for (int q = 0; q < 3; q++) { float4 v4 = tp[q]; t[0][2*q] = (v2f){v4.x, v4.y}; t[0][2*q+1] = (v2f){v4.z, v4.w}; }
-            }
-#pragma unroll
-            for (int st = 0; st < 12; st++) {
-                const int a = st / 6, jy = st % 6;
-#pragma unroll
-                for (int i = 0; i < RN; i++) FLR_PIN(acc[i][a]);
-                if (st < 11) {
-                    const float4* tp = (const float4*)(sFu + (st + 1) * 12);
-#pragma unroll
-                    for (int q = 0; q < 3; q++) { float4 v4 = tp[q]; t[st + 1][2*q] = (v2f){v4.x, v4.y}; t[st + 1][2*q+1] = (v2f){v4.z, v4.w}; }
+                        for (int jx = 0; jx < 6; jx++) acc[i][a] = __builtin_elementwise_fma((v2f)(w[i + jy][jx]), t[st][jx], acc[i][a]);
                 }
+                uint32_t scode[2 * RN];                          // per output row: codes of the lane's two columns (bits 0-1, 2-3)
+                if (MODE == 2) {
+                    const int pos = sxo + rux0 + 16, sh = (pos & 15) << 1;
+                    const uint32_t* sp = sS + (pos >> 4);
+#pragma unroll
+                    for (int r = 0; r < 2 * RN; r++) {
+                        int ry = 2 * n0 + r - dy;                    // rows outside the tile are not stored: any row's codes will do
+                        ry = min(max(ry, 0), p.TUH - 1);
+                        const uint32_t lo = sp[ry * P.nDw], hi = sp[ry * P.nDw + 1];
+                        scode[r] = __builtin_amdgcn_alignbit(hi, lo, (uint32_t)sh);
+                    }
+                }
+                // store; unless signs are WRITTEN (quads straddle lanes when dx == 1: the separate pass below does it) the activation
+                // is applied here
+                const bool c0ok = rux0 >= 0 && rux0 < p.TUW, c1ok = rux0 + 1 < p.TUW;
+                float* dstc = sU + rux0;
 #pragma unroll
                 for (int i = 0; i < RN; i++)
 #pragma unroll
-                    for (int jx = 0; jx < 6; jx++) acc[i][a] = __builtin_elementwise_fma((v2f)(w[i + jy][jx]), t[st][jx], acc[i][a]);
-            }
-            // store; unless signs are WRITTEN (quads straddle lanes when dx == 1: the separate pass below does it) the activation
-            // is applied here, the sign codes of the gradient pass having been fetched before the FIR math
-#pragma unroll
-            for (int i = 0; i < RN; i++)
-#pragma unroll
-                for (int a = 0; a < 2; a++) {
-                    const int ruy = 2 * (n0 + i) + a - dy;
-                    if (ruy < 0 || ruy >= p.TUH) continue;
-                    const int rux0 = 2 * m - dx;
-                    const int uy = uy0 + ruy;
-                    float v0 = acc[i][a].x * upGain, v1 = acc[i][a].y * upGain;
-                    if (p.signMode != 1) {                       // uniform branches; selects only inside
-                        const uint32_t sc = scode[2 * i + a];
-                        if (p.signMode == 2) {
-                            float m0 = (sc & 1) ? p.slope : 1.f, m1 = (sc & 4) ? p.slope : 1.f;
-                            m0 = (sc & 2) ? 0.f : m0; m1 = (sc & 8) ? 0.f : m1;
-                            v0 *= m0; v1 *= m1;
-                        } else {
-                            v0 *= v0 < 0.f ? p.slope : 1.f; v1 *= v1 < 0.f ? p.slope : 1.f;
-                            v0 = __builtin_amdgcn_fmed3f(v0, -p.clamp, p.clamp); v1 = __builtin_amdgcn_fmed3f(v1, -p.clamp, p.clamp);
+                    for (int a = 0; a < 2; a++) {
+                        const int ruy = 2 * (n0 + i) + a - dy;
+                        v2f v = acc[i][a] * (v2f)(upGain);
+                        if (MODE == 2) {
+                            const uint32_t sc = scode[2 * i + a];
+                            // bit-field masks (0 / ~0) of the four code bits; multiplier = bit1 ? 0 : (bit0 ? slope : 1)
+                            const uint32_t s0 = (uint32_t)__builtin_amdgcn_sbfe((int)sc, 0, 1), z0 = (uint32_t)__builtin_amdgcn_sbfe((int)sc, 1, 1);
+                            const uint32_t s1 = (uint32_t)__builtin_amdgcn_sbfe((int)sc, 2, 1), z1 = (uint32_t)__builtin_amdgcn_sbfe((int)sc, 3, 1);
+                            const uint32_t one = __float_as_uint(1.f), sl = __float_as_uint(slope);
+                            const float m0 = __uint_as_float(((s0 & sl) | (~s0 & one)) & ~z0);
+                            const float m1 = __uint_as_float(((s1 & sl) | (~s1 & one)) & ~z1);
+                            v = v * (v2f){m0, m1};
+                        } else if (MODE == 0) {
+                            v = v * (v2f){v.x < 0.f ? slope : 1.f, v.y < 0.f ? slope : 1.f};
+                            v.x = __builtin_amdgcn_fmed3f(v.x, -clampv, clampv); v.y = __builtin_amdgcn_fmed3f(v.y, -clampv, clampv);
                         }
-                        const bool rowin = uy < p.UH;
-                        v0 = (rowin && ux0 + rux0 < p.UW) ? v0 : 0.f;
-                        v1 = (rowin && ux0 + rux0 + 1 < p.UW) ? v1 : 0.f;
+                        if (MODE != 1 && edgeTile) {             // uniform
+                            const bool rowin = uy0 + ruy < p.UH;
+                            v.x = (rowin && ux0 + rux0 < p.UW) ? v.x : 0.f;
+                            v.y = (rowin && ux0 + rux0 + 1 < p.UW) ? v.y : 0.f;
+                        }
+                        if ((uint32_t)ruy < (uint32_t)p.TUH) {
+                            float* dst = dstc + ruy * P.UPC;
+                            if (dx == 0) { if (c0ok) *(v2f*)dst = v; }          // uniform; TUW is even: both columns or neither
+                            else { if (c0ok) dst[0] = v.x; if (c1ok) dst[1] = v.y; }
+                        }
                     }
-                    if (rux0 >= 0 && rux0 < p.TUW) sU[ruy * P.UPC + rux0] = v0;
-                    if (rux0 + 1 >= 0 && rux0 + 1 < p.TUW) sU[ruy * P.UPC + rux0 + 1] = v1;
-                }
-        }
+            }
+        };
+        if (p.signMode == 2) up2d(std::integral_constant<int, 2>{});
+        else if (p.signMode == 1) up2d(std::integral_constant<int, 1>{});
+        else up2d(std::integral_constant<int, 0>{});
     }
     __syncthreads();
 
@@ -1071,7 +1092,7 @@ static bool flr_rb_launch(FlrParams p, hipStream_t st, int* status) {
         } else {
             P.ofsX = szU; P.ofsH = 0; szR2 = szX > szV ? szX : szV; P.ofsV = szU;
         }
-        P.nDw = (p.TUW + 15 + 15) / 16 + 1;
+        P.nDw = (p.TUW + 15 + 15) / 16 + 2;
         const int szS = p.signMode == 2 ? p.TUH * P.nDw : 0;
         P.ofsS = szU + szR2;
         const size_t fl = (size_t)(SU == 1 ? FU : FU * FU) + (size_t)(SD == 1 ? FD : FD * FD) + szU + szR2 + szS;
@@ -1088,7 +1109,7 @@ static bool flr_rb_launch(FlrParams p, hipStream_t st, int* status) {
     P.b = p;
     P.mG = flr_magic(SU == 1 ? P.TVWa >> 3 : 1); P.mTUW = flr_magic(p.TUW); P.mMW = flr_magic(P.MW ? P.MW : 1);
     P.mQ4 = flr_magic(P.UPC >> 2); P.mTOW = flr_magic(p.TOW); P.mXP = flr_magic(P.XP);
-    P.mHW = flr_magic(p.TOW >> 1);
+    P.mHW = flr_magic(p.TOW >> 1); P.mDw = flr_magic(P.nDw);
     P.sdw = sizeof(T) == 2 && p.ys[3] == 1 && !(p.ys[2] & 1) && !(p.ys[1] & 1) && !(p.ys[0] & 1) && !((uintptr_t)p.y & 3);
     P.NW = (P.XP >> 1) + 1; P.dRy = NT / P.NW; P.dW = NT - P.dRy * P.NW; P.mNW = flr_magic(P.NW);
     P.ldw = sizeof(T) == 2 && p.xs[3] == 1 && !(p.xs[2] & 1) && !(p.xs[1] & 1) && !(p.xs[0] & 1) && !(p.XW & 1) && !((uintptr_t)p.x & 3)
