@@ -408,7 +408,8 @@ struct FlrRbParams {
     int NW, dRy, dW;                 // dwords per tile row (XP / 2 + 1); the step of (row, dword) when a lane moves on by NT items
     uint32_t mNW, mHW, mDw;               // ... by NW, TOW / 2
     int sdw;                         // 16-bit y whose rows start on dwords: the two columns of a lane leave as one dword
-    int skip;                        // profiling only (AGF_FLR_SKIP bit mask: 1 load, 2 up-FIR, 4 act, 8 down-FIR): phases left out, results wrong
+    int skip;                        // profiling builds only (-DAGF_PROFILE_PHASES=<mask>: 1 load, 2 up-FIR, 4 act, 8 down-FIR, 16 filter taps,
+                                     // 32 sign staging, 64 sum of y): phases left out, results wrong
 };
 
 // Scheduling fence: the value must be materialised here, and no memory access moves across.  Without tying the accumulators
@@ -476,7 +477,7 @@ __global__ void __launch_bounds__(NT, 4) flr_rb_kernel(FlrRbParams P) {
     const bool xpre = sizeof(T) == 2 && P.ldw == 2 && !(P.skip & 1);
     if constexpr (sizeof(T) == 2) { if (xpre) x_issue(); }
 
-    if (p.signMode == 2) {
+    if (p.signMode == 2 && !(P.skip & 32)) {
         // gradient pass: the tile's sign bits (2 per sample, 16 samples per aligned dword) are staged once, coalesced;
         // the FIR phases then pick their codes from LDS instead of issuing scattered byte loads
         const uint32_t* splane = (const uint32_t*)(p.s + (int64_t)p.SWB * p.SH * (int64_t)plane);
@@ -493,6 +494,7 @@ __global__ void __launch_bounds__(NT, 4) flr_rb_kernel(FlrRbParams P) {
 
     // ---- filters.  F(k) = f[size-1-k] unless flip.  2-D up taps are stored in the order the polyphase loop consumes them:
     //      sFu[((a*6 + jy)*6 + jx)*2 + b] = F(1-a+2jy, 1-b+2jx) ----
+    if (!(P.skip & 16)) {
     if (SU == 1) { for (int i = tid; i < FU; i += NT) sFu[i] = p.fu[(p.flip ? i : FU - 1 - i) * p.fus0]; }
     else {
         for (int i = tid; i < FU * FU; i += NT) {
@@ -504,6 +506,7 @@ __global__ void __launch_bounds__(NT, 4) flr_rb_kernel(FlrRbParams P) {
     if (SD == 1) { for (int i = tid; i < FD; i += NT) sFd[i] = p.fd[(p.flip ? i : FD - 1 - i) * p.fds0]; }
     else { for (int i = tid; i < FD * FD; i += NT) { int ky = i / FD, kx = i - ky * FD;
             sFd[i] = p.fd[(p.flip ? ky : FD - 1 - ky) * p.fds0 + (p.flip ? kx : FD - 1 - kx) * p.fds1]; } }
+    }
 
     // ---- 1. input tile + bias (zero outside the image).  Independent loads in flight per lane: with two workgroups per
     //      CU a load -> wait -> store loop would leave the phase bound by one HBM latency per row ----
@@ -1035,7 +1038,7 @@ __global__ void __launch_bounds__(NT, 4) flr_rb_kernel(FlrRbParams P) {
             }
         }
     }
-    if (p.ysum) flr_block_sum_to<NT>(ysum_local, p.ysum + c, flr_smem);
+    if (p.ysum && !(P.skip & 64)) flr_block_sum_to<NT>(ysum_local, p.ysum + c, flr_smem);
 }
 
 // host side: tile geometry + launch of the register-blocked kernel; returns false when the configuration is not one of its
@@ -1144,8 +1147,10 @@ static bool flr_rb_dispatch_nt(const FlrParams& p, hipStream_t st, int* status) 
 
 template <class T>
 static bool flr_rb_dispatch(const FlrParams& p, hipStream_t st, int* status) {
-    constexpr int nt = 512;
-    return nt == 512 ? flr_rb_dispatch_nt<T, 512>(p, st, status) : flr_rb_dispatch_nt<T, 256>(p, st, status);
+    // 512 threads, two workgroups per CU.  Measured slower: 256 x 4, 512 x 3 with smaller tiles (halo), 1024 x 1 with 150 KB tiles;
+    // several tiles per workgroup (the ~120 scalar parameters then live around the tile loop and spill into vector registers; as a
+    // non-inlined call per tile the kernel ran 2.2x slower)
+    return flr_rb_dispatch_nt<T, 512>(p, st, status);
 }
 
 extern "C" int agf_filtered_lrelu(const void* x, const float* fu, const float* fd, const void* b, uint8_t* s, void* y, int dtype,
