@@ -406,7 +406,7 @@ struct FlrRbParams {
     uint32_t mG, mTUW, mMW, mQ4, mTOW, mXP;   // magic numbers for division by nG, TUW, MW, UPC/4, TOW, XP
     int ldw;                         // 16-bit x whose rows start on dwords: the tile is fetched as dwords (two samples per load)
     int NW, dRy, dW;                 // dwords per tile row (XP / 2 + 1); the step of (row, dword) when a lane moves on by NT items
-    uint32_t mNW, mHW, mDw;               // ... by NW, TOW / 2
+    uint32_t mNW, mHW, mDw, mHU;     // ... by NW, TOW / 2, nDw, TUW / 2
     int sdw;                         // 16-bit y whose rows start on dwords: the two columns of a lane leave as one dword
     int skip;                        // profiling builds only (-DAGF_PROFILE_PHASES=<mask>: 1 load, 2 up-FIR, 4 act, 8 down-FIR, 16 filter taps,
                                      // 32 sign staging, 64 sum of y): phases left out, results wrong
@@ -988,53 +988,66 @@ __global__ void __launch_bounds__(NT, 4) flr_rb_kernel(FlrRbParams P) {
             }
         }
     } else {
-        // ---- 4'. separable down-FIR: vertical (lane = column, strip of RD rows), then horizontal ----
+        // ---- 4'. separable down-FIR: vertical (lane = TWO adjacent columns, strip of RD rows: b64 reads, packed FMAs), then
+        //      horizontal (lane = two adjacent outputs: the row window as b128 reads, (even tap, odd tap) sums in the two halves
+        //      of packed FMAs) ----
         constexpr int RD = DOWN == 2 ? 8 : 4;
-        float fd[FD];
+        v2f fdp[FD / 2];                                            // (tap 2q, tap 2q + 1)
 #pragma unroll
-        for (int k = 0; k < FD; k++) fd[k] = sFd[k];
+        for (int q = 0; q < FD / 2; q++) fdp[q] = *(const v2f*)(sFd + 2 * q);
         {
             const int strips = p.TOH / RD;
-            const int items = (P.skip & 8) ? 0 : strips * p.TUW;
+            const int halfU = p.TUW >> 1;                           // TUW is even
+            const int items = (P.skip & 8) ? 0 : strips * halfU;
             for (int it = tid; it < items; it += NT) {
-                const int strip = (int)FLR_DIV(it, p.TUW, P.mTUW), rux = it - strip * p.TUW;
-                const float* src = sU + (strip * RD * DOWN) * P.UPC + rux;
-                float acc[RD];
+                const int strip = (int)FLR_DIV(it, halfU, P.mHU), c2 = it - strip * halfU;
+                const float* src = sU + (strip * RD * DOWN) * P.UPC + 2 * c2;
+                v2f acc[RD];
 #pragma unroll
-                for (int o = 0; o < RD; o++) acc[o] = 0.f;
+                for (int o = 0; o < RD; o++) acc[o] = (v2f)(0.f);
                 constexpr int NROWS = DOWN * (RD - 1) + FD;
 #pragma unroll
                 for (int r = 0; r < NROWS; r++) {
-                    const float u = src[r * P.UPC];
+                    const v2f u = *(const v2f*)(src + r * P.UPC);
 #pragma unroll
                     for (int o = 0; o < RD; o++) {
                         const int k = r - DOWN * o;
-                        if (k >= 0 && k < FD) acc[o] = fmaf(u, fd[k], acc[o]);
+                        if (k >= 0 && k < FD) acc[o] = __builtin_elementwise_fma(u, (v2f)((k & 1) ? fdp[k >> 1].y : fdp[k >> 1].x), acc[o]);
                     }
                 }
 #pragma unroll
-                for (int o = 0; o < RD; o++) sV[(strip * RD + o) * P.UPC + rux] = acc[o];
+                for (int o = 0; o < RD; o++) *(v2f*)(sV + (strip * RD + o) * P.UPC + 2 * c2) = acc[o];
             }
         }
         __syncthreads();
         {
-            const int items = (P.skip & 8) ? 0 : p.TOH * p.TOW;
+            const int halfW = p.TOW >> 1;
+            const int items = (P.skip & 8) ? 0 : p.TOH * halfW;
             for (int it = tid; it < items; it += NT) {
-                const int roy = (int)FLR_DIV(it, p.TOW, P.mTOW), rox = it - roy * p.TOW;
-                const int oy = oy0 + roy, ox = ox0 + rox;
+                const int roy = (int)FLR_DIV(it, halfW, P.mHW), cx = it - roy * halfW;
+                const int oy = oy0 + roy, ox = ox0 + 2 * cx;
                 if (oy >= p.YH || ox >= p.YW) continue;
-                const float* src = sV + roy * P.UPC + DOWN * rox;
-                float a = 0.f;
-                if (DOWN == 2) {
+                const float4* src = (const float4*)(sV + roy * P.UPC + 2 * DOWN * cx);     // 16-byte aligned: UPC % 4 == 0
+                constexpr int NP = (FD + DOWN) / 2;                 // pairs of the window of two outputs
+                v2f w[NP + 1];
 #pragma unroll
-                    for (int q = 0; q < 6; q++) { float2 t = *(const float2*)(src + 2 * q); a = fmaf(t.x, fd[2*q], a); a = fmaf(t.y, fd[2*q+1], a); }
-                } else {
+                for (int q = 0; q < (NP + 1) / 2; q++) { const float4 t4 = src[q]; w[2 * q] = (v2f){t4.x, t4.y}; w[2 * q + 1] = (v2f){t4.z, t4.w}; }
+                v2f a0 = (v2f)(0.f), a1 = (v2f)(0.f);
 #pragma unroll
-                    for (int q = 0; q < 6; q++) { float4 t = *(const float4*)(src + 4 * q);
-                        a = fmaf(t.x, fd[4*q], a); a = fmaf(t.y, fd[4*q+1], a); a = fmaf(t.z, fd[4*q+2], a); a = fmaf(t.w, fd[4*q+3], a); }
+                for (int q = 0; q < FD / 2; q++) {
+                    a0 = __builtin_elementwise_fma(w[q], fdp[q], a0);
+                    a1 = __builtin_elementwise_fma(w[q + DOWN / 2], fdp[q], a1);
                 }
-                Elem<T>::store(yb + oy * p.ys[2] + ox * p.ys[3], a);
-                ysum_local += a;
+                const float r0 = a0.x + a0.y, r1 = a1.x + a1.y;
+                T* dst = yb + oy * p.ys[2] + ox * p.ys[3];
+                bool packed = false;
+                if constexpr (sizeof(T) == 2) {
+                    if (P.sdw && ox + 1 < p.YW) { *(uint32_t*)dst = Pack16<T>::pack(r0, r1); ysum_local += r0 + r1; packed = true; }
+                }
+                if (!packed) {
+                    Elem<T>::store(dst, r0); ysum_local += r0;
+                    if (ox + 1 < p.YW) { Elem<T>::store(dst + p.ys[3], r1); ysum_local += r1; }
+                }
             }
         }
     }
@@ -1112,7 +1125,7 @@ static bool flr_rb_launch(FlrParams p, hipStream_t st, int* status) {
     P.b = p;
     P.mG = flr_magic(SU == 1 ? P.TVWa >> 3 : 1); P.mTUW = flr_magic(p.TUW); P.mMW = flr_magic(P.MW ? P.MW : 1);
     P.mQ4 = flr_magic(P.UPC >> 2); P.mTOW = flr_magic(p.TOW); P.mXP = flr_magic(P.XP);
-    P.mHW = flr_magic(p.TOW >> 1); P.mDw = flr_magic(P.nDw);
+    P.mHW = flr_magic(p.TOW >> 1); P.mDw = flr_magic(P.nDw); P.mHU = flr_magic(p.TUW >> 1);
     P.sdw = sizeof(T) == 2 && p.ys[3] == 1 && !(p.ys[2] & 1) && !(p.ys[1] & 1) && !(p.ys[0] & 1) && !((uintptr_t)p.y & 3);
     P.NW = (P.XP >> 1) + 1; P.dRy = NT / P.NW; P.dW = NT - P.dRy * P.NW; P.mNW = flr_magic(P.NW);
     P.ldw = sizeof(T) == 2 && p.xs[3] == 1 && !(p.xs[2] & 1) && !(p.xs[1] & 1) && !(p.xs[0] & 1) && !(p.XW & 1) && !((uintptr_t)p.x & 3)
