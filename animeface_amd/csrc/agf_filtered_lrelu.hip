@@ -1160,9 +1160,11 @@ static bool flr_rb_dispatch_nt(const FlrParams& p, hipStream_t st, int* status) 
 
 template <class T>
 static bool flr_rb_dispatch(const FlrParams& p, hipStream_t st, int* status) {
-    // 512 threads, two workgroups per CU.  Measured slower: 256 x 4, 512 x 3 with smaller tiles (halo), 1024 x 1 with 150 KB tiles;
-    // several tiles per workgroup (the ~120 scalar parameters then live around the tile loop and spill into vector registers; as a
-    // non-inlined call per tile the kernel ran 2.2x slower)
+    // 512 threads, two workgroups per CU.  Measured slower: 256 x 4, 512 x 3 with smaller tiles (halo), 1024 x 1 with 150 KB tiles.
+    // Several tiles per workgroup do not pay either, although an empty workgroup of this size costs ~1.6 us: inlined, the ~120 scalar
+    // parameters live around the tile loop and spill into vector registers (5-12 % slower, even with the next tile's loads issued
+    // under the decimation); read through a per-phase opaque pointer they do not spill, and 1 .. 4 tiles per workgroup are all 6-8 %
+    // slower than one -- the CU's other workgroup already covers the turnaround; as a non-inlined call per tile 2.2x slower
     return flr_rb_dispatch_nt<T, 512>(p, st, status);
 }
 
