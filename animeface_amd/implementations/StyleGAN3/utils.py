@@ -20,6 +20,7 @@ from ...nnutils.loss import NonSaturatingLoss, r1_regularizer
 from ...thirdparty.diffaugment import DiffAugment
 from ... import distributed as dp
 from .model import Generator, Discriminator
+from ..StyleGAN2.conv import cached_weights, invalidate_cached, PrepPlan, recording_plans
 
 
 class TrainStep:
@@ -34,6 +35,9 @@ class TrainStep:
         self.adv_fn = NonSaturatingLoss()
         self.gp_fn = r1_regularizer()
         self.batches_done = 0
+        # prepared conv weights (bf16 OHWI copies in both orientations) live for one iteration and are made by one launch per network
+        # from the second iteration on, as in StyleGAN2.utils.TrainStep (136 preparation launches per iteration without)
+        self._plan_G, self._plan_D = PrepPlan(G.parameters()), PrepPlan(D.parameters())
 
     def _mbsd_group_size(self):
         from .model import MinibatchStdDev
@@ -50,6 +54,14 @@ class TrainStep:
             opt.zero_grad(set_to_none=True)
 
     def __call__(self, real):
+        with cached_weights(), recording_plans(self._plan_G, self._plan_D):
+            self._plan_G.run()
+            self._plan_D.run()
+            out = self._iteration(real)
+        self._plan_G.build(), self._plan_D.build()              # no-ops after the first iteration
+        return out
+
+    def _iteration(self, real):
         G, D = self.G, self.D
         self._zero(self.optimizer_D, self.reducer_D)
         self._zero(self.optimizer_G, self.reducer_G)
@@ -75,6 +87,8 @@ class TrainStep:
         if self.reducer_D is not None:
             self.reducer_D.finish()
         self.optimizer_D.step()
+        invalidate_cached(D.parameters())
+        self._plan_D.run()
 
         for p in D.parameters():
             p.requires_grad_(False)

@@ -347,7 +347,7 @@ def test_full_size_step_properties():
     b = run()
     assert all(abs(x) < 1e4 for pair in a for x in pair), a
     for (d0, g0), (d1, g1) in zip(a, b):
-        assert d0 == pytest.approx(d1, rel=2e-3, abs=1e-5) and g0 == pytest.approx(g1, rel=2e-3, abs=1e-5), (a, b)
+        assert d0 == pytest.approx(d1, rel=2e-3, abs=1e-5) and g0 == pytest.approx(g1, rel=5e-3, abs=1e-4), (a, b)
 
 
 @pytest.mark.parametrize('dtype,d_k,iters', [(torch.float32, 2, 6), (torch.bfloat16, 2, 6), (torch.float32, 4, 15)],
