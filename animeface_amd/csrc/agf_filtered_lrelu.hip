@@ -409,7 +409,7 @@ struct FlrRbParams {
     uint32_t mNW, mHW, mDw, mHU;     // ... by NW, TOW / 2, nDw, TUW / 2
     int sdw;                         // 16-bit y whose rows start on dwords: the two columns of a lane leave as one dword
     int skip;                        // profiling builds only (-DAGF_PROFILE_PHASES=<mask>: 1 load, 2 up-FIR, 4 act, 8 down-FIR, 16 filter taps,
-                                     // 32 sign staging, 64 sum of y): phases left out, results wrong
+                                     // 32 sign staging, 64 sum of y, 128 horizontal / 256 vertical pass of the separable interpolation): phases left out, results wrong
 };
 
 // Scheduling fence: the value must be materialised here, and no memory access moves across.  Without tying the accumulators
@@ -562,7 +562,7 @@ __global__ void __launch_bounds__(NT, 4) flr_rb_kernel(FlrRbParams P) {
         // ---- 2. horizontal up-FIR: sH[ry][v], v = 8g .. 8g+7 ----
         {
             const int nG = P.TVWa >> 3;
-            const int items = (P.skip & 2) ? 0 : p.TXH * nG;
+            const int items = (P.skip & (2 | 128)) ? 0 : p.TXH * nG;
             for (int it = tid; it < items; it += NT) {
                 const int ry = (int)FLR_DIV(it, nG, P.mG), g = it - ry * nG;
                 constexpr int NIN = UP == 2 ? 12 : 8;
@@ -604,7 +604,7 @@ __global__ void __launch_bounds__(NT, 4) flr_rb_kernel(FlrRbParams P) {
             const int coreW = (tx == p.tilesX - 1) ? p.TUW : p.TOW * DOWN;
             const int coreH = (ty == p.tilesY - 1) ? p.TUH : p.TOH * DOWN;
             const bool edgeTile = ux0 + p.TUW > p.UW || uy0 + p.TUH > p.UH;
-            const int items = (P.skip & 2) ? 0 : P.runsV * P.UPC;
+            const int items = (P.skip & (2 | 256)) ? 0 : P.runsV * P.UPC;
             const int q4 = P.UPC >> 2;
             const float slope = p.slope, clampv = p.clamp;
             for (int it = tid; it < items; it += NT) {
@@ -688,7 +688,7 @@ __global__ void __launch_bounds__(NT, 4) flr_rb_kernel(FlrRbParams P) {
             const int coreH = (ty == p.tilesY - 1) ? p.TUH : p.TOH * DOWN;
             const bool edgeTile = ux0 + p.TUW > p.UW || uy0 + p.TUH > p.UH;
             const int half = P.UPC >> 1, q4 = P.UPC >> 2;
-            const int items = (P.skip & 2) ? 0 : (P.runsV * 8 / RV) * half;
+            const int items = (P.skip & (2 | 256)) ? 0 : (P.runsV * 8 / RV) * half;
             const float slope = p.slope, clampv = p.clamp;
             uint8_t* splane = p.s + (int64_t)p.SWB * p.SH * plane64;
             for (int it = tid; it < items; it += NT) {
