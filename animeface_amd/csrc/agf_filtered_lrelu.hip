@@ -383,15 +383,22 @@ __global__ void __launch_bounds__(256) filtered_lrelu_kernel(FlrParams p0) {
 //
 // The kernel above spends two LDS reads (one sample, one tap) per FMA and is bound by LDS issue at ~5 % of the fp32 VALU
 // peak.  Here every phase keeps a window of samples in registers and loads a row of taps once for many FMAs:
+//   1  input tile          : 16-bit x with even width / pitch as aligned dwords (two samples per load, issued before the filter taps)
 //   2  horizontal up-FIR   : one lane = 8 consecutive up-resolution columns of one input row (12 / 8 inputs as b128 / b64
 //                            reads, 48 FMAs, taps in registers)
-//   3  vertical up-FIR     : one lane = one column, a run of 8 rows (9 / 7 b32 reads, 48 FMAs)
+//   3  vertical up-FIR     : one lane = TWO adjacent columns, a run of FLR_RV rows, packed fp32 FMAs; gain / leaky ReLU / clamp and the
+//      + activation          2-bit sign codes on the values while they are in registers (sign mode = template argument of the pass;
+//                            a lane pair assembles the sign bytes of its rows once per item); the gradient pass with a separable
+//                            up filter (sign read) still runs one column x 8 rows per lane
 //   3' 2-D (radial) up-FIR : one lane = one input column (two output columns), a run of RN input rows; a (RN+5) x 6
-//                            input window in registers; the 12 taps of one (row phase, tap row) serve 12*RN FMAs
-//   act                    : gain / leaky ReLU / clamp with sign write or sign read, in place on the LDS tile (float4)
-//   4  2-D (radial) down   : one lane = one output column, a strip of R4 output rows; sliding window of R4 rows x 12
-//                            samples (conflict-free b64 reads), the 12 taps of one tap row serve 12*R4 FMAs
-//   4' separable down      : vertical pass (lane = column, strip of R rows, taps in registers), then horizontal pass
+//                            input window in registers; the 12 taps of one (row phase, tap row) serve 12*RN FMAs; sign codes of
+//                            the gradient pass as one 4-bit field per row (v_alignbit over staged dwords), bit-mask multipliers
+//   act                    : separate in-place pass only for the 2-D up filter with sign WRITE
+//   4  2-D (radial) down   : one lane = two adjacent output columns, a strip of R4 output rows; sliding window of rows x 14
+//                            samples (three b128 + one b64 per row), the 12 taps of one tap row serve 2*12*R4 FMAs
+//   4' separable down      : vertical pass (lane = two columns, strip of RD rows, b64 reads), then horizontal pass (lane = two
+//                            outputs, b128 window reads), packed FMAs, paired stores
+// What bounded what, and what was tried and dropped: DESIGN.md section 3.4.
 // Up-resolution samples are computed on the lattice aligned to the input samples ("v" coordinates: v = tile coordinate +
 // d, d = phase of the tile origin), which makes every polyphase tap index a compile-time constant; results are stored
 // in tile coordinates so that the decimating reads stay 8-byte aligned.
@@ -578,7 +585,6 @@ __global__ void __launch_bounds__(NT, 4) flr_rb_kernel(FlrRbParams P) {
                 float o[8];
 #pragma unroll
                 for (int e = 0; e < 8; e++) {
-                    constexpr int dummy = 0; (void)dummy;
                     const int k0 = UP - 1 - (e % UP), b0 = e / UP;
                     float a = 0.f;
 #pragma unroll
