@@ -555,11 +555,6 @@ __global__ void __launch_bounds__(NT, 4) flr_rb_kernel(FlrRbParams P) {
     }
     __syncthreads();
     const int sxo = (ux0 + p.sofsx) - (((ux0 + p.sofsx) >> 4) << 4);       // sample offset of the tile inside its first sign dword
-    auto sign_code = [&](int ruy, int rux) -> uint32_t {                     // 2-bit code of tile sample (ruy, rux), rows outside -> 0
-        if ((uint32_t)ruy >= (uint32_t)p.TUH) return 0u;
-        const int pos = sxo + rux + 16;
-        return (sS[ruy * P.nDw + (pos >> 4)] >> ((pos & 15) << 1)) & 3u;
-    };
 
     const float upGain = (float)(UP * UP) * p.gain;
     if (SU == 1) {
@@ -597,95 +592,14 @@ __global__ void __launch_bounds__(NT, 4) flr_rb_kernel(FlrRbParams P) {
             }
         }
         __syncthreads();
-        // ---- 3. vertical up-FIR + activation: column rux (v = rux + dx), rows vy = 8s .. 8s+7 -> sU[vy - dy][rux].
+        // ---- 3. vertical up-FIR + activation: columns (rux, rux + 1) (v = rux + dx), rows vy = RV s .. RV s + RV - 1 -> sU[vy - dy][rux].
         //      The up-resolution values are in registers here, so gain / leaky ReLU / clamp and the sign bits are applied before
-        //      the store: no separate pass over sU.  This pass is VALU-issue-bound (PMC: VALU busy 100 %), and what it issues is
+        //      the store: no separate pass over sU.  This pass is VALU-issue-bound (PMC: VALU busy 100 %), and what it issued was
         //      mostly not the 6 FMAs of a sample: so the sign mode is resolved outside the item loop, samples beyond the logical
-        //      image are masked only in tiles that reach it, a lane keeps the 2-bit codes of its 8 rows in one register and the
-        //      quad (lanes 4q .. 4q+3 = the four samples of a sign byte; columns are padded to a multiple of 4 so that
-        //      lane & 3 == rux & 3) transposes them once per item: lane l then stores the bytes of rows l and l + 4 ----
-        auto vert = [&](auto modeTag) {
-            constexpr int MODE = decltype(modeTag)::value;
-            const int64_t plane64 = (int64_t)plane;
-            const int coreW = (tx == p.tilesX - 1) ? p.TUW : p.TOW * DOWN;
-            const int coreH = (ty == p.tilesY - 1) ? p.TUH : p.TOH * DOWN;
-            const bool edgeTile = ux0 + p.TUW > p.UW || uy0 + p.TUH > p.UH;
-            const int items = (P.skip & (2 | 256)) ? 0 : P.runsV * P.UPC;
-            const int q4 = P.UPC >> 2;
-            const float slope = p.slope, clampv = p.clamp;
-            for (int it = tid; it < items; it += NT) {
-                const int sr = (int)FLR_DIV(it >> 2, q4, P.mQ4), rux = it - sr * P.UPC;
-                const bool colok = rux < p.TUW;
-                const int ux = ux0 + rux;
-                constexpr int NROW = UP == 2 ? 9 : 7;
-                const float* src = sH + (UP == 2 ? 4 * sr : 2 * sr) * P.HP + (colok ? rux : 0) + dx;
-                const int ruy0 = 8 * sr - dy;
-                uint32_t scode[8];
-                if (MODE == 2) {
-#pragma unroll
-                    for (int e = 0; e < 8; e++) scode[e] = colok ? sign_code(ruy0 + e, rux) : 0u;
-                }
-                float h[NROW];
-#pragma unroll
-                for (int j = 0; j < NROW; j++) h[j] = src[j * P.HP];
-                const uint32_t rowLimit = colok ? (uint32_t)p.TUH : 0u;     // rows this lane stores: 0 <= ruy < rowLimit
-                const bool colin = colok && ux < p.UW;
-                float* dst = sU + ruy0 * P.UPC + rux;
-                uint32_t codes = 0;                                         // 2 bits per row
-#pragma unroll
-                for (int e = 0; e < 8; e++) {
-                    const int k0 = UP - 1 - (e % UP), b0 = e / UP;
-                    float a = 0.f;
-#pragma unroll
-                    for (int j = 0; j < 6; j++) a = fmaf(h[b0 + j], fu[k0 + j * UP], a);
-                    float v = a * upGain;
-                    uint32_t code = 0;
-                    if (MODE == 2) {
-                        float mul = (scode[e] & 1) ? slope : 1.f;
-                        mul = (scode[e] & 2) ? 0.f : mul;
-                        v *= mul;
-                    } else {
-                        const bool neg = v < 0.f;
-                        v *= neg ? slope : 1.f;
-                        const bool cl = fabsf(v) > clampv;
-                        v = __builtin_amdgcn_fmed3f(v, -clampv, clampv);
-                        if (MODE == 1) code = cl ? (2u << (2 * e)) : (neg ? (1u << (2 * e)) : 0u);
-                    }
-                    if (edgeTile) {                              // uniform
-                        const bool inimg = colin && uy0 + ruy0 + e < p.UH;
-                        v = inimg ? v : 0.f;
-                        code = inimg ? code : 0u;
-                    }
-                    codes |= code;
-                    if ((uint32_t)(ruy0 + e) < rowLimit) dst[e * P.UPC] = v;
-                }
-                if (MODE == 1) {
-                    codes = colok ? codes : 0u;                  // padding columns of the tile carry no sample
-                    // quad transpose: A[m] = codes of lane m of the quad; byte of row r = sum over m of (A[m] >> 2r & 3) << 2m
-                    const int l = rux & 3;
-                    uint32_t A[4];
-                    A[0] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)codes, 0x00, 0xF, 0xF, true);   // quad_perm [0,0,0,0]
-                    A[1] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)codes, 0x55, 0xF, 0xF, true);   // [1,1,1,1]
-                    A[2] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)codes, 0xAA, 0xF, 0xF, true);   // [2,2,2,2]
-                    A[3] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)codes, 0xFF, 0xF, 0xF, true);   // [3,3,3,3]
-                    uint32_t b0 = 0, b1 = 0;
-#pragma unroll
-                    for (int m = 0; m < 4; m++) {
-                        b0 |= __builtin_amdgcn_ubfe(A[m], (uint32_t)(2 * l), 2u) << (2 * m);
-                        b1 |= __builtin_amdgcn_ubfe(A[m], (uint32_t)(2 * l + 8), 2u) << (2 * m);
-                    }
-                    const int qx = rux - l, sx = (ux0 + qx) >> 2;
-                    if (qx < coreW && sx < p.SWB) {
-                        const int r0 = ruy0 + l, r1 = r0 + 4;
-                        uint8_t* sp = p.s + sx + (int64_t)p.SWB * (uy0 + (int64_t)p.SH * plane64);
-                        if ((uint32_t)r0 < (uint32_t)coreH && uy0 + r0 < p.SH) sp[(int64_t)p.SWB * r0] = (uint8_t)b0;
-                        if ((uint32_t)r1 < (uint32_t)coreH && uy0 + r1 < p.SH) sp[(int64_t)p.SWB * r1] = (uint8_t)b1;
-                    }
-                }
-            }
-        };
-        // The same pass with TWO adjacent columns per lane (sign modes 0 and 1): the FIR, the gain and the slope become packed fp32
-        // instructions (one per two samples), a row leaves as one b64 store, and a sign byte is the nibbles of two lanes.
+        //      image are masked only in tiles that reach it, the FIR, the gain and the slope are packed fp32 instructions on two
+        //      adjacent columns, a row leaves as one b64 store, a lane keeps the codes of its rows in one register and a lane PAIR
+        //      (= the four columns of a sign byte) exchanges them once per item; the gradient pass reads a row's two codes as one
+        //      4-bit field of the staged sign dwords ----
         auto vert2 = [&](auto modeTag) {
             constexpr int MODE = decltype(modeTag)::value;
             constexpr int RV = FLR_RV;                                      // rows per item
@@ -710,6 +624,8 @@ __global__ void __launch_bounds__(NT, 4) flr_rb_kernel(FlrRbParams P) {
                 const uint32_t rowLimit = colok ? (uint32_t)p.TUH : 0u;     // rows this lane stores: 0 <= ruy < rowLimit
                 float* dst = sU + ruy0 * P.UPC + rux;
                 uint32_t codes = 0;                                         // 4 bits per row: (column 0, column 1) x 2 bits
+                const int sgpos = sxo + (colok ? rux : 0) + 16, sgsh = (sgpos & 15) << 1;
+                const uint32_t* sgp = sS + (sgpos >> 4);
 #pragma unroll
                 for (int e = 0; e < RV; e++) {
                     const int k0 = UP - 1 - (e % UP), b0 = e / UP;
@@ -717,13 +633,24 @@ __global__ void __launch_bounds__(NT, 4) flr_rb_kernel(FlrRbParams P) {
 #pragma unroll
                     for (int j = 0; j < 6; j++) a = __builtin_elementwise_fma(h[b0 + j], (v2f)(fu[k0 + j * UP]), a);
                     v2f v = a * (v2f)(upGain);
-                    const bool n0 = v.x < 0.f, n1 = v.y < 0.f;
-                    v = v * (v2f){n0 ? slope : 1.f, n1 ? slope : 1.f};
-                    const bool c0 = fabsf(v.x) > clampv, c1 = fabsf(v.y) > clampv;
-                    v.x = __builtin_amdgcn_fmed3f(v.x, -clampv, clampv);
-                    v.y = __builtin_amdgcn_fmed3f(v.y, -clampv, clampv);
                     uint32_t code = 0;
-                    if (MODE == 1) code = (c0 ? (2u << (4 * e)) : (n0 ? (1u << (4 * e)) : 0u)) | (c1 ? (8u << (4 * e)) : (n1 ? (4u << (4 * e)) : 0u));
+                    if (MODE == 2) {
+                        // gradient pass: the two columns' codes are one 4-bit field of the staged sign dwords (rows outside the tile are
+                        // not stored: any row's codes will do); multiplier = bit1 ? 0 : (bit0 ? slope : 1) from sign-extended bit fields
+                        const int ry = min(max(ruy0 + e, 0), p.TUH - 1);
+                        const uint32_t sc = __builtin_amdgcn_alignbit(sgp[ry * P.nDw + 1], sgp[ry * P.nDw], (uint32_t)sgsh);
+                        const uint32_t s0 = (uint32_t)__builtin_amdgcn_sbfe((int)sc, 0, 1), z0 = (uint32_t)__builtin_amdgcn_sbfe((int)sc, 1, 1);
+                        const uint32_t s1 = (uint32_t)__builtin_amdgcn_sbfe((int)sc, 2, 1), z1 = (uint32_t)__builtin_amdgcn_sbfe((int)sc, 3, 1);
+                        const uint32_t one = __float_as_uint(1.f), sl = __float_as_uint(slope);
+                        v = v * (v2f){__uint_as_float(((s0 & sl) | (~s0 & one)) & ~z0), __uint_as_float(((s1 & sl) | (~s1 & one)) & ~z1)};
+                    } else {
+                        const bool n0 = v.x < 0.f, n1 = v.y < 0.f;
+                        v = v * (v2f){n0 ? slope : 1.f, n1 ? slope : 1.f};
+                        const bool c0 = fabsf(v.x) > clampv, c1 = fabsf(v.y) > clampv;
+                        v.x = __builtin_amdgcn_fmed3f(v.x, -clampv, clampv);
+                        v.y = __builtin_amdgcn_fmed3f(v.y, -clampv, clampv);
+                        if (MODE == 1) code = (c0 ? (2u << (4 * e)) : (n0 ? (1u << (4 * e)) : 0u)) | (c1 ? (8u << (4 * e)) : (n1 ? (4u << (4 * e)) : 0u));
+                    }
                     if (edgeTile) {                              // uniform
                         const bool rowin = uy0 + ruy0 + e < p.UH;
                         const bool i0 = rowin && ux < p.UW, i1 = rowin && ux + 1 < p.UW;
@@ -756,7 +683,7 @@ __global__ void __launch_bounds__(NT, 4) flr_rb_kernel(FlrRbParams P) {
             }
         };
         if (p.signMode == 1) vert2(std::integral_constant<int, 1>{});
-        else if (p.signMode == 2) vert(std::integral_constant<int, 2>{});
+        else if (p.signMode == 2) vert2(std::integral_constant<int, 2>{});
         else vert2(std::integral_constant<int, 0>{});
     } else {
         // ---- 3'. 2-D up-FIR (UP == 2, 12x12): input column m -> output columns v = 2m, 2m+1; RN input rows per run.
