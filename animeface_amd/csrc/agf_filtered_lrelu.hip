@@ -10,6 +10,8 @@
 // (one per code bit) whose 16-bit quarters are bit-interleaved by the quarter's first lane: 4 uint32 stores per wave.
 #include "agf_common.h"
 #include <type_traits>
+typedef __bf16 flr_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float flr_f32x16 __attribute__((ext_vector_type(16)));
 
 struct ActParams {
     void* x;
@@ -413,7 +415,9 @@ struct FlrRbParams {
     uint32_t mG, mTUW, mMW, mQ4, mTOW, mXP;   // magic numbers for division by nG, TUW, MW, UPC/4, TOW, XP
     int ldw;                         // 16-bit x whose rows start on dwords: the tile is fetched as dwords (two samples per load)
     int NW, dRy, dW;                 // dwords per tile row (XP / 2 + 1); the step of (row, dword) when a lane moves on by NT items
-    uint32_t mNW, mHW, mDw, mHU;     // ... by NW, TOW / 2, nDw, TUW / 2
+    uint32_t mNW, mHW, mDw, mHU, mWpr;   // ... by NW, TOW / 2, nDw, TUW / 2, XPb / 2
+    int mf;                          // 2-D up filter on the matrix pipe (bf16 x, no bias: the gradient pass): see up2d_mfma in the kernel
+    int XPb, TXHb, NRB, NCB;         // its bf16 input tile [TXHb][XPb] (origin: the even column at or left of tix0), 32-row x 8-column blocks
     int sdw;                         // 16-bit y whose rows start on dwords: the two columns of a lane leave as one dword
     int skip;                        // profiling builds only (-DAGF_PROFILE_PHASES=<mask>: 1 load, 2 up-FIR, 4 act, 8 down-FIR, 16 filter taps,
                                      // 32 sign staging, 64 sum of y, 128 horizontal / 256 vertical pass of the separable interpolation): phases left out, results wrong
@@ -421,6 +425,7 @@ struct FlrRbParams {
 
 // Scheduling fence: the value must be materialised here, and no memory access moves across.  Without tying the accumulators
 // to the fence the compiler sinks every FMA below all the loads of an unrolled phase (everything live at once -> spills).
+#define FLR_NFP 144                  // packed hi / lo taps of the 12 x 12 up filter (matrix-pipe interpolation)
 #define FLR_RV 4                     // rows per item of the two-column vertical pass (8: fewer, longer items; the last round of a tile is then a third full)
 #define FLR_PIN(v) asm volatile("" : "+v"(v) :: "memory")
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -438,7 +443,8 @@ __global__ void __launch_bounds__(NT, 4) flr_rb_kernel(FlrRbParams P) {
     constexpr int NFU = SU == 1 ? FU : FU * FU, NFD = SD == 1 ? FD : FD * FD;
     float* sFu = flr_smem;
     float* sFd = sFu + NFU;
-    float* base = sFd + NFD;
+    uint32_t* sFuP = (uint32_t*)(sFd + NFD);                    // 2-D up filter: the taps again as (bf16 hi | bf16 lo << 16), FLR_NFP words
+    float* base = sFd + NFD + (SU == 2 ? FLR_NFP : 0);
     float* sU = base + P.ofsU;
     float* sX = base + P.ofsX;
     float* sH = base + P.ofsH;
@@ -481,7 +487,7 @@ __global__ void __launch_bounds__(NT, 4) flr_rb_kernel(FlrRbParams P) {
         }
     };
     const float bias = p.b ? (float)Elem<T>::load((const T*)p.b + c) : 0.f;
-    const bool xpre = sizeof(T) == 2 && P.ldw == 2 && !(P.skip & 1);
+    const bool xpre = sizeof(T) == 2 && P.ldw == 2 && !(P.skip & 1) && !P.mf;
     if constexpr (sizeof(T) == 2) { if (xpre) x_issue(); }
 
     if (p.signMode == 2 && !(P.skip & 32)) {
@@ -507,7 +513,10 @@ __global__ void __launch_bounds__(NT, 4) flr_rb_kernel(FlrRbParams P) {
         for (int i = tid; i < FU * FU; i += NT) {
             int b = i & 1, jx = (i >> 1) % 6, jy = (i / 12) % 6, a = i / 72;
             int ky = 1 - a + 2 * jy, kx = 1 - b + 2 * jx;
-            sFu[i] = p.fu[(p.flip ? ky : FU - 1 - ky) * p.fus0 + (p.flip ? kx : FU - 1 - kx) * p.fus1];
+            const float v = p.fu[(p.flip ? ky : FU - 1 - ky) * p.fus0 + (p.flip ? kx : FU - 1 - kx) * p.fus1];
+            sFu[i] = v;
+            const uint32_t hb = f32_to_bf16_bits(v);
+            sFuP[i] = hb | (f32_to_bf16_bits(v - bf16_bits_to_f32(hb)) << 16);
         }
     }
     if (SD == 1) { for (int i = tid; i < FD; i += NT) sFd[i] = p.fd[(p.flip ? i : FD - 1 - i) * p.fds0]; }
@@ -519,8 +528,31 @@ __global__ void __launch_bounds__(NT, 4) flr_rb_kernel(FlrRbParams P) {
     //      CU a load -> wait -> store loop would leave the phase bound by one HBM latency per row ----
     {
         bool done = false;
+        if constexpr (SU == 2 && std::is_same<T, bf16_t>::value) {
+            if (P.mf) {
+                // matrix-pipe interpolation: the tile stays bf16 (the gradient has no bias to add), [TXHb][XPb] with its origin on the
+                // even column a0 <= tix0, zero outside the image and in the padding the 32 x 16 operand blocks reach into
+                done = true;
+                uint32_t* sXb = (uint32_t*)sX;
+                const int wpr = P.XPb >> 1, total = (P.skip & 1) ? 0 : P.TXHb * wpr;
+                for (int i0 = tid; i0 < total; i0 += NT * 8) {
+                    uint32_t v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const int i = i0 + u * NT;
+                        const int ry = (int)FLR_DIV(i, wpr, P.mWpr), w = i - ry * wpr;
+                        const int iy = tiy0 + ry, ix0 = xa0 + 2 * w;
+                        v[u] = 0u;
+                        if (i < total && ry < p.TXH && (uint32_t)iy < (uint32_t)p.XH && (uint32_t)ix0 < (uint32_t)p.XW)
+                            v[u] = ((const uint32_t*)xb)[(iy * (int)p.xs[2] + ix0) >> 1];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) { const int i = i0 + u * NT; if (i < total) sXb[i] = v[u]; }
+                }
+            }
+        }
         if constexpr (sizeof(T) == 2) {
-            if (P.ldw) {
+            if (P.ldw && !done) {
                 done = true;
                 const int total = (P.skip & 1) ? 0 : p.TXH * P.NW;
                 for (int i0 = tid; i0 < total; i0 += NT * 4) {
@@ -781,9 +813,125 @@ __global__ void __launch_bounds__(NT, 4) flr_rb_kernel(FlrRbParams P) {
                     }
             }
         };
-        if (p.signMode == 2) up2d(std::integral_constant<int, 2>{});
-        else if (p.signMode == 1) up2d(std::integral_constant<int, 1>{});
-        else up2d(std::integral_constant<int, 0>{});
+        // The same pass on the matrix pipe (bf16 x without bias = the gradient pass; P.mf).  The VALU version above is bound by its
+        // FMAs (36 per up-resolution sample, 65 % of the instructions it issues).  Here a wave takes a block of 32 input rows x 8
+        // input columns = 64 x 16 output samples:  out[2n + a][2m + b] = sum_jy sum_jx x[n + jy][m + jx] F(a, jy; b, jx)  is, for a fixed
+        // jy, the product  A_jy [32 rows n][16 columns k]  x  B_jy [16 columns k][32 = (a, 2m' + b)],  B_jy[k][(a, m', b)] = F(a, jy; b, k - m')
+        // (banded: 0 outside 0 <= k - m' < 6): six v_mfma_f32_32x32x16_bf16 per block, twelve with the taps split into bf16 hi + lo
+        // (the samples ARE bf16; hi + lo carries 16 mantissa bits of a tap, products and sums are fp32).  A_jy is the tile shifted down by
+        // jy rows: one ds_read_b128 per lane.  The twelve B fragments are the same for every block: each lane builds its own from the
+        // packed (hi | lo) taps and holds them in 48 VGPRs.  A lane ends up with one output column and 16 output rows: gain, sign
+        // multiplier (2-bit code from the staged dwords) and the store follow as in the VALU version.
+        auto up2d_mfma = [&](auto modeTag) {
+            constexpr int MODE = decltype(modeTag)::value;
+            const bool edgeTile = ux0 + p.TUW > p.UW || uy0 + p.TUH > p.UH;
+            const float slope = p.slope, clampv = p.clamp;
+            const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+            // B fragments of this lane (column (a, 2 m' + b), k = 8 lhi .. 8 lhi + 7): tap F(a, jy; b, k - m') or 0, from the packed taps
+            const int a = l31 >> 4, c16 = l31 & 15;
+            flr_bf16x8 B[12];
+            {
+                const int mp = c16 >> 1, b = c16 & 1;
+#pragma unroll
+                for (int jy = 0; jy < 6; jy++) {
+                    uint32_t raw[8];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        const int jx = 8 * lhi + i - mp;
+                        const bool ok = (uint32_t)jx < 6u;
+                        const uint32_t wv = sFuP[((a * 6 + jy) * 6 + (ok ? jx : 0)) * 2 + b];
+                        raw[i] = ok ? wv : 0u;
+                    }
+                    u32x4 hi4, lo4;
+                    hi4.x = (raw[0] & 0xFFFFu) | (raw[1] << 16); hi4.y = (raw[2] & 0xFFFFu) | (raw[3] << 16);
+                    hi4.z = (raw[4] & 0xFFFFu) | (raw[5] << 16); hi4.w = (raw[6] & 0xFFFFu) | (raw[7] << 16);
+                    lo4.x = (raw[0] >> 16) | (raw[1] & 0xFFFF0000u); lo4.y = (raw[2] >> 16) | (raw[3] & 0xFFFF0000u);
+                    lo4.z = (raw[4] >> 16) | (raw[5] & 0xFFFF0000u); lo4.w = (raw[6] >> 16) | (raw[7] & 0xFFFF0000u);
+                    B[2 * jy] = __builtin_bit_cast(flr_bf16x8, hi4);
+                    B[2 * jy + 1] = __builtin_bit_cast(flr_bf16x8, lo4);
+                }
+            }
+            const __bf16* sXb = (const __bf16*)sX;
+            const int nblk = (P.skip & 2) ? 0 : P.NRB * P.NCB;
+            const int dxx = dx + 2 * xoff;
+            for (int blk = wave; blk < nblk; blk += NT / 64) {
+                const int rb = blk / P.NCB, cb = blk - rb * P.NCB;
+                flr_f32x16 acc, accl;                               // two chains (hi / lo taps): dependent MFMAs are 16 passes apart
+#pragma unroll
+                for (int e = 0; e < 16; e++) { acc[e] = 0.f; accl[e] = 0.f; }
+                const __bf16* ap = sXb + (32 * rb + l31) * P.XPb + 8 * cb + 8 * lhi;
+#pragma unroll
+                for (int jy = 0; jy < 6; jy++) {
+                    const flr_bf16x8 A = *(const flr_bf16x8*)(ap + jy * P.XPb);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B[2 * jy], acc, 0, 0, 0);
+                    accl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B[2 * jy + 1], accl, 0, 0, 0);
+                }
+#pragma unroll
+                for (int e = 0; e < 16; e++) acc[e] += accl[e];
+                // lane: output column rux, output rows 2 (32 rb + m) + a - dy for m = 8 rg + 4 lhi + e  (acc[4 rg + e])
+                const int rux = 16 * cb + c16 - dxx;
+                const bool colok = rux >= 0 && rux < p.TUW;
+                const bool colin = colok && ux0 + rux < p.UW;
+                const int spos = sxo + max(rux, 0) + 16, ssh = (spos & 15) << 1;
+                const uint32_t* sp = sS + (spos >> 4);
+                // blocks whose 64 output rows all lie inside the tile (and the tile inside the image): no clamps, no row predicates, the gain
+                // folded into the multiplier table {gain, gain * slope, 0}; ~9 VALU instructions per sample instead of ~18
+                const int rowLo = 2 * (32 * rb) - dy, rowHi = 2 * (32 * rb + 31) + 1 - dy;
+                if (MODE == 2 && !edgeTile && rowLo >= -1 && rowHi < p.TUH) {     // (row -1: the first sample of the lanes with a = 0, lhi = 0)
+                    if (colok) {
+                        const uint32_t oneG = __float_as_uint(upGain), slopeG = __float_as_uint(upGain * slope);
+                        const int r0 = rowLo + 8 * lhi + a;                // row of (rg = 0, e = 0)
+                        float* up = sU + r0 * P.UPC + rux;
+                        const uint32_t* sq = sp + r0 * P.nDw;
+#pragma unroll
+                        for (int rg = 0; rg < 4; rg++)
+#pragma unroll
+                            for (int e = 0; e < 4; e++) {
+                                const int k = 2 * (8 * rg + e);                // rows below r0 (uniform)
+                                const uint32_t sc = sq[k * P.nDw] >> ssh;
+                                const uint32_t s0 = (uint32_t)__builtin_amdgcn_sbfe((int)sc, 0, 1), z0 = (uint32_t)__builtin_amdgcn_sbfe((int)sc, 1, 1);
+                                const float v = acc[4 * rg + e] * __uint_as_float(((s0 & slopeG) | (~s0 & oneG)) & ~z0);
+                                if (k > 0 || r0 >= 0) up[k * P.UPC] = v;
+                            }
+                    }
+                    continue;
+                }
+#pragma unroll
+                for (int rg = 0; rg < 4; rg++) {
+                    if (2 * (32 * rb + 8 * rg) - dy >= p.TUH) break;  // uniform: the rest of the block lies below the tile
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int ruy = 2 * (32 * rb + 8 * rg + 4 * lhi + e) + a - dy;
+                        float v = acc[4 * rg + e] * upGain;
+                        if (MODE == 2) {
+                            const int ry = min(max(ruy, 0), p.TUH - 1);
+                            const uint32_t sc = sp[ry * P.nDw] >> ssh;
+                            const uint32_t s0 = (uint32_t)__builtin_amdgcn_sbfe((int)sc, 0, 1), z0 = (uint32_t)__builtin_amdgcn_sbfe((int)sc, 1, 1);
+                            v *= __uint_as_float(((s0 & __float_as_uint(slope)) | (~s0 & __float_as_uint(1.f))) & ~z0);
+                        } else if (MODE == 0) {
+                            v *= v < 0.f ? slope : 1.f;
+                            v = __builtin_amdgcn_fmed3f(v, -clampv, clampv);
+                        }
+                        if (MODE != 1 && edgeTile) v = (colin && uy0 + ruy < p.UH) ? v : 0.f;       // uniform branch
+                        if (colok && (uint32_t)ruy < (uint32_t)p.TUH) sU[ruy * P.UPC + rux] = v;
+                    }
+                }
+            }
+        };
+        bool viaMfma = false;
+        if constexpr (std::is_same<T, bf16_t>::value) {
+            if (P.mf) {
+                viaMfma = true;
+                if (p.signMode == 2) up2d_mfma(std::integral_constant<int, 2>{});
+                else if (p.signMode == 1) up2d_mfma(std::integral_constant<int, 1>{});
+                else up2d_mfma(std::integral_constant<int, 0>{});
+            }
+        }
+        if (!viaMfma) {
+            if (p.signMode == 2) up2d(std::integral_constant<int, 2>{});
+            else if (p.signMode == 1) up2d(std::integral_constant<int, 1>{});
+            else up2d(std::integral_constant<int, 0>{});
+        }
     }
     __syncthreads();
 
@@ -1010,6 +1158,9 @@ static bool flr_rb_launch(FlrParams p, hipStream_t st, int* status) {
     FlrRbParams P;
     size_t lds = 0;
     bool balanced = SD == 2;
+    // 2-D up filter on the matrix pipe: bf16 samples that need no bias (the gradient pass), rows that start on dwords
+    const bool mfOk = std::is_same<T, bf16_t>::value && SU == 2 && !p.b && p.xs[3] == 1 && !(p.xs[2] & 1) && !(p.xs[1] & 1) && !(p.xs[0] & 1)
+                      && !(p.XW & 1) && !((uintptr_t)p.x & 3) && (int64_t)p.XH * p.xs[2] < (1ll << 31);
     for (;; strips--) {
         if (strips < 1) return false;
         const int TOH = strips * ROUT;
@@ -1034,6 +1185,16 @@ static bool flr_rb_launch(FlrParams p, hipStream_t st, int* status) {
         }
         p.TXW = P.XP;
         szX = p.TXH * P.XP;
+        P.mf = 0; P.XPb = P.TXHb = P.NRB = P.NCB = 0;
+        if (SU == 2 && mfOk) {
+            P.mf = 1;
+            P.NRB = (P.NR * RN + 31) / 32;
+            P.NCB = (P.MW + 1 + 7) / 8;                        // (+ 1: the origin moves to the even column at or left of tix0)
+            P.XPb = 8 * (P.NCB + 1);
+            if (!((P.XPb / 8) & 1)) P.XPb += 8;                  // odd number of 16-byte units per row: the 32 rows of an operand read
+            P.TXHb = 32 * P.NRB + 5;                             // spread over all banks
+            szX = (P.TXHb * P.XPb + 1) / 2;
+        }
         const int szU = p.TUH * P.UPC;
         const int szV = SD == 1 ? TOH * P.UPC : 0;
         // layout after the filters: [sU][R2]; separable up: sX overlays sU (dead before sU is written), R2 = max(sH, sV);
@@ -1049,7 +1210,7 @@ static bool flr_rb_launch(FlrParams p, hipStream_t st, int* status) {
         P.nDw = (p.TUW + 15 + 15) / 16 + 2;
         const int szS = p.signMode == 2 ? p.TUH * P.nDw : 0;
         P.ofsS = szU + szR2;
-        const size_t fl = (size_t)(SU == 1 ? FU : FU * FU) + (size_t)(SD == 1 ? FD : FD * FD) + szU + szR2 + szS;
+        const size_t fl = (size_t)(SU == 1 ? FU : FU * FU + FLR_NFP) + (size_t)(SD == 1 ? FD : FD * FD) + szU + szR2 + szS;
         lds = fl * sizeof(float);
         if (lds <= 78 * 1024) {                                  // two workgroups per CU
             if (balanced) break;
@@ -1069,7 +1230,7 @@ static bool flr_rb_launch(FlrParams p, hipStream_t st, int* status) {
     P.b = p;
     P.mG = flr_magic(SU == 1 ? P.TVWa >> 3 : 1); P.mTUW = flr_magic(p.TUW); P.mMW = flr_magic(P.MW ? P.MW : 1);
     P.mQ4 = flr_magic(P.UPC >> 2); P.mTOW = flr_magic(p.TOW); P.mXP = flr_magic(P.XP);
-    P.mHW = flr_magic(p.TOW >> 1); P.mDw = flr_magic(P.nDw); P.mHU = flr_magic(p.TUW >> 1);
+    P.mHW = flr_magic(p.TOW >> 1); P.mDw = flr_magic(P.nDw); P.mHU = flr_magic(p.TUW >> 1); P.mWpr = flr_magic(P.XPb ? P.XPb >> 1 : 1);
     P.sdw = sizeof(T) == 2 && p.ys[3] == 1 && !(p.ys[2] & 1) && !(p.ys[1] & 1) && !(p.ys[0] & 1) && !((uintptr_t)p.y & 3);
     P.NW = (P.XP >> 1) + 1; P.dRy = NT / P.NW; P.dW = NT - P.dRy * P.NW; P.mNW = flr_magic(P.NW);
     P.ldw = sizeof(T) == 2 && p.xs[3] == 1 && !(p.xs[2] & 1) && !(p.xs[1] & 1) && !(p.xs[0] & 1) && !(p.XW & 1) && !((uintptr_t)p.x & 3)

@@ -54,7 +54,7 @@ def _f_desc(f):
 def _native_fused(x, fu, fd, b, si, up, down, px0, px1, py0, py1, sx, sy, gain, slope, clamp, flip, write_signs, ysum=None):
     """Counterpart of ``_plugin.filtered_lrelu`` (reference filtered_lrelu.cpp:10-203): returns (y, so, rc)."""
     N, C, xh, xw = x.shape
-    b = b.contiguous()
+    b = b.contiguous() if b is not None else None       # None: no bias (the gradient pass; the bf16 kernel then runs its 2-D interpolation on the matrix pipe)
     fut_w, fut_h = int(fu.shape[-1]) - 1, int(fu.shape[0]) - 1
     fdt_w, fdt_h = int(fd.shape[-1]) - 1, int(fd.shape[0]) - 1
     cw = xw * up + (px0 + px1) - fut_w
@@ -196,10 +196,9 @@ def _filtered_lrelu_hip(up=1, down=1, padding=0, gain=np.sqrt(2), slope=0.2, cla
                     # (sum of dx over n, h, w) while it stores dx -- one pass less over dx
                     dyc = dy if _dense(dy) else dy.contiguous()
                     ysum = torch.zeros(dy.shape[1], dtype=torch.float32, device=dy.device) if ctx.needs_input_grad[3] else None
-                    zb = torch.zeros(dy.shape[1], dtype=dy.dtype, device=dy.device)
                     fu2 = fd if fd.ndim == 2 or down > 1 or fd.shape[0] > 1 else fd.square()[None]
                     fd2 = fu if fu.ndim == 2 or up > 1 or fu.shape[0] > 1 else fu.square()[None]
-                    dx, _, rc = _native_fused(dyc, fu2, fd2, zb, si, down, up, pp[0], pp[1], pp[2], pp[3], sx, sy, gg, slope,
+                    dx, _, rc = _native_fused(dyc, fu2, fd2, None, si, down, up, pp[0], pp[1], pp[2], pp[3], sx, sy, gg, slope,
                                               float('inf'), ff, False, ysum=ysum)
                     if rc < 0:
                         dx = None
