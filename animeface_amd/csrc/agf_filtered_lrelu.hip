@@ -921,10 +921,8 @@ __global__ void __launch_bounds__(NT, 4) flr_rb_kernel(FlrRbParams P) {
         bool viaMfma = false;
         if constexpr (std::is_same<T, bf16_t>::value) {
             if (P.mf) {
-                viaMfma = true;
-                if (p.signMode == 2) up2d_mfma(std::integral_constant<int, 2>{});
-                else if (p.signMode == 1) up2d_mfma(std::integral_constant<int, 1>{});
-                else up2d_mfma(std::integral_constant<int, 0>{});
+                viaMfma = true;                                     // (the host sets P.mf for the sign-read pass only)
+                up2d_mfma(std::integral_constant<int, 2>{});
             }
         }
         if (!viaMfma) {
@@ -1158,8 +1156,8 @@ static bool flr_rb_launch(FlrParams p, hipStream_t st, int* status) {
     FlrRbParams P;
     size_t lds = 0;
     bool balanced = SD == 2;
-    // 2-D up filter on the matrix pipe: bf16 samples that need no bias (the gradient pass), rows that start on dwords
-    const bool mfOk = std::is_same<T, bf16_t>::value && SU == 2 && !p.b && p.xs[3] == 1 && !(p.xs[2] & 1) && !(p.xs[1] & 1) && !(p.xs[0] & 1)
+    // 2-D up filter on the matrix pipe: bf16 samples that need no bias and read their signs (= the gradient pass), rows that start on dwords
+    const bool mfOk = std::is_same<T, bf16_t>::value && SU == 2 && !p.b && p.signMode == 2 && p.xs[3] == 1 && !(p.xs[2] & 1) && !(p.xs[1] & 1) && !(p.xs[0] & 1)
                       && !(p.XW & 1) && !((uintptr_t)p.x & 3) && (int64_t)p.XH * p.xs[2] < (1ll << 31);
     for (;; strips--) {
         if (strips < 1) return false;
