@@ -1145,17 +1145,17 @@ static bool flr_rb_launch(FlrParams p, hipStream_t st, int* status) {
     int TOW = (p.YW + nTx - 1) / nTx;
     TOW = (TOW + 1) & ~1;
     if (DOWN == 2 && (TOW & 1)) TOW++;
-    // Tile height.  2-D decimation: one lane per (strip, column pair), so NT / TOW strips.  Separable decimation: as tall as the LDS of
-    // two workgroups per CU allows (first pass of the loop below finds that height), then the smallest height that needs no more tile
-    // rows than it (second pass): 86 rows are 2 x 48, not 3 x 32 or 3 x 40 -- less halo, no ragged last tile, fewer workgroups
-    // (gradient kernels of the SG3-T 512 layers 26.3 -> 24.9 ms in all)
-    int strips = SD == 2 ? NT / TOW : 16;
+    // Tile height: as tall as the LDS of two workgroups per CU allows (first pass of the loop below finds that height), then the smallest
+    // height that needs no more tile rows than it (second pass): 86 rows are 2 x 48, not 3 x 32 or 3 x 40 -- less halo, no ragged last
+    // tile, fewer workgroups (gradient kernels of the SG3-T 512 layers 26.3 -> 24.9 ms in all; forward kernels, whose height used to be
+    // tied to one lane per (strip, column) of the decimation, 13.8 -> 13.6)
+    int strips = 16;
     if (strips < 1) strips = 1;
     int needStrips = (p.YH + ROUT - 1) / ROUT;
     if (strips > needStrips) strips = needStrips;
     FlrRbParams P;
     size_t lds = 0;
-    bool balanced = SD == 2;
+    bool balanced = false;
     // 2-D up filter on the matrix pipe: bf16 samples that need no bias and read their signs (= the gradient pass), rows that start on dwords
     const bool mfOk = std::is_same<T, bf16_t>::value && SU == 2 && !p.b && p.signMode == 2 && p.xs[3] == 1 && !(p.xs[2] & 1) && !(p.xs[1] & 1) && !(p.xs[0] & 1)
                       && !(p.XW & 1) && !((uintptr_t)p.x & 3) && (int64_t)p.XH * p.xs[2] < (1ll << 31);
