@@ -279,11 +279,16 @@ class SynthesisInput(nn.Module):
         W, H = self.size
         xs = ((2 * torch.arange(W, device=w.device, dtype=torch.float32) + 1) / W - 1) * (0.5 * W / self.sampling_rate)
         ys = ((2 * torch.arange(H, device=w.device, dtype=torch.float32) + 1) / H - 1) * (0.5 * H / self.sampling_rate)
-        arg = xs[None, None, :, None] * freqs[:, None, None, :, 0] + ys[None, :, None, None] * freqs[:, None, None, :, 1] \
-            + phases[:, None, None, :]                                                   # [B, H, W, C]
-        feat = torch.sin(arg * (2 * np.pi)) * amp[:, None, None, :]
-        out = feat @ (self.weight * self.scale).t()                                      # learned mix of the waves
-        return out.permute(0, 3, 1, 2)
+        # arg[b, h, w, c] = xs[w] f[b, c, 0] + ys[h] f[b, c, 1] + phase[b, c]  as ONE batched product  [H W, 3] @ [3, C]  (2 pi folded in),
+        # and the amplitudes folded into the per-sample mixing matrix: three passes over the [B, H, W, C] map instead of eight
+        # (the broadcast multiplies and adds ran at 0.2 TB/s: 1.2 ms of the iteration with their gradients)
+        ones = torch.ones((), device=w.device, dtype=torch.float32)
+        coords = torch.stack([xs[None, :].expand(H, W), ys[:, None].expand(H, W), ones.expand(H, W)], 2).reshape(1, H * W, 3)
+        wave = torch.cat([freqs.transpose(1, 2), phases[:, None, :]], 1) * (2 * np.pi)   # [B, 3, C]
+        feat = torch.sin(coords.expand(w.shape[0], -1, -1) @ wave)                       # [B, H W, C]
+        mix = (self.weight * self.scale).t()[None] * amp[:, :, None]                     # [B, C, C]: amplitude of wave c on its row
+        out = feat @ mix                                                                 # learned mix of the waves
+        return out.reshape(w.shape[0], H, W, self.channels).permute(0, 3, 1, 2)
 
 
 class PixelNorm(nn.Module):
