@@ -23,7 +23,7 @@ EXPORTS = ['agf_abi_version', 'agf_last_error', 'agf_device_info', 'agf_upfirdn2
            'agf_filtered_lrelu', 'agf_filtered_lrelu_act', 'agf_conv2d_fwd', 'agf_conv2d_fwd_mask', 'agf_conv2d_s2_fwd', 'agf_conv2d_s2_dgrad', 'agf_conv2d_wgrad', 'agf_conv2d_wgrad_ws', 'agf_conv2d_wgrad_workspace_bytes',
            'agf_act_bwd_reduce', 'agf_act_bwd_reduce_pooled', 'agf_act_bwd_reduce_scaled', 'agf_scale_dot', 'agf_demod_grad_finish', 'agf_planar_to_cl_pad', 'agf_cl_to_planar_crop', 'agf_cl_pad', 'agf_prep_weights', 'agf_prep_weights_multi', 'agf_prep_weights_blocks',
            'agf_modulate_weights', 'agf_conv2d_fwd_wimg', 'agf_conv2d_fwd_wimg_covers',
-           'agf_wsq', 'agf_style_demod_fwd', 'agf_style_demod_fwd_ld', 'agf_style_demod_bwd', 'agf_diffaug_sum', 'agf_diffaug_apply', 'agf_color_affine', 'agf_affine_resample', 'agf_upblur_border', 'agf_image_resample_rows', 'agf_image_finish']
+           'agf_wsq', 'agf_style_demod_fwd', 'agf_style_demod_fwd_ld', 'agf_style_demod_bwd', 'agf_diffaug_sum', 'agf_diffaug_apply', 'agf_color_affine', 'agf_affine_resample', 'agf_ada_pad_up2', 'agf_ada_warp_resample', 'agf_upblur_border', 'agf_image_resample_rows', 'agf_image_finish']
 
 _lib = None
 _i32x4 = ctypes.c_int32 * 4
@@ -124,13 +124,17 @@ def lib():
         L.agf_color_affine.argtypes = [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int32, ctypes.c_int64, ctypes.c_int, _vp]
         L.agf_affine_resample.restype = ctypes.c_int
         L.agf_affine_resample.argtypes = [_vp, _vp, _vp, ctypes.c_int] + [ctypes.c_int32] * 6 + [ctypes.c_int, _vp]
+        L.agf_ada_pad_up2.restype = ctypes.c_int
+        L.agf_ada_pad_up2.argtypes = [_vp, _vp, _vp, _vp, ctypes.c_int] + [ctypes.c_int32] * 4 + [ctypes.c_int, _vp]
+        L.agf_ada_warp_resample.restype = ctypes.c_int
+        L.agf_ada_warp_resample.argtypes = [_vp, _vp, _vp, _vp, ctypes.c_int] + [ctypes.c_int32] * 6 + [ctypes.c_int, _vp]
         L.agf_upblur_border.restype = ctypes.c_int
         L.agf_upblur_border.argtypes = [_vp, _vp, ctypes.c_int] + [ctypes.c_int32] * 4 + [ctypes.c_int, _vp]
         L.agf_image_resample_rows.restype = ctypes.c_int
         L.agf_image_resample_rows.argtypes = [_vp] * 5 + [ctypes.c_int32] * 8 + [_vp]
         L.agf_image_finish.restype = ctypes.c_int
         L.agf_image_finish.argtypes = [_vp] * 5 + [ctypes.c_int32, _vp, ctypes.c_int] + [ctypes.c_int32] * 6 + [ctypes.c_int, _vp]
-        if L.agf_abi_version() != 14:
+        if L.agf_abi_version() != 15:
             raise AgfError('libagf_ops.so ABI version mismatch')
         _lib = L
     return _lib

@@ -79,6 +79,14 @@ def load(step, path_or_state, map_location=None):
     if hasattr(step, 'pl_mean'):
         step.pl_mean = st.get('pl_mean', 0.)
     ada = _ada_of(step)
+    if 'ada' in st and 'signsum' in st['ada']['state']:
+        # the stored sign statistic is one rank's share (total / saved world size): a run resumed on another number of ranks carries
+        # total / current world size per rank, so that the all-reduced statistic of the first interval is the saved total
+        saved_world, cur_world = int(st.get('world_size', 1)), _rank_world()[1]
+        if saved_world != cur_world:
+            sd = dict(st['ada']['state'])
+            sd['signsum'] = sd['signsum'] * (saved_world / cur_world)
+            st = dict(st, ada=dict(st['ada'], state=sd))
     if 'ada' in st:
         if ada is not None:
             ada.load_state_dict(st['ada']['state'])
@@ -96,7 +104,8 @@ def load(step, path_or_state, map_location=None):
         own = None
         if side is not None and os.path.exists(side):
             own = torch.load(side, map_location='cpu', weights_only=False)
-            if int(own.get('batches_done', -1)) != int(st['batches_done']) or int(own.get('world_size', -1)) != world:
+            legacy = 'world_size' not in st and 'batches_done' not in own       # files of the format before the tags existed
+            if not legacy and (int(own.get('batches_done', -1)) != int(st['batches_done']) or int(own.get('world_size', -1)) != world):
                 own = None                                   # written by another save, or for another world size
         if own is not None:
             st = dict(st, rng_cpu=own['rng_cpu'], rng_cuda=own['rng_cuda'])

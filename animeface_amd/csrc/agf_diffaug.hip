@@ -165,7 +165,17 @@ extern "C" int agf_color_affine(const void* x, void* y, const float* m, int dtyp
 struct ResampleParams {
     const void* x; void* y; const float* theta;
     int B, C, Hin, Win, Hout, Wout;
+    // agf_ada_warp_resample: the input is the x2-upsampled, reflect-padded image written by agf_ada_pad_up2 -- densely packed with
+    // Hin = 2 (Hb + m[1] + m[3]), Win = 2 (Wb + m[0] + m[2]) where m = margins (x0, y0, x1, y1) lives in DEVICE memory
+    const int32_t* margins; int Hb, Wb;
 };
+
+static __device__ __forceinline__ void resample_dims(ResampleParams& p) {
+    if (p.margins) {
+        p.Win = 2 * (p.Wb + p.margins[0] + p.margins[2]);
+        p.Hin = 2 * (p.Hb + p.margins[1] + p.margins[3]);
+    }
+}
 
 static __device__ __forceinline__ void resample_matrix(const ResampleParams& p, int b, float (&A)[6]) {
     const float* t = p.theta + b * 6;
@@ -178,6 +188,7 @@ static __device__ __forceinline__ void resample_matrix(const ResampleParams& p, 
 
 template <class T>
 __global__ void __launch_bounds__(256) affine_resample_fwd_kernel(ResampleParams p) {
+    resample_dims(p);
     const int b = blockIdx.y;
     float A[6];
     resample_matrix(p, b, A);
@@ -207,6 +218,7 @@ __global__ void __launch_bounds__(256) affine_resample_fwd_kernel(ResampleParams
 // x = dy [B,C,Hout,Wout], y = dx [B,C,Hin,Win]
 template <class T>
 __global__ void __launch_bounds__(256) affine_resample_bwd_kernel(ResampleParams p) {
+    resample_dims(p);
     const int b = blockIdx.y;
     float A[6];
     resample_matrix(p, b, A);
@@ -249,10 +261,172 @@ extern "C" int agf_affine_resample(const void* x, void* y, const float* theta, i
     AGF_CHECK(B >= 1 && B <= 65535 && C >= 1 && C <= 4 && Hin >= 1 && Win >= 1 && Hout >= 1 && Wout >= 1, "affine_resample: bad shape (at most 4 channels)");
     ResampleParams p;
     p.x = x; p.y = y; p.theta = theta; p.B = B; p.C = C; p.Hin = Hin; p.Win = Win; p.Hout = Hout; p.Wout = Wout;
+    p.margins = nullptr; p.Hb = p.Wb = 0;
     const int64_t n = backward ? (int64_t)Hin * Win : (int64_t)Hout * Wout;
     int64_t bx = agf_ceil_div(n, 256);
     if (bx > 4096) bx = 4096;
     dim3 grid((unsigned)bx, (unsigned)B);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == AGF_F32) {
+        if (backward) hipLaunchKernelGGL((affine_resample_bwd_kernel<float>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((affine_resample_fwd_kernel<float>), grid, dim3(256), 0, st, p);
+    } else {
+        if (backward) hipLaunchKernelGGL((affine_resample_bwd_kernel<bf16_t>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((affine_resample_fwd_kernel<bf16_t>), grid, dim3(256), 0, st, p);
+    }
+    AGF_LAUNCH_CHECK();
+    return AGF_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// ADA geometric warp without a host synchronisation (thirdparty/ada/augment.py:268-283).  The reference reads the reflect-padding
+// margins back to the host (`margin.ceil().to(torch.int32)` unpacked into Python ints) because they size the padded tensor.  Here the
+// margins m = (x0, y0, x1, y1) stay in DEVICE memory: agf_ada_pad_up2 writes the x2-upsampled reflect-padded image DENSELY PACKED with
+// the data-dependent size [B, C, 2 (H + m1 + m3), 2 (W + m0 + m2)] into a workspace sized for the largest margins (W - 1, H - 1), the
+// resampling kernel reads it with the same device-side size, and nothing but that workspace has a data-dependent extent -- the pipe
+// can be recorded into a HIP graph.  The reflect padding is index math inside the FIR's gather: no padded tensor exists.
+//
+// Upsampling = upfirdn2d.upsample2d(xp, f, up=2) with the 12-tap low-pass f (separable, gain 2 per axis, padding (6, 5)):
+//     u[2a]   = 2 sum_{q<6} f[11 - 2q] xp[a + q - 3],      u[2a+1] = 2 sum_{q<6} f[10 - 2q] xp[a + q - 2]       (xp = 0 outside the padded image)
+// xp[t] = x[reflect(t - m0)] for 0 <= t < W + m0 + m1.
+struct PadUpParams {
+    const void* x; void* u; const int32_t* margins; const float* f;   // f: 12 taps
+    int B, C, H, W;
+};
+
+static __device__ __forceinline__ int reflect_src(int t, int m0, int n, int np) {       // padded index -> source index, -1 = outside the padded image
+    if (t < 0 || t >= np) return -1;
+    int r = t - m0;
+    if (r < 0) r = -r;
+    if (r >= n) r = 2 * (n - 1) - r;
+    return r;
+}
+
+template <class T>
+__global__ void __launch_bounds__(256) ada_pad_up2_fwd_kernel(PadUpParams p) {
+    __shared__ float sf[12];
+    if (threadIdx.x < 12) sf[threadIdx.x] = p.f[threadIdx.x];
+    __syncthreads();
+    const int mx0 = p.margins[0], my0 = p.margins[1], mx1 = p.margins[2], my1 = p.margins[3];
+    const int Wp = p.W + mx0 + mx1, Hp = p.H + my0 + my1;
+    const int64_t cells = (int64_t)Hp * Wp, total = cells * p.B * p.C;
+    const int Wu = 2 * Wp;
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < total; r += (int64_t)gridDim.x * 256) {
+        const int64_t plane = r / cells;
+        const int cell = (int)(r - plane * cells);
+        const int ay = cell / Wp, ax = cell - ay * Wp;
+        const T* xc = (const T*)p.x + plane * ((int64_t)p.H * p.W);
+        // 7 x 7 window of the padded image around (ay, ax): rows ay - 3 .. ay + 3
+        int sx[7];
+#pragma unroll
+        for (int k = 0; k < 7; k++) sx[k] = reflect_src(ax + k - 3, mx0, p.W, Wp);
+        float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+        for (int ky = 0; ky < 7; ky++) {
+            const int sy = reflect_src(ay + ky - 3, my0, p.H, Hp);
+            if (sy < 0) continue;
+            float h0 = 0.f, h1 = 0.f;                       // horizontal pass of this row: even / odd output column
+#pragma unroll
+            for (int k = 0; k < 7; k++) {
+                const float v = sx[k] >= 0 ? (float)Elem<T>::load(xc + (int64_t)sy * p.W + sx[k]) : 0.f;
+                if (k < 6) h0 += sf[11 - 2 * k] * v;        // even column 2 ax: taps q = k      (window offset q - 3)
+                if (k > 0) h1 += sf[12 - 2 * k] * v;        // odd column 2 ax + 1: q = k - 1    (window offset q - 2)
+            }
+            if (ky < 6) { acc[0][0] += sf[11 - 2 * ky] * h0; acc[0][1] += sf[11 - 2 * ky] * h1; }
+            if (ky > 0) { acc[1][0] += sf[12 - 2 * ky] * h0; acc[1][1] += sf[12 - 2 * ky] * h1; }
+        }
+        T* uc = (T*)p.u + plane * (4 * cells) + (int64_t)(2 * ay) * Wu + 2 * ax;
+        Elem<T>::store(uc, 4.f * acc[0][0]); Elem<T>::store(uc + 1, 4.f * acc[0][1]);
+        Elem<T>::store(uc + Wu, 4.f * acc[1][0]); Elem<T>::store(uc + Wu + 1, 4.f * acc[1][1]);
+    }
+}
+
+// adjoint: dx[i, j] = sum over the padded positions (a, b) that read x[i, j] of dxp[a, b],
+//          dxp[t] = 2 sum_q ( f[11 - 2q] du[2 (t - q + 3)] + f[10 - 2q] du[2 (t - q + 2) + 1] )        per axis
+template <class T>
+__global__ void __launch_bounds__(256) ada_pad_up2_bwd_kernel(PadUpParams p) {
+    __shared__ float sf[12];
+    if (threadIdx.x < 12) sf[threadIdx.x] = p.f[threadIdx.x];
+    __syncthreads();
+    const int mx0 = p.margins[0], my0 = p.margins[1], mx1 = p.margins[2], my1 = p.margins[3];
+    const int Wp = p.W + mx0 + mx1, Hp = p.H + my0 + my1;
+    const int Wu = 2 * Wp, Hu = 2 * Hp;
+    const int64_t pix = (int64_t)p.H * p.W, total = pix * p.B * p.C;
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < total; r += (int64_t)gridDim.x * 256) {
+        const int64_t plane = r / pix;
+        const int q = (int)(r - plane * pix);
+        const int i = q / p.W, j = q - i * p.W;
+        const T* gc = (const T*)p.u + plane * ((int64_t)Hu * Wu);
+        int ys[3], xs[3], ny = 0, nx = 0;
+        ys[ny++] = i + my0;
+        if (i >= 1 && i <= my0) ys[ny++] = my0 - i;
+        if (i <= p.H - 2 && i >= p.H - 1 - my1) ys[ny++] = my0 + 2 * (p.H - 1) - i;
+        xs[nx++] = j + mx0;
+        if (j >= 1 && j <= mx0) xs[nx++] = mx0 - j;
+        if (j <= p.W - 2 && j >= p.W - 1 - mx1) xs[nx++] = mx0 + 2 * (p.W - 1) - j;
+        float acc = 0.f;
+        for (int a = 0; a < ny; a++) {
+            for (int b = 0; b < nx; b++) {
+                const int ty = ys[a], tx = xs[b];
+                // up-resolution rows 2 (ty - q + 3) [tap f[11 - 2q]] and 2 (ty - q + 2) + 1 [tap f[10 - 2q]], q = 0..5: rows 2 ty - 5 .. 2 ty + 6,
+                // row 2 ty - 5 + k carries tap f[k] (k = 0: q = 5 odd form ... k = 11: q = 0 even form)
+#pragma unroll
+                for (int ky = 0; ky < 12; ky++) {
+                    const int uy = 2 * ty - 5 + ky;
+                    if (uy < 0 || uy >= Hu) continue;
+                    float h = 0.f;
+#pragma unroll
+                    for (int kx = 0; kx < 12; kx++) {
+                        const int ux = 2 * tx - 5 + kx;
+                        if (ux >= 0 && ux < Wu) h += sf[kx] * (float)Elem<T>::load(gc + (int64_t)uy * Wu + ux);
+                    }
+                    acc += sf[ky] * h;
+                }
+            }
+        }
+        Elem<T>::store((T*)p.x + r, 4.f * acc);
+    }
+}
+
+extern "C" int agf_ada_pad_up2(const void* x, void* u, const int32_t* margins, const float* f12, int dtype, int32_t B, int32_t C,
+                               int32_t H, int32_t W, int backward, void* stream) {
+    AGF_CHECK(x && u && margins && f12, "ada_pad_up2: null pointer");
+    AGF_CHECK(dtype == AGF_F32 || dtype == AGF_BF16, "ada_pad_up2: dtype must be f32 or bf16");
+    AGF_CHECK(B >= 1 && C >= 1 && H >= 2 && W >= 2, "ada_pad_up2: bad shape");
+    PadUpParams p;
+    p.x = x; p.u = u; p.margins = margins; p.f = f12; p.B = B; p.C = C; p.H = H; p.W = W;
+    // the amount of work is data-dependent (forward: one thread per 2x2 cell of the padded image): a fixed grid strides over it
+    const int64_t n = (int64_t)B * C * H * W;
+    int64_t bx = agf_ceil_div(n, 256);
+    if (bx > 16384) bx = 16384;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == AGF_F32) {
+        if (backward) hipLaunchKernelGGL((ada_pad_up2_bwd_kernel<float>), dim3((unsigned)bx), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((ada_pad_up2_fwd_kernel<float>), dim3((unsigned)bx), dim3(256), 0, st, p);
+    } else {
+        if (backward) hipLaunchKernelGGL((ada_pad_up2_bwd_kernel<bf16_t>), dim3((unsigned)bx), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((ada_pad_up2_fwd_kernel<bf16_t>), dim3((unsigned)bx), dim3(256), 0, st, p);
+    }
+    AGF_LAUNCH_CHECK();
+    return AGF_OK;
+}
+
+// agf_affine_resample on the workspace agf_ada_pad_up2 filled: the input size comes from the device-side margins (Hb, Wb = the size of
+// the image before padding and upsampling).  forward: u -> y [B, C, Hout, Wout]; backward: dy -> du (written over the whole dynamic extent).
+extern "C" int agf_ada_warp_resample(const void* x, void* y, const float* theta, const int32_t* margins, int dtype, int32_t B, int32_t C,
+                                     int32_t Hb, int32_t Wb, int32_t Hout, int32_t Wout, int backward, void* stream) {
+    AGF_CHECK(x && y && theta && margins, "ada_warp_resample: null pointer");
+    AGF_CHECK(dtype == AGF_F32 || dtype == AGF_BF16, "ada_warp_resample: dtype must be f32 or bf16");
+    AGF_CHECK(B >= 1 && B <= 65535 && C >= 1 && C <= 4 && Hb >= 2 && Wb >= 2 && Hout >= 1 && Wout >= 1, "ada_warp_resample: bad shape (at most 4 channels)");
+    ResampleParams p;
+    p.x = x; p.y = y; p.theta = theta; p.B = B; p.C = C; p.Hin = 0; p.Win = 0; p.Hout = Hout; p.Wout = Wout;
+    p.margins = margins; p.Hb = Hb; p.Wb = Wb;
+    dim3 grid(4096, (unsigned)B);                 // (the extent of the input is only known on the device: grid-stride loops)
+    if (!backward) {
+        const int64_t bx = agf_ceil_div((int64_t)Hout * Wout, 256);
+        grid.x = (unsigned)(bx > 4096 ? 4096 : bx);
+    }
     hipStream_t st = (hipStream_t)stream;
     if (dtype == AGF_F32) {
         if (backward) hipLaunchKernelGGL((affine_resample_bwd_kernel<float>), grid, dim3(256), 0, st, p);

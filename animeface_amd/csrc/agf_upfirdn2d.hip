@@ -602,7 +602,9 @@ static bool launch_planar_vec_cases(const UpfirdnParams& p, hipStream_t st) {
         const int groups = p.OW / OV, strips = (p.OH + R_ - 1) / R_;                                                            \
         const int64_t threads = (int64_t)groups * strips * p.N * p.C;                                                           \
         if (threads >= (1ll << 38)) return false;                                                                               \
-        if (groups <= 64 && (groups & (groups - 1)) == 0)                                                                       \
+        /* lane-shuffled halo only when the lane groups tile the input row exactly (no cropping / extra right padding): the last   \
+           group's right neighbour is then the image border */                                                                  \
+        if (groups <= 64 && (groups & (groups - 1)) == 0 && (int64_t)p.OW * D_ == (int64_t)p.W * U_)                            \
             hipLaunchKernelGGL((upfirdn2d_planar_vec<T, U_, D_, F_, F_, P_, R_, PF_, true>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, \
                                p, groups, strips);                                                                              \
         else                                                                                                                    \

@@ -42,6 +42,12 @@ def init_distributed():
 
 
 class GradReducer:
+    """Accumulation contract: between ``zero_grad()`` and ``finish()`` every parameter may receive ONE gradient while the reducer is
+    enabled (a second one raises: its bucket's all-reduce may already be in flight).  To accumulate several backward passes set
+    ``reducer.enabled = False`` for all but the last one: the hooks then only note which parameters were touched, autograd accumulates
+    into ``param.grad`` as usual, the last (enabled) pass launches the buckets it completes and ``finish()`` packs and launches the
+    rest -- including parameters that only the earlier passes touched."""
+
     def __init__(self, params, bucket_bytes=32 << 20, group=None, never_used=(), tail_bytes=8 << 20):
         """``never_used``: parameters the forward pass is known never to touch (``InjectNoise.scale``, reference F10).  A bucket is
         launched from the backward hooks once ALL of its parameters have their gradient, so such parameters would hold every bucket
@@ -78,6 +84,13 @@ class GradReducer:
             self._make_bucket(list(reversed(grp)))
         self.enabled = True
 
+    @property
+    def capturable(self):
+        """True when the all-reduce itself can be recorded into a HIP graph: RCCL collectives are stream-ordered kernels on RCCL's own
+        stream (torch forks it off the capturing stream and ``work.wait()`` joins it), so a captured iteration keeps the hook-launched,
+        backward-overlapped exchange.  gloo runs on host threads and cannot be captured."""
+        return (not self.collectives) or dist.get_backend(self.group) == 'nccl'
+
     def _make_bucket(self, plist):
         n = sum(p.numel() for p in plist)
         flat = torch.zeros(n, dtype=torch.float32, device=plist[0].device)
@@ -94,9 +107,11 @@ class GradReducer:
 
     def _make_hook(self, bucket):
         def hook(param):
+            # (recorded while disabled too: a parameter that only the earlier passes of an accumulation touch still carries a gradient,
+            #  which finish() must neither drop nor leave out of the exchange)
+            self._touched.add(id(param))
             if not self.enabled:
                 return
-            self._touched.add(id(param))
             bucket['pending'] -= 1
             # one backward per parameter between zero_grad() and finish(): a second one would launch the bucket with a partial gradient
             # and then accumulate into a buffer whose all-reduce is in flight
@@ -163,7 +178,7 @@ class GradReducer:
         instead of stepping them with g = 0 (their step count and second-moment decay would otherwise differ from the reference:
         ``InjectNoise.scale`` always, D's last bias on lazy-R1 iterations)."""
         ev0 = ev1 = None
-        if self.measure and self.buckets and self.buckets[0]['flat'].is_cuda:
+        if self.measure and self.buckets and self.buckets[0]['flat'].is_cuda and not torch.cuda.is_current_stream_capturing():
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
         for b in self.buckets:
@@ -189,10 +204,7 @@ class GradReducer:
         """Graph-replayed training (``GraphedTrainStep`` with reducers): the backward pass ran inside a HIP graph, where no hook fires, so
         every bucket is all-reduced here, between two graph launches, and waited for.  Which parameters received a gradient is a static
         property of the captured iteration kind (``detach_untouched`` ran when it was captured)."""
-        # (no event timing here: an event recorded right after a graph launch is not ordered against the graph's kernels the way a
-        #  stream-ordered launch is -- the pair read 110 ms for the discriminator's exchange; the exposed time of this mode is the whole
-        #  exchange by construction, and bench.py's step_ms carries it)
-        ev0 = ev1 = None
+        # (not event-timed: the exposed time of this mode is the whole exchange by construction; bench.py's step_ms carries it)
         for b in self.buckets:
             b['launched'] = False
             self._launch(b)
@@ -200,9 +212,6 @@ class GradReducer:
             if b['work'] is not None:
                 b['work'].wait()
                 b['work'] = None
-        if ev0 is not None:
-            ev1.record()
-            self._pending_events = getattr(self, '_pending_events', []) + [(ev0, ev1)]
         self.stats['steps'] += 1
         self.stats['buckets_at_finish'] += len(self.buckets)
 

@@ -958,8 +958,10 @@ class _FusedConv(torch.autograd.Function):
             link.premasked = False
             g = dy
             (A, B, Cn), link.sums = link.sums, None
-            dso, db = demod_grad_finish_raw(A, B, Cn, bias, s_out, s_out is not None and need_so, need_b and bias is not None)
-            db = db.to(bias.dtype) if db is not None else None
+            want_so, want_b = s_out is not None and need_so, need_b and bias is not None
+            if want_so or want_b:                      # (frozen parameters and detached styles: only x wants a gradient)
+                dso, db = demod_grad_finish_raw(A, B, Cn, bias, s_out, want_so, want_b)
+                db = db.to(bias.dtype) if db is not None else None
         elif link is not None and link.premasked:
             # the consumer's data-gradient launch already applied lrelu'(y) and summed the channels (agf_conv2d_fwd_mask)
             link.premasked = False

@@ -61,12 +61,22 @@ class TrainStep:
         self.ada = None
         self.policy = policy
         self._pending_ada_state = None
+        # (the p update counts calls on the host -- every ``interval``-th one moves p: under HIP-graph replay it runs after the replay,
+        #  on the D(real) logits the graph left in a static tensor; ``GraphedTrainStep`` sets this while it records / replays)
+        self._defer_ada_update = False
+        self._real_prob = None
         self.augment = (lambda x: self._ada_pipe(x)(x)) if policy == 'ada' else functools.partial(DiffAugment, policy=policy)
         self.latent_dim, self.sampler = latent_dim, sampler
         self.reducer_G, self.reducer_D = reducer_G, reducer_D
         self.loss = NonSaturatingLoss()
         self.r1_loss = r1_regularizer()
-        self.pl_mean = 0.
+        # running mean of the path-length penalty (reference utils.py:31-33, :100-103).  The reference keeps a host float; here it is a
+        # DEVICE scalar updated in place, so that a path-length iteration reads and writes it without a host synchronisation and can be
+        # replayed from a HIP graph (``pl_mean`` -- the property -- reads it back for checkpoints and logs)
+        self._pl_mean = None
+        self._pl_mean_init = 0.
+        if pl_lambda > 0:                                  # made now, not at first use: a tensor created while an iteration is being recorded
+            self._pl_mean_tensor(next(G.parameters()).device)     # would belong to the graph and be re-initialised by every replay
         self.batches_done = 0
         self._arena_D, self._arena_G = ZeroArena(), ZeroArena()        # zero-initialised backward scratch of the two half-steps
         # batched weight preparation (one launch per network and optimizer step)
@@ -74,6 +84,22 @@ class TrainStep:
         self.merge_d_passes = True                      # D(real) and D(fake) of the D-step as one batch-2B pass
         if hasattr(G, 'set_fused_epilogue'):
             G.set_fused_epilogue(pl_lambda == 0)     # the fused modulated conv has no double backward (path length needs it)
+
+    @property
+    def pl_mean(self):
+        return float(self._pl_mean) if self._pl_mean is not None else float(self._pl_mean_init)
+
+    @pl_mean.setter
+    def pl_mean(self, value):
+        if self._pl_mean is not None:
+            self._pl_mean.fill_(float(value))
+        else:
+            self._pl_mean_init = float(value)
+
+    def _pl_mean_tensor(self, device):
+        if self._pl_mean is None:
+            self._pl_mean = torch.full((), self._pl_mean_init, dtype=torch.float32, device=device)
+        return self._pl_mean
 
     def _mbsd_group_size(self):
         from .model import MiniBatchStdDev
@@ -136,7 +162,7 @@ class TrainStep:
 
         if self.G_ema is not None:
             update_ema(G, self.G_ema)
-        if self.ada is not None:
+        if self.ada is not None and not self._defer_ada_update:
             self.ada.update_p(self._real_prob)
         self.batches_done += 1
         # (detached: a caller that keeps the returned images would keep the iteration's autograd nodes -- and their stream -- alive into the
@@ -222,50 +248,67 @@ class TrainStep:
         fake, style = G(z)
         fake_aug = self.augment(fake)
         fake_prob = D(fake_aug)
+        pl_now = None
         if it % self.g_k == 0 and self.pl_lambda > 0 and it != 0:
-            pl = pl_penalty(style, fake, self.pl_mean, None)
+            pl_mean = self._pl_mean_tensor(fake.device)
+            pl = pl_penalty(style, fake, pl_mean, None)
             G_loss = pl * self.pl_lambda * self.g_k
             pl_now = pl.detach().float().clone()
+        else:
+            G_loss = self.loss.g_loss(fake_prob)
+        G_loss.backward()
+        if pl_now is not None:
             if self.reducer_G is not None and dp.dist.is_initialized() and dp.dist.get_world_size() > 1:
                 # the running path-length mean is a statistic of the GLOBAL batch: average it over the replicas so that every rank keeps
                 # the same pl_mean (otherwise their penalties, hence their losses, drift apart)
                 dp.dist.all_reduce(pl_now)
                 pl_now /= dp.dist.get_world_size()
-            self.pl_mean = update_pl_mean(self.pl_mean, float(pl_now))
-        else:
-            G_loss = self.loss.g_loss(fake_prob)
-        G_loss.backward()
+            # (in place, after the backward pass has consumed the old value: the tensor is a static input of a captured iteration)
+            pl_mean.copy_(update_pl_mean(pl_mean, pl_now))
         return G_loss, fake
 
 
 class GraphedTrainStep:
     """The iteration replayed from HIP graphs: the whole body of ``TrainStep.__call__`` -- both half-steps with
     their backward passes, both fused Adam steps, EMA -- is captured once per iteration kind (GAN-loss iteration, lazy-R1 iteration) with
-    ``torch.cuda.graph`` and replayed with ONE host call per iteration, so the ~1 400 launches of an iteration no longer cost host time
+    ``torch.cuda.graph`` and replayed with ONE host call per iteration, so the ~1 000 launches of an iteration no longer cost host time
     (the 128x128 / batch-32 configuration is launch-bound in eager mode).  The kernels, their order and their arithmetic are those of the
-    eager step; random draws come from torch's graph-safe generator state.  Needs (a gradient exchange never sits inside a graph: with
-    reducers the iteration becomes three graphs, see ``__init__``):
-    no path-length penalty (its running mean lives on the host), a DiffAugment policy (the ADA pipe synchronises with the host), capturable
-    optimizers (``build_optimizers(..., capturable=True)``), and input batches of one fixed shape."""
+    eager step; random draws come from torch's graph-safe generator state.  Needs capturable optimizers
+    (``build_optimizers(..., capturable=True)``) and input batches of one fixed shape.
 
-    def __init__(self, step, real, warmup=3):
+    Data parallelism (``dp_mode``):
+      * ``'ingraph'`` (default with RCCL): ONE graph per iteration kind for every world size.  The reducers' backward hooks fire while
+        the backward pass is being RECORDED: each complete bucket is packed and its ``all_reduce`` is recorded on RCCL's stream, forked
+        off the capturing stream at that point of the backward pass and joined by ``GradReducer.finish()`` right before the optimizer
+        nodes -- so the replayed iteration keeps the overlap of the exchange with the rest of backward that the eager hook path has.
+      * ``'segmented'`` (gloo, whose collectives run on host threads, or on request): THREE graphs cut at the two gradient exchanges,
+        the bucket buffers all-reduced between the launches (``GradReducer.exchange_all``); the exchange is then exposed."""
+
+    def __init__(self, step, real, warmup=3, dp_mode=None):
         if (step.reducer_G is None) != (step.reducer_D is None):
             raise RuntimeError('graph capture: both networks or neither must have a gradient reducer')
-        if step.pl_lambda > 0 or step.policy == 'ada':
-            raise RuntimeError('graph capture needs pl_lambda == 0 and a DiffAugment policy')
         self.step, self.graphs = step, {}
-        # Data parallel: no collective inside a graph.  The iteration is captured as THREE graphs cut at the two gradient exchanges; the
-        # bucket buffers are all-reduced between the launches (``GradReducer.exchange_all``).  The overlap of the exchange with the
-        # backward pass is given up (~1 ms per network over xGMI) for the ~6 ms of host / launch time a replayed iteration saves.
-        self.segmented = step.reducer_G is not None
+        reducers = step.reducer_G is not None
+        if dp_mode is None:
+            dp_mode = 'ingraph' if (reducers and step.reducer_G.capturable and step.reducer_D.capturable) else 'segmented'
+        if dp_mode not in ('ingraph', 'segmented'):
+            raise ValueError(f'dp_mode {dp_mode!r}')
+        if reducers and dp_mode == 'ingraph' and not (step.reducer_G.capturable and step.reducer_D.capturable):
+            raise RuntimeError("dp_mode 'ingraph' needs the RCCL backend (gloo collectives cannot be recorded into a graph)")
+        self.dp_mode = dp_mode if reducers else None
+        self.segmented = reducers and dp_mode == 'segmented'
+        if self.segmented and step.pl_lambda > 0:
+            raise RuntimeError('the three-graph data-parallel mode has no place for the all-reduce of the path-length mean (inside the '
+                               "G half-step): use dp_mode='ingraph' (RCCL) or pl_lambda == 0")
+        if reducers:
+            step.reducer_G.early = step.reducer_D.early = not self.segmented
         if self.segmented:
-            step.reducer_G.early = step.reducer_D.early = False
             self.pool = torch.cuda.graph_pool_handle()
         self.static_real = real.clone()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                      # eager iterations first: optimizer state, arenas and caches reach their final size
-            for _ in range(warmup):
+            for _ in range(warmup):                        # (and, with reducers, the RCCL communicator exists before anything is recorded)
                 step(self.static_real)
         torch.cuda.current_stream().wait_stream(side)
 
@@ -274,8 +317,13 @@ class GraphedTrainStep:
         return self.step.batches_done
 
     def _kind(self, it):
+        """What the loop body does at iteration ``it`` (reference utils.py:71-79, :96-106): the lazy R1 penalty replaces D's GAN loss every
+        ``d_k`` iterations, the lazy path-length penalty replaces G's every ``g_k``: up to four kinds, one graph each."""
         st = self.step
-        return 'r1' if (it % st.d_k == 0 and st.r1_lambda > 0 and it != 0) else 'gan'
+        kind = 'r1' if (it % st.d_k == 0 and st.r1_lambda > 0 and it != 0) else 'gan'
+        if it % st.g_k == 0 and st.pl_lambda > 0 and it != 0:
+            kind += '+pl'
+        return kind
 
     def _capture_segments(self, it):
         """Record the three segments of one iteration kind.  Nothing executes here; the hooks of the reducers fire while the backward
@@ -302,23 +350,31 @@ class GraphedTrainStep:
         if kind in self.graphs:
             return
         saved = st.batches_done
-        if self.segmented:
-            self.graphs[kind] = self._capture_segments(it)
-        else:
-            st.batches_done = it
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):                  # records; the Python body runs once and leaves batches_done advanced
-                out = st(self.static_real)
-            self.graphs[kind] = (graph, out)
+        st._defer_ada_update = True
+        try:
+            if self.segmented:
+                graph, out = self._capture_segments(it)
+            else:
+                st.batches_done = it
+                graph = torch.cuda.CUDAGraph()
+                # (with reducers: thread_local, see _capture_segments; the all-reduces are recorded from the backward hooks)
+                mode = dict(capture_error_mode='thread_local') if self.dp_mode == 'ingraph' else {}
+                with torch.cuda.graph(graph, **mode):      # records; the Python body runs once and leaves batches_done advanced
+                    out = st(self.static_real)
+            # (the D(real) logits of THIS kind's graph: what the ADA p update reads after each replay)
+            self.graphs[kind] = (graph, out, st._real_prob)
+        finally:
+            st._defer_ada_update = False
         st.batches_done = saved
 
     def capture_all(self):
         """Record both iteration kinds now (nothing executes, no collective is issued): lets a multi-process caller agree on success
         before the first replay."""
         st = self.step
-        self._capture(1)
-        if st.r1_lambda > 0:
-            self._capture(st.d_k)
+        import math
+        period = math.lcm(st.d_k if st.r1_lambda > 0 else 1, st.g_k if st.pl_lambda > 0 else 1)
+        for it in range(1, period + 1):                    # (captures each distinct kind once, in the order the run meets them)
+            self._capture(it)
 
     def __call__(self, real):
         st = self.step
@@ -326,7 +382,7 @@ class GraphedTrainStep:
         kind = self._kind(it)
         self.static_real.copy_(real)
         self._capture(it)
-        graph, out = self.graphs[kind]
+        graph, out, real_prob = self.graphs[kind]
         if self.segmented:
             graph[0].replay()
             st.reducer_D.exchange_all()
@@ -335,6 +391,8 @@ class GraphedTrainStep:
             graph[2].replay()
         else:
             graph.replay()
+        if st.ada is not None:
+            st.ada.update_p(real_prob)                      # host-counted schedule (reference nnutils/ada.py:25-36), a few tiny launches
         st.batches_done = it + 1
         return out
 
@@ -358,7 +416,7 @@ def train(max_iter, dataset, sampler, const_z, latent_dim,
           device, amp, save=1000, log_every=50, on_save=None, reducer_G=None, reducer_D=None, resume=None, checkpoint_path=None,
           graphs=False, log=print):
     """Same positional signature as the reference's ``train`` (utils.py:35-41).  ``graphs``: replay the iteration from HIP graphs
-    (``GraphedTrainStep``; single process, pl_lambda == 0, DiffAugment policy, capturable optimizers).  Every ``log_every`` iterations one
+    (``GraphedTrainStep``; capturable optimizers).  Every ``log_every`` iterations one
     line with the losses and the throughput since the previous line goes to ``log`` (the reference's ``Status`` shows losses only)."""
     if G_ema is not None:
         G_ema.eval()
@@ -457,7 +515,8 @@ def main(parser, dataset=None):
     const_z = sample_nnoise((16, args.style_dim), device=device)
     G, G_ema, D = build_models(args, device, compute_dtype)
     dp.broadcast_module(G), dp.broadcast_module(G_ema), dp.broadcast_module(D)
-    graphs = bool(args.hip_graphs) and args.pl_lambda == 0 and args.policy != 'ada'      # (several ranks: three graphs per iteration)
+    graphs = bool(args.hip_graphs)          # (every configuration can be recorded: lazy R1 / path length = one graph per iteration kind,
+    #                                          the ADA pipe keeps its margins on the device, RCCL all-reduces are recorded with the backward)
     optimizer_G, optimizer_D = build_optimizers(G, D, args.lr, (args.beta1, args.beta2), args.r1_lambda, args.pl_lambda, args.d_k, args.g_k,
                                                 capturable=graphs)
     reducer_G = dp.GradReducer(G.parameters(), never_used=dp.never_used_parameters(G)) if world > 1 else None

@@ -77,6 +77,66 @@ class _AffineResample(torch.autograd.Function):
         _lib.check(rc, 'affine_resample')
         return dx, None, None, None
 
+_WARP_WORKSPACES = {}
+
+
+def _warp_workspace(B, C, H, W, dtype, device):
+    """Scratch for the x2-upsampled reflect-padded image of ``_WarpNoSync``, sized for the largest margins the pipe can ask for
+    (W - 1 / H - 1 on each side); only the data-dependent extent is ever touched.  One buffer per shape, reused by every call (the calls
+    of a stream are ordered), static under HIP-graph capture."""
+    key = (B, C, H, W, dtype, device)
+    ws = _WARP_WORKSPACES.get(key)
+    if ws is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('the ADA pipe must run once eagerly before it is recorded into a HIP graph (its workspace is allocated on first use)')
+        ws = _WARP_WORKSPACES[key] = torch.empty(B * C * 4 * (3 * H - 2) * (3 * W - 2), dtype=dtype, device=device)
+    return ws
+
+
+class _WarpNoSync(torch.autograd.Function):
+    """reflect-pad by data-dependent margins -> x2 low-pass upsampling -> bilinear affine resampling (reference augment.py:268-283) with the
+    margins kept in device memory: ``agf_ada_pad_up2`` + ``agf_ada_warp_resample``.  No host synchronisation, no tensor whose shape
+    depends on the data (the intermediate lives, densely packed, in a workspace sized for the largest margins) -- the pipe can be
+    recorded into a HIP graph.  theta and the margins carry no gradient; the backward pass is the exact adjoint of both kernels."""
+
+    @staticmethod
+    def forward(ctx, x, theta, margins, f12, Hout, Wout):
+        from .. import _lib
+        x = x.contiguous()
+        theta = theta.detach().float().contiguous()
+        B, C, H, W = x.shape
+        ws = _warp_workspace(B, C, H, W, x.dtype, x.device)
+        L = _lib.lib()
+        rc = L.agf_ada_pad_up2(_lib.ptr(x), _lib.ptr(ws), _lib.ptr(margins), _lib.ptr(f12), _lib.dtype_code(x), B, C, H, W, 0, _lib.stream_ptr(x))
+        _lib.check(rc, 'ada_pad_up2')
+        y = torch.empty((B, C, Hout, Wout), dtype=x.dtype, device=x.device)
+        rc = L.agf_ada_warp_resample(_lib.ptr(ws), _lib.ptr(y), _lib.ptr(theta), _lib.ptr(margins), _lib.dtype_code(x), B, C, H, W, Hout, Wout, 0,
+                                     _lib.stream_ptr(x))
+        _lib.check(rc, 'ada_warp_resample')
+        ctx.save_for_backward(theta, margins, f12)
+        ctx.in_shape = (H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .. import _lib
+        theta, margins, f12 = ctx.saved_tensors
+        if torch.is_grad_enabled() and dy.requires_grad:
+            raise RuntimeError('the fused ADA warp has no double backward')
+        dy = dy.contiguous()
+        B, C, Hout, Wout = dy.shape
+        H, W = ctx.in_shape
+        ws = _warp_workspace(B, C, H, W, dy.dtype, dy.device)
+        L = _lib.lib()
+        rc = L.agf_ada_warp_resample(_lib.ptr(dy), _lib.ptr(ws), _lib.ptr(theta), _lib.ptr(margins), _lib.dtype_code(dy), B, C, H, W, Hout, Wout, 1,
+                                     _lib.stream_ptr(dy))
+        _lib.check(rc, 'ada_warp_resample')
+        dx = torch.empty((B, C, H, W), dtype=dy.dtype, device=dy.device)
+        rc = L.agf_ada_pad_up2(_lib.ptr(dx), _lib.ptr(ws), _lib.ptr(margins), _lib.ptr(f12), _lib.dtype_code(dy), B, C, H, W, 1, _lib.stream_ptr(dy))
+        _lib.check(rc, 'ada_pad_up2')
+        return dx, None, None, None, None, None
+
+
 class _ColorAffine(torch.autograd.Function):
     """y[b] = M[b,:,:3] @ x[b] + M[b,:,3:] on [B,3,HW] RGB planes as one streaming pass (agf_color_affine); M carries no gradient."""
 
@@ -107,6 +167,8 @@ class _ColorAffine(torch.autograd.Function):
 def _color_affine(flat, m):
     return _ColorAffine.apply(flat, m)
 
+HOST_MARGINS = False   # True: the reference's flow (margins read back to the host, a reflect-padded tensor, upsample2d); tests compare the two
+
 _CONSTS = {}
 
 
@@ -120,10 +182,23 @@ def _const_like(ref, value):
     return t
 
 
+def _dev_const(key, device, values):
+    """A read-only fp32 device tensor made from host numbers ONCE per (key, device): a ``torch.tensor(list, device=cuda)`` per call is a
+    pageable host-to-device copy each time -- hundreds per training step, and not something a HIP-graph capture may contain."""
+    k = ('const', key, device)
+    t = _CONSTS.get(k)
+    if t is None:
+        t = _CONSTS[k] = torch.tensor(values, dtype=torch.float32, device=device)
+    return t
+
+
 def _mat(rows, like=None):
     tensors = [v for row in rows for v in row if isinstance(v, torch.Tensor)]
     if not tensors:
-        return torch.tensor(rows, dtype=torch.float32, device=None if like is None else like.device)
+        dev = None if like is None else like.device
+        if dev is not None and dev.type == 'cuda':
+            return _dev_const(tuple(tuple(float(v) for v in row) for row in rows), dev, rows)
+        return torch.tensor(rows, dtype=torch.float32, device=dev)
     ref = tensors[0]
     cols = [v if isinstance(v, torch.Tensor) else _const_like(ref, float(v)) for row in rows for v in row]
     return torch.stack(cols, dim=-1).reshape(ref.shape + (len(rows), len(rows[0])))
@@ -268,7 +343,8 @@ class AugmentPipe(torch.nn.Module):
         # ---- colour: M maps input colour (r,g,b,1) to output colour ----
         eye4 = torch.eye(4, device=dev)
         M = eye4
-        luma = torch.as_tensor(np.asarray([1, 1, 1, 0]) / np.sqrt(3), dtype=torch.float32, device=dev)
+        luma = _dev_const('luma', dev, (np.asarray([1, 1, 1, 0]) / np.sqrt(3)).tolist()) if dev.type == 'cuda' else \
+            torch.as_tensor(np.asarray([1, 1, 1, 0]) / np.sqrt(3), dtype=torch.float32, device=dev)
         vv = torch.outer(luma, luma)
         if self.brightness > 0:
             b = rng.randn([B], dev) * self.brightness_std
@@ -343,12 +419,28 @@ class AugmentPipe(torch.nn.Module):
         cx, cy = (W - 1) / 2, (H - 1) / 2
         taps4 = self.Hz_geom.shape[0] // 4
         # how far the transformed image corners reach outside the frame decides the reflect padding
-        corners = torch.tensor([[-cx, -cy, 1], [cx, -cy, 1], [cx, cy, 1], [-cx, cy, 1]], dtype=torch.float32, device=dev)
+        mk = (lambda key, v: _dev_const((key, H, W, taps4), dev, v)) if dev.type == 'cuda' else \
+            (lambda key, v: torch.tensor(v, dtype=torch.float32, device=dev))
+        corners = mk('corners', [[-cx, -cy, 1], [cx, -cy, 1], [cx, cy, 1], [-cx, cy, 1]])
         reach = (G @ corners.t())[:, :2, :].permute(1, 0, 2).flatten(1)                  # [xy, B*4]
         reach = torch.cat([-reach, reach]).max(dim=1).values                              # x0, y0, x1, y1
-        slack = torch.tensor([taps4 * 2 - cx, taps4 * 2 - cy] * 2, dtype=torch.float32, device=dev)
-        lim = torch.tensor([W - 1, H - 1] * 2, dtype=torch.float32, device=dev)
+        slack = mk('slack', [taps4 * 2 - cx, taps4 * 2 - cy] * 2)
+        lim = mk('lim', [W - 1, H - 1] * 2)
         margin = torch.minimum(torch.clamp(reach + slack, min=0), lim)
+        out_shape = [B, C, (H + taps4 * 2) * 2, (W + taps4 * 2) * 2]
+        if HOST_MARGINS is False and images.is_cuda and images.dtype in (torch.float32, torch.bfloat16) and C <= 4 and H >= 2 and W >= 2 \
+                and not G.requires_grad and self.Hz_geom.ndim == 1 and self.Hz_geom.numel() == 12:
+            # the margins stay on the device (the reference unpacks them into Python ints here: a host synchronisation per call, and a
+            # tensor shape that depends on the data).  Same matrix algebra with 0-d tensors where the reference has Python numbers.
+            m = margin.ceil()
+            mx0, my0, mx1, my1 = m.unbind()
+            Wu, Hu = (mx0 + mx1 + W) * 2, (my0 + my1 + H) * 2                                 # size of the padded, x2-upsampled image
+            G = _shift2((mx0 - mx1) / 2, (my0 - my1) / 2) @ G
+            G = _zoom2(2, 2, like=images) @ G @ _zoom2(0.5, 0.5, like=images)
+            G = _shift2(-0.5, -0.5, like=images) @ G @ _shift2(0.5, 0.5, like=images)
+            G = _zoom2(2 / Wu, 2 / Hu) @ G @ _zoom2(out_shape[3] / 2, out_shape[2] / 2, like=images)
+            images = _WarpNoSync.apply(images, G[:, :2, :], m.to(torch.int32), self.Hz_geom, out_shape[2], out_shape[3])
+            return upfirdn2d.downsample2d(x=images, f=self.Hz_geom, down=2, padding=-taps4 * 2, flip_filter=True)
         mx0, my0, mx1, my1 = [int(v) for v in margin.ceil().to(torch.int32).tolist()]
         images = torch.nn.functional.pad(images, [mx0, mx1, my0, my1], mode='reflect')
         G = _shift2((mx0 - mx1) / 2, (my0 - my1) / 2, like=images) @ G
@@ -357,7 +449,6 @@ class AugmentPipe(torch.nn.Module):
         G = _zoom2(2, 2, like=images) @ G @ _zoom2(0.5, 0.5, like=images)
         G = _shift2(-0.5, -0.5, like=images) @ G @ _shift2(0.5, 0.5, like=images)
         # resample
-        out_shape = [B, C, (H + taps4 * 2) * 2, (W + taps4 * 2) * 2]
         G = _zoom2(2 / images.shape[3], 2 / images.shape[2], like=images) @ G @ _zoom2(out_shape[3] / 2, out_shape[2] / 2, like=images)
         if images.is_cuda and images.dtype in (torch.float32, torch.bfloat16) and C <= 4 and not G.requires_grad:
             images = _AffineResample.apply(images, G[:, :2, :], out_shape[2], out_shape[3])
@@ -373,7 +464,8 @@ class AugmentPipe(torch.nn.Module):
         dev = images.device
         nb = self.Hz_fbank.shape[0]
         assert len(self.imgfilter_bands) == nb
-        power = torch.tensor(np.array([10, 1, 1, 1]) / 13, dtype=torch.float32, device=dev)      # expected 1/f power per band
+        power = _dev_const('power', dev, (np.array([10, 1, 1, 1]) / 13).tolist()) if dev.type == 'cuda' else \
+            torch.tensor(np.array([10, 1, 1, 1]) / 13, dtype=torch.float32, device=dev)           # expected 1/f power per band
         gain = torch.ones([B, nb], device=dev)
         for i, strength in enumerate(self.imgfilter_bands):
             t_i = torch.exp2(rng.randn([B], dev) * self.imgfilter_std)

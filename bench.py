@@ -113,6 +113,10 @@ def main():
                                                          'backward hooks and overlaps the backward pass).  Default for every N: the iteration is replayed '
                                                          'from HIP graphs (GraphedTrainStep: same kernels, one host call per iteration and graph segment); '
                                                          'the iterations sampled for the per-launch roofline timing always run eagerly')
+    ap.add_argument('--dp-mode', default=None, choices=['ingraph', 'segmented'],
+                    help='several ranks under graph replay: ingraph (default with RCCL) = ONE graph per iteration kind with the bucket all-reduces '
+                         'recorded from the backward hooks on the RCCL stream (overlapped with the rest of backward); segmented = three graphs '
+                         'per iteration with the exchange between the launches')
     ap.add_argument('--no-r1-every-step', action='store_true', help='skip the side measurement with the R1 penalty on every iteration')
     ap.add_argument('--no-ada-variant', action='store_true', help='skip the side measurement with the ADA pipe (BASELINE configs[2] "+ ADA")')
     ap.add_argument('--no-upfirdn2d-rows', action='store_true', help='skip the three upfirdn2d roofline rows (SURVEY.md section 8d)')
@@ -143,11 +147,12 @@ def main():
     update_ema(G, G_ema, decay=0)
     dp.broadcast_module(G), dp.broadcast_module(G_ema), dp.broadcast_module(D)
     dp_on = world > 1 or dist.is_initialized()           # (AGF_FORCE_DP=1: a one-rank RCCL group, to exercise the path on a single-GPU box)
-    use_graphs = (not args.eager) and args.augment != 'ada'
-    # ONE execution mode for every N: HIP-graph replay.  With several ranks the iteration is three graphs cut at the two gradient exchanges,
-    # the all-reduce of the bucket buffers issued between the launches (tests/test_hip_dp.py: two ranks on one GPU over gloo, and a one-rank
-    # RCCL group via AGF_FORCE_DP=1).  If ANY rank fails to capture, every rank falls back to the eager loop (all-reduce from backward hooks,
-    # overlapped with the backward pass); --eager selects that loop outright.
+    use_graphs = not args.eager
+    # ONE execution mode for every N: HIP-graph replay, one graph per iteration kind.  With several ranks the bucket all-reduces are part of
+    # the graph: recorded from the reducers' backward hooks on the RCCL stream, forked off the backward pass where a bucket completes and
+    # joined before the optimizer nodes (tests/test_hip_dp.py: a one-rank RCCL group via AGF_FORCE_DP=1; --dp-mode segmented = three graphs
+    # with the exchange between the launches, the mode two ranks on one GPU over gloo are tested in).  If ANY rank fails to capture, every
+    # rank falls back to the eager loop (all-reduce from backward hooks, overlapped with the backward pass); --eager selects that loop.
     opt_G, opt_D = U.build_optimizers(G, D, 0.001, (0., 0.99), 10., 0., 16, 8, capturable=use_graphs)
     red_G = dp.GradReducer(G.parameters(), never_used=dp.never_used_parameters(G)) if dp_on else None
     red_D = dp.GradReducer(D.parameters()) if dp_on else None
@@ -192,7 +197,7 @@ def main():
         # replay issues collectives), so success is agreed on first and the eager loop is the fallback.
         ok = 1
         try:
-            step = U.GraphedTrainStep(eager_step, real, warmup=1)
+            step = U.GraphedTrainStep(eager_step, real, warmup=1, dp_mode=args.dp_mode)
             step.capture_all()
         except Exception as exc:                   # noqa: BLE001 -- any capture failure means: run eagerly
             print(f'[bench] rank {rank}: graph capture failed ({type(exc).__name__}: {exc}); eager launches', file=sys.stderr)
@@ -207,6 +212,7 @@ def main():
                 if red is not None:
                     red.early = True
         eager_step.batches_done = 0
+    runner = step if use_graphs else None
     if use_graphs:
         # one untimed replay of EACH captured graph: the first launch of a graph uploads its ~1 500 nodes to the device, a one-off cost that
         # would otherwise sit inside the timed window for the lazy-R1 graph (first replayed at iteration 16).  The replays are ordinary
@@ -282,23 +288,39 @@ def main():
 
     # BASELINE.json configs[2] literally reads "StyleGAN2 256x256 + ADA + R1": the same iteration with the adaptive augmentation pipe
     # (thirdparty/ada.py, 12 augmentations, p adapted from sign(D(real))) instead of DiffAugment -- a side figure measured after the window on
-    # the same networks; the pipe synchronises with the host once per iteration (its p update), so these iterations are launched eagerly
+    # the same networks.  The pipe keeps its reflect-padding margins on the device (agf_ada_pad_up2), so the iteration is replayed from a
+    # HIP graph like the headline; p is set to 0.3 first (it starts at 0 and moves by 5e-4 per interval: at p = 0 every augmentation is
+    # gated off and the pipe's cost would not show)
     ada_out = None
     if not args.no_ada_variant and args.augment != 'ada' and not dp_on:
-        ada_step = U.TrainStep(G, G_ema, D, opt_G, opt_D, 10., 0., 16, 8, 'ada', 512, functools.partial(sample_nnoise, device=dev))
+        ada_opt_G, ada_opt_D = (opt_G, opt_D)
+        ada_step = U.TrainStep(G, G_ema, D, ada_opt_G, ada_opt_D, 10., 0., 16, 8, 'ada', 512, functools.partial(sample_nnoise, device=dev))
         ada_step.batches_done = 1
-        for _ in range(3):
+        ada_step(real)
+        ada_step.ada.p.fill_(0.3)
+        for _ in range(2):
             ada_step(real)
+        ada_run, ada_exec = ada_step, 'eager launches'
+        if use_graphs:
+            try:
+                ada_run = U.GraphedTrainStep(ada_step, real, warmup=0)
+                ada_step.batches_done = 1
+                ada_run(real)                              # records the GAN-loss kind and replays it once
+                ada_exec = 'hip-graph replay'
+            except Exception as exc:                       # noqa: BLE001
+                print(f'[bench] ADA variant: graph capture failed ({type(exc).__name__}: {exc}); eager launches', file=sys.stderr)
+                ada_run = ada_step
         barrier()
         n_ada = 8
         ta = time.perf_counter()
         for _ in range(n_ada):
-            ada_step(real)
+            ada_step.batches_done = 1                      # GAN-loss iterations (the lazy-R1 ones cost the same extra as in the headline)
+            ada_run(real)
         barrier()
         ada_ms = (time.perf_counter() - ta) / n_ada * 1e3
         ada_out = {'value': round(args.batch * world / (ada_ms * 1e-3), 2), 'unit': 'img/s', 'ms_per_step': round(ada_ms, 3), 'steps': n_ada,
-                   'p': round(float(ada_step.ada.p) if hasattr(ada_step.ada, 'p') else -1.0, 4),
-                   'note': 'configs[2] "+ ADA": GAN-loss iterations with the ADA pipe in place of DiffAugment, eager launches, after the timed window'}
+                   'p': round(float(ada_step.ada.p), 4), 'execution': ada_exec,
+                   'note': 'configs[2] "+ ADA": GAN-loss iterations with the ADA pipe (12 augmentations, p forced to 0.3) in place of DiffAugment, after the timed window'}
     fir_out = None
     if rank == 0 and not args.no_upfirdn2d_rows:
         fir_out = upfirdn2d_roofline(dev, args.batch)
@@ -318,7 +340,8 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'bf16', 'data': 'synthetic', 'execution': ('hip-graph replay (the event-timed roofline sample is one eager iteration after the window)' + (': three graphs per iteration, gradient all-reduce between the launches' if dp_on else '')) if use_graphs else 'eager launches',
+            'dtype': 'bf16', 'data': 'synthetic', 'execution': ('hip-graph replay (the event-timed roofline sample is one eager iteration after the window)' + ((': three graphs per iteration, gradient all-reduce between the launches' if (runner is not None and runner.segmented) else
+                                                                                                                                     ': one graph per iteration kind, bucket all-reduces recorded on the RCCL stream from the backward hooks') if dp_on else '')) if use_graphs else 'eager launches',
             'config': {'workload': f'StyleGAN2 {S}x{S} G+D+lazy-R1 training step, batch {args.batch}/GPU '
                                    f'(BASELINE.json configs[2]: channels 32, max 512, style 512, d_k 16, r1_lambda 10, '
                                    + ('ADA pipe (12 augmentations, adaptive p)' if args.augment == 'ada' else f'DiffAugment {args.augment} = the reference SG2 default; --augment ada selects the ADA pipe') + ', Adam, EMA)',

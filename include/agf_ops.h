@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define AGF_ABI_VERSION 14
+#define AGF_ABI_VERSION 15
 
 /* element types of activation tensors */
 enum { AGF_F32 = 0, AGF_F16 = 1, AGF_BF16 = 2, AGF_F64 = 3 };
@@ -327,6 +327,22 @@ int agf_color_affine(const void* x, void* y, const float* m, int dtype, int32_t 
  * gather over the pre-image of each input pixel's bilinear support (no atomics, no grid gradient).  NCHW, fp32 or bf16, C <= 4. */
 int agf_affine_resample(const void* x, void* y, const float* theta, int dtype, int32_t B, int32_t C,
                         int32_t Hin, int32_t Win, int32_t Hout, int32_t Wout, int backward, void* stream);
+
+/* ADA geometric warp WITHOUT the host read-back of the reflect-padding margins (ABI v15).  The reference sizes its padded tensor from
+ * `margin.ceil().to(torch.int32)` unpacked into Python ints (thirdparty/ada/augment.py:268-272) -- a device-to-host synchronisation per
+ * call, which also keeps the pipe out of a HIP graph.  Here `margins` = (x0, y0, x1, y1) int32 stays in DEVICE memory:
+ *   agf_ada_pad_up2      backward = 0: x [B,C,H,W] -> u = upsample2d(reflect_pad(x, margins), f12, up=2)  (augment.py:272-275), DENSELY
+ *                        PACKED as [B, C, 2 (H + y0 + y1), 2 (W + x0 + x1)] in a workspace the caller sizes for the largest margins
+ *                        (x0, x1 <= W - 1; y0, y1 <= H - 1): B * C * 4 (3H - 2)(3W - 2) elements.  The reflect padding is index math
+ *                        inside the 12-tap polyphase gather.  backward = 1: u holds the gradient of that tensor, x receives the
+ *                        gradient of the image (adjoint FIR + fold of the reflected positions), every element written.
+ *   agf_ada_warp_resample  agf_affine_resample whose input is that workspace (its extent read from `margins`; Hb, Wb = H, W above).
+ *                        backward = 1: x = dy [B,C,Hout,Wout], y = the workspace, which receives du over its whole dynamic extent.
+ * f12: the 12 taps of AugmentPipe.Hz_geom (fp32, device).  NCHW, fp32 or bf16, C <= 4 for the resampling. */
+int agf_ada_pad_up2(const void* x, void* u, const int32_t* margins, const float* f12, int dtype, int32_t B, int32_t C,
+                    int32_t H, int32_t W, int backward, void* stream);
+int agf_ada_warp_resample(const void* x, void* y, const float* theta, const int32_t* margins, int dtype, int32_t B, int32_t C,
+                          int32_t Hb, int32_t Wb, int32_t Hout, int32_t Wout, int backward, void* stream);
 
 /* Border correction of the fused  nn.Upsample(x2, bilinear) -> Blur2d  pair of the StyleGAN2 generator (implementations/StyleGAN2/
  * model.py:138-175).  blur(up(x)) equals ONE clamp-mode agf_upfirdn2d with the composite filter [1,5,10,10,5,1] x itself except on the

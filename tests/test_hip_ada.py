@@ -138,3 +138,57 @@ def test_fused_affine_resample_matches_grid_sample(shape):
     for a, b in zip(outs[0], outs[1]):
         assert a.shape == b.shape
         assert (a - b).abs().max().item() <= 2e-4 * max(1.0, b.abs().max().item())
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('shape,pv', [((4, 3, 32, 32), 1.0), ((3, 3, 24, 40), 0.7), ((2, 1, 16, 16), 1.0)])
+def test_warp_with_device_side_margins_equals_the_host_margin_flow(shape, pv, dtype):
+    """The capturable geometric warp (margins kept on the device: agf_ada_pad_up2 + agf_ada_warp_resample, no padded tensor, no
+    data-dependent shape) against the reference's flow on the same operators (margins read back to the host, F.pad(reflect),
+    upsample2d, resampling of a tensor of data-dependent size) from the same random draws -- outputs and image gradients.  The margins of
+    these draws reach the clamp at W - 1 for the strong scale / rotation draws and 6 for the identity ones."""
+    from animeface_amd.thirdparty import ada as A
+    from animeface_amd import rng
+    g = torch.Generator().manual_seed(21)
+    x0 = torch.randn(*shape, generator=g).to(DEV).to(dtype)
+    dy = torch.randn(*shape, generator=g).to(DEV).to(dtype)
+    pipe = A.AugmentPipe(xflip=1, rotate90=1, xint=1, scale=1, rotate=1, aniso=1, xfrac=1).to(DEV)
+    pipe.p.copy_(torch.tensor(pv))
+    res = []
+    for host in (True, False):
+        A.HOST_MARGINS = host
+        try:
+            x = x0.clone().requires_grad_(True)
+            with rng.cpu_stream():
+                torch.manual_seed(77)
+                y = pipe(x)
+            (gx,) = torch.autograd.grad(y, x, dy)
+            res.append((y.detach().float().cpu(), gx.float().cpu()))
+        finally:
+            A.HOST_MARGINS = False
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    for a, b in zip(res[0], res[1]):
+        assert a.shape == b.shape
+        assert (a - b).abs().max().item() <= tol * max(1.0, a.abs().max().item()), (a - b).abs().max().item()
+
+
+def test_the_pipe_issues_no_host_synchronisation():
+    """``torch.cuda.set_sync_debug_mode('error')`` raises on every synchronising call: the whole pipe (all 12 augmentations + the p update)
+    must run without one -- the property HIP-graph capture needs (the reference's pipe synchronises on the margins, augment.py:270)."""
+    from animeface_amd.nnutils.ada import ADA
+    ada = ADA(8, 2, 1, 0.6).to(DEV)
+    ada.p.fill_(0.8)
+    x = torch.randn(8, 3, 32, 32, device=DEV)
+    logits = torch.randn(8, 1, device=DEV)
+    y = ada(x)                                               # first call: constants and the workspace are made (copies from the host)
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode('error')
+    try:
+        for _ in range(3):
+            xg = x.clone().requires_grad_(True)
+            y = ada(xg)
+            y.square().mean().backward()
+            ada.update_p(logits)
+    finally:
+        torch.cuda.set_sync_debug_mode('default')
+    assert torch.isfinite(y).all() and torch.isfinite(xg.grad).all()

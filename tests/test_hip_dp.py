@@ -274,3 +274,91 @@ def test_graph_replay_under_data_parallelism_equals_the_eager_exchange(tmp_path)
     # fp32: the two runs differ by summation order only (rocBLAS split-K / fp32 atomics); six Adam steps of lr 1e-3 with beta1 = 0 turn a
     # gradient that changes sign near zero into a +-lr step, so single weights may sit up to a few lr apart -- but only a handful
     assert worst <= 6e-3 and far <= 1e-3 * total, (worst, far, total)          # (one run in four takes another of the 2-3 run-to-run outcomes: ~50 of 390 000 weights)
+
+
+def _worker_rccl_ingraph(rank, world, port, out, mode):
+    """ONE rank, fp32, device generator.  mode: 'single' = no process group, the single-process single-graph replay; 'ingraph' = a one-rank
+    RCCL group (AGF_FORCE_DP=1) with the bucket all-reduces recorded into the graph from the backward hooks; 'segmented' = the same group
+    with three graphs per iteration and the exchange between the launches."""
+    import sys
+    import functools
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    if mode != 'single':
+        os.environ['AGF_FORCE_DP'] = '1'
+    from animeface_amd import distributed as dp
+    from animeface_amd.implementations.StyleGAN2 import model as M, utils as U
+    from animeface_amd.nnutils import sample_nnoise, update_ema
+    dp.init_distributed()
+    assert dp.dist.is_initialized() == (mode != 'single')
+    if mode != 'single':
+        assert dp.dist.get_backend() == 'nccl'
+    dev = torch.device('cuda', 0)
+    torch.manual_seed(0)
+    mk = lambda: M.Generator(CFG['image_size'], 3, CFG['style_dim'], CFG['channels'], CFG['max_channels'], 2, CFG['map_num_layers'], True, 0.01,
+                             compute_dtype=torch.float32)
+    G, G_ema = mk().to(dev), mk().to(dev)
+    D = M.Discriminator(CFG['image_size'], 3, CFG['channels'], CFG['max_channels'], 2, 4, compute_dtype=torch.float32).to(dev)
+    G.init_weight(functools.partial(M.init_weight_N01, lr=0.01), M.init_weight_N01)
+    D.apply(M.init_weight_N01)
+    G_ema.eval()
+    update_ema(G, G_ema, decay=0)
+    opt_G, opt_D = U.build_optimizers(G, D, 0.001, (0., 0.99), 10., 0., D_K, 8, capturable=True)
+    red_G = red_D = None
+    if mode != 'single':
+        red_G = dp.GradReducer(G.parameters(), bucket_bytes=1 << 18, never_used=dp.never_used_parameters(G))
+        red_D = dp.GradReducer(D.parameters(), bucket_bytes=1 << 18)
+        assert red_G.collectives and red_G.capturable and len(red_G.buckets) >= 3
+    step = U.TrainStep(G, G_ema, D, opt_G, opt_D, 10., 0., D_K, 8, 'color,translation', CFG['style_dim'],
+                       functools.partial(sample_nnoise, device=dev), red_G, red_D)
+    real = _shard(0, dev)
+    torch.manual_seed(1000)
+    for _ in range(2):
+        step(real)
+    runner = U.GraphedTrainStep(step, real, warmup=0, dp_mode=None if mode != 'segmented' else 'segmented')
+    if mode == 'ingraph':
+        assert runner.dp_mode == 'ingraph' and not runner.segmented
+    runner.capture_all()
+    losses = []
+    for _ in range(6):
+        dl, gl, _ = runner(real)
+        losses.append((float(dl), float(gl)))
+    torch.cuda.synchronize()
+    if mode == 'ingraph':
+        # every bucket except the never-used one (and, on lazy-R1 iterations, the one holding D's last bias) was launched from a hook
+        # while the backward pass was being recorded, i.e. its all-reduce sits beside the rest of backward inside the graph
+        rep = red_G.overlap_report()
+        assert rep['steps'] == 4 and rep['buckets_from_hooks'] >= (len(red_G.buckets) - 1) * rep['steps'], rep      # 2 eager + 2 recorded
+        scale = dp.never_used_parameters(G)[0]
+        assert not opt_G.state.get(scale), 'Adam stepped a parameter that never received a gradient'
+    torch.save(dict(G={k: v.cpu() for k, v in G.state_dict().items()}, D={k: v.cpu() for k, v in D.state_dict().items()},
+                    G_ema={k: v.cpu() for k, v in G_ema.state_dict().items()}, losses=losses), f'{out}.{mode}')
+    if mode != 'single':
+        dp.dist.barrier()
+        dp.dist.destroy_process_group()
+
+
+def test_rccl_all_reduce_recorded_inside_the_graph_equals_the_single_process_replay(tmp_path):
+    """The default data-parallel mode: ONE HIP graph per iteration kind, the bucket all-reduces recorded on the RCCL stream from the backward
+    hooks.  A one-rank RCCL group (AGF_FORCE_DP=1) exercises process group, hooks, capture of the collectives and replay on a single GPU;
+    averaged over one rank the exchange is the identity, so losses and weights must equal the single-process replay from the same seeds
+    (fp32: summation noise), and the three-graph mode on the same group."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / 'rccl')
+    for mode in ('single', 'ingraph', 'segmented'):
+        mp.start_processes(_worker_rccl_ingraph, args=(1, _free_port(), out, mode), nprocs=1, join=True, start_method='spawn')
+    ref = torch.load(f'{out}.single')
+    for mode in ('ingraph', 'segmented'):
+        got = torch.load(f'{out}.{mode}')
+        print(f'losses single : {ref["losses"]}\nlosses {mode}: {got["losses"]}')
+        for (d0, g0), (d1, g1) in zip(ref['losses'], got['losses']):
+            assert abs(d0 - d1) <= 1e-4 * max(1.0, abs(d0)) and abs(g0 - g1) <= 1e-4 * max(1.0, abs(g0))
+        worst, far, total = 0.0, 0, 0
+        for name in ('G', 'D', 'G_ema'):
+            for k in ref[name]:
+                diff = (ref[name][k].float() - got[name][k].float()).abs()
+                worst = max(worst, float(diff.max()))
+                far += int((diff > 1e-4).sum())
+                total += diff.numel()
+        print(f'{mode}: largest weight difference vs the single-process replay {worst:.3g}; {far} of {total} beyond 1e-4')
+        assert worst <= 8e-3 and far <= 1e-3 * total, (mode, worst, far, total)

@@ -350,9 +350,12 @@ def test_full_size_step_properties():
         assert d0 == pytest.approx(d1, rel=2e-3, abs=1e-5) and g0 == pytest.approx(g1, rel=5e-3, abs=1e-4), (a, b)
 
 
-@pytest.mark.parametrize('dtype,d_k,iters', [(torch.float32, 2, 6), (torch.bfloat16, 2, 6), (torch.float32, 4, 15)],
-                         ids=['fp32', 'bf16', 'fp32-gan-graph-first-three-r1-replays'])
-def test_graph_replayed_step_equals_the_eager_step(dtype, d_k, iters):
+@pytest.mark.parametrize('dtype,d_k,iters,pl_lambda,policy',
+                         [(torch.float32, 2, 6, 0., 'color,translation'), (torch.bfloat16, 2, 6, 0., 'color,translation'),
+                          (torch.float32, 4, 15, 0., 'color,translation'), (torch.float32, 2, 8, 2., 'color,translation'),
+                          (torch.float32, 2, 6, 0., 'ada')],
+                         ids=['fp32', 'bf16', 'fp32-gan-graph-first-three-r1-replays', 'fp32-path-length-g_k-3', 'fp32-ada-pipe'])
+def test_graph_replayed_step_equals_the_eager_step(dtype, d_k, iters, pl_lambda, policy):
     """GraphedTrainStep (the iteration captured into HIP graphs, one per iteration kind) against the eager TrainStep from the same seeds:
     the captured kernels, their order and torch's graph-safe random offsets are those of the eager run, so losses and weights agree --
     to fp32 summation noise in fp32 mode; in bf16 the losses agree and the weights are compared statistically (see tests/test_hip_dp.py
@@ -369,13 +372,16 @@ def test_graph_replayed_step_equals_the_eager_step(dtype, d_k, iters):
         D.apply(M.init_weight_N01)
         G_ema.eval()
         update_ema(G, G_ema, decay=0)
-        oG, oD = U.build_optimizers(G, D, 0.001, (0., 0.99), 10., 0., d_k, 8, capturable=True)
-        step = U.TrainStep(G, G_ema, D, oG, oD, 10., 0., d_k, 8, 'color,translation', TINY['style_dim'], functools.partial(sample_nnoise, device=DEV))
+        g_k = 3 if pl_lambda > 0 else 8                      # d_k = 2, g_k = 3: all four iteration kinds occur (gan, r1, gan+pl, r1+pl)
+        oG, oD = U.build_optimizers(G, D, 0.001, (0., 0.99), 10., pl_lambda, d_k, g_k, capturable=True)
+        step = U.TrainStep(G, G_ema, D, oG, oD, 10., pl_lambda, d_k, g_k, policy, TINY['style_dim'], functools.partial(sample_nnoise, device=DEV))
         gen = torch.Generator().manual_seed(9)
         real = (torch.rand(8, 3, 16, 16, generator=gen) * 2 - 1).to(DEV)
         torch.manual_seed(123)
         for _ in range(2):                                   # the warm-up GraphedTrainStep runs eagerly, in both arms
             step(real)
+        if policy == 'ada':
+            step.ada.p.fill_(0.6)                            # every augmentation of the pipe does work (p starts at 0 and moves by 1e-4 steps)
         runner = U.GraphedTrainStep(step, real, warmup=0) if graphed else step
         if graphed and d_k > 2:
             # the order bench.py uses: the GAN-loss graph is recorded BEFORE the lazy-R1 graph, whose backward takes more zeroed scratch
@@ -388,7 +394,12 @@ def test_graph_replayed_step_equals_the_eager_step(dtype, d_k, iters):
             losses.append((float(dl), float(gl)))
         assert step.batches_done == 2 + iters
         if graphed:
-            assert set(runner.graphs) == {'gan', 'r1'}
+            assert set(runner.graphs) == ({'gan', 'r1', 'gan+pl', 'r1+pl'} if pl_lambda > 0 else {'gan', 'r1'})
+        if pl_lambda > 0:
+            assert np.isfinite(step.pl_mean) and step.pl_mean > 0
+            losses.append((step.pl_mean, step.pl_mean))      # the device-side running mean is compared like a loss
+        if policy == 'ada':
+            losses.append((float(step.ada.p), float(step.ada.signsum)))
         return losses, {k: v.detach().clone() for k, v in list(G.state_dict().items()) + [('D.' + k, v) for k, v in D.state_dict().items()]}
     le, we = run(False)
     lg, wg = run(True)
