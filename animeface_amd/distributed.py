@@ -61,6 +61,7 @@ class GradReducer:
         self._touched = set()
         self.stats = dict(steps=0, buckets_from_hooks=0, buckets_at_finish=0, exposed_ms=0.0)
         self.measure = False             # bench.py: time the compute stream's wait in finish() with events
+        self.recording = False           # set by GraphedTrainStep while the iteration is recorded (dp_mode 'ingraph')
         self.early = True                # launch complete buckets from the backward hooks (False: all at finish(); the graph-segmented loop)
         skip = {id(p) for p in never_used}
         idle = [p for p in self.params if id(p) in skip]
@@ -129,12 +130,27 @@ class GradReducer:
             return
         bucket['launched'] = True
         if self.collectives:
+            if self.recording and not torch.cuda.is_current_stream_capturing():
+                # a collective issued from a stream outside the capture while RCCL's stream is inside it would be recorded into the graph
+                # AND handed to the process group's watchdog, which aborts the process when it polls the recorded event: fail here instead
+                raise RuntimeError('GradReducer: a bucket became complete on a stream that is not being recorded '
+                                   f'(stream {torch.cuda.current_stream().cuda_stream:#x}) while the iteration is recorded into a HIP graph')
             if dist.get_backend(self.group) == 'nccl':
                 # RCCL averages inside the reduction: no extra pass over the bucket
                 bucket['work'] = dist.all_reduce(bucket['flat'], op=dist.ReduceOp.AVG, group=self.group, async_op=True)
             else:
                 bucket['flat'].div_(self.world)
                 bucket['work'] = dist.all_reduce(bucket['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def drain(self):
+        """Before an iteration is recorded into a HIP graph: wait until the process group's watchdog thread has retired every collective
+        issued so far.  The watchdog polls (every 100 ms) the end events of the collectives it still holds; such a poll, landing after
+        RCCL's stream has joined the capture, aborts the process with hipErrorCapturedEvent -- the first recorded all-reduce comes within
+        ~50 ms of the start of the recording, so without this the capture lost that race in about one run in ten."""
+        if self.collectives and dist.get_backend(self.group) == 'nccl':
+            torch.cuda.synchronize()
+            pg = self.group if self.group is not None else dist.distributed_c10d._get_default_group()
+            pg._wait_for_pending_works()
 
     def zero_grad(self):
         """``grad = None`` for every parameter: the backward pass then hands each gradient tensor over as it is (no accumulation launch

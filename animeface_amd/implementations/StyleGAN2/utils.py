@@ -358,9 +358,19 @@ class GraphedTrainStep:
                 st.batches_done = it
                 graph = torch.cuda.CUDAGraph()
                 # (with reducers: thread_local, see _capture_segments; the all-reduces are recorded from the backward hooks)
-                mode = dict(capture_error_mode='thread_local') if self.dp_mode == 'ingraph' else {}
-                with torch.cuda.graph(graph, **mode):      # records; the Python body runs once and leaves batches_done advanced
-                    out = st(self.static_real)
+                ingraph = self.dp_mode == 'ingraph'
+                mode = dict(capture_error_mode='thread_local') if ingraph else {}
+                if ingraph:
+                    st.reducer_G.drain()
+                    st.reducer_G.recording = st.reducer_D.recording = True
+                try:
+                    # (with reducers the backward passes run on THIS thread while they are recorded: the hooks then issue the collectives
+                    #  from the thread that owns the capture, with the capturing stream current)
+                    with torch.autograd.set_multithreading_enabled(not ingraph), torch.cuda.graph(graph, **mode):
+                        out = st(self.static_real)         # records; the Python body runs once and leaves batches_done advanced
+                finally:
+                    if ingraph:
+                        st.reducer_G.recording = st.reducer_D.recording = False
             # (the D(real) logits of THIS kind's graph: what the ADA p update reads after each replay)
             self.graphs[kind] = (graph, out, st._real_prob)
         finally:

@@ -315,14 +315,20 @@ def _worker_rccl_ingraph(rank, world, port, out, mode):
     torch.manual_seed(1000)
     for _ in range(2):
         step(real)
+    import datetime
+    mark = lambda what: print(datetime.datetime.now().strftime('%H:%M:%S.%f'), mode, what, flush=True)
+    mark('eager done')
     runner = U.GraphedTrainStep(step, real, warmup=0, dp_mode=None if mode != 'segmented' else 'segmented')
     if mode == 'ingraph':
         assert runner.dp_mode == 'ingraph' and not runner.segmented
+    mark('capture begins')
     runner.capture_all()
+    mark('captured')
     losses = []
     for _ in range(6):
         dl, gl, _ = runner(real)
         losses.append((float(dl), float(gl)))
+        mark('replayed')
     torch.cuda.synchronize()
     if mode == 'ingraph':
         # every bucket except the never-used one (and, on lazy-R1 iterations, the one holding D's last bias) was launched from a hook
