@@ -23,7 +23,7 @@ EXPORTS = ['agf_abi_version', 'agf_last_error', 'agf_device_info', 'agf_upfirdn2
            'agf_filtered_lrelu', 'agf_filtered_lrelu_act', 'agf_conv2d_fwd', 'agf_conv2d_fwd_mask', 'agf_conv2d_s2_fwd', 'agf_conv2d_s2_dgrad', 'agf_conv2d_wgrad', 'agf_conv2d_wgrad_ws', 'agf_conv2d_wgrad_workspace_bytes',
            'agf_act_bwd_reduce', 'agf_act_bwd_reduce_pooled', 'agf_act_bwd_reduce_scaled', 'agf_scale_dot', 'agf_demod_grad_finish', 'agf_planar_to_cl_pad', 'agf_cl_to_planar_crop', 'agf_cl_pad', 'agf_prep_weights', 'agf_prep_weights_multi', 'agf_prep_weights_blocks',
            'agf_modulate_weights', 'agf_conv2d_fwd_wimg', 'agf_conv2d_fwd_wimg_covers',
-           'agf_wsq', 'agf_style_demod_fwd', 'agf_style_demod_fwd_ld', 'agf_style_demod_bwd', 'agf_diffaug_sum', 'agf_diffaug_apply', 'agf_color_affine', 'agf_affine_resample', 'agf_ada_pad_up2', 'agf_ada_warp_resample', 'agf_upblur_border', 'agf_image_resample_rows', 'agf_image_finish']
+           'agf_wsq', 'agf_style_demod_fwd', 'agf_style_demod_fwd_ld', 'agf_style_demod_bwd', 'agf_diffaug_sum', 'agf_diffaug_apply', 'agf_color_affine', 'agf_affine_resample', 'agf_ada_pad_up2', 'agf_ada_warp_resample', 'agf_upblur_border', 'agf_torgb_covers', 'agf_torgb_fwd', 'agf_torgb_bwd_workspace_floats', 'agf_torgb_bwd', 'agf_image_resample_rows', 'agf_image_finish']
 
 _lib = None
 _i32x4 = ctypes.c_int32 * 4
@@ -134,10 +134,34 @@ def lib():
         L.agf_image_resample_rows.argtypes = [_vp] * 5 + [ctypes.c_int32] * 8 + [_vp]
         L.agf_image_finish.restype = ctypes.c_int
         L.agf_image_finish.argtypes = [_vp] * 5 + [ctypes.c_int32, _vp, ctypes.c_int] + [ctypes.c_int32] * 6 + [ctypes.c_int, _vp]
-        if L.agf_abi_version() != 15:
+        L.agf_torgb_covers.restype = ctypes.c_int
+        L.agf_torgb_covers.argtypes = [ctypes.c_int32, ctypes.c_int32]
+        L.agf_torgb_fwd.restype = ctypes.c_int
+        L.agf_torgb_fwd.argtypes = [_vp] * 4 + [ctypes.c_int64, _vp, _vp, ctypes.c_int] + [ctypes.c_int32] * 5 + [ctypes.c_float, _vp]
+        L.agf_torgb_bwd_workspace_floats.restype = ctypes.c_int64
+        L.agf_torgb_bwd_workspace_floats.argtypes = [ctypes.c_int32] * 5
+        L.agf_torgb_bwd.restype = ctypes.c_int
+        L.agf_torgb_bwd.argtypes = [_vp] * 4 + [ctypes.c_int64] + [_vp] * 5 + [ctypes.c_int64, ctypes.c_int] + [ctypes.c_int32] * 5 + [ctypes.c_float, _vp]
+        if L.agf_abi_version() != 16:
             raise AgfError('libagf_ops.so ABI version mismatch')
         _lib = L
     return _lib
+
+
+_hip = None
+
+
+def memset_node(buf, nbytes):
+    """``hipMemsetAsync(buf, 0, nbytes)`` on torch's current stream: under capture this records a MEMSET NODE (torch's own fills are kernel
+    nodes).  Used only to shape the node structure of a recorded iteration (``TrainStep._pace``)."""
+    global _hip
+    if _hip is None:
+        _hip = ctypes.CDLL('libamdhip64.so')
+        _hip.hipMemsetAsync.restype = ctypes.c_int
+        _hip.hipMemsetAsync.argtypes = [_vp, ctypes.c_int, ctypes.c_size_t, _vp]
+    rc = _hip.hipMemsetAsync(_vp(buf.data_ptr()), 0, nbytes, _vp(torch.cuda.current_stream(buf.device).cuda_stream))
+    if rc != 0:
+        raise AgfError(f'hipMemsetAsync failed with status {rc}')
 
 
 def check(rc, what):

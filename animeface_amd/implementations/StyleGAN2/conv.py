@@ -855,6 +855,63 @@ def pool2x_linked(x, f, gain, link):
     return _PoolLinked.apply(x, f, gain, link)
 
 
+def torgb_covers(x, image_channels):
+    return x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and bool(_lib.lib().agf_torgb_covers(x.shape[1], image_channels))
+
+
+class _ToRGB(torch.autograd.Function):
+    """ToImage's 1x1 modulated conv without demodulation + skip sum (reference model.py:239-250) from channels-last features to a PLANAR
+    image, one streaming launch each way (``agf_torgb_fwd`` / ``agf_torgb_bwd``):
+    ``out = coef * conv1x1(x * (s_raw + 1), weight) + bias + pre``.  ``s_raw`` is the affine's raw output (a column block of the batched
+    style GEMM is read in place through its row stride).  First-order only, like the fused modulated conv."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, s_raw, pre, coef):
+        x = x.contiguous(memory_format=torch.channels_last)
+        N, C, H, W = x.shape
+        IC = weight.shape[0]
+        w = _f32(weight.detach()).reshape(IC, C)
+        b = _f32(bias.detach()).reshape(-1) if bias is not None else None
+        s_raw = s_raw.detach()
+        if not (s_raw.dtype == torch.float32 and s_raw.dim() == 2 and s_raw.stride(1) == 1 and s_raw.stride(0) >= C):
+            s_raw = _f32(s_raw)
+        p = pre.detach().to(x.dtype).contiguous() if pre is not None else None
+        out = torch.empty((N, IC, H, W), dtype=x.dtype, device=x.device)
+        rc = _lib.lib().agf_torgb_fwd(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(s_raw), s_raw.stride(0), _lib.ptr(p), _lib.ptr(out),
+                                      _lib.dtype_code(x), N, H, W, C, IC, float(coef), _lib.stream_ptr(x))
+        _lib.check(rc, 'torgb_fwd')
+        ctx.save_for_backward(x, weight, s_raw)
+        ctx.coef, ctx.has_pre, ctx.bias_shape = float(coef), pre is not None, (tuple(bias.shape) if bias is not None else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, s_raw = ctx.saved_tensors
+        if torch.is_grad_enabled() and dy.requires_grad:
+            raise RuntimeError('the fused ToRGB layer has no double backward; build the generator with fused_epilogue=False when pl_lambda > 0')
+        need_x, need_w, need_b, need_s, need_pre = ctx.needs_input_grad[:5]
+        N, C, H, W = x.shape
+        IC = weight.shape[0]
+        dy = dy.to(x.dtype).contiguous()
+        w = _f32(weight.detach()).reshape(IC, C)
+        dx = torch.empty_like(x)
+        ds = torch.empty((N, C), dtype=torch.float32, device=x.device) if need_s else None
+        dw = torch.empty((IC, C), dtype=torch.float32, device=x.device) if need_w else None
+        db = torch.empty((IC,), dtype=torch.float32, device=x.device) if (need_b and ctx.bias_shape is not None) else None
+        L = _lib.lib()
+        nws = int(L.agf_torgb_bwd_workspace_floats(N, H, W, C, IC))
+        ws = torch.empty(nws, dtype=torch.float32, device=x.device)
+        rc = L.agf_torgb_bwd(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(w), _lib.ptr(s_raw), s_raw.stride(0), _lib.ptr(dx), _lib.ptr(ds), _lib.ptr(dw),
+                             _lib.ptr(db), _lib.ptr(ws), nws, _lib.dtype_code(x), N, H, W, C, IC, ctx.coef, _lib.stream_ptr(x))
+        _lib.check(rc, 'torgb_bwd')
+        return (dx if need_x else None, dw.view_as(weight).to(weight.dtype) if dw is not None else None,
+                db.view(ctx.bias_shape) if db is not None else None, ds, dy if (need_pre and ctx.has_pre) else None, None)
+
+
+def torgb(x, weight, bias, s_raw, pre, coef):
+    return _ToRGB.apply(x, weight, bias, s_raw, pre, coef)
+
+
 _PREMASK = True        # tests/test_hip_conv.py::test_dblock_linked_backward_matches_unlinked runs the block with the fused hand-offs off
 
 

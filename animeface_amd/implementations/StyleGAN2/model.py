@@ -28,13 +28,14 @@ import torch.nn.functional as F
 
 from ...stylegan3_ops import upfirdn2d, bias_act
 from ... import rng
-from .conv import conv2d, conv2d_act, style_demod, PremaskLink, pool2x_linked, up_blur
+from .conv import conv2d, conv2d_act, style_demod, PremaskLink, pool2x_linked, up_blur, torgb, torgb_covers
 
 
 # bias / noise / leaky-ReLU run in the conv kernel's epilogue (with a fused backward).  The fused modulated conv has
 # no double backward, so the generator falls back to the separately differentiable ops when ``fused_epilogue=False``
 # (needed only for the path-length penalty, pl_lambda > 0).
 FUSED_EPILOGUE = True
+TORGB_FUSED = True        # ToImage as one streaming launch each way (agf_torgb_*); False: the MFMA 1x1 conv on zero-padded operands (tests / A-B runs)
 
 
 class ELR(nn.Module):
@@ -343,9 +344,18 @@ class ToImage(nn.Module):
         self.upsample = Upsample2x(up_name) if upsample else None
 
     def forward(self, x, y, pre=None):
-        x = self.conv(x, y).contiguous()          # RGB maps are kept NCHW (3 channels)
-        if pre is not None:
-            x = x + pre
+        conv = self.conv
+        if FUSED_EPILOGUE and TORGB_FUSED and getattr(conv, 'fused_epilogue', True) and not conv.demod and conv.kernel_size == 1 \
+                and torgb_covers(x, conv.out_channels) and (pre is None or pre.shape[1] == conv.out_channels):
+            # conv + bias + skip sum, channels-last features -> planar image, one streaming launch (and one in backward)
+            raw = conv.__dict__.pop('_s_raw', None)       # left by Synthesis._batched_affines
+            if raw is None:
+                raw = conv.affine(y)
+            x = torgb(x, conv.weight, conv.bias, raw, pre, conv.coef)
+        else:
+            x = conv(x, y).contiguous()          # RGB maps are kept NCHW (3 channels)
+            if pre is not None:
+                x = x + pre
         if self.upsample is not None:
             x = self.upsample(x)
         return x

@@ -82,6 +82,8 @@ class TrainStep:
         # batched weight preparation (one launch per network and optimizer step)
         self._plan_G, self._plan_D = PrepPlan(G.parameters()), PrepPlan(D.parameters())
         self.merge_d_passes = True                      # D(real) and D(fake) of the D-step as one batch-2B pass
+        self.pace_nodes = 0                             # memset nodes recorded at the start of a captured iteration (GraphedTrainStep.calibrate)
+        self._pace_buf = None
         if hasattr(G, 'set_fused_epilogue'):
             G.set_fused_epilogue(pl_lambda == 0)     # the fused modulated conv has no double backward (path length needs it)
 
@@ -118,6 +120,18 @@ class TrainStep:
                 self._pending_ada_state = None
         return self.ada
 
+    def _pace(self, real):
+        """``pace_nodes`` 1-KiB memset nodes at the head of a RECORDED iteration (nothing in eager mode).  They do no work; what they change
+        is the node structure of the graph, which on MI355X decides which of two package-power (PPT) regimes the replayed iteration
+        settles in -- ~2370 MHz / 12 % PPT-violation activity or ~2070 MHz / 51 % for the same kernels (profiles/r04_power_state.txt).
+        ``GraphedTrainStep`` picks the count by timing replays."""
+        if self.pace_nodes and real.is_cuda and torch.cuda.is_current_stream_capturing():
+            from ... import _lib
+            if self._pace_buf is None:
+                raise RuntimeError('pace buffer must exist before the capture starts')
+            for _ in range(self.pace_nodes):
+                _lib.memset_node(self._pace_buf, 1024)
+
     def _zero(self, opt, reducer):
         if reducer is not None:
             reducer.zero_grad()
@@ -127,6 +141,7 @@ class TrainStep:
     def __call__(self, real):
         G, D = self.G, self.D
         it = self.batches_done
+        self._pace(real)
         self._zero(self.optimizer_G, self.reducer_G)
         self._zero(self.optimizer_D, self.reducer_D)
 
@@ -172,6 +187,7 @@ class TrainStep:
     # ---- the same iteration cut at the two gradient exchanges (GraphedTrainStep under data parallelism: one HIP graph per segment, the
     #      all-reduce of the bucket buffers issued between two graph launches) ----
     def _seg1(self, real, it):
+        self._pace(real)
         self._zero(self.optimizer_G, self.reducer_G)
         self._zero(self.optimizer_D, self.reducer_D)
         with cached_weights(), recording_plans(self._plan_G, self._plan_D):
@@ -284,7 +300,22 @@ class GraphedTrainStep:
       * ``'segmented'`` (gloo, whose collectives run on host threads, or on request): THREE graphs cut at the two gradient exchanges,
         the bucket buffers all-reduced between the launches (``GradReducer.exchange_all``); the exchange is then exposed."""
 
-    def __init__(self, step, real, warmup=3, dp_mode=None):
+    PACE_CANDIDATES = (0, 1, 2)     # node counts recorded side by side when pace='auto'
+    PACE_BLOCK = 12                 # consecutive iterations per candidate while selecting (the first 5 of a block are not counted: the
+    #                                 package-power controller takes a few iterations to settle after the node structure changes)
+
+    def __init__(self, step, real, warmup=3, dp_mode=None, pace=0):
+        """``pace``: number of memset nodes at the head of every recorded iteration (``TrainStep._pace``), or ``'auto'``: every iteration kind
+        is recorded once per candidate count (``PACE_CANDIDATES``; the recordings stay resident, ~12 GB each at 256x256 / batch 64) and
+        the first ``len(PACE_CANDIDATES) * PACE_BLOCK`` training iterations rotate through them in blocks, timed with events; from
+        then on the count with the smallest median iteration time is replayed.  Every recording computes the same iteration, so the
+        selection costs no training step."""
+        self.pace, self.pace_report = pace, None
+        self._sel_events, self._sel_count = [], 0
+        if real.is_cuda and step._pace_buf is None:
+            step._pace_buf = torch.zeros(4096, dtype=torch.uint8, device=real.device)
+        self.candidates = tuple(self.PACE_CANDIDATES) if pace == 'auto' else (int(pace),)
+        self.pace_nodes = self.candidates[0]
         if (step.reducer_G is None) != (step.reducer_D is None):
             raise RuntimeError('graph capture: both networks or neither must have a gradient reducer')
         self.step, self.graphs = step, {}
@@ -344,13 +375,15 @@ class GraphedTrainStep:
             st._seg3()
         return (g1, g2, g3), (d_loss, g_loss, fake)
 
-    def _capture(self, it):
+    def _capture(self, it, nodes=None):
         st = self.step
         kind = self._kind(it)
-        if kind in self.graphs:
+        nodes = self.pace_nodes if nodes is None else nodes
+        if (kind, nodes) in self.graphs:
             return
         saved = st.batches_done
         st._defer_ada_update = True
+        st.pace_nodes = nodes
         try:
             if self.segmented:
                 graph, out = self._capture_segments(it)
@@ -372,27 +405,26 @@ class GraphedTrainStep:
                     if ingraph:
                         st.reducer_G.recording = st.reducer_D.recording = False
             # (the D(real) logits of THIS kind's graph: what the ADA p update reads after each replay)
-            self.graphs[kind] = (graph, out, st._real_prob)
+            self.graphs[(kind, nodes)] = (graph, out, st._real_prob)
         finally:
             st._defer_ada_update = False
         st.batches_done = saved
 
     def capture_all(self):
-        """Record both iteration kinds now (nothing executes, no collective is issued): lets a multi-process caller agree on success
-        before the first replay."""
+        """Record every iteration kind now, once per candidate node count (nothing executes, no collective is issued): lets a
+        multi-process caller agree on success before the first replay."""
         st = self.step
         import math
         period = math.lcm(st.d_k if st.r1_lambda > 0 else 1, st.g_k if st.pl_lambda > 0 else 1)
-        for it in range(1, period + 1):                    # (captures each distinct kind once, in the order the run meets them)
-            self._capture(it)
+        for nodes in self.candidates:
+            for it in range(1, period + 1):                # (captures each distinct kind once, in the order the run meets them)
+                self._capture(it, nodes)
 
-    def __call__(self, real):
+    def kinds(self):
+        return {k for k, _ in self.graphs}
+
+    def _replay(self, graph):
         st = self.step
-        it = st.batches_done
-        kind = self._kind(it)
-        self.static_real.copy_(real)
-        self._capture(it)
-        graph, out, real_prob = self.graphs[kind]
         if self.segmented:
             graph[0].replay()
             st.reducer_D.exchange_all()
@@ -401,6 +433,55 @@ class GraphedTrainStep:
             graph[2].replay()
         else:
             graph.replay()
+
+    def _select(self):
+        """One step of the online selection (pace='auto'): which candidate replays this iteration; after the last block, the decision.
+        Why a no-op node count matters at all: the MI355X package-power controller settles the SAME replayed kernels either near 2.37 GHz
+        (PPT-violation activity ~12 %, ~955 W) or near 2.07 GHz (~51 %, ~1120 W), and which one depends on the node structure of the
+        graph -- with memset nodes at the head of the iteration: bad, good, good, bad, good, good for 0..5 nodes in one build, good, bad,
+        good, good in another (profiles/r04_power_state.txt) -- and on nothing the kernels do."""
+        K, B = len(self.candidates), self.PACE_BLOCK
+        if self.pace_report is not None or K == 1:
+            return
+        i = self._sel_count
+        if i < K * B:
+            self.pace_nodes = self.candidates[i // B]
+            return
+        torch.cuda.synchronize()
+        med = {}
+        for c, n in enumerate(self.candidates):
+            ts = sorted(self._sel_events[c * B + j].elapsed_time(self._sel_events[c * B + j + 1]) for j in range(5, B - 1))
+            med[n] = round(ts[len(ts) // 2], 3)
+        self.pace_nodes = min(med, key=med.get)
+        self.pace_report = dict(nodes=self.pace_nodes, median_ms=med, candidates=list(self.candidates), block=B)
+        self._sel_events = []
+
+    def select_now(self, real):
+        """Run the selection iterations back to back (bench.py, before its warm-up): ordinary training iterations."""
+        while self.pace == 'auto' and self.pace_report is None and len(self.candidates) > 1:
+            self(real)
+        return self.pace_report
+
+    def __call__(self, real):
+        st = self.step
+        it = st.batches_done
+        kind = self._kind(it)
+        self.static_real.copy_(real)
+        self._select()
+        selecting = self.pace_report is None and len(self.candidates) > 1
+        self._capture(it)
+        graph, out, real_prob = self.graphs[(kind, self.pace_nodes)]
+        if selecting:
+            if not self._sel_events:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                self._sel_events.append(ev)
+        self._replay(graph)
+        if selecting:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self._sel_events.append(ev)
+            self._sel_count += 1
         if st.ada is not None:
             st.ada.update_p(real_prob)                      # host-counted schedule (reference nnutils/ada.py:25-36), a few tiny launches
         st.batches_done = it + 1

@@ -113,6 +113,8 @@ def main():
                                                          'backward hooks and overlaps the backward pass).  Default for every N: the iteration is replayed '
                                                          'from HIP graphs (GraphedTrainStep: same kernels, one host call per iteration and graph segment); '
                                                          'the iterations sampled for the per-launch roofline timing always run eagerly')
+    ap.add_argument('--pace', default='auto', help="memset nodes at the head of the recorded iteration: an integer, or 'auto' = calibrate 0..3 by timing replays (GraphedTrainStep.calibrate)")
+    ap.add_argument('--ab', default='', help='comma-separated A/B switches for same-box comparisons: no-torgb')
     ap.add_argument('--dp-mode', default=None, choices=['ingraph', 'segmented'],
                     help='several ranks under graph replay: ingraph (default with RCCL) = ONE graph per iteration kind with the bucket all-reduces '
                          'recorded from the backward hooks on the RCCL stream (overlapped with the rest of backward); segmented = three graphs '
@@ -128,6 +130,9 @@ def main():
     from animeface_amd.implementations.StyleGAN2 import model as M
     from animeface_amd.nnutils import sample_nnoise, update_ema
     import torch.distributed as dist
+    ab = set(filter(None, args.ab.split(',')))
+    if 'no-torgb' in ab:
+        M.TORGB_FUSED = False
 
     rank, world, local_rank = dp.init_distributed()
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
@@ -197,7 +202,7 @@ def main():
         # replay issues collectives), so success is agreed on first and the eager loop is the fallback.
         ok = 1
         try:
-            step = U.GraphedTrainStep(eager_step, real, warmup=1, dp_mode=args.dp_mode)
+            step = U.GraphedTrainStep(eager_step, real, warmup=1, dp_mode=args.dp_mode, pace=args.pace if args.pace == 'auto' else int(args.pace))
             step.capture_all()
         except Exception as exc:                   # noqa: BLE001 -- any capture failure means: run eagerly
             print(f'[bench] rank {rank}: graph capture failed ({type(exc).__name__}: {exc}); eager launches', file=sys.stderr)
@@ -217,11 +222,14 @@ def main():
         # one untimed replay of EACH captured graph: the first launch of a graph uploads its ~1 500 nodes to the device, a one-off cost that
         # would otherwise sit inside the timed window for the lazy-R1 graph (first replayed at iteration 16).  The replays are ordinary
         # training iterations of the (synthetic) run; the iteration counter is rewound so the timed window keeps its place in the schedule.
-        for it in (1, 16):
-            step.step.batches_done = it
-            step(real)
+        for entry in list(step.graphs.values()):
+            step._replay(entry[0])
         torch.cuda.synchronize()
         eager_step.batches_done = 0
+        # pace='auto': the first iterations rotate through the recordings with 0 / 1 / 2 memset nodes at their head and keep the fastest
+        # (GraphedTrainStep._select: the node structure decides which package-power regime the replay settles in); done here, before the
+        # warm-up, so that the timed window replays one recording only
+        step.select_now(real)
     for _ in range(args.warmup):
         step(real)
     # The timed window holds NOTHING but the K iterations: one host call per iteration under graph replay, plus one event record between
@@ -303,9 +311,14 @@ def main():
         ada_run, ada_exec = ada_step, 'eager launches'
         if use_graphs:
             try:
-                ada_run = U.GraphedTrainStep(ada_step, real, warmup=0)
+                ada_run = U.GraphedTrainStep(ada_step, real, warmup=0, pace=args.pace if args.pace == 'auto' else int(args.pace))
                 ada_step.batches_done = 1
                 ada_run(real)                              # records the GAN-loss kind and replays it once
+                for _ in range(64):                        # (pace='auto': the selection iterations, see above)
+                    if ada_run.pace_report is not None or len(ada_run.candidates) == 1:
+                        break
+                    ada_step.batches_done = 1
+                    ada_run(real)
                 ada_exec = 'hip-graph replay'
             except Exception as exc:                       # noqa: BLE001
                 print(f'[bench] ADA variant: graph capture failed ({type(exc).__name__}: {exc}); eager launches', file=sys.stderr)
@@ -355,6 +368,10 @@ def main():
                           'max_without_r1_steps': round(max([m for i, m in enumerate(step_ms) if not ((first_timed + i) % 16 == 0 and first_timed + i != 0)] or [0.0]), 3),
                           'all': [round(m, 2) for m in step_ms],
                           'note': 'GPU time between event records placed after each iteration of the timed window (no sync); the lazy-R1 iterations are the long ones'}
+        if runner is not None and runner.pace_report is not None:
+            out['pace'] = dict(runner.pace_report, note='memset nodes at the head of the recorded iteration, chosen by timing replays of each count before the warm-up (GraphedTrainStep.calibrate): the node structure decides which package-power regime the replay settles in')
+        elif runner is not None:
+            out['pace'] = {'nodes': runner.pace_nodes}
         if r1_ms is not None:
             out['r1_every_step'] = {'value': round(args.batch * world / (r1_ms * 1e-3), 2), 'unit': 'img/s', 'ms_per_step': round(r1_ms, 3),
                                     'note': 'the lazy-R1 iteration (penalty replaces the GAN loss) on every step: 4 steps after the timed window'}

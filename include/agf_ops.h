@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define AGF_ABI_VERSION 15
+#define AGF_ABI_VERSION 16
 
 /* element types of activation tensors */
 enum { AGF_F32 = 0, AGF_F16 = 1, AGF_BF16 = 2, AGF_F64 = 3 };
@@ -343,6 +343,23 @@ int agf_ada_pad_up2(const void* x, void* u, const int32_t* margins, const float*
                     int32_t H, int32_t W, int backward, void* stream);
 int agf_ada_warp_resample(const void* x, void* y, const float* theta, const int32_t* margins, int dtype, int32_t B, int32_t C,
                           int32_t Hb, int32_t Wb, int32_t Hout, int32_t Wout, int backward, void* stream);
+
+/* ToImage ("ToRGB") of the StyleGAN2 generator in one streaming pass each way (ABI v16; implementations/StyleGAN2/model.py:239-250: a 1x1
+ * ModulatedConv2d without demodulation, model.py:91-135, + the skip sum with the previous level's image).  With IC <= 4 output channels
+ * the layer is HBM-bound VALU work; the MFMA conv needed zero-padded weights / bias / gradient tensors and five passes over the feature map.
+ *   out[n,co,p] = coef * sum_c w[co,c] * (s_raw[n,c] + 1) * x[n,c,p] + bias[co] + pre[n,co,p]
+ * x [N][H][W][C] channels-last bf16 (C a power of two in 8..512, agf_torgb_covers); w [IC][C], bias [IC] (nullable), fp32;
+ * s_raw [N][C] fp32 with row stride s_stride (elements): the affine's raw output, the +1 of model.py:110 is applied here;
+ * pre (nullable) and out [N][IC][H][W] planar bf16.
+ * agf_torgb_bwd: dy [N][IC][H][W] planar bf16 -> dx [N][H][W][C] bf16, ds [N][C] (gradient of s_raw), dw [IC][C], db [IC] (each
+ * nullable except dx), fp32, reduced in a fixed order without atomics through `workspace` (agf_torgb_bwd_workspace_floats floats). */
+int agf_torgb_covers(int32_t C, int32_t IC);
+int agf_torgb_fwd(const void* x, const float* w, const float* bias, const float* s_raw, int64_t s_stride, const void* pre, void* out,
+                  int dtype, int32_t N, int32_t H, int32_t W, int32_t C, int32_t IC, float coef, void* stream);
+int64_t agf_torgb_bwd_workspace_floats(int32_t N, int32_t H, int32_t W, int32_t C, int32_t IC);
+int agf_torgb_bwd(const void* dy, const void* x, const float* w, const float* s_raw, int64_t s_stride, void* dx, float* ds, float* dw,
+                  float* db, float* workspace, int64_t workspace_floats, int dtype, int32_t N, int32_t H, int32_t W, int32_t C, int32_t IC,
+                  float coef, void* stream);
 
 /* Border correction of the fused  nn.Upsample(x2, bilinear) -> Blur2d  pair of the StyleGAN2 generator (implementations/StyleGAN2/
  * model.py:138-175).  blur(up(x)) equals ONE clamp-mode agf_upfirdn2d with the composite filter [1,5,10,10,5,1] x itself except on the

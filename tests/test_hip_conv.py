@@ -389,3 +389,43 @@ def test_stride2_conv_and_its_gradients_of_first_and_second_order(N, Cin, Cout, 
     s2 = (dz.float().square().sum() * 0.5 + dw.float().square().sum() * 0.5)
     ddw, = torch.autograd.grad(s2, [wd])
     torch.testing.assert_close(ddw.float().cpu(), ddwr.detach(), rtol=5e-2, atol=5e-2 * float(ddwr.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(3, 8, 3, 5, 7), (2, 32, 3, 64, 64), (4, 128, 3, 17, 16), (5, 512, 3, 4, 4), (2, 512, 3, 16, 16),
+                                   (64, 64, 3, 32, 32), (2, 16, 1, 9, 33), (1, 256, 4, 8, 8)],
+                         ids=lambda s: 'x'.join(map(str, s)))
+@pytest.mark.parametrize('with_pre', [False, True])
+def test_torgb_vs_composite(shape, with_pre):
+    """``agf_torgb_fwd`` / ``agf_torgb_bwd`` (ToImage: 1x1 modulated conv without demodulation + skip sum, reference model.py:239-250) against
+    the fp32 composite on the same bf16 inputs; s_raw read through the row stride of a wider matrix, as the batched style GEMM leaves it."""
+    from animeface_amd.implementations.StyleGAN2.conv import torgb
+    N, C, IC, H, W = shape
+    g = torch.Generator().manual_seed(N * 1000 + C + H)
+    dev = torch.device('cuda')
+    x = torch.randn(N, C, H, W, generator=g).to(dev).bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wide = torch.randn(N, C + 24, generator=g).to(dev).requires_grad_(True)
+    weight = (torch.randn(IC, C, 1, 1, generator=g)).to(dev).requires_grad_(True)
+    bias = torch.randn(1, IC, 1, 1, generator=g).to(dev).requires_grad_(True)
+    pre = torch.randn(N, IC, H, W, generator=g).to(dev).bfloat16().requires_grad_(True) if with_pre else None
+    dy = torch.randn(N, IC, H, W, generator=g).to(dev).bfloat16()
+    coef = 1.0 / C ** 0.5
+    out = torgb(x, weight, bias, wide[:, 8:8 + C], pre, coef)
+    assert out.shape == (N, IC, H, W) and out.is_contiguous() and out.dtype == torch.bfloat16
+    grads = torch.autograd.grad(out, [x, weight, bias, wide] + ([pre] if with_pre else []), dy)
+    xr, wr, br, sr = x.detach().float().requires_grad_(True), weight.detach().clone().requires_grad_(True), \
+        bias.detach().clone().requires_grad_(True), wide.detach().clone().requires_grad_(True)
+    pr = pre.detach().float().requires_grad_(True) if with_pre else None
+    s = sr[:, 8:8 + C] + 1
+    ref = torch.einsum('oc,nc,nchw->nohw', wr.reshape(IC, C) * coef, s, xr) + br
+    if with_pre:
+        ref = ref + pr
+    ref_grads = torch.autograd.grad(ref, [xr, wr, br, sr] + ([pr] if with_pre else []), dy.float())
+    scale = ref.abs().max().item()
+    assert (out.float() - ref).abs().max().item() <= 2 ** -7 * scale                   # one bf16 rounding of the result
+    names = ['dx', 'dw', 'db', 'ds_raw', 'dpre']
+    tols = [2 ** -7, 2e-4, 2e-4, 2e-4, 0.0]
+    for name, tol, a, b in zip(names, tols, grads, ref_grads):
+        assert a.shape == b.shape, name
+        err = (a.float() - b).abs().max().item()
+        assert err <= tol * max(b.abs().max().item(), 1e-6) + 1e-30, (name, err, b.abs().max().item())

@@ -240,7 +240,7 @@ def _worker_graphs(rank, world, port, out, graphed):
         losses.append((float(dl), float(gl)))
     torch.cuda.synchronize()
     if graphed:
-        assert runner.segmented and set(runner.graphs) == {'gan', 'r1'}
+        assert runner.segmented and runner.kinds() == {'gan', 'r1'}
     for m in (G, G_ema, D):
         dp.check_replica_consistency(m)
     scale = dp.never_used_parameters(G)[0]

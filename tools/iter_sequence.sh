@@ -1,0 +1,28 @@
+#!/bin/bash
+# Ordered launch list of ONE graph-replayed GAN-loss iteration (kernel name, duration, gap to the previous launch): what follows what, for
+# fusion hunting.   bash tools/iter_sequence.sh OUT.txt [extra bench.py args]
+out=${1:-gpurun_out/iter_sequence.txt}; shift
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+mkdir -p $(dirname $out)
+rm -rf /tmp/its; rocprofv3 --kernel-trace --output-format csv -d /tmp/its -o g -- python bench.py --steps 12 --warmup 2 --no-cpu-baseline --no-kernel-timer --no-r1-every-step --no-ada-variant --no-upfirdn2d-rows "$@" > /tmp/its_bench.log 2>&1
+tail -1 /tmp/its_bench.log | cut -c1-200 > $out
+python - >> $out <<'PY'
+import csv, glob, re
+f = glob.glob('/tmp/its/**/g_kernel_trace.csv', recursive=True)[0]
+rows = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'], r.get('Grid_Size_X', r.get('Grid_Size', '')), r.get('Workgroup_Size_X', r.get('Workgroup_Size', '')), r.get('Queue_Id', '?')) for r in csv.DictReader(open(f))]
+rows.sort()
+marks = [i for i, r in enumerate(rows) if 'tanh_backward' in r[2] or 'TanhBackward' in r[2]]
+a, b = marks[-3], marks[-2]
+import collections
+print('columns:', list(csv.DictReader(open(f)).fieldnames))
+print('queues in the window:', collections.Counter(r[5] for r in rows[a:b]))
+prev = rows[a - 1][1]
+def short(n):
+    n = re.sub(r'^void ', '', n)
+    n = re.sub(r'at::native::', '', n)
+    n = re.sub(r'\(.*', '', n)
+    return n[:150]
+for i, (s, e, n, g, w, q) in enumerate(rows[a:b]):
+    print('%4d %8.1f us  gap %6.1f  grid %8s wg %4s q%s  %s' % (i, (e - s) / 1e3, (s - prev) / 1e3, g, w, q, short(n)))
+    prev = e
+PY
