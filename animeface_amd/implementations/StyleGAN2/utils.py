@@ -65,7 +65,12 @@ class TrainStep:
         #  on the D(real) logits the graph left in a static tensor; ``GraphedTrainStep`` sets this while it records / replays)
         self._defer_ada_update = False
         self._real_prob = None
-        self.augment = (lambda x: self._ada_pipe(x)(x)) if policy == 'ada' else functools.partial(DiffAugment, policy=policy)
+        self.augment = self._augment_ada if policy == 'ada' else functools.partial(DiffAugment, policy=policy)
+        # the ADA pipe's per-sample decisions (draws + 3x3 / 4x4 matrix algebra: ~230 launches of a few microseconds per call) depend only on
+        # the batch shape: the three calls of an iteration are issued at its start on a SIDE STREAM, beside the generator's forward pass,
+        # and joined at the first call (a parallel branch of the recorded graph); off when the draws are replayed from the CPU stream
+        self.plan_ahead = True
+        self._ada_plans, self._ada_side, self._ada_join = [], None, False
         self.latent_dim, self.sampler = latent_dim, sampler
         self.reducer_G, self.reducer_D = reducer_G, reducer_D
         self.loss = NonSaturatingLoss()
@@ -132,6 +137,33 @@ class TrainStep:
             for _ in range(self.pace_nodes):
                 _lib.memset_node(self._pace_buf, 1024)
 
+    def _augment_ada(self, x):
+        pipe = self._ada_pipe(x)
+        if self._ada_plans:
+            shape, dtype, plan = self._ada_plans.pop(0)
+            if shape == tuple(x.shape) and dtype == x.dtype:
+                if self._ada_join:
+                    torch.cuda.current_stream().wait_stream(self._ada_side)
+                    self._ada_join = False
+                return pipe(x, plan=plan)
+        return pipe(x)
+
+    def _plan_ahead(self, real, calls=3):
+        from ... import rng
+        self._ada_plans, self._ada_join = [], False
+        if self.ada is None or not self.plan_ahead or rng._cpu or not real.is_cuda:
+            return
+        if self._ada_side is None:
+            if torch.cuda.is_current_stream_capturing():
+                return
+            self._ada_side = torch.cuda.Stream(real.device)
+        side = self._ada_side
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for plan in self.ada.plan_many(calls, tuple(real.shape), real.dtype, real.device):
+                self._ada_plans.append((tuple(real.shape), real.dtype, plan))
+        self._ada_join = True
+
     def _zero(self, opt, reducer):
         if reducer is not None:
             reducer.zero_grad()
@@ -142,6 +174,7 @@ class TrainStep:
         G, D = self.G, self.D
         it = self.batches_done
         self._pace(real)
+        self._plan_ahead(real)
         self._zero(self.optimizer_G, self.reducer_G)
         self._zero(self.optimizer_D, self.reducer_D)
 
@@ -225,9 +258,15 @@ class TrainStep:
     def _d_half(self, real, it):
         G, D = self.G, self.D
         z = self.sampler((real.size(0), self.latent_dim))
-        real_aug = self.augment(real)
-        with torch.no_grad():
-            fake, _ = G(z)
+        if self._ada_plans:
+            # the decisions of this iteration's augment calls are in flight on the side stream: the generator runs first, beside them
+            with torch.no_grad():
+                fake, _ = G(z)
+            real_aug = self.augment(real)
+        else:
+            real_aug = self.augment(real)
+            with torch.no_grad():
+                fake, _ = G(z)
         fake_aug = self.augment(fake)
         B = real.size(0)
         groups = self._mbsd_group_size()

@@ -276,10 +276,41 @@ class AugmentPipe(torch.nn.Module):
         keep = rng.rand(shape, device) < prob
         return torch.where(keep, value, neutral)                    # scalar overload: no fill launch for the neutral element
 
-    def forward(self, images, debug_percentile=None):
+    def forward(self, images, debug_percentile=None, plan=None):
+        """``plan``: the result of an earlier ``self.plan(images.shape, images.dtype, images.device)`` -- every per-sample decision of the
+        geometric and colour stages (random draws + 3x3 / 4x4 matrix algebra, ~230 tiny launches) depends on the batch SHAPE only, so a
+        trainer can issue it ahead of time on a side stream, beside the networks' kernels (``TrainStep._plan_ahead``)."""
         assert isinstance(images, torch.Tensor) and images.ndim == 4
-        B, C, H, W = images.shape
-        dev = images.device
+        if plan is None:
+            plan = self.plan(images.shape, images.dtype, images.device, debug_percentile)
+        return self.apply(images, plan, debug_percentile)
+
+    def plan(self, shape, dtype, dev, debug_percentile=None):
+        """The decisions of the geometric and colour stages for one batch (reference augment.py:188-347, same draws in the same order):
+        ``dict(warp=..., M=..., M3=...)`` for ``apply``."""
+        G, M = self._plan_matrices(shape, dev, debug_percentile)
+        return self._plan_finish(G, M, shape, dtype, dev)
+
+    def plan_many(self, calls, shape, dtype, dev):
+        """Plans for ``calls`` consecutive calls on batches of one shape: the per-sample decisions are independent draws, so the matrices of
+        all calls are built as ONE batch of ``calls * B`` samples (a third of the launches for the three calls of a training iteration);
+        only the reflect margins, a maximum over each call's own batch, are made per call."""
+        B = shape[0]
+        G, M = self._plan_matrices((calls * B,) + tuple(shape[1:]), dev, None)
+        return [self._plan_finish(None if G is None else G[i * B:(i + 1) * B], None if M is None else M[i * B:(i + 1) * B], shape, dtype, dev)
+                for i in range(calls)]
+
+    def _plan_finish(self, G, M, shape, dtype, dev):
+        B, C, H, W = shape
+        warp = self._warp_plan(G, shape, dtype, dev) if G is not None else None
+        M3 = None
+        if M is not None and C == 3 and dev.type == 'cuda' and not M.requires_grad:
+            M3 = M[:, :3, :].detach().float().contiguous()               # what agf_color_affine reads (made here: not on the image path)
+        return dict(warp=warp, M=M, M3=M3)
+
+    def _plan_matrices(self, shape, dev, debug_percentile=None):
+        """G [B,3,3] (output pixel -> input pixel, None when no geometric augmentation is enabled) and M [B,4,4] (colour, None likewise)."""
+        B, C, H, W = shape
         dbg = None if debug_percentile is None else torch.as_tensor(debug_percentile, dtype=torch.float32, device=dev)
         probit = None if dbg is None else torch.erfinv(dbg * 2 - 1)          # debug value of a standard normal draw
         p = self.p
@@ -337,8 +368,7 @@ class AugmentPipe(torch.nn.Module):
                 t = torch.full_like(t, float(probit * self.xfrac_std))
             G = G @ _shift2(-t[:, 0] * W, -t[:, 1] * H)
 
-        if G is not eye3:
-            images = self._warp(images, G)
+        G = None if G is eye3 else G
 
         # ---- colour: M maps input colour (r,g,b,1) to output colour ----
         eye4 = torch.eye(4, device=dev)
@@ -376,10 +406,21 @@ class AugmentPipe(torch.nn.Module):
             if dbg is not None:
                 s = torch.full_like(s, float(torch.exp2(probit * self.saturation_std)))
             M = (vv + (eye4 - vv) * s) @ M
-        if M is not eye4:
+        return G, (None if M is eye4 else M)
+
+    def apply(self, images, plan, debug_percentile=None):
+        B, C, H, W = images.shape
+        dev = images.device
+        dbg = None if debug_percentile is None else torch.as_tensor(debug_percentile, dtype=torch.float32, device=dev)
+        probit = None if dbg is None else torch.erfinv(dbg * 2 - 1)
+        p = self.p
+        if plan['warp'] is not None:
+            images = self._warp_apply(images, plan['warp'])
+        M = plan['M']
+        if M is not None:
             flat = images.reshape([B, C, H * W])
             if C == 3:
-                flat = _color_affine(flat, M[:, :3, :]) if flat.is_cuda and flat.dtype in (torch.float32, torch.bfloat16) and not M.requires_grad \
+                flat = _color_affine(flat, plan['M3'] if plan.get('M3') is not None else M[:, :3, :]) if flat.is_cuda and flat.dtype in (torch.float32, torch.bfloat16) and not M.requires_grad \
                     else M[:, :3, :3] @ flat + M[:, :3, 3:]
             elif C == 1:
                 Mg = M[:, :3, :].mean(dim=1, keepdims=True)
@@ -413,11 +454,12 @@ class AugmentPipe(torch.nn.Module):
         return images
 
     # -- geometric warp ------------------------------------------------------------------------------------------------
-    def _warp(self, images, G):
-        B, C, H, W = images.shape
-        dev = images.device
+    def _warp_plan(self, G, shape, dtype, dev):
+        """Margins of the reflect padding and the sampling matrix of the warp (reference augment.py:258-283): no image data involved."""
+        B, C, H, W = shape
         cx, cy = (W - 1) / 2, (H - 1) / 2
         taps4 = self.Hz_geom.shape[0] // 4
+        like = self.Hz_geom if self.Hz_geom.device == dev else torch.empty(0, device=dev)
         # how far the transformed image corners reach outside the frame decides the reflect padding
         mk = (lambda key, v: _dev_const((key, H, W, taps4), dev, v)) if dev.type == 'cuda' else \
             (lambda key, v: torch.tensor(v, dtype=torch.float32, device=dev))
@@ -428,7 +470,7 @@ class AugmentPipe(torch.nn.Module):
         lim = mk('lim', [W - 1, H - 1] * 2)
         margin = torch.minimum(torch.clamp(reach + slack, min=0), lim)
         out_shape = [B, C, (H + taps4 * 2) * 2, (W + taps4 * 2) * 2]
-        if HOST_MARGINS is False and images.is_cuda and images.dtype in (torch.float32, torch.bfloat16) and C <= 4 and H >= 2 and W >= 2 \
+        if HOST_MARGINS is False and dev.type == 'cuda' and dtype in (torch.float32, torch.bfloat16) and C <= 4 and H >= 2 and W >= 2 \
                 and not G.requires_grad and self.Hz_geom.ndim == 1 and self.Hz_geom.numel() == 12:
             # the margins stay on the device (the reference unpacks them into Python ints here: a host synchronisation per call, and a
             # tensor shape that depends on the data).  Same matrix algebra with 0-d tensors where the reference has Python numbers.
@@ -436,11 +478,19 @@ class AugmentPipe(torch.nn.Module):
             mx0, my0, mx1, my1 = m.unbind()
             Wu, Hu = (mx0 + mx1 + W) * 2, (my0 + my1 + H) * 2                                 # size of the padded, x2-upsampled image
             G = _shift2((mx0 - mx1) / 2, (my0 - my1) / 2) @ G
-            G = _zoom2(2, 2, like=images) @ G @ _zoom2(0.5, 0.5, like=images)
-            G = _shift2(-0.5, -0.5, like=images) @ G @ _shift2(0.5, 0.5, like=images)
-            G = _zoom2(2 / Wu, 2 / Hu) @ G @ _zoom2(out_shape[3] / 2, out_shape[2] / 2, like=images)
-            images = _WarpNoSync.apply(images, G[:, :2, :], m.to(torch.int32), self.Hz_geom, out_shape[2], out_shape[3])
+            G = _zoom2(2, 2, like=like) @ G @ _zoom2(0.5, 0.5, like=like)
+            G = _shift2(-0.5, -0.5, like=like) @ G @ _shift2(0.5, 0.5, like=like)
+            G = _zoom2(2 / Wu, 2 / Hu) @ G @ _zoom2(out_shape[3] / 2, out_shape[2] / 2, like=like)
+            return dict(kind='device', theta=G[:, :2, :].detach().float().contiguous(), margins=m.to(torch.int32), out_shape=out_shape, taps4=taps4)
+        return dict(kind='host', G=G, margin=margin, out_shape=out_shape, taps4=taps4)
+
+    def _warp_apply(self, images, wp):
+        out_shape, taps4 = wp['out_shape'], wp['taps4']
+        B, C, H, W = images.shape
+        if wp['kind'] == 'device':
+            images = _WarpNoSync.apply(images, wp['theta'], wp['margins'], self.Hz_geom, out_shape[2], out_shape[3])
             return upfirdn2d.downsample2d(x=images, f=self.Hz_geom, down=2, padding=-taps4 * 2, flip_filter=True)
+        G, margin = wp['G'], wp['margin']
         mx0, my0, mx1, my1 = [int(v) for v in margin.ceil().to(torch.int32).tolist()]
         images = torch.nn.functional.pad(images, [mx0, mx1, my0, my1], mode='reflect')
         G = _shift2((mx0 - mx1) / 2, (my0 - my1) / 2, like=images) @ G

@@ -55,6 +55,35 @@ def cpu_baseline(image_size, seconds_budget=30.0):
                        f'weighted {k - 1}:1 as in the loop (oracle/training.py, torch {torch.__version__} CPU)')
 
 
+class SmiSampler:
+    """One ``rocm-smi`` reading (core clock, socket power) taken ``delay`` seconds after construction on a host thread -- i.e. while the timed
+    window runs: the sustained clock decides 10 % of the result (profiles/r04_power_state.txt), so the record states it."""
+
+    def __init__(self, delay=0.25):
+        import threading
+        self.out, self.delay = None, delay
+        self.thread = threading.Thread(target=self._run, daemon=True)
+        self.thread.start()
+
+    def _run(self):
+        import re
+        import subprocess
+        try:
+            time.sleep(self.delay)
+            t = time.perf_counter()
+            txt = subprocess.run(['rocm-smi', '--showpower', '--showclocks'], capture_output=True, text=True, timeout=20).stdout
+            sclk = re.search(r'sclk clock level: \d+: \((\d+)Mhz\)', txt)
+            power = re.search(r'Power \(W\): ([0-9.]+)', txt)
+            self.out = {'sclk_mhz': int(sclk.group(1)) if sclk else None, 'socket_power_w': float(power.group(1)) if power else None,
+                        'note': 'one rocm-smi reading taken while the timed window runs (GPU 0)'}
+        except Exception as exc:                            # noqa: BLE001 -- a missing tool must not fail the benchmark
+            self.out = {'error': f'{type(exc).__name__}: {exc}'}
+
+    def result(self):
+        self.thread.join(timeout=25)
+        return self.out
+
+
 def upfirdn2d_roofline(dev, batch=64, reps=20):
     """The three SURVEY.md section 8(d) upfirdn2d rows at 256x256 (north_star: >= 60 % of the HBM roofline), timed in this process with HIP
     events on the launch stream: algorithmic bytes = (numel_in + numel_out) * sizeof(T) over the launch time, as a fraction of 8 TB/s.
@@ -240,6 +269,7 @@ def main():
     first_timed = step.batches_done
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     barrier()
+    smi = SmiSampler(delay=0.25) if rank == 0 else None        # one rocm-smi reading of clock / power while the window runs (host thread)
     t0 = time.perf_counter()
     marks[0].record()
     host_t = [t0]
@@ -249,6 +279,7 @@ def main():
         host_t.append(time.perf_counter())              # host time to ISSUE the iteration (no synchronisation): >= the GPU time means host-bound
     barrier()
     dt = time.perf_counter() - t0
+    smi_out = smi.result() if smi is not None else None
     step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
     if dp_on:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -263,12 +294,13 @@ def main():
         barrier()
         C.KernelTimer.active = timer
         ts = time.perf_counter()
-        eager_step.batches_done = 1
-        eager_step(real)
+        sampled_steps = 3
+        for _ in range(sampled_steps):
+            eager_step.batches_done = 1
+            eager_step(real)
         torch.cuda.synchronize()
-        sampled_ms = (time.perf_counter() - ts) * 1e3
+        sampled_ms = (time.perf_counter() - ts) * 1e3 / sampled_steps
         C.KernelTimer.active = None
-        sampled_steps = 1
         eager_step.batches_done = first_timed + args.steps
     r1_steps = sum(1 for it in range(first_timed, first_timed + args.steps) if it % 16 == 0 and it != 0)
 
@@ -372,6 +404,8 @@ def main():
             out['pace'] = dict(runner.pace_report, note='memset nodes at the head of the recorded iteration, chosen by timing replays of each count before the warm-up (GraphedTrainStep.calibrate): the node structure decides which package-power regime the replay settles in')
         elif runner is not None:
             out['pace'] = {'nodes': runner.pace_nodes}
+        if smi_out:
+            out['clocks'] = smi_out
         if r1_ms is not None:
             out['r1_every_step'] = {'value': round(args.batch * world / (r1_ms * 1e-3), 2), 'unit': 'img/s', 'ms_per_step': round(r1_ms, 3),
                                     'note': 'the lazy-R1 iteration (penalty replaces the GAN loss) on every step: 4 steps after the timed window'}
@@ -391,12 +425,15 @@ def main():
             traffic = measured_traffic()
             # algorithmic HBM bytes of a launch: activations in + out, weights once (bf16); a launch with the fused gradient epilogue also reads its
             # lrelu mask once (the pass it replaces would read it too)
+            def conv_bytes(key):
+                name, n, cin, cout, h, w, ks = key[:7]
+                fused = name == 'conv2d_fwd_kernel' and len(key) > 8 and key[8]      # + the lrelu mask the fused gradient epilogue reads (as large as y)
+                return n * h * w * (cin + cout + (cout if fused else 0)) * 2 + cout * cin * ks * ks * 2
             alg = {}
             for key, recs in timer.by_shape.items():
                 name, n, cin, cout, h, w, ks = key[:7]
                 alg.setdefault(name, [0, 0])
-                fused = name == 'conv2d_fwd_kernel' and len(key) > 8 and key[8]      # + the lrelu mask the fused gradient epilogue reads (as large as y)
-                alg[name][0] += len(recs) * (n * h * w * (cin + cout + (cout if fused else 0)) * 2 + cout * cin * ks * ks * 2)
+                alg[name][0] += len(recs) * conv_bytes(key)
                 alg[name][1] += len(recs)
             # conv launches WITHOUT a fused gradient epilogue (agf_conv2d_fwd_mask folds the lrelu-gradient pass, the skip-branch add and
             # the pooling adjoint of the layer below into the data-gradient launch: those launches do more than their conv flops)
@@ -405,7 +442,7 @@ def main():
                 if key[0] != 'conv2d_fwd_kernel':
                     continue
                 if len(key) > 8 and key[8]:
-                    fused_n += len(recs)
+                    fused_n += len(recs) // sampled_steps
                     continue
                 plain_ms += sum(a.elapsed_time(b) for a, b, _ in recs)
                 plain_fl += sum(f for _, _, f in recs)
@@ -425,8 +462,8 @@ def main():
                                                    + traffic.get('_source', 'no profile found') + ')',
                                    'algorithmic_bytes_per_launch': round(alg['conv2d_fwd_kernel'][0] / max(alg['conv2d_fwd_kernel'][1], 1))
                                    if 'conv2d_fwd_kernel' in alg else None,
-                                   'launches': k['launches'], 'avg_launch_ms': round(k['avg_ms'], 4),
-                                   'share_of_step_time': round(k['total_ms'] / max(dt * 1e3 / args.steps, 1e-9), 4),
+                                   'launches': k['launches'] // sampled_steps, 'avg_launch_ms': round(k['avg_ms'], 4),
+                                   'share_of_step_time': round(k['total_ms'] / sampled_steps / max(dt * 1e3 / args.steps, 1e-9), 4),
                                    'event_timed_steps': sampled_steps,
                                    'r1_iteration': (lambda q: None if not q else {'achieved': round(q['tflops'], 2), 'launches': q['launches'],
                                                                                     'note': 'conv launches of one lazy-R1 iteration (double backward), sampled after the timed window'})(
@@ -435,6 +472,55 @@ def main():
                                    'achieved_plain_launches': round(plain_fl / (plain_ms * 1e-3) / 1e12, 2) if plain_ms > 0 else None,
                                    'achieved_3x3_ge128_channels': round(big_fl / (big_ms * 1e-3) / 1e12, 2) if big_ms > 0 else None,
                                    'share_3x3_ge128_channels': round(big_ms / max(k['total_ms'], 1e-9), 3) if big_ms > 0 else None}
+            # the conv launches that are HBM-bound by arithmetic intensity (below the ridge of 2.5 PFLOP/s / 8 TB/s = 312 flop per byte: the
+            # few-channel 128x128 / 256x256 layers and every 1x1 launch) judged against BYTES: algorithmic bytes / time / 8 TB/s per shape
+            hbm_rows, hbm_ms, hbm_bytes = [], 0.0, 0
+            for key, recs in timer.by_shape.items():
+                if key[0] != 'conv2d_fwd_kernel':
+                    continue
+                ms = sum(a.elapsed_time(b) for a, b, _ in recs)
+                fl = sum(f for _, _, f in recs)
+                by = len(recs) * conv_bytes(key)
+                if fl / by < MFMA_BF16_PEAK / HBM_PEAK:
+                    hbm_ms += ms
+                    hbm_bytes += by
+                    hbm_rows.append((ms / sampled_steps, {'shape': 'N%d %d->%d %dx%d k%d%s%s' % (key[1], key[2], key[3], key[4], key[5], key[6], ' style' if key[7] else '', ' +mask' if len(key) > 8 and key[8] else ''),
+                                                           'launches': len(recs) // sampled_steps, 'ms': round(ms / sampled_steps, 3), 'flop_per_byte': round(fl / by, 1),
+                                                           'achieved': round(by / (ms * 1e-3) / 1e12, 3), 'frac': round(by / (ms * 1e-3) / HBM_PEAK, 3)}))
+            if hbm_ms > 0:
+                hbm_rows.sort(key=lambda r: -r[0])
+                out['roofline_conv_hbm'] = {'kernel': 'conv2d_fwd* launches below the MFMA / HBM ridge (%.0f flop per byte)' % (MFMA_BF16_PEAK / HBM_PEAK), 'bound': 'hbm',
+                                            'achieved': round(hbm_bytes / (hbm_ms * 1e-3) / 1e12, 3), 'peak': HBM_PEAK / 1e12, 'unit': 'TB/s',
+                                            'frac': round(hbm_bytes / (hbm_ms * 1e-3) / HBM_PEAK, 4), 'ms_per_step': round(hbm_ms / sampled_steps, 3),
+                                            'share_of_conv_time': round(hbm_ms / max(k['total_ms'], 1e-9), 3) if k else None,
+                                            'by_shape': [r[1] for r in hbm_rows[:12]]}
+            # whole-iteration arithmetic rate: every MFMA flop of one iteration (forward + data gradient + weight gradient) over the replayed
+            # iteration time; and the same for the lazy-R1 iteration (its own flop count, its own time)
+            flops_iter = sum(v['flops'] for v in summ.values()) / sampled_steps
+            p50_ms = sorted(step_ms)[len(step_ms) // 2]
+            out['whole_step'] = {'tflop_per_iteration': round(flops_iter / 1e12, 2), 'achieved': round(flops_iter / (p50_ms * 1e-3) / 1e12, 1),
+                                 'frac_of_mfma_peak': round(flops_iter / (p50_ms * 1e-3) / MFMA_BF16_PEAK, 4), 'unit': 'TFLOP/s',
+                                 'note': 'MFMA flops of one GAN-loss iteration (event-timed eager sample) over the replayed p50 iteration time'}
+            if timer_r1 is not None and r1_ms is not None:
+                fr1 = sum(v['flops'] for v in timer_r1.summary().values())
+                out['whole_step']['r1_iteration'] = {'tflop_per_iteration': round(fr1 / 1e12, 2), 'achieved': round(fr1 / (r1_ms * 1e-3) / 1e12, 1),
+                                                     'frac_of_mfma_peak': round(fr1 / (r1_ms * 1e-3) / MFMA_BF16_PEAK, 4)}
+            shapes_path = os.environ.get('AGF_BENCH_SHAPES_FILE')
+            if shapes_path:                                      # per-shape table of the sampled launches -> profiles/rNN_conv_shapes.txt
+                rows = []
+                for key, recs in timer.by_shape.items():
+                    ms = sum(a.elapsed_time(b) for a, b, _ in recs)
+                    fl = sum(f for _, _, f in recs)
+                    by = len(recs) * conv_bytes(key) if key[0] == 'conv2d_fwd_kernel' else len(recs) * (key[1] * key[4] * key[5] * (key[2] + key[3]) * 2 + key[2] * key[3] * key[6] ** 2 * 4)
+                    ridge = MFMA_BF16_PEAK / HBM_PEAK
+                    bound = 'mfma' if fl / by >= ridge else 'hbm'
+                    frac = fl / (ms * 1e-3) / MFMA_BF16_PEAK if bound == 'mfma' else by / (ms * 1e-3) / HBM_PEAK
+                    rows.append((ms / sampled_steps, len(recs) // sampled_steps, fl / max(ms, 1e-9) / 1e9, fl / by, by / (ms * 1e-3) / 1e12, bound, frac, key))
+                with open(shapes_path, 'w') as fh:
+                    fh.write('# per-shape table of the MFMA conv launches of one GAN-loss iteration (bench.py, %d event-timed eager iterations after the window)\n' % sampled_steps)
+                    fh.write('# ms/iter  launches  TFLOP/s  flop/B  TB/s(alg)  bound  frac-of-bound  (kernel, N, Cin, Cout, H, W, k, style-scaled[, fused gradient epilogue])\n')
+                    for ms, n, tf, ai, tb, bound, frac, key in sorted(rows, reverse=True):
+                        fh.write('%8.3f %4d %8.1f %7.1f %6.2f  %-4s %.3f  %s\n' % (ms, n, tf, ai, tb, bound, frac, key))
             if os.environ.get('AGF_BENCH_SHAPES') == '1':        # per-shape table of the sampled launches (diagnosis)
                 rows = []
                 for key, recs in timer.by_shape.items():
@@ -447,8 +533,8 @@ def main():
             if kw:
                 out['roofline_wgrad'] = {'kernel': 'conv2d_wgrad_kernel', 'bound': 'mfma', 'achieved': round(kw['tflops'], 2),
                                          'peak': MFMA_BF16_PEAK / 1e12, 'unit': 'TFLOP/s',
-                                         'frac': round(kw['tflops'] * 1e12 / MFMA_BF16_PEAK, 4), 'launches': kw['launches'],
-                                         'share_of_step_time': round(kw['total_ms'] / max(dt * 1e3 / args.steps, 1e-9), 4)}
+                                         'frac': round(kw['tflops'] * 1e12 / MFMA_BF16_PEAK, 4), 'launches': kw['launches'] // sampled_steps,
+                                         'share_of_step_time': round(kw['total_ms'] / sampled_steps / max(dt * 1e3 / args.steps, 1e-9), 4)}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(S)
         print(json.dumps(out), flush=True)
