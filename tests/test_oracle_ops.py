@@ -129,6 +129,21 @@ def test_filtered_lrelu(golden):
         torch.testing.assert_close(ddy, t(g[name + '_ddy']), rtol=1e-4, atol=1e-5)
 
 
+def test_filtered_lrelu_bf16_input_golden(golden):
+    """The oracle on the bf16-representable operands of the second reference fixture (radial down filter, up 2 / up 4, multi-tile maps)."""
+    g = golden('filtered_lrelu_bf16')
+    for name in [str(n) for n in g['names']]:
+        up, down, px0, px1, py0, py1 = [int(v) for v in g[name + '_cfg']]
+        x = t(g[name + '_x']).requires_grad_(True)
+        b = t(g[name + '_b']).requires_grad_(True)
+        y = OF.filtered_lrelu(x, fu=t(g[str(g[name + '_fu'])]), fd=t(g['fd12r']), b=b, up=up, down=down, padding=[px0, px1, py0, py1],
+                              gain=2 ** 0.5, slope=0.2, clamp=256.0)
+        torch.testing.assert_close(y, t(g[name + '_y']), rtol=1e-5, atol=1e-5)
+        dx, db = torch.autograd.grad(y, [x, b], t(g[name + '_dy']))
+        torch.testing.assert_close(dx, t(g[name + '_dx']), rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(db, t(g[name + '_db']), rtol=1e-4, atol=1e-4)
+
+
 def test_sign_packing_layout():
     code = torch.tensor([[[[0, 1, 2, 0, 1, 1, 2, 2, 0, 0, 0, 0, 1, 0, 0, 2, 1]]]], dtype=torch.uint8)
     p = OF.pack_signs(code)

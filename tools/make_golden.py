@@ -254,6 +254,32 @@ def gen_filtered_lrelu():
     save('filtered_lrelu', **arrays)
 
 
+def gen_filtered_lrelu_bf16():
+    """Reference `_ref` results on inputs that are exactly representable in bfloat16 (x, b, dy rounded to bf16 first), for the two SG3 layer
+    kinds whose gradient the HIP path interpolates on the matrix pipe: separable up 2 / up 4 with the 12x12 RADIAL down filter, map sizes
+    that span several kernel tiles.  The HIP bf16 path sees the same operands, so its results must equal the fp32 reference's up to the
+    final rounding to bf16 (tests/test_hip_ops.py::test_filtered_lrelu_bf16_golden)."""
+    from thirdparty.stylegan3_ops.ops import filtered_lrelu as FL
+    g = torch.Generator().manual_seed(44)
+    fu12 = sg3_filter(12, 2.0, 2.2, 8.0)
+    fu24 = sg3_filter(24, 2.0, 2.2, 16.0)
+    fd12r = sg3_filter(12, 2.0, 2.2, 8.0, radial=True)
+    arrays = dict(fu12=fu12, fu24=fu24, fd12r=fd12r)
+    names = []
+    bf = lambda t_: t_.to(torch.bfloat16).float()
+    for name, fu_k, up, pad, C, H, W in [('u2_fd12r', 'fu12', 2, [9, 8, 9, 8], 2, 76, 142), ('u4_fd12r', 'fu24', 4, [-6, -9, -6, -9], 2, 52, 84)]:
+        x = bf(torch.randn(1, C, H, W, generator=g) * 1.5).requires_grad_(True)
+        b = bf(torch.randn(C, generator=g)).requires_grad_(True)
+        y = FL.filtered_lrelu(x, fu=arrays[fu_k], fd=fd12r, b=b, up=up, down=2, padding=pad, gain=np.sqrt(2), slope=0.2, clamp=256.0)
+        dy = bf(torch.randn(y.shape, generator=g))
+        dx, db = torch.autograd.grad(y, [x, b], dy)
+        arrays.update({f'{name}_x': x, f'{name}_b': b, f'{name}_y': y, f'{name}_dy': dy, f'{name}_dx': dx, f'{name}_db': db,
+                       f'{name}_cfg': np.array([up, 2, *pad], dtype=np.int64), f'{name}_fu': np.array(fu_k)})
+        names.append(name)
+    arrays['names'] = np.array(names)
+    save('filtered_lrelu_bf16', **arrays)
+
+
 def import_sg2_model():
     import importlib.util
     spec = importlib.util.spec_from_file_location('ref_sg2_model', os.path.join(REF, 'implementations/StyleGAN2/model.py'))
@@ -722,7 +748,7 @@ if __name__ == '__main__':
     os.environ.setdefault('PYTHONDONTWRITEBYTECODE', '1')
     torch.set_num_threads(8)
     import_reference()
-    which = sys.argv[1:] or ['upfirdn2d', 'equiv', 'bias_act', 'filtered_lrelu', 'sg2_model', 'train', 'sg3_model', 'sg3_train', 'ada', 'conv2d_resample', 'image_pipeline', 'weights_md']
+    which = sys.argv[1:] or ['upfirdn2d', 'equiv', 'bias_act', 'filtered_lrelu', 'filtered_lrelu_bf16', 'sg2_model', 'train', 'sg3_model', 'sg3_train', 'ada', 'conv2d_resample', 'image_pipeline', 'weights_md']
     if 'upfirdn2d' in which:
         gen_upfirdn2d()
     if 'equiv' in which:
@@ -731,6 +757,8 @@ if __name__ == '__main__':
         gen_bias_act()
     if 'filtered_lrelu' in which:
         gen_filtered_lrelu()
+    if 'filtered_lrelu_bf16' in which:
+        gen_filtered_lrelu_bf16()
     if 'sg2_model' in which:
         gen_sg2_model()
     if 'train' in which:
