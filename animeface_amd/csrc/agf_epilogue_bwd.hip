@@ -20,6 +20,7 @@ struct ActBwdParams {
     float alpha, inv_alpha;
     int pooled, W;            // pooled: dy is [N,H/2,W/2,C], the gradient of a 2x2 box average: every input pixel of a 2x2 cell gets dy * dy_scale
     float dy_scale;
+    const uint32_t* mask;     // or null: 1 bit per element instead of y: one 32-bit word per (2x2 cell, 8-channel group), byte (h&1)*2 + (w&1), bit k = y[8 g + k] > 0 (agf_pool2x2)
     const float* dscale;      // [N,C] or null: the incoming gradient is dy * dscale[n,c] (agf_act_bwd_reduce_scaled: dy = the data gradient t of
     float* sumD;              //   the consumer's modulated conv, dscale = its style scale s); sumD[n,c] += sum_p y * dy  (= that conv's d s)
 };
@@ -27,7 +28,7 @@ struct ActBwdParams {
 #ifndef ACTBWD_U
 #define ACTBWD_U 2          // (4 measured the same: the kernel is not short of loads in flight)
 #endif
-template <class T, int VEC, bool SCALED = false>
+template <class T, int VEC, bool SCALED = false, bool MASKED = false>
 __global__ void __launch_bounds__(256) act_bwd_reduce_kernel(ActBwdParams p) {
     __shared__ float red[SCALED ? 4 : 3][256][VEC + 1];
     const int tid = threadIdx.x;
@@ -61,7 +62,16 @@ __global__ void __launch_bounds__(256) act_bwd_reduce_kernel(ActBwdParams p) {
                 } else {
                     VecIO<T, VEC>::load((const T*)p.dy + base + (int64_t)px * p.C, dy[u]);
                 }
-                VecIO<T, VEC>::load((const T*)p.y + base + (int64_t)px * p.C, y[u]);
+                if (MASKED) {
+                    // the sign of y from the 1-bit mask (1/16 of the bytes of y); only the sum of g is formed in this mode
+                    const int h = px / p.W, w = px - h * p.W;
+                    const unsigned word = p.mask[((int64_t)n * (p.HW >> 2) + (h >> 1) * (p.W >> 1) + (w >> 1)) * (p.C >> 3) + cg];
+                    const unsigned m = word >> (8 * ((h & 1) * 2 + (w & 1)));
+#pragma unroll
+                    for (int i = 0; i < VEC; i++) y[u][i] = ((m >> i) & 1u) ? 1.f : -1.f;
+                } else {
+                    VecIO<T, VEC>::load((const T*)p.y + base + (int64_t)px * p.C, y[u]);
+                }
                 nzv[u] = p.noise ? p.noise[(int64_t)n * p.HW + px] : 0.f;
             }
 #pragma unroll
@@ -178,22 +188,25 @@ static int plan(int C, int vec, int HW, int N, int* CG, int* pixLanes, int* pixP
 static int act_bwd_reduce_impl(const void* dy, const void* y, const float* noise, void* g,
                                float* sum_gy0, float* sum_g, float* sum_gnoise,
                                int dtype, int32_t N, int32_t H, int32_t W, int32_t C, float alpha, int pooled, float dy_scale, void* stream,
-                               const float* dscale = nullptr, float* sum_ydy = nullptr) {
-    AGF_CHECK(dy && y && g, "act_bwd_reduce: null pointer");
+                               const float* dscale = nullptr, float* sum_ydy = nullptr, const uint32_t* mask = nullptr) {
+    AGF_CHECK(dy && (y || mask) && g, "act_bwd_reduce: null pointer");
     AGF_CHECK(dtype == AGF_BF16 || dtype == AGF_F32, "act_bwd_reduce: dtype must be bf16 or f32");
     AGF_CHECK(alpha > 0.f, "act_bwd_reduce: the leaky slope must be positive");
     AGF_CHECK(N <= 65535, "act_bwd_reduce: batch too large");
     ActBwdParams p;
     p.dy = dy; p.y = y; p.noise = noise; p.g = g; p.sumA = sum_gy0; p.sumB = sum_g; p.sumC = sum_gnoise;
     p.N = N; p.HW = H * W; p.C = C; p.alpha = alpha; p.inv_alpha = 1.f / alpha;
-    p.pooled = pooled; p.W = W; p.dy_scale = dy_scale; p.dscale = dscale; p.sumD = sum_ydy;
+    p.pooled = pooled; p.W = W; p.dy_scale = dy_scale; p.dscale = dscale; p.sumD = sum_ydy; p.mask = mask;
     const int vec = dtype == AGF_BF16 ? 8 : 4;
     if (!plan(C, vec, p.HW, N, &p.CG, &p.pixLanes, &p.pixPerBlock, &p.chunks)) {
         agf_set_error("act_bwd_reduce: C=%d is not a multiple of %d (or too wide)", C, vec);
         return AGF_ENOKERNEL;
     }
     dim3 grid((unsigned)p.chunks, (unsigned)N), block(256);
-    if (dscale) {
+    if (mask) {
+        AGF_CHECK(dtype == AGF_BF16 && !dscale && !sum_gy0 && !sum_gnoise, "act_bwd_reduce: the 1-bit mask mode is bf16, bias sum only");
+        hipLaunchKernelGGL((act_bwd_reduce_kernel<bf16_t, 8, false, true>), grid, block, 0, (hipStream_t)stream, p);
+    } else if (dscale) {
         if (dtype == AGF_BF16) hipLaunchKernelGGL((act_bwd_reduce_kernel<bf16_t, 8, true>), grid, block, 0, (hipStream_t)stream, p);
         else hipLaunchKernelGGL((act_bwd_reduce_kernel<float, 4, true>), grid, block, 0, (hipStream_t)stream, p);
     } else if (dtype == AGF_BF16) hipLaunchKernelGGL((act_bwd_reduce_kernel<bf16_t, 8>), grid, block, 0, (hipStream_t)stream, p);
@@ -219,6 +232,71 @@ extern "C" int agf_act_bwd_reduce_pooled(const void* dy_half, const void* y, voi
                                          int dtype, int32_t N, int32_t H, int32_t W, int32_t C, float alpha, float dy_scale, void* stream) {
     AGF_CHECK(H % 2 == 0 && W % 2 == 0, "act_bwd_reduce_pooled: H and W must be even");
     return act_bwd_reduce_impl(dy_half, y, nullptr, g, nullptr, sum_g, nullptr, dtype, N, H, W, C, alpha, 1, dy_scale, stream);
+}
+
+extern "C" int agf_act_bwd_reduce_pooled_mask(const void* dy_half, const void* mask, void* g, float* sum_g,
+                                              int dtype, int32_t N, int32_t H, int32_t W, int32_t C, float alpha, float dy_scale, void* stream) {
+    AGF_CHECK(H % 2 == 0 && W % 2 == 0 && C % 8 == 0, "act_bwd_reduce_pooled_mask: H and W must be even, C a multiple of 8");
+    AGF_CHECK(mask, "act_bwd_reduce_pooled_mask: null mask");
+    return act_bwd_reduce_impl(dy_half, nullptr, nullptr, g, nullptr, sum_g, nullptr, dtype, N, H, W, C, alpha, 1, dy_scale, stream, nullptr, nullptr,
+                               (const uint32_t*)mask);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// agf_pool2x2: y[n, h, w, c] = gain / 4 * sum of the 2x2 cell of x (nn.AvgPool2d(2), reference implementations/StyleGAN2/model.py:204 -- the
+// [1,1] x [1,1] box FIR of upfirdn2d with down = 2), channels-last, and optionally the 1-bit sign mask of x for the activation backward
+// (one 32-bit word per 2x2 cell and 8-channel group: byte (h&1)*2 + (w&1), bit k = x[.., 8 g + k] > 0): the one pass that reads the full-resolution activation anyway also leaves what
+// the backward pass needs of it at 1/16 of its bytes.  Thread = one 16-byte channel vector of one OUTPUT pixel: four 16-byte loads.
+template <class T, int VEC, bool MASK>
+__global__ void __launch_bounds__(256) pool2x2_kernel(const T* __restrict__ x, T* __restrict__ y, uint32_t* __restrict__ mask,
+                                                      int N, int Ho, int Wo, int C, float gain, int64_t total) {
+    const int CG = C / VEC;
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < total; r += (int64_t)gridDim.x * 256) {
+        const int cg = (int)(r % CG);
+        int64_t q = r / CG;
+        const int ow = (int)(q % Wo); q /= Wo;
+        const int oh = (int)(q % Ho);
+        const int64_t n = q / Ho;
+        const int W = 2 * Wo;
+        const int64_t pix = (n * (2 * Ho) + 2 * oh) * W + 2 * ow;
+        const T* src = x + pix * C + cg * VEC;
+        float a[VEC], b[VEC], c[VEC], d[VEC], o[VEC];
+        VecIO<T, VEC>::load(src, a);
+        VecIO<T, VEC>::load(src + C, b);
+        VecIO<T, VEC>::load(src + (int64_t)W * C, c);
+        VecIO<T, VEC>::load(src + (int64_t)W * C + C, d);
+#pragma unroll
+        for (int i = 0; i < VEC; i++) o[i] = (a[i] + b[i] + c[i] + d[i]) * gain;
+        VecIO<T, VEC>::store(y + ((n * Ho + oh) * Wo + ow) * C + cg * VEC, o);
+        if (MASK) {
+            unsigned ma = 0, mb = 0, mc = 0, md = 0;
+#pragma unroll
+            for (int i = 0; i < VEC; i++) {
+                ma |= (a[i] > 0.f ? 1u : 0u) << i; mb |= (b[i] > 0.f ? 1u : 0u) << i;
+                mc |= (c[i] > 0.f ? 1u : 0u) << i; md |= (d[i] > 0.f ? 1u : 0u) << i;
+            }
+            mask[((n * Ho + oh) * Wo + ow) * CG + cg] = ma | (mb << 8) | (mc << 16) | (md << 24);     // one coalesced word per lane
+        }
+    }
+}
+
+extern "C" int agf_pool2x2(const void* x, void* y, void* mask, int dtype, int32_t N, int32_t H, int32_t W, int32_t C, float gain, void* stream) {
+    AGF_CHECK(x && y, "pool2x2: null pointer");
+    AGF_CHECK(dtype == AGF_BF16 || dtype == AGF_F32, "pool2x2: dtype must be bf16 or f32");
+    AGF_CHECK(N >= 1 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0, "pool2x2: H and W must be even");
+    const int vec = dtype == AGF_BF16 ? 8 : 4;
+    AGF_CHECK(C % vec == 0, "pool2x2: C must be a multiple of 16 bytes");
+    AGF_CHECK(!mask || dtype == AGF_BF16, "pool2x2: the sign mask is made for bfloat16 tensors");
+    const int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / vec);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipStream_t st = (hipStream_t)stream;
+    const float g4 = gain * 0.25f;
+    if (dtype == AGF_F32) hipLaunchKernelGGL((pool2x2_kernel<float, 4, false>), dim3((unsigned)blocks), dim3(256), 0, st, (const float*)x, (float*)y, nullptr, N, H / 2, W / 2, C, g4, total);
+    else if (mask) hipLaunchKernelGGL((pool2x2_kernel<bf16_t, 8, true>), dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, (uint32_t*)mask, N, H / 2, W / 2, C, g4, total);
+    else hipLaunchKernelGGL((pool2x2_kernel<bf16_t, 8, false>), dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, nullptr, N, H / 2, W / 2, C, g4, total);
+    AGF_LAUNCH_CHECK();
+    return AGF_OK;
 }
 
 extern "C" int agf_scale_dot(const void* x, const void* t, const float* s, void* dx, float* ds,

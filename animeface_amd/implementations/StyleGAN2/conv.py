@@ -518,6 +518,35 @@ def act_bwd_reduce_pooled_raw(dy_half, y, alpha, dy_scale, want_sum):
     return g, B
 
 
+def pool2x2_covers(x):
+    return x.is_cuda and x.dim() == 4 and x.dtype in (torch.bfloat16, torch.float32) and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 \
+        and x.shape[1] % (8 if x.dtype == torch.bfloat16 else 4) == 0
+
+
+def pool2x2_raw(x, gain=1.0, want_mask=False):
+    """One ``agf_pool2x2`` launch: gain * AvgPool2d(2)(x), channels-last; with ``want_mask`` (bf16) also the 1-bit sign mask of x
+    ([N, H/2, W/2, C/8] words: one byte per pixel of the 2x2 cell) that ``act_bwd_reduce_pooled_mask_raw`` reads in place of x."""
+    x = x.contiguous(memory_format=torch.channels_last)
+    N, C, H, W = x.shape
+    y = torch.empty((N, C, H // 2, W // 2), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    mask = torch.empty((N, H // 2, W // 2, C // 8), dtype=torch.int32, device=x.device) if want_mask else None
+    rc = _lib.lib().agf_pool2x2(_lib.ptr(x), _lib.ptr(y), _lib.ptr(mask), _lib.dtype_code(x), N, H, W, C, float(gain), _lib.stream_ptr(x))
+    _lib.check(rc, 'pool2x2')
+    return y, mask
+
+
+def act_bwd_reduce_pooled_mask_raw(dy_half, mask, like, alpha, dy_scale, want_sum):
+    """``agf_act_bwd_reduce_pooled_mask``: as ``act_bwd_reduce_pooled_raw`` with the sign of y read from the 1-bit mask."""
+    N, C, H, W = like.shape
+    assert dy_half.shape == (N, C, H // 2, W // 2) and dy_half.dtype == like.dtype and mask.shape == (N, H // 2, W // 2, C // 8)
+    g = torch.empty_like(like)
+    B = _zeros_f32((N, C), like.device) if want_sum else None
+    rc = _lib.lib().agf_act_bwd_reduce_pooled_mask(_lib.ptr(dy_half), _lib.ptr(mask), _lib.ptr(g), _lib.ptr(B),
+                                                   _lib.dtype_code(like), N, H, W, C, float(alpha), float(dy_scale), _lib.stream_ptr(like))
+    _lib.check(rc, 'act_bwd_reduce_pooled_mask')
+    return g, B
+
+
 def demod_grad_finish_raw(A, B, Cn, bias, s_out, want_dso, want_db, gain=1.0):
     """One ``agf_demod_grad_finish`` launch: (dso [N,C] or None, db [C] or None) from the sums of ``act_bwd_reduce``."""
     N, C = B.shape
@@ -771,13 +800,14 @@ class PremaskLink:
     """Handshake between two chained fused convs  y1 = lrelu(conv1(x) + b1);  y2 = conv2(y1)  where conv2 is the ONLY consumer of y1
     (the caller guarantees that: DBlock).  conv2's backward then produces the gradient of y1 already multiplied by lrelu'(y1) and its
     per-channel sums (``agf_conv2d_fwd_mask``), and conv1's backward skips its own pass over the tensor (``agf_act_bwd_reduce``)."""
-    __slots__ = ('armed', 'alpha', 'premasked', 'bsum', 'pooled', 'armed_mod', 'noise', 'sums')
+    __slots__ = ('armed', 'alpha', 'premasked', 'bsum', 'pooled', 'armed_mod', 'noise', 'sums', 'mask')
 
     def __init__(self):
         self.armed, self.alpha, self.premasked, self.bsum, self.pooled = False, 0.2, False, None, None
         # modulated producer -> modulated consumer (generator block): the consumer's backward runs agf_act_bwd_reduce_scaled, which
         # turns its unscaled data gradient t straight into the producer's masked gradient and leaves the producer's sums here
         self.armed_mod, self.noise, self.sums = False, None, None
+        self.mask = None     # 1-bit sign mask of the producer's output, left by the pooling consumer's forward (agf_pool2x2)
 
 
 class _UpBlur(torch.autograd.Function):
@@ -832,6 +862,14 @@ class _PoolLinked(torch.autograd.Function):
         from ...stylegan3_ops import upfirdn2d
         ctx.save_for_backward(f)
         ctx.gain, ctx.link, ctx.x_shape = gain, link, x.shape
+        if POOL_KERNEL and pool2x2_covers(x):
+            # the dedicated 2x2 kernel; when the producer's backward will take the pooled gradient through the link it also leaves the
+            # 1-bit sign mask of x, which that backward then reads instead of x (1/16 of the bytes)
+            want_mask = link is not None and link.armed and _PREMASK and x.dtype == torch.bfloat16
+            y, mask = pool2x2_raw(x.detach(), gain, want_mask)
+            if want_mask:
+                link.mask = mask
+            return y
         return upfirdn2d.downsample2d(x.detach(), f, down=2, gain=gain)
 
     @staticmethod
@@ -912,6 +950,7 @@ def torgb(x, weight, bias, s_raw, pre, coef):
     return _ToRGB.apply(x, weight, bias, s_raw, pre, coef)
 
 
+POOL_KERNEL = True     # agf_pool2x2 for the DBlock's AvgPool2d(2) (False: the [1,1] box FIR of upfirdn2d; tests compare the two)
 _PREMASK = True        # tests/test_hip_conv.py::test_dblock_linked_backward_matches_unlinked runs the block with the fused hand-offs off
 
 
@@ -940,7 +979,7 @@ class _FusedConv(torch.autograd.Function):
         if skip_pool is not None:
             from ...stylegan3_ops import upfirdn2d
             f, pool_gain = skip_pool
-            tp = upfirdn2d.downsample2d(x.detach(), f, down=2, gain=pool_gain)
+            tp = pool2x2_raw(x.detach(), pool_gain)[0] if (POOL_KERNEL and pool2x2_covers(x)) else upfirdn2d.downsample2d(x.detach(), f, down=2, gain=pool_gain)
             ctx.pool = (f, float(pool_gain))
         if post_link is not None and _PREMASK and act == ACT_LRELU and gain == 1.0 and s_out is None and noise is None \
                 and x.dtype == torch.bfloat16:
@@ -1006,7 +1045,11 @@ class _FusedConv(torch.autograd.Function):
         # weight-gradient scale and in the bias sum (no pass over the tensor for it)
         pg = float(gain)
         if pooled is not None:
-            g, B = act_bwd_reduce_pooled_raw(pooled[0], y, alpha, pooled[1], need_b and bias is not None)
+            mask, link.mask = link.mask, None
+            if mask is not None:
+                g, B = act_bwd_reduce_pooled_mask_raw(pooled[0], mask, y, alpha, pooled[1], need_b and bias is not None)
+            else:
+                g, B = act_bwd_reduce_pooled_raw(pooled[0], y, alpha, pooled[1], need_b and bias is not None)
             if need_b and bias is not None:
                 db = demod_grad_finish_raw(None, B, None, None, None, False, True)[1].to(bias.dtype)
         elif link is not None and link.premasked and link.sums is not None:

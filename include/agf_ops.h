@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define AGF_ABI_VERSION 16
+#define AGF_ABI_VERSION 17
 
 /* element types of activation tensors */
 enum { AGF_F32 = 0, AGF_F16 = 1, AGF_BF16 = 2, AGF_F64 = 3 };
@@ -239,6 +239,15 @@ int agf_act_bwd_reduce_scaled(const void* t, const void* y, const float* noise, 
  * the full-resolution gradient of the pooling is never written or re-read.  H, W even. */
 int agf_act_bwd_reduce_pooled(const void* dy_half, const void* y, void* g, float* sum_g,
                               int dtype, int32_t N, int32_t H, int32_t W, int32_t C, float alpha, float dy_scale, void* stream);
+
+/* nn.AvgPool2d(2) of a channels-last tensor (implementations/StyleGAN2/model.py:204; = the reference's upfirdn2d with the [1,1] x [1,1] box
+ * filter and down = 2, upfirdn2d.py downsample2d) as a dedicated streaming kernel (ABI v17):  y [N][H/2][W/2][C] = gain / 4 * (2x2 cell sum).
+ * mask (nullable, bf16 only): [N][H/2][W/2][C/8] 32-bit words, one per 2x2 cell and 8-channel group g: byte (h&1)*2 + (w&1), bit k =
+ * x[n, h, w, 8 g + k] > 0 -- the sign of the LeakyReLU output that the activation backward needs, at 1/16 of the bytes of x.  agf_act_bwd_reduce_pooled_mask is agf_act_bwd_reduce_pooled reading that mask
+ * instead of y. */
+int agf_pool2x2(const void* x, void* y, void* mask, int dtype, int32_t N, int32_t H, int32_t W, int32_t C, float gain, void* stream);
+int agf_act_bwd_reduce_pooled_mask(const void* dy_half, const void* mask, void* g, float* sum_g,
+                                   int dtype, int32_t N, int32_t H, int32_t W, int32_t C, float alpha, float dy_scale, void* stream);
 
 /*   dx = t * s[n,c]  (nullable),   ds[n,c] += sum_{h,w} x * t */
 int agf_scale_dot(const void* x, const void* t, const float* s, void* dx, float* ds,

@@ -429,3 +429,37 @@ def test_torgb_vs_composite(shape, with_pre):
         assert a.shape == b.shape, name
         err = (a.float() - b).abs().max().item()
         assert err <= tol * max(b.abs().max().item(), 1e-6) + 1e-30, (name, err, b.abs().max().item())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(3, 64, 32, 32), (2, 40, 18, 38), (5, 512, 4, 4), (2, 8, 64, 66), (64, 32, 16, 16)])
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+def test_pool2x2_and_sign_mask_vs_torch(shape, dtype):
+    """``agf_pool2x2`` = gain * AvgPool2d(2) (reference model.py:204) and, for bf16, the 1-bit sign mask that ``agf_act_bwd_reduce_pooled_mask``
+    reads in place of the activation: same g and bias sum as the variant that reads y."""
+    from animeface_amd.implementations.StyleGAN2 import conv as C
+    from animeface_amd.stylegan3_ops import upfirdn2d
+    N, Cc, H, W = shape
+    g = torch.Generator().manual_seed(Cc + H)
+    x = torch.randn(N, Cc, H, W, generator=g).to(DEV, dtype).contiguous(memory_format=torch.channels_last)
+    x[0, :, 0, 0] = 0                                                     # zeros are "not positive"
+    want_mask = dtype == torch.bfloat16
+    y, mask = C.pool2x2_raw(x, 0.7071, want_mask)
+    ref = F.avg_pool2d(x.float(), 2) * 0.7071
+    tol = 2 ** -8 if dtype == torch.bfloat16 else 1e-6
+    assert (y.float() - ref).abs().max().item() <= tol * ref.abs().max().item()
+    f = upfirdn2d.setup_filter([1, 1], device=DEV)
+    y_fir = upfirdn2d.downsample2d(x, f, down=2, gain=0.7071)            # the FIR formulation it replaces
+    assert (y.float() - y_fir.float()).abs().max().item() <= tol * ref.abs().max().item()
+    if not want_mask:
+        return
+    bits = (x.permute(0, 2, 3, 1) > 0).reshape(N, H // 2, 2, W // 2, 2, Cc // 8, 8).to(torch.int64)      # [n, oh, dy, ow, dx, g, k]
+    ar2, ar8 = torch.arange(2, device=DEV), torch.arange(8, device=DEV)
+    shifts = (8 * (2 * ar2[:, None, None] + ar2[None, :, None]) + ar8[None, None, :]).reshape(1, 1, 2, 1, 2, 1, 8)        # [dy, dx, k]
+    expect = (bits << shifts).sum(dim=(2, 4, 6))
+    assert torch.equal(mask.to(torch.int64) & 0xffffffff, expect)
+    dyh = torch.randn(N, Cc, H // 2, W // 2, generator=g).to(DEV, dtype).contiguous(memory_format=torch.channels_last)
+    g1, b1 = C.act_bwd_reduce_pooled_raw(dyh, x, 0.2, 0.25 * 0.7071, True)
+    g2, b2 = C.act_bwd_reduce_pooled_mask_raw(dyh, mask, x, 0.2, 0.25 * 0.7071, True)
+    assert torch.equal(g1, g2)
+    assert (b1 - b2).abs().max().item() <= 1e-5 * b1.abs().max().item()
