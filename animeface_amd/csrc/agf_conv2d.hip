@@ -212,6 +212,9 @@ static __device__ __forceinline__ void conv_epilogue_pl(const ConvParams& p, f32
     float msum[MT * 16];
 #pragma unroll
     for (int e = 0; e < MT * 16; e++) msum[e] = 0.f;
+    // residual of a LINEAR epilogue with unit gain (the DBlock's skip conv: y = conv + bias + pool(x)): added after the lane swap, where a
+    // lane owns 8 consecutive channels of a pixel -- one 16-byte load instead of two 8-byte gathers a pixel row apart
+    const bool resPost = MT == 1 && p.residual && p.act != 3 && p.gain == 1.f;     // (64-channel tile only: the 128-channel kernels have no registers to spare)
 #pragma unroll
     for (int j = 0; j < NJ; j++) {
         const int64_t pi = pixIdx[j];
@@ -252,7 +255,7 @@ static __device__ __forceinline__ void conv_epilogue_pl(const ConvParams& p, f32
                         }
 #pragma unroll
                         for (int e = 0; e < 4; e++) v[e] += nz[j];
-                        if (p.residual && valid[j]) {
+                        if (p.residual && !resPost && valid[j]) {
                             const u32x2 rr = *(const u32x2*)(p.residual + pi * p.Cout + co);
                             float a0, a1;
                             Pack16<bf16_t>::unpack(rr.x, a0, a1); v[0] += a0; v[1] += a1;
@@ -273,10 +276,19 @@ static __device__ __forceinline__ void conv_epilogue_pl(const ConvParams& p, f32
                 const auto s1 = __builtin_amdgcn_permlane32_swap(P[0][1], P[1][1], false, false);
                 u32x4 val = {s0[0], s1[0], s0[1], s1[1]};
                 const int cb = coW + i * 32 + (2 * q + lhi) * 8;
-                if (p.res_pooled || p.mask_y) {
+                if (p.res_pooled || p.mask_y || resPost) {
                     float g[8];
                     Pack16<bf16_t>::unpack(val.x, g[0], g[1]); Pack16<bf16_t>::unpack(val.y, g[2], g[3]);
                     Pack16<bf16_t>::unpack(val.z, g[4], g[5]); Pack16<bf16_t>::unpack(val.w, g[6], g[7]);
+                    if (MT == 1 && resPost) {
+                        float rv[8];
+                        u32x4 rsv = u32x4{0u, 0u, 0u, 0u};
+                        if (valid[j] && cb < p.Cout) rsv = *(const u32x4*)(p.residual + pi * p.Cout + cb);
+                        Pack16<bf16_t>::unpack(rsv.x, rv[0], rv[1]); Pack16<bf16_t>::unpack(rsv.y, rv[2], rv[3]);
+                        Pack16<bf16_t>::unpack(rsv.z, rv[4], rv[5]); Pack16<bf16_t>::unpack(rsv.w, rv[6], rv[7]);
+#pragma unroll
+                        for (int e = 0; e < 8; e++) g[e] += rv[e];
+                    }
                     if (p.res_pooled) {
                         float rv[8];
                         Pack16<bf16_t>::unpack(rp[i][q].x, rv[0], rv[1]); Pack16<bf16_t>::unpack(rp[i][q].y, rv[2], rv[3]);
@@ -1731,6 +1743,11 @@ static int conv2d_fwd_impl(const void* x, const void* w, void* y,
     if (ksize == 3) {
         // high-resolution, few-channel layers: the persistent multi-stage kernel (agf_conv2d_pipe.hip)
         const int rc = agf_conv2d_pipe_launch(p, (hipStream_t)stream);
+        if (rc == AGF_OK) { AGF_LAUNCH_CHECK(); return AGF_OK; }
+        if (rc != AGF_ENOKERNEL) return rc;
+    } else if (ksize == 1) {
+        // few-channel, many-pixel 1x1 layers (the DBlock's skip conv and its data gradient): the streaming kernel (agf_conv1x1.hip)
+        const int rc = agf_conv1x1_stream_launch(p, (hipStream_t)stream);
         if (rc == AGF_OK) { AGF_LAUNCH_CHECK(); return AGF_OK; }
         if (rc != AGF_ENOKERNEL) return rc;
     }

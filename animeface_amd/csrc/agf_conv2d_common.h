@@ -61,6 +61,9 @@ struct ConvParams {
 // persistent multi-stage direct-to-LDS kernel (agf_conv2d_pipe.hip); AGF_ENOKERNEL = shape not covered, use the other kernels
 int agf_conv2d_pipe_launch(const ConvParams& p, hipStream_t st);
 
+// streaming 1x1 kernel for the few-channel, many-pixel layers (agf_conv1x1.hip); AGF_ENOKERNEL = shape not covered
+int agf_conv1x1_stream_launch(const ConvParams& p, hipStream_t st);
+
 // multi-stage ring variant of the 3x3 weight gradient (agf_conv2d_wgrad_ring.hip); AGF_ENOKERNEL = shape not covered.
 // workspace (optional): scratch of agf_conv2d_wgrad_ring_workspace() bytes -> two-stage combine, dw is overwritten instead of accumulated into
 int agf_conv2d_wgrad_ring_launch(const void* x, const void* dy, float* dw, const float* in_scale, const float* out_scale,
