@@ -893,6 +893,49 @@ def pool2x_linked(x, f, gain, link):
     return _PoolLinked.apply(x, f, gain, link)
 
 
+class _MapLayer(torch.autograd.Function):
+    """``lrelu((x * coef @ W^T + b) * lr)``: MapLinear + LeakyReLU of the mapping network (reference model.py:71-78, :263-282) as one
+    launch (``agf_map_layer_fwd``), two in backward (``agf_map_layer_bwd``).  fp32, first-order."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, alpha, beta, slope):
+        x = _f32(x)
+        w = _f32(weight.detach())
+        b = _f32(bias.detach()) if bias is not None else None
+        B, Din = x.shape
+        Dout = w.shape[0]
+        y = torch.empty((B, Dout), dtype=torch.float32, device=x.device)
+        rc = _lib.lib().agf_map_layer_fwd(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), B, Din, Dout, float(alpha), float(beta), float(slope),
+                                          _lib.stream_ptr(x))
+        _lib.check(rc, 'map_layer_fwd')
+        ctx.save_for_backward(x, weight, y)
+        ctx.args = (float(alpha), float(beta), float(slope), bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        alpha, beta, slope, has_bias = ctx.args
+        if torch.is_grad_enabled() and dy.requires_grad:
+            raise RuntimeError('the fused mapping layer has no double backward (model.MAP_FUSED = False composes the separate operators)')
+        need_x, need_w, need_b = ctx.needs_input_grad[:3]
+        dy = _f32(dy)
+        w = _f32(weight.detach())
+        B, Din = x.shape
+        Dout = w.shape[0]
+        dx = torch.empty_like(x) if need_x else None
+        dw = torch.empty_like(w) if (need_w or (need_b and has_bias)) else None
+        db = torch.empty((Dout,), dtype=torch.float32, device=x.device) if (need_b and has_bias) else None
+        rc = _lib.lib().agf_map_layer_bwd(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(x), _lib.ptr(w), _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(db),
+                                          B, Din, Dout, alpha, beta, slope, _lib.stream_ptr(x))
+        _lib.check(rc, 'map_layer_bwd')
+        return dx, (dw.to(weight.dtype) if need_w else None), db, None, None, None
+
+
+def map_layer(x, weight, bias, alpha, beta, slope):
+    return _MapLayer.apply(x, weight, bias, alpha, beta, slope)
+
+
 def torgb_covers(x, image_channels):
     return x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and bool(_lib.lib().agf_torgb_covers(x.shape[1], image_channels))
 

@@ -28,13 +28,16 @@ import torch.nn.functional as F
 
 from ...stylegan3_ops import upfirdn2d, bias_act
 from ... import rng
-from .conv import conv2d, conv2d_act, style_demod, PremaskLink, pool2x_linked, up_blur, torgb, torgb_covers
+from .conv import conv2d, conv2d_act, style_demod, PremaskLink, pool2x_linked, up_blur, torgb, torgb_covers, map_layer
 
 
 # bias / noise / leaky-ReLU run in the conv kernel's epilogue (with a fused backward).  The fused modulated conv has
 # no double backward, so the generator falls back to the separately differentiable ops when ``fused_epilogue=False``
 # (needed only for the path-length penalty, pl_lambda > 0).
 FUSED_EPILOGUE = True
+MAP_FUSED = False         # mapping network: one launch per layer (agf_map_layer_*) instead of addmm + leaky_relu_.  OFF: 72 fewer launches per
+#                           iteration, and the replayed iteration is 1.1 ms SLOWER -- with it every pace candidate settles in a medium power
+#                           state (34.8 ms) instead of the good one (33.7 ms), profiles/r04_power_state.txt; tests compare the two paths
 TORGB_FUSED = True        # ToImage as one streaming launch each way (agf_torgb_*); False: the MFMA 1x1 conv on zero-padded operands (tests / A-B runs)
 
 
@@ -381,6 +384,15 @@ class Mapping(nn.Module):
         x = x.float()
         if self.normalize is not None:
             x = self.normalize(x)
+        mods = list(self.map)
+        if MAP_FUSED and x.is_cuda and x.dim() == 2 and len(mods) % 2 == 0 and all(
+                isinstance(a, MapLinear) and isinstance(a.linear, ELR) and isinstance(a.linear.layer, nn.Linear) and a.linear.layer.bias is not None
+                and isinstance(b, nn.LeakyReLU) for a, b in zip(mods[0::2], mods[1::2])):
+            # (x * coef @ W^T + b) * lr -> LeakyReLU, one launch per layer (and two in backward) instead of three (and seven)
+            for a, b in zip(mods[0::2], mods[1::2]):
+                elr = a.linear
+                x = map_layer(x, elr.layer.weight, elr.layer.bias, elr.coef * a.lr, a.lr, b.negative_slope)
+            return x
         return self.map(x)
 
 

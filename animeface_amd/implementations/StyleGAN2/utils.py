@@ -339,13 +339,13 @@ class GraphedTrainStep:
       * ``'segmented'`` (gloo, whose collectives run on host threads, or on request): THREE graphs cut at the two gradient exchanges,
         the bucket buffers all-reduced between the launches (``GradReducer.exchange_all``); the exchange is then exposed."""
 
-    PACE_CANDIDATES = (0, 1, 2)     # node counts recorded side by side when pace='auto'
+    PACE_CANDIDATES = (0, 1, 2, 3)  # node counts recorded side by side when pace='auto'
     PACE_BLOCK = 12                 # consecutive iterations per candidate while selecting (the first 5 of a block are not counted: the
     #                                 package-power controller takes a few iterations to settle after the node structure changes)
 
     def __init__(self, step, real, warmup=3, dp_mode=None, pace=0):
         """``pace``: number of memset nodes at the head of every recorded iteration (``TrainStep._pace``), or ``'auto'``: every iteration kind
-        is recorded once per candidate count (``PACE_CANDIDATES``; the recordings stay resident, ~12 GB each at 256x256 / batch 64) and
+        is recorded once per candidate count (``PACE_CANDIDATES``; the recordings stay resident, ~12 GB each at 256x256 / batch 64: 48 of 288 GB) and
         the first ``len(PACE_CANDIDATES) * PACE_BLOCK`` training iterations rotate through them in blocks, timed with events; from
         then on the count with the smallest median iteration time is replayed.  Every recording computes the same iteration, so the
         selection costs no training step."""

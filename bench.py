@@ -143,7 +143,7 @@ def main():
                                                          'from HIP graphs (GraphedTrainStep: same kernels, one host call per iteration and graph segment); '
                                                          'the iterations sampled for the per-launch roofline timing always run eagerly')
     ap.add_argument('--pace', default='auto', help="memset nodes at the head of the recorded iteration: an integer, or 'auto' = calibrate 0..3 by timing replays (GraphedTrainStep.calibrate)")
-    ap.add_argument('--ab', default='', help='comma-separated A/B switches for same-box comparisons: no-torgb')
+    ap.add_argument('--ab', default='', help='comma-separated A/B switches for same-box comparisons: no-torgb, no-mapfuse, candN (N pace candidates)')
     ap.add_argument('--dp-mode', default=None, choices=['ingraph', 'segmented'],
                     help='several ranks under graph replay: ingraph (default with RCCL) = ONE graph per iteration kind with the bucket all-reduces '
                          'recorded from the backward hooks on the RCCL stream (overlapped with the rest of backward); segmented = three graphs '
@@ -162,6 +162,11 @@ def main():
     ab = set(filter(None, args.ab.split(',')))
     if 'no-torgb' in ab:
         M.TORGB_FUSED = False
+    if 'no-mapfuse' in ab:
+        M.MAP_FUSED = False
+    for item in ab:
+        if item.startswith('cand'):
+            U.GraphedTrainStep.PACE_CANDIDATES = tuple(range(int(item[4:])))
 
     rank, world, local_rank = dp.init_distributed()
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'

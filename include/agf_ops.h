@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define AGF_ABI_VERSION 17
+#define AGF_ABI_VERSION 18
 
 /* element types of activation tensors */
 enum { AGF_F32 = 0, AGF_F16 = 1, AGF_BF16 = 2, AGF_F64 = 3 };
@@ -352,6 +352,17 @@ int agf_ada_pad_up2(const void* x, void* u, const int32_t* margins, const float*
                     int32_t H, int32_t W, int backward, void* stream);
 int agf_ada_warp_resample(const void* x, void* y, const float* theta, const int32_t* margins, int dtype, int32_t B, int32_t C,
                           int32_t Hb, int32_t Wb, int32_t Hout, int32_t Wout, int backward, void* stream);
+
+/* One layer of the mapping network (implementations/StyleGAN2/model.py:71-78 MapLinear + nn.LeakyReLU, :263-282), fp32 (ABI v18):
+ *   agf_map_layer_fwd:  y[b,o] = lrelu( alpha * sum_k x[b,k] W[o,k] + beta * bias[o] )        (alpha = coef * lr, beta = lr; bias nullable)
+ *   agf_map_layer_bwd:  g = dy * lrelu'(y);  dx = alpha * g @ W (nullable);  dW = alpha * g^T @ x and db = beta * sum_b g (dW nullable,
+ *                       db nullable; db is produced with dW).
+ * x [B][Din], W [Dout][Din], y / dy [B][Dout], dense row-major; Din, Dout <= 1024.  One launch forward, two backward (the library path
+ * was 3 and 7 launches per layer). */
+int agf_map_layer_fwd(const float* x, const float* W, const float* bias, float* y, int32_t B, int32_t Din, int32_t Dout,
+                      float alpha, float beta, float slope, void* stream);
+int agf_map_layer_bwd(const float* dy, const float* y, const float* x, const float* W, float* dx, float* dW, float* db,
+                      int32_t B, int32_t Din, int32_t Dout, float alpha, float beta, float slope, void* stream);
 
 /* ToImage ("ToRGB") of the StyleGAN2 generator in one streaming pass each way (ABI v16; implementations/StyleGAN2/model.py:239-250: a 1x1
  * ModulatedConv2d without demodulation, model.py:91-135, + the skip sum with the previous level's image).  With IC <= 4 output channels

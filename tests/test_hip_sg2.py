@@ -3,6 +3,7 @@ reference's own modules / train() and against the CPU oracle.
 
 fp32 compute mode: <= 1e-3 relative (north_star tolerance for fp32 activations).
 bf16 compute mode (the training path): compared with the fp32 oracle at bf16-level tolerance."""
+import functools
 import numpy as np
 import pytest
 import torch
@@ -456,3 +457,32 @@ def test_train_with_graphs_consumes_no_iterations_and_matches_the_eager_run():
     assert [h[0] for h in hg] == list(range(9))             # every iteration went through the logging path
     for (i0, d0, g0), (i1, d1, g1) in zip(he, hg):
         assert d0 == pytest.approx(d1, rel=1e-3, abs=1e-4) and g0 == pytest.approx(g1, rel=1e-3, abs=1e-4), (he, hg)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,D', [(64, 512), (128, 512), (5, 64), (70, 96)])
+def test_fused_mapping_network_matches_the_composite(B, D, monkeypatch):
+    """``agf_map_layer_fwd`` / ``agf_map_layer_bwd`` (MapLinear + LeakyReLU, reference model.py:71-78, :263-282): the mapping network on the
+    fused layers against the same module on addmm + leaky_relu_ -- outputs and every parameter gradient."""
+    from animeface_amd.implementations.StyleGAN2 import model as M
+    torch.manual_seed(B + D)
+    net = M.Mapping(D, 8, True, 0.01).to(DEV)
+    net.apply(functools.partial(M.init_weight_N01, lr=0.01))
+    for m in net.modules():
+        if isinstance(m, torch.nn.Linear):
+            m.bias.data.normal_()
+    z = torch.randn(B, D, device=DEV)
+    dy = torch.randn(B, D, device=DEV)
+
+    def run(fused):
+        monkeypatch.setattr(M, 'MAP_FUSED', fused)
+        zz = z.clone().requires_grad_(True)
+        out = net(zz)
+        grads = torch.autograd.grad(out, [zz] + list(net.parameters()), dy)
+        return out.detach(), [g.detach() for g in grads]
+    o1, g1 = run(True)
+    o0, g0 = run(False)
+    assert (o1 - o0).abs().max().item() <= 2e-5 * o0.abs().max().item()
+    for a, b in zip(g1, g0):
+        assert a.shape == b.shape
+        assert (a - b).abs().max().item() <= 5e-5 * b.abs().max().item() + 1e-12
