@@ -19,7 +19,7 @@ EDGE_ZERO, EDGE_CLAMP = 0, 1
 
 _DTYPES = {torch.float32: AGF_F32, torch.float16: AGF_F16, torch.bfloat16: AGF_BF16, torch.float64: AGF_F64}
 
-EXPORTS = ['agf_abi_version', 'agf_last_error', 'agf_device_info', 'agf_upfirdn2d', 'agf_upfirdn2d_fold_border', 'agf_bias_act',
+EXPORTS = ['agf_abi_version', 'agf_last_error', 'agf_device_info', 'agf_set_deterministic', 'agf_get_deterministic', 'agf_upfirdn2d', 'agf_upfirdn2d_fold_border', 'agf_bias_act',
            'agf_filtered_lrelu', 'agf_filtered_lrelu_act', 'agf_conv2d_fwd', 'agf_conv2d_fwd_mask', 'agf_conv2d_s2_fwd', 'agf_conv2d_s2_dgrad', 'agf_conv2d_wgrad', 'agf_conv2d_wgrad_ws', 'agf_conv2d_wgrad_workspace_bytes',
            'agf_act_bwd_reduce', 'agf_act_bwd_reduce_pooled', 'agf_act_bwd_reduce_pooled_mask', 'agf_pool2x2', 'agf_act_bwd_reduce_scaled', 'agf_scale_dot', 'agf_demod_grad_finish', 'agf_planar_to_cl_pad', 'agf_cl_to_planar_crop', 'agf_cl_pad', 'agf_prep_weights', 'agf_prep_weights_multi', 'agf_prep_weights_blocks',
            'agf_modulate_weights', 'agf_conv2d_fwd_wimg', 'agf_conv2d_fwd_wimg_covers',
@@ -150,7 +150,10 @@ def lib():
         L.agf_map_layer_fwd.argtypes = [_vp] * 4 + [ctypes.c_int32] * 3 + [ctypes.c_float] * 3 + [_vp]
         L.agf_map_layer_bwd.restype = ctypes.c_int
         L.agf_map_layer_bwd.argtypes = [_vp] * 7 + [ctypes.c_int32] * 3 + [ctypes.c_float] * 3 + [_vp]
-        if L.agf_abi_version() != 18:
+        L.agf_set_deterministic.restype = ctypes.c_int
+        L.agf_set_deterministic.argtypes = [ctypes.c_int]
+        L.agf_get_deterministic.restype = ctypes.c_int
+        if L.agf_abi_version() != 19:
             raise AgfError('libagf_ops.so ABI version mismatch')
         _lib = L
     return _lib
@@ -170,6 +173,16 @@ def memset_node(buf, nbytes):
     rc = _hip.hipMemsetAsync(_vp(buf.data_ptr()), 0, nbytes, _vp(torch.cuda.current_stream(buf.device).cuda_stream))
     if rc != 0:
         raise AgfError(f'hipMemsetAsync failed with status {rc}')
+
+
+def set_deterministic(on=True):
+    """Process-wide deterministic mode of the library (``agf_set_deterministic``): bit-reproducible reductions, slower.  Returns the
+    previous setting.  The Python side follows it where a kernel keeps its atomics (``deterministic()``)."""
+    return bool(lib().agf_set_deterministic(1 if on else 0))
+
+
+def deterministic():
+    return bool(lib().agf_get_deterministic())
 
 
 def check(rc, what):

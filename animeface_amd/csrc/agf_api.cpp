@@ -12,6 +12,13 @@ void agf_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* agf_last_error(void) { return g_err; }
+
+// Deterministic mode (process-wide): every launch whose reduction is normally finished with fp32 atomics from several workgroups is
+// re-shaped so that each output element has ONE writer (see agf_set_deterministic in include/agf_ops.h).
+static int g_deterministic = 0;
+int agf_deterministic(void) { return g_deterministic; }
+extern "C" int agf_set_deterministic(int on) { const int old = g_deterministic; g_deterministic = on ? 1 : 0; return old; }
+extern "C" int agf_get_deterministic(void) { return g_deterministic; }
 extern "C" int agf_abi_version(void) { return AGF_ABI_VERSION; }
 
 extern "C" int agf_device_info(int* cu_count, int* lds_bytes_per_block, int* wavefront_size) {

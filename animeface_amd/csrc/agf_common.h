@@ -11,6 +11,7 @@
 #define AGF_WAVE 64
 
 void agf_set_error(const char* fmt, ...);
+int agf_deterministic(void);          // agf_set_deterministic: one writer per output element (no cross-workgroup fp32 atomics)
 
 #define AGF_CHECK(cond, ...)                 \
     do {                                     \

@@ -2366,7 +2366,7 @@ static int conv2d_wgrad_impl(const void* x, const void* dy, float* dw,
     {
         // pointwise conv from 8 input channels on a large map without scales: the streaming reduction (see conv2d_wgrad_pw8_kernel)
         constexpr bool pw8 = true;
-        if (pw8 && dtype == AGF_BF16 && ksize == 1 && Cin == 8 && Cout >= 8 && Cout <= 64 && Cout % 8 == 0 && (256 % (Cout / 8)) == 0 && !in_scale && !out_scale &&
+        if (pw8 && !agf_deterministic() && dtype == AGF_BF16 && ksize == 1 && Cin == 8 && Cout >= 8 && Cout <= 64 && Cout % 8 == 0 && (256 % (Cout / 8)) == 0 && !in_scale && !out_scale &&
             (int64_t)N * H * W >= 65536 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0) {
             const int G = Cout / 8;
             const int64_t pixels = (int64_t)N * H * W;
@@ -2423,9 +2423,11 @@ static int conv2d_wgrad_impl(const void* x, const void* dy, float* dw,
     int want = ((wantBlocks ? wantBlocks : (ksize == 3 ? 256 : 512)) + base - 1) / base;
     int cap = p.pixTiles / 4 < 1 ? 1 : p.pixTiles / 4;
     p.splitK = want < 1 ? 1 : (want > cap ? cap : want);
+    const bool det = agf_deterministic() != 0;              // deterministic mode: one block per weight tile walks all pixel tiles (single writer)
+    if (det) p.splitK = 1;
     {
         constexpr bool epi_on = true;
-        p.epiScale = (epi_on && p.TI == 1 && (in_scale || out_scale)) ? 1 : 0;
+        p.epiScale = (epi_on && !det && p.TI == 1 && (in_scale || out_scale)) ? 1 : 0;
         p.perImage = 1;
         if (p.epiScale) {
             const int tpi = p.tilesW * p.tilesH;

@@ -92,7 +92,7 @@ extern "C" int agf_diffaug_sum(const void* x, float* out, const int32_t* win, in
     AGF_CHECK(B >= 1 && C >= 1 && H >= 1 && W >= 1 && B <= 65535, "diffaug_sum: bad shape");
     int64_t bx = agf_ceil_div((int64_t)C * H, 16);                    // ~16 image rows per block, 4 at a time
     if (bx > 128) bx = 128;
-    if (bx < 1) bx = 1;
+    if (bx < 1 || agf_deterministic()) bx = 1;                         // deterministic mode: one block (one writer) per sample
     dim3 grid((unsigned)bx, (unsigned)B);
     if (dtype == AGF_F32) hipLaunchKernelGGL((diffaug_sum_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, out, win, C, H, W);
     else hipLaunchKernelGGL((diffaug_sum_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, out, win, C, H, W);

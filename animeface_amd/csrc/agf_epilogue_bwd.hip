@@ -180,6 +180,7 @@ static int plan(int C, int vec, int HW, int N, int* CG, int* pixLanes, int* pixP
     int ppb = *pixLanes * ppl;
     while (ppb > *pixLanes && (int64_t)N * ((HW + ppb - 1) / ppb) < minb) ppb >>= 1;
     if (ppb < *pixLanes) ppb = *pixLanes;
+    if (agf_deterministic()) ppb = ((HW + *pixLanes - 1) / *pixLanes) * *pixLanes;      // one block per image: each (n, c) sum has a single writer
     *pixPerBlock = ppb;
     *chunks = (HW + ppb - 1) / ppb;
     return 1;

@@ -1135,9 +1135,12 @@ class _FusedConv(torch.autograd.Function):
             if pre is not None and pre.armed and s_in is None and need_x and x.dtype == torch.bfloat16 and x.shape[1] % 8 == 0 \
                     and dx_pool is None:
                 # x is the lrelu output of the producer this link came from and we are its only consumer: hand it the masked gradient
-                pre.bsum = _zeros_f32((256, x.shape[1]), x.device)
+                det = _lib.deterministic()            # the kernel's per-channel sums are atomics over 256 slots: reduce the output instead
+                pre.bsum = None if det else _zeros_f32((256, x.shape[1]), x.device)
                 t = conv2d_fwd_raw(g, prep.wq_ft, in_scale=s_out, prepared=True, gain=pg, mask_y=x, mask_alpha=pre.alpha, mask_sum=pre.bsum,
                                    res_pooled=res_pooled, res_scale=res_scale)
+                if det:
+                    pre.bsum = t.sum((0, 2, 3), dtype=torch.float32)[None]
                 pre.premasked = True
             else:
                 t = conv2d_fwd_raw(g, prep.wq_ft, in_scale=s_out, prepared=True, gain=pg, res_pooled=res_pooled, res_scale=res_scale)

@@ -143,6 +143,7 @@ def main():
                                                          'from HIP graphs (GraphedTrainStep: same kernels, one host call per iteration and graph segment); '
                                                          'the iterations sampled for the per-launch roofline timing always run eagerly')
     ap.add_argument('--pace', default='auto', help="memset nodes at the head of the recorded iteration: an integer, or 'auto' = calibrate 0..3 by timing replays (GraphedTrainStep.calibrate)")
+    ap.add_argument('--deterministic', action='store_true', help='agf_set_deterministic(1): one writer per output element instead of cross-workgroup fp32 atomics (bit-reproducible, slower)')
     ap.add_argument('--ab', default='', help='comma-separated A/B switches for same-box comparisons: no-torgb, no-mapfuse, candN (N pace candidates)')
     ap.add_argument('--dp-mode', default=None, choices=['ingraph', 'segmented'],
                     help='several ranks under graph replay: ingraph (default with RCCL) = ONE graph per iteration kind with the bucket all-reduces '
@@ -160,6 +161,9 @@ def main():
     from animeface_amd.nnutils import sample_nnoise, update_ema
     import torch.distributed as dist
     ab = set(filter(None, args.ab.split(',')))
+    if args.deterministic:
+        from animeface_amd import _lib as _agf
+        _agf.set_deterministic(True)
     if 'no-torgb' in ab:
         M.TORGB_FUSED = False
     if 'no-mapfuse' in ab:
@@ -411,6 +415,8 @@ def main():
             out['pace'] = {'nodes': runner.pace_nodes}
         if smi_out:
             out['clocks'] = smi_out
+        if args.deterministic:
+            out['deterministic'] = True
         if r1_ms is not None:
             out['r1_every_step'] = {'value': round(args.batch * world / (r1_ms * 1e-3), 2), 'unit': 'img/s', 'ms_per_step': round(r1_ms, 3),
                                     'note': 'the lazy-R1 iteration (penalty replaces the GAN loss) on every step: 4 steps after the timed window'}

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define AGF_ABI_VERSION 18
+#define AGF_ABI_VERSION 19
 
 /* element types of activation tensors */
 enum { AGF_F32 = 0, AGF_F16 = 1, AGF_BF16 = 2, AGF_F64 = 3 };
@@ -47,6 +47,16 @@ enum { AGF_EDGE_ZERO = 0, AGF_EDGE_CLAMP = 1 };
 int         agf_abi_version(void);
 const char* agf_last_error(void);          /* thread-local message of the last failing call */
 int         agf_device_info(int* cu_count, int* lds_bytes_per_block, int* wavefront_size);
+/* Deterministic mode (ABI v19, process-wide; returns the previous setting).  The reference's own ops accumulate with atomicAdd in two places
+ * (upfirdn2d.cu has none; bias_act / filtered_lrelu gradients go through torch reductions), cuDNN's weight gradients are nondeterministic
+ * unless torch.backends.cudnn.deterministic is set: this is the equivalent switch.  When on, every reduction that is otherwise finished
+ * with fp32 atomics from several workgroups gets ONE writer per output element -- the epilogue-backward sums and agf_scale_dot run one
+ * workgroup per image, agf_conv2d_wgrad runs without split-K (and not on the pointwise-8 streaming kernel), agf_diffaug_sum one workgroup
+ * per sample; agf_conv2d_wgrad_ws (two-stage combine), agf_torgb_bwd and the FIR kernels are deterministic as they are.  The per-channel
+ * sums of agf_conv2d_fwd_mask (mask_sum) stay atomic: deterministic callers pass mask_sum = NULL and reduce the output.  Slower, for
+ * reproducing a run bit for bit. */
+int         agf_set_deterministic(int on);
+int         agf_get_deterministic(void);
 
 /* ---------------------------------------------------------------------------------------------
  * upfirdn2d  --  replaces  Tensor upfirdn2d(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain)

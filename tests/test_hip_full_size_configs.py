@@ -113,3 +113,40 @@ def test_stylegan3_t_512_batch_16_full_size_step_properties():
     assert d0 == pytest.approx(d1, rel=2e-3, abs=1e-4) and g0 == pytest.approx(g1, rel=1e-2, abs=1e-3), (a, b)
     for (d0, g0), (d1, g1) in zip(a, b):                                 # later iterations: bf16 + Adam decorrelate a few weights
         assert d0 == pytest.approx(d1, rel=5e-2, abs=5e-2) and g0 == pytest.approx(g1, rel=5e-2, abs=5e-2), (a, b)
+
+
+def test_deterministic_mode_makes_a_full_size_run_bit_reproducible():
+    """``_lib.set_deterministic(True)`` (agf_set_deterministic: one writer per output element instead of cross-workgroup fp32 atomics): two
+    fresh runs of the 128x128 / batch-32 configuration from the same seeds -- four iterations, one of them a lazy-R1 (double-backward)
+    iteration -- end with IDENTICAL losses and IDENTICAL weights, bit for bit; without the switch the same comparison is only close."""
+    from animeface_amd import _lib
+    from animeface_amd.implementations.StyleGAN2 import model as M, utils as U
+    from animeface_amd.nnutils import sample_nnoise, update_ema
+
+    def run():
+        torch.manual_seed(0)
+        G, G_ema, D = M.Generator(128).to(DEV), M.Generator(128).to(DEV), M.Discriminator(128).to(DEV)
+        G.init_weight(functools.partial(M.init_weight_N01, lr=0.01), M.init_weight_N01)
+        D.apply(M.init_weight_N01)
+        G_ema.eval()
+        update_ema(G, G_ema, decay=0)
+        oG, oD = U.build_optimizers(G, D, 0.001, (0., 0.99), 10., 0., 2, 8, capturable=True)
+        step = U.TrainStep(G, G_ema, D, oG, oD, 10., 0., 2, 8, 'color,translation', 512, functools.partial(sample_nnoise, device=DEV))
+        real = (torch.rand(32, 3, 128, 128, generator=torch.Generator().manual_seed(3)) * 2 - 1).to(DEV)
+        torch.manual_seed(77)
+        losses = []
+        for _ in range(4):                                               # iterations 0..3: lazy R1 at 2 (d_k = 2)
+            dl, gl, _ = step(real)
+            losses.append((float(dl), float(gl)))
+        torch.cuda.synchronize()
+        return losses, {f'{k}.{n}': p.detach().clone() for k, net in (('G', G), ('D', D), ('G_ema', G_ema)) for n, p in net.named_parameters()}
+    old = _lib.set_deterministic(True)
+    try:
+        assert _lib.deterministic()
+        la, wa = run()
+        lb, wb = run()
+    finally:
+        _lib.set_deterministic(old)
+    assert la == lb, (la, lb)
+    differing = [n for n in wa if not torch.equal(wa[n], wb[n])]
+    assert not differing, f'{len(differing)} of {len(wa)} tensors differ between two deterministic runs, e.g. {differing[:4]}'
