@@ -1,7 +1,7 @@
 #!/bin/bash
 # Tracked measurements (one box): headline bench + kernel stats, BASELINE config 2 (128x128, batch 32), StyleGAN3-T 512x512,
 # kernel micro-benchmarks with the CPU rows, filtered_lrelu roofline table, conv HBM traffic inside the step.
-tag=${1:-r03}
+tag=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${tag}_driver_cmd.log 2>&1
