@@ -192,3 +192,33 @@ def test_the_pipe_issues_no_host_synchronisation():
     finally:
         torch.cuda.set_sync_debug_mode('default')
     assert torch.isfinite(y).all() and torch.isfinite(xg.grad).all()
+
+
+@pytest.mark.gpu
+def test_plan_then_apply_equals_the_one_call_forward_and_plan_many_batches_the_calls():
+    """``AugmentPipe.forward(x)`` = ``apply(x, plan(shape))`` with the same random draws (the split exists so that a trainer can issue the
+    decisions ahead of time, beside the networks' kernels); ``plan_many(k, ...)`` builds the matrices of k calls as one batch of k * B samples:
+    the same draws as ONE call on a k * B batch, cut into per-call plans whose reflect margins are each call's own maximum."""
+    from animeface_amd.nnutils.ada import ADA
+    dev = torch.device('cuda')
+    B, k = 6, 3
+    pipe = ADA(B).to(dev)
+    pipe.p.fill_(0.7)
+    x = (torch.rand(B, 3, 32, 32, device=dev) * 2 - 1)
+    torch.manual_seed(11)
+    y_one = pipe(x)
+    torch.manual_seed(11)
+    y_split = pipe.apply(x, pipe.plan(x.shape, x.dtype, dev))
+    assert torch.equal(y_one, y_split)
+    # plan_many: the matrices equal those of one call on the k * B batch
+    torch.manual_seed(12)
+    Gk, Mk = pipe._plan_matrices((k * B, 3, 32, 32), dev)
+    torch.manual_seed(12)
+    plans = pipe.plan_many(k, (B, 3, 32, 32), x.dtype, dev)
+    assert len(plans) == k
+    for i, pl in enumerate(plans):
+        assert torch.equal(pl['M'], Mk[i * B:(i + 1) * B])
+        ref = pipe._plan_finish(Gk[i * B:(i + 1) * B], Mk[i * B:(i + 1) * B], (B, 3, 32, 32), x.dtype, dev)
+        assert torch.equal(pl['warp']['theta'], ref['warp']['theta']) and torch.equal(pl['warp']['margins'], ref['warp']['margins'])
+        out = pipe.apply(x, pl)
+        assert out.shape == x.shape and torch.isfinite(out).all()

@@ -486,3 +486,46 @@ def test_fused_mapping_network_matches_the_composite(B, D, monkeypatch):
     for a, b in zip(g1, g0):
         assert a.shape == b.shape
         assert (a - b).abs().max().item() <= 5e-5 * b.abs().max().item() + 1e-12
+
+
+@pytest.mark.gpu
+def test_pace_selection_rotates_recordings_without_changing_the_run(monkeypatch):
+    """``GraphedTrainStep(pace='auto')``: every iteration kind is recorded once per candidate number of memset nodes; the first
+    len(candidates) * PACE_BLOCK iterations rotate through the recordings (timed with events), then one is kept.  Every recording computes
+    the same iteration, so the run equals the ``pace=0`` run (fp32: to summation noise), the selection consumes no iteration, and the
+    report names the chosen count and the medians it was chosen from."""
+    from animeface_amd.implementations.StyleGAN2 import utils as U
+    from animeface_amd.nnutils import sample_nnoise, update_ema
+    monkeypatch.setattr(U.GraphedTrainStep, 'PACE_CANDIDATES', (0, 1, 2))
+    monkeypatch.setattr(U.GraphedTrainStep, 'PACE_BLOCK', 7)
+
+    def run(pace, iters=26):
+        torch.manual_seed(5)
+        M, G, D = build(torch.float32)
+        _, G_ema, _ = build(torch.float32)
+        G.init_weight(functools.partial(M.init_weight_N01, lr=0.01), M.init_weight_N01)
+        D.apply(M.init_weight_N01)
+        G_ema.eval()
+        update_ema(G, G_ema, decay=0)
+        oG, oD = U.build_optimizers(G, D, 0.001, (0., 0.99), 10., 0., 4, 8, capturable=True)
+        step = U.TrainStep(G, G_ema, D, oG, oD, 10., 0., 4, 8, 'color,translation', TINY['style_dim'], functools.partial(sample_nnoise, device=DEV))
+        real = (torch.rand(8, 3, 16, 16, generator=torch.Generator().manual_seed(9)) * 2 - 1).to(DEV)
+        torch.manual_seed(123)
+        for _ in range(2):
+            step(real)
+        runner = U.GraphedTrainStep(step, real, warmup=0, pace=pace)
+        runner.capture_all()
+        losses = []
+        for _ in range(iters):
+            dl, gl, _ = runner(real)
+            losses.append((float(dl), float(gl)))
+        assert step.batches_done == 2 + iters
+        return losses, runner
+    l0, r0 = run(0)
+    la, ra = run('auto')
+    assert r0.pace_report is None and r0.kinds() == {'gan', 'r1'} and len(r0.graphs) == 2
+    rep = ra.pace_report
+    assert rep is not None and rep['nodes'] in (0, 1, 2) and set(rep['median_ms']) == {0, 1, 2} and len(ra.graphs) == 6
+    assert rep['nodes'] == min(rep['median_ms'], key=rep['median_ms'].get) == ra.pace_nodes
+    for (d0, g0), (d1, g1) in zip(l0, la):
+        assert d0 == pytest.approx(d1, rel=1e-4, abs=1e-5) and g0 == pytest.approx(g1, rel=1e-4, abs=1e-5), (l0, la)

@@ -38,11 +38,15 @@ real = torch.rand(a.batch, 3, a.image_size, a.image_size, device=dev) * 2 - 1
 for _ in range(a.warmup):
     step(real)
 torch.cuda.synchronize()
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import SmiSampler                                            # noqa: E402  (one rocm-smi reading while the timed loop runs)
+smi = SmiSampler(delay=0.5)
 t0 = time.time()
 for _ in range(a.steps):
     step(real)
 torch.cuda.synchronize()
 dtm = (time.time() - t0) / a.steps
+print('clocks', smi.result())
 print('sg3 %s batch %d: %.1f ms/iter, %.1f img/s' % ('fp32' if a.fp32 else 'bf16', a.batch, dtm * 1e3, a.batch / dtm))
 import json
 print(json.dumps({'metric': f'images/sec (G+D+R1 step) StyleGAN3-T {a.image_size}x{a.image_size} ' + ('fp32' if a.fp32 else 'bf16'), 'value': round(a.batch / dtm, 2),
