@@ -83,36 +83,87 @@ __global__ void __launch_bounds__(256) bias_act_scalar(BiasActParams p, int64_t 
     }
 }
 
-// 16-byte vector kernel: VEC elements per lane per iteration; requires all pointers 16-byte aligned.
-template <class T, int VEC, int A>
-__global__ void __launch_bounds__(256) bias_act_vec(BiasActParams p, int64_t nvec) {
-    for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * 256) {
-        const int64_t i0 = v * VEC;
-        float x[VEC], xr[VEC], yr[VEC], dy[VEC], b[VEC], y[VEC];
-        VecIO<T, VEC>::load((const T*)p.x + i0, x);
-        if (p.xref) VecIO<T, VEC>::load((const T*)p.xref + i0, xr);
-        if (p.yref) VecIO<T, VEC>::load((const T*)p.yref + i0, yr);
-        if (p.dy) VecIO<T, VEC>::load((const T*)p.dy + i0, dy);
-        if (p.b) {
-            if (p.stepB == 1 && p.sizeB % VEC == 0) {                 // channels-last: VEC consecutive channels
-                VecIO<T, VEC>::load((const T*)p.b + (i0 % p.sizeB), b);
-            } else if (p.stepB % VEC == 0) {                          // NCHW with H*W % VEC == 0: one channel per vector
-                float bv = (float)Elem<T>::load((const T*)p.b + (i0 / p.stepB) % p.sizeB);
+// 16-byte vector kernel: VEC elements per lane per access; requires all pointers 16-byte aligned.
+// Access pattern chosen by measurement (tools/probe/stream_variants.hip, 64 x 64 x 256 x 256 bias + lrelu, of 8 TB/s):
+//   grid-stride loop over a capped grid, one access per lane and iteration (the first version)      bf16 0.60-0.67   fp32 0.59-0.64
+//   the same with 4 stride-separated accesses in flight per lane                                      0.48-0.54        0.56-0.59
+//   FULL grid, a block owns 4 x 256 CONSECUTIVE vectors, all loads issued before the first use       0.73             0.78
+//   ... with non-temporal loads and stores                                                            0.82             0.85
+// i.e. on this chip a streaming pass wants every workgroup short and its bytes contiguous; capping the grid (the usual "2 048 blocks and
+// stride the rest") costs 15-25 %.  All indices are 32-bit (size_x <= INT32_MAX is part of the contract); the bias index of the
+// channels-last case advances by a constant with one conditional subtract instead of a 64-bit modulo per access.  Non-temporal accesses
+// are used for tensors that cannot stay in the 256 MB last-level cache anyway (NT); small ones keep the default policy so that the
+// consumer kernel still finds them there.
+template <class T, int VEC> struct RawVec;
+template <> struct RawVec<float, 4> {
+    static __device__ __forceinline__ void unpack(u32x4 t, float (&v)[4]) {
+        v[0] = __uint_as_float(t.x); v[1] = __uint_as_float(t.y); v[2] = __uint_as_float(t.z); v[3] = __uint_as_float(t.w);
+    }
+};
+template <class T> struct RawVec<T, 8> {
+    static __device__ __forceinline__ void unpack(u32x4 t, float (&v)[8]) {
+        Pack16<T>::unpack(t.x, v[0], v[1]); Pack16<T>::unpack(t.y, v[2], v[3]);
+        Pack16<T>::unpack(t.z, v[4], v[5]); Pack16<T>::unpack(t.w, v[6], v[7]);
+    }
+};
+
+// BMODE: 0 no bias, 1 channels-last (VEC consecutive channels per access), 2 one channel per access (NCHW, H*W % VEC == 0), 3 per element
+template <class T, int VEC, int A, int U, int BMODE, bool NT>
+__global__ void __launch_bounds__(256) bias_act_vec(BiasActParams p, uint32_t nvec, uint32_t bstep) {
+    const uint32_t v0 = blockIdx.x * (256u * U) + threadIdx.x;         // a block owns U * 256 consecutive vectors
+    const uint32_t sizeB = (uint32_t)p.sizeB, stepB = (uint32_t)p.stepB;
+    uint32_t bidx = BMODE == 1 ? (v0 * VEC) % sizeB : 0u;               // < 2^31: v0 * VEC <= size_x
+    const u32x4* px = (const u32x4*)p.x;
+    const u32x4* pxr = (const u32x4*)p.xref;
+    const u32x4* pyr = (const u32x4*)p.yref;
+    const u32x4* pdy = (const u32x4*)p.dy;
+    auto ld = [](const u32x4* q) { return NT ? __builtin_nontemporal_load(q) : *q; };
+    u32x4 rx[U], rxr[U], ryr[U], rdy[U], rb[U];
 #pragma unroll
-                for (int k = 0; k < VEC; k++) b[k] = bv;
-            } else {
-#pragma unroll
-                for (int k = 0; k < VEC; k++) b[k] = (float)Elem<T>::load((const T*)p.b + ((i0 + k) / p.stepB) % p.sizeB);
+    for (int k = 0; k < U; k++) {
+        const uint32_t v = v0 + k * 256u;
+        if (v < nvec) {
+            rx[k] = ld(px + v);
+            if (p.xref) rxr[k] = ld(pxr + v);
+            if (p.yref) ryr[k] = ld(pyr + v);
+            if (p.dy) rdy[k] = ld(pdy + v);
+            if (BMODE == 1) {
+                rb[k] = *(const u32x4*)((const T*)p.b + bidx);
+                bidx += bstep;
+                if (bidx >= sizeB) bidx -= sizeB;
             }
         }
+    }
 #pragma unroll
-        for (int k = 0; k < VEC; k++) {
-            float xx = x[k], xref = p.xref ? xr[k] : 0.f, yref = p.yref ? yr[k] : 0.f, d = p.dy ? dy[k] : 1.f;
-            float bb = p.b ? b[k] : 0.f;
-            if (p.grad == 0) xx += bb; else xref += bb;
-            y[k] = act_eval<float, A>(xx, xref, yref, d, p.grad, p.alpha, p.gain, p.clamp);
+    for (int k = 0; k < U; k++) {
+        const uint32_t v = v0 + k * 256u;
+        if (v >= nvec) break;
+        float x[VEC], xr[VEC], yr[VEC], dy[VEC], b[VEC], y[VEC];
+        RawVec<T, VEC>::unpack(rx[k], x);
+        if (p.xref) RawVec<T, VEC>::unpack(rxr[k], xr);
+        if (p.yref) RawVec<T, VEC>::unpack(ryr[k], yr);
+        if (p.dy) RawVec<T, VEC>::unpack(rdy[k], dy);
+        if (BMODE == 1) RawVec<T, VEC>::unpack(rb[k], b);
+        if (BMODE == 2) {
+            const float bv = (float)Elem<T>::load((const T*)p.b + ((v * VEC) / stepB) % sizeB);
+#pragma unroll
+            for (int e = 0; e < VEC; e++) b[e] = bv;
         }
-        VecIO<T, VEC>::store((T*)p.y + i0, y);
+        if (BMODE == 3) {
+#pragma unroll
+            for (int e = 0; e < VEC; e++) b[e] = (float)Elem<T>::load((const T*)p.b + ((v * VEC + e) / stepB) % sizeB);
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; e++) {
+            float xx = x[e], xref = p.xref ? xr[e] : 0.f, yref = p.yref ? yr[e] : 0.f, d = p.dy ? dy[e] : 1.f;
+            const float bb = BMODE ? b[e] : 0.f;
+            if (p.grad == 0) xx += bb; else xref += bb;
+            y[e] = act_eval<float, A>(xx, xref, yref, d, p.grad, p.alpha, p.gain, p.clamp);
+        }
+        u32x4 out;
+        if constexpr (VEC == 4) { out.x = __float_as_uint(y[0]); out.y = __float_as_uint(y[1]); out.z = __float_as_uint(y[2]); out.w = __float_as_uint(y[3]); }
+        else { out.x = Pack16<T>::pack(y[0], y[1]); out.y = Pack16<T>::pack(y[2], y[3]); out.z = Pack16<T>::pack(y[4], y[5]); out.w = Pack16<T>::pack(y[6], y[7]); }
+        if (NT) __builtin_nontemporal_store(out, (u32x4*)p.y + v); else *((u32x4*)p.y + v) = out;
     }
 }
 
@@ -125,9 +176,20 @@ static void launch_act(const BiasActParams& p, hipStream_t st) {
         if (al(p.x) && al(p.y) && al(p.xref) && al(p.yref) && al(p.dy) && al(p.b)) {
             int64_t nvec = p.sizeX / VEC;
             if (nvec > 0) {
-                int64_t blocks = agf_ceil_div(nvec, 256);
-                if (blocks > 256 * 64) blocks = 256 * 64;       // grid-stride beyond 64 blocks per CU
-                hipLaunchKernelGGL((bias_act_vec<T, VEC, A>), dim3((unsigned)blocks), dim3(256), 0, st, p, nvec);
+                constexpr int U = 4;
+                const dim3 grid((unsigned)agf_ceil_div(nvec, 256 * U)), block(256);
+                const uint32_t n = (uint32_t)nvec;
+                const int mode = !p.b ? 0 : (p.stepB == 1 && p.sizeB % VEC == 0) ? 1 : (p.stepB % VEC == 0) ? 2 : 3;
+                const uint32_t bstep = mode == 1 ? (uint32_t)((256u * VEC) % (uint32_t)p.sizeB) : 0u;
+                const bool nt = nvec * 16 > (int64_t)(64 << 20);     // x and y together exceed half of the last-level cache
+#define BA_LAUNCH(M, NTV) hipLaunchKernelGGL((bias_act_vec<T, VEC, A, U, M, NTV>), grid, block, 0, st, p, n, bstep)
+                switch (mode) {
+                    case 0: if (nt) BA_LAUNCH(0, true); else BA_LAUNCH(0, false); break;
+                    case 1: if (nt) BA_LAUNCH(1, true); else BA_LAUNCH(1, false); break;
+                    case 2: if (nt) BA_LAUNCH(2, true); else BA_LAUNCH(2, false); break;
+                    default: if (nt) BA_LAUNCH(3, true); else BA_LAUNCH(3, false); break;
+                }
+#undef BA_LAUNCH
                 done = nvec * VEC;
             }
         }

@@ -132,8 +132,10 @@ __global__ void __launch_bounds__(512, 2) conv2d_wgrad_ring_kernel(WgradRingPara
     // SC: this lane's channel of the A operand (dy: co) and of the B operand (x: ci); tail lanes hold zero fragments: any finite scale
     const int chA = co0 + wa * 32 + (lane & 31), chB = ci0 + wb * 32 + (lane & 31);
     const int chAc = chA < p.Cout ? chA : p.Cout - 1, chBc = chB < p.Cin ? chB : p.Cin - 1;
-    const __amdgpu_buffer_rsrc_t aScRes = __builtin_amdgcn_make_buffer_rsrc((void*)p.out_scale, 0, SC ? p.N * p.Cout * 4 : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t bScRes = __builtin_amdgcn_make_buffer_rsrc((void*)p.in_scale, 0, SC ? p.N * p.Cin * 4 : 0, 0x00020000);
+    // (either scale may be absent -- e.g. a gradient stored already times the demodulation scale: an empty resource then, every load of
+    //  it returns zero without touching memory, and the fragment scale below is 1)
+    const __amdgpu_buffer_rsrc_t aScRes = __builtin_amdgcn_make_buffer_rsrc((void*)p.out_scale, 0, (SC && p.out_scale) ? p.N * p.Cout * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t bScRes = __builtin_amdgcn_make_buffer_rsrc((void*)p.in_scale, 0, (SC && p.in_scale) ? p.N * p.Cin * 4 : 0, 0x00020000);
     auto issue_tile = [&](int pt, bool live, int stage) {
         int tw, th, n;
         if (p.lgTilesW >= 0) { tw = pt & (p.tilesW - 1); th = (pt >> p.lgTilesW) & (p.tilesH - 1); n = pt >> (p.lgTilesW + p.lgTilesH); }
@@ -188,8 +190,8 @@ __global__ void __launch_bounds__(512, 2) conv2d_wgrad_ring_kernel(WgradRingPara
         __builtin_amdgcn_sched_barrier(0);
         float scA = 1.f, scB = 1.f;
         if (SC) {
-            scA = sSide[((cur * 2 + 0) * 8 + wave) * 64 + lane];
-            scB = sSide[((cur * 2 + 1) * 8 + wave) * 64 + lane];
+            scA = p.out_scale ? sSide[((cur * 2 + 0) * 8 + wave) * 64 + lane] : 1.f;
+            scB = p.in_scale ? sSide[((cur * 2 + 1) * 8 + wave) * 64 + lane] : 1.f;
         }
         const bf16_t* aCur = sBase + cur * STAGE_E + aOff + (rowStart * p.TW + colHalf * 16) * 32;
         const bf16_t* bCur = sBase + cur * STAGE_E + bOff + (rowStart * PW + colHalf * 16) * 32;

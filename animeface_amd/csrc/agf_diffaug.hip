@@ -483,3 +483,251 @@ extern "C" int agf_ada_warp_resample(const void* x, void* y, const float* theta,
     AGF_LAUNCH_CHECK();
     return AGF_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// ADA: every per-sample decision of the geometric and colour stages in ONE launch (thirdparty/ada/augment.py:188-347 builds them as ~25
+// batched 3x3 / 4x4 matrix products and ~200 elementwise ops on [B] tensors, then :258-272 reduces the transformed corners to the reflect
+// margins).  The host draws the random numbers exactly as the reference does (same calls, same order, same shapes) and hands them over as
+// one flat buffer; a stage's slot is (offset of its value draw, offset of its gate draw), -1 = stage disabled.  One workgroup per call of
+// B samples: matrices -> corner reach -> workgroup maximum -> margins -> the sampling matrix theta of agf_ada_warp_resample.
+enum { ADA_XFLIP = 0, ADA_ROT90, ADA_XINT, ADA_SCALE, ADA_ROT_PRE, ADA_ANISO, ADA_ROT_POST, ADA_XFRAC,
+       ADA_BRIGHT, ADA_CONTRAST, ADA_LUMAFLIP, ADA_HUE, ADA_SATUR, ADA_STAGES };
+
+struct AdaPlanParams {
+    const float* draws; const float* p;
+    float* theta; int32_t* margins; float* M; float* M3;
+    int calls, B, H, W, taps4, geom, colour;
+    int off_v[ADA_STAGES], off_g[ADA_STAGES];
+    float strength[ADA_STAGES], prm[ADA_STAGES];
+};
+
+struct Aff2 { float a00, a01, a02, a10, a11, a12; };     // third row = (0, 0, 1)
+
+static __device__ __forceinline__ void aff_zoom(Aff2& g, float sx, float sy) { g.a00 *= sx; g.a10 *= sx; g.a01 *= sy; g.a11 *= sy; }
+static __device__ __forceinline__ void aff_spin(Aff2& g, float th) {
+    const float c = cosf(th), s = sinf(th);
+    const float b00 = g.a00 * c + g.a01 * s, b01 = g.a01 * c - g.a00 * s;
+    const float b10 = g.a10 * c + g.a11 * s, b11 = g.a11 * c - g.a10 * s;
+    g.a00 = b00; g.a01 = b01; g.a10 = b10; g.a11 = b11;
+}
+static __device__ __forceinline__ void aff_shift(Aff2& g, float tx, float ty) {
+    g.a02 = g.a00 * tx + g.a01 * ty + g.a02;
+    g.a12 = g.a10 * tx + g.a11 * ty + g.a12;
+}
+
+// G of sample s (output pixel -> input pixel), reference augment.py:188-256: G = G @ stage, in the reference's order
+static __device__ Aff2 ada_geometry(const AdaPlanParams& q, int s, float p) {
+    const float PI = 3.14159265358979323846f;
+    const float* d = q.draws;
+    Aff2 g = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f};
+    if (q.off_v[ADA_XFLIP] >= 0) {
+        float i = floorf(d[q.off_v[ADA_XFLIP] + s] * 2.f);
+        if (!(d[q.off_g[ADA_XFLIP] + s] < q.strength[ADA_XFLIP] * p)) i = 0.f;
+        aff_zoom(g, 1.f / (1.f - 2.f * i), 1.f);
+    }
+    if (q.off_v[ADA_ROT90] >= 0) {
+        float i = floorf(d[q.off_v[ADA_ROT90] + s] * 4.f);
+        if (!(d[q.off_g[ADA_ROT90] + s] < q.strength[ADA_ROT90] * p)) i = 0.f;
+        aff_spin(g, (PI / 2.f) * i);
+    }
+    if (q.off_v[ADA_XINT] >= 0) {
+        float tx = (d[q.off_v[ADA_XINT] + 2 * s] * 2.f - 1.f) * q.prm[ADA_XINT];
+        float ty = (d[q.off_v[ADA_XINT] + 2 * s + 1] * 2.f - 1.f) * q.prm[ADA_XINT];
+        if (!(d[q.off_g[ADA_XINT] + s] < q.strength[ADA_XINT] * p)) tx = ty = 0.f;
+        aff_shift(g, -rintf(tx * (float)q.W), -rintf(ty * (float)q.H));
+    }
+    if (q.off_v[ADA_SCALE] >= 0) {
+        float sc = exp2f(d[q.off_v[ADA_SCALE] + s] * q.prm[ADA_SCALE]);
+        if (!(d[q.off_g[ADA_SCALE] + s] < q.strength[ADA_SCALE] * p)) sc = 1.f;
+        aff_zoom(g, 1.f / sc, 1.f / sc);
+    }
+    float p_rot = 0.f;
+    if (q.off_v[ADA_ROT_PRE] >= 0) {
+        p_rot = 1.f - sqrtf(fminf(fmaxf(1.f - q.strength[ADA_ROT_PRE] * p, 0.f), 1.f));
+        float th = (d[q.off_v[ADA_ROT_PRE] + s] * 2.f - 1.f) * PI * q.prm[ADA_ROT_PRE];
+        if (!(d[q.off_g[ADA_ROT_PRE] + s] < p_rot)) th = 0.f;
+        aff_spin(g, th);
+    }
+    if (q.off_v[ADA_ANISO] >= 0) {
+        float sc = exp2f(d[q.off_v[ADA_ANISO] + s] * q.prm[ADA_ANISO]);
+        if (!(d[q.off_g[ADA_ANISO] + s] < q.strength[ADA_ANISO] * p)) sc = 1.f;
+        aff_zoom(g, 1.f / sc, sc);
+    }
+    if (q.off_v[ADA_ROT_POST] >= 0) {
+        float th = (d[q.off_v[ADA_ROT_POST] + s] * 2.f - 1.f) * PI * q.prm[ADA_ROT_POST];
+        if (!(d[q.off_g[ADA_ROT_POST] + s] < p_rot)) th = 0.f;
+        aff_spin(g, th);
+    }
+    if (q.off_v[ADA_XFRAC] >= 0) {
+        float tx = d[q.off_v[ADA_XFRAC] + 2 * s] * q.prm[ADA_XFRAC];
+        float ty = d[q.off_v[ADA_XFRAC] + 2 * s + 1] * q.prm[ADA_XFRAC];
+        if (!(d[q.off_g[ADA_XFRAC] + s] < q.strength[ADA_XFRAC] * p)) tx = ty = 0.f;
+        aff_shift(g, -tx * (float)q.W, -ty * (float)q.H);
+    }
+    return g;
+}
+
+// M <- A @ M for 4x4 homogeneous colour matrices (last row (0,0,0,1) on both sides)
+static __device__ __forceinline__ void col_left(float (&m)[3][4], const float (&a)[3][4]) {
+    float r[3][4];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float v = a[i][0] * m[0][j] + a[i][1] * m[1][j] + a[i][2] * m[2][j];
+            if (j == 3) v += a[i][3];
+            r[i][j] = v;
+        }
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) m[i][j] = r[i][j];
+}
+
+// colour matrix of sample s (rows 0..2 of the 4x4), reference augment.py:296-347: M = stage @ M
+static __device__ float ada_colour(const AdaPlanParams& q, int s, float p, float (&m)[3][4]) {
+    float m33 = 1.f;                                     // the reference's saturation matrix scales the homogeneous entry too (:343)
+    const float PI = 3.14159265358979323846f;
+    const float* d = q.draws;
+    const float lu = 0.57735026918962576451f;            // 1 / sqrt(3): the luma axis (1, 1, 1, 0) / sqrt(3)
+    const float vv = lu * lu;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) m[i][j] = (i == j) ? 1.f : 0.f;
+    if (q.off_v[ADA_BRIGHT] >= 0) {
+        float b = d[q.off_v[ADA_BRIGHT] + s] * q.prm[ADA_BRIGHT];
+        if (!(d[q.off_g[ADA_BRIGHT] + s] < q.strength[ADA_BRIGHT] * p)) b = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; i++) m[i][3] += b;
+    }
+    if (q.off_v[ADA_CONTRAST] >= 0) {
+        float c = exp2f(d[q.off_v[ADA_CONTRAST] + s] * q.prm[ADA_CONTRAST]);
+        if (!(d[q.off_g[ADA_CONTRAST] + s] < q.strength[ADA_CONTRAST] * p)) c = 1.f;
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) m[i][j] *= c;
+    }
+    if (q.off_v[ADA_LUMAFLIP] >= 0) {
+        float f = floorf(d[q.off_v[ADA_LUMAFLIP] + s] * 2.f);
+        if (!(d[q.off_g[ADA_LUMAFLIP] + s] < q.strength[ADA_LUMAFLIP] * p)) f = 0.f;
+        float a[3][4];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) a[i][j] = ((i == j) ? 1.f : 0.f) - (j < 3 ? 2.f * vv * f : 0.f);
+        col_left(m, a);
+    }
+    if (q.off_v[ADA_HUE] >= 0) {
+        float th = (d[q.off_v[ADA_HUE] + s] * 2.f - 1.f) * PI * q.prm[ADA_HUE];
+        if (!(d[q.off_g[ADA_HUE] + s] < q.strength[ADA_HUE] * p)) th = 0.f;
+        const float sn = sinf(th), c = cosf(th), k = 1.f - c;
+        const float dg = vv * k + c, up = vv * k - lu * sn, lo = vv * k + lu * sn;     // Rodrigues about (lu, lu, lu)
+        const float a[3][4] = {{dg, up, lo, 0.f}, {lo, dg, up, 0.f}, {up, lo, dg, 0.f}};
+        col_left(m, a);
+    }
+    if (q.off_v[ADA_SATUR] >= 0) {
+        float sa = exp2f(d[q.off_v[ADA_SATUR] + s] * q.prm[ADA_SATUR]);
+        if (!(d[q.off_g[ADA_SATUR] + s] < q.strength[ADA_SATUR] * p)) sa = 1.f;
+        float a[3][4];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) a[i][j] = (j < 3) ? vv + (((i == j) ? 1.f : 0.f) - vv) * sa : 0.f;
+        col_left(m, a);
+        m33 = sa;
+    }
+    return m33;
+}
+
+__global__ void __launch_bounds__(256) ada_plan_kernel(AdaPlanParams q) {
+    __shared__ float red[4][256 / AGF_WAVE];
+    __shared__ float mrg[4];
+    const int call = blockIdx.x, tid = threadIdx.x;
+    const float p = *q.p;
+    if (q.colour) {
+        for (int b = tid; b < q.B; b += 256) {
+            const int s = call * q.B + b;
+            float m[3][4];
+            const float m33 = ada_colour(q, s, p, m);
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    q.M[s * 16 + i * 4 + j] = m[i][j];
+                    q.M3[s * 12 + i * 4 + j] = m[i][j];
+                }
+#pragma unroll
+            for (int j = 0; j < 4; j++) q.M[s * 16 + 12 + j] = (j == 3) ? m33 : 0.f;
+        }
+    }
+    if (!q.geom) return;
+    // how far the transformed image corners reach outside the frame (augment.py:258-266)
+    const float cx = (float)(q.W - 1) / 2.f, cy = (float)(q.H - 1) / 2.f;
+    float r[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};     // max(-x), max(-y), max(x), max(y)
+    for (int b = tid; b < q.B; b += 256) {
+        const Aff2 g = ada_geometry(q, call * q.B + b, p);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float X = (k == 1 || k == 2) ? cx : -cx, Y = (k >= 2) ? cy : -cy;
+            const float x = g.a00 * X + g.a01 * Y + g.a02, y = g.a10 * X + g.a11 * Y + g.a12;
+            r[0] = fmaxf(r[0], -x); r[1] = fmaxf(r[1], -y); r[2] = fmaxf(r[2], x); r[3] = fmaxf(r[3], y);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+#pragma unroll
+        for (int o = AGF_WAVE / 2; o > 0; o >>= 1) r[k] = fmaxf(r[k], __shfl_xor(r[k], o));
+        if ((tid & (AGF_WAVE - 1)) == 0) red[k][tid / AGF_WAVE] = r[k];
+    }
+    __syncthreads();
+    if (tid < 4) {
+        float v = red[tid][0];
+        for (int w = 1; w < 256 / AGF_WAVE; w++) v = fmaxf(v, red[tid][w]);
+        const float slack = (float)(q.taps4 * 2) - ((tid & 1) ? cy : cx);
+        const float lim = (float)(((tid & 1) ? q.H : q.W) - 1);
+        v = ceilf(fminf(fmaxf(v + slack, 0.f), lim));
+        mrg[tid] = v;
+        q.margins[call * 4 + tid] = (int32_t)v;
+    }
+    __syncthreads();
+    const float mx0 = mrg[0], my0 = mrg[1], mx1 = mrg[2], my1 = mrg[3];
+    const float Wu = (mx0 + mx1 + (float)q.W) * 2.f, Hu = (my0 + my1 + (float)q.H) * 2.f;
+    const float outW = (float)((q.W + q.taps4 * 2) * 2), outH = (float)((q.H + q.taps4 * 2) * 2);
+    for (int b = tid; b < q.B; b += 256) {
+        const int s = call * q.B + b;
+        Aff2 g = ada_geometry(q, s, p);
+        // shift by the asymmetry of the padding, then to the x2-upsampled pixel grid, then to normalised coordinates (augment.py:270-281)
+        g.a02 += (mx0 - mx1) / 2.f; g.a12 += (my0 - my1) / 2.f;
+        g.a02 *= 2.f; g.a12 *= 2.f;                                   // zoom(2) @ G @ zoom(1/2)
+        g.a02 = g.a00 * 0.5f + g.a01 * 0.5f + g.a02 - 0.5f;           // shift(-1/2) @ G @ shift(1/2)
+        g.a12 = g.a10 * 0.5f + g.a11 * 0.5f + g.a12 - 0.5f;
+        const float rx = 2.f / Wu, ry = 2.f / Hu, cxs = outW / 2.f, cys = outH / 2.f;
+        float* t = q.theta + s * 6;
+        t[0] = rx * g.a00 * cxs; t[1] = rx * g.a01 * cys; t[2] = rx * g.a02;
+        t[3] = ry * g.a10 * cxs; t[4] = ry * g.a11 * cys; t[5] = ry * g.a12;
+    }
+}
+
+extern "C" int agf_ada_plan(const float* draws, const float* p, const int32_t* slots, const float* prm, float* theta, int32_t* margins,
+                            float* M, float* M3, int32_t calls, int32_t B, int32_t H, int32_t W, int32_t taps4, void* stream) {
+    AGF_CHECK(draws && p && slots && prm, "ada_plan: null pointer");
+    AGF_CHECK(calls >= 1 && B >= 1 && H >= 2 && W >= 2 && taps4 >= 0, "ada_plan: bad shape");
+    AdaPlanParams q;
+    q.draws = draws; q.p = p; q.theta = theta; q.margins = margins; q.M = M; q.M3 = M3;
+    q.calls = calls; q.B = B; q.H = H; q.W = W; q.taps4 = taps4;
+    q.geom = 0; q.colour = 0;
+    for (int i = 0; i < ADA_STAGES; i++) {
+        q.off_v[i] = slots[2 * i]; q.off_g[i] = slots[2 * i + 1];
+        q.strength[i] = prm[2 * i]; q.prm[i] = prm[2 * i + 1];
+        AGF_CHECK((q.off_v[i] >= 0) == (q.off_g[i] >= 0), "ada_plan: a stage needs both of its draws");
+        if (q.off_v[i] >= 0) (i < ADA_BRIGHT ? q.geom : q.colour) = 1;
+    }
+    AGF_CHECK(!q.geom || (theta && margins), "ada_plan: geometric stages enabled without theta / margins");
+    AGF_CHECK(!q.colour || (M && M3), "ada_plan: colour stages enabled without M / M3");
+    AGF_CHECK(q.geom || q.colour, "ada_plan: no stage enabled");
+    hipLaunchKernelGGL(ada_plan_kernel, dim3((unsigned)calls), dim3(256), 0, (hipStream_t)stream, q);
+    AGF_LAUNCH_CHECK();
+    return AGF_OK;
+}

@@ -23,6 +23,9 @@ struct ActBwdParams {
     const uint32_t* mask;     // or null: 1 bit per element instead of y: one 32-bit word per (2x2 cell, 8-channel group), byte (h&1)*2 + (w&1), bit k = y[8 g + k] > 0 (agf_pool2x2)
     const float* dscale;      // [N,C] or null: the incoming gradient is dy * dscale[n,c] (agf_act_bwd_reduce_scaled: dy = the data gradient t of
     float* sumD;              //   the consumer's modulated conv, dscale = its style scale s); sumD[n,c] += sum_p y * dy  (= that conv's d s)
+    const float* gscale;      // [N,C] or null: the STORED gradient is g * gscale[n,c] (the sums are of g itself).  g of a modulated layer is read only
+                              //   by that layer's data- and weight-gradient launches, both of which want g * d (d = its demodulation scale): with the
+                              //   product stored once here they run without an operand scale (the MFMA kernels' unscaled, direct-to-LDS variants)
 };
 
 #ifndef ACTBWD_U
@@ -36,9 +39,9 @@ __global__ void __launch_bounds__(256) act_bwd_reduce_kernel(ActBwdParams p) {
     const int n = blockIdx.y, chunk = blockIdx.x;
     const int p0 = chunk * p.pixPerBlock;
     const int p1 = min(p0 + p.pixPerBlock, p.HW);
-    float a[VEC], b[VEC], c[VEC], d[SCALED ? VEC : 1], sc[SCALED ? VEC : 1];
+    float a[VEC], b[VEC], c[VEC], d[SCALED ? VEC : 1], sc[SCALED ? VEC : 1], gs[VEC];
 #pragma unroll
-    for (int i = 0; i < VEC; i++) a[i] = b[i] = c[i] = 0.f;
+    for (int i = 0; i < VEC; i++) { a[i] = b[i] = c[i] = 0.f; gs[i] = p.gscale ? p.gscale[(int64_t)blockIdx.y * p.C + (tid % p.CG) * VEC + i] : 1.f; }
     if (SCALED) {
 #pragma unroll
         for (int i = 0; i < VEC; i++) { d[i] = 0.f; sc[i] = p.dscale[(int64_t)n * p.C + cg * VEC + i]; }
@@ -90,6 +93,7 @@ __global__ void __launch_bounds__(256) act_bwd_reduce_kernel(ActBwdParams p) {
                     g[i] = pos ? dy[u][i] : dy[u][i] * p.alpha;
                     const float y0 = pos ? y[u][i] : y[u][i] * p.inv_alpha;
                     a[i] += g[i] * y0; b[i] += g[i]; c[i] += g[i] * nz;
+                    g[i] *= gs[i];
                 }
                 VecIO<T, VEC>::store((T*)p.g + base + (int64_t)px * p.C, g);
             }
@@ -189,7 +193,7 @@ static int plan(int C, int vec, int HW, int N, int* CG, int* pixLanes, int* pixP
 static int act_bwd_reduce_impl(const void* dy, const void* y, const float* noise, void* g,
                                float* sum_gy0, float* sum_g, float* sum_gnoise,
                                int dtype, int32_t N, int32_t H, int32_t W, int32_t C, float alpha, int pooled, float dy_scale, void* stream,
-                               const float* dscale = nullptr, float* sum_ydy = nullptr, const uint32_t* mask = nullptr) {
+                               const float* dscale = nullptr, float* sum_ydy = nullptr, const uint32_t* mask = nullptr, const float* gscale = nullptr) {
     AGF_CHECK(dy && (y || mask) && g, "act_bwd_reduce: null pointer");
     AGF_CHECK(dtype == AGF_BF16 || dtype == AGF_F32, "act_bwd_reduce: dtype must be bf16 or f32");
     AGF_CHECK(alpha > 0.f, "act_bwd_reduce: the leaky slope must be positive");
@@ -197,7 +201,7 @@ static int act_bwd_reduce_impl(const void* dy, const void* y, const float* noise
     ActBwdParams p;
     p.dy = dy; p.y = y; p.noise = noise; p.g = g; p.sumA = sum_gy0; p.sumB = sum_g; p.sumC = sum_gnoise;
     p.N = N; p.HW = H * W; p.C = C; p.alpha = alpha; p.inv_alpha = 1.f / alpha;
-    p.pooled = pooled; p.W = W; p.dy_scale = dy_scale; p.dscale = dscale; p.sumD = sum_ydy; p.mask = mask;
+    p.pooled = pooled; p.W = W; p.dy_scale = dy_scale; p.dscale = dscale; p.sumD = sum_ydy; p.mask = mask; p.gscale = gscale;
     const int vec = dtype == AGF_BF16 ? 8 : 4;
     if (!plan(C, vec, p.HW, N, &p.CG, &p.pixLanes, &p.pixPerBlock, &p.chunks)) {
         agf_set_error("act_bwd_reduce: C=%d is not a multiple of %d (or too wide)", C, vec);
@@ -217,16 +221,16 @@ static int act_bwd_reduce_impl(const void* dy, const void* y, const float* noise
 }
 
 extern "C" int agf_act_bwd_reduce(const void* dy, const void* y, const float* noise, void* g,
-                                  float* sum_gy0, float* sum_g, float* sum_gnoise,
+                                  float* sum_gy0, float* sum_g, float* sum_gnoise, const float* g_scale,
                                   int dtype, int32_t N, int32_t H, int32_t W, int32_t C, float alpha, void* stream) {
-    return act_bwd_reduce_impl(dy, y, noise, g, sum_gy0, sum_g, sum_gnoise, dtype, N, H, W, C, alpha, 0, 1.f, stream);
+    return act_bwd_reduce_impl(dy, y, noise, g, sum_gy0, sum_g, sum_gnoise, dtype, N, H, W, C, alpha, 0, 1.f, stream, nullptr, nullptr, nullptr, g_scale);
 }
 
 extern "C" int agf_act_bwd_reduce_scaled(const void* t, const void* y, const float* noise, const float* t_scale, void* g,
-                                         float* sum_gy0, float* sum_g, float* sum_gnoise, float* sum_yt,
+                                         float* sum_gy0, float* sum_g, float* sum_gnoise, float* sum_yt, const float* g_scale,
                                          int dtype, int32_t N, int32_t H, int32_t W, int32_t C, float alpha, void* stream) {
     AGF_CHECK(t_scale && sum_yt, "act_bwd_reduce_scaled: null pointer");
-    return act_bwd_reduce_impl(t, y, noise, g, sum_gy0, sum_g, sum_gnoise, dtype, N, H, W, C, alpha, 0, 1.f, stream, t_scale, sum_yt);
+    return act_bwd_reduce_impl(t, y, noise, g, sum_gy0, sum_g, sum_gnoise, dtype, N, H, W, C, alpha, 0, 1.f, stream, t_scale, sum_yt, nullptr, g_scale);
 }
 
 extern "C" int agf_act_bwd_reduce_pooled(const void* dy_half, const void* y, void* g, float* sum_g,

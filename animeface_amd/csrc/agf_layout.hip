@@ -33,14 +33,23 @@ __global__ void __launch_bounds__(256) planar_to_cl_pad_kernel(LayoutParams p) {
     U* yrow = (U*)p.y + ((int64_t)(n * Hp + yp) * Wp) * p.Cp;
     if (rowIn) {
         // load [CT][PT] from the planar side, elementwise bounds (W may be odd; pad shifts alignment)
+        // (all of a lane's CT * PT / 256 element loads are issued before the first LDS write: as a rolled loop -- load, write, load, ... --
+        //  a block paid one HBM round trip per element and the kernel sat at 2.2 TB/s on the 534 x 534 StyleGAN3 layers)
         const U* xb = (const U*)p.x + ((int64_t)n * p.C * p.H + yi) * p.W;
-        for (int i = tid; i < CT * PT; i += 256) {
-            const int c = i / PT, px = i - c * PT;
-            const int cc = c0 + c, xi = xp0 + px - p.pad;
-            U v = 0;
-            if (cc < p.C && xi >= 0 && xi < p.W) v = xb[(int64_t)cc * p.H * p.W + xi];
-            tile[c * LP + px] = v;
+        constexpr int NL = CT * PT / 256;
+        static_assert(CT * PT % 256 == 0 && 256 % PT == 0, "tile must be a whole number of passes of the block");
+        const int px = tid % PT, xi = xp0 + px - p.pad;
+        const bool colIn = xi >= 0 && xi < p.W;
+        const int64_t plane = (int64_t)p.H * p.W;
+        U v[NL];
+#pragma unroll
+        for (int k = 0; k < NL; k++) {
+            const int cc = c0 + tid / PT + k * (256 / PT);
+            v[k] = 0;
+            if (colIn && cc < p.C) v[k] = xb[cc * plane + xi];
         }
+#pragma unroll
+        for (int k = 0; k < NL; k++) tile[(tid / PT + k * (256 / PT)) * LP + px] = v[k];
         __syncthreads();
     }
     // store: one 16-byte vector of VEC channels per (pixel, channel group)

@@ -176,7 +176,7 @@ template <class T> struct RawUnpack<T, 8> {
     }
 };
 
-template <class T, int VEC, int UP, int DN, int FW, int FH, int ROWS, int K00>
+template <class T, int VEC, int UP, int DN, int FW, int FH, int ROWS, int K00, int PD = 2>
 __global__ void __launch_bounds__(256) upfirdn2d_nhwc_rows(UpfirdnParams p) {
     // K00 = (floor(mid0/UP)+1)*UP - mid0 - 1 for the strip's first row: identical for every strip because ROWS*DN is a
     // multiple of UP, so the host passes it as a template argument and every (input row t, output row r) tap index
@@ -223,7 +223,7 @@ __global__ void __launch_bounds__(256) upfirdn2d_nhwc_rows(UpfirdnParams p) {
     // two-deep register pipeline over input rows: row t+1 is in flight (packed, 4 VGPRs per vector) while row t is
     // unpacked and accumulated; the empty asm statements stop the scheduler from hoisting every row's loads to the top
     // (which costs 256 VGPRs and one wave per SIMD).
-    u32x4 raw[2][NTX];
+    u32x4 raw[PD][NTX];
     auto load_row = [&](int t, u32x4 (&dst)[NTX]) {
         int iy = iyA + t;
         bool rowok = true;
@@ -235,14 +235,15 @@ __global__ void __launch_bounds__(256) upfirdn2d_nhwc_rows(UpfirdnParams p) {
             dst[jx] = v;
         }
     };
-    load_row(0, raw[0]);
+#pragma unroll
+    for (int t = 0; t < PD - 1; t++) if (t < TMAX) load_row(t, raw[t]);
 #pragma unroll
     for (int t = 0; t < TMAX; t++) {
-        if (t + 1 < TMAX) load_row(t + 1, raw[(t + 1) & 1]);
+        if (t + PD - 1 < TMAX) load_row(t + PD - 1, raw[(t + PD - 1) % PD]);
         asm volatile("" ::: "memory");
         float xv[NTX][VEC];
 #pragma unroll
-        for (int jx = 0; jx < NTX; jx++) RawUnpack<T, VEC>::run(raw[t & 1][jx], xv[jx]);
+        for (int jx = 0; jx < NTX; jx++) RawUnpack<T, VEC>::run(raw[t % PD][jx], xv[jx]);
 #pragma unroll
         for (int r = 0; r < ROWS; r++) {
             const int ky = t * UP + K00 - r * DN;                          // compile-time after unrolling
@@ -263,14 +264,14 @@ __global__ void __launch_bounds__(256) upfirdn2d_nhwc_rows(UpfirdnParams p) {
     }
 }
 
-template <class T, int VEC, int UP, int DN, int FW, int FH, int ROWS>
+template <class T, int VEC, int UP, int DN, int FW, int FH, int ROWS, int PD = 2>
 static void launch_rows(const UpfirdnParams& p, dim3 g, hipStream_t st) {
     // mid0 mod UP is strip-invariant (ROWS*DN % UP == 0)
     const int mid0 = UP - 1 - p.pady0;
     const int k00 = (agf_floor_div(mid0, UP) + 1) * UP - mid0 - 1;
     static_assert((ROWS * DN) % UP == 0, "strip height must preserve the row phase");
-    if (UP == 1 || k00 == 0) hipLaunchKernelGGL((upfirdn2d_nhwc_rows<T, VEC, UP, DN, FW, FH, ROWS, 0>), g, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((upfirdn2d_nhwc_rows<T, VEC, UP, DN, FW, FH, ROWS, (UP > 1 ? 1 : 0)>), g, dim3(256), 0, st, p);
+    if (UP == 1 || k00 == 0) hipLaunchKernelGGL((upfirdn2d_nhwc_rows<T, VEC, UP, DN, FW, FH, ROWS, 0, PD>), g, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((upfirdn2d_nhwc_rows<T, VEC, UP, DN, FW, FH, ROWS, (UP > 1 ? 1 : 0), PD>), g, dim3(256), 0, st, p);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -667,6 +668,19 @@ static bool launch_nhwc(const UpfirdnParams& p, hipStream_t st) {
         launch_rows<T, VEC, ux, dx, w, h, ROWS>(pp, gr, st);                                              \
         return true;                                                                                      \
     }
+#define NHWC_VAR(ux, dx, w, rows, pd, id)                                                                   \
+    if (var == id && p.upx == ux && p.upy == ux && p.downx == dx && p.downy == dx && p.fw == w && p.fh == w) {   \
+        dim3 gr((unsigned)agf_ceil_div((int64_t)p.OW * CG, 256), (unsigned)agf_ceil_div(p.OH, rows), (unsigned)p.N);   \
+        launch_rows<T, VEC, ux, dx, w, w, rows, pd>(pp, gr, st);                                          \
+        return true;                                                                                      \
+    }
+    { static const int var = getenv("AGF_X_VAR") ? atoi(getenv("AGF_X_VAR")) : 0;     // EXPERIMENT (to be removed)
+      NHWC_VAR(1, 2, 4, 8, 2, 1) NHWC_VAR(1, 2, 4, 4, 3, 2) NHWC_VAR(1, 2, 4, 8, 3, 3) NHWC_VAR(1, 2, 4, 2, 3, 4)
+      NHWC_VAR(1, 2, 6, 8, 2, 1) NHWC_VAR(1, 2, 6, 4, 3, 2) NHWC_VAR(1, 2, 6, 8, 3, 3) NHWC_VAR(1, 2, 6, 2, 3, 4)
+      NHWC_VAR(1, 1, 3, 8, 3, 2) NHWC_VAR(1, 1, 3, 16, 2, 1) NHWC_VAR(1, 1, 3, 16, 3, 3) NHWC_VAR(1, 1, 3, 4, 3, 4)
+      NHWC_VAR(2, 1, 4, 8, 3, 2) NHWC_VAR(2, 1, 4, 16, 2, 1) NHWC_VAR(2, 1, 4, 4, 3, 4)
+      NHWC_VAR(2, 1, 6, 8, 3, 2) NHWC_VAR(2, 1, 6, 4, 3, 4) }
+#undef NHWC_VAR
     NHWC_CASE(2, 2, 1, 1, 4, 4, 8)   // bilinear-equivalent 2x upsample  (StyleGAN2 Upsample2x, ToImage)
     NHWC_CASE(1, 1, 1, 1, 3, 3, 8)   // Blur2d
     NHWC_CASE(1, 1, 2, 2, 2, 2, 4)   // AvgPool2d(2)

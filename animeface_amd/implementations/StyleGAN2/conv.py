@@ -475,8 +475,9 @@ def conv2d(x, w, s_in=None, s_out=None):
 # ---------------------------------------------------------------------------------------------------------------
 # fused epilogue:  y = lrelu( s_out * conv(x * s_in, w) + bias + noise )   in ONE launch, with a fused backward
 
-def act_bwd_reduce_raw(dy, y, noise, alpha, want_sums):
-    """One ``agf_act_bwd_reduce`` launch: g = dy * lrelu'(y) and (optionally) the three per-(n,c) sums."""
+def act_bwd_reduce_raw(dy, y, noise, alpha, want_sums, g_scale=None):
+    """One ``agf_act_bwd_reduce`` launch: g = dy * lrelu'(y) and (optionally) the three per-(n,c) sums.  ``g_scale`` [N,C]: the returned
+    tensor is g * g_scale (the sums are of g)."""
     N, C, H, W = y.shape
     g = torch.empty_like(y)
     pool = _zeros_f32((sum(bool(w) for w in want_sums), N, C), y.device) if any(want_sums) else None
@@ -485,22 +486,22 @@ def act_bwd_reduce_raw(dy, y, noise, alpha, want_sums):
         sums.append(pool[j] if w else None)
         j += bool(w)
     rc = _lib.lib().agf_act_bwd_reduce(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(_f32(noise)), _lib.ptr(g),
-                                       _lib.ptr(sums[0]), _lib.ptr(sums[1]), _lib.ptr(sums[2]),
+                                       _lib.ptr(sums[0]), _lib.ptr(sums[1]), _lib.ptr(sums[2]), _lib.ptr(_f32(g_scale)),
                                        _lib.dtype_code(y), N, H, W, C, float(alpha), _lib.stream_ptr(y))
     _lib.check(rc, 'act_bwd_reduce')
     return g, sums
 
 
-def act_bwd_reduce_scaled_raw(t, y, noise, t_scale, alpha):
+def act_bwd_reduce_scaled_raw(t, y, noise, t_scale, alpha, g_scale=None):
     """One ``agf_act_bwd_reduce_scaled`` launch: g = (t * t_scale[n,c]) * lrelu'(y), the producer's three sums and the consumer's
-    ds[n,c] = sum_hw y * t.  Returns g, (A, B, Cn), ds."""
+    ds[n,c] = sum_hw y * t.  Returns g (times ``g_scale`` [N,C] when given), (A, B, Cn), ds."""
     N, C, H, W = y.shape
     g = torch.empty_like(y)
     pool = _zeros_f32((4 if noise is not None else 3, N, C), y.device)
     A, B, ds = pool[0], pool[1], pool[2]
     Cn = pool[3] if noise is not None else None
     rc = _lib.lib().agf_act_bwd_reduce_scaled(_lib.ptr(t), _lib.ptr(y), _lib.ptr(_f32(noise)), _lib.ptr(_f32(t_scale)), _lib.ptr(g),
-                                              _lib.ptr(A), _lib.ptr(B), _lib.ptr(Cn), _lib.ptr(ds),
+                                              _lib.ptr(A), _lib.ptr(B), _lib.ptr(Cn), _lib.ptr(ds), _lib.ptr(_f32(g_scale)),
                                               _lib.dtype_code(y), N, H, W, C, float(alpha), _lib.stream_ptr(y))
     _lib.check(rc, 'act_bwd_reduce_scaled')
     return g, (A, B, Cn), ds
@@ -800,7 +801,7 @@ class PremaskLink:
     """Handshake between two chained fused convs  y1 = lrelu(conv1(x) + b1);  y2 = conv2(y1)  where conv2 is the ONLY consumer of y1
     (the caller guarantees that: DBlock).  conv2's backward then produces the gradient of y1 already multiplied by lrelu'(y1) and its
     per-channel sums (``agf_conv2d_fwd_mask``), and conv1's backward skips its own pass over the tensor (``agf_act_bwd_reduce``)."""
-    __slots__ = ('armed', 'alpha', 'premasked', 'bsum', 'pooled', 'armed_mod', 'noise', 'sums', 'mask')
+    __slots__ = ('armed', 'alpha', 'premasked', 'bsum', 'pooled', 'armed_mod', 'noise', 'sums', 'mask', 'gscale', 'gscaled')
 
     def __init__(self):
         self.armed, self.alpha, self.premasked, self.bsum, self.pooled = False, 0.2, False, None, None
@@ -808,6 +809,9 @@ class PremaskLink:
         # turns its unscaled data gradient t straight into the producer's masked gradient and leaves the producer's sums here
         self.armed_mod, self.noise, self.sums = False, None, None
         self.mask = None     # 1-bit sign mask of the producer's output, left by the pooling consumer's forward (agf_pool2x2)
+        # the modulated producer's demodulation scale d [N,C]: the consumer's backward stores the producer's gradient already times d
+        # (``PRESCALE_G``) and says so in ``gscaled``
+        self.gscale, self.gscaled = None, False
 
 
 class _UpBlur(torch.autograd.Function):
@@ -994,6 +998,7 @@ def torgb(x, weight, bias, s_raw, pre, coef):
 
 
 POOL_KERNEL = True     # agf_pool2x2 for the DBlock's AvgPool2d(2) (False: the [1,1] box FIR of upfirdn2d; tests compare the two)
+PRESCALE_G = True      # a modulated layer's gradient tensor is stored times its demodulation scale by the pass that makes it (tests compare both ways)
 _PREMASK = True        # tests/test_hip_conv.py::test_dblock_linked_backward_matches_unlinked runs the block with the fused hand-offs off
 
 
@@ -1031,6 +1036,7 @@ class _FusedConv(torch.autograd.Function):
         elif post_link is not None and _PREMASK and act == ACT_LRELU and gain == 1.0 and x.dtype == torch.bfloat16 \
                 and s_out is not None:
             post_link.armed_mod, post_link.alpha, post_link.premasked, post_link.noise, post_link.sums = True, float(alpha), False, noise, None
+            post_link.gscale, post_link.gscaled = (s_out.detach() if (PRESCALE_G and residual is None) else None), False
             ctx.post_link = post_link
         return y if skip_pool is None else (y, tp)
 
@@ -1087,6 +1093,9 @@ class _FusedConv(torch.autograd.Function):
         # the output gain is not applied to the gradient tensor: it rides along in the data-gradient launch's epilogue gain, in the
         # weight-gradient scale and in the bias sum (no pass over the tensor for it)
         pg = float(gain)
+        # PRESCALE_G: the gradient tensor g of a modulated layer is stored as g * d by the pass that makes it (d = s_out), so that the data-
+        # and weight-gradient launches below take it without an operand scale (their faster unscaled variants)
+        g_scaled = False
         if pooled is not None:
             mask, link.mask = link.mask, None
             if mask is not None:
@@ -1100,6 +1109,7 @@ class _FusedConv(torch.autograd.Function):
             # (agf_act_bwd_reduce_scaled)
             link.premasked = False
             g = dy
+            g_scaled, link.gscaled = link.gscaled, False
             (A, B, Cn), link.sums = link.sums, None
             want_so, want_b = s_out is not None and need_so, need_b and bias is not None
             if want_so or want_b:                      # (frozen parameters and detached styles: only x wants a gradient)
@@ -1115,8 +1125,10 @@ class _FusedConv(torch.autograd.Function):
         elif act == ACT_LRELU:
             assert gain == 1.0 or s_out is None, 'demodulated layers use unit gain'
             want_so = s_out is not None and need_so
+            g_scaled = PRESCALE_G and s_out is not None and not need_r and x.dtype == torch.bfloat16
             g, (A, B, Cn) = act_bwd_reduce_raw(dy, y, noise, alpha,
-                                               (want_so, want_so or (need_b and bias is not None), want_so and noise is not None))
+                                               (want_so, want_so or (need_b and bias is not None), want_so and noise is not None),
+                                               g_scale=s_out if g_scaled else None)
             if B is not None:
                 dso, db = demod_grad_finish_raw(A, B, Cn, bias, s_out, want_so, need_b and bias is not None, pg)
                 db = db.to(bias.dtype) if db is not None else None
@@ -1137,20 +1149,20 @@ class _FusedConv(torch.autograd.Function):
                 # x is the lrelu output of the producer this link came from and we are its only consumer: hand it the masked gradient
                 det = _lib.deterministic()            # the kernel's per-channel sums are atomics over 256 slots: reduce the output instead
                 pre.bsum = None if det else _zeros_f32((256, x.shape[1]), x.device)
-                t = conv2d_fwd_raw(g, prep.wq_ft, in_scale=s_out, prepared=True, gain=pg, mask_y=x, mask_alpha=pre.alpha, mask_sum=pre.bsum,
-                                   res_pooled=res_pooled, res_scale=res_scale)
+                t = conv2d_fwd_raw(g, prep.wq_ft, in_scale=None if g_scaled else s_out, prepared=True, gain=pg, mask_y=x, mask_alpha=pre.alpha,
+                                   mask_sum=pre.bsum, res_pooled=res_pooled, res_scale=res_scale)
                 if det:
                     pre.bsum = t.sum((0, 2, 3), dtype=torch.float32)[None]
                 pre.premasked = True
             else:
-                t = conv2d_fwd_raw(g, prep.wq_ft, in_scale=s_out, prepared=True, gain=pg, res_pooled=res_pooled, res_scale=res_scale)
+                t = conv2d_fwd_raw(g, prep.wq_ft, in_scale=None if g_scaled else s_out, prepared=True, gain=pg, res_pooled=res_pooled, res_scale=res_scale)
             if s_in is None:
                 dx = t
             elif pre is not None and pre.armed_mod and need_x and x.dtype == torch.bfloat16 and x.shape[1] % 8 == 0 and dx_pool is None:
                 # x is the lrelu output of the modulated producer this link came from and this conv is its only consumer: one pass gives
                 # this conv's ds and the producer's masked gradient and sums (instead of scale_dot here + act_bwd_reduce there)
-                dx, pre.sums, dsi = act_bwd_reduce_scaled_raw(t, x, pre.noise, s_in, pre.alpha)
-                pre.premasked, pre.noise = True, None
+                dx, pre.sums, dsi = act_bwd_reduce_scaled_raw(t, x, pre.noise, s_in, pre.alpha, g_scale=pre.gscale)
+                pre.premasked, pre.noise, pre.gscaled, pre.gscale = True, None, pre.gscale is not None, None
             else:
                 dx, dsi = scale_dot_raw(x, t, s_in, want_dx=need_x)
             if dx_pool is not None and dx is not None:
@@ -1158,7 +1170,7 @@ class _FusedConv(torch.autograd.Function):
         elif dx_pool is not None and need_x:
             dx = dx_pool
         if need_w:
-            dw = conv2d_wgrad_raw(x, g, k, in_scale=s_in, out_scale=s_out, scale=coef * pg).to(weight.dtype)
+            dw = conv2d_wgrad_raw(x, g, k, in_scale=s_in, out_scale=None if g_scaled else s_out, scale=coef * pg).to(weight.dtype)
         return dx, dw, None, dsi, dso, db, None, dres, None, None, None, None, None, None
 
 

@@ -107,19 +107,95 @@ class TrainStep:
         return D_loss.detach(), G_loss.detach(), fake.detach()
 
 
+class GraphedTrainStep:
+    """The StyleGAN3 iteration replayed from HIP graphs: the body of ``TrainStep.__call__`` (G(z), both D passes, both backward passes, both
+    fused Adam steps, EMA) is recorded once per iteration kind -- adversarial loss only, or with the R1 penalty of every ``gp_every``-th
+    iteration (reference utils.py:50-53) -- and replayed with one host call.  Eagerly the ~2 700 launches of a 512x512 iteration take the
+    host longer to issue than the GPU to run (84.7 ms of kernels in a 104.9 ms iteration, profiles/r04_final_sg3_512_kernel_stats.csv).
+    Kernels, their order and their arithmetic are those of the eager step; random draws come from torch's graph-safe generator state.
+    Needs capturable optimizers (``build_optimizers(..., capturable=True)``), batches of one fixed shape, no gradient reducers (the
+    data-parallel exchange of this trainer is issued from the host) and an augmentation without a host-side schedule (``update_p``)."""
+
+    def __init__(self, step, real, warmup=2):
+        if not real.is_cuda:
+            raise RuntimeError('graph capture needs a GPU batch')
+        if step.reducer_G is not None or step.reducer_D is not None:
+            raise RuntimeError('StyleGAN3 graph capture: gradient reducers are not supported (run the eager TrainStep)')
+        if hasattr(step.augment, 'update_p'):
+            raise RuntimeError('StyleGAN3 graph capture: the ADA p schedule reads D(real) on the host (run the eager TrainStep)')
+        for opt in (step.optimizer_G, step.optimizer_D):
+            if not all(g.get('capturable', False) for g in opt.param_groups):
+                raise RuntimeError('graph capture needs capturable optimizers: build_optimizers(..., capturable=True)')
+        self.step, self.graphs = step, {}
+        self.static_real = real.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                      # eager iterations first: optimizer state, workspaces and caches reach their final size
+            for _ in range(warmup):
+                step(self.static_real)
+        torch.cuda.current_stream().wait_stream(side)
+
+    @property
+    def batches_done(self):
+        return self.step.batches_done
+
+    def _kind(self, it):
+        st = self.step
+        return 'r1' if (st.gp_lambda > 0 and it % st.gp_every == 0) else 'gan'
+
+    def kinds(self):
+        return set(self.graphs)
+
+    def _capture(self, it):
+        kind = self._kind(it)
+        if kind in self.graphs:
+            return
+        st = self.step
+        saved = st.batches_done
+        st.batches_done = it
+        graph = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(graph):
+                out = st(self.static_real)                 # records; the Python body runs once and leaves batches_done advanced
+        finally:
+            st.batches_done = saved
+        self.graphs[kind] = (graph, out)
+
+    def capture_all(self):
+        st = self.step
+        for it in range(1, (st.gp_every if st.gp_lambda > 0 else 1) + 1):
+            self._capture(it)
+
+    def __call__(self, real):
+        st = self.step
+        it = st.batches_done
+        self.static_real.copy_(real)
+        self._capture(it)
+        graph, out = self.graphs[self._kind(it)]
+        graph.replay()
+        st.batches_done = it + 1
+        return out
+
+
+GRAPH_AFTER = 2        # eager iterations at the start of train(graphs=True) before the iteration is recorded
+
+
 def train(max_iters, dataset, latent_dim, const_input,
           G, G_ema, D, optimizer_G, optimizer_D,
           gp_lambda, gp_every, augment,
           device, amp, save=1000, log_file=None, log_every=50, on_save=None, reducer_G=None, reducer_D=None, resume=None,
-          checkpoint_path=None, log=print):
+          checkpoint_path=None, log=print, graphs=False):
     """Same positional signature as the reference's ``train`` (utils.py:15-20).  Every ``log_every`` iterations one line with the losses
-    and the throughput since the previous line goes to ``log``."""
+    and the throughput since the previous line goes to ``log``.  ``graphs=True``: after ``GRAPH_AFTER`` ordinary eager iterations (optimizer
+    state, workspaces and caches then have their final size) the iteration is recorded into HIP graphs and replayed (``GraphedTrainStep``;
+    needs capturable optimizers); recording executes nothing, so no iteration is consumed."""
     import time
     from ... import distributed as _dp
     step = TrainStep(G, G_ema, D, optimizer_G, optimizer_D, gp_lambda, gp_every, augment, latent_dim, reducer_G, reducer_D)
     if resume is not None:                                  # full resume state (animeface_amd/checkpoint.py), not just G_ema
         from ... import checkpoint
         checkpoint.load(step, resume, map_location=device)
+    runner, it_start = step, step.batches_done
     history = []
     t_last, it_last = time.perf_counter(), step.batches_done
     world = _dp.dist.get_world_size() if _dp.dist.is_initialized() else 1
@@ -129,7 +205,9 @@ def train(max_iters, dataset, latent_dim, const_input,
         for real in dataset:
             real = real.to(device, non_blocking=True)
             it = step.batches_done
-            D_loss, G_loss, fake = step(real)
+            if graphs and runner is step and real.is_cuda and step.batches_done - it_start >= GRAPH_AFTER:
+                runner = GraphedTrainStep(step, real, warmup=0)
+            D_loss, G_loss, fake = runner(real)
             if it % save == 0 and checkpoint_path is not None and it > 0:
                 from ... import checkpoint
                 checkpoint.save(step, checkpoint_path)
@@ -148,12 +226,12 @@ def train(max_iters, dataset, latent_dim, const_input,
     return history
 
 
-def build_optimizers(G, D, lr, map_lr_scale, betas):
-    """reference utils.py:176-181."""
+def build_optimizers(G, D, lr, map_lr_scale, betas, capturable=False):
+    """reference utils.py:176-181.  ``capturable``: step counters on the device, so that the steps can be recorded into a HIP graph."""
     fused = all(p.is_cuda for p in G.parameters())
     optimizer_G = optim.Adam([{'params': G.synthesis.parameters()},
-                              {'params': G.map.parameters(), 'lr': lr * map_lr_scale}], lr=lr, betas=betas, fused=fused)
-    optimizer_D = optim.Adam(D.parameters(), lr=lr, betas=betas, fused=fused)
+                              {'params': G.map.parameters(), 'lr': lr * map_lr_scale}], lr=lr, betas=betas, fused=fused, capturable=capturable)
+    optimizer_D = optim.Adam(D.parameters(), lr=lr, betas=betas, fused=fused, capturable=capturable)
     return optimizer_G, optimizer_D
 
 
@@ -199,6 +277,7 @@ SG3_ARGS = dict(
     gp_every=[16, 'calc penalty every'],
     policy=['color,translation', 'policy for DiffAugment'],
     log_every=[50, 'iterations between log lines (losses, img/s); not a flag of the reference'],
+    hip_graphs=[False, 'replay the training iteration from HIP graphs (single GPU, DiffAugment)'],
     logfile=[str, 'log file'])
 
 
@@ -216,7 +295,8 @@ def main(parser, dataset=None):
     G, G_ema, D = build_models(args, device, compute_dtype)
     dp.broadcast_module(G), dp.broadcast_module(G_ema), dp.broadcast_module(D)
     D(G(const_input))                                             # the reference's warm-up call; it moves ema / w_avg
-    optimizer_G, optimizer_D = build_optimizers(G, D, args.lr, args.map_lr_scale, tuple(args.betas))
+    graphs = bool(args.hip_graphs) and world == 1 and device.type == 'cuda'
+    optimizer_G, optimizer_D = build_optimizers(G, D, args.lr, args.map_lr_scale, tuple(args.betas), capturable=graphs)
     reducer_G = dp.GradReducer(G.parameters()) if world > 1 else None
     reducer_D = dp.GradReducer(D.parameters()) if world > 1 else None
     if dataset is None:
@@ -228,4 +308,4 @@ def main(parser, dataset=None):
     augment = functools.partial(DiffAugment, policy=args.policy)
     return train(args.max_iters, dataset, args.latent_dim, const_input, G, G_ema, D, optimizer_G, optimizer_D,
                  args.gp_lambda, args.gp_every, augment, device, amp, args.save, args.logfile, log_every=args.log_every,
-                 reducer_G=reducer_G, reducer_D=reducer_D)
+                 reducer_G=reducer_G, reducer_D=reducer_D, graphs=graphs)

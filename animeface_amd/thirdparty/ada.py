@@ -167,6 +167,7 @@ class _ColorAffine(torch.autograd.Function):
 def _color_affine(flat, m):
     return _ColorAffine.apply(flat, m)
 
+FUSED_PLAN = True      # False: the decisions as the reference's chain of small batched tensor ops (tests compare the two)
 HOST_MARGINS = False   # True: the reference's flow (margins read back to the host, a reflect-padded tensor, upsample2d); tests compare the two
 
 _CONSTS = {}
@@ -288,6 +289,8 @@ class AugmentPipe(torch.nn.Module):
     def plan(self, shape, dtype, dev, debug_percentile=None):
         """The decisions of the geometric and colour stages for one batch (reference augment.py:188-347, same draws in the same order):
         ``dict(warp=..., M=..., M3=...)`` for ``apply``."""
+        if debug_percentile is None and self._fused_plan_covers(shape, dtype, torch.device(dev)):
+            return self._plan_fused(1, shape, dtype, torch.device(dev))[0]
         G, M = self._plan_matrices(shape, dev, debug_percentile)
         return self._plan_finish(G, M, shape, dtype, dev)
 
@@ -296,9 +299,68 @@ class AugmentPipe(torch.nn.Module):
         all calls are built as ONE batch of ``calls * B`` samples (a third of the launches for the three calls of a training iteration);
         only the reflect margins, a maximum over each call's own batch, are made per call."""
         B = shape[0]
+        if self._fused_plan_covers(shape, dtype, torch.device(dev)):
+            return self._plan_fused(calls, shape, dtype, torch.device(dev))
         G, M = self._plan_matrices((calls * B,) + tuple(shape[1:]), dev, None)
         return [self._plan_finish(None if G is None else G[i * B:(i + 1) * B], None if M is None else M[i * B:(i + 1) * B], shape, dtype, dev)
                 for i in range(calls)]
+
+    # -- the same decisions as ONE launch (agf_ada_plan) ---------------------------------------------------------------------------
+    _STAGES = (('xflip', None, 'u', 1), ('rotate90', None, 'u', 1), ('xint', 'xint_max', 'u', 2), ('scale', 'scale_std', 'n', 1),
+               ('rotate', 'rotate_max', 'u', 1), ('aniso', 'aniso_std', 'n', 1), ('rotate', 'rotate_max', 'u', 1),
+               ('xfrac', 'xfrac_std', 'n', 2), ('brightness', 'brightness_std', 'n', 1), ('contrast', 'contrast_std', 'n', 1),
+               ('lumaflip', None, 'u', 1), ('hue', 'hue_max', 'u', 1), ('saturation', 'saturation_std', 'n', 1))
+
+    def _fused_plan_covers(self, shape, dtype, dev):
+        """``agf_ada_plan`` serves what the device-margin warp serves (``_warp_plan``) with ``p`` resident on the same device."""
+        B, C, H, W = shape
+        return (FUSED_PLAN and not HOST_MARGINS and dev.type == 'cuda' and dtype in (torch.float32, torch.bfloat16) and C in (1, 3) and H >= 2
+                and W >= 2 and self.Hz_geom.ndim == 1 and self.Hz_geom.numel() == 12 and self.p.is_cuda and dev.index in (None, self.p.device.index)
+                and self.p.dtype == torch.float32
+                and any(getattr(self, st[0]) > 0 for st in self._STAGES))
+
+    def _plan_fused(self, calls, shape, dtype, dev):
+        """Plans of ``calls`` consecutive calls on batches of ``shape``: the random draws are the reference's (augment.py:188-347: a value draw,
+        then a gate draw per enabled stage, same shapes and order, for a batch of ``calls * B``), everything downstream of them -- gates,
+        the 3x3 / 4x4 matrix chains, corner reach, reflect margins, sampling matrix -- is one launch instead of ~200 per call."""
+        from .. import _lib
+        import ctypes
+        B, C, H, W = shape
+        Bt = calls * B
+        dev = self.p.device
+        draws, slots, prm, off = [], [], [], 0
+        for k, (name, par, kind, width) in enumerate(self._STAGES):
+            on = getattr(self, name) > 0 and not (name in ('hue', 'saturation') and C <= 1)
+            if not on:
+                slots += [-1, -1]
+                prm += [0., 0.]
+                continue
+            vshape = [Bt, 2] if width == 2 else ([Bt, 1, 1] if name in ('lumaflip', 'saturation') else [Bt])
+            gshape = [Bt, 1] if width == 2 else vshape
+            draws.append((rng.rand if kind == 'u' else rng.randn)(vshape, dev))          # value first, then its gate (``_gate``)
+            draws.append(rng.rand(gshape, dev))
+            slots += [off, off + Bt * width]
+            off += Bt * width + Bt
+            prm += [getattr(self, name), getattr(self, par) if par is not None else 0.]
+        flat = torch.cat([d.reshape(-1) for d in draws])
+        geom = any(s >= 0 for s in slots[:16])
+        colour = any(s >= 0 for s in slots[16:])
+        theta = torch.empty([Bt, 2, 3], dtype=torch.float32, device=dev) if geom else None
+        margins = torch.empty([calls, 4], dtype=torch.int32, device=dev) if geom else None
+        M = torch.empty([Bt, 4, 4], dtype=torch.float32, device=dev) if colour else None
+        M3 = torch.empty([Bt, 3, 4], dtype=torch.float32, device=dev) if colour else None
+        taps4 = self.Hz_geom.shape[0] // 4
+        ptr = lambda t: _lib.ptr(t) if t is not None else None
+        rc = _lib.lib().agf_ada_plan(_lib.ptr(flat), _lib.ptr(self.p), (ctypes.c_int32 * 26)(*slots), (ctypes.c_float * 26)(*prm), ptr(theta),
+                                     ptr(margins), ptr(M), ptr(M3), calls, B, H, W, taps4, _lib.stream_ptr(flat))
+        _lib.check(rc, 'ada_plan')
+        out_shape = [B, C, (H + taps4 * 2) * 2, (W + taps4 * 2) * 2]
+        plans = []
+        for i in range(calls):
+            cut = slice(i * B, (i + 1) * B)
+            warp = dict(kind='device', theta=theta[cut], margins=margins[i], out_shape=out_shape, taps4=taps4) if geom else None
+            plans.append(dict(warp=warp, M=M[cut] if colour else None, M3=M3[cut] if colour and C == 3 else None))
+        return plans
 
     def _plan_finish(self, G, M, shape, dtype, dev):
         B, C, H, W = shape

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define AGF_ABI_VERSION 19
+#define AGF_ABI_VERSION 20
 
 /* element types of activation tensors */
 enum { AGF_F32 = 0, AGF_F16 = 1, AGF_BF16 = 2, AGF_F64 = 3 };
@@ -229,18 +229,22 @@ int agf_conv2d_wgrad_ws(const void* x, const void* dy, float* dw,
  * Dense channels-last tensors; sum buffers are fp32 [N,C], ACCUMULATED into (zero them first), nullable.
  *   g       = dy * (y > 0 ? 1 : alpha)
  *   sum_gy0 += sum_{h,w} g * (y > 0 ? y : y / alpha)      sum_g += sum_{h,w} g      sum_gnoise += sum_{h,w} g * noise[n,h,w]
+ * g_scale [N,C] fp32, nullable (ABI v20): the tensor written to `g` is g * g_scale[n,c]; the sums are of g itself.  The g of a modulated
+ * layer is read only by that layer's data- and weight-gradient launches and both want g * d (d = its demodulation scale): storing the
+ * product here lets them run without an operand scale (the unscaled, direct-to-LDS variants of the MFMA kernels).
  */
 int agf_act_bwd_reduce(const void* dy, const void* y, const float* noise, void* g,
-                       float* sum_gy0, float* sum_g, float* sum_gnoise,
+                       float* sum_gy0, float* sum_g, float* sum_gnoise, const float* g_scale,
                        int dtype, int32_t N, int32_t H, int32_t W, int32_t C, float alpha, void* stream);
 
 /* agf_act_bwd_reduce fused with agf_scale_dot (ABI v13): y is the lrelu output of a modulated layer whose ONLY consumer is the next
  * modulated conv; t is that conv's unscaled data gradient and t_scale [N,C] its style scale.  One pass gives
  *   sum_yt[n,c] = sum_p y * t            (the consumer's gradient w.r.t. its style scale: what agf_scale_dot returns as ds)
  *   g           = (t * t_scale[n,c]) * lrelu'(y)   and sum_gy0 / sum_g / sum_gnoise of agf_act_bwd_reduce for the producer,
- * instead of writing dx = t * t_scale, reading it back and reading y a second time (6 tensor passes -> 3). */
+ * instead of writing dx = t * t_scale, reading it back and reading y a second time (6 tensor passes -> 3).  g_scale: as above (the
+ * PRODUCER's demodulation scale). */
 int agf_act_bwd_reduce_scaled(const void* t, const void* y, const float* noise, const float* t_scale, void* g,
-                              float* sum_gy0, float* sum_g, float* sum_gnoise, float* sum_yt,
+                              float* sum_gy0, float* sum_g, float* sum_gnoise, float* sum_yt, const float* g_scale,
                               int dtype, int32_t N, int32_t H, int32_t W, int32_t C, float alpha, void* stream);
 
 /* agf_act_bwd_reduce for an activation whose only consumer is a 2x2 box average (nn.AvgPool2d(2) after the last LeakyReLU of a DBlock,
@@ -362,6 +366,21 @@ int agf_ada_pad_up2(const void* x, void* u, const int32_t* margins, const float*
                     int32_t H, int32_t W, int backward, void* stream);
 int agf_ada_warp_resample(const void* x, void* y, const float* theta, const int32_t* margins, int dtype, int32_t B, int32_t C,
                           int32_t Hb, int32_t Wb, int32_t Hout, int32_t Wout, int backward, void* stream);
+
+/* ADA: all per-sample decisions of the geometric and colour stages in one launch (ABI v20).  The reference builds them as ~25 batched
+ * 3x3 / 4x4 matrix products over ~200 elementwise ops on [B] tensors (thirdparty/ada/augment.py:188-256 geometry, :296-347 colour) and
+ * reduces the transformed image corners to the reflect margins (:258-272).  The HOST still makes the reference's random draws (same calls,
+ * order and shapes) and concatenates them into `draws` (device, fp32); `p` is AugmentPipe.p (device scalar).
+ *   slots [13][2] (host, int32): offset into `draws` of a stage's value draw and of its gate draw, -1 / -1 = stage disabled; stages in the
+ *                 reference's order: xflip, rotate90, xint, scale, rotate (pre), aniso, rotate (post), xfrac | brightness, contrast,
+ *                 lumaflip, hue, saturation.  A [B, 2] draw (xint, xfrac) stays interleaved.  Offsets index a batch of calls * B samples.
+ *   prm   [13][2] (host, fp32): the stage's probability multiplier (xflip, rotate90, ... as in the constructor) and its parameter
+ *                 (xint_max, scale_std, rotate_max, aniso_std, rotate_max, xfrac_std, brightness_std, contrast_std, -, hue_max, saturation_std).
+ * Outputs (device): theta [calls * B][2][3] = the sampling matrix agf_ada_warp_resample reads, margins [calls][4] int32 = (x0, y0, x1, y1),
+ * each call's own maximum over its B samples (both null when no geometric stage is enabled); M [calls * B][4][4] and M3 [calls * B][3][4]
+ * (its first three rows: what agf_color_affine reads; both null when no colour stage is enabled).  taps4 = len(Hz_geom) / 4. */
+int agf_ada_plan(const float* draws, const float* p, const int32_t* slots, const float* prm, float* theta, int32_t* margins,
+                 float* M, float* M3, int32_t calls, int32_t B, int32_t H, int32_t W, int32_t taps4, void* stream);
 
 /* One layer of the mapping network (implementations/StyleGAN2/model.py:71-78 MapLinear + nn.LeakyReLU, :263-282), fp32 (ABI v18):
  *   agf_map_layer_fwd:  y[b,o] = lrelu( alpha * sum_k x[b,k] W[o,k] + beta * bias[o] )        (alpha = coef * lr, beta = lr; bias nullable)

@@ -195,30 +195,76 @@ def test_the_pipe_issues_no_host_synchronisation():
 
 
 @pytest.mark.gpu
-def test_plan_then_apply_equals_the_one_call_forward_and_plan_many_batches_the_calls():
+@pytest.mark.parametrize('fused', [True, False])
+def test_plan_then_apply_equals_the_one_call_forward_and_plan_many_batches_the_calls(fused):
     """``AugmentPipe.forward(x)`` = ``apply(x, plan(shape))`` with the same random draws (the split exists so that a trainer can issue the
     decisions ahead of time, beside the networks' kernels); ``plan_many(k, ...)`` builds the matrices of k calls as one batch of k * B samples:
-    the same draws as ONE call on a k * B batch, cut into per-call plans whose reflect margins are each call's own maximum."""
+    the same draws as ONE call on a k * B batch, cut into per-call plans whose reflect margins are each call's own maximum.  Both ways of
+    making the decisions: the one-launch ``agf_ada_plan`` and the reference's chain of small tensor ops."""
     from animeface_amd.nnutils.ada import ADA
+    from animeface_amd.thirdparty import ada as A
     dev = torch.device('cuda')
     B, k = 6, 3
     pipe = ADA(B).to(dev)
     pipe.p.fill_(0.7)
     x = (torch.rand(B, 3, 32, 32, device=dev) * 2 - 1)
-    torch.manual_seed(11)
-    y_one = pipe(x)
-    torch.manual_seed(11)
-    y_split = pipe.apply(x, pipe.plan(x.shape, x.dtype, dev))
-    assert torch.equal(y_one, y_split)
-    # plan_many: the matrices equal those of one call on the k * B batch
+    old = A.FUSED_PLAN
+    A.FUSED_PLAN = fused
+    try:
+        torch.manual_seed(11)
+        y_one = pipe(x)
+        torch.manual_seed(11)
+        y_split = pipe.apply(x, pipe.plan(x.shape, x.dtype, dev))
+        assert torch.equal(y_one, y_split)
+        torch.manual_seed(12)
+        plans = pipe.plan_many(k, (B, 3, 32, 32), x.dtype, dev)
+    finally:
+        A.FUSED_PLAN = old
+    # plan_many: the matrices equal those of one call on the k * B batch (the chain of tensor ops is the yardstick for both)
     torch.manual_seed(12)
     Gk, Mk = pipe._plan_matrices((k * B, 3, 32, 32), dev)
-    torch.manual_seed(12)
-    plans = pipe.plan_many(k, (B, 3, 32, 32), x.dtype, dev)
     assert len(plans) == k
     for i, pl in enumerate(plans):
-        assert torch.equal(pl['M'], Mk[i * B:(i + 1) * B])
         ref = pipe._plan_finish(Gk[i * B:(i + 1) * B], Mk[i * B:(i + 1) * B], (B, 3, 32, 32), x.dtype, dev)
-        assert torch.equal(pl['warp']['theta'], ref['warp']['theta']) and torch.equal(pl['warp']['margins'], ref['warp']['margins'])
+        if fused:
+            torch.testing.assert_close(pl['M'], Mk[i * B:(i + 1) * B], rtol=1e-5, atol=1e-6)
+            torch.testing.assert_close(pl['M3'], ref['M3'], rtol=1e-5, atol=1e-6)
+            torch.testing.assert_close(pl['warp']['theta'], ref['warp']['theta'], rtol=1e-5, atol=2e-6)
+        else:
+            assert torch.equal(pl['M'], Mk[i * B:(i + 1) * B]) and torch.equal(pl['warp']['theta'], ref['warp']['theta'])
+        assert torch.equal(pl['warp']['margins'], ref['warp']['margins'])
         out = pipe.apply(x, pl)
         assert out.shape == x.shape and torch.isfinite(out).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kw,C,pv', [(FULL, 3, 1.0), (FULL, 3, 0.35), (FULL, 1, 0.8), (dict(xflip=1, xint=1, rotate=1), 3, 0.9),
+                                     (dict(brightness=1, saturation=1, lumaflip=1), 3, 1.0), (dict(scale=1, aniso=1, xfrac=1, hue=1), 3, 0.6)])
+def test_one_launch_plan_equals_the_chain_of_tensor_ops(kw, C, pv):
+    """agf_ada_plan against the reference's own sequence of batched 3x3 / 4x4 products (``_plan_matrices`` + ``_warp_plan``, which the
+    golden fixtures of this file pin to thirdparty/ada/augment.py:188-347) on the same random draws: stage subsets, grey-scale images
+    (no hue / saturation draws), a ragged image, several calls, more samples than one workgroup pass."""
+    from animeface_amd.thirdparty import ada as A
+    dev = torch.device('cuda')
+    pipe = A.AugmentPipe(**kw).to(dev)
+    pipe.p.fill_(pv)
+    for B, H, W, calls in [(5, 24, 40, 2), (300, 16, 16, 1)]:
+        shape = (B, C, H, W)
+        assert pipe._fused_plan_covers(shape, torch.float32, dev)
+        torch.manual_seed(21)
+        plans = pipe._plan_fused(calls, shape, torch.float32, dev)
+        torch.manual_seed(21)
+        Gk, Mk = pipe._plan_matrices((calls * B, C, H, W), dev)
+        for i, pl in enumerate(plans):
+            cut = slice(i * B, (i + 1) * B)
+            ref = pipe._plan_finish(None if Gk is None else Gk[cut], None if Mk is None else Mk[cut], shape, torch.float32, dev)
+            if Mk is None:
+                assert pl['M'] is None and pl['M3'] is None
+            else:
+                torch.testing.assert_close(pl['M'], Mk[cut], rtol=1e-5, atol=1e-6)
+            if Gk is None:
+                assert pl['warp'] is None
+            else:
+                assert ref['warp']['kind'] == 'device'
+                assert torch.equal(pl['warp']['margins'], ref['warp']['margins'])
+                torch.testing.assert_close(pl['warp']['theta'], ref['warp']['theta'], rtol=1e-5, atol=2e-6)

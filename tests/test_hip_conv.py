@@ -236,6 +236,19 @@ def test_epilogue_backward_kernels_vs_torch(shape, dtype):
     assert rel(A, (gref * y0).sum((2, 3))) < 2e-3 and rel(B, gref.sum((2, 3))) < 2e-3 and rel(Cn, (gref * nz).sum((2, 3))) < 2e-3
     _, (A2, B2, C2) = act_bwd_reduce_raw(dy, y, None, alpha, (False, True, False))
     assert A2 is None and C2 is None and rel(B2, gref.sum((2, 3))) < 2e-3
+    # g_scale: the stored tensor is g * g_scale[n, c], the sums stay those of g (the gradient of a modulated layer, stored times its
+    # demodulation scale for the data- / weight-gradient launches)
+    gsc = (torch.rand(N, C, generator=g0) * 2 - 0.5).to(DEV)
+    g3, (A3, B3, C3) = act_bwd_reduce_raw(dy, y, nz, alpha, (True, True, True), g_scale=gsc)
+    assert rel(g3, gref * gsc[:, :, None, None]) < tol
+    assert rel(A3, A) < 1e-5 and rel(B3, B) < 1e-5 and rel(C3, Cn) < 1e-5
+    from animeface_amd.implementations.StyleGAN2.conv import act_bwd_reduce_scaled_raw
+    ts = (torch.rand(N, C, generator=g0) + 0.5).to(DEV)
+    for gs_ in (None, gsc):
+        g4, (A4, B4, C4), ds4 = act_bwd_reduce_scaled_raw(dy, y, nz, ts, alpha, g_scale=gs_)
+        g4ref = dyf * ts[:, :, None, None] * torch.where(yf > 0, 1.0, alpha)
+        assert rel(g4, g4ref * (1.0 if gs_ is None else gs_[:, :, None, None])) < tol
+        assert rel(ds4, (yf * dyf).sum((2, 3))) < 2e-3 and rel(B4, g4ref.sum((2, 3))) < 2e-3 and rel(A4, (g4ref * y0).sum((2, 3))) < 2e-3
     s = (torch.rand(N, C, generator=g0) + 0.5).to(DEV)
     dx, ds = scale_dot_raw(y, dy, s)
     assert rel(dx, dyf * s[:, :, None, None]) < tol and rel(ds, (yf * dyf).sum((2, 3))) < 2e-3
@@ -336,6 +349,37 @@ def test_dblock_linked_backward_matches_unlinked(monkeypatch):
         assert rel(a, b) < 2e-2, (a.shape, rel(a, b))
 
 
+@pytest.mark.gpu
+def test_generator_block_with_prescaled_gradients_matches_the_operand_scaled_launches(monkeypatch):
+    """conv.PRESCALE_G: the gradient tensor of a modulated layer is stored times its demodulation scale by the pass that produces it
+    (agf_act_bwd_reduce / agf_act_bwd_reduce_scaled, g_scale) and the data- / weight-gradient launches then run without that operand
+    scale -- against the same generator with the scale applied inside those launches (bf16: one rounding of g * d instead of two)."""
+    from animeface_amd.implementations.StyleGAN2 import model as M, conv as C
+    import functools
+    torch.manual_seed(3)
+    G = M.Generator(32, 3, 64, 32, 128, 2, 2, True, 0.01, compute_dtype=torch.bfloat16).to(DEV)
+    G.init_weight(functools.partial(M.init_weight_N01, lr=0.01), M.init_weight_N01)
+    z = torch.randn(4, 64, device=DEV)
+    gy = torch.randn(4, 3, 32, 32, device=DEV)
+    outs = []
+    for on in (True, False):
+        monkeypatch.setattr(C, 'PRESCALE_G', on)
+        torch.manual_seed(77)                               # the same noise draws in both passes
+        img, _ = G(z)
+        params = [p for p in G.parameters() if p.requires_grad]
+        grads = torch.autograd.grad(img, params, gy, allow_unused=True)
+        outs.append((img, grads))
+    assert rel(outs[0][0], outs[1][0]) == 0
+    n = 0
+    for a, b in zip(outs[0][1], outs[1][1]):
+        if a is None:
+            assert b is None
+            continue
+        assert rel(a, b) < 3e-2, (a.shape, rel(a, b))
+        n += 1
+    assert n > 20
+
+
 @pytest.mark.parametrize('seed', range(10))
 def test_conv_wgrad_random_shapes_vs_aten(seed):
     """Random map sizes / channel counts / scales through whichever weight-gradient kernel the launcher picks (ring with whole or ragged
@@ -350,9 +394,13 @@ def test_conv_wgrad_random_shapes_vs_aten(seed):
     dy = torch.randn(N, Cout, H, W, generator=rs).to(torch.bfloat16).to(DEV).contiguous(memory_format=torch.channels_last)
     s_in = (torch.rand(N, Cin, generator=rs) + 0.5).to(DEV) if scaled else None
     s_out = (torch.rand(N, Cout, generator=rs) + 0.5).to(DEV) if scaled else None
+    if seed in (3, 7):
+        s_out = None            # one operand scale only: the gradient arrives already times the demodulation scale (conv.PRESCALE_G)
+    if seed == 5:
+        s_in = None
     dw = conv2d_wgrad_raw(x, dy, 3, in_scale=s_in, out_scale=s_out, scale=1.5)
-    xf = x.float() * (s_in[:, :, None, None] if scaled else 1.0)
-    dyf = dy.float() * (s_out[:, :, None, None] if scaled else 1.0)
+    xf = x.float() * (s_in[:, :, None, None] if s_in is not None else 1.0)
+    dyf = dy.float() * (s_out[:, :, None, None] if s_out is not None else 1.0)
     wz = torch.zeros(Cout, Cin, 3, 3, device=DEV, requires_grad=True)
     (ref,) = torch.autograd.grad(F.conv2d(xf, wz, padding=1), wz, dyf)
     assert rel(dw, ref * 1.5) < (8e-3 if scaled else 1e-3), (N, Cin, Cout, H, W, scaled, rel(dw, ref * 1.5))

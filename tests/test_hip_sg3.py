@@ -192,6 +192,69 @@ def test_bf16_training_steps_run_and_stay_finite():
         assert torch.isfinite(p).all()
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['fp32', 'bf16'])
+def test_graph_replayed_step_equals_the_eager_step(dtype):
+    """StyleGAN3's GraphedTrainStep (one HIP graph per iteration kind: adversarial loss only / with the R1 penalty of every gp_every-th
+    iteration) against the eager TrainStep from the same seeds: same kernels in the same order with torch's graph-safe random offsets, so
+    the losses agree to summation noise (fp32) / bf16 resolution, the buffers the step advances in place (w_avg, the layers' magnitude
+    EMAs) move in both, and nothing non-finite appears.  Also: train(graphs=True) consumes no iteration for the recording."""
+    from animeface_amd.implementations.StyleGAN3 import utils as U
+    from animeface_amd.nnutils import update_ema, freeze
+    from animeface_amd.thirdparty.diffaugment import DiffAugment
+
+    def run(graphed, iters=7):
+        torch.manual_seed(5)
+        M, G, D = build(dtype)
+        _, G_ema, _ = build(dtype)
+        freeze(G_ema)
+        update_ema(G, G_ema, 0., copy_buffers=True)
+        oG, oD = U.build_optimizers(G, D, 0.0025, 0.01, (0., 0.99), capturable=True)
+        step = U.TrainStep(G, G_ema, D, oG, oD, 3., 3, functools.partial(DiffAugment, policy='color,translation'), CFG['latent_dim'])
+        gen = torch.Generator().manual_seed(9)
+        real = (torch.rand(8, 3, 32, 32, generator=gen) * 2 - 1).to(DEV)
+        torch.manual_seed(123)
+        for _ in range(2):                                   # eager in both arms (iteration 0 carries the R1 penalty)
+            step(real)
+        runner = U.GraphedTrainStep(step, real, warmup=0) if graphed else step
+        if graphed:
+            runner.capture_all()
+            assert runner.kinds() == {'gan', 'r1'}
+        losses = []
+        for _ in range(iters):                               # gp_every = 3: iterations 3 and 6 replay the R1 graph
+            dl, gl, fake = runner(real)
+            losses.append((float(dl), float(gl)))
+            assert torch.isfinite(fake).all()
+        assert step.batches_done == 2 + iters
+        return losses, {k: v.detach().float().clone() for k, v in list(G.state_dict().items()) + [('D.' + k, v) for k, v in D.state_dict().items()]}
+
+    le, we = run(False)
+    lg, wg = run(True)
+    tol = 2e-3 if dtype == torch.float32 else 5e-2
+    for (d0, g0), (d1, g1) in zip(le, lg):
+        assert d0 == pytest.approx(d1, rel=tol, abs=tol) and g0 == pytest.approx(g1, rel=tol, abs=tol), (le, lg)
+    far = total = 0
+    for k in we:
+        assert torch.isfinite(wg[k]).all(), k
+        d = (we[k] - wg[k]).abs()
+        far += int((d > (1e-3 if dtype == torch.float32 else 2e-2)).sum())
+        total += d.numel()
+    # (Adam with beta1 = 0 moves a weight whose gradient changes sign near zero by a few lr: the bound is on how many differ)
+    assert far <= (0.002 if dtype == torch.float32 else 0.05) * total, (far, total)
+    assert not torch.equal(we['map.w_avg'], torch.zeros_like(we['map.w_avg'])) and torch.allclose(we['map.w_avg'], wg['map.w_avg'], atol=1e-3)
+
+    # train(graphs=True): 2 eager iterations, then replays; every iteration is logged, none is consumed by the recording
+    torch.manual_seed(5)
+    M, G, D = build(dtype)
+    _, G_ema, _ = build(dtype)
+    freeze(G_ema)
+    update_ema(G, G_ema, 0., copy_buffers=True)
+    oG, oD = U.build_optimizers(G, D, 0.0025, 0.01, (0., 0.99), capturable=True)
+    real = torch.rand(8, 3, 32, 32, device=DEV) * 2 - 1
+    hist = U.train(6, [real], CFG['latent_dim'], torch.randn(2, CFG['latent_dim'], device=DEV), G, G_ema, D, oG, oD, 3., 3,
+                   functools.partial(DiffAugment, policy='color,translation'), torch.device(DEV), dtype == torch.bfloat16, log_every=1, log=None, graphs=True)
+    assert [h[0] for h in hist] == list(range(6)) and all(np.isfinite(h[1]) and np.isfinite(h[2]) for h in hist)
+
+
 def test_hip_model_vs_cpu_oracle_on_a_second_configuration():
     """A configuration / seed the fixtures do not contain: HIP fp32 networks against the CPU oracle (oracle/stylegan3.py, itself
     pinned to the reference by tests/test_oracle_sg3.py) on the same state_dict."""

@@ -22,6 +22,7 @@ ap.add_argument('--image-size', type=int, default=256)
 ap.add_argument('--steps', type=int, default=8)
 ap.add_argument('--warmup', type=int, default=2)
 ap.add_argument('--fp32', action='store_true')
+ap.add_argument('--eager', action='store_true', help='launch every kernel from the host instead of replaying the recorded iteration (HIP graphs)')
 a = ap.parse_args()
 dev = torch.device('cuda')
 dt = torch.float32 if a.fp32 else torch.bfloat16
@@ -32,12 +33,18 @@ freeze(G_ema)
 update_ema(G, G_ema, 0., copy_buffers=True)
 D = M.Discriminator(a.image_size, 3, 32, 512, compute_dtype=dt).to(dev)
 print('params G %d D %d' % (sum(p.numel() for p in G.parameters()), sum(p.numel() for p in D.parameters())))
-opt_G, opt_D = U.build_optimizers(G, D, 0.0025, 0.01, (0., 0.99))
+opt_G, opt_D = U.build_optimizers(G, D, 0.0025, 0.01, (0., 0.99), capturable=not a.eager)
 step = U.TrainStep(G, G_ema, D, opt_G, opt_D, 3., 16, functools.partial(DiffAugment, policy='color,translation'), 512)
 real = torch.rand(a.batch, 3, a.image_size, a.image_size, device=dev) * 2 - 1
 for _ in range(a.warmup):
     step(real)
+if not a.eager:
+    step = U.GraphedTrainStep(step, real, warmup=0)
+    step.capture_all()
+    for _ in range(2):                                                  # (first replays: the graphs are uploaded)
+        step(real)
 torch.cuda.synchronize()
+it0 = step.batches_done
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import SmiSampler                                            # noqa: E402  (one rocm-smi reading while the timed loop runs)
 smi = SmiSampler(delay=0.5)
@@ -47,9 +54,11 @@ for _ in range(a.steps):
 torch.cuda.synchronize()
 dtm = (time.time() - t0) / a.steps
 print('clocks', smi.result())
-print('sg3 %s batch %d: %.1f ms/iter, %.1f img/s' % ('fp32' if a.fp32 else 'bf16', a.batch, dtm * 1e3, a.batch / dtm))
+r1 = sum(1 for it in range(it0, it0 + a.steps) if it % 16 == 0)
+print('sg3 %s batch %d (%s, %d of the %d timed iterations carry the R1 penalty): %.1f ms/iter, %.1f img/s' %
+      ('fp32' if a.fp32 else 'bf16', a.batch, 'eager' if a.eager else 'HIP-graph replay', r1, a.steps, dtm * 1e3, a.batch / dtm))
 import json
 print(json.dumps({'metric': f'images/sec (G+D+R1 step) StyleGAN3-T {a.image_size}x{a.image_size} ' + ('fp32' if a.fp32 else 'bf16'), 'value': round(a.batch / dtm, 2),
                   'unit': 'img/s', 'n_gpus': 1, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dtm * 1e3, 2), 'dtype': 'fp32' if a.fp32 else 'bf16',
-                  'data': 'synthetic', 'config': {'workload': f'StyleGAN3-T {a.image_size}x{a.image_size} (14 layers, channels 32, kernel 3), batch {a.batch}, '
+                  'data': 'synthetic', 'mode': 'eager' if a.eager else 'hip-graph replay', 'r1_iterations_in_window': r1, 'config': {'workload': f'StyleGAN3-T {a.image_size}x{a.image_size} (14 layers, channels 32, kernel 3), batch {a.batch}, '
                                                            'gp_every 16 (reference implementations/StyleGAN3/utils.py defaults), DiffAugment color,translation'}}))
