@@ -108,7 +108,9 @@ template <class T> struct RawVec<T, 8> {
 };
 
 // BMODE: 0 no bias, 1 channels-last (VEC consecutive channels per access), 2 one channel per access (NCHW, H*W % VEC == 0), 3 per element
-template <class T, int VEC, int A, int U, int BMODE, bool NT>
+// REFS: any of xref / yref / dy present (the gradient passes); the forward instantiation carries no registers for them (134 -> ~50 VGPRs:
+// three waves per SIMD are too few for a streaming pass)
+template <class T, int VEC, int A, int U, int BMODE, bool NT, bool REFS>
 __global__ void __launch_bounds__(256) bias_act_vec(BiasActParams p, uint32_t nvec, uint32_t bstep) {
     const uint32_t v0 = blockIdx.x * (256u * U) + threadIdx.x;         // a block owns U * 256 consecutive vectors
     const uint32_t sizeB = (uint32_t)p.sizeB, stepB = (uint32_t)p.stepB;
@@ -118,20 +120,20 @@ __global__ void __launch_bounds__(256) bias_act_vec(BiasActParams p, uint32_t nv
     const u32x4* pyr = (const u32x4*)p.yref;
     const u32x4* pdy = (const u32x4*)p.dy;
     auto ld = [](const u32x4* q) { return NT ? __builtin_nontemporal_load(q) : *q; };
-    u32x4 rx[U], rxr[U], ryr[U], rdy[U], rb[U];
+    u32x4 rx[U], rxr[REFS ? U : 1], ryr[REFS ? U : 1], rdy[REFS ? U : 1], rb[U];
 #pragma unroll
     for (int k = 0; k < U; k++) {
         const uint32_t v = v0 + k * 256u;
         if (v < nvec) {
             rx[k] = ld(px + v);
-            if (p.xref) rxr[k] = ld(pxr + v);
-            if (p.yref) ryr[k] = ld(pyr + v);
-            if (p.dy) rdy[k] = ld(pdy + v);
-            if (BMODE == 1) {
-                rb[k] = *(const u32x4*)((const T*)p.b + bidx);
-                bidx += bstep;
-                if (bidx >= sizeB) bidx -= sizeB;
-            }
+            if (REFS && p.xref) rxr[k] = ld(pxr + v);
+            if (REFS && p.yref) ryr[k] = ld(pyr + v);
+            if (REFS && p.dy) rdy[k] = ld(pdy + v);
+        }
+        if (BMODE == 1) {                                             // (the index is valid for every k: no bounds condition)
+            rb[k] = *(const u32x4*)((const T*)p.b + bidx);
+            bidx += bstep;
+            bidx = bidx >= sizeB ? bidx - sizeB : bidx;
         }
     }
 #pragma unroll
@@ -140,9 +142,9 @@ __global__ void __launch_bounds__(256) bias_act_vec(BiasActParams p, uint32_t nv
         if (v >= nvec) break;
         float x[VEC], xr[VEC], yr[VEC], dy[VEC], b[VEC], y[VEC];
         RawVec<T, VEC>::unpack(rx[k], x);
-        if (p.xref) RawVec<T, VEC>::unpack(rxr[k], xr);
-        if (p.yref) RawVec<T, VEC>::unpack(ryr[k], yr);
-        if (p.dy) RawVec<T, VEC>::unpack(rdy[k], dy);
+        if (REFS && p.xref) RawVec<T, VEC>::unpack(rxr[k], xr);
+        if (REFS && p.yref) RawVec<T, VEC>::unpack(ryr[k], yr);
+        if (REFS && p.dy) RawVec<T, VEC>::unpack(rdy[k], dy);
         if (BMODE == 1) RawVec<T, VEC>::unpack(rb[k], b);
         if (BMODE == 2) {
             const float bv = (float)Elem<T>::load((const T*)p.b + ((v * VEC) / stepB) % sizeB);
@@ -155,7 +157,7 @@ __global__ void __launch_bounds__(256) bias_act_vec(BiasActParams p, uint32_t nv
         }
 #pragma unroll
         for (int e = 0; e < VEC; e++) {
-            float xx = x[e], xref = p.xref ? xr[e] : 0.f, yref = p.yref ? yr[e] : 0.f, d = p.dy ? dy[e] : 1.f;
+            float xx = x[e], xref = (REFS && p.xref) ? xr[e] : 0.f, yref = (REFS && p.yref) ? yr[e] : 0.f, d = (REFS && p.dy) ? dy[e] : 1.f;
             const float bb = BMODE ? b[e] : 0.f;
             if (p.grad == 0) xx += bb; else xref += bb;
             y[e] = act_eval<float, A>(xx, xref, yref, d, p.grad, p.alpha, p.gain, p.clamp);
@@ -176,13 +178,15 @@ static void launch_act(const BiasActParams& p, hipStream_t st) {
         if (al(p.x) && al(p.y) && al(p.xref) && al(p.yref) && al(p.dy) && al(p.b)) {
             int64_t nvec = p.sizeX / VEC;
             if (nvec > 0) {
-                constexpr int U = 4;
-                const dim3 grid((unsigned)agf_ceil_div(nvec, 256 * U)), block(256);
+                const bool refs = p.xref || p.yref || p.dy;
+                constexpr int U = 4, UR = 2;
+                const dim3 grid((unsigned)agf_ceil_div(nvec, 256 * (refs ? UR : U))), block(256);
                 const uint32_t n = (uint32_t)nvec;
                 const int mode = !p.b ? 0 : (p.stepB == 1 && p.sizeB % VEC == 0) ? 1 : (p.stepB % VEC == 0) ? 2 : 3;
                 const uint32_t bstep = mode == 1 ? (uint32_t)((256u * VEC) % (uint32_t)p.sizeB) : 0u;
                 const bool nt = nvec * 16 > (int64_t)(64 << 20);     // x and y together exceed half of the last-level cache
-#define BA_LAUNCH(M, NTV) hipLaunchKernelGGL((bias_act_vec<T, VEC, A, U, M, NTV>), grid, block, 0, st, p, n, bstep)
+#define BA_LAUNCH(M, NTV) do { if (refs) hipLaunchKernelGGL((bias_act_vec<T, VEC, A, UR, M, false, true>), grid, block, 0, st, p, n, bstep); \
+                               else hipLaunchKernelGGL((bias_act_vec<T, VEC, A, U, M, NTV, false>), grid, block, 0, st, p, n, bstep); } while (0)
                 switch (mode) {
                     case 0: if (nt) BA_LAUNCH(0, true); else BA_LAUNCH(0, false); break;
                     case 1: if (nt) BA_LAUNCH(1, true); else BA_LAUNCH(1, false); break;

@@ -87,6 +87,10 @@ static __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16
                 }
 #pragma unroll
                 for (int e = 0; e < 4; e++) v[e] *= p.gain;
+                if (p.post_scale) {
+                    f32x4 s = *(const f32x4*)(p.post_scale + (int64_t)n * p.Cout + co);
+                    v[0] *= s.x; v[1] *= s.y; v[2] *= s.z; v[3] *= s.w;
+                }
                 u32x2 o;
                 o.x = Pack16<bf16_t>::pack(v[0], v[1]);
                 o.y = Pack16<bf16_t>::pack(v[2], v[3]);
@@ -267,6 +271,10 @@ static __device__ __forceinline__ void conv_epilogue_pl(const ConvParams& p, f32
                         }
 #pragma unroll
                         for (int e = 0; e < 4; e++) v[e] *= p.gain;
+                        if (p.post_scale) {
+                            const f32x4 s = *(const f32x4*)(p.post_scale + (int64_t)n * p.Cout + co);
+                            v[0] *= s.x; v[1] *= s.y; v[2] *= s.z; v[3] *= s.w;
+                        }
                     }
                     P[r2][0] = Pack16<bf16_t>::pack(v[0], v[1]);
                     P[r2][1] = Pack16<bf16_t>::pack(v[2], v[3]);
@@ -1649,7 +1657,7 @@ static int launch_fwd(const ConvParams& p, hipStream_t st) {
         else              rc = p.in_scale ? launch_fwd_ws<1, true, 32, 64>(p, st) : launch_fwd_ws<1, false, 32, 64>(p, st);
         if (rc != AGF_ENOKERNEL) return rc;
     }
-    if (g_ws_enable && KS == 3 && MT == 1 && p.pixTiles >= 2048 && p.TW == 32 && p.TH == 8 && p.TI == 1 &&
+    if (g_ws_enable && !p.post_scale && KS == 3 && MT == 1 && p.pixTiles >= 2048 && p.TW == 32 && p.TH == 8 && p.TI == 1 &&
         (p.Cin <= 32 || (p.Cin <= 64 && p.Cout <= 32) || (g_ws_enable >= 2 && p.Cin <= 64 && p.Cout <= 64))) {
         int rc;
         constexpr int ws2 = 1;
@@ -1685,12 +1693,17 @@ static int conv2d_fwd_impl(const void* x, const void* w, void* y,
                            const float* noise, const void* residual,
                            int dtype, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
                            int act, float alpha, float act_gain,
-                           const void* mask_y, float mask_alpha, float* mask_sum, const void* res_pooled, float res_scale, void* stream) {
+                           const void* mask_y, float mask_alpha, float* mask_sum, const void* res_pooled, float res_scale, void* stream,
+                           const float* post_scale = nullptr) {
     AGF_CHECK(x && w && y, "conv2d_fwd: null pointer");
     AGF_CHECK(dtype == AGF_BF16 || dtype == AGF_F32, "conv2d_fwd: dtype must be bf16 or f32");
     if ((mask_y || res_pooled) && (dtype != AGF_BF16 || (Cout % 8) != 0 || ((uintptr_t)y % 16) != 0 || ((uintptr_t)mask_y % 16) != 0 ||
                                    ((uintptr_t)res_pooled % 16) != 0 || (res_pooled && (act != 1 || (H & 1) || (W & 1))))) {
         agf_set_error("conv2d_fwd_mask: needs bf16, Cout %% 8 == 0, 16-byte aligned tensors (and a linear epilogue on an even map for res_pooled)");
+        return AGF_ENOKERNEL;
+    }
+    if (post_scale && (dtype != AGF_BF16 || ksize != 3 || Cout < 64 || mask_y || res_pooled)) {
+        agf_set_error("conv2d_fwd: post_scale is served by the bf16 3x3 kernels with >= 64 output channels only");
         return AGF_ENOKERNEL;
     }
     if (dtype == AGF_F32) {
@@ -1722,6 +1735,7 @@ static int conv2d_fwd_impl(const void* x, const void* w, void* y,
     p.act = act; p.alpha = alpha; p.gain = act_gain;
     p.mask_y = (const bf16_t*)mask_y; p.mask_alpha = mask_alpha; p.mask_sum = mask_sum;
     p.res_pooled = (const bf16_t*)res_pooled; p.res_scale = res_scale;
+    p.post_scale = post_scale;
     {
         // 1x1 conv from 8 input channels to <= 32 outputs on a large map: the streaming kernel (see conv2d_pw8_kernel)
         constexpr bool pw8 = true;
@@ -1740,7 +1754,7 @@ static int conv2d_fwd_impl(const void* x, const void* w, void* y,
     p.xcdBand = 0;
     { constexpr int vs = 2;     // 2: register-only (permlane32), 1: through LDS, 0: direct
       p.vecStore = ((vs || mask_y || res_pooled) && (Cout % 8) == 0 && ((uintptr_t)y % 16) == 0) ? (vs == 2 ? 2 : 1) : 0; }
-    if (ksize == 3) {
+    if (ksize == 3 && !post_scale) {
         // high-resolution, few-channel layers: the persistent multi-stage kernel (agf_conv2d_pipe.hip)
         const int rc = agf_conv2d_pipe_launch(p, (hipStream_t)stream);
         if (rc == AGF_OK) { AGF_LAUNCH_CHECK(); return AGF_OK; }
@@ -1823,6 +1837,16 @@ extern "C" int agf_conv2d_fwd(const void* x, const void* w, void* y,
                               int act, float alpha, float act_gain, void* stream) {
     return conv2d_fwd_impl(x, w, y, in_scale, out_scale, bias, noise, residual, dtype, N, H, W, Cin, Cout, ksize, act, alpha, act_gain,
                            nullptr, 0.f, nullptr, nullptr, 0.f, stream);
+}
+
+extern "C" int agf_conv2d_fwd_post(const void* x, const void* w, void* y,
+                                   const float* in_scale, const float* out_scale, const float* bias,
+                                   const float* noise, const void* residual, const float* post_scale,
+                                   int dtype, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
+                                   int act, float alpha, float act_gain, void* stream) {
+    AGF_CHECK(post_scale, "conv2d_fwd_post: null post_scale");
+    return conv2d_fwd_impl(x, w, y, in_scale, out_scale, bias, noise, residual, dtype, N, H, W, Cin, Cout, ksize, act, alpha, act_gain,
+                           nullptr, 0.f, nullptr, nullptr, 0.f, stream, post_scale);
 }
 
 extern "C" int agf_conv2d_fwd_mask(const void* x, const void* w, void* y,

@@ -37,6 +37,8 @@ struct ConvParams {
     const float* bias;        // [Cout] or null
     const float* noise;       // [N,H,W] or null
     const bf16_t* residual;   // [N,H,W,Cout] or null
+    const float* post_scale;  // [N,Cout] or null: the stored output is act(...) * gain * post_scale[n,co] -- the style scale of the NEXT modulated conv,
+                              //   this layer's only consumer, which then takes its input unscaled (conv_epilogue / conv_epilogue_pl only)
     int N, H, W, Cin, Cout;
     int TI, TH, TW;           // pixel tile
     int tilesW, tilesH, tilesN, tilesCo, pixTiles;

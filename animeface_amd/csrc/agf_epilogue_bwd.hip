@@ -23,6 +23,7 @@ struct ActBwdParams {
     const uint32_t* mask;     // or null: 1 bit per element instead of y: one 32-bit word per (2x2 cell, 8-channel group), byte (h&1)*2 + (w&1), bit k = y[8 g + k] > 0 (agf_pool2x2)
     const float* dscale;      // [N,C] or null: the incoming gradient is dy * dscale[n,c] (agf_act_bwd_reduce_scaled: dy = the data gradient t of
     float* sumD;              //   the consumer's modulated conv, dscale = its style scale s); sumD[n,c] += sum_p y * dy  (= that conv's d s)
+    int ypre;                 // SCALED only: y holds y * dscale[n,c] (agf_conv2d_fwd_post): divided out on load
     const float* gscale;      // [N,C] or null: the STORED gradient is g * gscale[n,c] (the sums are of g itself).  g of a modulated layer is read only
                               //   by that layer's data- and weight-gradient launches, both of which want g * d (d = its demodulation scale): with the
                               //   product stored once here they run without an operand scale (the MFMA kernels' unscaled, direct-to-LDS variants)
@@ -42,9 +43,13 @@ __global__ void __launch_bounds__(256) act_bwd_reduce_kernel(ActBwdParams p) {
     float a[VEC], b[VEC], c[VEC], d[SCALED ? VEC : 1], sc[SCALED ? VEC : 1], gs[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; i++) { a[i] = b[i] = c[i] = 0.f; gs[i] = p.gscale ? p.gscale[(int64_t)blockIdx.y * p.C + (tid % p.CG) * VEC + i] : 1.f; }
+    float yinv[SCALED ? VEC : 1];
     if (SCALED) {
 #pragma unroll
-        for (int i = 0; i < VEC; i++) { d[i] = 0.f; sc[i] = p.dscale[(int64_t)n * p.C + cg * VEC + i]; }
+        for (int i = 0; i < VEC; i++) {
+            d[i] = 0.f; sc[i] = p.dscale[(int64_t)n * p.C + cg * VEC + i];
+            yinv[i] = !p.ypre ? 1.f : sc[i] != 0.f ? 1.f / sc[i] : 0.f;
+        }
     }
     const bool active = pl < p.pixLanes;
     if (active) {
@@ -74,6 +79,10 @@ __global__ void __launch_bounds__(256) act_bwd_reduce_kernel(ActBwdParams p) {
                     for (int i = 0; i < VEC; i++) y[u][i] = ((m >> i) & 1u) ? 1.f : -1.f;
                 } else {
                     VecIO<T, VEC>::load((const T*)p.y + base + (int64_t)px * p.C, y[u]);
+                }
+                if (SCALED) {
+#pragma unroll
+                    for (int i = 0; i < VEC; i++) y[u][i] *= yinv[i];
                 }
                 nzv[u] = p.noise ? p.noise[(int64_t)n * p.HW + px] : 0.f;
             }
@@ -193,7 +202,8 @@ static int plan(int C, int vec, int HW, int N, int* CG, int* pixLanes, int* pixP
 static int act_bwd_reduce_impl(const void* dy, const void* y, const float* noise, void* g,
                                float* sum_gy0, float* sum_g, float* sum_gnoise,
                                int dtype, int32_t N, int32_t H, int32_t W, int32_t C, float alpha, int pooled, float dy_scale, void* stream,
-                               const float* dscale = nullptr, float* sum_ydy = nullptr, const uint32_t* mask = nullptr, const float* gscale = nullptr) {
+                               const float* dscale = nullptr, float* sum_ydy = nullptr, const uint32_t* mask = nullptr, const float* gscale = nullptr,
+                               int ypre = 0) {
     AGF_CHECK(dy && (y || mask) && g, "act_bwd_reduce: null pointer");
     AGF_CHECK(dtype == AGF_BF16 || dtype == AGF_F32, "act_bwd_reduce: dtype must be bf16 or f32");
     AGF_CHECK(alpha > 0.f, "act_bwd_reduce: the leaky slope must be positive");
@@ -201,7 +211,7 @@ static int act_bwd_reduce_impl(const void* dy, const void* y, const float* noise
     ActBwdParams p;
     p.dy = dy; p.y = y; p.noise = noise; p.g = g; p.sumA = sum_gy0; p.sumB = sum_g; p.sumC = sum_gnoise;
     p.N = N; p.HW = H * W; p.C = C; p.alpha = alpha; p.inv_alpha = 1.f / alpha;
-    p.pooled = pooled; p.W = W; p.dy_scale = dy_scale; p.dscale = dscale; p.sumD = sum_ydy; p.mask = mask; p.gscale = gscale;
+    p.pooled = pooled; p.W = W; p.dy_scale = dy_scale; p.dscale = dscale; p.sumD = sum_ydy; p.mask = mask; p.gscale = gscale; p.ypre = ypre;
     const int vec = dtype == AGF_BF16 ? 8 : 4;
     if (!plan(C, vec, p.HW, N, &p.CG, &p.pixLanes, &p.pixPerBlock, &p.chunks)) {
         agf_set_error("act_bwd_reduce: C=%d is not a multiple of %d (or too wide)", C, vec);
@@ -227,10 +237,11 @@ extern "C" int agf_act_bwd_reduce(const void* dy, const void* y, const float* no
 }
 
 extern "C" int agf_act_bwd_reduce_scaled(const void* t, const void* y, const float* noise, const float* t_scale, void* g,
-                                         float* sum_gy0, float* sum_g, float* sum_gnoise, float* sum_yt, const float* g_scale,
+                                         float* sum_gy0, float* sum_g, float* sum_gnoise, float* sum_yt, const float* g_scale, int y_prescaled,
                                          int dtype, int32_t N, int32_t H, int32_t W, int32_t C, float alpha, void* stream) {
     AGF_CHECK(t_scale && sum_yt, "act_bwd_reduce_scaled: null pointer");
-    return act_bwd_reduce_impl(t, y, noise, g, sum_gy0, sum_g, sum_gnoise, dtype, N, H, W, C, alpha, 0, 1.f, stream, t_scale, sum_yt, nullptr, g_scale);
+    return act_bwd_reduce_impl(t, y, noise, g, sum_gy0, sum_g, sum_gnoise, dtype, N, H, W, C, alpha, 0, 1.f, stream, t_scale, sum_yt, nullptr, g_scale,
+                               y_prescaled);
 }
 
 extern "C" int agf_act_bwd_reduce_pooled(const void* dy_half, const void* y, void* g, float* sum_g,
@@ -252,7 +263,20 @@ extern "C" int agf_act_bwd_reduce_pooled_mask(const void* dy_half, const void* m
 // [1,1] x [1,1] box FIR of upfirdn2d with down = 2), channels-last, and optionally the 1-bit sign mask of x for the activation backward
 // (one 32-bit word per 2x2 cell and 8-channel group: byte (h&1)*2 + (w&1), bit k = x[.., 8 g + k] > 0): the one pass that reads the full-resolution activation anyway also leaves what
 // the backward pass needs of it at 1/16 of its bytes.  Thread = one 16-byte channel vector of one OUTPUT pixel: four 16-byte loads.
-template <class T, int VEC, bool MASK>
+template <class T, int VEC> struct PoolUnpack;
+template <> struct PoolUnpack<float, 4> {
+    static __device__ __forceinline__ void run(u32x4 r, float (&v)[4]) {
+        v[0] = __uint_as_float(r.x); v[1] = __uint_as_float(r.y); v[2] = __uint_as_float(r.z); v[3] = __uint_as_float(r.w);
+    }
+};
+template <class T> struct PoolUnpack<T, 8> {
+    static __device__ __forceinline__ void run(u32x4 r, float (&v)[8]) {
+        Pack16<T>::unpack(r.x, v[0], v[1]); Pack16<T>::unpack(r.y, v[2], v[3]);
+        Pack16<T>::unpack(r.z, v[4], v[5]); Pack16<T>::unpack(r.w, v[6], v[7]);
+    }
+};
+
+template <class T, int VEC, bool MASK, bool NT = false>
 __global__ void __launch_bounds__(256) pool2x2_kernel(const T* __restrict__ x, T* __restrict__ y, uint32_t* __restrict__ mask,
                                                       int N, int Ho, int Wo, int C, float gain, int64_t total) {
     const int CG = C / VEC;
@@ -266,10 +290,17 @@ __global__ void __launch_bounds__(256) pool2x2_kernel(const T* __restrict__ x, T
         const int64_t pix = (n * (2 * Ho) + 2 * oh) * W + 2 * ow;
         const T* src = x + pix * C + cg * VEC;
         float a[VEC], b[VEC], c[VEC], d[VEC], o[VEC];
-        VecIO<T, VEC>::load(src, a);
-        VecIO<T, VEC>::load(src + C, b);
-        VecIO<T, VEC>::load(src + (int64_t)W * C, c);
-        VecIO<T, VEC>::load(src + (int64_t)W * C + C, d);
+        if (NT) {
+            // the full-resolution activation is read exactly once, here (non-temporal: +3-5 % on a streaming pass, tools/probe/stream_variants.hip)
+            const u32x4 ra = __builtin_nontemporal_load((const u32x4*)src), rb = __builtin_nontemporal_load((const u32x4*)(src + C));
+            const u32x4 rc = __builtin_nontemporal_load((const u32x4*)(src + (int64_t)W * C)), rd = __builtin_nontemporal_load((const u32x4*)(src + (int64_t)W * C + C));
+            PoolUnpack<T, VEC>::run(ra, a); PoolUnpack<T, VEC>::run(rb, b); PoolUnpack<T, VEC>::run(rc, c); PoolUnpack<T, VEC>::run(rd, d);
+        } else {
+            VecIO<T, VEC>::load(src, a);
+            VecIO<T, VEC>::load(src + C, b);
+            VecIO<T, VEC>::load(src + (int64_t)W * C, c);
+            VecIO<T, VEC>::load(src + (int64_t)W * C + C, d);
+        }
 #pragma unroll
         for (int i = 0; i < VEC; i++) o[i] = (a[i] + b[i] + c[i] + d[i]) * gain;
         VecIO<T, VEC>::store(y + ((n * Ho + oh) * Wo + ow) * C + cg * VEC, o);
@@ -297,8 +328,11 @@ extern "C" int agf_pool2x2(const void* x, void* y, void* mask, int dtype, int32_
     if (blocks > 65536) blocks = 65536;
     hipStream_t st = (hipStream_t)stream;
     const float g4 = gain * 0.25f;
+    const bool nt = total * 64 > (int64_t)(96 << 20) && ((uintptr_t)x % 16) == 0;      // the input cannot stay in the last-level cache anyway
     if (dtype == AGF_F32) hipLaunchKernelGGL((pool2x2_kernel<float, 4, false>), dim3((unsigned)blocks), dim3(256), 0, st, (const float*)x, (float*)y, nullptr, N, H / 2, W / 2, C, g4, total);
+    else if (mask && nt) hipLaunchKernelGGL((pool2x2_kernel<bf16_t, 8, true, true>), dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, (uint32_t*)mask, N, H / 2, W / 2, C, g4, total);
     else if (mask) hipLaunchKernelGGL((pool2x2_kernel<bf16_t, 8, true>), dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, (uint32_t*)mask, N, H / 2, W / 2, C, g4, total);
+    else if (nt) hipLaunchKernelGGL((pool2x2_kernel<bf16_t, 8, false, true>), dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, nullptr, N, H / 2, W / 2, C, g4, total);
     else hipLaunchKernelGGL((pool2x2_kernel<bf16_t, 8, false>), dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, nullptr, N, H / 2, W / 2, C, g4, total);
     AGF_LAUNCH_CHECK();
     return AGF_OK;

@@ -163,6 +163,9 @@ __global__ void __launch_bounds__(256) upfirdn2d_nhwc_vec(UpfirdnParams p) {
 // (NTX vectors per lane) and accumulated into every output row of the strip it contributes to, so the vector-memory
 // instruction count per output drops 2-3x versus one-output-per-lane (which is instruction-issue / wave-launch bound, not
 // HBM bound) and ROWS x fewer waves are launched.  Row validity and tap indices are block-uniform (scalar) work.
+#ifndef ROWS_WAVES
+#define ROWS_WAVES 3      // waves per SIMD the register allocation of upfirdn2d_nhwc_rows must leave room for (without a target the
+#endif                    // scheduler spends every VGPR on hoisted loads: 230-255 registers, one or two waves per SIMD)
 template <class T, int VEC> struct RawUnpack;
 template <> struct RawUnpack<float, 4> {
     static __device__ __forceinline__ void run(u32x4 r, float (&v)[4]) {
@@ -177,7 +180,7 @@ template <class T> struct RawUnpack<T, 8> {
 };
 
 template <class T, int VEC, int UP, int DN, int FW, int FH, int ROWS, int K00, int PD = 2>
-__global__ void __launch_bounds__(256) upfirdn2d_nhwc_rows(UpfirdnParams p) {
+__global__ void __launch_bounds__(256, ROWS_WAVES) upfirdn2d_nhwc_rows(UpfirdnParams p) {
     // K00 = (floor(mid0/UP)+1)*UP - mid0 - 1 for the strip's first row: identical for every strip because ROWS*DN is a
     // multiple of UP, so the host passes it as a template argument and every (input row t, output row r) tap index
     //   ky(t, r) = t*UP + K00 - r*DN        is a compile-time constant: the strip body is branch-free straight-line code.
@@ -193,11 +196,15 @@ __global__ void __launch_bounds__(256) upfirdn2d_nhwc_rows(UpfirdnParams p) {
     const int oy0 = blockIdx.y * ROWS;
     const int midx = ox * DN + UP - 1 - p.padx0;
     const int inx0 = agf_floor_div(midx, UP);
-    const int kx0 = (inx0 + 1) * UP - midx - 1;
+    // (UP == 1: the column phase is 0 for every lane -- said explicitly, the filter taps below are then wave-uniform and live in
+    //  scalar registers: 36 VGPRs less for the 6 x 6 decimation, which ran at ONE wave per SIMD with spills, 0.27 of the HBM peak)
+    const int kx0 = UP == 1 ? 0 : (inx0 + 1) * UP - midx - 1;
     const int rowC = p.W * p.C;
-    const T* xb = (const T*)p.x + (int64_t)n * p.H * rowC + cg * VEC;
+    // addresses = a block-uniform row base (scalar registers) + a 32-bit per-lane byte offset: as 64-bit per-lane pointers the fully
+    // unrolled strip hoisted one address pair per (row, column) -- ~140 VGPRs of the 6 x 6 decimation
+    const char* xbn = (const char*)p.x + (int64_t)n * p.H * rowC * (int64_t)sizeof(T);
     // per-lane column offsets, validity and filter coefficients (the lane's x phase is fixed): coef[ky][jx] in registers
-    int xo[NTX]; bool xok[NTX];
+    unsigned xo[NTX]; bool xok[NTX];
     float coef[FH][NTX];
 #pragma unroll
     for (int jx = 0; jx < NTX; jx++) {
@@ -205,7 +212,7 @@ __global__ void __launch_bounds__(256) upfirdn2d_nhwc_rows(UpfirdnParams p) {
         const int kx = kx0 + jx * UP;
         bool ok = kx < FW;
         if (p.clamp_edge) ix = min(max(ix, 0), p.W - 1); else ok = ok && ix >= 0 && ix < p.W;
-        xok[jx] = ok; xo[jx] = ix * p.C;
+        xok[jx] = ok; xo[jx] = (unsigned)(ix * p.C + cg * VEC) * (unsigned)sizeof(T);
 #pragma unroll
         for (int ky = 0; ky < FH; ky++) {
             float c = 0.f;
@@ -228,10 +235,11 @@ __global__ void __launch_bounds__(256) upfirdn2d_nhwc_rows(UpfirdnParams p) {
         int iy = iyA + t;
         bool rowok = true;
         if (p.clamp_edge) iy = min(max(iy, 0), p.H - 1); else rowok = iy >= 0 && iy < p.H;      // block-uniform
+        const char* rowp = xbn + (int64_t)iy * rowC * (int64_t)sizeof(T);                         // block-uniform
 #pragma unroll
         for (int jx = 0; jx < NTX; jx++) {
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (rowok && xok[jx]) v = *(const u32x4*)(xb + iy * rowC + xo[jx]);
+            if (rowok && xok[jx]) v = *(const u32x4*)(rowp + xo[jx]);
             dst[jx] = v;
         }
     };
@@ -241,26 +249,38 @@ __global__ void __launch_bounds__(256) upfirdn2d_nhwc_rows(UpfirdnParams p) {
     for (int t = 0; t < TMAX; t++) {
         if (t + PD - 1 < TMAX) load_row(t + PD - 1, raw[(t + PD - 1) % PD]);
         asm volatile("" ::: "memory");
-        float xv[NTX][VEC];
+        // one input vector at a time: unpacked (VEC floats live, not NTX * VEC) and added to every output row of the strip it reaches
 #pragma unroll
-        for (int jx = 0; jx < NTX; jx++) RawUnpack<T, VEC>::run(raw[t % PD][jx], xv[jx]);
+        for (int jx = 0; jx < NTX; jx++) {
+            float xv[VEC];
+            RawUnpack<T, VEC>::run(raw[t % PD][jx], xv);
 #pragma unroll
-        for (int r = 0; r < ROWS; r++) {
-            const int ky = t * UP + K00 - r * DN;                          // compile-time after unrolling
-            if (ky >= 0 && ky < FH) {
+            for (int r = 0; r < ROWS; r++) {
+                const int ky = t * UP + K00 - r * DN;                      // compile-time after unrolling
+                if (ky >= 0 && ky < FH) {
 #pragma unroll
-                for (int jx = 0; jx < NTX; jx++)
-#pragma unroll
-                    for (int i = 0; i < VEC; i++) acc[r][i] += xv[jx][i] * coef[ky][jx];
+                    for (int i = 0; i < VEC; i++) acc[r][i] += xv[i] * coef[ky][jx];
+                }
             }
         }
-        asm volatile("" ::: "memory");
+        // the accumulators are tied to the fence: without that the compiler sinks the FMAs of every row below all loads of the unrolled
+        // strip (everything live at once: 255 VGPRs, one wave per SIMD for the 6 x 6 decimation; same lesson as FLR_PIN)
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) {
+            const int kyn = (t + 1) * UP + K00 - r * DN, kyc = t * UP + K00 - r * DN;
+            // (the small up-sampling filters allocate fewer registers without the tie: 84 vs 100, 36 vs 78)
+            if ((UP == 1 || FW >= 6) && ((kyc >= 0 && kyc < FH) || (kyn >= 0 && kyn < FH))) {
+#pragma unroll
+                for (int i = 0; i < VEC; i++) asm volatile("" : "+v"(acc[r][i]) :: "memory");
+            }
+        }
     }
-    T* yb = (T*)p.y + (int64_t)n * p.OH * ((int64_t)p.OW * p.C) + ox * p.C + cg * VEC;
+    char* ybn = (char*)p.y + (int64_t)n * p.OH * ((int64_t)p.OW * p.C) * (int64_t)sizeof(T);
+    const unsigned yo = (unsigned)(ox * p.C + cg * VEC) * (unsigned)sizeof(T);
 #pragma unroll
     for (int r = 0; r < ROWS; r++) {
         const int oy = oy0 + r;
-        if (oy < p.OH) VecIO<T, VEC>::store(yb + (int64_t)oy * p.OW * p.C, acc[r]);
+        if (oy < p.OH) VecIO<T, VEC>::store((T*)(ybn + (int64_t)oy * p.OW * p.C * (int64_t)sizeof(T) + yo), acc[r]);
     }
 }
 

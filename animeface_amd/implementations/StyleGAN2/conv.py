@@ -158,8 +158,8 @@ def prep_weights_raw(w, coef, dtype, want_q=True, want_ft=False):
 
 def conv2d_fwd_raw(x, w, in_scale=None, out_scale=None, bias=None, noise=None, residual=None,
                    act=ACT_LINEAR, alpha=0.2, gain=1.0, prepared=False, mask_y=None, mask_alpha=0.2, mask_sum=None,
-                   res_pooled=None, res_scale=1.0):
-    """One ``agf_conv2d_fwd`` launch.  x: [N,Cin,H,W] bf16 channels_last; w: [Cout,Cin,k,k] (any float dtype).
+                   res_pooled=None, res_scale=1.0, post_scale=None):
+    """One ``agf_conv2d_fwd`` launch (``post_scale`` [N,Cout]: ``agf_conv2d_fwd_post``, the stored output times that scale).  x: [N,Cin,H,W] bf16 channels_last; w: [Cout,Cin,k,k] (any float dtype).
     in_scale [N,Cin], out_scale [N,Cout], bias [Cout], noise [N,1,H,W] are fp32; residual like y.  Returns y bf16 channels_last."""
     _lib.require_gpu(x, 'conv2d')
     N, Cin, H, W = x.shape
@@ -177,7 +177,12 @@ def conv2d_fwd_raw(x, w, in_scale=None, out_scale=None, bias=None, noise=None, r
     timer = KernelTimer.active
     ev0 = timer.start() if timer is not None else None
     L = _lib.lib()
-    if in_scale is not None and x.dtype == torch.bfloat16 and residual is None and mask_y is None and res_pooled is None \
+    if post_scale is not None:
+        assert mask_y is None and res_pooled is None
+        rc = L.agf_conv2d_fwd_post(_lib.ptr(x), _lib.ptr(wq), _lib.ptr(y), _lib.ptr(in_scale), _lib.ptr(out_scale),
+                                   _lib.ptr(bias), _lib.ptr(noise), _lib.ptr(residual), _lib.ptr(_f32(post_scale)), _lib.dtype_code(x),
+                                   N, H, W, Cin, Cout, k, act, float(alpha), float(gain), _lib.stream_ptr(x))
+    elif in_scale is not None and x.dtype == torch.bfloat16 and residual is None and mask_y is None and res_pooled is None \
             and L.agf_conv2d_fwd_wimg_covers(N, H, W, Cin, Cout, k):
         # few-channel high-resolution layer with a style scale: fold the scale into one weight tensor per image (a few MB) and run the
         # streaming kernel, whose activation path is a pure DMA stream (``agf_modulate_weights`` + ``agf_conv2d_fwd_wimg``)
@@ -475,6 +480,12 @@ def conv2d(x, w, s_in=None, s_out=None):
 # ---------------------------------------------------------------------------------------------------------------
 # fused epilogue:  y = lrelu( s_out * conv(x * s_in, w) + bias + noise )   in ONE launch, with a fused backward
 
+def _inv_scale(s):
+    """1 / s with 0 where s is 0 (the reciprocal of a style scale folded into a stored activation)."""
+    s = s.float()
+    return torch.where(s != 0, 1.0 / s, torch.zeros_like(s))
+
+
 def act_bwd_reduce_raw(dy, y, noise, alpha, want_sums, g_scale=None):
     """One ``agf_act_bwd_reduce`` launch: g = dy * lrelu'(y) and (optionally) the three per-(n,c) sums.  ``g_scale`` [N,C]: the returned
     tensor is g * g_scale (the sums are of g)."""
@@ -492,16 +503,17 @@ def act_bwd_reduce_raw(dy, y, noise, alpha, want_sums, g_scale=None):
     return g, sums
 
 
-def act_bwd_reduce_scaled_raw(t, y, noise, t_scale, alpha, g_scale=None):
+def act_bwd_reduce_scaled_raw(t, y, noise, t_scale, alpha, g_scale=None, y_prescaled=False):
     """One ``agf_act_bwd_reduce_scaled`` launch: g = (t * t_scale[n,c]) * lrelu'(y), the producer's three sums and the consumer's
-    ds[n,c] = sum_hw y * t.  Returns g (times ``g_scale`` [N,C] when given), (A, B, Cn), ds."""
+    ds[n,c] = sum_hw y * t.  Returns g (times ``g_scale`` [N,C] when given), (A, B, Cn), ds.  ``y_prescaled``: the tensor passed as y holds
+    y * t_scale (``POSTSCALE_X``); the kernel divides the scale out."""
     N, C, H, W = y.shape
     g = torch.empty_like(y)
     pool = _zeros_f32((4 if noise is not None else 3, N, C), y.device)
     A, B, ds = pool[0], pool[1], pool[2]
     Cn = pool[3] if noise is not None else None
     rc = _lib.lib().agf_act_bwd_reduce_scaled(_lib.ptr(t), _lib.ptr(y), _lib.ptr(_f32(noise)), _lib.ptr(_f32(t_scale)), _lib.ptr(g),
-                                              _lib.ptr(A), _lib.ptr(B), _lib.ptr(Cn), _lib.ptr(ds), _lib.ptr(_f32(g_scale)),
+                                              _lib.ptr(A), _lib.ptr(B), _lib.ptr(Cn), _lib.ptr(ds), _lib.ptr(_f32(g_scale)), int(bool(y_prescaled)),
                                               _lib.dtype_code(y), N, H, W, C, float(alpha), _lib.stream_ptr(y))
     _lib.check(rc, 'act_bwd_reduce_scaled')
     return g, (A, B, Cn), ds
@@ -801,7 +813,7 @@ class PremaskLink:
     """Handshake between two chained fused convs  y1 = lrelu(conv1(x) + b1);  y2 = conv2(y1)  where conv2 is the ONLY consumer of y1
     (the caller guarantees that: DBlock).  conv2's backward then produces the gradient of y1 already multiplied by lrelu'(y1) and its
     per-channel sums (``agf_conv2d_fwd_mask``), and conv1's backward skips its own pass over the tensor (``agf_act_bwd_reduce``)."""
-    __slots__ = ('armed', 'alpha', 'premasked', 'bsum', 'pooled', 'armed_mod', 'noise', 'sums', 'mask', 'gscale', 'gscaled')
+    __slots__ = ('armed', 'alpha', 'premasked', 'bsum', 'pooled', 'armed_mod', 'noise', 'sums', 'mask', 'gscale', 'gscaled', 'yscaled')
 
     def __init__(self):
         self.armed, self.alpha, self.premasked, self.bsum, self.pooled = False, 0.2, False, None, None
@@ -812,6 +824,9 @@ class PremaskLink:
         # the modulated producer's demodulation scale d [N,C]: the consumer's backward stores the producer's gradient already times d
         # (``PRESCALE_G``) and says so in ``gscaled``
         self.gscale, self.gscaled = None, False
+        # ``POSTSCALE_X``: the modulated producer stored its output times the consumer's style scale (agf_conv2d_fwd_post); the consumer
+        # then reads its input unscaled
+        self.yscaled = False
 
 
 class _UpBlur(torch.autograd.Function):
@@ -998,6 +1013,8 @@ def torgb(x, weight, bias, s_raw, pre, coef):
 
 
 POOL_KERNEL = True     # agf_pool2x2 for the DBlock's AvgPool2d(2) (False: the [1,1] box FIR of upfirdn2d; tests compare the two)
+POSTSCALE_X = True     # the first modulated conv of a StyleBlock stores its output times the second one's style scale (>= 128 channels), which then
+#                        runs on the unscaled (direct-to-LDS) kernel forward and in its weight gradient (tests compare both ways)
 PRESCALE_G = True      # a modulated layer's gradient tensor is stored times its demodulation scale by the pass that makes it (tests compare both ways)
 _PREMASK = True        # tests/test_hip_conv.py::test_dblock_linked_backward_matches_unlinked runs the block with the fused hand-offs off
 
@@ -1014,10 +1031,19 @@ class _FusedConv(torch.autograd.Function):
     producer's lrelu mask folded into the same launch an unlucky order would have masked only one of the two branches)."""
 
     @staticmethod
-    def forward(ctx, x, weight, coef, s_in, s_out, bias, noise, residual, act, alpha, gain, pre_link=None, post_link=None, skip_pool=None):
+    def forward(ctx, x, weight, coef, s_in, s_out, bias, noise, residual, act, alpha, gain, pre_link=None, post_link=None, skip_pool=None,
+                post_scale=None):
         prep = prepared_weights(weight, coef, x.dtype)
-        y = conv2d_fwd_raw(x, prep.wq, in_scale=s_in, out_scale=s_out, bias=bias, noise=noise, residual=residual,
-                           act=act, alpha=alpha, gain=gain, prepared=True)
+        # this layer's input arrives already times s_in when its producer said so on the link (POSTSCALE_X)
+        x_pre = pre_link is not None and pre_link.yscaled and s_in is not None
+        # ... and this layer scales its own output for its consumer when the chain hand-off below will be armed and the layers are wide
+        # enough for the consumer to be bound by the matrix pipe (below that its streaming kernels take the scale for free)
+        chain_mod = post_link is not None and _PREMASK and act == ACT_LRELU and gain == 1.0 and x.dtype == torch.bfloat16 and s_out is not None
+        post = post_scale.detach() if (POSTSCALE_X and post_scale is not None and chain_mod and residual is None and skip_pool is None
+                                       and weight.shape[0] >= 128 and weight.shape[2] == 3) else None
+        y = conv2d_fwd_raw(x, prep.wq, in_scale=None if x_pre else s_in, out_scale=s_out, bias=bias, noise=noise, residual=residual,
+                           act=act, alpha=alpha, gain=gain, prepared=True, post_scale=post)
+        ctx.x_pre, ctx.post = x_pre, post
         ctx.save_for_backward(x, weight, s_in, s_out, bias, noise, y if (act == ACT_LRELU or s_out is not None) else None)
         ctx.coef, ctx.act, ctx.alpha, ctx.gain = coef, act, alpha, gain
         ctx.has_residual = residual is not None
@@ -1037,6 +1063,7 @@ class _FusedConv(torch.autograd.Function):
                 and s_out is not None:
             post_link.armed_mod, post_link.alpha, post_link.premasked, post_link.noise, post_link.sums = True, float(alpha), False, noise, None
             post_link.gscale, post_link.gscaled = (s_out.detach() if (PRESCALE_G and residual is None) else None), False
+            post_link.yscaled = post is not None
             ctx.post_link = post_link
         return y if skip_pool is None else (y, tp)
 
@@ -1044,6 +1071,7 @@ class _FusedConv(torch.autograd.Function):
     def backward(ctx, dy, dtp=None):
         x, weight, s_in, s_out, bias, noise, y = ctx.saved_tensors
         coef, act, alpha, gain = ctx.coef, ctx.act, ctx.alpha, ctx.gain
+        x_pre, post = ctx.x_pre, ctx.post            # POSTSCALE_X: x holds x * s_in / y holds y * post
         need_x, need_w, _, need_si, need_so, need_b, _, need_r = ctx.needs_input_grad[:8]
         need_r = need_r and ctx.has_residual
         link = ctx.post_link
@@ -1089,7 +1117,7 @@ class _FusedConv(torch.autograd.Function):
                     dx = dx + dx_pool
             if need_w:
                 dw = (_ConvWgrad.apply(x, g, None, None, k) * coef).to(weight.dtype)
-            return dx, dw, None, None, None, db, None, dres, None, None, None, None, None, None
+            return dx, dw, None, None, None, db, None, dres, None, None, None, None, None, None, None
         # the output gain is not applied to the gradient tensor: it rides along in the data-gradient launch's epilogue gain, in the
         # weight-gradient scale and in the bias sum (no pass over the tensor for it)
         pg = float(gain)
@@ -1124,6 +1152,10 @@ class _FusedConv(torch.autograd.Function):
             link.bsum = None
         elif act == ACT_LRELU:
             assert gain == 1.0 or s_out is None, 'demodulated layers use unit gain'
+            if post is not None:
+                # (not the path the generator takes: the consumer normally hands this layer its masked gradient; here the stored
+                #  output has to be divided by the consumer's style scale first)
+                y = (y.float() * _inv_scale(post)[:, :, None, None]).to(y.dtype).contiguous(memory_format=torch.channels_last)
             want_so = s_out is not None and need_so
             g_scaled = PRESCALE_G and s_out is not None and not need_r and x.dtype == torch.bfloat16
             g, (A, B, Cn) = act_bwd_reduce_raw(dy, y, noise, alpha,
@@ -1161,21 +1193,23 @@ class _FusedConv(torch.autograd.Function):
             elif pre is not None and pre.armed_mod and need_x and x.dtype == torch.bfloat16 and x.shape[1] % 8 == 0 and dx_pool is None:
                 # x is the lrelu output of the modulated producer this link came from and this conv is its only consumer: one pass gives
                 # this conv's ds and the producer's masked gradient and sums (instead of scale_dot here + act_bwd_reduce there)
-                dx, pre.sums, dsi = act_bwd_reduce_scaled_raw(t, x, pre.noise, s_in, pre.alpha, g_scale=pre.gscale)
+                dx, pre.sums, dsi = act_bwd_reduce_scaled_raw(t, x, pre.noise, s_in, pre.alpha, g_scale=pre.gscale, y_prescaled=x_pre)
                 pre.premasked, pre.noise, pre.gscaled, pre.gscale = True, None, pre.gscale is not None, None
             else:
                 dx, dsi = scale_dot_raw(x, t, s_in, want_dx=need_x)
+                if x_pre:
+                    dsi = dsi * _inv_scale(s_in)
             if dx_pool is not None and dx is not None:
                 dx = dx + dx_pool
         elif dx_pool is not None and need_x:
             dx = dx_pool
         if need_w:
-            dw = conv2d_wgrad_raw(x, g, k, in_scale=s_in, out_scale=None if g_scaled else s_out, scale=coef * pg).to(weight.dtype)
-        return dx, dw, None, dsi, dso, db, None, dres, None, None, None, None, None, None
+            dw = conv2d_wgrad_raw(x, g, k, in_scale=None if x_pre else s_in, out_scale=None if g_scaled else s_out, scale=coef * pg).to(weight.dtype)
+        return dx, dw, None, dsi, dso, db, None, dres, None, None, None, None, None, None, None
 
 
 def conv2d_act(x, weight, bias=None, s_in=None, s_out=None, noise=None, alpha=0.2, fused=True, coef=1.0,
-               act='lrelu', residual=None, gain=1.0, pre_link=None, post_link=None, skip_pool=None):
+               act='lrelu', residual=None, gain=1.0, pre_link=None, post_link=None, skip_pool=None, post_scale=None):
     """act( s_out * conv(x * s_in, weight * coef) + bias + noise + residual ) * gain; act = 'lrelu' | 'linear'.
     bias [Cout], noise [N,1,H,W] (no gradient), residual like the output.
     ``fused=False`` evaluates the same expression with the separately differentiable ops (any-order gradients).
@@ -1199,7 +1233,7 @@ def conv2d_act(x, weight, bias=None, s_in=None, s_out=None, noise=None, alpha=0.
                 return _FusedConv.apply(x, weight, coef, s_in, s_out, bias, noise, residual,
                                         ACT_LRELU if act == 'lrelu' else ACT_LINEAR, alpha, gain, pre_link, post_link, None), tp
         return _FusedConv.apply(x, weight, coef, s_in, s_out, bias, noise, residual,
-                                ACT_LRELU if act == 'lrelu' else ACT_LINEAR, alpha, gain, pre_link, post_link, skip_pool)
+                                ACT_LRELU if act == 'lrelu' else ACT_LINEAR, alpha, gain, pre_link, post_link, skip_pool, post_scale)
     x_in = x
     out = conv2d(x, weight * coef if coef != 1.0 else weight, s_in, s_out)
     if noise is not None:

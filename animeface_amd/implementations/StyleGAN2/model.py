@@ -253,19 +253,25 @@ class StyleBlock(nn.Module):
             x = up_blur(x, self._f6)
             i = 2
         link = None          # between consecutive modulated convs of the block: the first one's output has the second as its only consumer
+        ahead = None         # (s, d) of the next modulated conv when they were taken early
         while i < len(mods):
             m = mods[i]
             if isinstance(m, ModulatedConv2d) and i + 2 < len(mods) + 0 and isinstance(mods[i + 1], InjectNoise) \
                     and isinstance(mods[i + 2], nn.LeakyReLU):
                 # modconv -> +bias -> +noise -> lrelu, noise drawn exactly where the reference draws it
-                s, d = m.scales(y)
+                s, d = ahead if ahead is not None else m.scales(y)
+                ahead = None
                 pre = self.__dict__.get('_noise')
                 noise = pre.pop(0) if pre else InjectNoise.draw(x[:, :1])
                 fused = FUSED_EPILOGUE and getattr(self, 'fused_epilogue', True)
                 chained = fused and i + 3 < len(mods) and isinstance(mods[i + 3], ModulatedConv2d)
                 nxt = PremaskLink() if chained else None
+                if chained:
+                    # the next conv's style scale, known already: this conv may store its output times it (conv.POSTSCALE_X), and the
+                    # next conv then reads an unscaled operand
+                    ahead = mods[i + 3].scales(y)
                 x = conv2d_act(x, m.weight, m.bias.reshape(-1), s, d, noise, alpha=mods[i + 2].negative_slope,
-                               fused=fused, coef=m.coef, pre_link=link, post_link=nxt)
+                               fused=fused, coef=m.coef, pre_link=link, post_link=nxt, post_scale=ahead[0] if chained else None)
                 link = nxt
                 i += 3
             elif isinstance(m, ModulatedConv2d):

@@ -148,6 +148,17 @@ int agf_conv2d_fwd(const void* x, const void* w, void* y,
                    int dtype, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
                    int act, float alpha, float act_gain, void* stream);
 
+/* agf_conv2d_fwd whose stored output is additionally multiplied by post_scale[n,co] (fp32 [N,Cout]) AFTER activation and gain (ABI v20):
+ *   y = epilogue(...) * post_scale[n,co]
+ * for a modulated layer whose only consumer is the next modulated conv (implementations/StyleGAN2/model.py:154-180, the two convs of a
+ * StyleBlock): post_scale = that conv's style scale, which then reads its input unscaled -- the MFMA kernel's direct-to-LDS variant has no
+ * place to scale an operand.  bf16, 3x3, Cout >= 64; AGF_ENOKERNEL otherwise. */
+int agf_conv2d_fwd_post(const void* x, const void* w, void* y,
+                        const float* in_scale, const float* out_scale, const float* bias,
+                        const float* noise, const void* residual, const float* post_scale,
+                        int dtype, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
+                        int act, float alpha, float act_gain, void* stream);
+
 /* agf_conv2d_fwd (linear epilogue) for data-gradient launches, with up to two more autograd nodes folded into the same epilogue:
  *   t = epilogue(...)                                        as agf_conv2d_fwd
  *   t += res_scale * res_pooled[n, h/2, w/2, co]             res_pooled [N,H/2,W/2,Cout], nullable: the gradient that reaches this conv's
@@ -242,9 +253,10 @@ int agf_act_bwd_reduce(const void* dy, const void* y, const float* noise, void* 
  *   sum_yt[n,c] = sum_p y * t            (the consumer's gradient w.r.t. its style scale: what agf_scale_dot returns as ds)
  *   g           = (t * t_scale[n,c]) * lrelu'(y)   and sum_gy0 / sum_g / sum_gnoise of agf_act_bwd_reduce for the producer,
  * instead of writing dx = t * t_scale, reading it back and reading y a second time (6 tensor passes -> 3).  g_scale: as above (the
- * PRODUCER's demodulation scale). */
+ * PRODUCER's demodulation scale).  y_prescaled = 1: the tensor passed as y holds y * t_scale[n,c] (written so by agf_conv2d_fwd_post);
+ * the kernel divides it out (a zero scale gives y = 0). */
 int agf_act_bwd_reduce_scaled(const void* t, const void* y, const float* noise, const float* t_scale, void* g,
-                              float* sum_gy0, float* sum_g, float* sum_gnoise, float* sum_yt, const float* g_scale,
+                              float* sum_gy0, float* sum_g, float* sum_gnoise, float* sum_yt, const float* g_scale, int y_prescaled,
                               int dtype, int32_t N, int32_t H, int32_t W, int32_t C, float alpha, void* stream);
 
 /* agf_act_bwd_reduce for an activation whose only consumer is a 2x2 box average (nn.AvgPool2d(2) after the last LeakyReLU of a DBlock,

@@ -350,32 +350,36 @@ def test_dblock_linked_backward_matches_unlinked(monkeypatch):
 
 
 @pytest.mark.gpu
-def test_generator_block_with_prescaled_gradients_matches_the_operand_scaled_launches(monkeypatch):
+@pytest.mark.parametrize('switch,size,chan', [('PRESCALE_G', 32, 32), ('POSTSCALE_X', 32, 32), ('POSTSCALE_X', 64, 128)])
+def test_generator_with_prescaled_operands_matches_the_operand_scaled_launches(monkeypatch, switch, size, chan):
     """conv.PRESCALE_G: the gradient tensor of a modulated layer is stored times its demodulation scale by the pass that produces it
     (agf_act_bwd_reduce / agf_act_bwd_reduce_scaled, g_scale) and the data- / weight-gradient launches then run without that operand
-    scale -- against the same generator with the scale applied inside those launches (bf16: one rounding of g * d instead of two)."""
+    scale.  conv.POSTSCALE_X: the first modulated conv of a block stores its output times the second one's style scale
+    (agf_conv2d_fwd_post), the second one reads an unscaled operand, and its backward divides the scale out again (y_prescaled).
+    Both against the same generator with the scales applied inside the launches (bf16: one rounding of the product instead of two);
+    the 64 x 64 / 128-channel case reaches the 128-channel tile kernels."""
     from animeface_amd.implementations.StyleGAN2 import model as M, conv as C
     import functools
     torch.manual_seed(3)
-    G = M.Generator(32, 3, 64, 32, 128, 2, 2, True, 0.01, compute_dtype=torch.bfloat16).to(DEV)
+    G = M.Generator(size, 3, 64, chan, 128, 2, 2, True, 0.01, compute_dtype=torch.bfloat16).to(DEV)
     G.init_weight(functools.partial(M.init_weight_N01, lr=0.01), M.init_weight_N01)
     z = torch.randn(4, 64, device=DEV)
-    gy = torch.randn(4, 3, 32, 32, device=DEV)
+    gy = torch.randn(4, 3, size, size, device=DEV)
     outs = []
     for on in (True, False):
-        monkeypatch.setattr(C, 'PRESCALE_G', on)
+        monkeypatch.setattr(C, switch, on)
         torch.manual_seed(77)                               # the same noise draws in both passes
         img, _ = G(z)
         params = [p for p in G.parameters() if p.requires_grad]
         grads = torch.autograd.grad(img, params, gy, allow_unused=True)
         outs.append((img, grads))
-    assert rel(outs[0][0], outs[1][0]) == 0
+    assert rel(outs[0][0], outs[1][0]) <= (0 if switch == 'PRESCALE_G' else 2e-2)
     n = 0
     for a, b in zip(outs[0][1], outs[1][1]):
         if a is None:
             assert b is None
             continue
-        assert rel(a, b) < 3e-2, (a.shape, rel(a, b))
+        assert rel(a, b) < 4e-2, (a.shape, rel(a, b))
         n += 1
     assert n > 20
 

@@ -77,7 +77,16 @@ static void run(const char* name, const u32x4* x, u32x4* y, const u32x4* b, uint
     printf("%-4s U=%d mode=%d ntl=%d nts=%d blocks=%6d : %7.1f us  %5.2f TB/s  %.3f of 8\n", name, U, MODE, (int)NTL, (int)NTS, blocks, best * 1e3, bytes / best / 1e9, bytes / best / 1e9 / 8.0);
 }
 
-int main() {
+__global__ void fill_random(uint32_t* p, size_t n, uint32_t seed) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        uint32_t h = (uint32_t)i * 2654435761u ^ seed; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+        // two bf16 (or one fp32) of magnitude ~1 with random sign and mantissa: exponent field 0x3f
+        p[i] = (h & 0x807f807fu) | 0x3f003f00u;
+    }
+}
+
+int main(int argc, char** argv) {
+    const bool randomData = argc > 1;
     for (int pass = 0; pass < 2; pass++) {
         const bool bf = pass == 0;
         const size_t bytes = (size_t)64 * 64 * 256 * 256 * (bf ? 2 : 4);
@@ -85,9 +94,11 @@ int main() {
         u32x4 *x, *y, *b;
         hipMalloc(&x, bytes); hipMalloc(&y, bytes); hipMalloc(&b, 4096);
         hipMemset(x, 0x3c, bytes); hipMemset(b, 0, 4096);
+        if (randomData) { hipLaunchKernelGGL(fill_random, dim3(65536), dim3(256), 0, 0, (uint32_t*)x, bytes / 4, 12345u); hipDeviceSynchronize(); }
+        printf("# %s data\n", randomData ? "random" : "constant");
         const uint32_t bmask = bf ? 7 : 15;                  // 64 channels = 8 / 16 vectors
         const char* n = bf ? "bf16" : "fp32";
-        const int grids[] = {0, 2048, 4096, 16384};
+        const int grids[] = {0, 16384};
         for (int g : grids) {
 #define RUN(U, M, L, S) if (bf) run<true, U, M, L, S>(n, x, y, b, nvec, bmask, g); else run<false, U, M, L, S>(n, x, y, b, nvec, bmask, g);
             RUN(1, 0, false, false) RUN(1, 0, true, false) RUN(1, 0, false, true) RUN(1, 0, true, true)
