@@ -32,7 +32,7 @@ struct ActBwdParams {
 #ifndef ACTBWD_U
 #define ACTBWD_U 2          // (4 measured the same: the kernel is not short of loads in flight)
 #endif
-template <class T, int VEC, bool SCALED = false, bool MASKED = false>
+template <class T, int VEC, bool SCALED = false, bool MASKED = false, bool NT = false>
 __global__ void __launch_bounds__(256) act_bwd_reduce_kernel(ActBwdParams p) {
     __shared__ float red[SCALED ? 4 : 3][256][VEC + 1];
     const int tid = threadIdx.x;
@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(256) act_bwd_reduce_kernel(ActBwdParams p) {
                     const int h = px / p.W, w = px - h * p.W;
                     VecIO<T, VEC>::load((const T*)p.dy + ((int64_t)n * (p.HW >> 2) + (h >> 1) * (p.W >> 1) + (w >> 1)) * p.C + cg * VEC, dy[u]);
                 } else {
-                    VecIO<T, VEC>::load((const T*)p.dy + base + (int64_t)px * p.C, dy[u]);
+                    agf_vload<T, VEC, NT>((const T*)p.dy + base + (int64_t)px * p.C, dy[u]);
                 }
                 if (MASKED) {
                     // the sign of y from the 1-bit mask (1/16 of the bytes of y); only the sum of g is formed in this mode
@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(256) act_bwd_reduce_kernel(ActBwdParams p) {
 #pragma unroll
                     for (int i = 0; i < VEC; i++) y[u][i] = ((m >> i) & 1u) ? 1.f : -1.f;
                 } else {
-                    VecIO<T, VEC>::load((const T*)p.y + base + (int64_t)px * p.C, y[u]);
+                    agf_vload<T, VEC, NT>((const T*)p.y + base + (int64_t)px * p.C, y[u]);
                 }
                 if (SCALED) {
 #pragma unroll
@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(256) act_bwd_reduce_kernel(ActBwdParams p) {
                     a[i] += g[i] * y0; b[i] += g[i]; c[i] += g[i] * nz;
                     g[i] *= gs[i];
                 }
-                VecIO<T, VEC>::store((T*)p.g + base + (int64_t)px * p.C, g);
+                agf_vstore<T, VEC, NT>((T*)p.g + base + (int64_t)px * p.C, g);
             }
         }
     }
@@ -135,7 +135,7 @@ struct ScaleDotParams {
     int N, HW, C, CG, pixLanes, pixPerBlock;
 };
 
-template <class T, int VEC>
+template <class T, int VEC, bool NT = false>
 __global__ void __launch_bounds__(256) scale_dot_kernel(ScaleDotParams p) {
     __shared__ float red[256][VEC + 1];
     const int tid = threadIdx.x;
@@ -155,18 +155,18 @@ __global__ void __launch_bounds__(256) scale_dot_kernel(ScaleDotParams p) {
             const int px2 = px + p.pixLanes;
             const bool two = px2 < p1;
             float x[2][VEC], t[2][VEC], o[VEC];
-            VecIO<T, VEC>::load((const T*)p.x + base + (int64_t)px * p.C, x[0]);
-            VecIO<T, VEC>::load((const T*)p.t + base + (int64_t)px * p.C, t[0]);
+            agf_vload<T, VEC, NT>((const T*)p.x + base + (int64_t)px * p.C, x[0]);
+            agf_vload<T, VEC, NT>((const T*)p.t + base + (int64_t)px * p.C, t[0]);
             if (two) {
-                VecIO<T, VEC>::load((const T*)p.x + base + (int64_t)px2 * p.C, x[1]);
-                VecIO<T, VEC>::load((const T*)p.t + base + (int64_t)px2 * p.C, t[1]);
+                agf_vload<T, VEC, NT>((const T*)p.x + base + (int64_t)px2 * p.C, x[1]);
+                agf_vload<T, VEC, NT>((const T*)p.t + base + (int64_t)px2 * p.C, t[1]);
             }
 #pragma unroll
             for (int u = 0; u < 2; u++) {
                 if (u == 1 && !two) break;
 #pragma unroll
                 for (int i = 0; i < VEC; i++) { acc[i] += x[u][i] * t[u][i]; o[i] = t[u][i] * sc[i]; }
-                if (p.dx) VecIO<T, VEC>::store((T*)p.dx + base + (int64_t)(u ? px2 : px) * p.C, o);
+                if (p.dx) agf_vstore<T, VEC, NT>((T*)p.dx + base + (int64_t)(u ? px2 : px) * p.C, o);
             }
         }
     }
@@ -218,14 +218,20 @@ static int act_bwd_reduce_impl(const void* dy, const void* y, const float* noise
         return AGF_ENOKERNEL;
     }
     dim3 grid((unsigned)p.chunks, (unsigned)N), block(256);
+    // operands and result are each touched once by this pass; past the last-level cache they go non-temporal (bf16 only: the training path)
+    const bool nt = dtype == AGF_BF16 && agf_streams_past_cache((int64_t)N * H * W * C * 2);
+    hipStream_t st = (hipStream_t)stream;
     if (mask) {
         AGF_CHECK(dtype == AGF_BF16 && !dscale && !sum_gy0 && !sum_gnoise, "act_bwd_reduce: the 1-bit mask mode is bf16, bias sum only");
-        hipLaunchKernelGGL((act_bwd_reduce_kernel<bf16_t, 8, false, true>), grid, block, 0, (hipStream_t)stream, p);
+        if (nt) hipLaunchKernelGGL((act_bwd_reduce_kernel<bf16_t, 8, false, true, true>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((act_bwd_reduce_kernel<bf16_t, 8, false, true>), grid, block, 0, st, p);
     } else if (dscale) {
-        if (dtype == AGF_BF16) hipLaunchKernelGGL((act_bwd_reduce_kernel<bf16_t, 8, true>), grid, block, 0, (hipStream_t)stream, p);
-        else hipLaunchKernelGGL((act_bwd_reduce_kernel<float, 4, true>), grid, block, 0, (hipStream_t)stream, p);
-    } else if (dtype == AGF_BF16) hipLaunchKernelGGL((act_bwd_reduce_kernel<bf16_t, 8>), grid, block, 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((act_bwd_reduce_kernel<float, 4>), grid, block, 0, (hipStream_t)stream, p);
+        if (dtype == AGF_BF16 && nt) hipLaunchKernelGGL((act_bwd_reduce_kernel<bf16_t, 8, true, false, true>), grid, block, 0, st, p);
+        else if (dtype == AGF_BF16) hipLaunchKernelGGL((act_bwd_reduce_kernel<bf16_t, 8, true>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((act_bwd_reduce_kernel<float, 4, true>), grid, block, 0, st, p);
+    } else if (dtype == AGF_BF16 && nt) hipLaunchKernelGGL((act_bwd_reduce_kernel<bf16_t, 8, false, false, true>), grid, block, 0, st, p);
+    else if (dtype == AGF_BF16) hipLaunchKernelGGL((act_bwd_reduce_kernel<bf16_t, 8>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((act_bwd_reduce_kernel<float, 4>), grid, block, 0, st, p);
     AGF_LAUNCH_CHECK();
     return AGF_OK;
 }
@@ -352,7 +358,8 @@ extern "C" int agf_scale_dot(const void* x, const void* t, const float* s, void*
         return AGF_ENOKERNEL;
     }
     dim3 grid((unsigned)chunks, (unsigned)N), block(256);
-    if (dtype == AGF_BF16) hipLaunchKernelGGL((scale_dot_kernel<bf16_t, 8>), grid, block, 0, (hipStream_t)stream, p);
+    if (dtype == AGF_BF16 && agf_streams_past_cache((int64_t)N * H * W * C * 2)) hipLaunchKernelGGL((scale_dot_kernel<bf16_t, 8, true>), grid, block, 0, (hipStream_t)stream, p);
+    else if (dtype == AGF_BF16) hipLaunchKernelGGL((scale_dot_kernel<bf16_t, 8>), grid, block, 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((scale_dot_kernel<float, 4>), grid, block, 0, (hipStream_t)stream, p);
     AGF_LAUNCH_CHECK();
     return AGF_OK;

@@ -268,8 +268,8 @@ __global__ void __launch_bounds__(256, ROWS_WAVES) upfirdn2d_nhwc_rows(UpfirdnPa
 #pragma unroll
         for (int r = 0; r < ROWS; r++) {
             const int kyn = (t + 1) * UP + K00 - r * DN, kyc = t * UP + K00 - r * DN;
-            // (the small up-sampling filters allocate fewer registers without the tie: 84 vs 100, 36 vs 78)
-            if ((UP == 1 || FW >= 6) && ((kyc >= 0 && kyc < FH) || (kyn >= 0 && kyn < FH))) {
+            // (the up-sampling filters do not need the tie -- 36-156 VGPRs without -- and the 6 x 6 one ran 11 % slower with it)
+            if (UP == 1 && ((kyc >= 0 && kyc < FH) || (kyn >= 0 && kyn < FH))) {
 #pragma unroll
                 for (int i = 0; i < VEC; i++) asm volatile("" : "+v"(acc[r][i]) :: "memory");
             }
@@ -688,19 +688,6 @@ static bool launch_nhwc(const UpfirdnParams& p, hipStream_t st) {
         launch_rows<T, VEC, ux, dx, w, h, ROWS>(pp, gr, st);                                              \
         return true;                                                                                      \
     }
-#define NHWC_VAR(ux, dx, w, rows, pd, id)                                                                   \
-    if (var == id && p.upx == ux && p.upy == ux && p.downx == dx && p.downy == dx && p.fw == w && p.fh == w) {   \
-        dim3 gr((unsigned)agf_ceil_div((int64_t)p.OW * CG, 256), (unsigned)agf_ceil_div(p.OH, rows), (unsigned)p.N);   \
-        launch_rows<T, VEC, ux, dx, w, w, rows, pd>(pp, gr, st);                                          \
-        return true;                                                                                      \
-    }
-    { static const int var = getenv("AGF_X_VAR") ? atoi(getenv("AGF_X_VAR")) : 0;     // EXPERIMENT (to be removed)
-      NHWC_VAR(1, 2, 4, 8, 2, 1) NHWC_VAR(1, 2, 4, 4, 3, 2) NHWC_VAR(1, 2, 4, 8, 3, 3) NHWC_VAR(1, 2, 4, 2, 3, 4)
-      NHWC_VAR(1, 2, 6, 8, 2, 1) NHWC_VAR(1, 2, 6, 4, 3, 2) NHWC_VAR(1, 2, 6, 8, 3, 3) NHWC_VAR(1, 2, 6, 2, 3, 4)
-      NHWC_VAR(1, 1, 3, 8, 3, 2) NHWC_VAR(1, 1, 3, 16, 2, 1) NHWC_VAR(1, 1, 3, 16, 3, 3) NHWC_VAR(1, 1, 3, 4, 3, 4)
-      NHWC_VAR(2, 1, 4, 8, 3, 2) NHWC_VAR(2, 1, 4, 16, 2, 1) NHWC_VAR(2, 1, 4, 4, 3, 4)
-      NHWC_VAR(2, 1, 6, 8, 3, 2) NHWC_VAR(2, 1, 6, 4, 3, 4) }
-#undef NHWC_VAR
     NHWC_CASE(2, 2, 1, 1, 4, 4, 8)   // bilinear-equivalent 2x upsample  (StyleGAN2 Upsample2x, ToImage)
     NHWC_CASE(1, 1, 1, 1, 3, 3, 8)   // Blur2d
     NHWC_CASE(1, 1, 2, 2, 2, 2, 4)   // AvgPool2d(2)
