@@ -12,9 +12,12 @@ struct LayoutParams {
     const void* x; void* y;
     int N, C, H, W, pad, Cp;
     int tilesW, tilesC;
+    const float* scale;       // planar_to_cl_pad only: [N][Cp] fp32 or null -- y = x * scale[n, c] (agf_planar_to_cl_pad_scaled)
 };
 
-template <class U, int CT>            // U = uint16_t (bf16 / fp16) or uint32_t (fp32)
+// SC: 0 = plain copy, 1 = bf16 values times scale[n, c], 2 = fp32 values times scale[n, c] (applied where a lane holds a 16-byte vector of
+// consecutive channels of one pixel)
+template <class U, int CT, int SC = 0>            // U = uint16_t (bf16 / fp16) or uint32_t (fp32)
 __global__ void __launch_bounds__(256) planar_to_cl_pad_kernel(LayoutParams p) {
     constexpr int PT = 64;
     constexpr int VEC = 16 / (int)sizeof(U);                   // channels per 16-byte vector
@@ -61,6 +64,14 @@ __global__ void __launch_bounds__(256) planar_to_cl_pad_kernel(LayoutParams p) {
         U v[VEC];
 #pragma unroll
         for (int e = 0; e < VEC; e++) v[e] = rowIn ? tile[(g * VEC + e) * LP + px] : (U)0;
+        if (SC != 0 && rowIn) {
+            const float* sc = p.scale + (int64_t)n * p.Cp + cc;
+#pragma unroll
+            for (int e = 0; e < VEC; e++) {
+                if (SC == 1) v[e] = (U)f32_to_bf16_bits(bf16_bits_to_f32((uint32_t)v[e]) * sc[e]);
+                else v[e] = (U)__float_as_uint(__uint_as_float((uint32_t)v[e]) * sc[e]);
+            }
+        }
         *(uint4*)(yrow + (int64_t)xp * p.Cp + cc) = *(const uint4*)v;
     }
 }
@@ -106,26 +117,45 @@ static int layout_common(LayoutParams& p, const void* x, void* y, int dtype, int
     const int vec = dtype == AGF_F32 ? 4 : 8;
     AGF_CHECK(Cp % vec == 0, "layout: the channels-last channel count must be a multiple of 16 bytes");
     AGF_CHECK(((uintptr_t)x % 16) == 0 || true, "layout");
-    p.x = x; p.y = y; p.N = N; p.C = C; p.H = H; p.W = W; p.pad = pad; p.Cp = Cp;
+    p.x = x; p.y = y; p.N = N; p.C = C; p.H = H; p.W = W; p.pad = pad; p.Cp = Cp; p.scale = nullptr;
     (void)name;
     return AGF_OK;
 }
 
-extern "C" int agf_planar_to_cl_pad(const void* x, void* y, int dtype, int32_t N, int32_t C, int32_t H, int32_t W,
-                                    int32_t pad, int32_t Cp, void* stream) {
+static int planar_to_cl_pad_impl(const void* x, void* y, const float* scale, int dtype, int32_t N, int32_t C, int32_t H, int32_t W,
+                                 int32_t pad, int32_t Cp, void* stream) {
     LayoutParams p;
     int rc = layout_common(p, x, y, dtype, N, C, H, W, pad, Cp, "planar_to_cl_pad");
     if (rc != AGF_OK) return rc;
     AGF_CHECK(((uintptr_t)y % 16) == 0, "planar_to_cl_pad: y must be 16-byte aligned");
+    AGF_CHECK(!scale || dtype != AGF_F16, "planar_to_cl_pad_scaled: bf16 or f32");
+    p.scale = scale;
     const int CT = dtype == AGF_F32 ? 32 : 64;
     p.tilesW = (W + 2 * pad + 63) / 64; p.tilesC = (Cp + CT - 1) / CT;
     const int64_t gx = (int64_t)p.tilesW * p.tilesC * (H + 2 * pad);
     AGF_CHECK(gx < (1ll << 31) && N < 65536, "planar_to_cl_pad: tensor too large");
     dim3 grid((unsigned)gx, (unsigned)N);
-    if (dtype == AGF_F32) hipLaunchKernelGGL((planar_to_cl_pad_kernel<uint32_t, 32>), grid, dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((planar_to_cl_pad_kernel<uint16_t, 64>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == AGF_F32) {
+        if (scale) hipLaunchKernelGGL((planar_to_cl_pad_kernel<uint32_t, 32, 2>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((planar_to_cl_pad_kernel<uint32_t, 32>), grid, dim3(256), 0, st, p);
+    } else {
+        if (scale) hipLaunchKernelGGL((planar_to_cl_pad_kernel<uint16_t, 64, 1>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((planar_to_cl_pad_kernel<uint16_t, 64>), grid, dim3(256), 0, st, p);
+    }
     AGF_LAUNCH_CHECK();
     return AGF_OK;
+}
+
+extern "C" int agf_planar_to_cl_pad(const void* x, void* y, int dtype, int32_t N, int32_t C, int32_t H, int32_t W,
+                                    int32_t pad, int32_t Cp, void* stream) {
+    return planar_to_cl_pad_impl(x, y, nullptr, dtype, N, C, H, W, pad, Cp, stream);
+}
+
+extern "C" int agf_planar_to_cl_pad_scaled(const void* x, void* y, const float* scale, int dtype, int32_t N, int32_t C, int32_t H, int32_t W,
+                                           int32_t pad, int32_t Cp, void* stream) {
+    AGF_CHECK(scale, "planar_to_cl_pad_scaled: null scale");
+    return planar_to_cl_pad_impl(x, y, scale, dtype, N, C, H, W, pad, Cp, stream);
 }
 
 extern "C" int agf_cl_to_planar_crop(const void* x, void* y, int dtype, int32_t N, int32_t C, int32_t H, int32_t W,

@@ -89,6 +89,56 @@ class Linear(nn.Module):
         return bias_act.bias_act(x, self.bias.to(x.dtype) if self.bias is not None else None, act=self.act_name)
 
 
+FOLD_SCALES = True     # the modulated conv's operand scales ride in the planar -> channels-last conversions (tests compare both ways)
+
+
+class _ModConvPlanar(torch.autograd.Function):
+    """y = d * conv(x * s, w) for planar x / y, with every per-sample scale folded into a layout conversion that happens anyway:
+    the style scale s into the planar -> channels-last pass of x, the demodulation scale d of the OUTPUT GRADIENT into the same pass of dy.
+    The three MFMA launches (forward, data gradient, weight gradient) then carry no operand scale and run on the unscaled kernel variants
+    (direct-to-LDS for >= 128 channels), which the operand-scaled variants trail by 20-40 %.  The gradients of s and d come from the
+    scaled tensors:  ds = sum_hw (x s) t / s,  dd = sum_hw (dy d)(d conv) / d^2.  First order only (the generator is never differentiated
+    twice in the StyleGAN3 loop, reference implementations/StyleGAN3/utils.py:30-77)."""
+
+    @staticmethod
+    def forward(ctx, x, w, s_in, d, extra):
+        from ..StyleGAN2.conv import conv2d_fwd_raw
+        cout, cin, k = w.shape[0], w.shape[1], w.shape[2]
+        cin_p, cout_p = layout.padded_channels(cin, x.dtype), layout.padded_channels(cout, x.dtype)
+        w_p = F.pad(w, [0, 0, 0, 0, 0, cin_p - cin, 0, cout_p - cout]) if (cin_p != cin or cout_p != cout) else w
+        s_p = F.pad(s_in.float(), [0, cin_p - cin])
+        d_p = F.pad(d.float(), [0, cout_p - cout], value=1.0) if d is not None else None
+        xs = layout._to_cl_raw(x, extra, cin_p, scale=s_p)
+        y_cl = conv2d_fwd_raw(xs, w_p, in_scale=None, out_scale=d_p)
+        ctx.save_for_backward(xs, w_p, s_p, d_p, y_cl if d is not None else None)
+        ctx.dims = (cin, cout, k, extra)
+        return layout._to_planar_raw(y_cl, 0, cout)
+
+    @staticmethod
+    def backward(ctx, dy):
+        from ..StyleGAN2.conv import conv2d_fwd_raw, conv2d_wgrad_raw, scale_dot_raw, flip_transpose, _inv_scale
+        if torch.is_grad_enabled():
+            raise RuntimeError('the scale-folded StyleGAN3 modulated conv is first-order only (set model.FOLD_SCALES = False)')
+        xs, w_p, s_p, d_p, y_cl = ctx.saved_tensors
+        cin, cout, k, extra = ctx.dims
+        cout_p = w_p.shape[0]
+        dx = dw = ds = dd = None
+        g_cl = layout._to_cl_raw(dy.to(xs.dtype), 0, cout_p, scale=d_p)                 # dy * d, channels-last
+        if ctx.needs_input_grad[1]:
+            dw = conv2d_wgrad_raw(xs, g_cl, k)[:cout, :cin].to(w_p.dtype)
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[2]:
+            t = conv2d_fwd_raw(g_cl, flip_transpose(w_p))                                # gradient w.r.t. (x * s), channels-last, padded map
+            dx_cl, ds_raw = scale_dot_raw(xs, t, s_p, want_dx=ctx.needs_input_grad[0])  # dx = t * s;  sum_hw (x s) t
+            if ctx.needs_input_grad[2]:
+                ds = (ds_raw * _inv_scale(s_p))[:, :cin]
+            if dx_cl is not None:
+                dx = layout._to_planar_raw(dx_cl, extra, cin)
+        if d_p is not None and ctx.needs_input_grad[3]:
+            _, dots = scale_dot_raw(g_cl, y_cl, d_p, want_dx=False)                      # sum_hw (dy d)(d conv)
+            dd = (dots / d_p.square())[:, :cout]
+        return dx, dw, ds, dd, None
+
+
 class ModulatedConv(nn.Module):
     """reference model.py:32-74.  eps 1e-8; ``input_gain`` multiplies the weights AFTER demodulation, i.e. it scales the
     input channels but does not enter d."""
@@ -113,6 +163,8 @@ class ModulatedConv(nn.Module):
         assert extra >= 0
         w = self.weight * self.scale
         cout, cin = w.shape[0], w.shape[1]
+        if FOLD_SCALES and x.is_cuda and x.dtype in (torch.bfloat16, torch.float32):
+            return _ModConvPlanar.apply(x, w, s_in, d, extra)
         # planar -> channels-last with the zero border and the channel count rounded up to a 16-byte vector in ONE pass
         # (agf_planar_to_cl_pad); the conv then runs on padded channel counts and the way back crops them again
         cin_p, cout_p = layout.padded_channels(cin, x.dtype), layout.padded_channels(cout, x.dtype)

@@ -15,10 +15,17 @@ def padded_channels(c, dtype):
     return (c + v - 1) // v * v
 
 
-def _to_cl_raw(x, pad, cp):
+def _to_cl_raw(x, pad, cp, scale=None):
+    """``scale`` [N, cp] fp32: the output is multiplied by scale[n, c] on the way (``agf_planar_to_cl_pad_scaled``)."""
     N, C, H, W = x.shape
     x = x.contiguous()
     y = torch.empty((N, cp, H + 2 * pad, W + 2 * pad), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    if scale is not None:
+        scale = scale.float().contiguous()
+        assert tuple(scale.shape) == (N, cp)
+        _lib.check(_lib.lib().agf_planar_to_cl_pad_scaled(_lib.ptr(x), _lib.ptr(y), _lib.ptr(scale), _lib.dtype_code(x), N, C, H, W, pad, cp,
+                                                          _lib.stream_ptr(x)), 'planar_to_cl_pad_scaled')
+        return y
     _lib.check(_lib.lib().agf_planar_to_cl_pad(_lib.ptr(x), _lib.ptr(y), _lib.dtype_code(x), N, C, H, W, pad, cp,
                                                _lib.stream_ptr(x)), 'planar_to_cl_pad')
     return y

@@ -295,6 +295,11 @@ int agf_demod_grad_finish(const float* A, const float* B, const float* Cn, const
  */
 int agf_planar_to_cl_pad(const void* x, void* y, int dtype, int32_t N, int32_t C, int32_t H, int32_t W,
                          int32_t pad, int32_t Cp, void* stream);
+/* agf_planar_to_cl_pad whose output is multiplied by scale[n, c] (fp32 [N][Cp], ABI v20): the StyleGAN3 layer's modulated conv
+ * (implementations/StyleGAN3/model.py:32-74) reads its input through this conversion anyway, so the style scale (forward) and the
+ * demodulation scale of the output gradient (backward) ride along and the MFMA launches run without an operand scale.  bf16 or f32. */
+int agf_planar_to_cl_pad_scaled(const void* x, void* y, const float* scale, int dtype, int32_t N, int32_t C, int32_t H, int32_t W,
+                                int32_t pad, int32_t Cp, void* stream);
 int agf_cl_to_planar_crop(const void* x, void* y, int dtype, int32_t N, int32_t C, int32_t H, int32_t W,
                           int32_t pad, int32_t Cp, void* stream);
 

@@ -255,6 +255,31 @@ def test_graph_replayed_step_equals_the_eager_step(dtype):
     assert [h[0] for h in hist] == list(range(6)) and all(np.isfinite(h[1]) and np.isfinite(h[2]) for h in hist)
 
 
+@pytest.mark.parametrize('dtype,tol', [(torch.float32, 2e-4), (torch.bfloat16, 3e-2)], ids=['fp32', 'bf16'])
+@pytest.mark.parametrize('demod', [True, False])
+def test_modulated_conv_with_folded_scales_matches_the_operand_scaled_path(dtype, tol, demod, monkeypatch):
+    """model.FOLD_SCALES: the modulated conv's style scale rides in the planar -> channels-last conversion of its input, the demodulation
+    scale of the output gradient in the same conversion of dy (agf_planar_to_cl_pad_scaled), and the MFMA launches run unscaled --
+    against the composite with the scales inside the launches: output and all four gradients (x, weight, style, and through the
+    demodulation the weight again), ragged channel counts (padded to a 16-byte vector) included."""
+    from animeface_amd.implementations.StyleGAN3 import model as M
+    torch.manual_seed(2)
+    conv = M.ModulatedConv(20, 44, 3, 2, demod=demod).to(DEV)
+    x0 = torch.randn(3, 20, 18, 22, device=DEV).to(dtype)
+    s0 = torch.randn(3, 20, device=DEV) * 0.5 + 1.0
+    gy = torch.randn(3, 44, 20, 24, device=DEV).to(dtype)
+    gain = torch.tensor(0.7, device=DEV)
+    outs = []
+    for on in (True, False):
+        monkeypatch.setattr(M, 'FOLD_SCALES', on)
+        x, s = x0.clone().requires_grad_(True), s0.clone().requires_grad_(True)
+        y = conv(x, s, gain)
+        assert y.shape == gy.shape
+        outs.append((y,) + torch.autograd.grad(y, [x, s, conv.weight], gy))
+    for a, b in zip(outs[0], outs[1]):
+        assert a.shape == b.shape and relerr(a, b.detach().float().cpu()) < tol, (a.shape, relerr(a, b.detach().float().cpu()))
+
+
 def test_hip_model_vs_cpu_oracle_on_a_second_configuration():
     """A configuration / seed the fixtures do not contain: HIP fp32 networks against the CPU oracle (oracle/stylegan3.py, itself
     pinned to the reference by tests/test_oracle_sg3.py) on the same state_dict."""
