@@ -13,11 +13,14 @@ struct LayoutParams {
     int N, C, H, W, pad, Cp;
     int tilesW, tilesC;
     const float* scale;       // planar_to_cl_pad only: [N][Cp] fp32 or null -- y = x * scale[n, c] (agf_planar_to_cl_pad_scaled)
+    int xshift;               // PAIR kernels: the tile grid starts xshift (= pad & 1) padded columns left of column 0, so that a tile's first INPUT column is even
 };
 
 // SC: 0 = plain copy, 1 = bf16 values times scale[n, c], 2 = fp32 values times scale[n, c] (applied where a lane holds a 16-byte vector of
 // consecutive channels of one pixel)
-template <class U, int CT, int SC = 0>            // U = uint16_t (bf16 / fp16) or uint32_t (fp32)
+// PAIR (16-bit elements, W even): the planar side moves as aligned dwords = two pixels of one channel.  With one 2-byte element per lane a
+// wave-level load carries 128 bytes and the address unit, not HBM, set the pace (2.2 TB/s on the 534 x 534 StyleGAN3 layers).
+template <class U, int CT, int SC = 0, bool PAIR = false>            // U = uint16_t (bf16 / fp16) or uint32_t (fp32)
 __global__ void __launch_bounds__(256) planar_to_cl_pad_kernel(LayoutParams p) {
     constexpr int PT = 64;
     constexpr int VEC = 16 / (int)sizeof(U);                   // channels per 16-byte vector
@@ -29,12 +32,28 @@ __global__ void __launch_bounds__(256) planar_to_cl_pad_kernel(LayoutParams p) {
     const int tc = bx % p.tilesC;
     const int yp = bx / p.tilesC;                               // padded row
     const int n = blockIdx.y;
-    const int c0 = tc * CT, xp0 = tw * PT;                      // padded column of the tile start
+    const int c0 = tc * CT, xp0 = tw * PT - (PAIR ? p.xshift : 0);   // padded column of the tile start
     const int tid = threadIdx.x;
     const int yi = yp - p.pad;
     const bool rowIn = yi >= 0 && yi < p.H;
     U* yrow = (U*)p.y + ((int64_t)(n * Hp + yp) * Wp) * p.Cp;
-    if (rowIn) {
+    if (PAIR && rowIn) {
+        const U* xb = (const U*)p.x + ((int64_t)n * p.C * p.H + yi) * p.W;
+        constexpr int NL = CT * PT / 2 / 256;                   // dwords per lane
+        const int d = tid % (PT / 2), xi = xp0 + 2 * d - p.pad;   // even: xi and xi + 1 are inside the row together (W is even)
+        const bool colIn = xi >= 0 && xi < p.W;
+        const int64_t plane = (int64_t)p.H * p.W;
+        uint32_t v[NL];
+#pragma unroll
+        for (int k = 0; k < NL; k++) {
+            const int cc = c0 + tid / (PT / 2) + k * (512 / PT);
+            v[k] = 0u;
+            if (colIn && cc < p.C) v[k] = *(const uint32_t*)(xb + cc * plane + xi);
+        }
+#pragma unroll
+        for (int k = 0; k < NL; k++) ((uint32_t*)tile)[((tid / (PT / 2) + k * (512 / PT)) * LP + 2 * d) / 2] = v[k];
+        __syncthreads();
+    } else if (rowIn) {
         // load [CT][PT] from the planar side, elementwise bounds (W may be odd; pad shifts alignment)
         // (all of a lane's CT * PT / 256 element loads are issued before the first LDS write: as a rolled loop -- load, write, load, ... --
         //  a block paid one HBM round trip per element and the kernel sat at 2.2 TB/s on the 534 x 534 StyleGAN3 layers)
@@ -60,7 +79,7 @@ __global__ void __launch_bounds__(256) planar_to_cl_pad_kernel(LayoutParams p) {
     for (int i = tid; i < PT * GROUPS; i += 256) {
         const int px = i / GROUPS, g = i - px * GROUPS;
         const int xp = xp0 + px, cc = c0 + g * VEC;
-        if (xp >= Wp || cc >= p.Cp) continue;
+        if (xp < 0 || xp >= Wp || cc >= p.Cp) continue;
         U v[VEC];
 #pragma unroll
         for (int e = 0; e < VEC; e++) v[e] = rowIn ? tile[(g * VEC + e) * LP + px] : (U)0;
@@ -76,7 +95,7 @@ __global__ void __launch_bounds__(256) planar_to_cl_pad_kernel(LayoutParams p) {
     }
 }
 
-template <class U, int CT>
+template <class U, int CT, bool PAIR = false>
 __global__ void __launch_bounds__(256) cl_to_planar_crop_kernel(LayoutParams p) {
     constexpr int PT = 64;
     constexpr int VEC = 16 / (int)sizeof(U);
@@ -103,6 +122,15 @@ __global__ void __launch_bounds__(256) cl_to_planar_crop_kernel(LayoutParams p) 
     }
     __syncthreads();
     U* yb = (U*)p.y + ((int64_t)n * p.C * p.H + yi) * p.W;
+    if (PAIR) {
+#pragma unroll
+        for (int k = 0; k < CT * PT / 2 / 256; k++) {
+            const int c = tid / (PT / 2) + k * (512 / PT), d = tid % (PT / 2);
+            const int cc = c0 + c, xi = x0 + 2 * d;
+            if (cc < p.C && xi < p.W) *(uint32_t*)(yb + (int64_t)cc * p.H * p.W + xi) = ((const uint32_t*)tile)[(c * LP + 2 * d) / 2];
+        }
+        return;
+    }
     for (int i = tid; i < CT * PT; i += 256) {
         const int c = i / PT, px = i - c * PT;
         const int cc = c0 + c, xi = x0 + px;
@@ -117,7 +145,7 @@ static int layout_common(LayoutParams& p, const void* x, void* y, int dtype, int
     const int vec = dtype == AGF_F32 ? 4 : 8;
     AGF_CHECK(Cp % vec == 0, "layout: the channels-last channel count must be a multiple of 16 bytes");
     AGF_CHECK(((uintptr_t)x % 16) == 0 || true, "layout");
-    p.x = x; p.y = y; p.N = N; p.C = C; p.H = H; p.W = W; p.pad = pad; p.Cp = Cp; p.scale = nullptr;
+    p.x = x; p.y = y; p.N = N; p.C = C; p.H = H; p.W = W; p.pad = pad; p.Cp = Cp; p.scale = nullptr; p.xshift = 0;
     (void)name;
     return AGF_OK;
 }
@@ -131,7 +159,9 @@ static int planar_to_cl_pad_impl(const void* x, void* y, const float* scale, int
     AGF_CHECK(!scale || dtype != AGF_F16, "planar_to_cl_pad_scaled: bf16 or f32");
     p.scale = scale;
     const int CT = dtype == AGF_F32 ? 32 : 64;
-    p.tilesW = (W + 2 * pad + 63) / 64; p.tilesC = (Cp + CT - 1) / CT;
+    const bool pair = dtype != AGF_F32 && (W % 2) == 0 && ((uintptr_t)x % 4) == 0;
+    p.xshift = pair ? (pad & 1) : 0;
+    p.tilesW = (W + 2 * pad + p.xshift + 63) / 64; p.tilesC = (Cp + CT - 1) / CT;
     const int64_t gx = (int64_t)p.tilesW * p.tilesC * (H + 2 * pad);
     AGF_CHECK(gx < (1ll << 31) && N < 65536, "planar_to_cl_pad: tensor too large");
     dim3 grid((unsigned)gx, (unsigned)N);
@@ -139,6 +169,9 @@ static int planar_to_cl_pad_impl(const void* x, void* y, const float* scale, int
     if (dtype == AGF_F32) {
         if (scale) hipLaunchKernelGGL((planar_to_cl_pad_kernel<uint32_t, 32, 2>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((planar_to_cl_pad_kernel<uint32_t, 32>), grid, dim3(256), 0, st, p);
+    } else if (pair) {
+        if (scale) hipLaunchKernelGGL((planar_to_cl_pad_kernel<uint16_t, 64, 1, true>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((planar_to_cl_pad_kernel<uint16_t, 64, 0, true>), grid, dim3(256), 0, st, p);
     } else {
         if (scale) hipLaunchKernelGGL((planar_to_cl_pad_kernel<uint16_t, 64, 1>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((planar_to_cl_pad_kernel<uint16_t, 64>), grid, dim3(256), 0, st, p);
@@ -170,6 +203,7 @@ extern "C" int agf_cl_to_planar_crop(const void* x, void* y, int dtype, int32_t 
     AGF_CHECK(gx < (1ll << 31) && N < 65536, "cl_to_planar_crop: tensor too large");
     dim3 grid((unsigned)gx, (unsigned)N);
     if (dtype == AGF_F32) hipLaunchKernelGGL((cl_to_planar_crop_kernel<uint32_t, 32>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    else if ((W % 2) == 0 && ((uintptr_t)y % 4) == 0) hipLaunchKernelGGL((cl_to_planar_crop_kernel<uint16_t, 64, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((cl_to_planar_crop_kernel<uint16_t, 64>), grid, dim3(256), 0, (hipStream_t)stream, p);
     AGF_LAUNCH_CHECK();
     return AGF_OK;
