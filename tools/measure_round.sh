@@ -4,15 +4,15 @@
 tag=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${tag}_driver_cmd.log 2>&1
+AGF_BENCH_SHAPES_FILE=gpurun_out/${tag}_conv_shapes.txt python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${tag}_driver_cmd.log 2>&1
 tail -1 gpurun_out/${tag}_driver_cmd.log | cut -c1-300
 python bench.py --steps 32 --warmup 4 --no-cpu-baseline > gpurun_out/${tag}_bench_step.log 2>&1
 tail -1 gpurun_out/${tag}_bench_step.log | cut -c1-300
 python bench.py --image-size 128 --batch 32 --steps 32 --warmup 4 --no-cpu-baseline > gpurun_out/${tag}_bench_128_b32.log 2>&1
 tail -1 gpurun_out/${tag}_bench_128_b32.log | cut -c1-300
-python tools/bench_sg3.py --image-size 512 --batch 16 --steps 6 --warmup 2 > gpurun_out/${tag}_sg3_512_b16.log 2>&1
+python tools/bench_sg3.py --image-size 512 --batch 16 --steps 16 --warmup 2 > gpurun_out/${tag}_sg3_512_b16.log 2>&1     # (16 steps: one of them carries the R1 penalty)
 tail -1 gpurun_out/${tag}_sg3_512_b16.log | cut -c1-300
-python tools/bench_sg3.py --image-size 256 --batch 32 --steps 6 --warmup 2 > gpurun_out/${tag}_sg3_256_b32.log 2>&1
+python tools/bench_sg3.py --image-size 256 --batch 32 --steps 16 --warmup 2 > gpurun_out/${tag}_sg3_256_b32.log 2>&1
 tail -1 gpurun_out/${tag}_sg3_256_b32.log | cut -c1-200
 python tools/bench_kernels.py --cpu > gpurun_out/${tag}_kernel_microbench.jsonl 2>/dev/null
 python tools/bench_flrelu.py > gpurun_out/${tag}_flrelu_roofline.jsonl 2>/dev/null
