@@ -213,6 +213,86 @@ static __device__ __forceinline__ void conv_epilogue_pl(const ConvParams& p, f32
                     if (valid[j] && cb < p.Cout) mk[j][i][q] = *(const u32x4*)(p.mask_y + pixIdx[j] * p.Cout + cb);
                 }
     }
+    if (p.pool_mask) {
+        // ---- the 2x2 average of the DBlock (nn.AvgPool2d(2), implementations/StyleGAN2/model.py:204) taken HERE: with TW == 32 a lane's pixels
+        //      j, j + 1 are rows h, h + 1 of one column and lane ^ 1 holds the neighbouring column, so a 2x2 cell is two registers of this
+        //      lane and two of its neighbour.  The values are rounded to bf16 first and summed in agf_pool2x2's order ((a + b) + c) + d:
+        //      bit-identical to conv -> pool2x2, whose full-resolution write and re-read disappear. ----
+        auto value = [&](int j, int i, int q) -> u32x4 {
+            uint32_t P[2][2];
+#pragma unroll
+            for (int r2 = 0; r2 < 2; r2++) {
+                const int rg = 2 * q + r2;
+                const int co = coW + i * 32 + rg * 8 + lhi * 4;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = acc[i][j][rg * 4 + e];
+                if (co < p.Cout) {
+                    if (p.out_scale) {
+                        const f32x4 s = *(const f32x4*)(p.out_scale + (int64_t)nimg[j] * p.Cout + co);
+                        v[0] *= s.x; v[1] *= s.y; v[2] *= s.z; v[3] *= s.w;
+                    }
+                    if (p.bias) {
+                        const f32x4 bb = *(const f32x4*)(p.bias + co);
+                        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] += nz[j];
+                    if (p.act == 3) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) v[e] = v[e] > 0.f ? v[e] : v[e] * p.alpha;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] *= p.gain;
+                }
+                P[r2][0] = Pack16<bf16_t>::pack(v[0], v[1]);
+                P[r2][1] = Pack16<bf16_t>::pack(v[2], v[3]);
+            }
+            const auto s0 = __builtin_amdgcn_permlane32_swap(P[0][0], P[1][0], false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(P[0][1], P[1][1], false, false);
+            return u32x4{s0[0], s1[0], s0[1], s1[1]};
+        };
+        auto unpack8 = [](u32x4 t, float (&f)[8]) {
+            Pack16<bf16_t>::unpack(t.x, f[0], f[1]); Pack16<bf16_t>::unpack(t.y, f[2], f[3]);
+            Pack16<bf16_t>::unpack(t.z, f[4], f[5]); Pack16<bf16_t>::unpack(t.w, f[6], f[7]);
+        };
+        auto bits8 = [](const float (&f)[8]) {
+            unsigned m = 0;
+#pragma unroll
+            for (int e = 0; e < 8; e++) m |= (f[e] > 0.f ? 1u : 0u) << e;
+            return m;
+        };
+        const int cells = (p.H >> 1) * (p.W >> 1);
+#pragma unroll
+        for (int jp = 0; jp < NJ / 2; jp++) {
+            const int j0 = 2 * jp;
+            const int64_t cell = (int64_t)nimg[j0] * cells + hw2[j0];
+#pragma unroll
+            for (int i = 0; i < MT; i++) {
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const u32x4 va = value(j0, i, q), vc = value(j0 + 1, i, q);
+                    u32x4 vb, vd;
+                    vb.x = __shfl_xor(va.x, 1); vb.y = __shfl_xor(va.y, 1); vb.z = __shfl_xor(va.z, 1); vb.w = __shfl_xor(va.w, 1);
+                    vd.x = __shfl_xor(vc.x, 1); vd.y = __shfl_xor(vc.y, 1); vd.z = __shfl_xor(vc.z, 1); vd.w = __shfl_xor(vc.w, 1);
+                    float a[8], b[8], c[8], d[8], o[8];
+                    unpack8(va, a); unpack8(vb, b); unpack8(vc, c); unpack8(vd, d);
+#pragma unroll
+                    for (int e = 0; e < 8; e++) o[e] = (a[e] + b[e] + c[e] + d[e]) * p.pool_gain;
+                    const unsigned word = bits8(a) | (bits8(b) << 8) | (bits8(c) << 16) | (bits8(d) << 24);
+                    const int cb = coW + i * 32 + (2 * q + lhi) * 8;
+                    if (!(l31 & 1) && valid[j0] && cb < p.Cout) {
+                        u32x4 out;
+                        out.x = Pack16<bf16_t>::pack(o[0], o[1]); out.y = Pack16<bf16_t>::pack(o[2], o[3]);
+                        out.z = Pack16<bf16_t>::pack(o[4], o[5]); out.w = Pack16<bf16_t>::pack(o[6], o[7]);
+                        *(u32x4*)(p.y + cell * p.Cout + cb) = out;
+                        p.pool_mask[cell * (p.Cout >> 3) + (cb >> 3)] = word;
+                    }
+                }
+            }
+        }
+        return;
+    }
     float msum[MT * 16];
 #pragma unroll
     for (int e = 0; e < MT * 16; e++) msum[e] = 0.f;
@@ -1657,7 +1737,7 @@ static int launch_fwd(const ConvParams& p, hipStream_t st) {
         else              rc = p.in_scale ? launch_fwd_ws<1, true, 32, 64>(p, st) : launch_fwd_ws<1, false, 32, 64>(p, st);
         if (rc != AGF_ENOKERNEL) return rc;
     }
-    if (g_ws_enable && !p.post_scale && KS == 3 && MT == 1 && p.pixTiles >= 2048 && p.TW == 32 && p.TH == 8 && p.TI == 1 &&
+    if (g_ws_enable && !p.post_scale && !p.pool_mask && KS == 3 && MT == 1 && p.pixTiles >= 2048 && p.TW == 32 && p.TH == 8 && p.TI == 1 &&
         (p.Cin <= 32 || (p.Cin <= 64 && p.Cout <= 32) || (g_ws_enable >= 2 && p.Cin <= 64 && p.Cout <= 64))) {
         int rc;
         constexpr int ws2 = 1;
@@ -1694,7 +1774,7 @@ static int conv2d_fwd_impl(const void* x, const void* w, void* y,
                            int dtype, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
                            int act, float alpha, float act_gain,
                            const void* mask_y, float mask_alpha, float* mask_sum, const void* res_pooled, float res_scale, void* stream,
-                           const float* post_scale = nullptr) {
+                           const float* post_scale = nullptr, void* pool_mask = nullptr, float pool_gain = 0.f) {
     AGF_CHECK(x && w && y, "conv2d_fwd: null pointer");
     AGF_CHECK(dtype == AGF_BF16 || dtype == AGF_F32, "conv2d_fwd: dtype must be bf16 or f32");
     if ((mask_y || res_pooled) && (dtype != AGF_BF16 || (Cout % 8) != 0 || ((uintptr_t)y % 16) != 0 || ((uintptr_t)mask_y % 16) != 0 ||
@@ -1704,6 +1784,11 @@ static int conv2d_fwd_impl(const void* x, const void* w, void* y,
     }
     if (post_scale && (dtype != AGF_BF16 || ksize != 3 || Cout < 64 || mask_y || res_pooled)) {
         agf_set_error("conv2d_fwd: post_scale is served by the bf16 3x3 kernels with >= 64 output channels only");
+        return AGF_ENOKERNEL;
+    }
+    if (pool_mask && (dtype != AGF_BF16 || ksize != 3 || (Cout % 8) || (H & 1) || (W & 1) || W < 32 || mask_y || res_pooled || residual || post_scale ||
+                      ((uintptr_t)y % 16) || ((uintptr_t)pool_mask % 4))) {
+        agf_set_error("conv2d_fwd_pool: bf16 3x3 conv on an even map at least 32 wide, Cout %% 8 == 0, no residual");
         return AGF_ENOKERNEL;
     }
     if (dtype == AGF_F32) {
@@ -1736,6 +1821,7 @@ static int conv2d_fwd_impl(const void* x, const void* w, void* y,
     p.mask_y = (const bf16_t*)mask_y; p.mask_alpha = mask_alpha; p.mask_sum = mask_sum;
     p.res_pooled = (const bf16_t*)res_pooled; p.res_scale = res_scale;
     p.post_scale = post_scale;
+    p.pool_mask = (uint32_t*)pool_mask; p.pool_gain = pool_gain;
     {
         // 1x1 conv from 8 input channels to <= 32 outputs on a large map: the streaming kernel (see conv2d_pw8_kernel)
         constexpr bool pw8 = true;
@@ -1821,6 +1907,10 @@ static int conv2d_fwd_impl(const void* x, const void* w, void* y,
         p.mPW = pw <= 1 ? 0u : (uint32_t)(0xFFFFFFFFull / pw) + 1u;      // exact for operands < 2^16
         p.mPH = ph <= 1 ? 0u : (uint32_t)(0xFFFFFFFFull / ph) + 1u;
     }
+    if (p.pool_mask && (p.TW != 32 || p.flat || p.vecStore != 2 || (p.TH & 1))) {
+        agf_set_error("conv2d_fwd_pool: the tiling of this shape has no 2x2 cells inside a lane pair");
+        return AGF_ENOKERNEL;
+    }
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if (ksize == 3) rc = MT == 2 ? launch_fwd<3, 2>(p, st) : launch_fwd<3, 1>(p, st);
@@ -1837,6 +1927,14 @@ extern "C" int agf_conv2d_fwd(const void* x, const void* w, void* y,
                               int act, float alpha, float act_gain, void* stream) {
     return conv2d_fwd_impl(x, w, y, in_scale, out_scale, bias, noise, residual, dtype, N, H, W, Cin, Cout, ksize, act, alpha, act_gain,
                            nullptr, 0.f, nullptr, nullptr, 0.f, stream);
+}
+
+extern "C" int agf_conv2d_fwd_pool(const void* x, const void* w, void* y_pooled, void* mask, const float* bias,
+                                   int dtype, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
+                                   int act, float alpha, float act_gain, float pool_gain, void* stream) {
+    AGF_CHECK(y_pooled && mask, "conv2d_fwd_pool: null output");
+    return conv2d_fwd_impl(x, w, y_pooled, nullptr, nullptr, bias, nullptr, nullptr, dtype, N, H, W, Cin, Cout, ksize, act, alpha, act_gain,
+                           nullptr, 0.f, nullptr, nullptr, 0.f, stream, nullptr, mask, pool_gain * 0.25f);
 }
 
 extern "C" int agf_conv2d_fwd_post(const void* x, const void* w, void* y,

@@ -39,6 +39,9 @@ struct ConvParams {
     const bf16_t* residual;   // [N,H,W,Cout] or null
     const float* post_scale;  // [N,Cout] or null: the stored output is act(...) * gain * post_scale[n,co] -- the style scale of the NEXT modulated conv,
                               //   this layer's only consumer, which then takes its input unscaled (conv_epilogue / conv_epilogue_pl only)
+    uint32_t* pool_mask;      // or null.  Non-null (agf_conv2d_fwd_pool): y is the POOLED tensor [N][H/2][W/2][Cout] = pool_gain * (sum of the 2x2 cell of the
+    float pool_gain;          //   bf16-rounded epilogue result), pool_mask [N][H/2][W/2][Cout/8] the 1-bit sign mask of the full-resolution result (the format of
+                              //   agf_pool2x2); the full-resolution tensor is never written (conv_epilogue_pl with TW == 32, and the pipe kernel)
     int N, H, W, Cin, Cout;
     int TI, TH, TW;           // pixel tile
     int tilesW, tilesH, tilesN, tilesCo, pixTiles;

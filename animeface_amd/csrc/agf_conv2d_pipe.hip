@@ -67,6 +67,10 @@ static constexpr int pipe_younger(int c, int lpw, int P, int S, int PF) {
 //      more together than the sum of each alone.
 template <int KS, int MT, int NWM, int NWN, int NJ, int NCH, int NSTAGE, int PMAX, int EPI, bool WS>
 __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_pipe_kernel(PipeParams pp) {
+    // EPI 3 (agf_conv2d_fwd_pool): the operands of EPI 0, but what leaves the tile is its 2x2 average and the 1-bit sign mask of the
+    // full-resolution result (see the pooled branch of the epilogue); everywhere else it is EPI 0
+    constexpr bool POOL = EPI == 3;
+    constexpr int EP = POOL ? 0 : EPI;
     const ConvParams& p = pp.c;
     constexpr int NW = NWM * NWN;
     constexpr int TAPS = KS * KS, HALO = KS / 2, BM = 32 * NWM * MT;
@@ -82,7 +86,7 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_pipe_kernel(Pipe
     constexpr int LPW_HI = (NOPS + NW - 1) / NW, LPW_LO = NOPS / NW;
     constexpr int KG = LPW_HI;
     constexpr int PA = MT * NJ * 2;                      // 16-byte vectors of the tile's mask (pooled residual) per lane
-    constexpr int PCNT = EPI == 0 ? NJ : EPI * PA;       // prefetch loads per wave and tile
+    constexpr int PCNT = EP == 0 ? NJ : EP * PA;       // prefetch loads per wave and tile
     constexpr int SCNT = 2 * MT * NJ;                    // stores per wave and tile
     constexpr int PF = NCH >= 2 ? NCH - 2 : 0;           // chunk at whose start the epilogue operands are requested
     constexpr int TCONS = (NSTAGE - 1 + NCH - 1) / NCH;  // first tiles: the conservative wait count (operations of the prologue)
@@ -182,11 +186,12 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_pipe_kernel(Pipe
 #pragma unroll
     for (int i = 0; i < MT; i++) aBase[i] = (wm * 32 * MT + i * 32 + l31) * 16 + ((lhi ^ ((l31 >> 3) & 1)) << 3);
 
-    // ---- epilogue operands that live in registers: the tile's lrelu mask / pooled residual (EPI 1, 2) or its noise (EPI 0) ----
+    // ---- epilogue operands that live in registers: the tile's lrelu mask / pooled residual (EP 1, 2) or its noise (EP 0) ----
     const int coW = wm * 32 * MT;
-    u32x4 preA[EPI >= 1 ? PA : 1], preB[EPI == 2 ? PA : 1];
+    u32x4 preA[EP >= 1 ? PA : 1], preB[EP == 2 ? PA : 1];
     float nzv[NJ];
     int pixOff[NJ];                                                  // byte offset of the lane's pixel j in an image of y (Cout channels), or OOB
+    int cellOff[POOL ? NJ : 1];                                      // POOL: byte offset of the pixel's 2x2 cell in an image of the pooled tensor, or OOB
     auto prefetch = [&](int ord) {
         const int pt = tFirst + ord * nPer;
         const int tw = pt & ((1 << pp.tilesWl2) - 1), th = (pt >> pp.tilesWl2) & ((1 << pp.tilesHl2) - 1), n0 = pt >> (pp.tilesWl2 + pp.tilesHl2);
@@ -200,12 +205,13 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_pipe_kernel(Pipe
             const bool valid = h < p.H && w < p.W;
             pixOff[j] = valid ? (h * p.W + w) * pp.yPix * 2 : PIPE_OOB;
             hw2[j] = valid ? ((h >> 1) * (p.W >> 1) + (w >> 1)) * p.Cout * 2 : PIPE_OOB;
-            if (EPI == 0) {
+            if (POOL) cellOff[j] = hw2[j];
+            if (EP == 0) {
                 const __amdgpu_buffer_rsrc_t nRes = __builtin_amdgcn_make_buffer_rsrc((void*)(p.noise + (int64_t)n0 * p.H * p.W), 0, p.noise ? p.H * p.W * 4 : 0, 0x00020000);
                 nzv[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(nRes, valid ? (h * p.W + w) * 4 : PIPE_OOB, 0, 0));
             }
         }
-        if (EPI >= 1) {
+        if (EP >= 1) {
             const __amdgpu_buffer_rsrc_t mRes = __builtin_amdgcn_make_buffer_rsrc((void*)(p.mask_y + (int64_t)n0 * p.H * p.W * p.Cout), 0, p.mask_y ? outImg : 0, 0x00020000);
             const __amdgpu_buffer_rsrc_t rRes = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res_pooled + (int64_t)n0 * (p.H >> 1) * (p.W >> 1) * p.Cout), 0, p.res_pooled ? outImg >> 2 : 0, 0x00020000);
 #pragma unroll
@@ -214,12 +220,12 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_pipe_kernel(Pipe
                 const int cb = coW + i * 32 + (2 * q + lhi) * 8;
                 const int offA = cb < p.Cout ? pixOff[j] + cb * 2 : PIPE_OOB, offB = cb < p.Cout ? hw2[j] + cb * 2 : PIPE_OOB;
                 preA[s] = __builtin_amdgcn_raw_buffer_load_b128(mRes, offA, 0, 0);
-                if (EPI == 2) preB[s] = __builtin_amdgcn_raw_buffer_load_b128(rRes, offB, 0, 0);
+                if (EP == 2) preB[s] = __builtin_amdgcn_raw_buffer_load_b128(rRes, offB, 0, 0);
             }
         }
     };
 
-    float msumAcc = 0.f;                                             // EPI >= 1: this lane's share of the masked channel sums (see the flush)
+    float msumAcc = 0.f;                                             // EP >= 1: this lane's share of the masked channel sums (see the flush)
     int msumIdx = 0;
 
     f32x16 acc[MT][NJ];
@@ -243,8 +249,82 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_pipe_kernel(Pipe
                     }
             return;
         }
-        float msum[EPI >= 1 ? MT * 16 : 1];
-        if (EPI >= 1) {
+        if (POOL) {
+            // lane pixels j, j + 1 are rows h, h + 1 of one column (TW == 32), lane ^ 1 holds the neighbouring column: a 2x2 cell is two
+            // registers here and two there.  Rounded to bf16 first and summed as agf_pool2x2 does, ((a + b) + c) + d: bit-identical to
+            // conv -> pool2x2 without the full-resolution write and re-read.  Same number of stores per wave as the plain epilogue
+            // (NJ / 2 * MT * 2 vectors + as many mask words = 2 MT NJ), so the counted waits hold.
+            const int cells = (p.H >> 1) * (p.W >> 1);
+            const __amdgpu_buffer_rsrc_t pRes = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (int64_t)n0 * cells * p.Cout), 0, cells * p.Cout * 2, 0x00020000);
+            const __amdgpu_buffer_rsrc_t kRes = __builtin_amdgcn_make_buffer_rsrc((void*)(p.pool_mask + (int64_t)n0 * cells * (p.Cout >> 3)), 0, cells * (p.Cout >> 3) * 4, 0x00020000);
+            auto value = [&](int j, int i, int q) -> u32x4 {
+                uint32_t Pk[2][2];
+#pragma unroll
+                for (int r2 = 0; r2 < 2; r2++) {
+                    const int rg = 2 * q + r2;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = acc[i][j][rg * 4 + e];
+                    const int co = coW + i * 32 + rg * 8 + lhi * 4;
+                    const f32x4 bb = *(const f32x4*)(side + 64 + co);
+                    if (p.out_scale) {
+                        const f32x4 os = *(const f32x4*)(side + co);
+                        v[0] *= os.x; v[1] *= os.y; v[2] *= os.z; v[3] *= os.w;
+                    }
+                    v[0] += bb.x + nzv[j]; v[1] += bb.y + nzv[j]; v[2] += bb.z + nzv[j]; v[3] += bb.w + nzv[j];
+                    if (p.act == 3) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) v[e] = v[e] > 0.f ? v[e] : v[e] * p.alpha;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] *= p.gain;
+                    Pk[r2][0] = Pack16<bf16_t>::pack(v[0], v[1]);
+                    Pk[r2][1] = Pack16<bf16_t>::pack(v[2], v[3]);
+                }
+                const auto s0 = __builtin_amdgcn_permlane32_swap(Pk[0][0], Pk[1][0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(Pk[0][1], Pk[1][1], false, false);
+                return u32x4{s0[0], s1[0], s0[1], s1[1]};
+            };
+            auto unpack8 = [](u32x4 t, float (&f)[8]) {
+                Pack16<bf16_t>::unpack(t.x, f[0], f[1]); Pack16<bf16_t>::unpack(t.y, f[2], f[3]);
+                Pack16<bf16_t>::unpack(t.z, f[4], f[5]); Pack16<bf16_t>::unpack(t.w, f[6], f[7]);
+            };
+            auto bits8 = [](const float (&f)[8]) {
+                unsigned m = 0;
+#pragma unroll
+                for (int e = 0; e < 8; e++) m |= (f[e] > 0.f ? 1u : 0u) << e;
+                return m;
+            };
+#pragma unroll
+            for (int jp = 0; jp < NJ / 2; jp++) {
+                const int j0 = 2 * jp;
+#pragma unroll
+                for (int i = 0; i < MT; i++) {
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        const u32x4 va = value(j0, i, q), vc = value(j0 + 1, i, q);
+                        u32x4 vb, vd;
+                        vb.x = __shfl_xor(va.x, 1); vb.y = __shfl_xor(va.y, 1); vb.z = __shfl_xor(va.z, 1); vb.w = __shfl_xor(va.w, 1);
+                        vd.x = __shfl_xor(vc.x, 1); vd.y = __shfl_xor(vc.y, 1); vd.z = __shfl_xor(vc.z, 1); vd.w = __shfl_xor(vc.w, 1);
+                        float a[8], b[8], c[8], d[8], o[8];
+                        unpack8(va, a); unpack8(vb, b); unpack8(vc, c); unpack8(vd, d);
+#pragma unroll
+                        for (int e = 0; e < 8; e++) o[e] = (a[e] + b[e] + c[e] + d[e]) * p.pool_gain;
+                        const unsigned word = bits8(a) | (bits8(b) << 8) | (bits8(c) << 16) | (bits8(d) << 24);
+                        const int cb = coW + i * 32 + (2 * q + lhi) * 8;
+                        const bool keep = !(l31 & 1) && cellOff[j0] != PIPE_OOB && cb < p.Cout;
+                        u32x4 out;
+                        out.x = Pack16<bf16_t>::pack(o[0], o[1]); out.y = Pack16<bf16_t>::pack(o[2], o[3]);
+                        out.z = Pack16<bf16_t>::pack(o[4], o[5]); out.w = Pack16<bf16_t>::pack(o[6], o[7]);
+                        __builtin_amdgcn_raw_buffer_store_b128(out, pRes, keep ? cellOff[j0] + cb * 2 : PIPE_OOB, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(word, kRes, keep ? (cellOff[j0] >> 2) + (cb >> 1) : PIPE_OOB, 0, 0);
+                    }
+                }
+            }
+            return;
+        }
+        float msum[EP >= 1 ? MT * 16 : 1];
+        if (EP >= 1) {
 #pragma unroll
             for (int e = 0; e < MT * 16; e++) msum[e] = 0.f;
         }
@@ -261,7 +341,7 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_pipe_kernel(Pipe
                         float v[4];
 #pragma unroll
                         for (int e = 0; e < 4; e++) v[e] = acc[i][j][rg * 4 + e];
-                        if (EPI == 0) {
+                        if (EP == 0) {
                             const int co = coW + i * 32 + rg * 8 + lhi * 4;
                             const f32x4 bb = *(const f32x4*)(side + 64 + co);
                             if (p.out_scale) {
@@ -283,12 +363,12 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_pipe_kernel(Pipe
                     const auto s1 = __builtin_amdgcn_permlane32_swap(Pk[0][1], Pk[1][1], false, false);
                     u32x4 val = {s0[0], s1[0], s0[1], s1[1]};
                     const int cb = coW + i * 32 + (2 * q + lhi) * 8;
-                    if (EPI >= 1) {
+                    if (EP >= 1) {
                         const int s = (j * MT + i) * 2 + q;
                         float g[8];
                         Pack16<bf16_t>::unpack(val.x, g[0], g[1]); Pack16<bf16_t>::unpack(val.y, g[2], g[3]);
                         Pack16<bf16_t>::unpack(val.z, g[4], g[5]); Pack16<bf16_t>::unpack(val.w, g[6], g[7]);
-                        if (EPI == 2) {   // pooled residual (zeros when absent)
+                        if (EP == 2) {   // pooled residual (zeros when absent)
                             float rv[8];
                             Pack16<bf16_t>::unpack(preB[s].x, rv[0], rv[1]); Pack16<bf16_t>::unpack(preB[s].y, rv[2], rv[3]);
                             Pack16<bf16_t>::unpack(preB[s].z, rv[4], rv[5]); Pack16<bf16_t>::unpack(preB[s].w, rv[6], rv[7]);
@@ -314,7 +394,7 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_pipe_kernel(Pipe
                 }
             }
         }
-        if (EPI >= 1) {
+        if (EP >= 1) {
             // halving butterfly over the 32 lanes of each half-wave (see conv_epilogue_pl): lane l keeps the total of value index
             // bit0*NV/2 + bit1*NV/4 + ... ; accumulated over the block's tiles in ONE register
             constexpr int NV = MT * 16;
@@ -430,7 +510,7 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_pipe_kernel(Pipe
         });
     }
 
-    if (EPI >= 1 && p.mask_y && p.mask_sum) {             // block-uniform
+    if (EP >= 1 && p.mask_y && p.mask_sum) {             // block-uniform
         // add the waves that share the channels through LDS, then ONE atomic per channel and block
         red[wave * 64 + lane] = msumAcc;
         __syncthreads();
@@ -463,6 +543,12 @@ static int launch_pipe_e(const PipeParams& pp, int blocksPerCU, hipStream_t st) 
 
 template <int KS, int MT, int NWM, int NWN, int NJ, int NCH, int NSTAGE, int PMAX, bool WS = false>
 static int launch_pipe(const PipeParams& pp, int blocksPerCU, hipStream_t st) {
+    if (pp.c.pool_mask) {
+        // conv + lrelu + 2x2 average + sign mask: instantiated for the one shape class the networks pool after on this kernel (the
+        // discriminator's 64 -> 64 conv on the 256 x 256 / 128 x 128 maps: 33..64 output channels, Cin 64, shared weights)
+        if constexpr (MT == 2 && NCH == 4 && WS && NJ % 2 == 0) return launch_pipe_e<KS, MT, NWM, NWN, NJ, NCH, NSTAGE, PMAX, 3, WS>(pp, blocksPerCU, st);
+        else return AGF_ENOKERNEL;
+    }
     if (pp.c.res_pooled) return launch_pipe_e<KS, MT, NWM, NWN, NJ, NCH, NSTAGE, PMAX, 2, WS>(pp, blocksPerCU, st);
     if (pp.c.mask_y)     return launch_pipe_e<KS, MT, NWM, NWN, NJ, NCH, NSTAGE, PMAX, 1, WS>(pp, blocksPerCU, st);
     return launch_pipe_e<KS, MT, NWM, NWN, NJ, NCH, NSTAGE, PMAX, 0, WS>(pp, blocksPerCU, st);
@@ -482,7 +568,7 @@ int agf_conv2d_pipe_launch(const ConvParams& p0, hipStream_t st) {
     // 128-channel kernel has only 2-4 K chunks per tile to amortise its prologue and epilogue over (590 TFLOP/s); two launches of this
     // kernel, one per 64-channel half of the weights, each writing its channel slice of y, are faster (the second reads x from L2 / MALL)
     constexpr int split = 1;
-    if (split && p0.Cout == 128 && (p0.Cin == 32 || p0.Cin == 64) && !p0.mask_y && !p0.res_pooled && !p0.out_scale && !p0.in_scale && !p0.residual &&
+    if (split && !p0.pool_mask && p0.Cout == 128 && (p0.Cin == 32 || p0.Cin == 64) && !p0.mask_y && !p0.res_pooled && !p0.out_scale && !p0.in_scale && !p0.residual &&
         !p0.noise && ((uintptr_t)p0.y % 16) == 0 && pipe_covers(p0.N, p0.H, p0.W, p0.Cin, 64)) {
         for (int half = 0; half < 2; half++) {
             ConvParams q = p0;
@@ -558,6 +644,7 @@ static int pipe_launch(const ConvParams& p0, int64_t wImgStride, hipStream_t st,
     ConvParams p = p0;
     if (p.in_scale || p.residual) return AGF_ENOKERNEL;
     if ((p.mask_y || p.res_pooled) && (p.out_scale || p.bias || p.noise)) return AGF_ENOKERNEL;
+    if (p.pool_mask && ((p.H & 1) || (p.W & 1) || (p.H % 16) || (p.W % 32) || yPix)) return AGF_ENOKERNEL;      // whole tiles only: every 2x2 cell inside one
     if (((uintptr_t)p.y % 16) || !pipe_covers(p.N, p.H, p.W, p.Cin, p.Cout)) return AGF_ENOKERNEL;
     p.flat = 0; p.TI = 1; p.TW = 32; p.TH = 16; p.twShift = 5; p.thShift = 4;
     p.tilesW = (p.W + 31) / 32; p.tilesH = (p.H + 15) / 16; p.tilesN = p.N; p.tilesCo = 1;

@@ -215,6 +215,28 @@ def conv2d_fwd_raw(x, w, in_scale=None, out_scale=None, bias=None, noise=None, r
     return y
 
 
+def conv2d_fwd_pool_raw(x, wq, bias, alpha, gain, pool_gain):
+    """``agf_conv2d_fwd_pool``: pool_gain * AvgPool2d(2)(lrelu(conv(x, wq) + bias) * gain) and the 1-bit sign mask of the un-pooled result,
+    without writing it.  ``wq``: prepared OHWI weights.  Returns (pooled, mask), or None when no kernel covers the shape."""
+    N, Cin, H, W = x.shape
+    Cout, k = wq.shape[0], wq.shape[2]
+    if x.dtype != torch.bfloat16 or k != 3 or Cout % 8 or H % 2 or W % 2 or W < 32:
+        return None
+    x = x.contiguous(memory_format=torch.channels_last)
+    y = torch.empty((N, Cout, H // 2, W // 2), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    mask = torch.empty((N, H // 2, W // 2, Cout // 8), dtype=torch.int32, device=x.device)
+    timer = KernelTimer.active
+    ev0 = timer.start() if timer is not None else None
+    rc = _lib.lib().agf_conv2d_fwd_pool(_lib.ptr(x), _lib.ptr(wq), _lib.ptr(y), _lib.ptr(mask), _lib.ptr(_f32(bias)), _lib.dtype_code(x),
+                                        N, H, W, Cin, Cout, k, ACT_LRELU, float(alpha), float(gain), float(pool_gain), _lib.stream_ptr(x))
+    if rc == _lib.AGF_ENOKERNEL:
+        return None
+    if timer is not None:
+        timer.stop('conv2d_fwd_kernel', ev0, 2.0 * N * H * W * Cin * Cout * k * k, (N, Cin, Cout, H, W, k, False, False))
+    _lib.check(rc, 'conv2d_fwd_pool')
+    return y, mask
+
+
 @functools.lru_cache(maxsize=None)
 def _wgrad_workspace_bytes(dtype_code, N, H, W, Cin, Cout, ksize, scaled):
     return int(_lib.lib().agf_conv2d_wgrad_workspace_bytes(dtype_code, N, H, W, Cin, Cout, ksize, int(scaled)))
@@ -550,12 +572,14 @@ def pool2x2_raw(x, gain=1.0, want_mask=False):
 
 def act_bwd_reduce_pooled_mask_raw(dy_half, mask, like, alpha, dy_scale, want_sum):
     """``agf_act_bwd_reduce_pooled_mask``: as ``act_bwd_reduce_pooled_raw`` with the sign of y read from the 1-bit mask."""
+    if not isinstance(like, torch.Tensor):            # (the shape of y: the tensor itself may never have been written, ``conv2d_fwd_pool_raw``)
+        like = torch.empty(tuple(like), dtype=dy_half.dtype, device='meta')
     N, C, H, W = like.shape
     assert dy_half.shape == (N, C, H // 2, W // 2) and dy_half.dtype == like.dtype and mask.shape == (N, H // 2, W // 2, C // 8)
-    g = torch.empty_like(like)
-    B = _zeros_f32((N, C), like.device) if want_sum else None
+    g = torch.empty((N, C, H, W), dtype=dy_half.dtype, device=dy_half.device, memory_format=torch.channels_last)
+    B = _zeros_f32((N, C), dy_half.device) if want_sum else None
     rc = _lib.lib().agf_act_bwd_reduce_pooled_mask(_lib.ptr(dy_half), _lib.ptr(mask), _lib.ptr(g), _lib.ptr(B),
-                                                   _lib.dtype_code(like), N, H, W, C, float(alpha), float(dy_scale), _lib.stream_ptr(like))
+                                                   _lib.dtype_code(dy_half), N, H, W, C, float(alpha), float(dy_scale), _lib.stream_ptr(dy_half))
     _lib.check(rc, 'act_bwd_reduce_pooled_mask')
     return g, B
 
@@ -1013,6 +1037,7 @@ def torgb(x, weight, bias, s_raw, pre, coef):
 
 
 POOL_KERNEL = True     # agf_pool2x2 for the DBlock's AvgPool2d(2) (False: the [1,1] box FIR of upfirdn2d; tests compare the two)
+FUSE_POOL = True       # the DBlock's last conv writes its 2x2 average + sign mask instead of the activation (agf_conv2d_fwd_pool; tests compare both ways)
 POSTSCALE_X = True     # the first modulated conv of a StyleBlock stores its output times the second one's style scale (>= 128 channels), which then
 #                        runs on the unscaled (direct-to-LDS) kernel forward and in its weight gradient (tests compare both ways)
 PRESCALE_G = True      # a modulated layer's gradient tensor is stored times its demodulation scale by the pass that makes it (tests compare both ways)
@@ -1032,8 +1057,32 @@ class _FusedConv(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, coef, s_in, s_out, bias, noise, residual, act, alpha, gain, pre_link=None, post_link=None, skip_pool=None,
-                post_scale=None):
+                post_scale=None, out_pool=None):
         prep = prepared_weights(weight, coef, x.dtype)
+        ctx.out_pool = None
+        if out_pool is not None:
+            # ``out_pool = (f, pool_gain)``: the op returns pool_gain * AvgPool2d(2)(y) INSTEAD of y (the last conv of a DBlock, whose only
+            # consumer is the pooling).  One launch writes the pooled tensor and the 1-bit sign mask the backward needs; y never exists.
+            assert s_in is None and s_out is None and noise is None and residual is None and skip_pool is None and post_link is None \
+                and post_scale is None and act == ACT_LRELU
+            f, pool_gain = out_pool
+            res = conv2d_fwd_pool_raw(x, prep.wq, bias, alpha, gain, pool_gain) if (FUSE_POOL and x.is_cuda) else None
+            y = None
+            if res is None:
+                y = conv2d_fwd_raw(x, prep.wq, bias=bias, act=act, alpha=alpha, gain=gain, prepared=True)
+                if POOL_KERNEL and pool2x2_covers(y) and y.dtype == torch.bfloat16:
+                    res = pool2x2_raw(y, pool_gain, True)
+                    y = None
+                else:
+                    from ...stylegan3_ops import upfirdn2d
+                    res = (upfirdn2d.downsample2d(y, f, down=2, gain=pool_gain), None)
+            tp, mask = res
+            ctx.save_for_backward(x, weight, None, None, bias, None, y)
+            ctx.coef, ctx.act, ctx.alpha, ctx.gain = coef, act, alpha, gain
+            ctx.has_residual, ctx.pre_link, ctx.post_link, ctx.pool = False, pre_link, None, None
+            ctx.x_pre, ctx.post = False, None
+            ctx.out_pool = (f, float(pool_gain), mask, (x.shape[0], weight.shape[0], x.shape[2], x.shape[3]))
+            return tp
         # this layer's input arrives already times s_in when its producer said so on the link (POSTSCALE_X)
         x_pre = pre_link is not None and pre_link.yscaled and s_in is not None
         # ... and this layer scales its own output for its consumer when the chain hand-off below will be armed and the layers are wide
@@ -1075,9 +1124,27 @@ class _FusedConv(torch.autograd.Function):
         need_x, need_w, _, need_si, need_so, need_b, _, need_r = ctx.needs_input_grad[:8]
         need_r = need_r and ctx.has_residual
         link = ctx.post_link
-        pooled = None
-        if link is not None and link.pooled is not None:
+        pooled = pmask = None
+        y_like = y
+        if ctx.out_pool is not None:
+            # dy is the gradient of the POOLED output
+            f, pool_gain, omask, y_shape = ctx.out_pool
+            if not torch.is_grad_enabled() and omask is not None and x.dtype == torch.bfloat16:
+                pooled, pmask, y_like = (dy.to(x.dtype).contiguous(memory_format=torch.channels_last), pool_gain * 0.25), omask, y_shape
+            else:
+                # a graph is being recorded (R1), or no mask: the ordinary differentiable adjoint of the pooling on the full-resolution
+                # lattice, and the activation recomputed (it was never stored; one more forward launch in the lazy-R1 iterations only)
+                from ...stylegan3_ops import upfirdn2d
+                if y is None:
+                    y = conv2d_fwd_raw(x.detach(), prepared_weights(weight, coef, x.dtype).wq, bias=bias, act=act, alpha=alpha, gain=gain, prepared=True)
+                _, _, ih, iw = y.shape
+                _, _, oh, ow = dy.shape
+                dy = upfirdn2d.upfirdn2d(dy, f, up=2, padding=[1, iw - 2 * ow, 1, ih - 2 * oh], flip_filter=True, gain=pool_gain)
+                dy = dy.to(x.dtype).contiguous(memory_format=torch.channels_last)
+                y_like = y
+        elif link is not None and link.pooled is not None:
             pooled, link.pooled = link.pooled, None                 # dy is a zero-stride placeholder: the real gradient is pooled[0]
+            pmask, link.mask = link.mask, None
         else:
             dy = dy.to(x.dtype).contiguous(memory_format=torch.channels_last)
         k = weight.shape[2]
@@ -1117,7 +1184,7 @@ class _FusedConv(torch.autograd.Function):
                     dx = dx + dx_pool
             if need_w:
                 dw = (_ConvWgrad.apply(x, g, None, None, k) * coef).to(weight.dtype)
-            return dx, dw, None, None, None, db, None, dres, None, None, None, None, None, None, None
+            return dx, dw, None, None, None, db, None, dres, None, None, None, None, None, None, None, None
         # the output gain is not applied to the gradient tensor: it rides along in the data-gradient launch's epilogue gain, in the
         # weight-gradient scale and in the bias sum (no pass over the tensor for it)
         pg = float(gain)
@@ -1125,9 +1192,9 @@ class _FusedConv(torch.autograd.Function):
         # and weight-gradient launches below take it without an operand scale (their faster unscaled variants)
         g_scaled = False
         if pooled is not None:
-            mask, link.mask = link.mask, None
+            mask = pmask
             if mask is not None:
-                g, B = act_bwd_reduce_pooled_mask_raw(pooled[0], mask, y, alpha, pooled[1], need_b and bias is not None)
+                g, B = act_bwd_reduce_pooled_mask_raw(pooled[0], mask, y_like, alpha, pooled[1], need_b and bias is not None)
             else:
                 g, B = act_bwd_reduce_pooled_raw(pooled[0], y, alpha, pooled[1], need_b and bias is not None)
             if need_b and bias is not None:
@@ -1205,11 +1272,11 @@ class _FusedConv(torch.autograd.Function):
             dx = dx_pool
         if need_w:
             dw = conv2d_wgrad_raw(x, g, k, in_scale=None if x_pre else s_in, out_scale=None if g_scaled else s_out, scale=coef * pg).to(weight.dtype)
-        return dx, dw, None, dsi, dso, db, None, dres, None, None, None, None, None, None, None
+        return dx, dw, None, dsi, dso, db, None, dres, None, None, None, None, None, None, None, None
 
 
 def conv2d_act(x, weight, bias=None, s_in=None, s_out=None, noise=None, alpha=0.2, fused=True, coef=1.0,
-               act='lrelu', residual=None, gain=1.0, pre_link=None, post_link=None, skip_pool=None, post_scale=None):
+               act='lrelu', residual=None, gain=1.0, pre_link=None, post_link=None, skip_pool=None, post_scale=None, out_pool=None):
     """act( s_out * conv(x * s_in, weight * coef) + bias + noise + residual ) * gain; act = 'lrelu' | 'linear'.
     bias [Cout], noise [N,1,H,W] (no gradient), residual like the output.
     ``fused=False`` evaluates the same expression with the separately differentiable ops (any-order gradients).
@@ -1233,7 +1300,8 @@ def conv2d_act(x, weight, bias=None, s_in=None, s_out=None, noise=None, alpha=0.
                 return _FusedConv.apply(x, weight, coef, s_in, s_out, bias, noise, residual,
                                         ACT_LRELU if act == 'lrelu' else ACT_LINEAR, alpha, gain, pre_link, post_link, None), tp
         return _FusedConv.apply(x, weight, coef, s_in, s_out, bias, noise, residual,
-                                ACT_LRELU if act == 'lrelu' else ACT_LINEAR, alpha, gain, pre_link, post_link, skip_pool, post_scale)
+                                ACT_LRELU if act == 'lrelu' else ACT_LINEAR, alpha, gain, pre_link, post_link, skip_pool, post_scale, out_pool)
+    assert out_pool is None, 'out_pool is a feature of the fused path'
     x_in = x
     out = conv2d(x, weight * coef if coef != 1.0 else weight, s_in, s_out)
     if noise is not None:

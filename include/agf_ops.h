@@ -159,6 +159,16 @@ int agf_conv2d_fwd_post(const void* x, const void* w, void* y,
                         int dtype, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
                         int act, float alpha, float act_gain, void* stream);
 
+/* Conv + bias + lrelu + nn.AvgPool2d(2) in one launch (ABI v20): the last conv of a DBlock (implementations/StyleGAN2/model.py:186-212) is
+ * consumed only by the 2x2 average.  y_pooled [N][H/2][W/2][Cout] = pool_gain / 4 * (sum of the 2x2 cell of the bf16-rounded epilogue
+ * result) -- bit-identical to agf_conv2d_fwd followed by agf_pool2x2 -- and mask [N][H/2][W/2][Cout/8] the 1-bit sign mask of the
+ * full-resolution result in agf_pool2x2's format (what agf_act_bwd_reduce_pooled_mask reads); the full-resolution activation is never
+ * written.  bf16, 3x3, even maps at least 32 wide whose tiling keeps a 2x2 cell inside a lane pair; AGF_ENOKERNEL otherwise (callers
+ * then run the two launches). */
+int agf_conv2d_fwd_pool(const void* x, const void* w, void* y_pooled, void* mask, const float* bias,
+                        int dtype, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
+                        int act, float alpha, float act_gain, float pool_gain, void* stream);
+
 /* agf_conv2d_fwd (linear epilogue) for data-gradient launches, with up to two more autograd nodes folded into the same epilogue:
  *   t = epilogue(...)                                        as agf_conv2d_fwd
  *   t += res_scale * res_pooled[n, h/2, w/2, co]             res_pooled [N,H/2,W/2,Cout], nullable: the gradient that reaches this conv's

@@ -376,6 +376,70 @@ def test_act_bwd_reduce_pooled_vs_composite(shape):
     assert rel(B, ref.sum((2, 3))) < 5e-3
 
 
+POOL_CASES = [(4, 32, 64, 64, 64, '64 co x 256 px tiles (generic kernel)'), (16, 64, 64, 256, 256, 'persistent streaming kernel (64 -> 64 @256x256)'),
+              (8, 128, 128, 128, 128, '128 co x 512 px tiles (direct-to-LDS)'), (6, 64, 136, 32, 96, 'partial co tile, several column tiles'),
+              (3, 64, 64, 16, 16, 'map narrower than a tile row: no kernel, two launches')]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', POOL_CASES, ids=[c[-1] for c in POOL_CASES])
+def test_conv_fwd_pool_is_bit_identical_to_conv_then_pool2x2(case):
+    """agf_conv2d_fwd_pool (conv + bias + lrelu + 2x2 average + 1-bit sign mask, the activation never written) against agf_conv2d_fwd followed
+    by agf_pool2x2 with the mask: the pooled tensor and the mask must be IDENTICAL (the epilogue rounds to bf16 first and sums in pool2x2's
+    order), on every kernel family that carries the pooled epilogue; shapes without one return None."""
+    from animeface_amd.implementations.StyleGAN2.conv import conv2d_fwd_raw, conv2d_fwd_pool_raw, pool2x2_raw, prep_weights_raw, ACT_LRELU
+    N, Cin, Cout, H, W, what = case
+    x, w, g = make(N, Cin, Cout, H, W, 3)
+    bias = torch.randn(Cout, generator=g).to(DEV)
+    wq = prep_weights_raw(w.float(), 0.9, torch.bfloat16)[0]
+    res = conv2d_fwd_pool_raw(x, wq, bias, 0.2, 1.0, 0.7)
+    if W < 32:
+        assert res is None
+        return
+    assert res is not None, what
+    y = conv2d_fwd_raw(x, wq, bias=bias, act=ACT_LRELU, alpha=0.2, gain=1.0, prepared=True)
+    tp_ref, mask_ref = pool2x2_raw(y, 0.7, True)
+    assert torch.equal(res[0], tp_ref) and torch.equal(res[1], mask_ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(4, 32, 64, 64, 64), (16, 64, 64, 256, 256), (4, 64, 128, 128, 128)], ids=['64x64', '256x256-streaming', '128x128-128ch'])
+def test_dblock_with_the_pooled_conv_output_matches_conv_then_pool(monkeypatch, shape):
+    """conv.FUSE_POOL: the DBlock's last conv returns its 2x2 average (one autograd node, the activation never stored) -- against the same
+    block with the separate pooling op: identical output, gradients equal up to the order of the bias-sum atomics."""
+    from animeface_amd.implementations.StyleGAN2 import model as M, conv as C
+    N, Cin, Cout, H, W = shape
+    torch.manual_seed(3)
+    blk = M.DBlock(Cin, Cout).to(DEV)
+    blk.apply(M.init_weight_N01)
+    x0 = torch.randn(N, Cin, H, W, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(N, Cout, H // 2, W // 2, device=DEV).to(torch.bfloat16)
+    outs = []
+    for on in (True, False):
+        monkeypatch.setattr(C, 'FUSE_POOL', on)
+        x = x0.clone().requires_grad_(True)
+        y = blk(x)
+        grads = torch.autograd.grad(y, [x] + list(blk.parameters()), gy)
+        outs.append((y, grads))
+    assert rel(outs[0][0], outs[1][0]) == 0
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert rel(a, b) < 1e-3, (a.shape, rel(a, b))
+    # second order (the lazy-R1 iteration differentiates the discriminator twice): the activation is recomputed, same numbers
+    if H <= 64:
+        vals = []
+        for on in (True, False):
+            monkeypatch.setattr(C, 'FUSE_POOL', on)
+            x = x0.clone().requires_grad_(True)
+            (gx,) = torch.autograd.grad(blk(x).float().sum(), x, create_graph=True)
+            pen = gx.float().square().sum()
+            vals.append(torch.autograd.grad(pen, list(blk.parameters()), allow_unused=True))
+        for a, b in zip(vals[0], vals[1]):
+            if a is None:
+                assert b is None
+            else:
+                assert rel(a, b) < 2e-2, (a.shape, rel(a, b))
+
+
 @pytest.mark.gpu
 def test_dblock_linked_backward_matches_unlinked(monkeypatch):
     """DBlock with the PremaskLink / pooled-gradient fusions against the same block with them switched off (bf16, same inputs)."""
