@@ -179,12 +179,18 @@ static __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16
 //      exposed per tile instead of one per 32-pixel strip.
 //      Channel sums of the masked output: 16*MT values per lane, reduced over the 32 lanes of a half-wave with a halving butterfly
 //      (each step a lane keeps the half of the values its lane bit selects: 16*MT - 1 shuffles instead of 5 * 16*MT). ----
-template <int MT, int NJ>
+// PLAIN: the launch has no lrelu mask, no pooled residual and no residual operand (every forward conv and the unfused data gradients): an
+// instantiation without their registers (the mask vectors alone are 64 VGPRs of the general epilogue, which spills 20)
+template <int MT, int NJ, bool POOL = false, bool PLAIN = false>
 static __device__ __forceinline__ void conv_epilogue_pl(const ConvParams& p, f32x16 (&acc)[MT][NJ], unsigned char* smem_raw,
                                                         int wave, int lane, int wm, int wn, int n0, int h0, int w0, int flatP0, int co0,
                                                         int nwn, int nwaves, int slot) {
     const int l31 = lane & 31, lhi = lane >> 5;
     const int coW = co0 + wm * 32 * MT;
+    // (compile-time nulls in the PLAIN instantiation: the branches below and their registers disappear)
+    const bf16_t* const mask_y = PLAIN ? nullptr : p.mask_y;
+    const bf16_t* const res_pooled = PLAIN ? nullptr : p.res_pooled;
+    const bf16_t* const residual = PLAIN ? nullptr : p.residual;
     int64_t pixIdx[NJ]; int nimg[NJ]; bool valid[NJ]; float nz[NJ]; int hw2[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; j++) {
@@ -201,7 +207,7 @@ static __device__ __forceinline__ void conv_epilogue_pl(const ConvParams& p, f32
     }
     // the mask operand: this lane's post-swap vectors (pixel j, channel group (i, 2q + lhi))
     u32x4 mk[NJ][MT][2];
-    if (p.mask_y) {
+    if (mask_y) {
 #pragma unroll
         for (int j = 0; j < NJ; j++)
 #pragma unroll
@@ -210,10 +216,12 @@ static __device__ __forceinline__ void conv_epilogue_pl(const ConvParams& p, f32
                 for (int q = 0; q < 2; q++) {
                     const int cb = coW + i * 32 + (2 * q + lhi) * 8;
                     mk[j][i][q] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
-                    if (valid[j] && cb < p.Cout) mk[j][i][q] = *(const u32x4*)(p.mask_y + pixIdx[j] * p.Cout + cb);
+                    if (valid[j] && cb < p.Cout) mk[j][i][q] = *(const u32x4*)(mask_y + pixIdx[j] * p.Cout + cb);
                 }
     }
-    if (p.pool_mask) {
+    // (POOL is an instantiation of its own: as a run-time branch of the common epilogue it cost EVERY launch of the direct-to-LDS kernel
+    //  73-80 spilled registers instead of 20, and the conv family 865 -> 840 TFLOP/s)
+    if constexpr (POOL) {
         // ---- the 2x2 average of the DBlock (nn.AvgPool2d(2), implementations/StyleGAN2/model.py:204) taken HERE: with TW == 32 a lane's pixels
         //      j, j + 1 are rows h, h + 1 of one column and lane ^ 1 holds the neighbouring column, so a 2x2 cell is two registers of this
         //      lane and two of its neighbour.  The values are rounded to bf16 first and summed in agf_pool2x2's order ((a + b) + c) + d:
@@ -269,25 +277,33 @@ static __device__ __forceinline__ void conv_epilogue_pl(const ConvParams& p, f32
             const int64_t cell = (int64_t)nimg[j0] * cells + hw2[j0];
 #pragma unroll
             for (int i = 0; i < MT; i++) {
-#pragma unroll
-                for (int q = 0; q < 2; q++) {
-                    const u32x4 va = value(j0, i, q), vc = value(j0 + 1, i, q);
-                    u32x4 vb, vd;
-                    vb.x = __shfl_xor(va.x, 1); vb.y = __shfl_xor(va.y, 1); vb.z = __shfl_xor(va.z, 1); vb.w = __shfl_xor(va.w, 1);
-                    vd.x = __shfl_xor(vc.x, 1); vd.y = __shfl_xor(vc.y, 1); vd.z = __shfl_xor(vc.z, 1); vd.w = __shfl_xor(vc.w, 1);
-                    float a[8], b[8], c[8], d[8], o[8];
-                    unpack8(va, a); unpack8(vb, b); unpack8(vc, c); unpack8(vd, d);
-#pragma unroll
-                    for (int e = 0; e < 8; e++) o[e] = (a[e] + b[e] + c[e] + d[e]) * p.pool_gain;
-                    const unsigned word = bits8(a) | (bits8(b) << 8) | (bits8(c) << 16) | (bits8(d) << 24);
-                    const int cb = coW + i * 32 + (2 * q + lhi) * 8;
-                    if (!(l31 & 1) && valid[j0] && cb < p.Cout) {
-                        u32x4 out;
-                        out.x = Pack16<bf16_t>::pack(o[0], o[1]); out.y = Pack16<bf16_t>::pack(o[2], o[3]);
-                        out.z = Pack16<bf16_t>::pack(o[4], o[5]); out.w = Pack16<bf16_t>::pack(o[6], o[7]);
-                        *(u32x4*)(p.y + cell * p.Cout + cb) = out;
-                        p.pool_mask[cell * (p.Cout >> 3) + (cb >> 3)] = word;
-                    }
+                // the lanes of a pair share the work: the even lane (column w) pools channel group 2*0 + lhi, the odd one (column w + 1) group
+                // 2*1 + lhi; each sends the other the two vectors it does not pool itself (DPP) and every lane stores
+                const bool odd = (l31 & 1) != 0;
+                const u32x4 a0 = value(j0, i, 0), a1 = value(j0, i, 1), c0 = value(j0 + 1, i, 0), c1 = value(j0 + 1, i, 1);
+                u32x4 mineA, mineC, recvA, recvC;
+                mineA.x = odd ? a1.x : a0.x; mineA.y = odd ? a1.y : a0.y; mineA.z = odd ? a1.z : a0.z; mineA.w = odd ? a1.w : a0.w;
+                mineC.x = odd ? c1.x : c0.x; mineC.y = odd ? c1.y : c0.y; mineC.z = odd ? c1.z : c0.z; mineC.w = odd ? c1.w : c0.w;
+                recvA.x = agf_swap1(odd ? a0.x : a1.x); recvA.y = agf_swap1(odd ? a0.y : a1.y); recvA.z = agf_swap1(odd ? a0.z : a1.z); recvA.w = agf_swap1(odd ? a0.w : a1.w);
+                recvC.x = agf_swap1(odd ? c0.x : c1.x); recvC.y = agf_swap1(odd ? c0.y : c1.y); recvC.z = agf_swap1(odd ? c0.z : c1.z); recvC.w = agf_swap1(odd ? c0.w : c1.w);
+                // cell = (a b / c d) with a, c in the even column: the even lane owns a, c; the odd lane owns b, d.  Sum in agf_pool2x2's order
+                float fa[8], fb[8], fc[8], fd[8], o[8];
+                unpack8(mineA, fa); unpack8(recvA, fb); unpack8(mineC, fc); unpack8(recvC, fd);
+        #pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const float s = fa[e] + fb[e];                          // a + b (commutative: same bits on both lanes)
+                    const float c = odd ? fd[e] : fc[e], d = odd ? fc[e] : fd[e];
+                    o[e] = ((s + c) + d) * p.pool_gain;
+                }
+                const unsigned bA = bits8(fa), bB = bits8(fb), bC = bits8(fc), bD = bits8(fd);
+                const unsigned word = odd ? (bB | (bA << 8) | (bD << 16) | (bC << 24)) : (bA | (bB << 8) | (bC << 16) | (bD << 24));
+                const int cb = coW + i * 32 + (2 * (odd ? 1 : 0) + lhi) * 8;
+                if (valid[j0] && cb < p.Cout) {
+                    u32x4 out;
+                    out.x = Pack16<bf16_t>::pack(o[0], o[1]); out.y = Pack16<bf16_t>::pack(o[2], o[3]);
+                    out.z = Pack16<bf16_t>::pack(o[4], o[5]); out.w = Pack16<bf16_t>::pack(o[6], o[7]);
+                    *(u32x4*)(p.y + cell * p.Cout + cb) = out;
+                    p.pool_mask[cell * (p.Cout >> 3) + (cb >> 3)] = word;
                 }
             }
         }
@@ -298,13 +314,13 @@ static __device__ __forceinline__ void conv_epilogue_pl(const ConvParams& p, f32
     for (int e = 0; e < MT * 16; e++) msum[e] = 0.f;
     // residual of a LINEAR epilogue with unit gain (the DBlock's skip conv: y = conv + bias + pool(x)): added after the lane swap, where a
     // lane owns 8 consecutive channels of a pixel -- one 16-byte load instead of two 8-byte gathers a pixel row apart
-    const bool resPost = MT == 1 && p.residual && p.act != 3 && p.gain == 1.f;     // (64-channel tile only: the 128-channel kernels have no registers to spare)
+    const bool resPost = MT == 1 && residual && p.act != 3 && p.gain == 1.f;     // (64-channel tile only: the 128-channel kernels have no registers to spare)
 #pragma unroll
     for (int j = 0; j < NJ; j++) {
         const int64_t pi = pixIdx[j];
         const int n = nimg[j];
         u32x4 rp[MT][2];
-        if (p.res_pooled) {
+        if (res_pooled) {
             // gradient of the pooled skip branch, read at half resolution (no upsampled tensor, no separate add)
             const int64_t qi = (int64_t)n * (p.H >> 1) * (p.W >> 1) + hw2[j];
 #pragma unroll
@@ -313,7 +329,7 @@ static __device__ __forceinline__ void conv_epilogue_pl(const ConvParams& p, f32
                 for (int q = 0; q < 2; q++) {
                     const int cb = coW + i * 32 + (2 * q + lhi) * 8;
                     rp[i][q] = u32x4{0u, 0u, 0u, 0u};
-                    if (valid[j] && cb < p.Cout) rp[i][q] = *(const u32x4*)(p.res_pooled + qi * p.Cout + cb);
+                    if (valid[j] && cb < p.Cout) rp[i][q] = *(const u32x4*)(res_pooled + qi * p.Cout + cb);
                 }
         }
 #pragma unroll
@@ -339,8 +355,8 @@ static __device__ __forceinline__ void conv_epilogue_pl(const ConvParams& p, f32
                         }
 #pragma unroll
                         for (int e = 0; e < 4; e++) v[e] += nz[j];
-                        if (p.residual && !resPost && valid[j]) {
-                            const u32x2 rr = *(const u32x2*)(p.residual + pi * p.Cout + co);
+                        if (residual && !resPost && valid[j]) {
+                            const u32x2 rr = *(const u32x2*)(residual + pi * p.Cout + co);
                             float a0, a1;
                             Pack16<bf16_t>::unpack(rr.x, a0, a1); v[0] += a0; v[1] += a1;
                             Pack16<bf16_t>::unpack(rr.y, a0, a1); v[2] += a0; v[3] += a1;
@@ -364,27 +380,27 @@ static __device__ __forceinline__ void conv_epilogue_pl(const ConvParams& p, f32
                 const auto s1 = __builtin_amdgcn_permlane32_swap(P[0][1], P[1][1], false, false);
                 u32x4 val = {s0[0], s1[0], s0[1], s1[1]};
                 const int cb = coW + i * 32 + (2 * q + lhi) * 8;
-                if (p.res_pooled || p.mask_y || resPost) {
+                if (res_pooled || mask_y || resPost) {
                     float g[8];
                     Pack16<bf16_t>::unpack(val.x, g[0], g[1]); Pack16<bf16_t>::unpack(val.y, g[2], g[3]);
                     Pack16<bf16_t>::unpack(val.z, g[4], g[5]); Pack16<bf16_t>::unpack(val.w, g[6], g[7]);
                     if (MT == 1 && resPost) {
                         float rv[8];
                         u32x4 rsv = u32x4{0u, 0u, 0u, 0u};
-                        if (valid[j] && cb < p.Cout) rsv = *(const u32x4*)(p.residual + pi * p.Cout + cb);
+                        if (valid[j] && cb < p.Cout) rsv = *(const u32x4*)(residual + pi * p.Cout + cb);
                         Pack16<bf16_t>::unpack(rsv.x, rv[0], rv[1]); Pack16<bf16_t>::unpack(rsv.y, rv[2], rv[3]);
                         Pack16<bf16_t>::unpack(rsv.z, rv[4], rv[5]); Pack16<bf16_t>::unpack(rsv.w, rv[6], rv[7]);
 #pragma unroll
                         for (int e = 0; e < 8; e++) g[e] += rv[e];
                     }
-                    if (p.res_pooled) {
+                    if (res_pooled) {
                         float rv[8];
                         Pack16<bf16_t>::unpack(rp[i][q].x, rv[0], rv[1]); Pack16<bf16_t>::unpack(rp[i][q].y, rv[2], rv[3]);
                         Pack16<bf16_t>::unpack(rp[i][q].z, rv[4], rv[5]); Pack16<bf16_t>::unpack(rp[i][q].w, rv[6], rv[7]);
 #pragma unroll
                         for (int e = 0; e < 8; e++) g[e] += rv[e] * p.res_scale;
                     }
-                    if (p.mask_y) {
+                    if (mask_y) {
                         // the layer below's lrelu gradient, applied where the gradient tensor is produced
                         float a[8];
                         Pack16<bf16_t>::unpack(mk[j][i][q].x, a[0], a[1]); Pack16<bf16_t>::unpack(mk[j][i][q].y, a[2], a[3]);
@@ -403,7 +419,7 @@ static __device__ __forceinline__ void conv_epilogue_pl(const ConvParams& p, f32
             }
         }
     }
-    if (p.mask_y && p.mask_sum) {             // block-uniform
+    if (mask_y && p.mask_sum) {             // block-uniform
         // halving butterfly over the 32 lanes of each half-wave: after step m a lane keeps the half of the remaining values that its
         // bit m selects, so lane l ends with the total of value index  bit0*NV/2 + bit1*NV/4 + ...  (NV = 16*MT values per lane)
         constexpr int NV = MT * 16;
@@ -447,7 +463,7 @@ static __device__ __forceinline__ void conv_epilogue_pl(const ConvParams& p, f32
 //   <MT=2, NWN=4, NWM=1>: 64 co x 512 px, 4 waves of 64 co x 128 px, 57 KB LDS, two blocks per CU -- the 64-output-channel layers.
 //     A wave tile of 32 co x 128 px reads 1 A + 4 B fragments (5 KB of LDS) per 4 MFMAs: four SIMDs then ask for 160 B/clk of
 //     the CU's 128 B/clk of LDS bandwidth; 64 co x 128 px reads 2 A + 4 B per 8 MFMAs (96 B/clk).
-template <int KS, int MT, bool IN_SCALE, int KC, int NWN, int PMAX, int NWM = 2, int NJ = 4, int OCC = 2>
+template <int KS, int MT, bool IN_SCALE, int KC, int NWN, int PMAX, int NWM = 2, int NJ = 4, int OCC = 2, bool POOL = false>
 __global__ void __launch_bounds__(64 * NWM * NWN, OCC) conv2d_fwd_kernel(ConvParams p) {   // 2 waves per SIMD: two 4-wave blocks or one 8-wave block per CU
     constexpr int NTHR = 64 * NWM * NWN;
     // KC = channels per K chunk (16 or 32); LDS row pitch = KC + 8 elements (48 / 80 bytes: conflict-free ds_read_b128)
@@ -634,7 +650,7 @@ __global__ void __launch_bounds__(64 * NWM * NWN, OCC) conv2d_fwd_kernel(ConvPar
         }
     }
 
-    if (p.vecStore == 2) conv_epilogue_pl<MT, NJ>(p, acc, smem_raw, wave, lane, wm, wn, n0, h0, w0, flatP0, co0, NWN, NWM * NWN, pixTile & 255);
+    if (POOL || p.vecStore == 2) conv_epilogue_pl<MT, NJ, POOL>(p, acc, smem_raw, wave, lane, wm, wn, n0, h0, w0, flatP0, co0, NWN, NWM * NWN, pixTile & 255);
     else conv_epilogue<MT, NJ>(p, acc, smem_raw, wave, lane, wm, wn, n0, h0, w0, flatP0, co0, NWN, NWM * NWN, pixTile & 255);
 }
 
@@ -648,7 +664,7 @@ __global__ void __launch_bounds__(64 * NWM * NWN, OCC) conv2d_fwd_kernel(ConvPar
 // A wave-level load lands as 64 consecutive 16-byte slots, so both tiles are stored UNPADDED ([row][16 channels] = 32-byte rows;
 // a fragment read is then 32 rows x 2 halves = 1 KB contiguous: conflict-free without the generic kernel's row padding).
 // Out-of-image halo pixels, channel tails and co tails are lanes whose buffer offset is out of range: the hardware writes zeros.
-template <int KS, int MT, int NWN, int PMAX, int NWM, int NJ>
+template <int KS, int MT, int NWN, int PMAX, int NWM, int NJ, bool POOL = false, bool PLAIN = false>
 __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_dl_kernel(ConvParams p) {
     constexpr int NTHR = 64 * NWM * NWN;
     constexpr int KC = 16;
@@ -812,11 +828,11 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_dl_kernel(ConvPa
             __syncthreads();                                          // ... and so have everyone's; everyone is done with `cur`
         }
     }
-    if (p.vecStore == 2) conv_epilogue_pl<MT, NJ>(p, acc, smem_raw, wave, lane, wm, wn, n0, h0, w0, 0, co0, NWN, NWM * NWN, pixTile & 255);
+    if (POOL || p.vecStore == 2) conv_epilogue_pl<MT, NJ, POOL, PLAIN>(p, acc, smem_raw, wave, lane, wm, wn, n0, h0, w0, 0, co0, NWN, NWM * NWN, pixTile & 255);
     else conv_epilogue<MT, NJ>(p, acc, smem_raw, wave, lane, wm, wn, n0, h0, w0, 0, co0, NWN, NWM * NWN, pixTile & 255);
 }
 
-template <int KS, int MT, int NWN, int PMAX, int NWM, int NJ>
+template <int KS, int MT, int NWN, int PMAX, int NWM, int NJ, bool POOL = false, bool PLAIN = false>
 static int launch_fwd_dl(const ConvParams& p0, hipStream_t st) {
     constexpr int TAPS = KS * KS, HALO = KS / 2, BM = 32 * NWM * MT, NTHR = 64 * NWM * NWN;
     ConvParams p = p0;
@@ -828,9 +844,9 @@ static int launch_fwd_dl(const ConvParams& p0, hipStream_t st) {
     if (lds < (size_t)(NTHR / 64) * 32 * (64 * MT + 16) + 4096) lds = (size_t)(NTHR / 64) * 32 * (64 * MT + 16) + 4096;     // the epilogue strips
     if (lds > 160 * 1024) return AGF_ENOKERNEL;
     const int slots = ((p.pixTiles + 7) / 8) * p.tilesCo;
-    hipError_t e = hipFuncSetAttribute((const void*)conv2d_fwd_dl_kernel<KS, MT, NWN, PMAX, NWM, NJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)conv2d_fwd_dl_kernel<KS, MT, NWN, PMAX, NWM, NJ, POOL, PLAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { agf_set_error("conv2d_fwd: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e)); return AGF_ELAUNCH; }
-    hipLaunchKernelGGL((conv2d_fwd_dl_kernel<KS, MT, NWN, PMAX, NWM, NJ>), dim3((unsigned)(slots * 8)), dim3(NTHR), lds, st, p);
+    hipLaunchKernelGGL((conv2d_fwd_dl_kernel<KS, MT, NWN, PMAX, NWM, NJ, POOL, PLAIN>), dim3((unsigned)(slots * 8)), dim3(NTHR), lds, st, p);
     return AGF_OK;
 }
 
@@ -1687,7 +1703,7 @@ __global__ void __launch_bounds__(256) conv2d_wgrad_f32_kernel(WgradF32Params p)
 
 static int pow2_ceil(int v) { int r = 1; while (r < v) r <<= 1; return r; }
 
-template <int KS, int MT, bool SC, int KC, int NWN, int PMAX, int NWM = 2, int NJ = 4, int OCC = 2>
+template <int KS, int MT, bool SC, int KC, int NWN, int PMAX, int NWM = 2, int NJ = 4, int OCC = 2, bool POOL = false>
 static int launch_fwd_v(const ConvParams& p0, hipStream_t st) {
     constexpr int TAPS = KS * KS, HALO = KS / 2, BM = 32 * NWM * MT, PITCH = KC + 8;
     ConvParams p = p0;
@@ -1698,9 +1714,9 @@ static int launch_fwd_v(const ConvParams& p0, hipStream_t st) {
     if (lds > 160 * 1024) { agf_set_error("conv2d_fwd: tile needs %zu bytes of LDS", lds); return AGF_ENOKERNEL; }
     const int slots = ((p.pixTiles + 7) / 8) * p.tilesCo;
     dim3 grid((unsigned)(slots * 8)), block(64 * NWM * NWN);
-    hipError_t e = hipFuncSetAttribute((const void*)conv2d_fwd_kernel<KS, MT, SC, KC, NWN, PMAX, NWM, NJ, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)conv2d_fwd_kernel<KS, MT, SC, KC, NWN, PMAX, NWM, NJ, OCC, POOL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { agf_set_error("conv2d_fwd: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e)); return AGF_ELAUNCH; }
-    hipLaunchKernelGGL((conv2d_fwd_kernel<KS, MT, SC, KC, NWN, PMAX, NWM, NJ, OCC>), grid, block, lds, st, p);
+    hipLaunchKernelGGL((conv2d_fwd_kernel<KS, MT, SC, KC, NWN, PMAX, NWM, NJ, OCC, POOL>), grid, block, lds, st, p);
     return AGF_OK;
 }
 
@@ -1726,6 +1742,16 @@ constexpr int g_ws_enable = 1;     // (2 would also send 64 -> 64 layers to the 
 
 template <int KS, int MT>
 static int launch_fwd(const ConvParams& p, hipStream_t st) {
+    if (p.pool_mask) {
+        // conv + lrelu + 2x2 average (agf_conv2d_fwd_pool): the instantiations that carry the pooled epilogue -- the two direct-to-LDS tiles
+        // and the 64 co x 256 px generic tile, unscaled input
+        if constexpr (KS == 3) {
+            if (p.in_scale || p.flat || p.TW != 32) return AGF_ENOKERNEL;
+            if (MT == 2) return p.Cout <= 64 ? launch_fwd_dl<KS, 2, 4, 612, 1, 4, true>(p, st) : launch_fwd_dl<KS, 2, 4, 612, 2, 4, true>(p, st);
+            return launch_fwd_v<KS, 1, false, 32, 2, 576, 2, 4, 2, true>(p, st);
+        }
+        return AGF_ENOKERNEL;
+    }
     // weight-stationary kernel: Cin <= 32 (two blocks per CU), or Cin <= 64 with Cout <= 32 (32-channel co tile: the
     // generic 64-channel tile would waste half of its MFMAs there); measured per layer in tools/ab_ws.sh
     constexpr int ws1 = 1;
@@ -1760,7 +1786,9 @@ static int launch_fwd(const ConvParams& p, hipStream_t st) {
         return p.in_scale ? launch_fwd_v<KS, 1, true, 32, 2, 160, 2, 1>(p, st) : launch_fwd_v<KS, 1, false, 32, 2, 160, 2, 1>(p, st);
     constexpr int dl = 1;
     if (dl && KS == 3 && MT == 2 && !p.in_scale && !p.flat) {
-        const int rc = p.Cout <= 64 ? launch_fwd_dl<KS, 2, 4, 612, 1, 4>(p, st) : launch_fwd_dl<KS, 2, 4, 612, 2, 4>(p, st);
+        const bool plain = KS == 3 && !p.mask_y && !p.res_pooled && !p.residual && p.vecStore == 2;
+        const int rc = p.Cout <= 64 ? (plain ? launch_fwd_dl<KS, 2, 4, 612, 1, 4, false, true>(p, st) : launch_fwd_dl<KS, 2, 4, 612, 1, 4>(p, st))
+                                    : (plain ? launch_fwd_dl<KS, 2, 4, 612, 2, 4, false, true>(p, st) : launch_fwd_dl<KS, 2, 4, 612, 2, 4>(p, st));
         if (rc != AGF_ENOKERNEL) return rc;
     }
     if (MT == 2 && p.Cout <= 64) return p.in_scale ? launch_fwd_v<KS, 2, true, 16, 4, 612, 1>(p, st) : launch_fwd_v<KS, 2, false, 16, 4, 612, 1>(p, st);

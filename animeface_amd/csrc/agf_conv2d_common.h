@@ -28,6 +28,11 @@ static __device__ __forceinline__ u32x4 scale_vec8(u32x4 val, const float* sc) {
     return val;
 }
 
+// the value of lane ^ 1: DPP quad_perm [1, 0, 3, 2] -- one VALU move (a __shfl_xor is a ds_bpermute through the LDS pipe)
+static __device__ __forceinline__ uint32_t agf_swap1(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);
+}
+
 struct ConvParams {
     const bf16_t* x;          // [N,H,W,Cin]
     const bf16_t* w;          // [Cout,KS,KS,Cin]

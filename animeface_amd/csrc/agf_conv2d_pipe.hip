@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_pipe_kernel(Pipe
     constexpr int KG = LPW_HI;
     constexpr int PA = MT * NJ * 2;                      // 16-byte vectors of the tile's mask (pooled residual) per lane
     constexpr int PCNT = EP == 0 ? NJ : EP * PA;       // prefetch loads per wave and tile
-    constexpr int SCNT = 2 * MT * NJ;                    // stores per wave and tile
+    constexpr int SCNT = POOL ? MT * NJ : 2 * MT * NJ;    // stores per wave and tile (pooled: NJ / 2 * MT vectors + as many mask words)
     constexpr int PF = NCH >= 2 ? NCH - 2 : 0;           // chunk at whose start the epilogue operands are requested
     constexpr int TCONS = (NSTAGE - 1 + NCH - 1) / NCH;  // first tiles: the conservative wait count (operations of the prologue)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -252,8 +252,8 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_pipe_kernel(Pipe
         if (POOL) {
             // lane pixels j, j + 1 are rows h, h + 1 of one column (TW == 32), lane ^ 1 holds the neighbouring column: a 2x2 cell is two
             // registers here and two there.  Rounded to bf16 first and summed as agf_pool2x2 does, ((a + b) + c) + d: bit-identical to
-            // conv -> pool2x2 without the full-resolution write and re-read.  Same number of stores per wave as the plain epilogue
-            // (NJ / 2 * MT * 2 vectors + as many mask words = 2 MT NJ), so the counted waits hold.
+            // conv -> pool2x2 without the full-resolution write and re-read.  Stores per wave and tile: NJ / 2 * MT vectors + as many mask
+            // words (SCNT, which the counted waits use).
             const int cells = (p.H >> 1) * (p.W >> 1);
             const __amdgpu_buffer_rsrc_t pRes = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (int64_t)n0 * cells * p.Cout), 0, cells * p.Cout * 2, 0x00020000);
             const __amdgpu_buffer_rsrc_t kRes = __builtin_amdgcn_make_buffer_rsrc((void*)(p.pool_mask + (int64_t)n0 * cells * (p.Cout >> 3)), 0, cells * (p.Cout >> 3) * 4, 0x00020000);
@@ -300,19 +300,29 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_pipe_kernel(Pipe
                 const int j0 = 2 * jp;
 #pragma unroll
                 for (int i = 0; i < MT; i++) {
-#pragma unroll
-                    for (int q = 0; q < 2; q++) {
-                        const u32x4 va = value(j0, i, q), vc = value(j0 + 1, i, q);
-                        u32x4 vb, vd;
-                        vb.x = __shfl_xor(va.x, 1); vb.y = __shfl_xor(va.y, 1); vb.z = __shfl_xor(va.z, 1); vb.w = __shfl_xor(va.w, 1);
-                        vd.x = __shfl_xor(vc.x, 1); vd.y = __shfl_xor(vc.y, 1); vd.z = __shfl_xor(vc.z, 1); vd.w = __shfl_xor(vc.w, 1);
-                        float a[8], b[8], c[8], d[8], o[8];
-                        unpack8(va, a); unpack8(vb, b); unpack8(vc, c); unpack8(vd, d);
-#pragma unroll
-                        for (int e = 0; e < 8; e++) o[e] = (a[e] + b[e] + c[e] + d[e]) * p.pool_gain;
-                        const unsigned word = bits8(a) | (bits8(b) << 8) | (bits8(c) << 16) | (bits8(d) << 24);
-                        const int cb = coW + i * 32 + (2 * q + lhi) * 8;
-                        const bool keep = !(l31 & 1) && cellOff[j0] != PIPE_OOB && cb < p.Cout;
+                    // the lanes of a pair share the work: the even lane (column w) pools channel group 2*0 + lhi, the odd one (column w + 1) group
+                    // 2*1 + lhi; each sends the other the two vectors it does not pool itself (DPP) and every lane stores
+                    const bool odd = (l31 & 1) != 0;
+                    const u32x4 a0 = value(j0, i, 0), a1 = value(j0, i, 1), c0 = value(j0 + 1, i, 0), c1 = value(j0 + 1, i, 1);
+                    u32x4 mineA, mineC, recvA, recvC;
+                    mineA.x = odd ? a1.x : a0.x; mineA.y = odd ? a1.y : a0.y; mineA.z = odd ? a1.z : a0.z; mineA.w = odd ? a1.w : a0.w;
+                    mineC.x = odd ? c1.x : c0.x; mineC.y = odd ? c1.y : c0.y; mineC.z = odd ? c1.z : c0.z; mineC.w = odd ? c1.w : c0.w;
+                    recvA.x = agf_swap1(odd ? a0.x : a1.x); recvA.y = agf_swap1(odd ? a0.y : a1.y); recvA.z = agf_swap1(odd ? a0.z : a1.z); recvA.w = agf_swap1(odd ? a0.w : a1.w);
+                    recvC.x = agf_swap1(odd ? c0.x : c1.x); recvC.y = agf_swap1(odd ? c0.y : c1.y); recvC.z = agf_swap1(odd ? c0.z : c1.z); recvC.w = agf_swap1(odd ? c0.w : c1.w);
+                    // cell = (a b / c d) with a, c in the even column: the even lane owns a, c; the odd lane owns b, d.  Sum in agf_pool2x2's order
+                    float fa[8], fb[8], fc[8], fd[8], o[8];
+                    unpack8(mineA, fa); unpack8(recvA, fb); unpack8(mineC, fc); unpack8(recvC, fd);
+            #pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        const float s = fa[e] + fb[e];                          // a + b (commutative: same bits on both lanes)
+                        const float c = odd ? fd[e] : fc[e], d = odd ? fc[e] : fd[e];
+                        o[e] = ((s + c) + d) * p.pool_gain;
+                    }
+                    const unsigned bA = bits8(fa), bB = bits8(fb), bC = bits8(fc), bD = bits8(fd);
+                    const unsigned word = odd ? (bB | (bA << 8) | (bD << 16) | (bC << 24)) : (bA | (bB << 8) | (bC << 16) | (bD << 24));
+                    const int cb = coW + i * 32 + (2 * (odd ? 1 : 0) + lhi) * 8;
+                    {
+                        const bool keep = cellOff[j0] != PIPE_OOB && cb < p.Cout;
                         u32x4 out;
                         out.x = Pack16<bf16_t>::pack(o[0], o[1]); out.y = Pack16<bf16_t>::pack(o[2], o[3]);
                         out.z = Pack16<bf16_t>::pack(o[4], o[5]); out.w = Pack16<bf16_t>::pack(o[6], o[7]);
