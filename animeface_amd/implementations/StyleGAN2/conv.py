@@ -232,7 +232,7 @@ def conv2d_fwd_pool_raw(x, wq, bias, alpha, gain, pool_gain):
     if rc == _lib.AGF_ENOKERNEL:
         return None
     if timer is not None:
-        timer.stop('conv2d_fwd_kernel', ev0, 2.0 * N * H * W * Cin * Cout * k * k, (N, Cin, Cout, H, W, k, False, False))
+        timer.stop('conv2d_fwd_kernel', ev0, 2.0 * N * H * W * Cin * Cout * k * k, (N, Cin, Cout, H, W, k, False, False, 'pool'))
     _lib.check(rc, 'conv2d_fwd_pool')
     return y, mask
 

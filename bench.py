@@ -441,6 +441,8 @@ def main():
             def conv_bytes(key):
                 name, n, cin, cout, h, w, ks = key[:7]
                 fused = name == 'conv2d_fwd_kernel' and len(key) > 8 and key[8]      # + the lrelu mask the fused gradient epilogue reads (as large as y)
+                if len(key) > 9 and key[9] == 'pool':                                 # agf_conv2d_fwd_pool: the 2x2 average + one mask bit per element leave, not y
+                    return n * h * w * cin * 2 + n * (h // 2) * (w // 2) * cout * 2 + n * h * w * cout // 8 + cout * cin * ks * ks * 2
                 return n * h * w * (cin + cout + (cout if fused else 0)) * 2 + cout * cin * ks * ks * 2
             alg = {}
             for key, recs in timer.by_shape.items():
@@ -497,7 +499,7 @@ def main():
                 if fl / by < MFMA_BF16_PEAK / HBM_PEAK:
                     hbm_ms += ms
                     hbm_bytes += by
-                    hbm_rows.append((ms / sampled_steps, {'shape': 'N%d %d->%d %dx%d k%d%s%s' % (key[1], key[2], key[3], key[4], key[5], key[6], ' style' if key[7] else '', ' +mask' if len(key) > 8 and key[8] else ''),
+                    hbm_rows.append((ms / sampled_steps, {'shape': 'N%d %d->%d %dx%d k%d%s%s' % (key[1], key[2], key[3], key[4], key[5], key[6], ' style' if key[7] else '', (' +mask' if len(key) > 8 and key[8] else '') + (' +pool' if len(key) > 9 and key[9] == 'pool' else '')),
                                                            'launches': len(recs) // sampled_steps, 'ms': round(ms / sampled_steps, 3), 'flop_per_byte': round(fl / by, 1),
                                                            'achieved': round(by / (ms * 1e-3) / 1e12, 3), 'frac': round(by / (ms * 1e-3) / HBM_PEAK, 3)}))
             if hbm_ms > 0:
