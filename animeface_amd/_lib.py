@@ -23,7 +23,7 @@ EXPORTS = ['agf_abi_version', 'agf_last_error', 'agf_device_info', 'agf_set_dete
            'agf_filtered_lrelu', 'agf_filtered_lrelu_act', 'agf_conv2d_fwd', 'agf_conv2d_fwd_post', 'agf_conv2d_fwd_pool', 'agf_conv2d_fwd_mask', 'agf_conv2d_s2_fwd', 'agf_conv2d_s2_dgrad', 'agf_conv2d_wgrad', 'agf_conv2d_wgrad_ws', 'agf_conv2d_wgrad_workspace_bytes',
            'agf_act_bwd_reduce', 'agf_act_bwd_reduce_pooled', 'agf_act_bwd_reduce_pooled_mask', 'agf_pool2x2', 'agf_act_bwd_reduce_scaled', 'agf_scale_dot', 'agf_demod_grad_finish', 'agf_planar_to_cl_pad', 'agf_planar_to_cl_pad_scaled', 'agf_cl_to_planar_crop', 'agf_cl_pad', 'agf_prep_weights', 'agf_prep_weights_multi', 'agf_prep_weights_blocks',
            'agf_modulate_weights', 'agf_conv2d_fwd_wimg', 'agf_conv2d_fwd_wimg_covers',
-           'agf_wsq', 'agf_style_demod_fwd', 'agf_style_demod_fwd_ld', 'agf_style_demod_bwd', 'agf_diffaug_sum', 'agf_diffaug_apply', 'agf_color_affine', 'agf_affine_resample', 'agf_ada_pad_up2', 'agf_ada_warp_resample', 'agf_ada_plan', 'agf_upblur_border', 'agf_map_layer_fwd', 'agf_map_layer_bwd', 'agf_torgb_covers', 'agf_torgb_fwd', 'agf_torgb_bwd_workspace_floats', 'agf_torgb_bwd', 'agf_image_resample_rows', 'agf_image_finish']
+           'agf_wsq', 'agf_style_demod_fwd', 'agf_style_demod_fwd_ld', 'agf_style_demod_bwd', 'agf_diffaug_sum', 'agf_diffaug_apply', 'agf_color_affine', 'agf_affine_resample', 'agf_ada_pad_up2', 'agf_ada_warp_resample', 'agf_ada_plan', 'agf_upblur_border', 'agf_upblur_border_scaled', 'agf_upfirdn2d_chscale', 'agf_map_layer_fwd', 'agf_map_layer_bwd', 'agf_torgb_covers', 'agf_torgb_fwd', 'agf_torgb_bwd_workspace_floats', 'agf_torgb_bwd', 'agf_image_resample_rows', 'agf_image_finish']
 
 _lib = None
 _i32x4 = ctypes.c_int32 * 4
@@ -137,6 +137,12 @@ def lib():
         L.agf_ada_warp_resample.argtypes = [_vp, _vp, _vp, _vp, ctypes.c_int] + [ctypes.c_int32] * 6 + [ctypes.c_int, _vp]
         L.agf_ada_plan.restype = ctypes.c_int
         L.agf_ada_plan.argtypes = [_vp, _vp, ctypes.c_int32 * 26, ctypes.c_float * 26] + [_vp] * 4 + [ctypes.c_int32] * 5 + [_vp]
+        L.agf_upfirdn2d_chscale.restype = ctypes.c_int
+        L.agf_upfirdn2d_chscale.argtypes = [_vp, _vp, _vp, _vp, ctypes.c_int, _i32x4, _i64x4, _i32x2, _i64x2, _i32x4, _i64x4,
+                                            ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                            ctypes.c_int, ctypes.c_float, ctypes.c_int, _vp]
+        L.agf_upblur_border_scaled.restype = ctypes.c_int
+        L.agf_upblur_border_scaled.argtypes = [_vp, _vp, _vp, ctypes.c_int] + [ctypes.c_int32] * 4 + [_vp]
         L.agf_upblur_border.restype = ctypes.c_int
         L.agf_upblur_border.argtypes = [_vp, _vp, ctypes.c_int] + [ctypes.c_int32] * 4 + [ctypes.c_int, _vp]
         L.agf_image_resample_rows.restype = ctypes.c_int

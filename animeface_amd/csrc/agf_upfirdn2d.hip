@@ -33,6 +33,7 @@ struct UpfirdnParams {
     int tilesX, tilesY;          // nchw_tile only
     int tileInW, tileInH;
     int cg_shift;                // nhwc_vec: log2(C / VEC) or -1
+    const float* chscale;        // nhwc_rows only: [N][C] fp32 or null -- the stored result is multiplied by chscale[n, c] (agf_upfirdn2d_chscale)
 };
 
 #define MAX_FILTER_TAPS 1024     // up to 32x32 (reference limit: 32x32 in the small kernels)
@@ -273,6 +274,16 @@ __global__ void __launch_bounds__(256, ROWS_WAVES) upfirdn2d_nhwc_rows(UpfirdnPa
 #pragma unroll
                 for (int i = 0; i < VEC; i++) asm volatile("" : "+v"(acc[r][i]) :: "memory");
             }
+        }
+    }
+    if (p.chscale) {
+        // a per-sample, per-channel factor commutes with the FIR: the style scale of the modulated conv that consumes this tensor
+        const float* sc = p.chscale + (int64_t)n * p.C + cg * VEC;
+#pragma unroll
+        for (int i = 0; i < VEC; i++) {
+            const float s = sc[i];
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) acc[r][i] *= s;
         }
     }
     char* ybn = (char*)p.y + (int64_t)n * p.OH * ((int64_t)p.OW * p.C) * (int64_t)sizeof(T);
@@ -697,6 +708,7 @@ static bool launch_nhwc(const UpfirdnParams& p, hipStream_t st) {
     NHWC_CASE(2, 2, 1, 1, 6, 6, 8)   // fused Upsample2x -> Blur2d of the StyleGAN2 generator (composite [1,5,10,10,5,1] filter)
     NHWC_CASE(1, 1, 2, 2, 6, 6, 4)   // its adjoint
 #undef NHWC_CASE
+    if (p.chscale) return false;                      // only the row-marching specialisations carry the channel scale
     hipLaunchKernelGGL((upfirdn2d_nhwc_vec<T, VEC, 0, 0, 0, 0, 0, 0>), g, b, 0, st, pp);
     return true;
 }
@@ -710,6 +722,7 @@ static int launch_typed(UpfirdnParams& p, bool dense_nchw, bool dense_nhwc, int 
         else if constexpr (sizeof(T) == 2) ok = launch_nhwc<T, 8>(p, st);
         if (ok) return AGF_OK;
     }
+    if (p.chscale) { agf_set_error("upfirdn2d_chscale: served by the channels-last row kernels only"); return AGF_ENOKERNEL; }
     if (dense_nchw && sizeof(T) <= 4 && p.OW >= 64) {
         constexpr bool planar_on = true;
         if constexpr (sizeof(T) <= 4) { if (planar_on && launch_planar_vec_cases<T>(p, st)) return AGF_OK; }
@@ -845,12 +858,12 @@ __global__ void __launch_bounds__(256) upfirdn2d_fold_border_cl(UpfirdnParams p,
     }
 }
 
-extern "C" int agf_upfirdn2d(const void* x, const float* f, void* y, int dtype,
-                             const int32_t in_size[4], const int64_t in_stride[4],
-                             const int32_t f_size[2], const int64_t f_stride[2],
-                             const int32_t out_size[4], const int64_t out_stride[4],
-                             int upx, int upy, int downx, int downy, int padx0, int pady0,
-                             int flip, float gain, int edge_mode, void* stream) {
+static int upfirdn2d_impl(const void* x, const float* f, void* y, int dtype,
+                          const int32_t in_size[4], const int64_t in_stride[4],
+                          const int32_t f_size[2], const int64_t f_stride[2],
+                          const int32_t out_size[4], const int64_t out_stride[4],
+                          int upx, int upy, int downx, int downy, int padx0, int pady0,
+                          int flip, float gain, int edge_mode, void* stream, const float* chscale) {
     // validation mirrors upfirdn2d.cpp:13-34
     AGF_CHECK(x && f && y, "upfirdn2d: null pointer");
     AGF_CHECK(dtype >= AGF_F32 && dtype <= AGF_F64, "upfirdn2d: unsupported dtype %d", dtype);
@@ -876,6 +889,7 @@ extern "C" int agf_upfirdn2d(const void* x, const float* f, void* y, int dtype,
     p.upx = upx; p.upy = upy; p.downx = downx; p.downy = downy; p.padx0 = padx0; p.pady0 = pady0;
     p.flip = flip ? 1 : 0; p.clamp_edge = edge_mode == AGF_EDGE_CLAMP; p.gain = gain;
     p.tilesX = p.tilesY = p.tileInW = p.tileInH = 0; p.cg_shift = -1;
+    p.chscale = chscale;
 
     auto dense = [](const int32_t* sz, const int64_t* st, bool nhwc) {
         int64_t N = sz[0], C = sz[1], H = sz[2], W = sz[3];
@@ -896,6 +910,27 @@ extern "C" int agf_upfirdn2d(const void* x, const float* f, void* y, int dtype,
     if (rc != AGF_OK) return rc;
     AGF_LAUNCH_CHECK();
     return AGF_OK;
+}
+
+extern "C" int agf_upfirdn2d(const void* x, const float* f, void* y, int dtype,
+                             const int32_t in_size[4], const int64_t in_stride[4],
+                             const int32_t f_size[2], const int64_t f_stride[2],
+                             const int32_t out_size[4], const int64_t out_stride[4],
+                             int upx, int upy, int downx, int downy, int padx0, int pady0,
+                             int flip, float gain, int edge_mode, void* stream) {
+    return upfirdn2d_impl(x, f, y, dtype, in_size, in_stride, f_size, f_stride, out_size, out_stride, upx, upy, downx, downy, padx0, pady0,
+                          flip, gain, edge_mode, stream, nullptr);
+}
+
+extern "C" int agf_upfirdn2d_chscale(const void* x, const float* f, void* y, const float* chscale, int dtype,
+                                     const int32_t in_size[4], const int64_t in_stride[4],
+                                     const int32_t f_size[2], const int64_t f_stride[2],
+                                     const int32_t out_size[4], const int64_t out_stride[4],
+                                     int upx, int upy, int downx, int downy, int padx0, int pady0,
+                                     int flip, float gain, int edge_mode, void* stream) {
+    AGF_CHECK(chscale, "upfirdn2d_chscale: null scale");
+    return upfirdn2d_impl(x, f, y, dtype, in_size, in_stride, f_size, f_stride, out_size, out_stride, upx, upy, downx, downy, padx0, pady0,
+                          flip, gain, edge_mode, stream, chscale);
 }
 
 extern "C" int agf_upfirdn2d_fold_border(const void* x, const float* f, void* y, int dtype,
@@ -958,7 +993,7 @@ static __device__ __forceinline__ void upblur_taps(int j, int L, int (&idx)[3], 
 }
 
 template <class T, int VEC>
-__global__ void __launch_bounds__(256) upblur_border_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int C, int H, int W) {
+__global__ void __launch_bounds__(256) upblur_border_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int C, int H, int W, const float* __restrict__ scale) {
     const int OH = 2 * H, OW = 2 * W, CG = C / VEC;
     const int per = 2 * OW + 2 * (OH - 2);
     const int64_t total = (int64_t)N * per * CG;
@@ -999,6 +1034,10 @@ __global__ void __launch_bounds__(256) upblur_border_fwd_kernel(const T* __restr
 #pragma unroll
                 for (int e = 0; e < VEC; e++) d[e] += 0.0625f * v[e];
             }
+        }
+        if (scale) {                                                     // y already holds FIR(x) * scale[n, c] (agf_upfirdn2d_chscale)
+#pragma unroll
+            for (int e = 0; e < VEC; e++) d[e] *= scale[(int64_t)n * C + cg * VEC + e];
         }
         T* yp = y + (((int64_t)n * OH + oy) * OW + ox) * C + cg * VEC;
         VecIO<T, VEC>::load(yp, v);
@@ -1065,7 +1104,7 @@ __global__ void __launch_bounds__(256) upblur_border_bwd_kernel(const T* __restr
     }
 }
 
-extern "C" int agf_upblur_border(const void* x, void* y, int dtype, int32_t N, int32_t C, int32_t H, int32_t W, int backward, void* stream) {
+static int upblur_border_impl(const void* x, void* y, const float* scale, int dtype, int32_t N, int32_t C, int32_t H, int32_t W, int backward, void* stream) {
     AGF_CHECK(x && y, "upblur_border: null pointer");
     AGF_CHECK(dtype == AGF_F32 || dtype == AGF_BF16, "upblur_border: dtype must be f32 or bf16");
     AGF_CHECK(N >= 1 && C >= 1 && H >= 2 && W >= 2, "upblur_border: the map must be at least 2x2");
@@ -1077,11 +1116,20 @@ extern "C" int agf_upblur_border(const void* x, void* y, int dtype, int32_t N, i
     hipStream_t st = (hipStream_t)stream;
     if (dtype == AGF_BF16) {
         if (backward) hipLaunchKernelGGL((upblur_border_bwd_kernel<bf16_t, 8>), dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, N, C, H, W);
-        else hipLaunchKernelGGL((upblur_border_fwd_kernel<bf16_t, 8>), dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, N, C, H, W);
+        else hipLaunchKernelGGL((upblur_border_fwd_kernel<bf16_t, 8>), dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, N, C, H, W, scale);
     } else {
         if (backward) hipLaunchKernelGGL((upblur_border_bwd_kernel<float, 4>), dim3((unsigned)blocks), dim3(256), 0, st, (const float*)x, (float*)y, N, C, H, W);
-        else hipLaunchKernelGGL((upblur_border_fwd_kernel<float, 4>), dim3((unsigned)blocks), dim3(256), 0, st, (const float*)x, (float*)y, N, C, H, W);
+        else hipLaunchKernelGGL((upblur_border_fwd_kernel<float, 4>), dim3((unsigned)blocks), dim3(256), 0, st, (const float*)x, (float*)y, N, C, H, W, scale);
     }
     AGF_LAUNCH_CHECK();
     return AGF_OK;
+}
+
+extern "C" int agf_upblur_border(const void* x, void* y, int dtype, int32_t N, int32_t C, int32_t H, int32_t W, int backward, void* stream) {
+    return upblur_border_impl(x, y, nullptr, dtype, N, C, H, W, backward, stream);
+}
+
+extern "C" int agf_upblur_border_scaled(const void* x, void* y, const float* scale, int dtype, int32_t N, int32_t C, int32_t H, int32_t W, void* stream) {
+    AGF_CHECK(scale, "upblur_border_scaled: null scale");
+    return upblur_border_impl(x, y, scale, dtype, N, C, H, W, 0, stream);
 }

@@ -860,15 +860,28 @@ class _UpBlur(torch.autograd.Function):
     adjoint (decimating FIR + border fold) followed by the adjoint of the border correction.  First-order only."""
 
     @staticmethod
-    def forward(ctx, x, f6):
+    def forward(ctx, x, f6, scale=None):
+        """``scale`` [N, C] (no gradient): the result is stored times scale[n, c] -- the style scale of the modulated conv that consumes it
+        (``POSTSCALE_X``).  The backward is unchanged: that conv hands back the gradient w.r.t. the UNSCALED tensor (its ``dx = t * s``)."""
         from ...stylegan3_ops import upfirdn2d as U
         x = x.contiguous(memory_format=torch.channels_last)
         N, C, H, W = x.shape
+        ctx.save_for_backward(f6)
+        ctx.x_shape = x.shape
+        if scale is not None:
+            L = _lib.lib()
+            sc = _f32(scale.detach())
+            y = torch.empty((N, C, 2 * H, 2 * W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+            rc = L.agf_upfirdn2d_chscale(_lib.ptr(x), _lib.ptr(f6), _lib.ptr(y), _lib.ptr(sc), _lib.dtype_code(x),
+                                         _lib.sizes4(x), _lib.strides4(x), _lib._i32x2(*f6.shape), _lib._i64x2(*f6.stride()),
+                                         _lib.sizes4(y), _lib.strides4(y), 2, 2, 1, 1, 3, 3, 0, 4.0, _lib.EDGE_CLAMP, _lib.stream_ptr(x))
+            _lib.check(rc, 'upfirdn2d_chscale')
+            rc = L.agf_upblur_border_scaled(_lib.ptr(x), _lib.ptr(y), _lib.ptr(sc), _lib.dtype_code(x), N, C, H, W, _lib.stream_ptr(x))
+            _lib.check(rc, 'upblur_border_scaled')
+            return y
         y = U._launch(x, f6, 2, 2, 1, 1, 3, 2, 3, 2, False, 4.0, 'clamp')
         rc = _lib.lib().agf_upblur_border(_lib.ptr(x), _lib.ptr(y), _lib.dtype_code(x), N, C, H, W, 0, _lib.stream_ptr(x))
         _lib.check(rc, 'upblur_border')
-        ctx.save_for_backward(f6)
-        ctx.x_shape = x.shape
         return y
 
     @staticmethod
@@ -888,11 +901,11 @@ class _UpBlur(torch.autograd.Function):
         _lib.check(rc, 'upfirdn2d_fold_border')
         rc = _lib.lib().agf_upblur_border(_lib.ptr(dy), _lib.ptr(dx), _lib.dtype_code(dy), N, C, H, W, 1, _lib.stream_ptr(dy))
         _lib.check(rc, 'upblur_border')
-        return dx, None
+        return dx, None, None
 
 
-def up_blur(x, f6):
-    return _UpBlur.apply(x, f6)
+def up_blur(x, f6, scale=None):
+    return _UpBlur.apply(x, f6, scale)
 
 
 class _PoolLinked(torch.autograd.Function):

@@ -29,12 +29,17 @@ import torch.nn.functional as F
 from ...stylegan3_ops import upfirdn2d, bias_act
 from ... import rng
 from .conv import conv2d, conv2d_act, style_demod, PremaskLink, pool2x_linked, up_blur, torgb, torgb_covers, map_layer
+from . import conv as conv_mod
 
 
 # bias / noise / leaky-ReLU run in the conv kernel's epilogue (with a fused backward).  The fused modulated conv has
 # no double backward, so the generator falls back to the separately differentiable ops when ``fused_epilogue=False``
 # (needed only for the path-length penalty, pl_lambda > 0).
 FUSED_EPILOGUE = True
+UPBLUR_PRESCALE = False   # the first modulated conv's style scale in the fused upsample + blur pass (agf_upfirdn2d_chscale), so that this conv too
+#                           runs on the unscaled direct-to-LDS kernel.  Built, tested, OFF: with it the conv family is faster in isolation and EVERY
+#                           pace candidate (0..5 nodes) replays in the high-power regime: 35.6 ms at 2 150-2 176 MHz / 1 175-1 192 W against
+#                           32.3 ms at 2 376 MHz / 952-990 W without (profiles/r04b_upblur_prescale_power.txt) -- the step sits at the package-power limit
 MAP_FUSED = False         # mapping network: one launch per layer (agf_map_layer_*) instead of addmm + leaky_relu_.  OFF: 72 fewer launches per
 #                           iteration, and the replayed iteration is 1.1 ms SLOWER -- with it every pace candidate settles in a medium power
 #                           state (34.8 ms) instead of the good one (33.7 ms), profiles/r04_power_state.txt; tests compare the two paths
@@ -250,10 +255,21 @@ class StyleBlock(nn.Module):
             # bilinear x2 followed by the [1,2,1] blur: one pass with the composite filter (+ a border-only correction)
             if getattr(self, '_f6', None) is None or self._f6.device != x.device:
                 self._f6 = upfirdn2d.setup_filter([1, 5, 10, 10, 5, 1], device=x.device)
-            x = up_blur(x, self._f6)
+            # the first modulated conv is this tensor's only consumer: with >= 128 input channels (where that conv is bound by the matrix
+            # pipe) its style scale rides in the up-sampling pass and the conv reads an unscaled operand (conv.POSTSCALE_X)
+            first = mods[2] if len(mods) > 4 and isinstance(mods[2], ModulatedConv2d) and isinstance(mods[3], InjectNoise) else None
+            pre_up = first is not None and UPBLUR_PRESCALE and conv_mod.POSTSCALE_X and x.dtype == torch.bfloat16 and first.weight.shape[1] >= 128 \
+                and first.weight.shape[1] % 8 == 0
+            ahead0 = first.scales(y) if pre_up else None
+            x = up_blur(x, self._f6, ahead0[0] if pre_up else None)
             i = 2
+        else:
+            pre_up, ahead0 = False, None
         link = None          # between consecutive modulated convs of the block: the first one's output has the second as its only consumer
         ahead = None         # (s, d) of the next modulated conv when they were taken early
+        if pre_up:
+            link, ahead = PremaskLink(), ahead0
+            link.yscaled = True          # (nothing else armed: the link only tells the conv that its input arrives times its style scale)
         while i < len(mods):
             m = mods[i]
             if isinstance(m, ModulatedConv2d) and i + 2 < len(mods) + 0 and isinstance(mods[i + 1], InjectNoise) \

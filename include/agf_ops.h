@@ -445,6 +445,18 @@ int agf_torgb_bwd(const void* dy, const void* x, const float* w, const float* s_
  *   backward = 1: x = dy [N,2H,2W,C], y = dx [N,H,W,C] (the composite's adjoint), receives the correction's adjoint in place */
 int agf_upblur_border(const void* x, void* y, int dtype, int32_t N, int32_t C, int32_t H, int32_t W, int backward, void* stream);
 
+/* The same two passes with the result multiplied by scale[n, c] (fp32 [N][C], ABI v20): a per-sample, per-channel factor commutes with
+ * the FIR, so the style scale of the modulated conv that is this tensor's only consumer rides in the up-sampling pass and that conv
+ * reads an unscaled operand (conv.POSTSCALE_X).  agf_upfirdn2d_chscale = agf_upfirdn2d served by the channels-last row kernels only
+ * (AGF_ENOKERNEL otherwise); agf_upblur_border_scaled = the forward border correction on a tensor that already holds FIR(x) * scale. */
+int agf_upfirdn2d_chscale(const void* x, const float* f, void* y, const float* chscale, int dtype,
+                          const int32_t in_size[4], const int64_t in_stride[4],
+                          const int32_t f_size[2], const int64_t f_stride[2],
+                          const int32_t out_size[4], const int64_t out_stride[4],
+                          int upx, int upy, int downx, int downy, int padx0, int pady0,
+                          int flip, float gain, int edge_mode, void* stream);
+int agf_upblur_border_scaled(const void* x, void* y, const float* scale, int dtype, int32_t N, int32_t C, int32_t H, int32_t W, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * GPU-side input transform (new: the reference runs torchvision / Pillow transforms in DataLoader worker processes,
  * dataset/_base.py:18-37: Resize -> CenterCrop -> RandomHorizontalFlip -> ToTensor -> Normalize(0.5, 0.5)).  Decoded uint8 images

@@ -1,4 +1,4 @@
-"""BASELINE.json configurations 2 and 4 at FULL size under ``-m gpu`` (configuration 3, StyleGAN2 256x256 batch 64, is
+"""BASELINE.json configurations 2, 3 (with the ADA pipe) and 4 at FULL size under ``-m gpu`` (configuration 3 with DiffAugment is
 tests/test_hip_sg2.py::test_full_size_step_properties): the size-independent properties a full-size run admits -- everything finite, the
 discriminator frozen in the generator half-step, never-used parameters never stepped, a replay from the same seeds reproduces the
 losses, and (StyleGAN2) the HIP-graph replay agrees with the eager iteration.  Element-wise parity lives in the layer-wise tests."""
@@ -62,6 +62,58 @@ def test_stylegan2_128_batch_32_full_size_step_properties():
     # graph replay vs eager in bf16: same kernels and random offsets; after a few optimizer steps roundings have flipped, so the losses
     # are compared loosely and only over the first iterations
     for (d0, g0), (d2, g2) in list(zip(a, c))[:3]:
+        assert d0 == pytest.approx(d2, rel=5e-2, abs=5e-2) and g0 == pytest.approx(g2, rel=5e-2, abs=5e-2), (a, c)
+
+
+def test_stylegan2_256_batch_64_with_ada_full_size_step_properties():
+    """configs[2] as literally written: "StyleGAN2 256x256 + ADA + R1, batch 64/GPU" -- the ADA pipe (every augmentation of the default
+    policy doing work: p forced to 0.3) in place of DiffAugment, eager and replayed from HIP graphs incl. a lazy-R1 iteration: finite
+    everywhere, the discriminator frozen in the generator half-step, the sign statistic of the p schedule accumulating on the device,
+    the replay agreeing with the eager run from the same seeds over the first iterations."""
+    from animeface_amd.implementations.StyleGAN2 import model as M, utils as U
+    from animeface_amd.nnutils import sample_nnoise, update_ema
+
+    def run(graphed):
+        torch.manual_seed(0)
+        G, G_ema, D = M.Generator(256).to(DEV), M.Generator(256).to(DEV), M.Discriminator(256).to(DEV)
+        G.init_weight(functools.partial(M.init_weight_N01, lr=0.01), M.init_weight_N01)
+        D.apply(M.init_weight_N01)
+        G_ema.eval()
+        update_ema(G, G_ema, decay=0)
+        oG, oD = U.build_optimizers(G, D, 0.001, (0., 0.99), 10., 0., 4, 8, capturable=True)
+        step = U.TrainStep(G, G_ema, D, oG, oD, 10., 0., 4, 8, 'ada', 512, functools.partial(sample_nnoise, device=DEV))
+        gen = torch.Generator().manual_seed(3)
+        real = (torch.rand(64, 3, 256, 256, generator=gen) * 2 - 1).to(DEV)
+        seen = {}
+        orig = step._g_half
+
+        def g_half(real, it):
+            out = orig(real, it)
+            seen['d_frozen'] = all(not p.requires_grad for p in D.parameters())
+            return out
+        step._g_half = g_half
+        torch.manual_seed(77)
+        for _ in range(2):
+            step(real)
+        assert step.ada is not None
+        step.ada.p.fill_(0.3)
+        runner = U.GraphedTrainStep(step, real, warmup=0) if graphed else step
+        losses = []
+        for _ in range(4):                                               # iterations 2..5: lazy R1 at 4 (d_k = 4)
+            dl, gl, fake = runner(real)
+            losses.append((float(dl), float(gl)))
+        if graphed:
+            assert runner.kinds() == {'gan', 'r1'}
+        assert seen['d_frozen']
+        assert torch.isfinite(fake).all() and tuple(fake.shape) == (64, 3, 256, 256)
+        for net in (G, D, G_ema):
+            for n, p in net.named_parameters():
+                assert torch.isfinite(p).all(), n
+        assert 0.0 <= float(step.ada.p) <= 1.0 and torch.isfinite(step.ada.signsum).all()
+        return losses
+    a, c = run(False), run(True)
+    assert all(abs(x) < 1e4 for pair in a + c for x in pair), (a, c)
+    for (d0, g0), (d2, g2) in list(zip(a, c))[:2]:
         assert d0 == pytest.approx(d2, rel=5e-2, abs=5e-2) and g0 == pytest.approx(g2, rel=5e-2, abs=5e-2), (a, c)
 
 
