@@ -180,7 +180,7 @@ template <class T> struct RawUnpack<T, 8> {
     }
 };
 
-template <class T, int VEC, int UP, int DN, int FW, int FH, int ROWS, int K00, int PD = 2>
+template <class T, int VEC, int UP, int DN, int FW, int FH, int ROWS, int K00, int PD = 2, bool CHS = false>
 __global__ void __launch_bounds__(256, ROWS_WAVES) upfirdn2d_nhwc_rows(UpfirdnParams p) {
     // K00 = (floor(mid0/UP)+1)*UP - mid0 - 1 for the strip's first row: identical for every strip because ROWS*DN is a
     // multiple of UP, so the host passes it as a template argument and every (input row t, output row r) tap index
@@ -276,8 +276,9 @@ __global__ void __launch_bounds__(256, ROWS_WAVES) upfirdn2d_nhwc_rows(UpfirdnPa
             }
         }
     }
-    if (p.chscale) {
+    if constexpr (CHS) {
         // a per-sample, per-channel factor commutes with the FIR: the style scale of the modulated conv that consumes this tensor
+        // (an instantiation of its own: as a run-time branch it cost the 6 x 6 up-sampling kernel 49-62 spilled registers)
         const float* sc = p.chscale + (int64_t)n * p.C + cg * VEC;
 #pragma unroll
         for (int i = 0; i < VEC; i++) {
@@ -296,13 +297,24 @@ __global__ void __launch_bounds__(256, ROWS_WAVES) upfirdn2d_nhwc_rows(UpfirdnPa
 }
 
 template <class T, int VEC, int UP, int DN, int FW, int FH, int ROWS, int PD = 2>
-static void launch_rows(const UpfirdnParams& p, dim3 g, hipStream_t st) {
+static bool launch_rows(const UpfirdnParams& p, dim3 g, hipStream_t st) {
     // mid0 mod UP is strip-invariant (ROWS*DN % UP == 0)
     const int mid0 = UP - 1 - p.pady0;
     const int k00 = (agf_floor_div(mid0, UP) + 1) * UP - mid0 - 1;
     static_assert((ROWS * DN) % UP == 0, "strip height must preserve the row phase");
+    if (p.chscale) {
+        // the channel-scaled variant exists for the generator's fused upsample + blur only (6 x 6 composite, up 2)
+        if constexpr (UP == 2 && DN == 1 && FW == 6) {
+            if (k00 == 0) hipLaunchKernelGGL((upfirdn2d_nhwc_rows<T, VEC, UP, DN, FW, FH, ROWS, 0, PD, true>), g, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((upfirdn2d_nhwc_rows<T, VEC, UP, DN, FW, FH, ROWS, 1, PD, true>), g, dim3(256), 0, st, p);
+            return true;
+        } else {
+            return false;
+        }
+    }
     if (UP == 1 || k00 == 0) hipLaunchKernelGGL((upfirdn2d_nhwc_rows<T, VEC, UP, DN, FW, FH, ROWS, 0, PD>), g, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((upfirdn2d_nhwc_rows<T, VEC, UP, DN, FW, FH, ROWS, (UP > 1 ? 1 : 0), PD>), g, dim3(256), 0, st, p);
+    return true;
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -696,8 +708,7 @@ static bool launch_nhwc(const UpfirdnParams& p, hipStream_t st) {
     if (p.upx == ux && p.upy == uy && p.downx == dx && p.downy == dy && p.fw == w && p.fh == h && ux == uy && dx == dy && w == h) { \
         constexpr int ROWS = rows;                                                                        \
         dim3 gr((unsigned)agf_ceil_div((int64_t)p.OW * CG, 256), (unsigned)agf_ceil_div(p.OH, ROWS), (unsigned)p.N);   \
-        launch_rows<T, VEC, ux, dx, w, h, ROWS>(pp, gr, st);                                              \
-        return true;                                                                                      \
+        return launch_rows<T, VEC, ux, dx, w, h, ROWS>(pp, gr, st);                                       \
     }
     NHWC_CASE(2, 2, 1, 1, 4, 4, 8)   // bilinear-equivalent 2x upsample  (StyleGAN2 Upsample2x, ToImage)
     NHWC_CASE(1, 1, 1, 1, 3, 3, 8)   // Blur2d
