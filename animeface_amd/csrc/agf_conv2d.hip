@@ -1915,7 +1915,10 @@ static int conv2d_fwd_impl(const void* x, const void* w, void* y,
         const int span = (BLOCK_PIX + W - 2) / W + 1;                  // most rows 256 consecutive pixels can touch
         const int Pflat = (span + 2 * halo) * (W + 2 * halo);
         const double used = (double)N * H * W / ((double)p.pixTiles * blockPix);
-        if (flat_on && p.TI == 1 && W > 1 && H * W >= BLOCK_PIX && used < 0.72 && Pflat <= (ksize == 3 ? 450 : 256) && H * W < 65536) {
+        // (an unscaled launch on the 128-channel tile runs the direct-to-LDS kernel, ~1.7x the flat 64 co x 256 px kernel per useful flop:
+        //  there the rectangular tiles win down to ~60 % use -- the 54 x 54, 512-channel layers of StyleGAN3 at 71 %)
+        const double flatBelow = (MT == 2 && !in_scale && ksize == 3) ? 0.60 : 0.72;
+        if (flat_on && p.TI == 1 && W > 1 && H * W >= BLOCK_PIX && used < flatBelow && Pflat <= (ksize == 3 ? 450 : 256) && H * W < 65536) {
             MT = 1; blockPix = BLOCK_PIX;
             p.flat = 1; p.TI = 1; p.TW = W; p.TH = span;
             p.flatTiles = (H * W + BLOCK_PIX - 1) / BLOCK_PIX;
