@@ -95,7 +95,8 @@ __global__ void __launch_bounds__(256) planar_to_cl_pad_kernel(LayoutParams p) {
     }
 }
 
-template <class U, int CT, bool PAIR = false>
+// SC as above: the planar result times scale[n, c] (agf_cl_to_planar_crop_scaled: dx = t * s of a modulated conv's input gradient)
+template <class U, int CT, bool PAIR = false, int SC = 0>
 __global__ void __launch_bounds__(256) cl_to_planar_crop_kernel(LayoutParams p) {
     constexpr int PT = 64;
     constexpr int VEC = 16 / (int)sizeof(U);
@@ -127,14 +128,28 @@ __global__ void __launch_bounds__(256) cl_to_planar_crop_kernel(LayoutParams p) 
         for (int k = 0; k < CT * PT / 2 / 256; k++) {
             const int c = tid / (PT / 2) + k * (512 / PT), d = tid % (PT / 2);
             const int cc = c0 + c, xi = x0 + 2 * d;
-            if (cc < p.C && xi < p.W) *(uint32_t*)(yb + (int64_t)cc * p.H * p.W + xi) = ((const uint32_t*)tile)[(c * LP + 2 * d) / 2];
+            if (cc < p.C && xi < p.W) {
+                uint32_t w = ((const uint32_t*)tile)[(c * LP + 2 * d) / 2];
+                if (SC == 1) {
+                    const float sc = p.scale[(int64_t)n * p.Cp + cc];
+                    float lo, hi;
+                    Pack16<bf16_t>::unpack(w, lo, hi);
+                    w = Pack16<bf16_t>::pack(lo * sc, hi * sc);
+                }
+                *(uint32_t*)(yb + (int64_t)cc * p.H * p.W + xi) = w;
+            }
         }
         return;
     }
     for (int i = tid; i < CT * PT; i += 256) {
         const int c = i / PT, px = i - c * PT;
         const int cc = c0 + c, xi = x0 + px;
-        if (cc < p.C && xi < p.W) yb[(int64_t)cc * p.H * p.W + xi] = tile[c * LP + px];
+        if (cc < p.C && xi < p.W) {
+            U v = tile[c * LP + px];
+            if (SC == 1) v = (U)f32_to_bf16_bits(bf16_bits_to_f32((uint32_t)v) * p.scale[(int64_t)n * p.Cp + cc]);
+            if (SC == 2) v = (U)__float_as_uint(__uint_as_float((uint32_t)v) * p.scale[(int64_t)n * p.Cp + cc]);
+            yb[(int64_t)cc * p.H * p.W + xi] = v;
+        }
     }
 }
 
@@ -191,22 +206,44 @@ extern "C" int agf_planar_to_cl_pad_scaled(const void* x, void* y, const float* 
     return planar_to_cl_pad_impl(x, y, scale, dtype, N, C, H, W, pad, Cp, stream);
 }
 
-extern "C" int agf_cl_to_planar_crop(const void* x, void* y, int dtype, int32_t N, int32_t C, int32_t H, int32_t W,
-                                     int32_t pad, int32_t Cp, void* stream) {
+static int cl_to_planar_crop_impl(const void* x, void* y, const float* scale, int dtype, int32_t N, int32_t C, int32_t H, int32_t W,
+                                  int32_t pad, int32_t Cp, void* stream) {
     LayoutParams p;
     int rc = layout_common(p, x, y, dtype, N, C, H, W, pad, Cp, "cl_to_planar_crop");
     if (rc != AGF_OK) return rc;
     AGF_CHECK(((uintptr_t)x % 16) == 0, "cl_to_planar_crop: x must be 16-byte aligned");
+    AGF_CHECK(!scale || dtype != AGF_F16, "cl_to_planar_crop_scaled: bf16 or f32");
+    p.scale = scale;
     const int CT = dtype == AGF_F32 ? 32 : 64;
     p.tilesW = (W + 63) / 64; p.tilesC = (C + CT - 1) / CT;
     const int64_t gx = (int64_t)p.tilesW * p.tilesC * H;
     AGF_CHECK(gx < (1ll << 31) && N < 65536, "cl_to_planar_crop: tensor too large");
     dim3 grid((unsigned)gx, (unsigned)N);
-    if (dtype == AGF_F32) hipLaunchKernelGGL((cl_to_planar_crop_kernel<uint32_t, 32>), grid, dim3(256), 0, (hipStream_t)stream, p);
-    else if ((W % 2) == 0 && ((uintptr_t)y % 4) == 0) hipLaunchKernelGGL((cl_to_planar_crop_kernel<uint16_t, 64, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((cl_to_planar_crop_kernel<uint16_t, 64>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    hipStream_t st = (hipStream_t)stream;
+    const bool pair = (W % 2) == 0 && ((uintptr_t)y % 4) == 0;
+    if (dtype == AGF_F32) {
+        if (scale) hipLaunchKernelGGL((cl_to_planar_crop_kernel<uint32_t, 32, false, 2>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((cl_to_planar_crop_kernel<uint32_t, 32>), grid, dim3(256), 0, st, p);
+    } else if (pair) {
+        if (scale) hipLaunchKernelGGL((cl_to_planar_crop_kernel<uint16_t, 64, true, 1>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((cl_to_planar_crop_kernel<uint16_t, 64, true>), grid, dim3(256), 0, st, p);
+    } else {
+        if (scale) hipLaunchKernelGGL((cl_to_planar_crop_kernel<uint16_t, 64, false, 1>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((cl_to_planar_crop_kernel<uint16_t, 64>), grid, dim3(256), 0, st, p);
+    }
     AGF_LAUNCH_CHECK();
     return AGF_OK;
+}
+
+extern "C" int agf_cl_to_planar_crop(const void* x, void* y, int dtype, int32_t N, int32_t C, int32_t H, int32_t W,
+                                     int32_t pad, int32_t Cp, void* stream) {
+    return cl_to_planar_crop_impl(x, y, nullptr, dtype, N, C, H, W, pad, Cp, stream);
+}
+
+extern "C" int agf_cl_to_planar_crop_scaled(const void* x, void* y, const float* scale, int dtype, int32_t N, int32_t C, int32_t H, int32_t W,
+                                            int32_t pad, int32_t Cp, void* stream) {
+    AGF_CHECK(scale, "cl_to_planar_crop_scaled: null scale");
+    return cl_to_planar_crop_impl(x, y, scale, dtype, N, C, H, W, pad, Cp, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -128,11 +128,11 @@ class _ModConvPlanar(torch.autograd.Function):
             dw = conv2d_wgrad_raw(xs, g_cl, k)[:cout, :cin].to(w_p.dtype)
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[2]:
             t = conv2d_fwd_raw(g_cl, flip_transpose(w_p))                                # gradient w.r.t. (x * s), channels-last, padded map
-            dx_cl, ds_raw = scale_dot_raw(xs, t, s_p, want_dx=ctx.needs_input_grad[0])  # dx = t * s;  sum_hw (x s) t
+            _, ds_raw = scale_dot_raw(xs, t, s_p, want_dx=False)                        # sum_hw (x s) t  (no dx tensor: ...)
             if ctx.needs_input_grad[2]:
                 ds = (ds_raw * _inv_scale(s_p))[:, :cin]
-            if dx_cl is not None:
-                dx = layout._to_planar_raw(dx_cl, extra, cin)
+            if ctx.needs_input_grad[0]:
+                dx = layout._to_planar_raw(t, extra, cin, scale=s_p)                    # ... dx = t * s rides in the way back to planar
         if d_p is not None and ctx.needs_input_grad[3]:
             _, dots = scale_dot_raw(g_cl, y_cl, d_p, want_dx=False)                      # sum_hw (dy d)(d conv)
             dd = (dots / d_p.square())[:, :cout]

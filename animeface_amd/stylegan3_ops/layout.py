@@ -31,11 +31,18 @@ def _to_cl_raw(x, pad, cp, scale=None):
     return y
 
 
-def _to_planar_raw(x, pad, c):
+def _to_planar_raw(x, pad, c, scale=None):
+    """``scale`` [N, cp] fp32: the output is multiplied by scale[n, c] on the way (``agf_cl_to_planar_crop_scaled``)."""
     N, cp, Hp, Wp = x.shape
     x = x.contiguous(memory_format=torch.channels_last)
     H, W = Hp - 2 * pad, Wp - 2 * pad
     y = torch.empty((N, c, H, W), dtype=x.dtype, device=x.device)
+    if scale is not None:
+        scale = scale.float().contiguous()
+        assert tuple(scale.shape) == (N, cp)
+        _lib.check(_lib.lib().agf_cl_to_planar_crop_scaled(_lib.ptr(x), _lib.ptr(y), _lib.ptr(scale), _lib.dtype_code(x), N, c, H, W, pad, cp,
+                                                           _lib.stream_ptr(x)), 'cl_to_planar_crop_scaled')
+        return y
     _lib.check(_lib.lib().agf_cl_to_planar_crop(_lib.ptr(x), _lib.ptr(y), _lib.dtype_code(x), N, c, H, W, pad, cp,
                                                 _lib.stream_ptr(x)), 'cl_to_planar_crop')
     return y

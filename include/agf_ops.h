@@ -310,6 +310,10 @@ int agf_planar_to_cl_pad(const void* x, void* y, int dtype, int32_t N, int32_t C
  * demodulation scale of the output gradient (backward) ride along and the MFMA launches run without an operand scale.  bf16 or f32. */
 int agf_planar_to_cl_pad_scaled(const void* x, void* y, const float* scale, int dtype, int32_t N, int32_t C, int32_t H, int32_t W,
                                 int32_t pad, int32_t Cp, void* stream);
+/* ... and its adjoint with the same scale: y[n,c] = crop(x)[n,c] * scale[n, c] (scale fp32 [N][Cp]) -- the gradient t of a modulated conv's
+ * scaled input becomes dx = t * s on the way back to the planar layout, and agf_scale_dot only forms ds (no dx tensor). */
+int agf_cl_to_planar_crop_scaled(const void* x, void* y, const float* scale, int dtype, int32_t N, int32_t C, int32_t H, int32_t W,
+                                 int32_t pad, int32_t Cp, void* stream);
 int agf_cl_to_planar_crop(const void* x, void* y, int dtype, int32_t N, int32_t C, int32_t H, int32_t W,
                           int32_t pad, int32_t Cp, void* stream);
 
