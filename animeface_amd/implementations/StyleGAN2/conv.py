@@ -298,6 +298,19 @@ def conv2d_wgrad_raw(x, dy, ksize, in_scale=None, out_scale=None, scale=1.0):
     return dw
 
 
+def grad_wanted(t):
+    """Inside a backward: will the running autograd pass use a gradient for ``t``?  ``ctx.needs_input_grad`` only says that ``t`` required a
+    gradient at forward time; under ``autograd.grad(inputs=...)`` (the R1 / path-length passes, reference nnutils/loss/penalty.py:11-26) the
+    engine drops what does not lead to ``inputs`` -- for a convolution that is the whole weight-gradient launch.  Errs on the side of True."""
+    if t is None or not t.requires_grad:
+        return False
+    try:
+        node = t.grad_fn if t.grad_fn is not None else torch.autograd.graph._get_grad_fn_or_grad_acc(t)
+        return bool(torch._C._will_engine_execute_node(node))
+    except (RuntimeError, AttributeError):
+        return True         # a leaf the pass captures directly, no pass running, or a torch without the query
+
+
 def flip_transpose(w):
     """Weights of the adjoint (dgrad) convolution: spatial flip + swap of the channel axes."""
     return w.flip([2, 3]).transpose(0, 1)
@@ -329,7 +342,7 @@ class _ConvFwd(torch.autograd.Function):
                         dx = t * s_in[:, :, None, None].to(t.dtype)
                     if ctx.needs_input_grad[2]:
                         ds_in = (x.float() * t.float()).sum((2, 3))
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and grad_wanted(w):
             dw = _ConvWgrad.apply(x, dy, s_in, s_out, w.shape[2]).to(w.dtype)
         if s_out is not None and ctx.needs_input_grad[3]:
             if not torch.is_grad_enabled() and y.shape[1] % 8 == 0 and y.dtype == torch.bfloat16:
@@ -1182,6 +1195,8 @@ class _FusedConv(torch.autograd.Function):
                 raise RuntimeError('the fused modulated conv has no double backward; build the generator with '
                                    'fused_epilogue=False when pl_lambda > 0')
             from ...stylegan3_ops import bias_act as _ba
+            # (autograd.grad(inputs=images) of R1 wants neither parameter gradient: no weight-gradient launch, no channel sum)
+            need_w, need_b = need_w and grad_wanted(weight), need_b and grad_wanted(bias)
             if act == ACT_LRELU:
                 g = _ba._bias_act_hip(dim=1, act='lrelu', alpha=alpha, gain=gain).Grad.apply(dy, None, None, y)
             else:

@@ -441,6 +441,49 @@ def test_dblock_with_the_pooled_conv_output_matches_conv_then_pool(monkeypatch, 
 
 
 @pytest.mark.gpu
+def test_r1_image_gradient_pass_launches_no_parameter_gradients(monkeypatch):
+    """autograd.grad(D(x).sum(), x, create_graph=True) (reference nnutils/loss/penalty.py:11-26) only wants the image gradient: the conv
+    backward asks the engine (conv.grad_wanted) and launches neither a weight gradient nor a bias sum; the penalty's parameter gradients
+    (second-order pass, which does want them) are bit-identical to the ones computed with the query switched off."""
+    from animeface_amd.implementations.StyleGAN2 import model as M, conv as C
+    torch.manual_seed(5)
+    blk = M.DBlock(32, 64).to(DEV)
+    blk.apply(M.init_weight_N01)
+    x0 = torch.randn(4, 32, 32, 32, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    calls = []
+    real_wgrad = C.conv2d_wgrad_raw
+    monkeypatch.setattr(C, 'conv2d_wgrad_raw', lambda *a, **k: (calls.append(1), real_wgrad(*a, **k))[1])
+    vals, first, second = [], [], []
+    for query in (True, False):
+        if not query:
+            monkeypatch.setattr(C, 'grad_wanted', lambda t: t is not None and t.requires_grad)
+        x = x0.clone().requires_grad_(True)
+        calls.clear()
+        (gx,) = torch.autograd.grad(blk(x).float().sum(), x, create_graph=True)
+        first.append(len(calls))
+        pen = gx.float().square().sum()
+        calls.clear()
+        vals.append(torch.autograd.grad(pen, list(blk.parameters()), allow_unused=True))
+        second.append(len(calls))
+    assert first == [0, 3], first              # two 3x3 convs + the 1x1 skip conv, only without the query
+    assert second[0] == second[1] > 0
+    for a, b in zip(vals[0], vals[1]):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert torch.equal(a, b)
+    # an ordinary backward wants everything
+    calls.clear()
+    monkeypatch.undo()
+    monkeypatch.setattr(C, 'conv2d_wgrad_raw', lambda *a, **k: (calls.append(1), real_wgrad(*a, **k))[1])
+    x = x0.clone().requires_grad_(True)
+    with torch.enable_grad():
+        blk(x).float().sum().backward(create_graph=True)
+    assert len(calls) == 3 and all(p.grad is not None for p in blk.parameters())
+    for p in blk.parameters():
+        p.grad = None
+
+
+@pytest.mark.gpu
 def test_dblock_linked_backward_matches_unlinked(monkeypatch):
     """DBlock with the PremaskLink / pooled-gradient fusions against the same block with them switched off (bf16, same inputs)."""
     from animeface_amd.implementations.StyleGAN2 import model as M, conv as C
