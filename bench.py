@@ -143,6 +143,7 @@ def main():
                                                          'from HIP graphs (GraphedTrainStep: same kernels, one host call per iteration and graph segment); '
                                                          'the iterations sampled for the per-launch roofline timing always run eagerly')
     ap.add_argument('--pace', default='auto', help="memset nodes at the head of the recorded iteration: an integer, or 'auto' = calibrate 0..3 by timing replays (GraphedTrainStep.calibrate)")
+    ap.add_argument('--ada-p', type=float, default=None, help="with --augment ada: start the pipe's probability here instead of 0 (at 0 every augmentation is gated off and the reflect margins are minimal)")
     ap.add_argument('--deterministic', action='store_true', help='agf_set_deterministic(1): one writer per output element instead of cross-workgroup fp32 atomics (bit-reproducible, slower)')
     ap.add_argument('--ab', default='', help='comma-separated A/B switches for same-box comparisons: no-torgb, mapfuse / no-mapfuse, upscale (model.UPBLUR_PRESCALE), candN (N pace candidates)')
     ap.add_argument('--dp-mode', default=None, choices=['ingraph', 'segmented'],
@@ -211,6 +212,8 @@ def main():
                        functools.partial(sample_nnoise, device=dev), red_G, red_D)
     gen = torch.Generator(device='cpu').manual_seed(rank)
     real = (torch.rand(args.batch, 3, S, S, generator=gen) * 2 - 1).to(dev)
+    if args.ada_p is not None and args.augment == 'ada':
+        step._ada_pipe(real).p.fill_(args.ada_p)
 
     # Load phase (untimed, before the W warm-up steps): run each code path of the loop once -- a GAN-loss iteration and a lazy-R1
     # iteration -- on scratch copies of the networks, so that every kernel variant is resident and the allocator pools have their
@@ -378,6 +381,7 @@ def main():
         ada_ms = (time.perf_counter() - ta) / n_ada * 1e3
         ada_out = {'value': round(args.batch * world / (ada_ms * 1e-3), 2), 'unit': 'img/s', 'ms_per_step': round(ada_ms, 3), 'steps': n_ada,
                    'p': round(float(ada_step.ada.p), 4), 'execution': ada_exec,
+                   'pace': getattr(ada_run, 'pace_report', None),
                    'note': 'configs[2] "+ ADA": GAN-loss iterations with the ADA pipe (12 augmentations, p forced to 0.3) in place of DiffAugment, after the timed window'}
     fir_out = None
     if rank == 0 and not args.no_upfirdn2d_rows:
