@@ -6,12 +6,12 @@ import torch
 from animeface_amd.implementations.StyleGAN2.conv import conv2d_fwd_raw, prep_weights_raw
 N, Cin, Cout, H, W = [int(v) for v in sys.argv[1:6]]
 mode = sys.argv[6] if len(sys.argv) > 6 else ''
-mask = mode == 'mask'
+mask = mode in ('mask', 'masknosum')
 x = torch.randn(N, Cin, H, W, device='cuda').to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
 w = torch.randn(Cout, Cin, 3, 3, device='cuda') / (Cin * 9) ** 0.5
 wq = prep_weights_raw(w, 1.0, torch.bfloat16)[0]
 my = torch.randn(N, Cout, H, W, device='cuda').to(torch.bfloat16).contiguous(memory_format=torch.channels_last) if mask else None
-ms_ = torch.zeros(256, Cout, device='cuda') if mask else None
+ms_ = torch.zeros(256, Cout, device='cuda') if mode == 'mask' else None
 from animeface_amd.implementations.StyleGAN2.conv import ACT_LRELU
 kw = {}
 if mode in ('bias', 'demod'):
