@@ -681,74 +681,84 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_dl_kernel(ConvPa
     bf16_t* sW = (bf16_t*)smem_raw;                                  // [2][WBUF]
     bf16_t* sX = sW + 2 * WBUF;                                      // [2][XBUF]
 
-    // PERSISTENT over tiles: a block walks the slots  b >> 3, + gridDim.x / 8, ...  of its XCD (launch_fwd_dl caps the grid at the blocks
-    // the chip holds at once).  While the LAST channel chunk of a tile is contracted, chunk 0 of the block's NEXT tile is already on its way
-    // into the other LDS buffer, so the load latency a fresh block would sit through (address setup, first DMA round trip, block dispatch)
-    // is hidden under the last chunk's MFMAs and the epilogue's stores -- with one 8-wave block per CU nothing else would cover it.
     const int b = blockIdx.x;
-    const int xcd = b & 7, slotStep = (int)(gridDim.x >> 3);
-    int slot = b >> 3;
+    const int xcd = b & 7, slot = b >> 3;
     // xcdBand: XCD x owns the contiguous band of pixel tiles [x * xcdBand, (x+1) * xcdBand) -- tiles that share halo rows run on
     // the same XCD at about the same time, so its L2 serves the halo re-reads; 0 = tiles interleaved over the XCDs
-    auto tile_of = [&](int s, int& pixTile, int& coTile) -> bool {
-        const int pt = s / p.tilesCo;
-        pixTile = p.xcdBand ? xcd * p.xcdBand + pt : pt * 8 + xcd;
-        coTile = s - pt * p.tilesCo;
-        return pixTile < p.pixTiles && !(p.xcdBand && pt >= p.xcdBand);
-    };
-    int pixTile, coTile;
-    if (!tile_of(slot, pixTile, coTile)) return;
+    const int pixTile = p.xcdBand ? xcd * p.xcdBand + slot / p.tilesCo : (slot / p.tilesCo) * 8 + xcd;
+    const int coTile = slot % p.tilesCo;
+    if (pixTile >= p.pixTiles || (p.xcdBand && slot / p.tilesCo >= p.xcdBand)) return;
+    int tq = pixTile;
+    const int tw = tq % p.tilesW; tq /= p.tilesW;
+    const int th = tq % p.tilesH;
+    const int tn = tq / p.tilesH;
+    const int n0 = tn * p.TI, h0 = th * p.TH, w0 = tw * p.TW;
+    const int co0 = coTile * BM;
     const int PW = p.TW + 2 * HALO, PH = p.TH + 2 * HALO;
     const int P = p.TI * PH * PW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / NWN, wn = wave % NWN;
     const int l31 = lane & 31, lhi = lane >> 5;
-    auto geometry = [&](int pt, int ct, int& n0, int& h0, int& w0, int& co0) {
-        int tq = pt;
-        const int tw = tq % p.tilesW; tq /= p.tilesW;
-        const int th = tq % p.tilesH;
-        const int tn = tq / p.tilesH;
-        n0 = tn * p.TI; h0 = th * p.TH; w0 = tw * p.TW; co0 = ct * BM;
-    };
+
+    // LDS layout of the activation patch: TWO PLANES, plane h = channels [8h, 8h + 8) of every patch pixel as 16-byte rows
+    // ([2][PMAX][8]).  A lane (pixel column l31, k-half lhi) of a B fragment reads plane lhi at row bPix + tap shift: the shift is a
+    // constant BYTE OFFSET for every lane (an immediate of the ds_read), 16 consecutive pixels are 256 contiguous bytes (every bank
+    // once: conflict-free for any shift).  The earlier [pixel][2 halves] rows needed a swizzle that depended on bit 3 of the SHIFTED
+    // pixel index, so every (tap, j) pair had its own pair of address registers -- 72 VGPRs, which left the compiler no room to fetch
+    // the next tap's fragments under the current tap's MFMAs (it spilled, and every tap exposed its LDS latency).
+    // Weights keep 32-byte rows with the row-bit-3 swizzle (their tap offset is a multiple of BM rows: already an immediate).
+    int bRow[NJ][KS];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+        const int q = wn * (32 * NJ) + j * 32 + l31;
+        const int c = q & (p.TW - 1), r = (q >> p.twShift) & (p.TH - 1), ti = q >> (p.twShift + p.thShift);
+#pragma unroll
+        for (int kh = 0; kh < KS; kh++) bRow[j][kh] = (lhi * PMAX + (ti * PH + r + kh) * PW + c) * 8;      // element offset inside one X buffer
+    }
+    int aBase[MT];
+#pragma unroll
+    for (int i = 0; i < MT; i++) aBase[i] = (wm * 32 * MT + i * 32 + l31) * KC + ((lhi ^ ((l31 >> 3) & 1)) << 3);
 
     f32x16 acc[MT][NJ];
+#pragma unroll
+    for (int i = 0; i < MT; i++)
+#pragma unroll
+        for (int j = 0; j < NJ; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-    // buffer descriptors: the tile's TI images of x (offsets stay below 2^31 for any image size), the whole weight tensor
+    // buffer descriptors: the block's TI images of x (offsets stay below 2^31 for any image size), the whole weight tensor
     const int64_t imgBytes = (int64_t)p.H * p.W * p.Cin * 2;
-    __amdgpu_buffer_rsrc_t xRes;
+    int64_t xBytes = imgBytes * (n0 + p.TI <= p.N ? p.TI : p.N - n0);
+    if (xBytes > 0x60000000) xBytes = 0x60000000;
+    const __amdgpu_buffer_rsrc_t xRes = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (int64_t)n0 * p.H * p.W * p.Cin), 0, (int)xBytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wRes = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.Cout * TAPS * p.Cin * 2, 0x00020000);
     // chunk-invariant byte offsets of this thread's vectors (channel 0 of the chunk), OOB for halo pixels outside the image / co tails
     int xoff[XV], woff[WV];
     const int half = (tid & 1) ^ ((tid >> 4) & 1);                    // which 8-channel half this lane's WEIGHT slot holds (swizzle above)
     unsigned xHalf = 0;                                               // bit i: this lane's activation slot of piece i lies in plane 1
 #pragma unroll
-    for (int i = 0; i < XV; i++) xHalf |= (unsigned)(tid + i * NTHR >= PMAX ? 1 : 0) << i;
-    auto offsets = [&](int n0, int h0, int w0, int co0, int opq) {
-        int64_t xBytes = imgBytes * (n0 + p.TI <= p.N ? p.TI : p.N - n0);
-        if (xBytes > 0x60000000) xBytes = 0x60000000;
-        xRes = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (int64_t)n0 * p.H * p.W * p.Cin), 0, (int)xBytes, 0x00020000);
-#pragma unroll
-        for (int i = 0; i < XV; i++) {
-            const int v = tid + opq + i * NTHR;                       // slot: plane v / PMAX, patch pixel v % PMAX
-            const int hx = v >= PMAX ? 1 : 0;
-            const int pix = v - hx * PMAX;
-            xoff[i] = OOB;
-            if (pix < P) {
-                const int t2 = PW == 1 ? pix : (int)__umulhi((uint32_t)pix, p.mPW); const int pc = pix - t2 * PW;
-                const int ti = PH == 1 ? t2 : (int)__umulhi((uint32_t)t2, p.mPH); const int pr = t2 - ti * PH;
-                const int n = n0 + ti, h = h0 + pr - HALO, w = w0 + pc - HALO;
-                if (n < p.N && h >= 0 && h < p.H && w >= 0 && w < p.W) xoff[i] = (((ti * p.H + h) * p.W + w) * p.Cin + hx * 8) * 2;
-            }
+    for (int i = 0; i < XV; i++) {
+        const int v = tid + i * NTHR;                                 // slot: plane v / PMAX, patch pixel v % PMAX
+        const int hx = v >= PMAX ? 1 : 0;
+        const int pix = v - hx * PMAX;
+        xHalf |= (unsigned)hx << i;
+        xoff[i] = OOB;
+        if (pix < P) {
+            const int t2 = PW == 1 ? pix : (int)__umulhi((uint32_t)pix, p.mPW); const int pc = pix - t2 * PW;
+            const int ti = PH == 1 ? t2 : (int)__umulhi((uint32_t)t2, p.mPH); const int pr = t2 - ti * PH;
+            const int n = n0 + ti, h = h0 + pr - HALO, w = w0 + pc - HALO;
+            if (n < p.N && h >= 0 && h < p.H && w >= 0 && w < p.W) xoff[i] = (((ti * p.H + h) * p.W + w) * p.Cin + hx * 8) * 2;
         }
+    }
 #pragma unroll
-        for (int i = 0; i < WV; i++) {
-            const int v = tid + opq + i * NTHR;
-            const int row = v >> 1;
-            const int tap = row / BM, co = row - tap * BM;
-            woff[i] = OOB;
-            if (v < WTOT && co0 + co < p.Cout) woff[i] = (((co0 + co) * TAPS + tap) * p.Cin + half * 8) * 2;
-        }
-    };
+    for (int i = 0; i < WV; i++) {
+        const int v = tid + i * NTHR;
+        const int row = v >> 1;
+        const int tap = row / BM, co = row - tap * BM;
+        woff[i] = OOB;
+        if (v < WTOT && co0 + co < p.Cout) woff[i] = (((co0 + co) * TAPS + tap) * p.Cin + half * 8) * 2;
+    }
     typedef __attribute__((address_space(3))) void* lds_ptr;
     // one DMA piece = one wave-load (1 KB per wave): pieces [0, WV) carry the weight chunk, [WV, WV + XV) the activation patch
     auto issue_range = [&](int c0, int buf, int lo, int hi) {
@@ -775,106 +785,51 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_dl_kernel(ConvPa
     constexpr int NP = WV + XV;
 
     const int nChunks = (p.Cin + KC - 1) / KC;
-    int n0, h0, w0, co0;
-    geometry(pixTile, coTile, n0, h0, w0, co0);
-    offsets(n0, h0, w0, co0, 0);
-    int bufBase = 0;                                                  // the LDS buffer that holds chunk 0 of the current tile
     issue(0, 0);
-    for (;;) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int ch = 0; ch < nChunks; ch++) {
+        const int cur = ch & 1;
+        const bool more = ch + 1 < nChunks;
+        const bf16_t* cW = sW + cur * WBUF;
+        const bf16_t* cX = sX + cur * XBUF;
+        // fragments are fetched ONE TAP AHEAD: the ds_reads of tap t + 1 are in flight under the MFMAs of tap t
+        bf16x8 af[2][MT], bfr[2][NJ];
+        auto fetch = [&](int tap, int kh, int kw, int slot) {
 #pragma unroll
-        for (int i = 0; i < MT; i++)
+            for (int i = 0; i < MT; i++) af[slot][i] = *(const bf16x8*)(cW + tap * BM * KC + aBase[i]);
 #pragma unroll
-            for (int j = 0; j < NJ; j++)
+            for (int j = 0; j < NJ; j++) bfr[slot][j] = *(const bf16x8*)(cX + bRow[j][kh] + kw * 8);
+        };
+        fetch(0, 0, 0, 0);
 #pragma unroll
-                for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-        // Lane constants of the fragment reads, recomputed per tile behind an opaque zero: hoisted out of the tile loop they would stay live
-        // across the epilogue, whose mask / residual vectors already need every register (137 spilled registers instead of 10)
-        int opq = 0;
-        asm volatile("" : "+v"(opq));
-        const int l31o = l31 + opq;
-        // LDS layout of the activation patch: TWO PLANES, plane h = channels [8h, 8h + 8) of every patch pixel as 16-byte rows
-        // ([2][PMAX][8]).  A lane (pixel column l31, k-half lhi) of a B fragment reads plane lhi at row bPix + tap shift: the shift is a
-        // constant BYTE OFFSET for every lane (an immediate of the ds_read), 16 consecutive pixels are 256 contiguous bytes (every bank
-        // once: conflict-free for any shift).  The earlier [pixel][2 halves] rows needed a swizzle that depended on bit 3 of the SHIFTED
-        // pixel index, so every (tap, j) pair had its own pair of address registers -- 72 VGPRs, which left the compiler no room to fetch
-        // the next tap's fragments under the current tap's MFMAs (it spilled, and every tap exposed its LDS latency).
-        // Weights keep 32-byte rows with the row-bit-3 swizzle (their tap offset is a multiple of BM rows: already an immediate).
-        int bRow[NJ][KS];
+        for (int kh = 0; kh < KS; kh++) {
 #pragma unroll
-        for (int j = 0; j < NJ; j++) {
-            const int q = wn * (32 * NJ) + j * 32 + l31o;
-            const int c = q & (p.TW - 1), r = (q >> p.twShift) & (p.TH - 1), ti = q >> (p.twShift + p.thShift);
+            for (int kw = 0; kw < KS; kw++) {
+                const int tap = kh * KS + kw;
+                const int slot = tap & 1;
+                if (tap + 1 < TAPS) fetch(tap + 1, (tap + 1) / KS, (tap + 1) % KS, slot ^ 1);
 #pragma unroll
-            for (int kh = 0; kh < KS; kh++) bRow[j][kh] = (lhi * PMAX + (ti * PH + r + kh) * PW + c) * 8;      // element offset inside one X buffer
-        }
-        int aBase[MT];
+                for (int i = 0; i < MT; i++)
 #pragma unroll
-        for (int i = 0; i < MT; i++) aBase[i] = (wm * 32 * MT + i * 32 + l31o) * KC + ((lhi ^ ((l31o >> 3) & 1)) << 3);
-
-        offsets(n0, h0, w0, co0, opq);                                // (again: they do not live through the epilogue either)
-        // chunk 0 of this tile has landed for every wave (first tile: issued above; later tiles: issued under the previous tile's last chunk),
-        // and every wave is done with the previous tile's last buffer
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        int nPix, nCo;
-        const bool hasNext = tile_of(slot + slotStep, nPix, nCo);
-        int nn0 = 0, nh0 = 0, nw0 = 0, nco0 = 0;
-        for (int ch = 0; ch < nChunks; ch++) {
-            const int cur = (bufBase + ch) & 1;
-            const bool more = ch + 1 < nChunks;
-            if (!more && hasNext) {
-                // this tile issues no more loads: its descriptor and offsets make room for the next tile's
-                geometry(nPix, nCo, nn0, nh0, nw0, nco0);
-                offsets(nn0, nh0, nw0, nco0, opq);
-            }
-            const bool feed = more || hasNext;
-            const int c0next = more ? (ch + 1) * KC : 0;
-            const bf16_t* cW = sW + cur * WBUF;
-            const bf16_t* cX = sX + cur * XBUF;
-            // fragments are fetched ONE TAP AHEAD: the ds_reads of tap t + 1 are in flight under the MFMAs of tap t
-            bf16x8 af[2][MT], bfr[2][NJ];
-            auto fetch = [&](int tap, int kh, int kw, int slot2) {
-#pragma unroll
-                for (int i = 0; i < MT; i++) af[slot2][i] = *(const bf16x8*)(cW + tap * BM * KC + aBase[i]);
-#pragma unroll
-                for (int j = 0; j < NJ; j++) bfr[slot2][j] = *(const bf16x8*)(cX + bRow[j][kh] + kw * 8);
-            };
-            fetch(0, 0, 0, 0);
-#pragma unroll
-            for (int kh = 0; kh < KS; kh++) {
-#pragma unroll
-                for (int kw = 0; kw < KS; kw++) {
-                    const int tap = kh * KS + kw;
-                    const int slot2 = tap & 1;
-                    if (tap + 1 < TAPS) fetch(tap + 1, (tap + 1) / KS, (tap + 1) % KS, slot2 ^ 1);
-#pragma unroll
-                    for (int i = 0; i < MT; i++)
-#pragma unroll
-                        for (int j = 0; j < NJ; j++)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[slot2][i], bfr[slot2][j], acc[i][j], 0, 0, 0);
-                    if (feed) {
-                        // the next chunk's DMA pieces go out BETWEEN the taps' MFMA groups (one or two per tap over the first TAPS - 1 taps; the last
-                        // tap covers the youngest pieces' flight): issued in one burst at the top of the chunk they cost every wave ~1 000 cycles in
-                        // lock step, during which the matrix pipe idles (+6-11 % on the >= 128-channel layers, tools/ab_dl.sh)
-                        constexpr int T1 = TAPS > 1 ? TAPS - 1 : 1;
-                        if (tap < T1) issue_range(c0next, cur ^ 1, tap * NP / T1, (tap + 1) * NP / T1);
-                    }
+                    for (int j = 0; j < NJ; j++)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[slot][i], bfr[slot][j], acc[i][j], 0, 0, 0);
+                if (more) {
+                    // the next chunk's DMA pieces go out BETWEEN the taps' MFMA groups (one or two per tap over the first TAPS - 1 taps; the last
+                    // tap covers the youngest pieces' flight): issued in one burst at the top of the chunk they cost every wave ~1 000 cycles in
+                    // lock step, during which the matrix pipe idles (+6-11 % on the >= 128-channel layers, tools/ab_dl.sh)
+                    constexpr int T1 = TAPS > 1 ? TAPS - 1 : 1;
+                    if (tap < T1) issue_range((ch + 1) * KC, cur ^ 1, tap * NP / T1, (tap + 1) * NP / T1);
                 }
             }
-            if (more) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's loads of the next chunk have landed ...
-                __syncthreads();                                      // ... and so have everyone's; everyone is done with `cur`
-            }
         }
-        // (the channel-sum scratch of the masked epilogue lies BEHIND the two buffer sets: the next tile's chunk 0 is landing in one of them)
-        unsigned char* scratch = smem_raw + (size_t)2 * (WBUF + XBUF) * 2;
-        if (POOL || p.vecStore == 2) conv_epilogue_pl<MT, NJ, POOL, PLAIN>(p, acc, scratch, wave, lane, wm, wn, n0, h0, w0, 0, co0, NWN, NWM * NWN, pixTile & 255);
-        else conv_epilogue<MT, NJ>(p, acc, smem_raw, wave, lane, wm, wn, n0, h0, w0, 0, co0, NWN, NWM * NWN, pixTile & 255);   // (one tile per block: see launch_fwd_dl)
-        if (!hasNext) break;
-        slot += slotStep; pixTile = nPix;
-        n0 = nn0; h0 = nh0; w0 = nw0; co0 = nco0;
-        bufBase = (bufBase + nChunks) & 1;
+        if (ch + 1 < nChunks) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's loads of the next chunk have landed ...
+            __syncthreads();                                          // ... and so have everyone's; everyone is done with `cur`
+        }
     }
+    if (POOL || p.vecStore == 2) conv_epilogue_pl<MT, NJ, POOL, PLAIN>(p, acc, smem_raw, wave, lane, wm, wn, n0, h0, w0, 0, co0, NWN, NWM * NWN, pixTile & 255);
+    else conv_epilogue<MT, NJ>(p, acc, smem_raw, wave, lane, wm, wn, n0, h0, w0, 0, co0, NWN, NWM * NWN, pixTile & 255);
 }
 
 template <int KS, int MT, int NWN, int PMAX, int NWM, int NJ, bool POOL = false, bool PLAIN = false>
@@ -885,17 +840,10 @@ static int launch_fwd_dl(const ConvParams& p0, hipStream_t st) {
     const int P = p.TI * (p.TH + 2 * HALO) * (p.TW + 2 * HALO);
     if (P > PMAX || p.flat || p.in_scale) return AGF_ENOKERNEL;
     if ((int64_t)p.Cout * TAPS * p.Cin * 2 >= 0x60000000ll || (int64_t)p.TI * p.H * p.W * p.Cin * 2 >= 0x60000000ll) return AGF_ENOKERNEL;
-    size_t lds = (size_t)2 * (TAPS * BM * 2 + PMAX * 2) * 16 + (size_t)(NTHR / 64) * 256;       // two buffer sets + the channel-sum scratch
+    size_t lds = (size_t)2 * (TAPS * BM * 2 + PMAX * 2) * 16;
     if (lds < (size_t)(NTHR / 64) * 32 * (64 * MT + 16) + 4096) lds = (size_t)(NTHR / 64) * 32 * (64 * MT + 16) + 4096;     // the epilogue strips
     if (lds > 160 * 1024) return AGF_ENOKERNEL;
-    int slots = ((p.pixTiles + 7) / 8) * p.tilesCo;
-    // persistent blocks for the 8-wave tiling (one block per CU: nothing else covers a fresh block's first load): as many blocks as the chip
-    // holds at once, each walking slots and prefetching its next tile under the current one's last chunk -- +3-5 % on the plain launches,
-    // +5-8 % on the ones with the fused gradient epilogue (tools/ab_persist.sh, profiles/r04c_dl_persistent.txt).  The 4-wave tiling has two
-    // blocks per CU that cover for each other (measured: no difference) and keeps one tile per block; so does the strip epilogue, which
-    // re-uses the buffers the prefetch lands in
-    constexpr bool persist = true;
-    if (persist && (POOL || p.vecStore == 2) && 2 * lds > 160 * 1024 && slots > 256 / 8) slots = 256 / 8;
+    const int slots = ((p.pixTiles + 7) / 8) * p.tilesCo;
     hipError_t e = hipFuncSetAttribute((const void*)conv2d_fwd_dl_kernel<KS, MT, NWN, PMAX, NWM, NJ, POOL, PLAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { agf_set_error("conv2d_fwd: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e)); return AGF_ELAUNCH; }
     hipLaunchKernelGGL((conv2d_fwd_dl_kernel<KS, MT, NWN, PMAX, NWM, NJ, POOL, PLAIN>), dim3((unsigned)(slots * 8)), dim3(NTHR), lds, st, p);
