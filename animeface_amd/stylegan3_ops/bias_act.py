@@ -76,49 +76,58 @@ def _native(x, b, xref, yref, dy, grad, dim, act_idx, alpha, gain, clamp):
 _bias_act_hip_cache = dict()
 
 
+def _layout_of(t):
+    """The memory order the op keeps: channels-last when the tensor already is (rank > 2, unit channel stride), NCHW otherwise."""
+    return torch.channels_last if (t.ndim > 2 and t.stride(1) == 1) else torch.contiguous_format
+
+
 def _bias_act_hip(dim=1, act='linear', alpha=None, gain=None, clamp=None):
+    """Autograd op factory, one pair of classes per parameter set (cached, as the reference's ``_bias_act_cuda``: bias_act.py:128-211)."""
     assert clamp is None or clamp >= 0
     spec = activation_funcs[act]
-    alpha = float(alpha if alpha is not None else spec.def_alpha)
-    gain = float(gain if gain is not None else spec.def_gain)
-    clamp = float(clamp if clamp is not None else -1)
+    alpha = float(spec.def_alpha if alpha is None else alpha)
+    gain = float(spec.def_gain if gain is None else gain)
+    clamp = -1.0 if clamp is None else float(clamp)
     key = (dim, act, alpha, gain, clamp)
-    if key in _bias_act_hip_cache:
-        return _bias_act_hip_cache[key]
+    op = _bias_act_hip_cache.get(key)
+    if op is not None:
+        return op
+    identity = act == 'linear' and gain == 1 and clamp < 0        # without a bias the op then returns its input, and its gradient is dy
+
+    def sum_but(t, keep):
+        return t.sum([d for d in range(t.ndim) if d != keep])
 
     class BiasActHip(torch.autograd.Function):
         @staticmethod
         def forward(ctx, x, b):
-            ctx.memory_format = torch.channels_last if x.ndim > 2 and x.stride(1) == 1 else torch.contiguous_format
+            ctx.memory_format = _layout_of(x)
             x = x.contiguous(memory_format=ctx.memory_format)
-            b = b.contiguous() if b is not None else None
-            y = x
-            if act != 'linear' or gain != 1 or clamp >= 0 or b is not None:
-                y = _native(x, b, None, None, None, 0, dim, spec.cuda_idx, alpha, gain, clamp)
-            need_x = 'x' in spec.ref or spec.has_2nd_grad
+            b = None if b is None else b.contiguous()
+            y = x if (identity and b is None) else _native(x, b, None, None, None, 0, dim, spec.cuda_idx, alpha, gain, clamp)
+            keep_x = 'x' in spec.ref or spec.has_2nd_grad
             ctx.has_b = b is not None
             # y is also kept when clamping so that the clamp's zero-gradient region is honoured for every activation
             # (the reference's native path drops it for act='linear', whose ref is ''; its `_ref` path -- the oracle -- does not)
-            ctx.save_for_backward(x if need_x else None, b if need_x else None, y if ('y' in spec.ref or clamp >= 0) else None)
+            keep_y = 'y' in spec.ref or clamp >= 0
+            ctx.save_for_backward(x if keep_x else None, b if keep_x else None, y if keep_y else None)
             return y
 
         @staticmethod
         def backward(ctx, dy):
             dy = dy.contiguous(memory_format=ctx.memory_format)
             x, b, y = ctx.saved_tensors
+            want_b = ctx.has_b and ctx.needs_input_grad[1]
             dx = db = None
             if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
-                dx = dy
-                if act != 'linear' or gain != 1 or clamp >= 0:
-                    dx = BiasActHipGrad.apply(dy, x, b, y)
-            if ctx.has_b and ctx.needs_input_grad[1]:
-                db = dx.sum([i for i in range(dx.ndim) if i != dim])
+                dx = dy if identity else BiasActHipGrad.apply(dy, x, b, y)
+            if want_b:
+                db = sum_but(dx, dim)
             return dx, db
 
     class BiasActHipGrad(torch.autograd.Function):
         @staticmethod
         def forward(ctx, dy, x, b, y):
-            ctx.memory_format = torch.channels_last if dy.ndim > 2 and dy.stride(1) == 1 else torch.contiguous_format
+            ctx.memory_format = _layout_of(dy)
             dx = _native(dy, b, x, y, None, 1, dim, spec.cuda_idx, alpha, gain, clamp)
             ctx.save_for_backward(dy if spec.has_2nd_grad else None, x, b, y)
             return dx
@@ -127,13 +136,14 @@ def _bias_act_hip(dim=1, act='linear', alpha=None, gain=None, clamp=None):
         def backward(ctx, d_dx):
             d_dx = d_dx.contiguous(memory_format=ctx.memory_format)
             dy, x, b, y = ctx.saved_tensors
+            want_dy, want_x, want_b = ctx.needs_input_grad[:3]
             d_dy = d_x = d_b = None
-            if ctx.needs_input_grad[0]:
-                d_dy = BiasActHipGrad.apply(d_dx, x, b, y)
-            if spec.has_2nd_grad and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
+            if want_dy:
+                d_dy = BiasActHipGrad.apply(d_dx, x, b, y)           # linear in dy: the same pass on the incoming gradient
+            if spec.has_2nd_grad and (want_x or want_b):
                 d_x = _native(d_dx, b, x, y, dy, 2, dim, spec.cuda_idx, alpha, gain, clamp)
-            if spec.has_2nd_grad and b is not None and ctx.needs_input_grad[2]:
-                d_b = d_x.sum([i for i in range(d_x.ndim) if i != dim])
+                if b is not None and want_b:
+                    d_b = sum_but(d_x, dim)
             return d_dy, d_x, d_b, None
 
     BiasActHip.Grad = BiasActHipGrad
@@ -143,6 +153,5 @@ def _bias_act_hip(dim=1, act='linear', alpha=None, gain=None, clamp=None):
 
 def bias_act(x, b=None, dim=1, act='linear', alpha=None, gain=None, clamp=None, impl='hip'):
     """Fused bias and activation (reference bias_act.py:47-81): ``+b`` -> ``act`` -> ``*gain`` -> clamp."""
-    assert isinstance(x, torch.Tensor)
-    assert impl in ['hip', 'cuda']
+    assert isinstance(x, torch.Tensor) and impl in ('hip', 'cuda')
     return _bias_act_hip(dim=dim, act=act, alpha=alpha, gain=gain, clamp=clamp).apply(x, b)

@@ -29,7 +29,7 @@ class _Margins:
     """Padding of the composite op as [left, right, top, bottom]; FIR stages widen it so that the output size is x * up / down."""
 
     def __init__(self, padding):
-        self.l, self.r, self.t, self.b = _fir._parse_padding(padding)
+        self.l, self.r, self.t, self.b = _fir._lrtb_padding(padding)
 
     def widen(self, fw, fh, factor, upsampling):
         # a centred FIR of fw taps on a lattice resampled by `factor`: the same split upsample2d / downsample2d use
@@ -97,7 +97,7 @@ def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight
         if not (isinstance(v, int) and v >= 1):
             raise AssertionError(f'{name} must be a positive int')
     cout, cin_g, kh, kw = (int(s) for s in w.shape)
-    fw, fh = _fir._get_filter_size(f)
+    fw, fh = _fir._taps_wh(f)
     m = _Margins(padding)
     m.widen(fw, fh, up, upsampling=True)
     m.widen(fw, fh, down, upsampling=False)

@@ -18,27 +18,6 @@ from .. import _lib
 from . import upfirdn2d
 
 
-def _get_filter_size(f):
-    if f is None:
-        return 1, 1
-    assert isinstance(f, torch.Tensor)
-    assert 1 <= f.ndim <= 2
-    return f.shape[-1], f.shape[0]      # width, height
-
-
-def _parse_padding(padding):
-    if isinstance(padding, int):
-        padding = [padding, padding]
-    assert isinstance(padding, (list, tuple))
-    assert all(isinstance(x, (int, np.integer)) for x in padding)
-    padding = [int(x) for x in padding]
-    if len(padding) == 2:
-        px, py = padding
-        padding = [px, px, py, py]
-    px0, px1, py0, py1 = padding
-    return px0, px1, py0, py1
-
-
 def _dense(t):
     """contiguous in NCHW or channels-last order (what the kernels read at full width)"""
     return t.is_contiguous() or t.is_contiguous(memory_format=torch.channels_last)
@@ -116,19 +95,29 @@ def _native_act_(y, si, sx, sy, gain, slope, clamp, write_signs):
 _filtered_lrelu_hip_cache = dict()
 
 
+def _as_positive_float(value, what, allow_zero):
+    """The reference's scalar checks (filtered_lrelu.py:122-128): the value must be exactly representable as a float and positive
+    (or non-negative); AssertionError otherwise."""
+    number = float(value)
+    assert value == number and (number >= 0 if allow_zero else number > 0), what
+    return number
+
+
+def _unit_filter(x):
+    return torch.ones([1, 1], dtype=torch.float32, device=x.device)
+
+
 def _filtered_lrelu_hip(up=1, down=1, padding=0, gain=np.sqrt(2), slope=0.2, clamp=None, flip_filter=False):
-    assert isinstance(up, int) and up >= 1
-    assert isinstance(down, int) and down >= 1
-    px0, px1, py0, py1 = _parse_padding(padding)
-    assert gain == float(gain) and gain > 0
-    gain = float(gain)
-    assert slope == float(slope) and slope >= 0
-    slope = float(slope)
-    assert clamp is None or (clamp == float(clamp) and clamp >= 0)
-    clamp = float(clamp if clamp is not None else 'inf')
-    key = (up, down, px0, px1, py0, py1, gain, slope, clamp, flip_filter)
-    if key in _filtered_lrelu_hip_cache:
-        return _filtered_lrelu_hip_cache[key]
+    """Autograd op factory, one class per parameter set (cached, as the reference's ``_filtered_lrelu_cuda``: filtered_lrelu.py:116-270)."""
+    assert isinstance(up, int) and isinstance(down, int) and min(up, down) >= 1
+    pl, pr, pt, pb = upfirdn2d._lrtb_padding(padding)
+    gain = _as_positive_float(gain, 'gain', allow_zero=False)
+    slope = _as_positive_float(slope, 'slope', allow_zero=True)
+    clamp = float('inf') if clamp is None else _as_positive_float(clamp, 'clamp', allow_zero=True)
+    key = (up, down, pl, pr, pt, pb, gain, slope, clamp, flip_filter)
+    op = _filtered_lrelu_hip_cache.get(key)
+    if op is not None:
+        return op
 
     class FilteredLReluHip(torch.autograd.Function):
         @staticmethod
@@ -137,78 +126,77 @@ def _filtered_lrelu_hip(up=1, down=1, padding=0, gain=np.sqrt(2), slope=0.2, cla
             _lib.require_gpu(x, 'filtered_lrelu')
             if x.dtype not in (torch.float16, torch.bfloat16, torch.float32):
                 raise RuntimeError('x and b must be float16, bfloat16 or float32')
-            if fu is None:
-                fu = torch.ones([1, 1], dtype=torch.float32, device=x.device)
-            if fd is None:
-                fd = torch.ones([1, 1], dtype=torch.float32, device=x.device)
+            fu = _unit_filter(x) if fu is None else fu
+            fd = _unit_filter(x) if fd is None else fd
             assert 1 <= fu.ndim <= 2 and 1 <= fd.ndim <= 2
             if fu.dtype != torch.float32 or fd.dtype != torch.float32:
                 raise RuntimeError('fu and fd must be float32')
+            # a single separable tap on an axis that is not resampled is a full 1x1 filter (filtered_lrelu.py:141-145)
             if up == 1 and fu.ndim == 1 and fu.shape[0] == 1:
-                fu = fu.square()[None]
+                fu = fu.square().unsqueeze(0)
             if down == 1 and fd.ndim == 1 and fd.shape[0] == 1:
-                fd = fd.square()[None]
+                fd = fd.square().unsqueeze(0)
+            channels = x.shape[1]
             if b is None:
-                b = torch.zeros([x.shape[1]], dtype=x.dtype, device=x.device)
+                b = x.new_zeros([channels])
             if b.dtype != x.dtype:
                 raise RuntimeError('x and b must have the same dtype')
-            if b.dim() != 1 or b.shape[0] != x.shape[1]:
+            if b.dim() != 1 or b.shape[0] != channels:
                 raise RuntimeError('b must be a vector with the same number of channels as x')
             have_si = si is not None and si.numel() > 0
             write_signs = (not have_si) and (x.requires_grad or b.requires_grad)
-            strides = [x.stride(i) for i in range(x.ndim) if x.size(i) > 1]
-            if any(a < c for a, c in zip(strides[:-1], strides[1:])):
+            # the kernels read any strides; an order other than NCHW / channels-last just reads slowly (filtered_lrelu.py:160-163 warns too)
+            live = [x.stride(d) for d in range(x.ndim) if x.size(d) > 1]
+            if any(outer < inner for outer, inner in zip(live, live[1:])):
                 warnings.warn('low-performance memory layout detected in filtered_lrelu input', RuntimeWarning)
 
-            y, so, rc = _native_fused(x, fu, fd, b, si if have_si else None, up, down, px0, px1, py0, py1, sx, sy,
-                                      gain, slope, clamp, flip_filter, write_signs)
+            signs_in = si if have_si else None
+            y, so, rc = _native_fused(x, fu, fd, b, signs_in, up, down, pl, pr, pt, pb, sx, sy, gain, slope, clamp, flip_filter, write_signs)
             if rc < 0:
-                # generic composition; only the bit-packed sign tensor is kept for the gradient
-                y = x.add(b.unsqueeze(-1).unsqueeze(-1))
-                y = upfirdn2d.upfirdn2d(x=y, f=fu, up=up, padding=[px0, px1, py0, py1], gain=up ** 2, flip_filter=flip_filter)
-                so = _native_act_(y, si if have_si else None, sx, sy, gain, slope, clamp, write_signs)
-                y = upfirdn2d.upfirdn2d(x=y, f=fd, down=down, flip_filter=flip_filter)
+                # no fused kernel for this parameter set: bias, upsampling FIR, activation in place (which writes the packed signs), decimating FIR
+                t = x + b.reshape(1, -1, 1, 1)
+                t = upfirdn2d.upfirdn2d(t, fu, up=up, padding=[pl, pr, pt, pb], gain=up ** 2, flip_filter=flip_filter)
+                so = _native_act_(t, signs_in, sx, sy, gain, slope, clamp, write_signs)
+                y = upfirdn2d.upfirdn2d(t, fd, down=down, flip_filter=flip_filter)
 
             ctx.save_for_backward(fu, fd, (si if have_si else so))
-            ctx.x_shape = x.shape
-            ctx.y_shape = y.shape
-            ctx.s_ofs = sx, sy
+            ctx.in_hw, ctx.out_hw, ctx.sign_origin = (x.shape[2], x.shape[3]), (y.shape[2], y.shape[3]), (sx, sy)
             return y
 
         @staticmethod
         def backward(ctx, dy):
             fu, fd, si = ctx.saved_tensors
-            _, _, xh, xw = ctx.x_shape
-            _, _, yh, yw = ctx.y_shape
-            sx, sy = ctx.s_ofs
+            (in_h, in_w), (out_h, out_w), (sx, sy) = ctx.in_hw, ctx.out_hw, ctx.sign_origin
+            want_x, want_b = ctx.needs_input_grad[0], ctx.needs_input_grad[3]
             dx = db = None
-            if ctx.needs_input_grad[0] or ctx.needs_input_grad[3]:
-                pp = [(fu.shape[-1] - 1) + (fd.shape[-1] - 1) - px0,
-                      xw * up - yw * down + px0 - (up - 1),
-                      (fu.shape[0] - 1) + (fd.shape[0] - 1) - py0,
-                      xh * up - yh * down + py0 - (up - 1)]
-                gg = gain * (up ** 2) / (down ** 2)
-                ff = (not flip_filter)
-                sx = sx - (fu.shape[-1] - 1) + px0
-                sy = sy - (fu.shape[0] - 1) + py0
+            if want_x or want_b:
+                # the adjoint is the op itself with up <-> down, fu <-> fd, flipped taps, no clamp, and the sign tensor read at an offset
+                # (filtered_lrelu.py:233-262)
+                uw, uh = fu.shape[-1] - 1, fu.shape[0] - 1
+                dw, dh = fd.shape[-1] - 1, fd.shape[0] - 1
+                adj = [uw + dw - pl, in_w * up - out_w * down + pl - (up - 1),
+                       uh + dh - pt, in_h * up - out_h * down + pt - (up - 1)]
+                adj_gain = gain * (up ** 2) / (down ** 2)
+                adj_flip = not flip_filter
+                ox, oy = sx - uw + pl, sy - uh + pt
                 if not torch.is_grad_enabled() and dy.dtype in (torch.float16, torch.bfloat16, torch.float32) and si is not None and si.numel():
                     # no graph is being recorded: run the gradient pass directly and let the kernel accumulate the bias gradient
                     # (sum of dx over n, h, w) while it stores dx -- one pass less over dx
                     dyc = dy if _dense(dy) else dy.contiguous()
-                    ysum = torch.zeros(dy.shape[1], dtype=torch.float32, device=dy.device) if ctx.needs_input_grad[3] else None
+                    ysum = torch.zeros(dy.shape[1], dtype=torch.float32, device=dy.device) if want_b else None
                     fu2 = fd if fd.ndim == 2 or down > 1 or fd.shape[0] > 1 else fd.square()[None]
                     fd2 = fu if fu.ndim == 2 or up > 1 or fu.shape[0] > 1 else fu.square()[None]
-                    dx, _, rc = _native_fused(dyc, fu2, fd2, None, si, down, up, pp[0], pp[1], pp[2], pp[3], sx, sy, gg, slope,
-                                              float('inf'), ff, False, ysum=ysum)
+                    dx, _, rc = _native_fused(dyc, fu2, fd2, None, si, down, up, adj[0], adj[1], adj[2], adj[3], ox, oy, adj_gain, slope,
+                                              float('inf'), adj_flip, False, ysum=ysum)
                     if rc < 0:
                         dx = None
                     elif ysum is not None:
                         db = ysum.to(dy.dtype)
                 if dx is None:
-                    dx = _filtered_lrelu_hip(up=down, down=up, padding=pp, gain=gg, slope=slope, clamp=None,
-                                             flip_filter=ff).apply(dy, fd, fu, None, si, sx, sy)
-            if ctx.needs_input_grad[3] and db is None:
-                db = dx.sum([0, 2, 3])
+                    dx = _filtered_lrelu_hip(up=down, down=up, padding=adj, gain=adj_gain, slope=slope, clamp=None,
+                                             flip_filter=adj_flip).apply(dy, fd, fu, None, si, ox, oy)
+            if want_b and db is None:
+                db = dx.sum((0, 2, 3))
             return dx, None, None, db, None, None, None
 
     _filtered_lrelu_hip_cache[key] = FilteredLReluHip
@@ -219,7 +207,6 @@ def filtered_lrelu(x, fu=None, fd=None, b=None, up=1, down=1, padding=0, gain=np
                    flip_filter=False, impl='hip'):
     """bias -> upsample FIR (fu) -> *gain -> leaky ReLU -> clamp -> downsample FIR (fd)
     (reference filtered_lrelu.py:50-110; semantics filtered_lrelu.py:53-76)."""
-    assert isinstance(x, torch.Tensor)
-    assert impl in ['hip', 'cuda']
-    return _filtered_lrelu_hip(up=up, down=down, padding=padding, gain=gain, slope=slope, clamp=clamp,
-                               flip_filter=flip_filter).apply(x, fu, fd, b, None, 0, 0)
+    assert isinstance(x, torch.Tensor) and impl in ('hip', 'cuda')
+    op = _filtered_lrelu_hip(up=up, down=down, padding=padding, gain=gain, slope=slope, clamp=clamp, flip_filter=flip_filter)
+    return op.apply(x, fu, fd, b, None, 0, 0)

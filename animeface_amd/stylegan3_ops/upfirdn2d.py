@@ -13,58 +13,53 @@ import torch
 from .. import _lib
 
 
-def _parse_scaling(scaling):
-    if isinstance(scaling, int):
-        scaling = [scaling, scaling]
-    assert isinstance(scaling, (list, tuple))
-    assert all(isinstance(x, int) for x in scaling)
-    sx, sy = scaling
-    assert sx >= 1 and sy >= 1
-    return sx, sy
+def _xy_factors(value):
+    """An up / down factor as (x, y): one int for both axes or a pair of ints, each at least 1 (anything else: AssertionError, as the
+    reference's argument checks raise, upfirdn2d.py:27-35)."""
+    pair = (value, value) if isinstance(value, int) else value
+    assert isinstance(pair, (list, tuple)) and all(isinstance(v, int) for v in pair)
+    fx, fy = pair
+    assert min(fx, fy) >= 1
+    return fx, fy
 
 
-def _parse_padding(padding):
-    if isinstance(padding, int):
-        padding = [padding, padding]
-    assert isinstance(padding, (list, tuple))
-    assert all(isinstance(x, (int, np.integer)) for x in padding)
-    padding = [int(x) for x in padding]
-    if len(padding) == 2:
-        padx, pady = padding
-        padding = [padx, padx, pady, pady]
-    padx0, padx1, pady0, pady1 = padding
-    return padx0, padx1, pady0, pady1
+def _lrtb_padding(value):
+    """Padding as (left, right, top, bottom): one int for all four sides, (x, y) for both sides of an axis, or the four values
+    (reference upfirdn2d.py:38-48); numpy integers are accepted."""
+    sides = (value, value) if isinstance(value, int) else value
+    assert isinstance(sides, (list, tuple)) and all(isinstance(v, (int, np.integer)) for v in sides)
+    sides = tuple(int(v) for v in sides)
+    if len(sides) == 2:
+        sides = (sides[0], sides[0], sides[1], sides[1])
+    left, right, top, bottom = sides
+    return left, right, top, bottom
 
 
-def _get_filter_size(f):
+def _taps_wh(f):
+    """(width, height) of a filter tensor: [taps] is separable (the same taps on both axes), [fh, fw] is full, None is the identity."""
     if f is None:
         return 1, 1
-    assert isinstance(f, torch.Tensor) and f.ndim in [1, 2]
-    fw, fh = int(f.shape[-1]), int(f.shape[0])
-    assert fw >= 1 and fh >= 1
-    return fw, fh
+    assert isinstance(f, torch.Tensor) and 1 <= f.ndim <= 2
+    w, h = int(f.shape[-1]), int(f.shape[0])
+    assert min(w, h) >= 1
+    return w, h
 
 
 def setup_filter(f, device=torch.device('cpu'), normalize=True, flip_filter=False, gain=1, separable=None):
-    """Reference upfirdn2d.py:64-108: returns fp32 [fh, fw] (or [taps] when separable: 1-D input with >= 8 taps)."""
-    if f is None:
-        f = 1
-    f = torch.as_tensor(f, dtype=torch.float32)
-    assert f.ndim in [0, 1, 2]
-    assert f.numel() > 0
-    if f.ndim == 0:
-        f = f[np.newaxis]
-    if separable is None:
-        separable = (f.ndim == 1 and f.numel() >= 8)
-    if f.ndim == 1 and not separable:
-        f = f.ger(f)
-    assert f.ndim == (1 if separable else 2)
+    """Reference upfirdn2d.py:64-108: returns fp32 [fh, fw] (or [taps] when separable: 1-D input with >= 8 taps unless told otherwise)."""
+    taps = torch.as_tensor(1 if f is None else f, dtype=torch.float32)
+    assert taps.ndim <= 2 and taps.numel() > 0
+    if taps.ndim == 0:
+        taps = taps.reshape(1)
+    keep_1d = (taps.ndim == 1 and taps.numel() >= 8) if separable is None else separable
+    if taps.ndim == 1 and not keep_1d:
+        taps = torch.outer(taps, taps)
+    assert taps.ndim == (1 if keep_1d else 2)
     if normalize:
-        f = f / f.sum()
+        taps = taps / taps.sum()
     if flip_filter:
-        f = f.flip(list(range(f.ndim)))
-    f = f * (gain ** (f.ndim / 2))
-    return f.to(device=device)
+        taps = taps.flip(tuple(range(taps.ndim)))
+    return (taps * gain ** (taps.ndim / 2)).to(device=device)
 
 
 def _launch(x, f2d, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain, edge):
@@ -121,64 +116,65 @@ _upfirdn2d_hip_cache = dict()
 
 
 def _upfirdn2d_hip(up=1, down=1, padding=0, flip_filter=False, gain=1, edge='zero'):
-    """Autograd op factory, cached by parameters like the reference's ``_upfirdn2d_cuda`` (upfirdn2d.py:211-267)."""
-    upx, upy = _parse_scaling(up)
-    downx, downy = _parse_scaling(down)
-    padx0, padx1, pady0, pady1 = _parse_padding(padding)
-    key = (upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip_filter, gain, edge)
-    if key in _upfirdn2d_hip_cache:
-        return _upfirdn2d_hip_cache[key]
+    """Autograd op factory, one class per parameter set (cached, as the reference's ``_upfirdn2d_cuda`` is: upfirdn2d.py:211-267)."""
+    ux, uy = _xy_factors(up)
+    dnx, dny = _xy_factors(down)
+    pl, pr, pt, pb = _lrtb_padding(padding)
+    key = (ux, uy, dnx, dny, pl, pr, pt, pb, flip_filter, gain, edge)
+    op = _upfirdn2d_hip_cache.get(key)
+    if op is not None:
+        return op
 
     class Upfirdn2dHip(torch.autograd.Function):
         @staticmethod
         def forward(ctx, x, f):
             assert isinstance(x, torch.Tensor) and x.ndim == 4
-            if f is None:
-                f = torch.ones([1, 1], dtype=torch.float32, device=x.device)
-            if f.ndim == 1 and f.shape[0] == 1:
-                f = f.square().unsqueeze(0)                     # separable-1 -> full 1x1 (upfirdn2d.py:231-232)
-            assert isinstance(f, torch.Tensor) and f.ndim in [1, 2]
-            if f.ndim == 2:
-                y = _launch(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip_filter, gain, edge)
+            taps = torch.ones([1, 1], dtype=torch.float32, device=x.device) if f is None else f
+            if taps.ndim == 1 and taps.shape[0] == 1:
+                taps = taps.square().unsqueeze(0)                       # one separable tap = a full 1x1 filter (upfirdn2d.py:231-232)
+            assert isinstance(taps, torch.Tensor) and 1 <= taps.ndim <= 2
+            if taps.ndim == 2:
+                y = _launch(x, taps, ux, uy, dnx, dny, pl, pr, pt, pb, flip_filter, gain, edge)
             else:
                 assert edge == 'zero'
-                # x-pass with gain 1, then y-pass with the full gain (upfirdn2d.py:238-239)
-                y = _launch(x, f.unsqueeze(0), upx, 1, downx, 1, padx0, padx1, 0, 0, flip_filter, 1.0, edge)
-                y = _launch(y, f.unsqueeze(1), 1, upy, 1, downy, 0, 0, pady0, pady1, flip_filter, gain, edge)
-            ctx.save_for_backward(f)
-            ctx.x_shape = x.shape
+                # separable: a row pass with unit gain, then a column pass that carries the gain (upfirdn2d.py:238-239)
+                rows = _launch(x, taps.unsqueeze(0), ux, 1, dnx, 1, pl, pr, 0, 0, flip_filter, 1.0, edge)
+                y = _launch(rows, taps.unsqueeze(1), 1, uy, 1, dny, 0, 0, pt, pb, flip_filter, gain, edge)
+            ctx.save_for_backward(taps)
+            ctx.in_hw = (x.shape[2], x.shape[3])
             return y
 
         @staticmethod
         def backward(ctx, dy):
-            f, = ctx.saved_tensors
-            _, _, ih, iw = ctx.x_shape
-            _, _, oh, ow = dy.shape
-            fw, fh = _get_filter_size(f)
-            p = [fw - padx0 - 1, iw * upx - ow * downx + padx0 - upx + 1,
-                 fh - pady0 - 1, ih * upy - oh * downy + pady0 - upy + 1]
+            (taps,) = ctx.saved_tensors
+            in_h, in_w = ctx.in_hw
+            out_h, out_w = dy.shape[2], dy.shape[3]
+            tw, th = _taps_wh(taps)
+            # the adjoint is the same op with up <-> down, the filter flipped and this padding (upfirdn2d.py:245-263)
+            adj = [tw - pl - 1, in_w * ux - out_w * dnx + pl - ux + 1,
+                   th - pt - 1, in_h * uy - out_h * dny + pt - uy + 1]
             dx = None
             if ctx.needs_input_grad[0]:
                 if edge == 'zero':
-                    dx = _upfirdn2d_hip(up=down, down=up, padding=p, flip_filter=(not flip_filter), gain=gain).apply(dy, f)
+                    dx = _upfirdn2d_hip(up=down, down=up, padding=adj, flip_filter=(not flip_filter), gain=gain).apply(dy, taps)
                 else:
-                    rx = (max(padx0, padx1, 0) + upx - 1) // upx + 1
-                    ry = (max(pady0, pady1, 0) + upy - 1) // upy + 1
-                    if torch.is_grad_enabled() or f.ndim != 2:
+                    rx = (max(pl, pr, 0) + ux - 1) // ux + 1
+                    ry = (max(pt, pb, 0) + uy - 1) // uy + 1
+                    if torch.is_grad_enabled() or taps.ndim != 2:
                         # differentiable form: adjoint on the replicate-extended domain, then fold the extension onto the edges
-                        pe = [p[0] + rx * upx, p[1] + rx * upx, p[2] + ry * upy, p[3] + ry * upy]
-                        g = _upfirdn2d_hip(up=down, down=up, padding=pe, flip_filter=(not flip_filter), gain=gain).apply(dy, f)
+                        ext = [adj[0] + rx * ux, adj[1] + rx * ux, adj[2] + ry * uy, adj[3] + ry * uy]
+                        g = _upfirdn2d_hip(up=down, down=up, padding=ext, flip_filter=(not flip_filter), gain=gain).apply(dy, taps)
                         dx = _fold_edges(g, rx, ry)
                     else:
                         # fast form: ordinary zero-mode adjoint + a border-only kernel that adds the folded extension terms
-                        dx = _launch(dy, f, downx, downy, upx, upy, p[0], p[1], p[2], p[3], not flip_filter, gain, 'zero')
+                        dx = _launch(dy, taps, dnx, dny, ux, uy, adj[0], adj[1], adj[2], adj[3], not flip_filter, gain, 'zero')
                         rc = _lib.lib().agf_upfirdn2d_fold_border(
-                            _lib.ptr(dy), _lib.ptr(f), _lib.ptr(dx), _lib.dtype_code(dy),
-                            _lib.sizes4(dy), _lib.strides4(dy), _lib._i32x2(*f.shape), _lib._i64x2(*f.stride()),
-                            _lib.sizes4(dx), _lib.strides4(dx), downx, downy, upx, upy, p[0], p[2],
+                            _lib.ptr(dy), _lib.ptr(taps), _lib.ptr(dx), _lib.dtype_code(dy),
+                            _lib.sizes4(dy), _lib.strides4(dy), _lib._i32x2(*taps.shape), _lib._i64x2(*taps.stride()),
+                            _lib.sizes4(dx), _lib.strides4(dx), dnx, dny, ux, uy, adj[0], adj[2],
                             int(not flip_filter), float(gain), rx, ry, _lib.stream_ptr(dy))
                         _lib.check(rc, 'upfirdn2d_fold_border')
-            assert not ctx.needs_input_grad[1]
+            assert not ctx.needs_input_grad[1]                         # the filter is a constant of the op
             return dx, None
 
     _upfirdn2d_hip_cache[key] = Upfirdn2dHip
@@ -196,26 +192,27 @@ def upfirdn2d(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1, impl='hi
 
 
 def filter2d(x, f, padding=0, flip_filter=False, gain=1, impl='hip'):
-    """Reference upfirdn2d.py:271-303."""
-    padx0, padx1, pady0, pady1 = _parse_padding(padding)
-    fw, fh = _get_filter_size(f)
-    p = [padx0 + fw // 2, padx1 + (fw - 1) // 2, pady0 + fh // 2, pady1 + (fh - 1) // 2]
-    return upfirdn2d(x, f, padding=p, flip_filter=flip_filter, gain=gain, impl=impl)
+    """Filter at unchanged size (reference upfirdn2d.py:271-303): the taps' extent is split over the two sides, the larger half first."""
+    pl, pr, pt, pb = _lrtb_padding(padding)
+    tw, th = _taps_wh(f)
+    same = [pl + tw // 2, pr + (tw - 1) // 2, pt + th // 2, pb + (th - 1) // 2]
+    return upfirdn2d(x, f, padding=same, flip_filter=flip_filter, gain=gain, impl=impl)
 
 
 def upsample2d(x, f, up=2, padding=0, flip_filter=False, gain=1, impl='hip', edge='zero'):
-    """Reference upfirdn2d.py:307-342."""
-    upx, upy = _parse_scaling(up)
-    padx0, padx1, pady0, pady1 = _parse_padding(padding)
-    fw, fh = _get_filter_size(f)
-    p = [padx0 + (fw + upx - 1) // 2, padx1 + (fw - upx) // 2, pady0 + (fh + upy - 1) // 2, pady1 + (fh - upy) // 2]
-    return upfirdn2d(x, f, up=up, padding=p, flip_filter=flip_filter, gain=gain * upx * upy, impl=impl, edge=edge)
+    """Zero-insertion upsampling by ``up`` followed by the filter, output = input * up; the gain makes up for the inserted zeros
+    (reference upfirdn2d.py:307-342)."""
+    ux, uy = _xy_factors(up)
+    pl, pr, pt, pb = _lrtb_padding(padding)
+    tw, th = _taps_wh(f)
+    grown = [pl + (tw + ux - 1) // 2, pr + (tw - ux) // 2, pt + (th + uy - 1) // 2, pb + (th - uy) // 2]
+    return upfirdn2d(x, f, up=up, padding=grown, flip_filter=flip_filter, gain=gain * ux * uy, impl=impl, edge=edge)
 
 
 def downsample2d(x, f, down=2, padding=0, flip_filter=False, gain=1, impl='hip'):
-    """Reference upfirdn2d.py:346-381."""
-    downx, downy = _parse_scaling(down)
-    padx0, padx1, pady0, pady1 = _parse_padding(padding)
-    fw, fh = _get_filter_size(f)
-    p = [padx0 + (fw - downx + 1) // 2, padx1 + (fw - downx) // 2, pady0 + (fh - downy + 1) // 2, pady1 + (fh - downy) // 2]
-    return upfirdn2d(x, f, down=down, padding=p, flip_filter=flip_filter, gain=gain, impl=impl)
+    """The filter followed by keeping every ``down``-th sample, output = input / down (reference upfirdn2d.py:346-381)."""
+    dnx, dny = _xy_factors(down)
+    pl, pr, pt, pb = _lrtb_padding(padding)
+    tw, th = _taps_wh(f)
+    shrunk = [pl + (tw - dnx + 1) // 2, pr + (tw - dnx) // 2, pt + (th - dny + 1) // 2, pb + (th - dny) // 2]
+    return upfirdn2d(x, f, down=down, padding=shrunk, flip_filter=flip_filter, gain=gain, impl=impl)
