@@ -162,7 +162,7 @@ def lib():
         L.agf_pool2x2.restype = ctypes.c_int
         L.agf_pool2x2.argtypes = [_vp, _vp, _vp, ctypes.c_int] + [ctypes.c_int32] * 4 + [ctypes.c_float, _vp]
         L.agf_act_bwd_reduce_pooled_mask.restype = ctypes.c_int
-        L.agf_act_bwd_reduce_pooled_mask.argtypes = [_vp] * 4 + [ctypes.c_int] + [ctypes.c_int32] * 4 + [ctypes.c_float, ctypes.c_float, _vp]
+        L.agf_act_bwd_reduce_pooled_mask.argtypes = [_vp] * 5 + [ctypes.c_int] + [ctypes.c_int32] * 4 + [ctypes.c_float, ctypes.c_float, _vp]
         L.agf_map_layer_fwd.restype = ctypes.c_int
         L.agf_map_layer_fwd.argtypes = [_vp] * 4 + [ctypes.c_int32] * 3 + [ctypes.c_float] * 3 + [_vp]
         L.agf_map_layer_bwd.restype = ctypes.c_int
@@ -170,7 +170,7 @@ def lib():
         L.agf_set_deterministic.restype = ctypes.c_int
         L.agf_set_deterministic.argtypes = [ctypes.c_int]
         L.agf_get_deterministic.restype = ctypes.c_int
-        if L.agf_abi_version() != 20:
+        if L.agf_abi_version() != 21:
             raise AgfError('libagf_ops.so ABI version mismatch')
         _lib = L
     return _lib

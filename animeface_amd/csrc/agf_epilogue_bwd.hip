@@ -101,7 +101,8 @@ __global__ void __launch_bounds__(256) act_bwd_reduce_kernel(ActBwdParams p) {
                     if (SCALED) { d[i] += y[u][i] * dy[u][i]; dy[u][i] *= sc[i]; }
                     g[i] = pos ? dy[u][i] : dy[u][i] * p.alpha;
                     const float y0 = pos ? y[u][i] : y[u][i] * p.inv_alpha;
-                    a[i] += g[i] * y0; b[i] += g[i]; c[i] += g[i] * nz;
+                    a[i] += MASKED ? dy[u][i] : g[i] * y0;          // (1-bit mask mode: no y0 -- slot A carries the sum of the UNMASKED gradient instead)
+                    b[i] += g[i]; c[i] += g[i] * nz;
                     g[i] *= gs[i];
                 }
                 agf_vstore<T, VEC, NT>((T*)p.g + base + (int64_t)px * p.C, g);
@@ -222,7 +223,7 @@ static int act_bwd_reduce_impl(const void* dy, const void* y, const float* noise
     const bool nt = dtype == AGF_BF16 && agf_streams_past_cache((int64_t)N * H * W * C * 2);
     hipStream_t st = (hipStream_t)stream;
     if (mask) {
-        AGF_CHECK(dtype == AGF_BF16 && !dscale && !sum_gy0 && !sum_gnoise, "act_bwd_reduce: the 1-bit mask mode is bf16, bias sum only");
+        AGF_CHECK(dtype == AGF_BF16 && !dscale && !sum_gnoise, "act_bwd_reduce: the 1-bit mask mode is bf16, sums of g and of dy only");
         if (nt) hipLaunchKernelGGL((act_bwd_reduce_kernel<bf16_t, 8, false, true, true>), grid, block, 0, st, p);
         else hipLaunchKernelGGL((act_bwd_reduce_kernel<bf16_t, 8, false, true>), grid, block, 0, st, p);
     } else if (dscale) {
@@ -256,11 +257,13 @@ extern "C" int agf_act_bwd_reduce_pooled(const void* dy_half, const void* y, voi
     return act_bwd_reduce_impl(dy_half, y, nullptr, g, nullptr, sum_g, nullptr, dtype, N, H, W, C, alpha, 1, dy_scale, stream);
 }
 
-extern "C" int agf_act_bwd_reduce_pooled_mask(const void* dy_half, const void* mask, void* g, float* sum_g,
+extern "C" int agf_act_bwd_reduce_pooled_mask(const void* dy_half, const void* mask, void* g, float* sum_g, float* sum_dy,
                                               int dtype, int32_t N, int32_t H, int32_t W, int32_t C, float alpha, float dy_scale, void* stream) {
     AGF_CHECK(H % 2 == 0 && W % 2 == 0 && C % 8 == 0, "act_bwd_reduce_pooled_mask: H and W must be even, C a multiple of 8");
     AGF_CHECK(mask, "act_bwd_reduce_pooled_mask: null mask");
-    return act_bwd_reduce_impl(dy_half, nullptr, nullptr, g, nullptr, sum_g, nullptr, dtype, N, H, W, C, alpha, 1, dy_scale, stream, nullptr, nullptr,
+    // sum_dy (nullable): [N,C] += the sum over the full-resolution pixels of the incoming gradient BEFORE the lrelu mask, i.e.
+    // 4 * dy_scale * sum over the cells of dy_half -- the bias gradient of the DBlock's skip conv, whose output gradient this tensor also is
+    return act_bwd_reduce_impl(dy_half, nullptr, nullptr, g, sum_dy, sum_g, nullptr, dtype, N, H, W, C, alpha, 1, dy_scale, stream, nullptr, nullptr,
                                (const uint32_t*)mask);
 }
 

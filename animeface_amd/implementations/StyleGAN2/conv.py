@@ -583,18 +583,21 @@ def pool2x2_raw(x, gain=1.0, want_mask=False):
     return y, mask
 
 
-def act_bwd_reduce_pooled_mask_raw(dy_half, mask, like, alpha, dy_scale, want_sum):
-    """``agf_act_bwd_reduce_pooled_mask``: as ``act_bwd_reduce_pooled_raw`` with the sign of y read from the 1-bit mask."""
+def act_bwd_reduce_pooled_mask_raw(dy_half, mask, like, alpha, dy_scale, want_sum, want_dy_sum=False):
+    """``agf_act_bwd_reduce_pooled_mask``: as ``act_bwd_reduce_pooled_raw`` with the sign of y read from the 1-bit mask.  ``want_dy_sum``:
+    also R [N,C] = the per-channel sum of the UNMASKED incoming gradient over the full-resolution pixels (= 4 * dy_scale * the sum of
+    ``dy_half`` over its cells); returns (g, B, R) then."""
     if not isinstance(like, torch.Tensor):            # (the shape of y: the tensor itself may never have been written, ``conv2d_fwd_pool_raw``)
         like = torch.empty(tuple(like), dtype=dy_half.dtype, device='meta')
     N, C, H, W = like.shape
     assert dy_half.shape == (N, C, H // 2, W // 2) and dy_half.dtype == like.dtype and mask.shape == (N, H // 2, W // 2, C // 8)
     g = torch.empty((N, C, H, W), dtype=dy_half.dtype, device=dy_half.device, memory_format=torch.channels_last)
     B = _zeros_f32((N, C), dy_half.device) if want_sum else None
-    rc = _lib.lib().agf_act_bwd_reduce_pooled_mask(_lib.ptr(dy_half), _lib.ptr(mask), _lib.ptr(g), _lib.ptr(B),
+    R = _zeros_f32((N, C), dy_half.device) if want_dy_sum else None
+    rc = _lib.lib().agf_act_bwd_reduce_pooled_mask(_lib.ptr(dy_half), _lib.ptr(mask), _lib.ptr(g), _lib.ptr(B), _lib.ptr(R),
                                                    _lib.dtype_code(dy_half), N, H, W, C, float(alpha), float(dy_scale), _lib.stream_ptr(dy_half))
     _lib.check(rc, 'act_bwd_reduce_pooled_mask')
-    return g, B
+    return (g, B, R) if want_dy_sum else (g, B)
 
 
 def demod_grad_finish_raw(A, B, Cn, bias, s_out, want_dso, want_db, gain=1.0):
@@ -866,6 +869,23 @@ class PremaskLink:
         self.yscaled = False
 
 
+class PoolSkipLink:
+    """Handshake between the two convs that receive the DBlock's output gradient dy (reference model.py:186-212:
+    out = (down(block(x)) + down(skip(x))) / sqrt 2): the 1x1 skip conv, whose bias gradient is the channel sum of dy, and the block's last
+    conv, whose backward turns the same dy into its full-resolution masked gradient (``agf_act_bwd_reduce_pooled_mask``).  The skip conv's
+    backward runs FIRST (the last conv's gradient comes out of it: the pooled output is the skip conv's residual operand); it therefore runs
+    the last conv's pass itself -- the pass that reads dy anyway also sums it -- and leaves g and the bias sums here; six bf16 ``sum``
+    launches per iteration (0.32 ms) disappear.  ``SKIP_SUM_LINK = False`` keeps the two passes apart (tests compare both ways)."""
+    __slots__ = ('args', 'stash')
+
+    def __init__(self):
+        self.args = None      # (mask, alpha, pool_gain, y_shape, dtype) of the last conv, set by its forward
+        self.stash = None     # (g, B, data_ptr of dy) left by the skip conv's backward
+
+
+SKIP_SUM_LINK = True
+
+
 class _UpBlur(torch.autograd.Function):
     """``Blur2d([1,2,1])(Upsample(x2, bilinear)(x))`` of the StyleGAN2 generator block (reference model.py:138-175) in ONE pass over the
     upsampled tensor instead of two: the clamp-mode upfirdn2d with the composite filter [1,5,10,10,5,1] x itself, plus a border-only
@@ -1083,9 +1103,10 @@ class _FusedConv(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, coef, s_in, s_out, bias, noise, residual, act, alpha, gain, pre_link=None, post_link=None, skip_pool=None,
-                post_scale=None, out_pool=None):
+                post_scale=None, out_pool=None, skip_link=None):
         prep = prepared_weights(weight, coef, x.dtype)
         ctx.out_pool = None
+        ctx.skip_link = skip_link if SKIP_SUM_LINK else None
         if out_pool is not None:
             # ``out_pool = (f, pool_gain)``: the op returns pool_gain * AvgPool2d(2)(y) INSTEAD of y (the last conv of a DBlock, whose only
             # consumer is the pooling).  One launch writes the pooled tensor and the 1-bit sign mask the backward needs; y never exists.
@@ -1108,6 +1129,9 @@ class _FusedConv(torch.autograd.Function):
             ctx.has_residual, ctx.pre_link, ctx.post_link, ctx.pool = False, pre_link, None, None
             ctx.x_pre, ctx.post = False, None
             ctx.out_pool = (f, float(pool_gain), mask, (x.shape[0], weight.shape[0], x.shape[2], x.shape[3]))
+            if ctx.skip_link is not None:
+                ctx.skip_link.args = (mask, float(alpha), float(pool_gain), ctx.out_pool[3], x.dtype) if mask is not None else None
+                ctx.skip_link.stash = None
             return tp
         # this layer's input arrives already times s_in when its producer said so on the link (POSTSCALE_X)
         x_pre = pre_link is not None and pre_link.yscaled and s_in is not None
@@ -1212,7 +1236,7 @@ class _FusedConv(torch.autograd.Function):
                     dx = dx + dx_pool
             if need_w:
                 dw = (_ConvWgrad.apply(x, g, None, None, k) * coef).to(weight.dtype)
-            return dx, dw, None, None, None, db, None, dres, None, None, None, None, None, None, None, None
+            return dx, dw, None, None, None, db, None, dres, None, None, None, None, None, None, None, None, None
         # the output gain is not applied to the gradient tensor: it rides along in the data-gradient launch's epilogue gain, in the
         # weight-gradient scale and in the bias sum (no pass over the tensor for it)
         pg = float(gain)
@@ -1221,7 +1245,11 @@ class _FusedConv(torch.autograd.Function):
         g_scaled = False
         if pooled is not None:
             mask = pmask
-            if mask is not None:
+            sl = ctx.skip_link
+            if mask is not None and sl is not None and sl.stash is not None and sl.stash[2] == pooled[0].data_ptr():
+                g, B, _ = sl.stash                     # the skip conv's backward already ran this layer's pass on the same dy (PoolSkipLink)
+                sl.stash = None
+            elif mask is not None:
                 g, B = act_bwd_reduce_pooled_mask_raw(pooled[0], mask, y_like, alpha, pooled[1], need_b and bias is not None)
             else:
                 g, B = act_bwd_reduce_pooled_raw(pooled[0], y, alpha, pooled[1], need_b and bias is not None)
@@ -1262,7 +1290,17 @@ class _FusedConv(torch.autograd.Function):
         else:
             assert s_out is None, 'linear epilogue with a demodulation scale is not used by the networks'
             g = dy
-            if need_b and bias is not None:
+            sl = ctx.skip_link
+            if sl is not None and sl.args is not None and need_r and pg == 1.0 and g.dtype == sl.args[4] == torch.bfloat16 \
+                    and tuple(g.shape) == (sl.args[3][0], sl.args[3][1], sl.args[3][2] // 2, sl.args[3][3] // 2):
+                # g is also the gradient of the partner's pooled output (it leaves this backward as ``dres``): run the partner's pass over it
+                # now, with the sum this layer's bias needs (PoolSkipLink)
+                pmask, a2, pool_gain, y_shape, _ = sl.args
+                g2, B2, R = act_bwd_reduce_pooled_mask_raw(g, pmask, y_shape, a2, pool_gain * 0.25, True, want_dy_sum=True)
+                sl.stash = (g2, B2, g.data_ptr())
+                if need_b and bias is not None:
+                    db = (R.sum(0) * (1.0 / pool_gain)).to(bias.dtype)
+            elif need_b and bias is not None:
                 db = channel_sum_raw(g, pg).to(bias.dtype)
         if need_r:
             dres = g * pg if pg != 1.0 else g
@@ -1300,11 +1338,11 @@ class _FusedConv(torch.autograd.Function):
             dx = dx_pool
         if need_w:
             dw = conv2d_wgrad_raw(x, g, k, in_scale=None if x_pre else s_in, out_scale=None if g_scaled else s_out, scale=coef * pg).to(weight.dtype)
-        return dx, dw, None, dsi, dso, db, None, dres, None, None, None, None, None, None, None, None
+        return dx, dw, None, dsi, dso, db, None, dres, None, None, None, None, None, None, None, None, None
 
 
 def conv2d_act(x, weight, bias=None, s_in=None, s_out=None, noise=None, alpha=0.2, fused=True, coef=1.0,
-               act='lrelu', residual=None, gain=1.0, pre_link=None, post_link=None, skip_pool=None, post_scale=None, out_pool=None):
+               act='lrelu', residual=None, gain=1.0, pre_link=None, post_link=None, skip_pool=None, post_scale=None, out_pool=None, skip_link=None):
     """act( s_out * conv(x * s_in, weight * coef) + bias + noise + residual ) * gain; act = 'lrelu' | 'linear'.
     bias [Cout], noise [N,1,H,W] (no gradient), residual like the output.
     ``fused=False`` evaluates the same expression with the separately differentiable ops (any-order gradients).
@@ -1328,7 +1366,7 @@ def conv2d_act(x, weight, bias=None, s_in=None, s_out=None, noise=None, alpha=0.
                 return _FusedConv.apply(x, weight, coef, s_in, s_out, bias, noise, residual,
                                         ACT_LRELU if act == 'lrelu' else ACT_LINEAR, alpha, gain, pre_link, post_link, None), tp
         return _FusedConv.apply(x, weight, coef, s_in, s_out, bias, noise, residual,
-                                ACT_LRELU if act == 'lrelu' else ACT_LINEAR, alpha, gain, pre_link, post_link, skip_pool, post_scale, out_pool)
+                                ACT_LRELU if act == 'lrelu' else ACT_LINEAR, alpha, gain, pre_link, post_link, skip_pool, post_scale, out_pool, skip_link)
     assert out_pool is None, 'out_pool is a feature of the fused path'
     x_in = x
     out = conv2d(x, weight * coef if coef != 1.0 else weight, s_in, s_out)

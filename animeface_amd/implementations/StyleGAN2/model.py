@@ -28,7 +28,7 @@ import torch.nn.functional as F
 
 from ...stylegan3_ops import upfirdn2d, bias_act
 from ... import rng
-from .conv import conv2d, conv2d_act, style_demod, PremaskLink, pool2x_linked, up_blur, torgb, torgb_covers, map_layer
+from .conv import conv2d, conv2d_act, style_demod, PremaskLink, PoolSkipLink, pool2x_linked, up_blur, torgb, torgb_covers, map_layer
 from . import conv as conv_mod
 
 
@@ -64,7 +64,7 @@ class ELR(nn.Module):
         return F.linear(x * self.coef, self.layer.weight, self.layer.bias)
 
 
-def elr_conv2d(elr, x, act=None, residual=None, gain=1.0, out_gain=1.0, pre_link=None, post_link=None, skip_pool=None, out_pool=None):
+def elr_conv2d(elr, x, act=None, residual=None, gain=1.0, out_gain=1.0, pre_link=None, post_link=None, skip_pool=None, out_pool=None, skip_link=None):
     """``ELR(nn.Conv2d)`` on the MFMA conv; coef is folded into the weights; optional fused-order bias + lrelu.
     ``out_gain`` (linear layers only) scales the conv + bias part of the output by a constant for free: it is folded into the
     weight coefficient and the bias instead of being applied to the output tensor (nothing to undo in backward either)."""
@@ -78,7 +78,7 @@ def elr_conv2d(elr, x, act=None, residual=None, gain=1.0, out_gain=1.0, pre_link
         bias = bias * out_gain if bias is not None else None
     return conv2d_act(x, conv.weight, bias, alpha=0.2, fused=FUSED_EPILOGUE, coef=coef,
                       act='lrelu' if act == 'lrelu' else 'linear', residual=residual, gain=gain,
-                      pre_link=pre_link, post_link=post_link, skip_pool=skip_pool, out_pool=out_pool)
+                      pre_link=pre_link, post_link=post_link, skip_pool=skip_pool, out_pool=out_pool, skip_link=skip_link)
 
 
 def Linear(name, *args, **kwargs):
@@ -325,6 +325,7 @@ class DBlock(nn.Module):
         t_pooled = None
         c = float(1 / np.sqrt(2))
         pooled_out = False
+        sl = PoolSkipLink()      # the skip conv's backward runs the last conv's activation-gradient pass on their common dy (conv.PoolSkipLink)
         for i in range(0, len(mods), 2):
             last = i + 2 >= len(mods)
             # the last conv's only consumer is the 2x2 average: it returns the pooled tensor itself (conv.FUSE_POOL: one launch writes the
@@ -334,7 +335,7 @@ class DBlock(nn.Module):
             if i == 0 and pooled:
                 x, t_pooled = elr_conv2d(mods[i], x, act='lrelu', pre_link=pre, post_link=post, skip_pool=(self.down.f, 1))
             elif pooled_out:
-                x = elr_conv2d(mods[i], x, act='lrelu', pre_link=pre, out_pool=(self.down.f, c))
+                x = elr_conv2d(mods[i], x, act='lrelu', pre_link=pre, out_pool=(self.down.f, c), skip_link=sl)
             else:
                 x = elr_conv2d(mods[i], x, act='lrelu', pre_link=pre, post_link=post)
             pre = post
@@ -342,7 +343,8 @@ class DBlock(nn.Module):
             # avg-pool commutes with the 1x1 skip conv: pool first (4x less work), identical result
             # (skip(pool(t)) + pool(x)) / sqrt(2): the residual add runs in the 1x1 conv's epilogue; the 1/sqrt(2) costs nothing:
             # it is folded into the skip conv's weight coefficient / bias and into the gain of the pooling FIR of x
-            return elr_conv2d(self.skip, t_pooled, residual=x if pooled_out else self.down(x, gain=c, link=pre), out_gain=c)
+            return elr_conv2d(self.skip, t_pooled, residual=x if pooled_out else self.down(x, gain=c, link=pre), out_gain=c,
+                              skip_link=sl if pooled_out else None)
         t = self.skip(t)
         return (self.down(x) + self.down(t)) / np.sqrt(2)
 

@@ -145,7 +145,7 @@ def main():
     ap.add_argument('--pace', default='auto', help="memset nodes at the head of the recorded iteration: an integer, or 'auto' = calibrate 0..3 by timing replays (GraphedTrainStep.calibrate)")
     ap.add_argument('--ada-p', type=float, default=None, help="with --augment ada: start the pipe's probability here instead of 0 (at 0 every augmentation is gated off and the reflect margins are minimal)")
     ap.add_argument('--deterministic', action='store_true', help='agf_set_deterministic(1): one writer per output element instead of cross-workgroup fp32 atomics (bit-reproducible, slower)')
-    ap.add_argument('--ab', default='', help='comma-separated A/B switches for same-box comparisons: no-torgb, mapfuse / no-mapfuse, upscale (model.UPBLUR_PRESCALE), candN (N pace candidates)')
+    ap.add_argument('--ab', default='', help='comma-separated A/B switches for same-box comparisons: no-torgb, mapfuse / no-mapfuse, upscale (model.UPBLUR_PRESCALE), noskiplink (conv.SKIP_SUM_LINK off), candN (N pace candidates)')
     ap.add_argument('--dp-mode', default=None, choices=['ingraph', 'segmented'],
                     help='several ranks under graph replay: ingraph (default with RCCL) = ONE graph per iteration kind with the bucket all-reduces '
                          'recorded from the backward hooks on the RCCL stream (overlapped with the rest of backward); segmented = three graphs '
@@ -173,6 +173,9 @@ def main():
         M.MAP_FUSED = True
     if 'upscale' in ab:
         M.UPBLUR_PRESCALE = True
+    if 'noskiplink' in ab:
+        from animeface_amd.implementations.StyleGAN2 import conv as _C
+        _C.SKIP_SUM_LINK = False
     for item in ab:
         if item.startswith('cand'):
             U.GraphedTrainStep.PACE_CANDIDATES = tuple(range(int(item[4:])))

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define AGF_ABI_VERSION 20
+#define AGF_ABI_VERSION 21
 
 /* element types of activation tensors */
 enum { AGF_F32 = 0, AGF_F16 = 1, AGF_BF16 = 2, AGF_F64 = 3 };
@@ -282,7 +282,10 @@ int agf_act_bwd_reduce_pooled(const void* dy_half, const void* y, void* g, float
  * x[n, h, w, 8 g + k] > 0 -- the sign of the LeakyReLU output that the activation backward needs, at 1/16 of the bytes of x.  agf_act_bwd_reduce_pooled_mask is agf_act_bwd_reduce_pooled reading that mask
  * instead of y. */
 int agf_pool2x2(const void* x, void* y, void* mask, int dtype, int32_t N, int32_t H, int32_t W, int32_t C, float gain, void* stream);
-int agf_act_bwd_reduce_pooled_mask(const void* dy_half, const void* mask, void* g, float* sum_g,
+/* (ABI v21) sum_dy (nullable, [N][C], zero-initialised by the caller): += the per-channel sum of the incoming gradient BEFORE the mask over the
+ * full-resolution pixels = 4 * dy_scale * (sum of dy_half over the cells): the bias gradient of the DBlock's 1x1 skip conv, whose output
+ * gradient dy_half also is (reference implementations/StyleGAN2/model.py:186-212: out = (down(block(x)) + down(skip(x))) / sqrt 2). */
+int agf_act_bwd_reduce_pooled_mask(const void* dy_half, const void* mask, void* g, float* sum_g, float* sum_dy,
                                    int dtype, int32_t N, int32_t H, int32_t W, int32_t C, float alpha, float dy_scale, void* stream);
 
 /*   dx = t * s[n,c]  (nullable),   ds[n,c] += sum_{h,w} x * t */

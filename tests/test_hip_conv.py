@@ -484,6 +484,50 @@ def test_r1_image_gradient_pass_launches_no_parameter_gradients(monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(4, 32, 64, 64, 64), (8, 64, 128, 32, 32)], ids=['64x64', '32x32'])
+def test_dblock_skip_conv_bias_gradient_from_the_last_convs_pass(monkeypatch, shape):
+    """conv.PoolSkipLink: the DBlock's output gradient dy reaches the 1x1 skip conv (bias gradient = channel sum of dy) and the block's last
+    conv (agf_act_bwd_reduce_pooled_mask turns dy into its masked full-resolution gradient).  With the link the skip conv's backward runs
+    that pass -- which then also sums dy (``sum_dy``, ABI v21) -- and no separate ``sum`` launch exists.  Against the two separate passes:
+    same gradients (the masked gradient tensor bit-identical, the sums up to the order of the fp32 atomics)."""
+    from animeface_amd.implementations.StyleGAN2 import model as M, conv as C
+    N, Cin, Cout, H, W = shape
+    torch.manual_seed(11)
+    blk = M.DBlock(Cin, Cout).to(DEV)
+    blk.apply(M.init_weight_N01)
+    for p in blk.parameters():
+        if p.ndim == 1:
+            p.data.normal_()
+    x0 = torch.randn(N, Cin, H, W, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(N, Cout, H // 2, W // 2, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    sums = []
+    real_sum = C.channel_sum_raw
+    monkeypatch.setattr(C, 'channel_sum_raw', lambda *a, **k: (sums.append(1), real_sum(*a, **k))[1])
+    outs, counts = [], []
+    for on in (True, False):
+        monkeypatch.setattr(C, 'SKIP_SUM_LINK', on)
+        sums.clear()
+        x = x0.clone().requires_grad_(True)
+        y = blk(x)
+        grads = torch.autograd.grad(y, [x] + list(blk.parameters()), gy)
+        outs.append((y, grads))
+        counts.append(len(sums))
+    assert counts == [0, 1], counts
+    assert torch.equal(outs[0][0], outs[1][0])
+    names = ['x'] + [n for n, _ in blk.named_parameters()]
+    for n, a, b in zip(names, outs[0][1], outs[1][1]):
+        assert rel(a, b) < 2e-3, (n, rel(a, b))
+    assert rel(dict(zip(names, outs[0][1]))['skip.layer.bias'], (gy.float().sum((0, 2, 3)) / 2 ** 0.5)) < 2e-3
+    # the raw op: sum_dy = 4 * dy_scale * sum over the cells of dy
+    y_full = torch.randn(N, Cout, H, W, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    _, mask = C.pool2x2_raw(y_full, 1.0, True)
+    g1, B1 = C.act_bwd_reduce_pooled_mask_raw(gy, mask, y_full, 0.2, 0.3, True)
+    g2, B2, R = C.act_bwd_reduce_pooled_mask_raw(gy, mask, y_full, 0.2, 0.3, True, want_dy_sum=True)
+    assert torch.equal(g1, g2) and rel(B1, B2) < 1e-5
+    assert rel(R, 4 * 0.3 * gy.float().sum((2, 3))) < 1e-4
+
+
+@pytest.mark.gpu
 def test_dblock_linked_backward_matches_unlinked(monkeypatch):
     """DBlock with the PremaskLink / pooled-gradient fusions against the same block with them switched off (bf16, same inputs)."""
     from animeface_amd.implementations.StyleGAN2 import model as M, conv as C
