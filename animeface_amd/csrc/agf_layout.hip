@@ -403,3 +403,55 @@ extern "C" int agf_prep_weights_multi(const void* descs_device, int32_t count, i
     AGF_LAUNCH_CHECK();
     return AGF_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// agf_sum_squares: slots[b % SLOTS] += sum of x^2 over block b's elements -- the mean-square statistic of a StyleGAN3 layer's input
+// (reference implementations/StyleGAN3/model.py:174-176: x.detach().to(float32).square().mean(), tracked as an EMA that normalises the
+// layer).  One read of the tensor on the streaming pattern of tools/probe/stream_variants.hip: the whole grid, a block owns U * 256
+// consecutive 16-byte vectors, every load in flight before the first use, non-temporal (the tensor is read once here and its real
+// consumer, the layout conversion, comes later).  ATen's vector_norm ran the same read at 2.1-2.9 TB/s (tools/probe/sumsq_probe.py).
+template <class T, int VEC, int U>
+__global__ void __launch_bounds__(256) sum_squares_kernel(const T* __restrict__ x, float* __restrict__ slots, int64_t nvec, int64_t n, int nslots) {
+    const int64_t v0 = (int64_t)blockIdx.x * (U * 256) + threadIdx.x;
+    float f[U][VEC];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int64_t v = v0 + (int64_t)u * 256;
+        if (v < nvec) agf_vload<T, VEC, true>(x + v * VEC, f[u]);
+        else {
+#pragma unroll
+            for (int i = 0; i < VEC; i++) f[u][i] = 0.f;
+        }
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int u = 0; u < U; u++)
+#pragma unroll
+        for (int i = 0; i < VEC; i++) acc += f[u][i] * f[u][i];
+    if (blockIdx.x == 0 && threadIdx.x == 0)                        // the elements beyond the last whole vector
+        for (int64_t e = nvec * VEC; e < n; e++) { const float t = Elem<T>::load(x + e); acc += t * t; }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(slots + (blockIdx.x % nslots), red[0] + red[1] + red[2] + red[3]);
+}
+
+extern "C" int agf_sum_squares(const void* x, float* slots, int32_t nslots, int dtype, int64_t n, void* stream) {
+    AGF_CHECK(x && slots && nslots >= 1, "sum_squares: null pointer");
+    AGF_CHECK(n >= 1, "sum_squares: empty tensor");
+    AGF_CHECK(dtype == AGF_BF16 || dtype == AGF_F16 || dtype == AGF_F32, "sum_squares: dtype must be float16, bfloat16 or float32");
+    AGF_CHECK(((uintptr_t)x % 16) == 0, "sum_squares: x must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    constexpr int U = 8;
+    const int VEC = dtype == AGF_F32 ? 4 : 8;
+    const int64_t nvec = n / VEC;
+    const int64_t blocks = nvec ? (nvec + U * 256 - 1) / (U * 256) : 1;
+    AGF_CHECK(blocks < (1ll << 31), "sum_squares: tensor too large");
+    if (dtype == AGF_F32) hipLaunchKernelGGL((sum_squares_kernel<float, 4, U>), dim3((unsigned)blocks), dim3(256), 0, st, (const float*)x, slots, nvec, n, nslots);
+    else if (dtype == AGF_F16) hipLaunchKernelGGL((sum_squares_kernel<f16_t, 8, U>), dim3((unsigned)blocks), dim3(256), 0, st, (const f16_t*)x, slots, nvec, n, nslots);
+    else hipLaunchKernelGGL((sum_squares_kernel<bf16_t, 8, U>), dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)x, slots, nvec, n, nslots);
+    AGF_LAUNCH_CHECK();
+    return AGF_OK;
+}

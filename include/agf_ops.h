@@ -288,6 +288,11 @@ int agf_pool2x2(const void* x, void* y, void* mask, int dtype, int32_t N, int32_
 int agf_act_bwd_reduce_pooled_mask(const void* dy_half, const void* mask, void* g, float* sum_g, float* sum_dy,
                                    int dtype, int32_t N, int32_t H, int32_t W, int32_t C, float alpha, float dy_scale, void* stream);
 
+/* (ABI v21) slots[b % nslots] += the sum of x^2 over the elements block b owns, x any dense tensor of n elements (fp32 / fp16 / bf16, 16-byte
+ * aligned); the caller zero-initialises `slots` (fp32 [nslots]) and adds them up.  Replaces the reduction of the StyleGAN3 layer's input
+ * statistic, implementations/StyleGAN3/model.py:174-176 (x.detach().to(torch.float32).square().mean()): one streaming read of x. */
+int agf_sum_squares(const void* x, float* slots, int32_t nslots, int dtype, int64_t n, void* stream);
+
 /*   dx = t * s[n,c]  (nullable),   ds[n,c] += sum_{h,w} x * t */
 int agf_scale_dot(const void* x, const void* t, const float* s, void* dx, float* ds,
                   int dtype, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);

@@ -398,3 +398,24 @@ def test_bf16_networks_layer_by_layer_vs_the_bf16_emulating_oracle(golden, confi
         rms = float((af - bf).square().mean().sqrt() / bf.square().mean().sqrt().clamp_min(1e-12))
         print(f'   grad {k}: rms rel {rms:.4f}')
         assert rms < 0.08, (k, rms)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize('shape', [(2, 3, 5, 7), (16, 512, 36, 36), (4, 72, 148, 148), (1, 1, 1, 1), (3, 1, 1, 2731)])
+def test_mean_square_kernel_vs_vector_norm(dtype, shape, monkeypatch):
+    """``agf_sum_squares`` (the StyleGAN3 layer's input statistic, reference model.py:174-176) against x.float().square().mean() in fp64, incl. sizes
+    that are not a multiple of the vector width, and the channels-last order."""
+    from animeface_amd.implementations.StyleGAN3 import model as M
+    torch.manual_seed(0)
+    x = (torch.randn(shape, device=DEV) * 3).to(dtype)
+    want = x.double().square().mean()
+    got = M.mean_square(x)
+    assert got.dtype == torch.float32 and got.dim() == 0
+    assert abs(got.double() - want) / want < 2e-5
+    if x.dim() == 4 and shape[1] > 1:
+        got_cl = M.mean_square(x.contiguous(memory_format=torch.channels_last))
+        assert abs(got_cl.double() - want) / want < 2e-5
+    monkeypatch.setattr(M, 'SUM_SQUARES_KERNEL', False)
+    ref = M.mean_square(x)
+    assert abs(ref.double() - want) / want < 2e-5
