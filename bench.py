@@ -146,6 +146,7 @@ def main():
     ap.add_argument('--ada-p', type=float, default=None, help="with --augment ada: start the pipe's probability here instead of 0 (at 0 every augmentation is gated off and the reflect margins are minimal)")
     ap.add_argument('--deterministic', action='store_true', help='agf_set_deterministic(1): one writer per output element instead of cross-workgroup fp32 atomics (bit-reproducible, slower)')
     ap.add_argument('--ab', default='', help='comma-separated A/B switches for same-box comparisons: no-torgb, mapfuse / no-mapfuse, upscale (model.UPBLUR_PRESCALE), noskiplink (conv.SKIP_SUM_LINK off), candN (N pace candidates)')
+    ap.add_argument('--dp-bucket-mib', type=int, default=32, help='bucket size of the gradient all-reduce (GradReducer bucket_bytes), for A/B runs')
     ap.add_argument('--dp-mode', default=None, choices=['ingraph', 'segmented'],
                     help='several ranks under graph replay: ingraph (default with RCCL) = ONE graph per iteration kind with the bucket all-reduces '
                          'recorded from the backward hooks on the RCCL stream (overlapped with the rest of backward); segmented = three graphs '
@@ -205,8 +206,8 @@ def main():
     # with the exchange between the launches, the mode two ranks on one GPU over gloo are tested in).  If ANY rank fails to capture, every
     # rank falls back to the eager loop (all-reduce from backward hooks, overlapped with the backward pass); --eager selects that loop.
     opt_G, opt_D = U.build_optimizers(G, D, 0.001, (0., 0.99), 10., 0., 16, 8, capturable=use_graphs)
-    red_G = dp.GradReducer(G.parameters(), never_used=dp.never_used_parameters(G)) if dp_on else None
-    red_D = dp.GradReducer(D.parameters()) if dp_on else None
+    red_G = dp.GradReducer(G.parameters(), never_used=dp.never_used_parameters(G), bucket_bytes=args.dp_bucket_mib << 20) if dp_on else None
+    red_D = dp.GradReducer(D.parameters(), bucket_bytes=args.dp_bucket_mib << 20) if dp_on else None
     for red in (red_G, red_D):
         if red is not None:
             red.measure = True
