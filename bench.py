@@ -147,10 +147,13 @@ def main():
     ap.add_argument('--deterministic', action='store_true', help='agf_set_deterministic(1): one writer per output element instead of cross-workgroup fp32 atomics (bit-reproducible, slower)')
     ap.add_argument('--ab', default='', help='comma-separated A/B switches for same-box comparisons: no-torgb, mapfuse / no-mapfuse, upscale (model.UPBLUR_PRESCALE), noskiplink (conv.SKIP_SUM_LINK off), candN (N pace candidates)')
     ap.add_argument('--dp-bucket-mib', type=int, default=32, help='bucket size of the gradient all-reduce (GradReducer bucket_bytes), for A/B runs')
-    ap.add_argument('--dp-mode', default=None, choices=['ingraph', 'segmented'],
-                    help='several ranks under graph replay: ingraph (default with RCCL) = ONE graph per iteration kind with the bucket all-reduces '
-                         'recorded from the backward hooks on the RCCL stream (overlapped with the rest of backward); segmented = three graphs '
-                         'per iteration with the exchange between the launches')
+    ap.add_argument('--dp-mode', default='segmented', choices=['ingraph', 'segmented'],
+                    help='several ranks under graph replay: segmented (default here) = three graphs per iteration with the bucket all-reduces issued '
+                         'between the launches (plain RCCL calls, exposed); ingraph (the library default with RCCL) = ONE graph per iteration kind '
+                         'with the all-reduces recorded from the backward hooks on the RCCL stream, overlapped with the rest of backward.  The '
+                         'one-graph recording settles in the low-clock package-power regime on every pace candidate and bucket size tried '
+                         '(37.7 against 33.85 ms per step on a one-rank RCCL group, profiles/r04c_dp_one_rank_modes.txt), which costs more than '
+                         'the exposed exchange is expected to')
     ap.add_argument('--no-r1-every-step', action='store_true', help='skip the side measurement with the R1 penalty on every iteration')
     ap.add_argument('--no-ada-variant', action='store_true', help='skip the side measurement with the ADA pipe (BASELINE configs[2] "+ ADA")')
     ap.add_argument('--no-upfirdn2d-rows', action='store_true', help='skip the three upfirdn2d roofline rows (SURVEY.md section 8d)')
