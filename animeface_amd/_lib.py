@@ -19,7 +19,7 @@ EDGE_ZERO, EDGE_CLAMP = 0, 1
 
 _DTYPES = {torch.float32: AGF_F32, torch.float16: AGF_F16, torch.bfloat16: AGF_BF16, torch.float64: AGF_F64}
 
-EXPORTS = ['agf_abi_version', 'agf_last_error', 'agf_device_info', 'agf_set_deterministic', 'agf_get_deterministic', 'agf_upfirdn2d', 'agf_upfirdn2d_fold_border', 'agf_bias_act',
+EXPORTS = ['agf_abi_version', 'agf_last_error', 'agf_device_info', 'agf_set_deterministic', 'agf_get_deterministic', 'agf_memset_node', 'agf_upfirdn2d', 'agf_upfirdn2d_fold_border', 'agf_bias_act',
            'agf_filtered_lrelu', 'agf_filtered_lrelu_act', 'agf_conv2d_fwd', 'agf_conv2d_fwd_post', 'agf_conv2d_fwd_pool', 'agf_conv2d_fwd_mask', 'agf_conv2d_s2_fwd', 'agf_conv2d_s2_dgrad', 'agf_conv2d_wgrad', 'agf_conv2d_wgrad_ws', 'agf_conv2d_wgrad_workspace_bytes',
            'agf_act_bwd_reduce', 'agf_act_bwd_reduce_pooled', 'agf_act_bwd_reduce_pooled_mask', 'agf_pool2x2', 'agf_act_bwd_reduce_scaled', 'agf_scale_dot', 'agf_sum_squares', 'agf_demod_grad_finish', 'agf_planar_to_cl_pad', 'agf_planar_to_cl_pad_scaled', 'agf_cl_to_planar_crop_scaled', 'agf_cl_to_planar_crop', 'agf_cl_pad', 'agf_prep_weights', 'agf_prep_weights_multi', 'agf_prep_weights_blocks',
            'agf_modulate_weights', 'agf_conv2d_fwd_wimg', 'agf_conv2d_fwd_wimg_covers',
@@ -172,26 +172,19 @@ def lib():
         L.agf_set_deterministic.restype = ctypes.c_int
         L.agf_set_deterministic.argtypes = [ctypes.c_int]
         L.agf_get_deterministic.restype = ctypes.c_int
-        if L.agf_abi_version() != 21:
+        L.agf_memset_node.restype = ctypes.c_int
+        L.agf_memset_node.argtypes = [_vp, ctypes.c_int, ctypes.c_int64, _vp]
+        if L.agf_abi_version() != 22:
             raise AgfError('libagf_ops.so ABI version mismatch')
         _lib = L
     return _lib
 
 
-_hip = None
-
-
 def memset_node(buf, nbytes):
-    """``hipMemsetAsync(buf, 0, nbytes)`` on torch's current stream: under capture this records a MEMSET NODE (torch's own fills are kernel
-    nodes).  Used only to shape the node structure of a recorded iteration (``TrainStep._pace``)."""
-    global _hip
-    if _hip is None:
-        _hip = ctypes.CDLL('libamdhip64.so')
-        _hip.hipMemsetAsync.restype = ctypes.c_int
-        _hip.hipMemsetAsync.argtypes = [_vp, ctypes.c_int, ctypes.c_size_t, _vp]
-    rc = _hip.hipMemsetAsync(_vp(buf.data_ptr()), 0, nbytes, _vp(torch.cuda.current_stream(buf.device).cuda_stream))
-    if rc != 0:
-        raise AgfError(f'hipMemsetAsync failed with status {rc}')
+    """``hipMemsetAsync(buf, 0, nbytes)`` on torch's current stream (``agf_memset_node``: through the HIP runtime the library and torch
+    share): under capture this records a MEMSET NODE (torch's own fills are kernel nodes).  Used only to shape the node structure of a
+    recorded iteration (``TrainStep._pace``)."""
+    check(lib().agf_memset_node(_vp(buf.data_ptr()), 0, int(nbytes), stream_ptr(buf)), 'memset_node')
 
 
 def set_deterministic(on=True):

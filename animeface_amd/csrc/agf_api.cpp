@@ -21,6 +21,15 @@ extern "C" int agf_set_deterministic(int on) { const int old = g_deterministic; 
 extern "C" int agf_get_deterministic(void) { return g_deterministic; }
 extern "C" int agf_abi_version(void) { return AGF_ABI_VERSION; }
 
+// hipMemsetAsync on the caller's stream through the HIP runtime THIS library is linked against (the one torch's stream handle belongs
+// to): under stream capture it records a memset node, which is what the caller wants it for.
+extern "C" int agf_memset_node(void* buf, int value, int64_t nbytes, void* stream) {
+    if (!buf || nbytes <= 0) { agf_set_error("agf_memset_node: null buffer or non-positive size"); return AGF_EINVAL; }
+    const hipError_t e = hipMemsetAsync(buf, value, (size_t)nbytes, (hipStream_t)stream);
+    if (e != hipSuccess) { agf_set_error("agf_memset_node: hipMemsetAsync failed: %s", hipGetErrorString(e)); return AGF_ELAUNCH; }
+    return AGF_OK;
+}
+
 extern "C" int agf_device_info(int* cu_count, int* lds_bytes_per_block, int* wavefront_size) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) { agf_set_error("no HIP device"); return AGF_ELAUNCH; }

@@ -216,20 +216,38 @@ class GradReducer:
                     if id(p) not in self._touched:
                         p.grad = None
 
-    def exchange_all(self):
-        """Graph-replayed training (``GraphedTrainStep`` with reducers): the backward pass ran inside a HIP graph, where no hook fires, so
-        every bucket is all-reduced here, between two graph launches, and waited for.  Which parameters received a gradient is a static
+    def launch_all(self):
+        """Graph-replayed training (``GraphedTrainStep``, segmented mode): the backward pass ran inside a HIP graph, where no hook fires, so
+        every bucket's all-reduce is issued here, right after that graph's launch: on the collective's own stream, ordered behind the
+        graph by the event the process group records on the current stream.  What the caller launches next on the compute stream runs
+        beside the exchange; ``wait_all()`` makes the compute stream wait for it.  Which parameters received a gradient is a static
         property of the captured iteration kind (``detach_untouched`` ran when it was captured)."""
-        # (not event-timed: the exposed time of this mode is the whole exchange by construction; bench.py's step_ms carries it)
         for b in self.buckets:
             b['launched'] = False
             self._launch(b)
+        self.stats['steps'] += 1
+        self.stats['buckets_at_finish'] += len(self.buckets)
+
+    def wait_all(self):
+        """The compute stream waits for the all-reduces issued by ``launch_all()``.  With ``measure`` the wait is bracketed by two events
+        on the compute stream: their distance is the time the compute stream had nothing to run because of the exchange (the exposed
+        part; 0 when the work launched in between outlasts the collective)."""
+        ev0 = ev1 = None
+        if self.measure and self.buckets and self.buckets[0]['flat'].is_cuda:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
         for b in self.buckets:
             if b['work'] is not None:
                 b['work'].wait()
                 b['work'] = None
-        self.stats['steps'] += 1
-        self.stats['buckets_at_finish'] += len(self.buckets)
+        if ev0 is not None:
+            ev1.record()
+            self._pending_events = getattr(self, '_pending_events', []) + [(ev0, ev1)]
+
+    def exchange_all(self):
+        """``launch_all()`` + ``wait_all()`` with nothing in between: the whole exchange is exposed."""
+        self.launch_all()
+        self.wait_all()
 
     def detach_untouched(self):
         """``grad = None`` for the parameters whose hook did not fire since ``zero_grad()`` (second half of ``finish()``)."""

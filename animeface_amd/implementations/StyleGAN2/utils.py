@@ -139,13 +139,16 @@ class TrainStep:
 
     def _augment_ada(self, x):
         pipe = self._ada_pipe(x)
+        if self._ada_join:
+            # the side stream that makes the plans is joined at the first call of the iteration, whichever branch that call takes (a forked
+            # stream left unjoined fails a capture)
+            torch.cuda.current_stream().wait_stream(self._ada_side)
+            self._ada_join = False
         if self._ada_plans:
             shape, dtype, plan = self._ada_plans.pop(0)
             if shape == tuple(x.shape) and dtype == x.dtype:
-                if self._ada_join:
-                    torch.cuda.current_stream().wait_stream(self._ada_side)
-                    self._ada_join = False
                 return pipe(x, plan=plan)
+            self._ada_plans = []                    # made for another shape: none of the remaining ones fits either
         return pipe(x)
 
     def _plan_ahead(self, real, calls=3):
@@ -154,7 +157,7 @@ class TrainStep:
         if self.ada is None or not self.plan_ahead or rng._cpu or not real.is_cuda:
             return
         if self._ada_side is None:
-            if torch.cuda.is_current_stream_capturing():
+            if torch.cuda.is_current_stream_capturing():     # (GraphedTrainStep creates it before recording: not reached from there)
                 return
             self._ada_side = torch.cuda.Stream(real.device)
         side = self._ada_side
@@ -233,19 +236,33 @@ class TrainStep:
             self.reducer_D.pack_all()               # gradients -> bucket buffers (one multi-tensor copy per bucket, inside the graph)
         return D_loss.detach()
 
-    def _seg2(self, real, it):
+    def _seg2a(self, real, it):
+        """The part of the G half-step that does not depend on D's optimizer step: the generator's forward pass.  Replayed while D's bucket
+        all-reduces are in flight on the collective's stream; the prepared-weight scope and the gradient arena stay open until ``_seg2b``."""
+        import contextlib
+        self._g_scope = contextlib.ExitStack()
+        self._g_scope.enter_context(cached_weights())
+        self._g_scope.enter_context(recording_plans(self._plan_G, self._plan_D))
+        if self._plan_G is not None:
+            self._plan_G.install()                  # refreshed in segment 1, unchanged since
+        self._g_scope.enter_context(zero_arena(self._arena_G, real.device))
+        self._g_fwd_out = self._g_fwd(real)
+
+    def _seg2b(self, real, it):
+        """After D's exchange: D's optimizer step, then the rest of the G half-step (augment, frozen D, backward through both)."""
         D = self.D
         self.optimizer_D.step()
-        with cached_weights(), recording_plans(self._plan_G, self._plan_D):
-            if self._plan_G is not None:
-                self._plan_G.install()              # refreshed in segment 1, unchanged since
+        fake, style = self._g_fwd_out
+        self._g_fwd_out = None
+        with self._g_scope:
+            if self._plan_D is not None:
                 self._plan_D.run()
             for p in D.parameters():
                 p.requires_grad_(False)
-            with zero_arena(self._arena_G, real.device):
-                G_loss, fake = self._g_half(real, it)
+            G_loss, fake = self._g_rest(real, it, fake, style)
             for p in D.parameters():
                 p.requires_grad_(True)
+        self._g_scope = None
         if self.reducer_G is not None:
             self.reducer_G.pack_all()
         return G_loss.detach(), fake.detach()
@@ -297,10 +314,18 @@ class TrainStep:
         D_loss.backward()
         return D_loss
 
-    def _g_half(self, real, it):
-        G, D = self.G, self.D
+    def _g_fwd(self, real):
+        """The generator's forward pass of the G half-step (reference utils.py:89-91): reads nothing of D, so under data parallelism it runs
+        beside D's gradient exchange (``_seg2a``)."""
         z = self.sampler((real.size(0), self.latent_dim))
-        fake, style = G(z)
+        return self.G(z)
+
+    def _g_half(self, real, it):
+        fake, style = self._g_fwd(real)
+        return self._g_rest(real, it, fake, style)
+
+    def _g_rest(self, real, it, fake, style):
+        G, D = self.G, self.D
         fake_aug = self.augment(fake)
         fake_prob = D(fake_aug)
         pl_now = None
@@ -332,12 +357,15 @@ class GraphedTrainStep:
     (``build_optimizers(..., capturable=True)``) and input batches of one fixed shape.
 
     Data parallelism (``dp_mode``):
-      * ``'ingraph'`` (default with RCCL): ONE graph per iteration kind for every world size.  The reducers' backward hooks fire while
-        the backward pass is being RECORDED: each complete bucket is packed and its ``all_reduce`` is recorded on RCCL's stream, forked
-        off the capturing stream at that point of the backward pass and joined by ``GradReducer.finish()`` right before the optimizer
-        nodes -- so the replayed iteration keeps the overlap of the exchange with the rest of backward that the eager hook path has.
-      * ``'segmented'`` (gloo, whose collectives run on host threads, or on request): THREE graphs cut at the two gradient exchanges,
-        the bucket buffers all-reduced between the launches (``GradReducer.exchange_all``); the exchange is then exposed."""
+      * ``'segmented'`` (default): FOUR graphs cut at the two gradient exchanges -- [D half-step] -> D's bucket all-reduces on the
+        collective's stream BESIDE [generator forward of the G half-step] (it reads nothing of D: ~3 ms of compute cover the ~1 ms
+        exchange) -> [D's Adam, rest of the G half-step] -> G's bucket all-reduces (exposed: G's Adam needs all of them and the next
+        iteration starts with G's forward pass) -> [G's Adam, EMA].  Works with every backend (gloo's collectives run on host threads);
+        the mode the two-rank tests cover and the one that stays in the high-clock package-power regime.
+      * ``'ingraph'`` (RCCL only; the default only when ``pl_lambda > 0``, whose ``pl_mean`` all-reduce sits inside the G half-step): ONE
+        graph per iteration kind.  The reducers' backward hooks fire while the backward pass is being RECORDED: each complete bucket is
+        packed and its ``all_reduce`` is recorded on RCCL's stream, forked off the capturing stream at that point of the backward pass and
+        joined by ``GradReducer.finish()`` right before the optimizer nodes."""
 
     PACE_CANDIDATES = (0, 1, 2, 3)  # node counts recorded side by side when pace='auto'
     PACE_BLOCK = 12                 # consecutive iterations per candidate while selecting (the first 5 of a block are not counted: the
@@ -360,7 +388,11 @@ class GraphedTrainStep:
         self.step, self.graphs = step, {}
         reducers = step.reducer_G is not None
         if dp_mode is None:
-            dp_mode = 'ingraph' if (reducers and step.reducer_G.capturable and step.reducer_D.capturable) else 'segmented'
+            # the segmented mode is the one covered by tests with two real ranks (tests/test_hip_dp.py) and the one that stays in the
+            # high-clock regime (profiles/r04c_dp_one_rank_modes.txt); only a path-length run needs the one-graph mode (the all-reduce of
+            # ``pl_mean`` sits inside the G half-step)
+            ingraph = reducers and step.pl_lambda > 0 and step.reducer_G.capturable and step.reducer_D.capturable
+            dp_mode = 'ingraph' if ingraph else 'segmented'
         if dp_mode not in ('ingraph', 'segmented'):
             raise ValueError(f'dp_mode {dp_mode!r}')
         if reducers and dp_mode == 'ingraph' and not (step.reducer_G.capturable and step.reducer_D.capturable):
@@ -368,13 +400,15 @@ class GraphedTrainStep:
         self.dp_mode = dp_mode if reducers else None
         self.segmented = reducers and dp_mode == 'segmented'
         if self.segmented and step.pl_lambda > 0:
-            raise RuntimeError('the three-graph data-parallel mode has no place for the all-reduce of the path-length mean (inside the '
+            raise RuntimeError('the segmented data-parallel mode has no place for the all-reduce of the path-length mean (inside the '
                                "G half-step): use dp_mode='ingraph' (RCCL) or pl_lambda == 0")
         if reducers:
             step.reducer_G.early = step.reducer_D.early = not self.segmented
         if self.segmented:
             self.pool = torch.cuda.graph_pool_handle()
         self.static_real = real.clone()
+        if step.policy == 'ada' and step._ada_side is None and real.is_cuda:
+            step._ada_side = torch.cuda.Stream(real.device)      # the recording must not depend on whether an eager ADA iteration ran first
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                      # eager iterations first: optimizer state, arenas and caches reach their final size
@@ -400,19 +434,23 @@ class GraphedTrainStep:
         passes are recorded, which tells which parameters this kind of iteration gives a gradient (the others get ``grad = None`` before
         the optimizer step is recorded, as ``GradReducer.finish()`` does in the eager loop)."""
         st = self.step
-        g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        g1, g2a, g2b, g3 = (torch.cuda.CUDAGraph() for _ in range(4))
         # (thread_local: the process group's watchdog thread polls the events of earlier collectives; under the default global capture
         #  mode such a call from another thread invalidates the capture)
         mode = dict(pool=self.pool, capture_error_mode='thread_local')
         with torch.cuda.graph(g1, **mode):
             d_loss = st._seg1(self.static_real, it)
         st.reducer_D.detach_untouched()
-        with torch.cuda.graph(g2, **mode):
-            g_loss, fake = st._seg2(self.static_real, it)
+        # (the autograd graph of the generator's forward pass lives across the boundary between the two recordings: both use torch's one
+        #  capture stream and one memory pool, and are always replayed in this order)
+        with torch.cuda.graph(g2a, **mode):
+            st._seg2a(self.static_real, it)
+        with torch.cuda.graph(g2b, **mode):
+            g_loss, fake = st._seg2b(self.static_real, it)
         st.reducer_G.detach_untouched()
         with torch.cuda.graph(g3, **mode):
             st._seg3()
-        return (g1, g2, g3), (d_loss, g_loss, fake)
+        return (g1, g2a, g2b, g3), (d_loss, g_loss, fake)
 
     def _capture(self, it, nodes=None):
         st = self.step
@@ -465,11 +503,15 @@ class GraphedTrainStep:
     def _replay(self, graph):
         st = self.step
         if self.segmented:
-            graph[0].replay()
-            st.reducer_D.exchange_all()
-            graph[1].replay()
-            st.reducer_G.exchange_all()
-            graph[2].replay()
+            g1, g2a, g2b, g3 = graph
+            g1.replay()
+            st.reducer_D.launch_all()          # D's buckets on the collective's stream, ordered behind segment 1 ...
+            g2a.replay()                       # ... beside the generator's forward pass of the G half-step on the compute stream
+            st.reducer_D.wait_all()
+            g2b.replay()
+            st.reducer_G.launch_all()          # (G's optimizer step needs all of G's gradients and the next iteration starts with G's
+            st.reducer_G.wait_all()            #  forward pass: nothing to run beside this one)
+            g3.replay()
         else:
             graph.replay()
 
@@ -482,18 +524,30 @@ class GraphedTrainStep:
         K, B = len(self.candidates), self.PACE_BLOCK
         if self.pace_report is not None or K == 1:
             return
-        i = self._sel_count
-        if i < K * B:
+        i = self._sel_count                      # GAN-loss iterations timed so far (the lazy-regularisation kinds are other, longer graphs:
+        if i < K * B:                            #  replayed with the current candidate, not timed)
             self.pace_nodes = self.candidates[i // B]
             return
         torch.cuda.synchronize()
         med = {}
         for c, n in enumerate(self.candidates):
-            ts = sorted(self._sel_events[c * B + j].elapsed_time(self._sel_events[c * B + j + 1]) for j in range(5, B - 1))
+            ts = sorted(a.elapsed_time(b) for a, b in self._sel_events[c * B + 5:(c + 1) * B])
             med[n] = round(ts[len(ts) // 2], 3)
-        self.pace_nodes = min(med, key=med.get)
-        self.pace_report = dict(nodes=self.pace_nodes, median_ms=med, candidates=list(self.candidates), block=B)
+        local = dict(med)
+        if dp.dist.is_initialized() and dp.dist.get_world_size() > 1:
+            # one choice for the whole job: a data-parallel iteration lasts as long as its slowest rank, so the candidates are judged by
+            # the MAXIMUM of the ranks' medians (every rank computes the same vector, hence the same choice)
+            t = torch.tensor([med[n] for n in self.candidates], dtype=torch.float32, device=self.static_real.device)
+            dp.dist.all_reduce(t, op=dp.dist.ReduceOp.MAX)
+            med = {n: round(float(v), 3) for n, v in zip(self.candidates, t.tolist())}
+        choice = min(med, key=med.get)
+        self.pace_nodes = choice
+        self.pace_report = dict(nodes=self.pace_nodes, median_ms=med, candidates=list(self.candidates), block=B,
+                                timed='GAN-loss iterations only', this_rank_median_ms=local if local != med else None)
         self._sel_events = []
+        # the recordings of the rejected candidates are dropped (each holds its own activation pool: ~12 GB at 256x256 / batch 64)
+        for key in [k for k in self.graphs if k[1] != self.pace_nodes]:
+            del self.graphs[key]
 
     def select_now(self, real):
         """Run the selection iterations back to back (bench.py, before its warm-up): ordinary training iterations."""
@@ -507,19 +561,16 @@ class GraphedTrainStep:
         kind = self._kind(it)
         self.static_real.copy_(real)
         self._select()
-        selecting = self.pace_report is None and len(self.candidates) > 1
+        selecting = self.pace_report is None and len(self.candidates) > 1 and kind == 'gan'
         self._capture(it)
         graph, out, real_prob = self.graphs[(kind, self.pace_nodes)]
         if selecting:
-            if not self._sel_events:
-                ev = torch.cuda.Event(enable_timing=True)
-                ev.record()
-                self._sel_events.append(ev)
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
         self._replay(graph)
         if selecting:
-            ev = torch.cuda.Event(enable_timing=True)
-            ev.record()
-            self._sel_events.append(ev)
+            ev1.record()
+            self._sel_events.append((ev0, ev1))
             self._sel_count += 1
         if st.ada is not None:
             st.ada.update_p(real_prob)                      # host-counted schedule (reference nnutils/ada.py:25-36), a few tiny launches

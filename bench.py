@@ -129,6 +129,44 @@ def measured_traffic():
     return d
 
 
+def self_launch(n_gpus):
+    """``python bench.py --gpus N`` with N > 1 and no torchrun environment: re-execute this command under ``torch.distributed.run``, one rank
+    per GPU of this node (127.0.0.1 rendezvous on a free port), which is exactly what a caller that launches the ranks itself would have
+    done.  ``exec`` replaces the process, so stdout (rank 0's one JSON line) and the exit code are the job's."""
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')        # dmabuf IPC between the ranks (RCCL over xGMI on this driver)
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or n_gpus) // n_gpus)))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n_gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execve(sys.executable, cmd, env)
+
+
+def launch_probe():
+    """``--launch-probe``: what tests/test_bench_launch.py runs on a CPU box -- the ranks rendezvous (gloo without a GPU), all-reduce a one and
+    rank 0 prints what it saw; nothing of the benchmark runs."""
+    from animeface_amd import distributed as dp
+    import torch.distributed as dist
+    rank, world, local_rank = dp.init_distributed()
+    t = torch.ones(1)
+    if dist.is_initialized():
+        if torch.cuda.is_available():
+            t = t.cuda(local_rank)
+        dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({'launch_probe': True, 'world': world, 'ranks_seen': int(t.item()), 'local_rank': local_rank,
+                          'backend': dist.get_backend() if dist.is_initialized() else None}))
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -148,17 +186,23 @@ def main():
     ap.add_argument('--ab', default='', help='comma-separated A/B switches for same-box comparisons: no-torgb, mapfuse / no-mapfuse, upscale (model.UPBLUR_PRESCALE), noskiplink (conv.SKIP_SUM_LINK off), candN (N pace candidates)')
     ap.add_argument('--dp-bucket-mib', type=int, default=32, help='bucket size of the gradient all-reduce (GradReducer bucket_bytes), for A/B runs')
     ap.add_argument('--dp-mode', default='segmented', choices=['ingraph', 'segmented'],
-                    help='several ranks under graph replay: segmented (default here) = three graphs per iteration with the bucket all-reduces issued '
-                         'between the launches (plain RCCL calls, exposed); ingraph (the library default with RCCL) = ONE graph per iteration kind '
-                         'with the all-reduces recorded from the backward hooks on the RCCL stream, overlapped with the rest of backward.  The '
-                         'one-graph recording settles in the low-clock package-power regime on every pace candidate and bucket size tried '
-                         '(37.7 against 33.85 ms per step on a one-rank RCCL group, profiles/r04c_dp_one_rank_modes.txt), which costs more than '
-                         'the exposed exchange is expected to')
+                    help='several ranks under graph replay: segmented (default, also the library default) = four graphs per iteration cut at '
+                         "the two gradient exchanges; D's bucket all-reduces run on the RCCL stream BESIDE the generator's forward pass of the G "
+                         "half-step (which does not read D), G's between the backward graph and the optimizer graph (exposed: G's optimizer "
+                         'step needs them and the next iteration starts with G).  ingraph = ONE graph per iteration kind with the all-reduces '
+                         'recorded from the backward hooks on the RCCL stream; that recording settles in the low-clock package-power regime '
+                         'on every pace candidate and bucket size tried (37.7 against 33.85 ms per step on a one-rank RCCL group, '
+                         'profiles/r04c_dp_one_rank_modes.txt)')
     ap.add_argument('--no-r1-every-step', action='store_true', help='skip the side measurement with the R1 penalty on every iteration')
     ap.add_argument('--no-ada-variant', action='store_true', help='skip the side measurement with the ADA pipe (BASELINE configs[2] "+ ADA")')
     ap.add_argument('--no-upfirdn2d-rows', action='store_true', help='skip the three upfirdn2d roofline rows (SURVEY.md section 8d)')
     ap.add_argument('--augment', default='color,translation', help="DiffAugment policy (the reference's SG2 default) or 'ada'")
+    ap.add_argument('--launch-probe', action='store_true', help='only start the ranks, all-reduce a one and print what rank 0 saw (the CPU test of the launcher)')
     args = ap.parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ and 'RANK' not in os.environ:
+        self_launch(args.gpus)                       # does not return
+    if args.launch_probe:
+        return launch_probe()
 
     from animeface_amd import distributed as dp
     from animeface_amd.implementations.StyleGAN2 import utils as U, conv as C
@@ -203,11 +247,11 @@ def main():
     dp.broadcast_module(G), dp.broadcast_module(G_ema), dp.broadcast_module(D)
     dp_on = world > 1 or dist.is_initialized()           # (AGF_FORCE_DP=1: a one-rank RCCL group, to exercise the path on a single-GPU box)
     use_graphs = not args.eager
-    # ONE execution mode for every N: HIP-graph replay, one graph per iteration kind.  With several ranks the bucket all-reduces are part of
-    # the graph: recorded from the reducers' backward hooks on the RCCL stream, forked off the backward pass where a bucket completes and
-    # joined before the optimizer nodes (tests/test_hip_dp.py: a one-rank RCCL group via AGF_FORCE_DP=1; --dp-mode segmented = three graphs
-    # with the exchange between the launches, the mode two ranks on one GPU over gloo are tested in).  If ANY rank fails to capture, every
-    # rank falls back to the eager loop (all-reduce from backward hooks, overlapped with the backward pass); --eager selects that loop.
+    # ONE execution mode for every N: HIP-graph replay.  With several ranks the iteration is four graphs cut at the two gradient exchanges:
+    # D's bucket all-reduces run on the RCCL stream beside the generator's forward pass of the G half-step, G's between the backward graph
+    # and the optimizer graph (GraphedTrainStep, dp_mode 'segmented'; tests/test_hip_dp.py: two ranks on one GPU over gloo and a one-rank
+    # RCCL group via AGF_FORCE_DP=1).  --dp-mode ingraph = one graph per iteration kind with the all-reduces recorded from the backward
+    # hooks.  If ANY rank fails to capture, every rank falls back to the eager loop (all-reduce from backward hooks); --eager selects it.
     opt_G, opt_D = U.build_optimizers(G, D, 0.001, (0., 0.99), 10., 0., 16, 8, capturable=use_graphs)
     red_G = dp.GradReducer(G.parameters(), never_used=dp.never_used_parameters(G), bucket_bytes=args.dp_bucket_mib << 20) if dp_on else None
     red_D = dp.GradReducer(D.parameters(), bucket_bytes=args.dp_bucket_mib << 20) if dp_on else None
@@ -250,7 +294,7 @@ def main():
     eager_step = step
     if use_graphs:
         # capture both iteration kinds before anything is timed (a capture records, it does not execute).  With several ranks the
-        # iteration is three graphs cut at the two gradient exchanges; every rank must have captured before any rank replays (the
+        # iteration is four graphs cut at the two gradient exchanges; every rank must have captured before any rank replays (the
         # replay issues collectives), so success is agreed on first and the eager loop is the fallback.
         ok = 1
         try:
@@ -409,7 +453,7 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'bf16', 'data': 'synthetic', 'execution': ('hip-graph replay (the event-timed roofline sample is one eager iteration after the window)' + ((': three graphs per iteration, gradient all-reduce between the launches' if (runner is not None and runner.segmented) else
+            'dtype': 'bf16', 'data': 'synthetic', 'execution': ('hip-graph replay (the event-timed roofline sample is one eager iteration after the window)' + ((": four graphs per iteration; D's gradient all-reduce beside the generator's forward pass of the G half-step, G's between the backward and the optimizer graph" if (runner is not None and runner.segmented) else
                                                                                                                                      ': one graph per iteration kind, bucket all-reduces recorded on the RCCL stream from the backward hooks') if dp_on else '')) if use_graphs else 'eager launches',
             'config': {'workload': f'StyleGAN2 {S}x{S} G+D+lazy-R1 training step, batch {args.batch}/GPU '
                                    f'(BASELINE.json configs[2]: channels 32, max 512, style 512, d_k 16, r1_lambda 10, '

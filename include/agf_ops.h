@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define AGF_ABI_VERSION 21
+#define AGF_ABI_VERSION 22
 
 /* element types of activation tensors */
 enum { AGF_F32 = 0, AGF_F16 = 1, AGF_BF16 = 2, AGF_F64 = 3 };
@@ -57,6 +57,10 @@ int         agf_device_info(int* cu_count, int* lds_bytes_per_block, int* wavefr
  * reproducing a run bit for bit. */
 int         agf_set_deterministic(int on);
 int         agf_get_deterministic(void);
+/* hipMemsetAsync(buf, value, nbytes) on `stream` through the HIP runtime this library links (ABI v22; no reference counterpart).  Under
+ * stream capture it records a MEMSET node; GraphedTrainStep uses such nodes to shape the node structure of a recorded iteration
+ * (TrainStep._pace).  Exported so that the Python side never opens a second copy of the HIP runtime by name. */
+int         agf_memset_node(void* buf, int value, int64_t nbytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * upfirdn2d  --  replaces  Tensor upfirdn2d(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain)

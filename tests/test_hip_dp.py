@@ -252,7 +252,7 @@ def _worker_graphs(rank, world, port, out, graphed):
 
 
 def test_graph_replay_under_data_parallelism_equals_the_eager_exchange(tmp_path):
-    """GraphedTrainStep with reducers: three graphs per iteration kind, all-reduce of the bucket buffers between the launches -- against
+    """GraphedTrainStep with reducers: four graphs per iteration kind, the bucket all-reduces between the launches (D's beside the generator forward of the G half-step) -- against
     the eager two-rank loop from the same seeds (fp32: weights to summation noise)."""
     import torch.multiprocessing as mp
     out = str(tmp_path / 'dpg')
@@ -279,7 +279,7 @@ def test_graph_replay_under_data_parallelism_equals_the_eager_exchange(tmp_path)
 def _worker_rccl_ingraph(rank, world, port, out, mode):
     """ONE rank, fp32, device generator.  mode: 'single' = no process group, the single-process single-graph replay; 'ingraph' = a one-rank
     RCCL group (AGF_FORCE_DP=1) with the bucket all-reduces recorded into the graph from the backward hooks; 'segmented' = the same group
-    with three graphs per iteration and the exchange between the launches."""
+    with the iteration cut into four graphs at the two exchanges."""
     import sys
     import functools
     sys.path.insert(0, ROOT)
@@ -318,7 +318,7 @@ def _worker_rccl_ingraph(rank, world, port, out, mode):
     import datetime
     mark = lambda what: print(datetime.datetime.now().strftime('%H:%M:%S.%f'), mode, what, flush=True)
     mark('eager done')
-    runner = U.GraphedTrainStep(step, real, warmup=0, dp_mode=None if mode != 'segmented' else 'segmented')
+    runner = U.GraphedTrainStep(step, real, warmup=0, dp_mode=None if mode == 'single' else mode)
     if mode == 'ingraph':
         assert runner.dp_mode == 'ingraph' and not runner.segmented
     mark('capture begins')
@@ -345,10 +345,10 @@ def _worker_rccl_ingraph(rank, world, port, out, mode):
 
 
 def test_rccl_all_reduce_recorded_inside_the_graph_equals_the_single_process_replay(tmp_path):
-    """The default data-parallel mode: ONE HIP graph per iteration kind, the bucket all-reduces recorded on the RCCL stream from the backward
+    """The one-graph data-parallel mode: ONE HIP graph per iteration kind, the bucket all-reduces recorded on the RCCL stream from the backward
     hooks.  A one-rank RCCL group (AGF_FORCE_DP=1) exercises process group, hooks, capture of the collectives and replay on a single GPU;
     averaged over one rank the exchange is the identity, so losses and weights must equal the single-process replay from the same seeds
-    (fp32: summation noise), and the three-graph mode on the same group."""
+    (fp32: summation noise), and the segmented mode on the same group."""
     import torch.multiprocessing as mp
     out = str(tmp_path / 'rccl')
     for mode in ('single', 'ingraph', 'segmented'):
