@@ -257,6 +257,12 @@ class GradReducer:
                     if id(p) not in self._touched:
                         p.grad = None
 
+    def reset_stats(self):
+        """Forget the counters and pending timing events (bench.py: right before its timed window, so that the report covers the window
+        only -- not the eager warm-up iterations or the first, node-uploading replay of each recorded graph)."""
+        self._pending_events = []
+        self.stats = dict(steps=0, buckets_from_hooks=0, buckets_at_finish=0, exposed_ms=0.0)
+
     def overlap_report(self):
         """Counters for bench.py: how many buckets were launched from backward hooks (overlappable) vs. only at ``finish()``, and the time
         the compute stream spent waiting for the exchange in ``finish()`` (the exposed, non-overlapped part)."""

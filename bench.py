@@ -336,6 +336,9 @@ def main():
     first_timed = step.batches_done
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     barrier()
+    for red in (red_G, red_D):
+        if red is not None:
+            red.reset_stats()                                # the `rccl` report below covers the timed window only
     smi = SmiSampler(delay=0.25) if rank == 0 else None        # one rocm-smi reading of clock / power while the window runs (host thread)
     t0 = time.perf_counter()
     marks[0].record()
@@ -348,6 +351,7 @@ def main():
     dt = time.perf_counter() - t0
     smi_out = smi.result() if smi is not None else None
     step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    rccl_report = {'G': red_G.overlap_report(), 'D': red_D.overlap_report()} if dp_on else None
     if dp_on:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -486,9 +490,11 @@ def main():
         if dp_on:
             # what the exchange looked like: RCCL ranks, buckets launched from backward hooks (overlappable) vs. at finish(), and the time
             # the compute stream waited for the exchange (exposed); hidden = the rest of the all-reduce time
-            out['rccl'] = {'rccl_ranks': world, 'backend': dist.get_backend(),
-                           'G': red_G.overlap_report() if red_G is not None else None,
-                           'D': red_D.overlap_report() if red_D is not None else None}
+            out['rccl'] = {'rccl_ranks': world, 'backend': dist.get_backend(), 'mode': (runner.dp_mode if runner is not None else 'eager hooks'),
+                           'G': rccl_report['G'], 'D': rccl_report['D'],
+                           'exposed_ms_per_step': round(sum((rccl_report[k].get('exposed_ms_per_step') or 0.0) for k in 'GD'), 4),
+                           'note': "timed window only; exposed = time the compute stream waited for the exchange (events around the wait): in the "
+                                   "segmented mode D's all-reduces run beside the generator's forward pass of the G half-step, G's are exposed"}
         if timer is not None:
             summ = timer.summary()
             k = summ.get('conv2d_fwd_kernel')
