@@ -181,14 +181,21 @@ static __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16
 //      (each step a lane keeps the half of the values its lane bit selects: 16*MT - 1 shuffles instead of 5 * 16*MT). ----
 // PLAIN: the launch has no lrelu mask, no pooled residual and no residual operand (every forward conv and the unfused data gradients): an
 // instantiation without their registers (the mask vectors alone are 64 VGPRs of the general epilogue, which spills 20)
-template <int MT, int NJ, bool POOL = false, bool PLAIN = false>
+// BITS == 2: the lrelu mask of a launch of this instantiation arrives as bits only (mask_y is a compile-time null: its 16 * MT * NJ / 4
+//     registers -- 64 of the 128-channel tile -- are gone; the mask costs MT * NJ)
+// BITS (the 1-bit mask, read and written): 0 = compiled out (the generic 8-wave kernel, which has no registers for a second mask path),
+//     1 = run-time, next to mask_y, 2 = the mask of this instantiation arrives as bits ONLY (MB above)
+template <int MT, int NJ, bool POOL = false, bool PLAIN = false, int BITS = 1>
 static __device__ __forceinline__ void conv_epilogue_pl(const ConvParams& p, f32x16 (&acc)[MT][NJ], unsigned char* smem_raw,
                                                         int wave, int lane, int wm, int wn, int n0, int h0, int w0, int flatP0, int co0,
                                                         int nwn, int nwaves, int slot) {
     const int l31 = lane & 31, lhi = lane >> 5;
     const int coW = co0 + wm * 32 * MT;
     // (compile-time nulls in the PLAIN instantiation: the branches below and their registers disappear)
-    const bf16_t* const mask_y = PLAIN ? nullptr : p.mask_y;
+    const bf16_t* const mask_y = (PLAIN || BITS == 2) ? nullptr : p.mask_y;
+    const uint32_t* const mask_bits = (PLAIN || BITS == 0) ? nullptr : p.mask_bits;
+    uint32_t* const bits_out = (POOL || BITS == 0) ? nullptr : p.bits_out;
+    const int c32 = p.Cout >> 5;                                         // dwords of mask bits per pixel
     const bf16_t* const res_pooled = PLAIN ? nullptr : p.res_pooled;
     const bf16_t* const residual = PLAIN ? nullptr : p.residual;
     int64_t pixIdx[NJ]; int nimg[NJ]; bool valid[NJ]; float nz[NJ]; int hw2[NJ];
@@ -218,6 +225,17 @@ static __device__ __forceinline__ void conv_epilogue_pl(const ConvParams& p, f32
                     mk[j][i][q] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
                     if (valid[j] && cb < p.Cout) mk[j][i][q] = *(const u32x4*)(mask_y + pixIdx[j] * p.Cout + cb);
                 }
+    }
+    // ... or as bits: one dword per (pixel, 32-channel block) -- both half-waves load the same words
+    uint32_t mb[NJ][MT];
+    if (mask_bits) {
+#pragma unroll
+        for (int j = 0; j < NJ; j++)
+#pragma unroll
+            for (int i = 0; i < MT; i++) {
+                mb[j][i] = 0xffffffffu;
+                if (valid[j] && coW + i * 32 < p.Cout) mb[j][i] = mask_bits[pixIdx[j] * c32 + ((coW + i * 32) >> 5)];
+            }
     }
     // (POOL is an instantiation of its own: as a run-time branch of the common epilogue it cost EVERY launch of the direct-to-LDS kernel
     //  73-80 spilled registers instead of 20, and the conv family 865 -> 840 TFLOP/s)
@@ -315,10 +333,14 @@ static __device__ __forceinline__ void conv_epilogue_pl(const ConvParams& p, f32
     // residual of a LINEAR epilogue with unit gain (the DBlock's skip conv: y = conv + bias + pool(x)): added after the lane swap, where a
     // lane owns 8 consecutive channels of a pixel -- one 16-byte load instead of two 8-byte gathers a pixel row apart
     const bool resPost = MT == 1 && residual && p.act != 3 && p.gain == 1.f;     // (64-channel tile only: the 128-channel kernels have no registers to spare)
+    uint32_t wprev = 0u;                                                 // bits_out, MT == 1: the word of pixel j - 1 (pixels leave in pairs)
 #pragma unroll
     for (int j = 0; j < NJ; j++) {
         const int64_t pi = pixIdx[j];
         const int n = nimg[j];
+        uint32_t wbits[MT];                                              // bits_out: this lane's two bytes of the (pixel, 32-channel block) word
+#pragma unroll
+        for (int i = 0; i < MT; i++) wbits[i] = 0u;
         u32x4 rp[MT][2];
         if (res_pooled) {
             // gradient of the pooled skip branch, read at half resolution (no upsampled tensor, no separate add)
@@ -380,7 +402,7 @@ static __device__ __forceinline__ void conv_epilogue_pl(const ConvParams& p, f32
                 const auto s1 = __builtin_amdgcn_permlane32_swap(P[0][1], P[1][1], false, false);
                 u32x4 val = {s0[0], s1[0], s0[1], s1[1]};
                 const int cb = coW + i * 32 + (2 * q + lhi) * 8;
-                if (res_pooled || mask_y || resPost) {
+                if (res_pooled || mask_y || mask_bits || resPost) {
                     float g[8];
                     Pack16<bf16_t>::unpack(val.x, g[0], g[1]); Pack16<bf16_t>::unpack(val.y, g[2], g[3]);
                     Pack16<bf16_t>::unpack(val.z, g[4], g[5]); Pack16<bf16_t>::unpack(val.w, g[6], g[7]);
@@ -412,14 +434,56 @@ static __device__ __forceinline__ void conv_epilogue_pl(const ConvParams& p, f32
                             msum[(i * 2 + q) * 8 + e] += live ? g[e] : 0.f;
                         }
                     }
+                    if (mask_bits) {
+                        // the same gradient from the 1-bit mask: byte 2q + lhi of the block's word holds this lane's 8 channels
+                        const uint32_t byte = mb[j][i] >> (8 * (2 * q + lhi));
+                        const bool live = valid[j] && cb < p.Cout;
+#pragma unroll
+                        for (int e = 0; e < 8; e++) {
+                            g[e] = ((byte >> e) & 1u) ? g[e] : g[e] * p.mask_alpha;
+                            msum[(i * 2 + q) * 8 + e] += live ? g[e] : 0.f;
+                        }
+                    }
                     val.x = Pack16<bf16_t>::pack(g[0], g[1]); val.y = Pack16<bf16_t>::pack(g[2], g[3]);
                     val.z = Pack16<bf16_t>::pack(g[4], g[5]); val.w = Pack16<bf16_t>::pack(g[6], g[7]);
                 }
                 if (valid[j] && cb < p.Cout) *(u32x4*)(p.y + pi * p.Cout + cb) = val;
+                if (bits_out) {
+                    // sign bits of the STORED bf16 values (what a consumer reading y itself would test): a bf16 is > 0 iff its 16 bits, read as
+                    // a signed integer, are > 0
+                    uint32_t byte = 0u;
+                    byte |= ((int16_t)(val.x & 0xffffu) > 0 ? 1u : 0u) | ((int16_t)(val.x >> 16) > 0 ? 2u : 0u);
+                    byte |= ((int16_t)(val.y & 0xffffu) > 0 ? 4u : 0u) | ((int16_t)(val.y >> 16) > 0 ? 8u : 0u);
+                    byte |= ((int16_t)(val.z & 0xffffu) > 0 ? 16u : 0u) | ((int16_t)(val.z >> 16) > 0 ? 32u : 0u);
+                    byte |= ((int16_t)(val.w & 0xffffu) > 0 ? 64u : 0u) | ((int16_t)(val.w >> 16) > 0 ? 128u : 0u);
+                    wbits[i] |= byte << (8 * (2 * q + lhi));
+                }
+            }
+        }
+        if (bits_out) {
+            // a (pixel, 32-channel block) word is two bytes here and two in lane ^ 32: one v_permlane32_swap + OR assembles two words at a
+            // time -- blocks i = 0 / 1 of this pixel (MT == 2), or pixels j - 1 / j of the one block (MT == 1) -- the lower half-wave ends up
+            // with the first, the upper with the second: one dword store per lane
+            if constexpr (MT == 2) {
+                const auto sw = __builtin_amdgcn_permlane32_swap(wbits[0], wbits[1], false, false);
+                const uint32_t word = sw[0] | sw[1];
+                const int cb32 = coW + lhi * 32;
+                if (valid[j] && cb32 < p.Cout) bits_out[pi * c32 + (cb32 >> 5)] = word;
+            } else if constexpr (NJ == 1) {
+                const auto sw = __builtin_amdgcn_permlane32_swap(wbits[0], wbits[0], false, false);
+                const uint32_t word = sw[0] | sw[1];
+                if (lhi == 0 && valid[j] && coW < p.Cout) bits_out[pi * c32 + (coW >> 5)] = word;
+            } else {
+                if (j & 1) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(wprev, wbits[0], false, false);
+                    const uint32_t word = sw[0] | sw[1];
+                    const int jj = lhi ? j : j - 1;
+                    if (valid[jj] && coW < p.Cout) bits_out[pixIdx[jj] * c32 + (coW >> 5)] = word;
+                } else wprev = wbits[0];
             }
         }
     }
-    if (mask_y && p.mask_sum) {             // block-uniform
+    if ((mask_y || mask_bits) && p.mask_sum) {             // block-uniform
         // halving butterfly over the 32 lanes of each half-wave: after step m a lane keeps the half of the remaining values that its
         // bit m selects, so lane l ends with the total of value index  bit0*NV/2 + bit1*NV/4 + ...  (NV = 16*MT values per lane)
         constexpr int NV = MT * 16;
@@ -650,7 +714,7 @@ __global__ void __launch_bounds__(64 * NWM * NWN, OCC) conv2d_fwd_kernel(ConvPar
         }
     }
 
-    if (POOL || p.vecStore == 2) conv_epilogue_pl<MT, NJ, POOL>(p, acc, smem_raw, wave, lane, wm, wn, n0, h0, w0, flatP0, co0, NWN, NWM * NWN, pixTile & 255);
+    if (POOL || p.vecStore == 2) conv_epilogue_pl<MT, NJ, POOL, false, MT == 2 ? 0 : 1>(p, acc, smem_raw, wave, lane, wm, wn, n0, h0, w0, flatP0, co0, NWN, NWM * NWN, pixTile & 255);
     else conv_epilogue<MT, NJ>(p, acc, smem_raw, wave, lane, wm, wn, n0, h0, w0, flatP0, co0, NWN, NWM * NWN, pixTile & 255);
 }
 
@@ -666,6 +730,8 @@ __global__ void __launch_bounds__(64 * NWM * NWN, OCC) conv2d_fwd_kernel(ConvPar
 // Out-of-image halo pixels, channel tails and co tails are lanes whose buffer offset is out of range: the hardware writes zeros.
 template <int KS, int MT, int NWN, int PMAX, int NWM, int NJ, bool POOL = false, bool PLAIN = false>
 __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_dl_kernel(ConvParams p) {
+    // (the instantiation with the fused gradient epilogue takes the lrelu mask as BITS only: conv_epilogue_pl MB)
+    constexpr bool MB = !POOL && !PLAIN;
     constexpr int NTHR = 64 * NWM * NWN;
     constexpr int KC = 16;
     constexpr int TAPS = KS * KS;
@@ -788,6 +854,9 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_dl_kernel(ConvPa
     issue(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+#ifdef AGF_DL_PRIO
+    if (wave >= NTHR / 128) __builtin_amdgcn_s_setprio(1);           // the later-dispatched half loses every VALU arbitration otherwise (MI355X_MICROARCH.md)
+#endif
     for (int ch = 0; ch < nChunks; ch++) {
         const int cur = ch & 1;
         const bool more = ch + 1 < nChunks;
@@ -818,7 +887,10 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_dl_kernel(ConvPa
                     // the next chunk's DMA pieces go out BETWEEN the taps' MFMA groups (one or two per tap over the first TAPS - 1 taps; the last
                     // tap covers the youngest pieces' flight): issued in one burst at the top of the chunk they cost every wave ~1 000 cycles in
                     // lock step, during which the matrix pipe idles (+6-11 % on the >= 128-channel layers, tools/ab_dl.sh)
-                    constexpr int T1 = TAPS > 1 ? TAPS - 1 : 1;
+#ifndef AGF_DL_T1
+#define AGF_DL_T1 (TAPS - 1)
+#endif
+                    constexpr int T1 = TAPS > 1 ? (AGF_DL_T1) : 1;
                     if (tap < T1) issue_range((ch + 1) * KC, cur ^ 1, tap * NP / T1, (tap + 1) * NP / T1);
                 }
             }
@@ -828,7 +900,7 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_dl_kernel(ConvPa
             __syncthreads();                                          // ... and so have everyone's; everyone is done with `cur`
         }
     }
-    if (POOL || p.vecStore == 2) conv_epilogue_pl<MT, NJ, POOL, PLAIN>(p, acc, smem_raw, wave, lane, wm, wn, n0, h0, w0, 0, co0, NWN, NWM * NWN, pixTile & 255);
+    if (POOL || p.vecStore == 2) conv_epilogue_pl<MT, NJ, POOL, PLAIN, MB ? 2 : 1>(p, acc, smem_raw, wave, lane, wm, wn, n0, h0, w0, 0, co0, NWN, NWM * NWN, pixTile & 255);
     else conv_epilogue<MT, NJ>(p, acc, smem_raw, wave, lane, wm, wn, n0, h0, w0, 0, co0, NWN, NWM * NWN, pixTile & 255);
 }
 
@@ -1755,7 +1827,7 @@ static int launch_fwd(const ConvParams& p, hipStream_t st) {
     // weight-stationary kernel: Cin <= 32 (two blocks per CU), or Cin <= 64 with Cout <= 32 (32-channel co tile: the
     // generic 64-channel tile would waste half of its MFMAs there); measured per layer in tools/ab_ws.sh
     constexpr int ws1 = 1;
-    if (g_ws_enable != 0 && ws1 != 0 && (ws1 == 2 || p.in_scale) && KS == 1 && MT == 1 && p.pixTiles >= 2048 && p.TW == 32 && p.TH == 8 && p.TI == 1 && p.Cin <= 32 && p.Cout <= 64) {
+    if (g_ws_enable != 0 && ws1 != 0 && !p.mask_bits && !p.bits_out && (ws1 == 2 || p.in_scale) && KS == 1 && MT == 1 && p.pixTiles >= 2048 && p.TW == 32 && p.TH == 8 && p.TI == 1 && p.Cin <= 32 && p.Cout <= 64) {
         // 1x1 convs with few channels (FromRGB / ToRGB / the 32 -> 64 skip): pure streaming work.  One 256-pixel tile per block left
         // them at ~2 TB/s (block prologue per 20 KB of traffic); the persistent kernel keeps the weights in LDS and streams tiles.
         int rc;
@@ -1763,7 +1835,7 @@ static int launch_fwd(const ConvParams& p, hipStream_t st) {
         else              rc = p.in_scale ? launch_fwd_ws<1, true, 32, 64>(p, st) : launch_fwd_ws<1, false, 32, 64>(p, st);
         if (rc != AGF_ENOKERNEL) return rc;
     }
-    if (g_ws_enable && !p.post_scale && !p.pool_mask && KS == 3 && MT == 1 && p.pixTiles >= 2048 && p.TW == 32 && p.TH == 8 && p.TI == 1 &&
+    if (g_ws_enable && !p.post_scale && !p.pool_mask && !p.mask_bits && !p.bits_out && KS == 3 && MT == 1 && p.pixTiles >= 2048 && p.TW == 32 && p.TH == 8 && p.TI == 1 &&
         (p.Cin <= 32 || (p.Cin <= 64 && p.Cout <= 32) || (g_ws_enable >= 2 && p.Cin <= 64 && p.Cout <= 64))) {
         int rc;
         constexpr int ws2 = 1;
@@ -1785,12 +1857,13 @@ static int launch_fwd(const ConvParams& p, hipStream_t st) {
     if (KS == 3 && MT == 1 && !p.flat && p.TI * p.TH * p.TW == 64)
         return p.in_scale ? launch_fwd_v<KS, 1, true, 32, 2, 160, 2, 1>(p, st) : launch_fwd_v<KS, 1, false, 32, 2, 160, 2, 1>(p, st);
     constexpr int dl = 1;
-    if (dl && KS == 3 && MT == 2 && !p.in_scale && !p.flat) {
-        const bool plain = KS == 3 && !p.mask_y && !p.res_pooled && !p.residual && p.vecStore == 2;
+    if (dl && KS == 3 && MT == 2 && !p.in_scale && !p.flat && !p.mask_y) {        // (a bf16 mask: the generic 8-wave kernel below; the networks pass bits)
+        const bool plain = KS == 3 && !p.mask_bits && !p.res_pooled && !p.residual && p.vecStore == 2;
         const int rc = p.Cout <= 64 ? (plain ? launch_fwd_dl<KS, 2, 4, 612, 1, 4, false, true>(p, st) : launch_fwd_dl<KS, 2, 4, 612, 1, 4>(p, st))
                                     : (plain ? launch_fwd_dl<KS, 2, 4, 612, 2, 4, false, true>(p, st) : launch_fwd_dl<KS, 2, 4, 612, 2, 4>(p, st));
         if (rc != AGF_ENOKERNEL) return rc;
     }
+    if (MT == 2 && (p.mask_bits || p.bits_out)) return AGF_ENOKERNEL;            // (the generic 8-wave kernel has the bits compiled out)
     if (MT == 2 && p.Cout <= 64) return p.in_scale ? launch_fwd_v<KS, 2, true, 16, 4, 612, 1>(p, st) : launch_fwd_v<KS, 2, false, 16, 4, 612, 1>(p, st);
     if (MT == 2) return p.in_scale ? launch_fwd_v<KS, 2, true, 16, 4, 612>(p, st) : launch_fwd_v<KS, 2, false, 16, 4, 612>(p, st);
     return p.in_scale ? launch_fwd_v<KS, 1, true, 32, 2, (KS == 3 ? 576 : 256)>(p, st) : launch_fwd_v<KS, 1, false, 32, 2, (KS == 3 ? 576 : 256)>(p, st);
@@ -1802,12 +1875,18 @@ static int conv2d_fwd_impl(const void* x, const void* w, void* y,
                            int dtype, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
                            int act, float alpha, float act_gain,
                            const void* mask_y, float mask_alpha, float* mask_sum, const void* res_pooled, float res_scale, void* stream,
-                           const float* post_scale = nullptr, void* pool_mask = nullptr, float pool_gain = 0.f) {
+                           const float* post_scale = nullptr, void* pool_mask = nullptr, float pool_gain = 0.f,
+                           const void* mask_bits = nullptr, void* bits_out = nullptr) {
     AGF_CHECK(x && w && y, "conv2d_fwd: null pointer");
     AGF_CHECK(dtype == AGF_BF16 || dtype == AGF_F32, "conv2d_fwd: dtype must be bf16 or f32");
     if ((mask_y || res_pooled) && (dtype != AGF_BF16 || (Cout % 8) != 0 || ((uintptr_t)y % 16) != 0 || ((uintptr_t)mask_y % 16) != 0 ||
                                    ((uintptr_t)res_pooled % 16) != 0 || (res_pooled && (act != 1 || (H & 1) || (W & 1))))) {
         agf_set_error("conv2d_fwd_mask: needs bf16, Cout %% 8 == 0, 16-byte aligned tensors (and a linear epilogue on an even map for res_pooled)");
+        return AGF_ENOKERNEL;
+    }
+    if ((mask_bits || bits_out) && (dtype != AGF_BF16 || ksize != 3 || (Cout % 32) != 0 || ((uintptr_t)y % 16) != 0 || ((uintptr_t)mask_bits % 4) != 0 ||
+                                    ((uintptr_t)bits_out % 4) != 0 || (mask_bits && mask_y) || pool_mask || post_scale)) {
+        agf_set_error("conv2d_fwd: the 1-bit mask needs a bf16 3x3 conv with Cout %% 32 == 0, a 16-byte aligned y and no bf16 mask / pooled output / post scale");
         return AGF_ENOKERNEL;
     }
     if (post_scale && (dtype != AGF_BF16 || ksize != 3 || Cout < 64 || mask_y || res_pooled)) {
@@ -1847,6 +1926,7 @@ static int conv2d_fwd_impl(const void* x, const void* w, void* y,
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
     p.act = act; p.alpha = alpha; p.gain = act_gain;
     p.mask_y = (const bf16_t*)mask_y; p.mask_alpha = mask_alpha; p.mask_sum = mask_sum;
+    p.mask_bits = (const uint32_t*)mask_bits; p.bits_out = (uint32_t*)bits_out;
     p.res_pooled = (const bf16_t*)res_pooled; p.res_scale = res_scale;
     p.post_scale = post_scale;
     p.pool_mask = (uint32_t*)pool_mask; p.pool_gain = pool_gain;
@@ -1868,6 +1948,7 @@ static int conv2d_fwd_impl(const void* x, const void* w, void* y,
     p.xcdBand = 0;
     { constexpr int vs = 2;     // 2: register-only (permlane32), 1: through LDS, 0: direct
       p.vecStore = ((vs || mask_y || res_pooled) && (Cout % 8) == 0 && ((uintptr_t)y % 16) == 0) ? (vs == 2 ? 2 : 1) : 0; }
+    if ((mask_bits || bits_out) && p.vecStore != 2) { agf_set_error("conv2d_fwd: the 1-bit mask is served by the register epilogue only"); return AGF_ENOKERNEL; }
     if (ksize == 3 && !post_scale) {
         // high-resolution, few-channel layers: the persistent multi-stage kernel (agf_conv2d_pipe.hip)
         const int rc = agf_conv2d_pipe_launch(p, (hipStream_t)stream);
@@ -1988,6 +2069,28 @@ extern "C" int agf_conv2d_fwd_mask(const void* x, const void* w, void* y,
     AGF_CHECK(mask_y || res_pooled, "conv2d_fwd_mask: neither a mask nor a pooled residual");
     return conv2d_fwd_impl(x, w, y, in_scale, out_scale, bias, noise, residual, dtype, N, H, W, Cin, Cout, ksize, act, alpha, act_gain,
                            mask_y, mask_alpha, mask_sum, res_pooled, res_scale, stream);
+}
+
+extern "C" int agf_conv2d_fwd_bits(const void* x, const void* w, void* y, void* bits_out,
+                                   const float* in_scale, const float* out_scale, const float* bias,
+                                   const float* noise, const void* residual,
+                                   int dtype, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
+                                   int act, float alpha, float act_gain, void* stream) {
+    AGF_CHECK(bits_out, "conv2d_fwd_bits: null bits_out");
+    return conv2d_fwd_impl(x, w, y, in_scale, out_scale, bias, noise, residual, dtype, N, H, W, Cin, Cout, ksize, act, alpha, act_gain,
+                           nullptr, 0.f, nullptr, nullptr, 0.f, stream, nullptr, nullptr, 0.f, nullptr, bits_out);
+}
+
+extern "C" int agf_conv2d_fwd_maskbits(const void* x, const void* w, void* y,
+                                       const float* in_scale, const float* out_scale, const float* bias,
+                                       const float* noise, const void* residual,
+                                       int dtype, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
+                                       int act, float alpha, float act_gain,
+                                       const void* mask_bits, float mask_alpha, float* mask_sum,
+                                       const void* res_pooled, float res_scale, void* stream) {
+    AGF_CHECK(mask_bits, "conv2d_fwd_maskbits: null mask_bits");
+    return conv2d_fwd_impl(x, w, y, in_scale, out_scale, bias, noise, residual, dtype, N, H, W, Cin, Cout, ksize, act, alpha, act_gain,
+                           nullptr, mask_alpha, mask_sum, res_pooled, res_scale, stream, nullptr, nullptr, 0.f, mask_bits, nullptr);
 }
 
 // ---- stride-2 3x3 convolution and its data gradient on conv2d_fwd_taps_kernel ----

@@ -55,6 +55,9 @@ struct ConvParams {
     const bf16_t* mask_y;     // fused lrelu gradient (agf_conv2d_fwd_mask): y *= mask_y > 0 ? 1 : mask_alpha; null = off
     float mask_alpha;
     float* mask_sum;          // [256][Cout] fp32: += sum over pixels of the masked output (nullable)
+    const uint32_t* mask_bits;// the same lrelu mask as ONE BIT per element (agf_conv2d_fwd_maskbits): [N][H][W][Cout/32] dwords, bit 8g + e of dword k =
+                              //   (y[.., 32k + 8g + e] > 0), written by the producer's launch through bits_out; replaces mask_y (Cout % 32 == 0)
+    uint32_t* bits_out;       // or null: this launch also writes the sign bits of its stored output in that format (agf_conv2d_fwd_bits)
     const bf16_t* res_pooled; // [N,H/2,W/2,Cout]: y += res_scale * res_pooled[h/2,w/2] before the mask (the adjoint of a 2x2 average that shares
     float res_scale;          //   this conv's input: the other branch of a residual block); null = off
     int vecStore;             // epilogue: transpose through LDS and store 16-byte vectors (needs Cout % 8 == 0, y 16-byte aligned)

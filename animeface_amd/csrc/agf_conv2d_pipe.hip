@@ -69,8 +69,11 @@ template <int KS, int MT, int NWM, int NWN, int NJ, int NCH, int NSTAGE, int PMA
 __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_pipe_kernel(PipeParams pp) {
     // EPI 3 (agf_conv2d_fwd_pool): the operands of EPI 0, but what leaves the tile is its 2x2 average and the 1-bit sign mask of the
     // full-resolution result (see the pooled branch of the epilogue); everywhere else it is EPI 0
+    // EPI 4: EPI 0 + the sign bits of the stored output (agf_conv2d_fwd_bits); EPI 5 / 6: EPI 1 / 2 with the lrelu mask read as bits
+    // (agf_conv2d_fwd_maskbits: MT * NJ dwords per lane instead of 2 * MT * NJ 16-byte vectors)
     constexpr bool POOL = EPI == 3;
-    constexpr int EP = POOL ? 0 : EPI;
+    constexpr bool BOUT = EPI == 4, MBITS = EPI == 5 || EPI == 6;
+    constexpr int EP = (POOL || BOUT) ? 0 : EPI == 5 ? 1 : EPI == 6 ? 2 : EPI;
     const ConvParams& p = pp.c;
     constexpr int NW = NWM * NWN;
     constexpr int TAPS = KS * KS, HALO = KS / 2, BM = 32 * NWM * MT;
@@ -86,8 +89,9 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_pipe_kernel(Pipe
     constexpr int LPW_HI = (NOPS + NW - 1) / NW, LPW_LO = NOPS / NW;
     constexpr int KG = LPW_HI;
     constexpr int PA = MT * NJ * 2;                      // 16-byte vectors of the tile's mask (pooled residual) per lane
-    constexpr int PCNT = EP == 0 ? NJ : EP * PA;       // prefetch loads per wave and tile
-    constexpr int SCNT = POOL ? MT * NJ : 2 * MT * NJ;    // stores per wave and tile (pooled: NJ / 2 * MT vectors + as many mask words)
+    constexpr int PCNT = EP == 0 ? NJ : MBITS ? MT * NJ + (EP - 1) * PA : EP * PA;       // prefetch loads per wave and tile
+    constexpr int SCNT = POOL ? MT * NJ : 2 * MT * NJ + (BOUT ? (MT == 2 ? NJ : NJ / 2) : 0);    // stores per wave and tile (pooled: NJ / 2 * MT vectors + as many mask words)
+    static_assert(!BOUT || MT == 2 || NJ % 2 == 0, "sign-bit words of the 32-channel tile leave in pixel pairs");
     constexpr int PF = NCH >= 2 ? NCH - 2 : 0;           // chunk at whose start the epilogue operands are requested
     constexpr int TCONS = (NSTAGE - 1 + NCH - 1) / NCH;  // first tiles: the conservative wait count (operations of the prologue)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -188,7 +192,8 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_pipe_kernel(Pipe
 
     // ---- epilogue operands that live in registers: the tile's lrelu mask / pooled residual (EP 1, 2) or its noise (EP 0) ----
     const int coW = wm * 32 * MT;
-    u32x4 preA[EP >= 1 ? PA : 1], preB[EP == 2 ? PA : 1];
+    u32x4 preA[(EP >= 1 && !MBITS) ? PA : 1], preB[EP == 2 ? PA : 1];
+    uint32_t preM[MBITS ? MT * NJ : 1];                              // MBITS: the mask words of (pixel j, 32-channel block i)
     float nzv[NJ];
     int pixOff[NJ];                                                  // byte offset of the lane's pixel j in an image of y (Cout channels), or OOB
     int cellOff[POOL ? NJ : 1];                                      // POOL: byte offset of the pixel's 2x2 cell in an image of the pooled tensor, or OOB
@@ -214,12 +219,22 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_pipe_kernel(Pipe
         if (EP >= 1) {
             const __amdgpu_buffer_rsrc_t mRes = __builtin_amdgcn_make_buffer_rsrc((void*)(p.mask_y + (int64_t)n0 * p.H * p.W * p.Cout), 0, p.mask_y ? outImg : 0, 0x00020000);
             const __amdgpu_buffer_rsrc_t rRes = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res_pooled + (int64_t)n0 * (p.H >> 1) * (p.W >> 1) * p.Cout), 0, p.res_pooled ? outImg >> 2 : 0, 0x00020000);
+            if (MBITS) {
+                // (a pixel's y is Cout * 2 bytes, its mask words Cout / 8 bytes: the word offset is the pixel offset / 16)
+                const __amdgpu_buffer_rsrc_t bRes = __builtin_amdgcn_make_buffer_rsrc((void*)(p.mask_bits + (int64_t)n0 * p.H * p.W * (p.Cout >> 5)), 0, outImg >> 4, 0x00020000);
+#pragma unroll
+                for (int s = 0; s < MT * NJ; s++) {
+                    const int j = s / MT, i = s % MT;
+                    const int off = (pixOff[j] != PIPE_OOB && coW + i * 32 < p.Cout) ? (pixOff[j] >> 4) + ((coW + i * 32) >> 3) : PIPE_OOB;
+                    preM[s] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(bRes, off, 0, 0);
+                }
+            }
 #pragma unroll
             for (int s = 0; s < PA; s++) {                           // slot s = (j, i, q): this lane's post-swap vector
                 const int j = s / (MT * 2), i = (s / 2) % MT, q = s & 1;
                 const int cb = coW + i * 32 + (2 * q + lhi) * 8;
                 const int offA = cb < p.Cout ? pixOff[j] + cb * 2 : PIPE_OOB, offB = cb < p.Cout ? hw2[j] + cb * 2 : PIPE_OOB;
-                preA[s] = __builtin_amdgcn_raw_buffer_load_b128(mRes, offA, 0, 0);
+                if (!MBITS) preA[s] = __builtin_amdgcn_raw_buffer_load_b128(mRes, offA, 0, 0);
                 if (EP == 2) preB[s] = __builtin_amdgcn_raw_buffer_load_b128(rRes, offB, 0, 0);
             }
         }
@@ -338,8 +353,16 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_pipe_kernel(Pipe
 #pragma unroll
             for (int e = 0; e < MT * 16; e++) msum[e] = 0.f;
         }
+        // BOUT: the sign-bit words go to [pixel][yPix / 32] dwords: a pixel's words start at its y offset / 16 (yPix * 2 bytes of y per pixel,
+        // yPix / 8 bytes of bits), this launch's first block at word bitsOrg (a channel slice of a wider tensor: the 128-channel split)
+        const __amdgpu_buffer_rsrc_t oRes = __builtin_amdgcn_make_buffer_rsrc((void*)((BOUT && p.bits_out) ? p.bits_out + (int64_t)n0 * p.H * p.W * (pp.yPix >> 5) : nullptr), 0,
+                                                                              (BOUT && p.bits_out) ? (p.H * p.W * pp.yPix) >> 3 : 0, 0x00020000);
+        uint32_t wprev = 0u;
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
+            uint32_t wbits[MT];
+#pragma unroll
+            for (int i = 0; i < MT; i++) wbits[i] = 0u;
 #pragma unroll
             for (int i = 0; i < MT; i++) {
 #pragma unroll
@@ -385,7 +408,17 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_pipe_kernel(Pipe
 #pragma unroll
                             for (int e = 0; e < 8; e++) g[e] += rv[e] * p.res_scale;
                         }
-                        if (p.mask_y) {
+                        if constexpr (MBITS) {
+                            if (p.mask_bits) {
+                                const uint32_t byte = preM[j * MT + i] >> (8 * (2 * q + lhi));
+                                const bool live = pixOff[j] != PIPE_OOB && cb < p.Cout;
+#pragma unroll
+                                for (int e = 0; e < 8; e++) {
+                                    g[e] = ((byte >> e) & 1u) ? g[e] : g[e] * p.mask_alpha;
+                                    msum[(i * 2 + q) * 8 + e] += live ? g[e] : 0.f;
+                                }
+                            }
+                        } else if (p.mask_y) {
                             float a[8];
                             Pack16<bf16_t>::unpack(preA[s].x, a[0], a[1]); Pack16<bf16_t>::unpack(preA[s].y, a[2], a[3]);
                             Pack16<bf16_t>::unpack(preA[s].z, a[4], a[5]); Pack16<bf16_t>::unpack(preA[s].w, a[6], a[7]);
@@ -401,7 +434,30 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_pipe_kernel(Pipe
                     }
                     const int offY = cb < p.Cout ? pixOff[j] + cb * 2 : PIPE_OOB;
                     __builtin_amdgcn_raw_buffer_store_b128(val, yRes, offY, 0, 0);
+                    if constexpr (BOUT) {
+                        uint32_t byte = 0u;
+                        byte |= ((int16_t)(val.x & 0xffffu) > 0 ? 1u : 0u) | ((int16_t)(val.x >> 16) > 0 ? 2u : 0u);
+                        byte |= ((int16_t)(val.y & 0xffffu) > 0 ? 4u : 0u) | ((int16_t)(val.y >> 16) > 0 ? 8u : 0u);
+                        byte |= ((int16_t)(val.z & 0xffffu) > 0 ? 16u : 0u) | ((int16_t)(val.z >> 16) > 0 ? 32u : 0u);
+                        byte |= ((int16_t)(val.w & 0xffffu) > 0 ? 64u : 0u) | ((int16_t)(val.w >> 16) > 0 ? 128u : 0u);
+                        wbits[i] |= byte << (8 * (2 * q + lhi));
+                    }
                 }
+            }
+            if constexpr (BOUT) {
+                // two bytes of a (pixel, 32-channel block) word are here, two in lane ^ 32 (see conv_epilogue_pl): one swap + OR assembles the
+                // words of blocks 0 / 1 (MT == 2) or of pixels j - 1 / j (MT == 1); lower half-wave stores the first, upper the second
+                if constexpr (MT == 2) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(wbits[0], wbits[1], false, false);
+                    const int cb32 = coW + lhi * 32;
+                    const int off = (pixOff[j] != PIPE_OOB && cb32 < p.Cout) ? (pixOff[j] >> 4) + (cb32 >> 3) : PIPE_OOB;
+                    __builtin_amdgcn_raw_buffer_store_b32(sw[0] | sw[1], oRes, off, 0, 0);
+                } else if (j & 1) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(wprev, wbits[0], false, false);
+                    const int po = lhi ? pixOff[j] : pixOff[j - 1];
+                    const int off = (po != PIPE_OOB && coW < p.Cout) ? (po >> 4) + (coW >> 3) : PIPE_OOB;
+                    __builtin_amdgcn_raw_buffer_store_b32(sw[0] | sw[1], oRes, off, 0, 0);
+                } else wprev = wbits[0];
             }
         }
         if (EP >= 1) {
@@ -520,7 +576,7 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_pipe_kernel(Pipe
         });
     }
 
-    if (EP >= 1 && p.mask_y && p.mask_sum) {             // block-uniform
+    if (EP >= 1 && (MBITS ? p.mask_bits != nullptr : p.mask_y != nullptr) && p.mask_sum) {             // block-uniform
         // add the waves that share the channels through LDS, then ONE atomic per channel and block
         red[wave * 64 + lane] = msumAcc;
         __syncthreads();
@@ -559,6 +615,16 @@ static int launch_pipe(const PipeParams& pp, int blocksPerCU, hipStream_t st) {
         if constexpr (MT == 2 && NCH == 4 && WS && NJ % 2 == 0) return launch_pipe_e<KS, MT, NWM, NWN, NJ, NCH, NSTAGE, PMAX, 3, WS>(pp, blocksPerCU, st);
         else return AGF_ENOKERNEL;
     }
+    if (pp.c.mask_bits) {
+        // the mask as bits: instantiated for the shapes the discriminator's hand-offs produce on this kernel (shared weights, Cin <= 64)
+        if constexpr (WS) return pp.c.res_pooled ? launch_pipe_e<KS, MT, NWM, NWN, NJ, NCH, NSTAGE, PMAX, 6, WS>(pp, blocksPerCU, st)
+                                                 : launch_pipe_e<KS, MT, NWM, NWN, NJ, NCH, NSTAGE, PMAX, 5, WS>(pp, blocksPerCU, st);
+        else return AGF_ENOKERNEL;
+    }
+    if (pp.c.bits_out) {
+        if constexpr (WS) return launch_pipe_e<KS, MT, NWM, NWN, NJ, NCH, NSTAGE, PMAX, 4, WS>(pp, blocksPerCU, st);
+        else return AGF_ENOKERNEL;
+    }
     if (pp.c.res_pooled) return launch_pipe_e<KS, MT, NWM, NWN, NJ, NCH, NSTAGE, PMAX, 2, WS>(pp, blocksPerCU, st);
     if (pp.c.mask_y)     return launch_pipe_e<KS, MT, NWM, NWN, NJ, NCH, NSTAGE, PMAX, 1, WS>(pp, blocksPerCU, st);
     return launch_pipe_e<KS, MT, NWM, NWN, NJ, NCH, NSTAGE, PMAX, 0, WS>(pp, blocksPerCU, st);
@@ -578,7 +644,7 @@ int agf_conv2d_pipe_launch(const ConvParams& p0, hipStream_t st) {
     // 128-channel kernel has only 2-4 K chunks per tile to amortise its prologue and epilogue over (590 TFLOP/s); two launches of this
     // kernel, one per 64-channel half of the weights, each writing its channel slice of y, are faster (the second reads x from L2 / MALL)
     constexpr int split = 1;
-    if (split && !p0.pool_mask && p0.Cout == 128 && (p0.Cin == 32 || p0.Cin == 64) && !p0.mask_y && !p0.res_pooled && !p0.out_scale && !p0.in_scale && !p0.residual &&
+    if (split && !p0.pool_mask && p0.Cout == 128 && (p0.Cin == 32 || p0.Cin == 64) && !p0.mask_y && !p0.mask_bits && !p0.res_pooled && !p0.out_scale && !p0.in_scale && !p0.residual &&
         !p0.noise && ((uintptr_t)p0.y % 16) == 0 && pipe_covers(p0.N, p0.H, p0.W, p0.Cin, 64)) {
         for (int half = 0; half < 2; half++) {
             ConvParams q = p0;
@@ -586,12 +652,21 @@ int agf_conv2d_pipe_launch(const ConvParams& p0, hipStream_t st) {
             q.w = p0.w + (int64_t)half * 64 * 9 * p0.Cin;
             q.y = p0.y + half * 64;
             q.bias = p0.bias ? p0.bias + half * 64 : nullptr;
+            q.bits_out = p0.bits_out ? p0.bits_out + half * 2 : nullptr;      // (the half's two words of every pixel's four)
             const int rc = pipe_launch(q, 0, st, 128);
             if (rc != AGF_OK) return half == 0 ? rc : AGF_ELAUNCH;
         }
         return AGF_OK;
     }
     return pipe_launch(p0, 0, st);
+}
+
+// Whether a producer conv (Cin -> Cout, 3x3) may hand its consumer the lrelu mask as bits without landing on a slower kernel: every kernel
+// family writes / reads them except this file's re-streamed-weight instantiations (Cin = 128 with <= 64 outputs per block)
+extern "C" int agf_conv2d_maskbits_covers(int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout) {
+    if (Cout % 32) return 0;
+    if (Cin > 64 && Cout <= 64 && pipe_covers(N, H, W, Cin, Cout)) return 0;
+    return 1;
 }
 
 // wmod[n][co][tap][ci] = w[co][tap][ci] * s[n][ci]: the style modulation folded into one weight tensor per image (what the reference
@@ -653,7 +728,8 @@ static int pipe_launch(const ConvParams& p0, int64_t wImgStride, hipStream_t st,
     if (!mode) return AGF_ENOKERNEL;
     ConvParams p = p0;
     if (p.in_scale || p.residual) return AGF_ENOKERNEL;
-    if ((p.mask_y || p.res_pooled) && (p.out_scale || p.bias || p.noise)) return AGF_ENOKERNEL;
+    if ((p.mask_bits || p.bits_out) && (wImgStride != 0 || p.Cin > 64 || (p.Cout % 32) || p.pool_mask)) return AGF_ENOKERNEL;
+    if ((p.mask_y || p.mask_bits || p.res_pooled) && (p.out_scale || p.bias || p.noise)) return AGF_ENOKERNEL;
     if (p.pool_mask && ((p.H & 1) || (p.W & 1) || (p.H % 16) || (p.W % 32) || yPix)) return AGF_ENOKERNEL;      // whole tiles only: every 2x2 cell inside one
     if (((uintptr_t)p.y % 16) || !pipe_covers(p.N, p.H, p.W, p.Cin, p.Cout)) return AGF_ENOKERNEL;
     p.flat = 0; p.TI = 1; p.TW = 32; p.TH = 16; p.twShift = 5; p.thShift = 4;
@@ -666,7 +742,7 @@ static int pipe_launch(const ConvParams& p0, int64_t wImgStride, hipStream_t st,
     pp.band = (p.pixTiles + 7) / 8;
     pp.wImgStride = wImgStride;
     pp.yPix = yPix ? yPix : p.Cout;
-    if (pp.yPix != p.Cout && (p.mask_y || p.res_pooled || p.out_scale || wImgStride)) return AGF_ENOKERNEL;
+    if (pp.yPix != p.Cout && (p.mask_y || p.mask_bits || p.res_pooled || p.out_scale || wImgStride)) return AGF_ENOKERNEL;
     constexpr int pipe_dbg = 0;
     pp.dbg = pipe_dbg;
     constexpr int cnt_st = 0;

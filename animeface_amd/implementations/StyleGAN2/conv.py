@@ -156,9 +156,20 @@ def prep_weights_raw(w, coef, dtype, want_q=True, want_ft=False):
     return wq, wft
 
 
+def mask_bits_like(N, C, H, W, device):
+    """The 1-bit lrelu mask of a [N,C,H,W] channels-last activation: int32 [N,H,W,C/32], bit 8g + e of word k = (y[.., 32k + 8g + e] > 0)."""
+    return torch.empty((N, H, W, C // 32), dtype=torch.int32, device=device)
+
+
+def mask_bits_covers(N, H, W, Cin, Cout):
+    """Whether BOTH launches of a DBlock hand-off -- the producer's forward conv (Cin -> Cout) and the consumer's data gradient (-> Cout) --
+    run on kernels that write / read the 1-bit mask (``agf_conv2d_maskbits_covers``)."""
+    return bool(_lib.lib().agf_conv2d_maskbits_covers(N, H, W, Cin, Cout))
+
+
 def conv2d_fwd_raw(x, w, in_scale=None, out_scale=None, bias=None, noise=None, residual=None,
                    act=ACT_LINEAR, alpha=0.2, gain=1.0, prepared=False, mask_y=None, mask_alpha=0.2, mask_sum=None,
-                   res_pooled=None, res_scale=1.0, post_scale=None):
+                   res_pooled=None, res_scale=1.0, post_scale=None, bits_out=None, mask_bits=None):
     """One ``agf_conv2d_fwd`` launch (``post_scale`` [N,Cout]: ``agf_conv2d_fwd_post``, the stored output times that scale).  x: [N,Cin,H,W] bf16 channels_last; w: [Cout,Cin,k,k] (any float dtype).
     in_scale [N,Cin], out_scale [N,Cout], bias [Cout], noise [N,1,H,W] are fp32; residual like y.  Returns y bf16 channels_last."""
     _lib.require_gpu(x, 'conv2d')
@@ -192,6 +203,22 @@ def conv2d_fwd_raw(x, w, in_scale=None, out_scale=None, bias=None, noise=None, r
         rc = L.agf_conv2d_fwd_wimg(_lib.ptr(x), _lib.ptr(wmod), _lib.ptr(y), _lib.ptr(out_scale), _lib.ptr(bias), _lib.ptr(noise),
                                    _lib.dtype_code(x), N, H, W, Cin, Cout, k, act, float(alpha), float(gain), Cout * k * k * Cin,
                                    _lib.stream_ptr(x))
+    elif bits_out is not None:
+        # ``agf_conv2d_fwd_bits``: the launch also leaves the sign bits of its output (one per element): what the data-gradient launch of this
+        # layer's only consumer reads as the lrelu mask instead of the bf16 tensor itself (``mask_bits`` below)
+        assert mask_y is None and res_pooled is None and mask_bits is None and bits_out.shape == (N, H, W, Cout // 32) and bits_out.dtype == torch.int32
+        rc = L.agf_conv2d_fwd_bits(_lib.ptr(x), _lib.ptr(wq), _lib.ptr(y), _lib.ptr(bits_out), _lib.ptr(in_scale), _lib.ptr(out_scale),
+                                   _lib.ptr(bias), _lib.ptr(noise), _lib.ptr(residual), _lib.dtype_code(x),
+                                   N, H, W, Cin, Cout, k, act, float(alpha), float(gain), _lib.stream_ptr(x))
+    elif mask_bits is not None:
+        assert mask_y is None and mask_bits.shape == (N, H, W, Cout // 32) and mask_bits.dtype == torch.int32 and mask_bits.is_contiguous()
+        assert res_pooled is None or (res_pooled.shape == (N, Cout, H // 2, W // 2) and res_pooled.dtype == x.dtype
+                                      and res_pooled.is_contiguous(memory_format=torch.channels_last))
+        rc = L.agf_conv2d_fwd_maskbits(_lib.ptr(x), _lib.ptr(wq), _lib.ptr(y), _lib.ptr(in_scale), _lib.ptr(out_scale),
+                                       _lib.ptr(bias), _lib.ptr(noise), _lib.ptr(residual), _lib.dtype_code(x),
+                                       N, H, W, Cin, Cout, k, act, float(alpha), float(gain),
+                                       _lib.ptr(mask_bits), float(mask_alpha), _lib.ptr(mask_sum),
+                                       _lib.ptr(res_pooled), float(res_scale), _lib.stream_ptr(x))
     elif mask_y is not None or res_pooled is not None:
         # ``agf_conv2d_fwd_mask``: + res_scale * res_pooled[h/2, w/2] (the gradient of a pooled sibling branch), then multiplied by the
         # leaky-ReLU derivative taken from ``mask_y`` (same shape as y) with the per-channel sum accumulated into ``mask_sum`` [256, Cout]
@@ -210,7 +237,8 @@ def conv2d_fwd_raw(x, w, in_scale=None, out_scale=None, bias=None, noise=None, r
                                        N, H, W, Cin, Cout, k, act, float(alpha), float(gain), _lib.stream_ptr(x))
     if timer is not None:
         timer.stop('conv2d_fwd_kernel', ev0, 2.0 * N * H * W * Cin * Cout * k * k,
-                   (N, Cin, Cout, H, W, k, in_scale is not None, mask_y is not None or res_pooled is not None))
+                   (N, Cin, Cout, H, W, k, in_scale is not None, mask_y is not None or res_pooled is not None or mask_bits is not None)
+                   + ((False, 'bits') if (mask_bits is not None or bits_out is not None) else ()))
     _lib.check(rc, 'conv2d_fwd')
     return y
 
@@ -853,7 +881,7 @@ class PremaskLink:
     """Handshake between two chained fused convs  y1 = lrelu(conv1(x) + b1);  y2 = conv2(y1)  where conv2 is the ONLY consumer of y1
     (the caller guarantees that: DBlock).  conv2's backward then produces the gradient of y1 already multiplied by lrelu'(y1) and its
     per-channel sums (``agf_conv2d_fwd_mask``), and conv1's backward skips its own pass over the tensor (``agf_act_bwd_reduce``)."""
-    __slots__ = ('armed', 'alpha', 'premasked', 'bsum', 'pooled', 'armed_mod', 'noise', 'sums', 'mask', 'gscale', 'gscaled', 'yscaled')
+    __slots__ = ('armed', 'alpha', 'premasked', 'bsum', 'pooled', 'armed_mod', 'noise', 'sums', 'mask', 'gscale', 'gscaled', 'yscaled', 'bits')
 
     def __init__(self):
         self.armed, self.alpha, self.premasked, self.bsum, self.pooled = False, 0.2, False, None, None
@@ -867,6 +895,9 @@ class PremaskLink:
         # ``POSTSCALE_X``: the modulated producer stored its output times the consumer's style scale (agf_conv2d_fwd_post); the consumer
         # then reads its input unscaled
         self.yscaled = False
+        # ``MASK_BITS``: the un-modulated producer's launch also wrote the sign bits of its output (``agf_conv2d_fwd_bits``); the consumer's
+        # data-gradient launch then reads those (1/16 of the bytes, 4 instead of 64 registers per lane of the 128-channel tile)
+        self.bits = None
 
 
 class PoolSkipLink:
@@ -1087,6 +1118,7 @@ FUSE_POOL = True       # the DBlock's last conv writes its 2x2 average + sign ma
 POSTSCALE_X = True     # the first modulated conv of a StyleBlock stores its output times the second one's style scale (>= 128 channels), which then
 #                        runs on the unscaled (direct-to-LDS) kernel forward and in its weight gradient (tests compare both ways)
 PRESCALE_G = True      # a modulated layer's gradient tensor is stored times its demodulation scale by the pass that makes it (tests compare both ways)
+MASK_BITS = True       # the lrelu mask of the DBlock hand-off travels as one bit per element (agf_conv2d_fwd_bits / _maskbits; tests compare both ways)
 _PREMASK = True        # tests/test_hip_conv.py::test_dblock_linked_backward_matches_unlinked runs the block with the fused hand-offs off
 
 
@@ -1140,8 +1172,25 @@ class _FusedConv(torch.autograd.Function):
         chain_mod = post_link is not None and _PREMASK and act == ACT_LRELU and gain == 1.0 and x.dtype == torch.bfloat16 and s_out is not None
         post = post_scale.detach() if (POSTSCALE_X and post_scale is not None and chain_mod and residual is None and skip_pool is None
                                        and weight.shape[0] >= 128 and weight.shape[2] == 3) else None
-        y = conv2d_fwd_raw(x, prep.wq, in_scale=None if x_pre else s_in, out_scale=s_out, bias=bias, noise=noise, residual=residual,
-                           act=act, alpha=alpha, gain=gain, prepared=True, post_scale=post)
+        # the un-modulated chain hand-off (see post_link.armed below): leave the sign bits of y for the consumer's data-gradient launch
+        arm_plain = post_link is not None and _PREMASK and act == ACT_LRELU and gain == 1.0 and s_out is None and noise is None \
+            and x.dtype == torch.bfloat16
+        bits = None
+        if arm_plain and MASK_BITS and x.is_cuda and any(ctx.needs_input_grad[:8]) and post is None and s_in is None and weight.shape[2] == 3 \
+                and weight.shape[0] % 32 == 0 \
+                and mask_bits_covers(x.shape[0], x.shape[2], x.shape[3], weight.shape[1], weight.shape[0]):
+            bits = mask_bits_like(x.shape[0], weight.shape[0], x.shape[2], x.shape[3], x.device)
+        try:
+            y = conv2d_fwd_raw(x, prep.wq, in_scale=None if x_pre else s_in, out_scale=s_out, bias=bias, noise=noise, residual=residual,
+                               act=act, alpha=alpha, gain=gain, prepared=True, post_scale=post, bits_out=bits)
+        except _lib.AgfError as exc:                  # (no kernel writes the bits for this tiling: the consumer reads y itself)
+            if bits is None or getattr(exc, 'status', 0) != -2:
+                raise
+            bits = None
+            y = conv2d_fwd_raw(x, prep.wq, in_scale=None if x_pre else s_in, out_scale=s_out, bias=bias, noise=noise, residual=residual,
+                               act=act, alpha=alpha, gain=gain, prepared=True, post_scale=post)
+        if post_link is not None:
+            post_link.bits = bits
         ctx.x_pre, ctx.post = x_pre, post
         ctx.save_for_backward(x, weight, s_in, s_out, bias, noise, y if (act == ACT_LRELU or s_out is not None) else None)
         ctx.coef, ctx.act, ctx.alpha, ctx.gain = coef, act, alpha, gain
@@ -1314,8 +1363,18 @@ class _FusedConv(torch.autograd.Function):
                 # x is the lrelu output of the producer this link came from and we are its only consumer: hand it the masked gradient
                 det = _lib.deterministic()            # the kernel's per-channel sums are atomics over 256 slots: reduce the output instead
                 pre.bsum = None if det else _zeros_f32((256, x.shape[1]), x.device)
-                t = conv2d_fwd_raw(g, prep.wq_ft, in_scale=None if g_scaled else s_out, prepared=True, gain=pg, mask_y=x, mask_alpha=pre.alpha,
-                                   mask_sum=pre.bsum, res_pooled=res_pooled, res_scale=res_scale)
+                mbits, pre.bits = pre.bits, None
+                if mbits is not None and (s_out is not None and not g_scaled):
+                    mbits = None                      # (not a case the networks produce: a scaled consumer of an un-modulated producer)
+                try:
+                    t = conv2d_fwd_raw(g, prep.wq_ft, in_scale=None if g_scaled else s_out, prepared=True, gain=pg,
+                                       mask_y=x if mbits is None else None, mask_bits=mbits, mask_alpha=pre.alpha,
+                                       mask_sum=pre.bsum, res_pooled=res_pooled, res_scale=res_scale)
+                except _lib.AgfError as exc:          # (no kernel reads the bits for this tiling: the bf16 mask, as before)
+                    if mbits is None or getattr(exc, 'status', 0) != -2:
+                        raise
+                    t = conv2d_fwd_raw(g, prep.wq_ft, in_scale=None if g_scaled else s_out, prepared=True, gain=pg, mask_y=x,
+                                       mask_alpha=pre.alpha, mask_sum=pre.bsum, res_pooled=res_pooled, res_scale=res_scale)
                 if det:
                     pre.bsum = t.sum((0, 2, 3), dtype=torch.float32)[None]
                 pre.premasked = True

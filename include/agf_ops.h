@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define AGF_ABI_VERSION 22
+#define AGF_ABI_VERSION 23
 
 /* element types of activation tensors */
 enum { AGF_F32 = 0, AGF_F16 = 1, AGF_BF16 = 2, AGF_F64 = 3 };
@@ -192,6 +192,28 @@ int agf_conv2d_fwd_mask(const void* x, const void* w, void* y,
                         int act, float alpha, float act_gain,
                         const void* mask_y, float mask_alpha, float* mask_sum,
                         const void* res_pooled, float res_scale, void* stream);
+
+/* The lrelu mask of agf_conv2d_fwd_mask as ONE BIT per element (ABI v23).  The reference's LeakyReluBackward re-reads the activation
+ * (implementations/StyleGAN2/model.py:186-212: nn.LeakyReLU between the two convs of a DBlock); all it needs is the sign.
+ *   agf_conv2d_fwd_bits     = agf_conv2d_fwd that ALSO writes bits_out [N][H][W][Cout/32] dwords: bit 8g + e of dword k = (y[n,h,w,32k+8g+e] > 0),
+ *                             tested on the stored (bf16-rounded) value -- bit-identical to what agf_conv2d_fwd_mask derives from mask_y = y
+ *   agf_conv2d_fwd_maskbits = agf_conv2d_fwd_mask with mask_bits (that format, for THIS launch's output shape) in place of mask_y
+ *   agf_conv2d_maskbits_covers(N, H, W, Cin, Cout): 1 when a Cin -> Cout producer and its consumer's data gradient both run on kernels that
+ *                             write / read the bits at full speed
+ * bf16, 3x3, Cout % 32 == 0, y 16-byte aligned; AGF_ENOKERNEL otherwise (callers fall back to agf_conv2d_fwd / agf_conv2d_fwd_mask). */
+int agf_conv2d_fwd_bits(const void* x, const void* w, void* y, void* bits_out,
+                        const float* in_scale, const float* out_scale, const float* bias,
+                        const float* noise, const void* residual,
+                        int dtype, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
+                        int act, float alpha, float act_gain, void* stream);
+int agf_conv2d_fwd_maskbits(const void* x, const void* w, void* y,
+                            const float* in_scale, const float* out_scale, const float* bias,
+                            const float* noise, const void* residual,
+                            int dtype, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
+                            int act, float alpha, float act_gain,
+                            const void* mask_bits, float mask_alpha, float* mask_sum,
+                            const void* res_pooled, float res_scale, void* stream);
+int agf_conv2d_maskbits_covers(int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout);
 
 /* The stride-2 3x3 convolution of the StyleGAN3 discriminator's downsampling blocks (thirdparty/stylegan3_ops/ops/conv2d_resample.py:100-103:
  * `_conv2d_wrapper(x, w, stride=down)` after the FIR; implementations/StyleGAN3/model.py:410-417) and its data gradient, evaluated on the

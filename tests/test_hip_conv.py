@@ -736,3 +736,83 @@ def test_pool2x2_and_sign_mask_vs_torch(shape, dtype):
     g2, b2 = C.act_bwd_reduce_pooled_mask_raw(dyh, mask, x, 0.2, 0.25 * 0.7071, True)
     assert torch.equal(g1, g2)
     assert (b1 - b2).abs().max().item() <= 1e-5 * b1.abs().max().item()
+
+
+def _bits_reference(y):
+    """[N,C,H,W] channels-last bf16 -> int32 [N,H,W,C/32] in the agf_conv2d_fwd_bits format (bit 8g + e of word k = channel 32k + 8g + e > 0)."""
+    N, C, H, W = y.shape
+    pos = (y.float() > 0).permute(0, 2, 3, 1).reshape(N, H, W, C // 32, 32).to(torch.int64)
+    word = (pos << torch.arange(32, device=y.device)).sum(-1)
+    return torch.where(word >= 2 ** 31, word - 2 ** 32, word).to(torch.int32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('N,Cin,Cout,H,W', [
+    (8, 32, 64, 256, 256),      # producer on the streaming kernel, 64-channel tile (weights resident)
+    (16, 64, 128, 128, 128),    # the 128-channel split of the streaming kernel: two launches, each its two words of a pixel's four
+    (4, 128, 256, 64, 64),      # the 8-wave direct-to-LDS kernel
+    (16, 64, 32, 128, 128),     # 32-channel tile: words leave in pixel pairs
+    (16, 512, 512, 16, 16),     # 64 co x 256 px generic tile (MT = 1, NJ = 4)
+    (32, 512, 512, 8, 8),       # 64-pixel tiles (NJ = 1)
+    (4, 128, 96, 40, 56),       # ragged map, Cout = 3 words
+])
+def test_sign_bits_of_the_forward_launch_and_the_masked_data_gradient_equal_the_bf16_mask_path(N, Cin, Cout, H, W):
+    """agf_conv2d_fwd_bits writes exactly the signs of the y it stores (and the same y as agf_conv2d_fwd); agf_conv2d_fwd_maskbits on those
+    bits equals agf_conv2d_fwd_mask on y itself -- output bit for bit, channel sums to fp32 summation order -- with and without the pooled
+    residual, on every kernel family that serves the discriminator's hand-offs."""
+    from animeface_amd.implementations.StyleGAN2 import conv as C
+    torch.manual_seed(N + Cin + H)
+    x = torch.randn(N, Cin, H, W, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(Cout, Cin, 3, 3, device=DEV) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, device=DEV) * 0.1
+    wq = C.prep_weights_raw(w, 1.0, torch.bfloat16)[0]
+    bits = C.mask_bits_like(N, Cout, H, W, DEV)
+    bits.fill_(0x5a5a5a5a)
+    y0 = C.conv2d_fwd_raw(x, wq, bias=b, act=C.ACT_LRELU, prepared=True)
+    y1 = C.conv2d_fwd_raw(x, wq, bias=b, act=C.ACT_LRELU, prepared=True, bits_out=bits)
+    assert torch.equal(y0, y1)
+    assert torch.equal(bits, _bits_reference(y1))
+    # the consumer: data gradient of a (Cout -> C2) conv, i.e. a C2 -> Cout launch whose output is masked by y1
+    C2 = Cout if Cout >= 64 else 64
+    g = torch.randn(N, C2, H, W, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w2 = torch.randn(Cout, C2, 3, 3, device=DEV) / (C2 * 9) ** 0.5
+    w2q = C.prep_weights_raw(w2, 1.0, torch.bfloat16)[0]
+    for pooled in ((False, True) if (H % 2 == 0 and W % 2 == 0) else (False,)):
+        rp = torch.randn(N, Cout, H // 2, W // 2, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last) if pooled else None
+        s0, s1 = torch.zeros(256, Cout, device=DEV), torch.zeros(256, Cout, device=DEV)
+        t0 = C.conv2d_fwd_raw(g, w2q, prepared=True, mask_y=y1, mask_alpha=0.2, mask_sum=s0, res_pooled=rp, res_scale=0.25)
+        t1 = C.conv2d_fwd_raw(g, w2q, prepared=True, mask_bits=bits, mask_alpha=0.2, mask_sum=s1, res_pooled=rp, res_scale=0.25)
+        assert torch.equal(t0, t1), (pooled, rel(t0, t1))
+        assert rel(s0.sum(0), s1.sum(0)) < 1e-5
+
+
+@pytest.mark.gpu
+def test_dblock_backward_with_the_mask_as_bits_is_bit_identical(monkeypatch):
+    """conv.MASK_BITS: the DBlock's hand-off (conv1's lrelu mask applied inside conv2's data-gradient launch) with the mask travelling as
+    bits against the same block reading the bf16 activation: identical outputs and gradients (the bits are the signs of the stored values)."""
+    from animeface_amd.implementations.StyleGAN2 import model as M, conv as C
+    torch.manual_seed(3)
+    for cin, cout, size in ((32, 64, 64), (128, 256, 64)):
+        blk = M.DBlock(cin, cout).to(DEV)
+        blk.apply(M.init_weight_N01)
+        x0 = torch.randn(8, cin, size, size, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        gy = torch.randn(8, cout, size // 2, size // 2, device=DEV).to(torch.bfloat16)
+        outs, used = [], []
+        orig = C.conv2d_fwd_raw
+
+        def spy(*a, **k):
+            used.append(k.get('mask_bits') is not None)
+            return orig(*a, **k)
+        monkeypatch.setattr(C, 'conv2d_fwd_raw', spy)
+        for on in (True, False):
+            monkeypatch.setattr(C, 'MASK_BITS', on)
+            del used[:]
+            x = x0.clone().requires_grad_(True)
+            y = blk(x)
+            grads = torch.autograd.grad(y, [x] + list(blk.parameters()), gy)
+            outs.append((y, grads))
+            assert any(used) == on
+        monkeypatch.setattr(C, 'conv2d_fwd_raw', orig)
+        assert torch.equal(outs[0][0], outs[1][0])
+        for a, b in zip(outs[0][1], outs[1][1]):
+            assert rel(a, b) < 1e-5, (a.shape, rel(a, b))      # (bias sums: fp32 atomics in another order)
