@@ -854,9 +854,6 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_dl_kernel(ConvPa
     issue(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-#ifdef AGF_DL_PRIO
-    if (wave >= NTHR / 128) __builtin_amdgcn_s_setprio(1);           // the later-dispatched half loses every VALU arbitration otherwise (MI355X_MICROARCH.md)
-#endif
     for (int ch = 0; ch < nChunks; ch++) {
         const int cur = ch & 1;
         const bool more = ch + 1 < nChunks;
@@ -887,10 +884,7 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_dl_kernel(ConvPa
                     // the next chunk's DMA pieces go out BETWEEN the taps' MFMA groups (one or two per tap over the first TAPS - 1 taps; the last
                     // tap covers the youngest pieces' flight): issued in one burst at the top of the chunk they cost every wave ~1 000 cycles in
                     // lock step, during which the matrix pipe idles (+6-11 % on the >= 128-channel layers, tools/ab_dl.sh)
-#ifndef AGF_DL_T1
-#define AGF_DL_T1 (TAPS - 1)
-#endif
-                    constexpr int T1 = TAPS > 1 ? (AGF_DL_T1) : 1;
+                    constexpr int T1 = TAPS > 1 ? TAPS - 1 : 1;
                     if (tap < T1) issue_range((ch + 1) * KC, cur ^ 1, tap * NP / T1, (tap + 1) * NP / T1);
                 }
             }
@@ -1851,6 +1845,9 @@ static int launch_fwd(const ConvParams& p, hipStream_t st) {
         else                             rc = p.in_scale ? launch_fwd_ws<3, true, 64, 32>(p, st) : launch_fwd_ws<3, false, 64, 32>(p, st);
         if (rc != AGF_ENOKERNEL) return rc;
     }
+    if (KS == 3 && MT == 1 && p.narrow) {
+        return p.in_scale ? launch_fwd_v<KS, 1, true, 32, 4, 576, 1, 2, 2>(p, st) : launch_fwd_v<KS, 1, false, 32, 4, 576, 1, 2, 2>(p, st);
+    }
     constexpr int w64b = 0;
     if (w64b && KS == 3 && MT == 1 && !p.flat && p.TI == 1 && p.TW == 32 && p.TH == 8 && p.Cout > 32 && p.Cout <= 64 && p.Cin >= 32)
         return p.in_scale ? launch_fwd_v<KS, 2, true, 16, 4, 340, 1, 2, 3>(p, st) : launch_fwd_v<KS, 2, false, 16, 4, 340, 1, 2, 3>(p, st);
@@ -1980,7 +1977,17 @@ static int conv2d_fwd_impl(const void* x, const void* w, void* y,
     constexpr bool small_on = true;
     const bool smallTile = small_on && MT == 1 && ksize == 3 && H * W <= 64 && H >= 4 && W >= 4 && (int64_t)N * H * W >= 256 &&
                            (int64_t)N * H * W <= (in_scale ? 8192 : 4096);      // measured: beyond that the 256-pixel tiles fill the chip
-    if (smallTile) blockPix = 64;
+#ifndef AGF_SMALL_MODE
+#define AGF_SMALL_MODE 0
+#endif
+    // narrow tile (probe): 32 co x 256 px (4 waves along the pixels) instead of 64 co x 64 px for the 8x8 (and 4x4) maps: a quarter of the
+    // weight traffic per pixel out of L2, 4x the matrix work per chunk to cover the loads
+    bool narrow = false;
+    const bool narrowOK = !mask_y && !mask_bits && !bits_out && !res_pooled && !pool_mask;      // (the 64 co tilings keep those epilogues)
+    if (AGF_SMALL_MODE >= 1 && narrowOK && smallTile && H * W == 64 && (int64_t)N * H * W >= 2048) narrow = true;
+    if (AGF_SMALL_MODE >= 2 && narrowOK && smallTile && H * W == 16 && (int64_t)N * H * W >= 1024) narrow = true;
+    if (smallTile && !narrow) blockPix = 64;
+    p.narrow = narrow ? 1 : 0;
     p.TW = pow2_ceil(W) < 32 ? pow2_ceil(W) : 32;
     int th = pow2_ceil(H);
     p.TH = th < blockPix / p.TW ? th : blockPix / p.TW;

@@ -68,6 +68,7 @@ struct ConvParams {
     int flat, flatTiles;      // flat tiling: a tile = 256 consecutive pixels (row-major) of one image; flatTiles = tiles per image
     uint32_t mW;              // magic multiplier for division by W (flat tiling)
     int xcdBand;              // pixel tiles per XCD (contiguous bands), 0 = interleaved
+    int narrow;               // 32 co x 256 px tiling of the small maps (launch_fwd)
     int yMul, yOffH, yOffW, yH, yW;   // conv_epilogue: strided store into a [N, yH, yW, Cout] tensor (yMul = 0: the ordinary [N, H, W, Cout])
 };
 

@@ -180,7 +180,11 @@ template <class T> struct RawUnpack<T, 8> {
     }
 };
 
-template <class T, int VEC, int UP, int DN, int FW, int FH, int ROWS, int K00, int PD = 2, bool CHS = false>
+// STRIPS > 1: a lane marches over STRIPS consecutive strips and KEEPS the last OV = TMAX - ROWS * DN / UP input rows of a strip (packed, in
+// registers) for the next one, which needs exactly those rows again: a strip then loads only its ROWS * DN / UP new rows.  With one strip
+// per lane the [1,2,1] blur fetched 653 MB for 512 MB of input and the 4 x 4 decimation 651 MB (10 input rows per 8 new ones:
+// profiles/r04b_upfirdn_hbm_pmc.txt) -- at 6.0-6.4 TB/s of HBM traffic, i.e. at what the memory system delivers, the re-read WAS the gap.
+template <class T, int VEC, int UP, int DN, int FW, int FH, int ROWS, int K00, int PD = 2, bool CHS = false, int STRIPS = 1>
 __global__ void __launch_bounds__(256, ROWS_WAVES) upfirdn2d_nhwc_rows(UpfirdnParams p) {
     // K00 = (floor(mid0/UP)+1)*UP - mid0 - 1 for the strip's first row: identical for every strip because ROWS*DN is a
     // multiple of UP, so the host passes it as a template argument and every (input row t, output row r) tap index
@@ -194,7 +198,9 @@ __global__ void __launch_bounds__(256, ROWS_WAVES) upfirdn2d_nhwc_rows(UpfirdnPa
     const int ox = (p.cg_shift >= 0) ? (idx >> p.cg_shift) : (idx / CG);
     const int cg = idx - ox * CG;
     const int n = blockIdx.z;
-    const int oy0 = blockIdx.y * ROWS;
+    constexpr int NEW = ROWS * DN / UP;                                    // input rows a strip adds to the previous strip's
+    constexpr int OV = STRIPS > 1 ? TMAX - NEW : 0;                        // rows two consecutive strips share
+    static_assert(STRIPS == 1 || (OV >= 0 && OV <= NEW), "carried rows must all come from the strip's own loads");
     const int midx = ox * DN + UP - 1 - p.padx0;
     const int inx0 = agf_floor_div(midx, UP);
     // (UP == 1: the column phase is 0 for every lane -- said explicitly, the filter taps below are then wave-uniform and live in
@@ -221,6 +227,13 @@ __global__ void __launch_bounds__(256, ROWS_WAVES) upfirdn2d_nhwc_rows(UpfirdnPa
             coef[ky][jx] = c * p.gain;
         }
     }
+    char* ybn = (char*)p.y + (int64_t)n * p.OH * ((int64_t)p.OW * p.C) * (int64_t)sizeof(T);
+    const unsigned yo = (unsigned)(ox * p.C + cg * VEC) * (unsigned)sizeof(T);
+    u32x4 keep[OV > 0 ? OV : 1][NTX];                                      // rows [TMAX - OV, TMAX) of the previous strip = rows [0, OV) of this one
+#pragma unroll 1
+    for (int strip = 0; strip < STRIPS; strip++) {
+    const int oy0 = (blockIdx.y * STRIPS + strip) * ROWS;
+    if (STRIPS > 1 && oy0 >= p.OH) break;                                  // block-uniform
     float acc[ROWS][VEC];
 #pragma unroll
     for (int r = 0; r < ROWS; r++)
@@ -244,17 +257,24 @@ __global__ void __launch_bounds__(256, ROWS_WAVES) upfirdn2d_nhwc_rows(UpfirdnPa
             dst[jx] = v;
         }
     };
+    if (OV > 0 && strip == 0) {
 #pragma unroll
-    for (int t = 0; t < PD - 1; t++) if (t < TMAX) load_row(t, raw[t]);
+        for (int t = 0; t < OV; t++) load_row(t, keep[t]);                 // the first strip of a lane has no predecessor to inherit from
+    }
+    // rows [0, OV) come from `keep`, rows [OV, TMAX) through the pipeline (slot (t - OV) % PD)
+#pragma unroll
+    for (int t = OV; t < OV + PD - 1; t++) if (t < TMAX) load_row(t, raw[(t - OV) % PD]);
 #pragma unroll
     for (int t = 0; t < TMAX; t++) {
-        if (t + PD - 1 < TMAX) load_row(t + PD - 1, raw[(t + PD - 1) % PD]);
+        if (t >= OV && t + PD - 1 < TMAX) load_row(t + PD - 1, raw[(t + PD - 1 - OV) % PD]);
         asm volatile("" ::: "memory");
         // one input vector at a time: unpacked (VEC floats live, not NTX * VEC) and added to every output row of the strip it reaches
 #pragma unroll
         for (int jx = 0; jx < NTX; jx++) {
             float xv[VEC];
-            RawUnpack<T, VEC>::run(raw[t % PD][jx], xv);
+            const u32x4 rv = t < OV ? keep[t < OV ? t : 0][jx] : raw[(t - OV) % PD][jx];
+            if (OV > 0 && t >= TMAX - OV) keep[t - (TMAX - OV)][jx] = rv;  // (t >= OV here: the slot was consumed at the top of this strip)
+            RawUnpack<T, VEC>::run(rv, xv);
 #pragma unroll
             for (int r = 0; r < ROWS; r++) {
                 const int ky = t * UP + K00 - r * DN;                      // compile-time after unrolling
@@ -287,16 +307,15 @@ __global__ void __launch_bounds__(256, ROWS_WAVES) upfirdn2d_nhwc_rows(UpfirdnPa
             for (int r = 0; r < ROWS; r++) acc[r][i] *= s;
         }
     }
-    char* ybn = (char*)p.y + (int64_t)n * p.OH * ((int64_t)p.OW * p.C) * (int64_t)sizeof(T);
-    const unsigned yo = (unsigned)(ox * p.C + cg * VEC) * (unsigned)sizeof(T);
 #pragma unroll
     for (int r = 0; r < ROWS; r++) {
         const int oy = oy0 + r;
         if (oy < p.OH) VecIO<T, VEC>::store((T*)(ybn + (int64_t)oy * p.OW * p.C * (int64_t)sizeof(T) + yo), acc[r]);
     }
+    }   // strip
 }
 
-template <class T, int VEC, int UP, int DN, int FW, int FH, int ROWS, int PD = 2>
+template <class T, int VEC, int UP, int DN, int FW, int FH, int ROWS, int PD = 2, int STRIPS = 1>
 static bool launch_rows(const UpfirdnParams& p, dim3 g, hipStream_t st) {
     // mid0 mod UP is strip-invariant (ROWS*DN % UP == 0)
     const int mid0 = UP - 1 - p.pady0;
@@ -312,8 +331,8 @@ static bool launch_rows(const UpfirdnParams& p, dim3 g, hipStream_t st) {
             return false;
         }
     }
-    if (UP == 1 || k00 == 0) hipLaunchKernelGGL((upfirdn2d_nhwc_rows<T, VEC, UP, DN, FW, FH, ROWS, 0, PD>), g, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((upfirdn2d_nhwc_rows<T, VEC, UP, DN, FW, FH, ROWS, (UP > 1 ? 1 : 0), PD>), g, dim3(256), 0, st, p);
+    if (UP == 1 || k00 == 0) hipLaunchKernelGGL((upfirdn2d_nhwc_rows<T, VEC, UP, DN, FW, FH, ROWS, 0, PD, false, STRIPS>), g, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((upfirdn2d_nhwc_rows<T, VEC, UP, DN, FW, FH, ROWS, (UP > 1 ? 1 : 0), PD, false, STRIPS>), g, dim3(256), 0, st, p);
     return true;
 }
 
@@ -704,20 +723,27 @@ static bool launch_nhwc(const UpfirdnParams& p, hipStream_t st) {
     for (int sft = 0; sft < 31; sft++) if ((1 << sft) == CG) q.cg_shift = sft;
     dim3 g((unsigned)agf_ceil_div((int64_t)p.OW * CG, 256), (unsigned)p.OH, (unsigned)p.N), b(256);
     const UpfirdnParams& pp = q;
-#define NHWC_CASE(ux, uy, dx, dy, w, h, rows)                                                             \
+    // strips: consecutive strips per lane with the shared input rows carried in registers (the kernel's STRIPS) -- used when the launch
+    // still has >= 4 workgroups per CU of work left (small maps keep one strip per lane: more lanes)
+#define NHWC_CASE(ux, uy, dx, dy, w, h, rows, strips)                                                     \
     if (p.upx == ux && p.upy == uy && p.downx == dx && p.downy == dy && p.fw == w && p.fh == h && ux == uy && dx == dy && w == h) { \
         constexpr int ROWS = rows;                                                                        \
+        const int64_t wgs = agf_ceil_div((int64_t)p.OW * CG, 256) * agf_ceil_div(p.OH, ROWS * strips) * p.N;   \
+        if (strips > 1 && !p.chscale && wgs >= 1024) {                                                    \
+            dim3 gs((unsigned)agf_ceil_div((int64_t)p.OW * CG, 256), (unsigned)agf_ceil_div(p.OH, ROWS * strips), (unsigned)p.N);   \
+            return launch_rows<T, VEC, ux, dx, w, h, ROWS, 2, strips>(pp, gs, st);                        \
+        }                                                                                                 \
         dim3 gr((unsigned)agf_ceil_div((int64_t)p.OW * CG, 256), (unsigned)agf_ceil_div(p.OH, ROWS), (unsigned)p.N);   \
         return launch_rows<T, VEC, ux, dx, w, h, ROWS>(pp, gr, st);                                       \
     }
-    NHWC_CASE(2, 2, 1, 1, 4, 4, 8)   // bilinear-equivalent 2x upsample  (StyleGAN2 Upsample2x, ToImage)
-    NHWC_CASE(1, 1, 1, 1, 3, 3, 8)   // Blur2d
-    NHWC_CASE(1, 1, 2, 2, 2, 2, 4)   // AvgPool2d(2)
-    NHWC_CASE(1, 1, 2, 2, 4, 4, 4)   // adjoint of the 2x upsample; StyleGAN3-D downsample
-    NHWC_CASE(2, 2, 1, 1, 2, 2, 8)   // adjoint of AvgPool2d(2)
-    NHWC_CASE(1, 1, 1, 1, 4, 4, 4)   // StyleGAN3-D filter2d before the strided conv
-    NHWC_CASE(2, 2, 1, 1, 6, 6, 8)   // fused Upsample2x -> Blur2d of the StyleGAN2 generator (composite [1,5,10,10,5,1] filter)
-    NHWC_CASE(1, 1, 2, 2, 6, 6, 4)   // its adjoint
+    NHWC_CASE(2, 2, 1, 1, 4, 4, 8, 1)   // bilinear-equivalent 2x upsample  (StyleGAN2 Upsample2x, ToImage)
+    NHWC_CASE(1, 1, 1, 1, 3, 3, 8, 4)   // Blur2d
+    NHWC_CASE(1, 1, 2, 2, 2, 2, 4, 1)   // AvgPool2d(2)
+    NHWC_CASE(1, 1, 2, 2, 4, 4, 4, 4)   // adjoint of the 2x upsample; StyleGAN3-D downsample
+    NHWC_CASE(2, 2, 1, 1, 2, 2, 8, 1)   // adjoint of AvgPool2d(2)
+    NHWC_CASE(1, 1, 1, 1, 4, 4, 4, 1)   // StyleGAN3-D filter2d before the strided conv
+    NHWC_CASE(2, 2, 1, 1, 6, 6, 8, 1)   // fused Upsample2x -> Blur2d of the StyleGAN2 generator (composite [1,5,10,10,5,1] filter)
+    NHWC_CASE(1, 1, 2, 2, 6, 6, 4, 1)   // its adjoint (4 shared rows per strip: carrying them spills)
 #undef NHWC_CASE
     if (p.chscale) return false;                      // only the row-marching specialisations carry the channel scale
     hipLaunchKernelGGL((upfirdn2d_nhwc_vec<T, VEC, 0, 0, 0, 0, 0, 0>), g, b, 0, st, pp);
