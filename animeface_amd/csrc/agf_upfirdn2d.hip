@@ -180,10 +180,12 @@ template <class T> struct RawUnpack<T, 8> {
     }
 };
 
-// STRIPS > 1: a lane marches over STRIPS consecutive strips and KEEPS the last OV = TMAX - ROWS * DN / UP input rows of a strip (packed, in
-// registers) for the next one, which needs exactly those rows again: a strip then loads only its ROWS * DN / UP new rows.  With one strip
-// per lane the [1,2,1] blur fetched 653 MB for 512 MB of input and the 4 x 4 decimation 651 MB (10 input rows per 8 new ones:
-// profiles/r04b_upfirdn_hbm_pmc.txt) -- at 6.0-6.4 TB/s of HBM traffic, i.e. at what the memory system delivers, the re-read WAS the gap.
+// STRIPS > 1 (built for VERDICT r4 item 7, NOT used: NHWC_STRIPS = 1): a lane marches over STRIPS consecutive strips and KEEPS the last
+// OV = TMAX - ROWS * DN / UP input rows of a strip (packed, in registers) for the next one, which needs exactly those rows again: a strip
+// then loads only its ROWS * DN / UP new rows.  With one strip per lane the [1,2,1] blur fetches 653 MB for 512 MB of input and the 4 x 4
+// decimation 651 MB (10 input rows per 8 new ones); with four strips 572 / 554 MB (PMC) -- and the launches take 221 instead of 204 us and
+// 135 instead of 128: a quarter of the lanes, each a serial load -> FMA -> store chain per strip, keep fewer loads in flight than the
+// re-read costs.  The kernels move 6.0-6.4 TB/s with one strip per lane, which is what this memory system delivers to any kernel.
 template <class T, int VEC, int UP, int DN, int FW, int FH, int ROWS, int K00, int PD = 2, bool CHS = false, int STRIPS = 1>
 __global__ void __launch_bounds__(256, ROWS_WAVES) upfirdn2d_nhwc_rows(UpfirdnParams p) {
     // K00 = (floor(mid0/UP)+1)*UP - mid0 - 1 for the strip's first row: identical for every strip because ROWS*DN is a
@@ -725,21 +727,27 @@ static bool launch_nhwc(const UpfirdnParams& p, hipStream_t st) {
     const UpfirdnParams& pp = q;
     // strips: consecutive strips per lane with the shared input rows carried in registers (the kernel's STRIPS) -- used when the launch
     // still has >= 4 workgroups per CU of work left (small maps keep one strip per lane: more lanes)
+#ifndef NHWC_STRIPS
+#define NHWC_STRIPS 1      // measured (profiles/r05_upfirdn_strips.txt): 2 / 4 strips per lane cut the fetched bytes as designed and run 5-10 % SLOWER
+#endif
+#ifndef NHWC_STRIP_PD
+#define NHWC_STRIP_PD 2
+#endif
 #define NHWC_CASE(ux, uy, dx, dy, w, h, rows, strips)                                                     \
     if (p.upx == ux && p.upy == uy && p.downx == dx && p.downy == dy && p.fw == w && p.fh == h && ux == uy && dx == dy && w == h) { \
         constexpr int ROWS = rows;                                                                        \
         const int64_t wgs = agf_ceil_div((int64_t)p.OW * CG, 256) * agf_ceil_div(p.OH, ROWS * strips) * p.N;   \
         if (strips > 1 && !p.chscale && wgs >= 1024) {                                                    \
             dim3 gs((unsigned)agf_ceil_div((int64_t)p.OW * CG, 256), (unsigned)agf_ceil_div(p.OH, ROWS * strips), (unsigned)p.N);   \
-            return launch_rows<T, VEC, ux, dx, w, h, ROWS, 2, strips>(pp, gs, st);                        \
+            return launch_rows<T, VEC, ux, dx, w, h, ROWS, NHWC_STRIP_PD, strips>(pp, gs, st);            \
         }                                                                                                 \
         dim3 gr((unsigned)agf_ceil_div((int64_t)p.OW * CG, 256), (unsigned)agf_ceil_div(p.OH, ROWS), (unsigned)p.N);   \
         return launch_rows<T, VEC, ux, dx, w, h, ROWS>(pp, gr, st);                                       \
     }
     NHWC_CASE(2, 2, 1, 1, 4, 4, 8, 1)   // bilinear-equivalent 2x upsample  (StyleGAN2 Upsample2x, ToImage)
-    NHWC_CASE(1, 1, 1, 1, 3, 3, 8, 4)   // Blur2d
+    NHWC_CASE(1, 1, 1, 1, 3, 3, 8, NHWC_STRIPS)   // Blur2d
     NHWC_CASE(1, 1, 2, 2, 2, 2, 4, 1)   // AvgPool2d(2)
-    NHWC_CASE(1, 1, 2, 2, 4, 4, 4, 4)   // adjoint of the 2x upsample; StyleGAN3-D downsample
+    NHWC_CASE(1, 1, 2, 2, 4, 4, 4, NHWC_STRIPS)   // adjoint of the 2x upsample; StyleGAN3-D downsample
     NHWC_CASE(2, 2, 1, 1, 2, 2, 8, 1)   // adjoint of AvgPool2d(2)
     NHWC_CASE(1, 1, 1, 1, 4, 4, 4, 1)   // StyleGAN3-D filter2d before the strided conv
     NHWC_CASE(2, 2, 1, 1, 6, 6, 8, 1)   // fused Upsample2x -> Blur2d of the StyleGAN2 generator (composite [1,5,10,10,5,1] filter)

@@ -7,6 +7,11 @@ import sys
 import os
 
 import torch
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
+from animeface_amd import _lib as _agf_lib
+if _os.environ.get('AGF_PROBE_LIB'):
+    _agf_lib.LIB_PATH = _os.path.join(_os.path.dirname(_agf_lib.LIB_PATH), 'libagf_ops_%s.so' % _os.environ['AGF_PROBE_LIB'])
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from animeface_amd.stylegan3_ops import upfirdn2d as U, bias_act as B  # noqa: E402
