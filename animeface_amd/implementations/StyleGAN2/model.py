@@ -36,10 +36,11 @@ from . import conv as conv_mod
 # no double backward, so the generator falls back to the separately differentiable ops when ``fused_epilogue=False``
 # (needed only for the path-length penalty, pl_lambda > 0).
 FUSED_EPILOGUE = True
-UPBLUR_PRESCALE = False   # the first modulated conv's style scale in the fused upsample + blur pass (agf_upfirdn2d_chscale), so that this conv too
-#                           runs on the unscaled direct-to-LDS kernel.  Built, tested, OFF: with it the conv family is faster in isolation and EVERY
-#                           pace candidate (0..5 nodes) replays in the high-power regime: 35.6 ms at 2 150-2 176 MHz / 1 175-1 192 W against
-#                           32.3 ms at 2 376 MHz / 952-990 W without (profiles/r04b_upblur_prescale_power.txt) -- the step sits at the package-power limit
+UPBLUR_PRESCALE = True    # the first modulated conv's style scale in the fused upsample + blur pass (agf_upfirdn2d_chscale), so that this conv too
+#                           runs on the unscaled direct-to-LDS kernel.  Round 4 left it OFF: every pace candidate then replayed in the high-power
+#                           regime (35.6 against 32.3 ms, profiles/r04b_upblur_prescale_power.txt).  Round 5, after the 1-bit masks: two of four
+#                           candidates stay at the full clock and the step is 31.8 against 32.3 ms (profiles/r05_switches.txt): ON
+UPBLUR_PRESCALE_MIN_CIN = 64    # ... for first convs with at least this many input channels (64: 31.6 ms, 128: 31.8 ms, same file)
 MAP_FUSED = False         # mapping network: one launch per layer (agf_map_layer_*) instead of addmm + leaky_relu_.  OFF: 72 fewer launches per
 #                           iteration, and the replayed iteration is 1.1 ms SLOWER -- with it every pace candidate settles in a medium power
 #                           state (34.8 ms) instead of the good one (33.7 ms), profiles/r04_power_state.txt; tests compare the two paths
@@ -258,7 +259,7 @@ class StyleBlock(nn.Module):
             # the first modulated conv is this tensor's only consumer: with >= 128 input channels (where that conv is bound by the matrix
             # pipe) its style scale rides in the up-sampling pass and the conv reads an unscaled operand (conv.POSTSCALE_X)
             first = mods[2] if len(mods) > 4 and isinstance(mods[2], ModulatedConv2d) and isinstance(mods[3], InjectNoise) else None
-            pre_up = first is not None and UPBLUR_PRESCALE and conv_mod.POSTSCALE_X and x.dtype == torch.bfloat16 and first.weight.shape[1] >= 128 \
+            pre_up = first is not None and UPBLUR_PRESCALE and conv_mod.POSTSCALE_X and x.dtype == torch.bfloat16 and first.weight.shape[1] >= UPBLUR_PRESCALE_MIN_CIN \
                 and first.weight.shape[1] % 8 == 0
             ahead0 = first.scales(y) if pre_up else None
             x = up_blur(x, self._f6, ahead0[0] if pre_up else None)

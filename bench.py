@@ -183,7 +183,7 @@ def main():
     ap.add_argument('--pace', default='auto', help="memset nodes at the head of the recorded iteration: an integer, or 'auto' = calibrate 0..3 by timing replays (GraphedTrainStep.calibrate)")
     ap.add_argument('--ada-p', type=float, default=None, help="with --augment ada: start the pipe's probability here instead of 0 (at 0 every augmentation is gated off and the reflect margins are minimal)")
     ap.add_argument('--deterministic', action='store_true', help='agf_set_deterministic(1): one writer per output element instead of cross-workgroup fp32 atomics (bit-reproducible, slower)')
-    ap.add_argument('--ab', default='', help='comma-separated A/B switches for same-box comparisons: no-torgb, mapfuse / no-mapfuse, upscale (model.UPBLUR_PRESCALE), noskiplink (conv.SKIP_SUM_LINK off), candN (N pace candidates)')
+    ap.add_argument('--ab', default='', help='comma-separated A/B switches for same-box comparisons: no-torgb, mapfuse / no-mapfuse, upscale / no-upscale / upscale64 / upscale128 (model.UPBLUR_PRESCALE, .._MIN_CIN), noskiplink (conv.SKIP_SUM_LINK off), candN (N pace candidates)')
     ap.add_argument('--dp-bucket-mib', type=int, default=32, help='bucket size of the gradient all-reduce (GradReducer bucket_bytes), for A/B runs')
     ap.add_argument('--dp-mode', default='segmented', choices=['ingraph', 'segmented'],
                     help='several ranks under graph replay: segmented (default, also the library default) = four graphs per iteration cut at '
@@ -221,6 +221,12 @@ def main():
         M.MAP_FUSED = True
     if 'upscale' in ab:
         M.UPBLUR_PRESCALE = True
+    if 'no-upscale' in ab:
+        M.UPBLUR_PRESCALE = False
+    if 'upscale64' in ab:
+        M.UPBLUR_PRESCALE, M.UPBLUR_PRESCALE_MIN_CIN = True, 64
+    if 'upscale128' in ab:
+        M.UPBLUR_PRESCALE, M.UPBLUR_PRESCALE_MIN_CIN = True, 128
     if 'noskiplink' in ab:
         from animeface_amd.implementations.StyleGAN2 import conv as _C
         _C.SKIP_SUM_LINK = False

@@ -549,7 +549,8 @@ def test_dblock_linked_backward_matches_unlinked(monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('switch,size,chan', [('PRESCALE_G', 32, 32), ('POSTSCALE_X', 32, 32), ('POSTSCALE_X', 64, 128)])
+@pytest.mark.parametrize('switch,size,chan', [('PRESCALE_G', 32, 32), ('POSTSCALE_X', 32, 32), ('POSTSCALE_X', 64, 128), ('UPBLUR_PRESCALE', 64, 128),
+                                              ('UPBLUR_PRESCALE_64', 64, 64)])
 def test_generator_with_prescaled_operands_matches_the_operand_scaled_launches(monkeypatch, switch, size, chan):
     """conv.PRESCALE_G: the gradient tensor of a modulated layer is stored times its demodulation scale by the pass that produces it
     (agf_act_bwd_reduce / agf_act_bwd_reduce_scaled, g_scale) and the data- / weight-gradient launches then run without that operand
@@ -571,7 +572,13 @@ def test_generator_with_prescaled_operands_matches_the_operand_scaled_launches(m
         return img, torch.autograd.grad(img, params, gy, allow_unused=True)
     outs = []
     for on in (True, False):
-        monkeypatch.setattr(C, switch, on)
+        if switch.startswith('UPBLUR_PRESCALE'):
+            # model.UPBLUR_PRESCALE: the first modulated conv of a block reads an input the fused upsample + blur pass already multiplied by
+            # its style scale (agf_upfirdn2d_chscale); judged like POSTSCALE_X below (another place of rounding)
+            monkeypatch.setattr(M, 'UPBLUR_PRESCALE', on)
+            monkeypatch.setattr(M, 'UPBLUR_PRESCALE_MIN_CIN', 64 if switch.endswith('_64') else 128)
+        else:
+            monkeypatch.setattr(C, switch, on)
         outs.append(run(G))
     if switch == 'PRESCALE_G':
         assert rel(outs[0][0], outs[1][0]) == 0
@@ -601,7 +608,7 @@ def test_generator_with_prescaled_operands_matches_the_operand_scaled_launches(m
         worse += ea > eb
         s_on, s_off, n = s_on + ea, s_off + eb, n + 1
     assert n > 20 and s_on <= 1.25 * s_off + 5e-3 * n, (s_on / n, s_off / n)
-    print(f'POSTSCALE_X {size}/{chan}: image error vs fp32 {e_on:.4f} (on) / {e_off:.4f} (off); mean gradient error {s_on / n:.4f} / {s_off / n:.4f}; '
+    print(f'{switch} {size}/{chan}: image error vs fp32 {e_on:.4f} (on) / {e_off:.4f} (off); mean gradient error {s_on / n:.4f} / {s_off / n:.4f}; '
           f'{worse} of {n} gradients further from fp32 with it on')
 
 
