@@ -419,6 +419,8 @@ struct FlrRbParams {
     int mf;                          // 2-D up filter on the matrix pipe (bf16 x, no bias: the gradient pass): see up2d_mfma in the kernel
     int XPb, TXHb, NRB, NCB;         // its bf16 input tile [TXHb][XPb] (origin: the even column at or left of tix0), 32-row x 8-column blocks
     int sdw;                         // 16-bit y whose rows start on dwords: the two columns of a lane leave as one dword
+    int CB, RB;                      // radial decimation on the matrix pipe (UB): 8-column / 16-row output blocks of a tile
+    int VW;                          // columns the vertical up pass covers (TUW rounded up to 4; = UPC unless UB, whose pitch is wider)
     int skip;                        // profiling builds only (-DAGF_PROFILE_PHASES=<mask>: 1 load, 2 up-FIR, 4 act, 8 down-FIR, 16 filter taps,
                                      // 32 sign staging, 64 sum of y, 128 horizontal / 256 vertical pass of the separable interpolation): phases left out, results wrong
 };
@@ -433,18 +435,23 @@ static __device__ __forceinline__ uint32_t flr_div(uint32_t a, uint32_t magic) {
 static inline uint32_t flr_magic(uint32_t d) { return d <= 1 ? 0u : (uint32_t)(0xFFFFFFFFull / d) + 1u; }
 #define FLR_DIV(a, d, magic) ((d) <= 1 ? (uint32_t)(a) : flr_div((uint32_t)(a), (magic)))
 
-template <class T, int UP, int DOWN, int SU, int SD, int RN, int R4, int NT>
+#define FLR_NFDP 1152                // UB: the 12 x 12 down filter as zero-padded bf16 rows, [12 tap rows][2 alignments][hi, lo][48] (words)
+// UB = 1 (bf16 x / y, separable up filter, radial 12 x 12 down filter: the forward pass of layers 0-11): the activated up-resolution
+// tile is kept in bf16 (half the LDS: taller tiles) and the decimation runs on the matrix pipe, see "4m" below.
+template <class T, int UP, int DOWN, int SU, int SD, int RN, int R4, int NT, int UB>
 __global__ void __launch_bounds__(NT, 4) flr_rb_kernel(FlrRbParams P) {
     constexpr int FU = 6 * UP, FD = 6 * DOWN;
     static_assert(SU == 1 || UP == 2, "2-D up filter: factor 2 only");
     static_assert(SD == 1 || DOWN == 2, "2-D down filter: factor 2 only");
+    static_assert(!UB || (SU == 1 && SD == 2 && std::is_same<T, bf16_t>::value), "bf16 tile + matrix-pipe decimation: bf16, separable up, radial down");
     extern __shared__ __attribute__((aligned(16))) float flr_smem[];
     const FlrParams& p = P.b;
     constexpr int NFU = SU == 1 ? FU : FU * FU, NFD = SD == 1 ? FD : FD * FD;
     float* sFu = flr_smem;
     float* sFd = sFu + NFU;
     uint32_t* sFuP = (uint32_t*)(sFd + NFD);                    // 2-D up filter: the taps again as (bf16 hi | bf16 lo << 16), FLR_NFP words
-    float* base = sFd + NFD + (SU == 2 ? FLR_NFP : 0);
+    uint32_t* sFdP = (uint32_t*)(sFd + NFD);                    // UB: FLR_NFDP words
+    float* base = sFd + NFD + (SU == 2 ? FLR_NFP : 0) + (UB ? FLR_NFDP : 0);
     float* sU = base + P.ofsU;
     float* sX = base + P.ofsX;
     float* sH = base + P.ofsH;
@@ -522,6 +529,7 @@ __global__ void __launch_bounds__(NT, 4) flr_rb_kernel(FlrRbParams P) {
     if (SD == 1) { for (int i = tid; i < FD; i += NT) sFd[i] = p.fd[(p.flip ? i : FD - 1 - i) * p.fds0]; }
     else { for (int i = tid; i < FD * FD; i += NT) { int ky = i / FD, kx = i - ky * FD;
             sFd[i] = p.fd[(p.flip ? ky : FD - 1 - ky) * p.fds0 + (p.flip ? kx : FD - 1 - kx) * p.fds1]; } }
+    if constexpr (UB) { for (int i = tid; i < FLR_NFDP; i += NT) sFdP[i] = 0u; }      // (the padded bf16 tap table: entries follow after the barrier)
     }
 
     // ---- 1. input tile + bias (zero outside the image).  Independent loads in flight per lane: with two workgroups per
@@ -586,6 +594,19 @@ __global__ void __launch_bounds__(NT, 4) flr_rb_kernel(FlrRbParams P) {
         }
     }
     __syncthreads();
+    if constexpr (UB) {
+        // the down filter for the matrix pipe (read in the decimation, three barriers from here): tap row ky as bf16 hi and lo parts (hi + lo
+        // carries 16 mantissa bits), zero-padded -- element i of copy c <-> tap i - 2 c - 14 -- so that a lane reads the eight taps of its
+        // operand column as two aligned 8-byte words (copy 1 serves the even output columns, whose window starts 4 bytes off).  The table
+        // was zeroed before the barrier above; here the 576 tap entries, one per thread
+        uint16_t* zp = (uint16_t*)sFdP;
+        for (int i = tid; i < 12 * 4 * 12; i += NT) {
+            const int e = i % 12, part = (i / 12) & 1, cpy = (i / 24) & 1, ky = i / 48;
+            const float v = sFd[ky * 12 + e];
+            const uint32_t hb = f32_to_bf16_bits(v);
+            zp[((ky * 2 + cpy) * 2 + part) * 48 + e + 2 * cpy + 14] = (uint16_t)(part ? f32_to_bf16_bits(v - bf16_bits_to_f32(hb)) : hb);
+        }
+    }
     const int sxo = (ux0 + p.sofsx) - (((ux0 + p.sofsx) >> 4) << 4);       // sample offset of the tile inside its first sign dword
 
     const float upGain = (float)(UP * UP) * p.gain;
@@ -624,6 +645,15 @@ __global__ void __launch_bounds__(NT, 4) flr_rb_kernel(FlrRbParams P) {
             }
         }
         __syncthreads();
+        if constexpr (UB) {
+            // columns between the vertical pass's width and the pitch: zero (operand columns of the last blocks; a tap of 0 times a NaN is a
+            // NaN).  (Here, not earlier: the input tile shares this memory and the horizontal pass has just finished with it)
+            const int padW = (P.UPC - P.VW) >> 1;
+            for (int i = tid; i < p.TUH * padW; i += NT) {
+                const int r = i / padW, w = i - r * padW;
+                ((uint32_t*)sU)[((r * P.UPC + P.VW) >> 1) + w] = 0u;
+            }
+        }
         // ---- 3. vertical up-FIR + activation: columns (rux, rux + 1) (v = rux + dx), rows vy = RV s .. RV s + RV - 1 -> sU[vy - dy][rux].
         //      The up-resolution values are in registers here, so gain / leaky ReLU / clamp and the sign bits are applied before
         //      the store: no separate pass over sU.  This pass is VALU-issue-bound (PMC: VALU busy 100 %), and what it issued was
@@ -639,7 +669,7 @@ __global__ void __launch_bounds__(NT, 4) flr_rb_kernel(FlrRbParams P) {
             const int coreW = (tx == p.tilesX - 1) ? p.TUW : p.TOW * DOWN;
             const int coreH = (ty == p.tilesY - 1) ? p.TUH : p.TOH * DOWN;
             const bool edgeTile = ux0 + p.TUW > p.UW || uy0 + p.TUH > p.UH;
-            const int half = P.UPC >> 1, q4 = P.UPC >> 2;
+            const int half = P.VW >> 1, q4 = P.VW >> 2;
             const int items = (P.skip & (2 | 256)) ? 0 : (P.runsV * 8 / RV) * half;
             const float slope = p.slope, clampv = p.clamp;
             uint8_t* splane = p.s + (int64_t)p.SWB * p.SH * plane64;
@@ -653,7 +683,8 @@ __global__ void __launch_bounds__(NT, 4) flr_rb_kernel(FlrRbParams P) {
                 v2f h[NROW];
 #pragma unroll
                 for (int j = 0; j < NROW; j++) h[j] = (v2f){src[j * P.HP], src[j * P.HP + 1]};
-                const uint32_t rowLimit = colok ? (uint32_t)p.TUH : 0u;     // rows this lane stores: 0 <= ruy < rowLimit
+                const uint32_t rowLimit = (UB || colok) ? (uint32_t)p.TUH : 0u;     // rows this lane stores: 0 <= ruy < rowLimit (UB: columns TUW .. VW - 1
+                //                                                                      are zeroed, the matrix pipe reads them)
                 float* dst = sU + ruy0 * P.UPC + rux;
                 uint32_t codes = 0;                                         // 4 bits per row: (column 0, column 1) x 2 bits
                 const int sgpos = sxo + (colok ? rux : 0) + 16, sgsh = (sgpos & 15) << 1;
@@ -690,7 +721,10 @@ __global__ void __launch_bounds__(NT, 4) flr_rb_kernel(FlrRbParams P) {
                         code = (i0 ? code & (3u << (4 * e)) : 0u) | (i1 ? code & (12u << (4 * e)) : 0u);
                     }
                     codes |= code;
-                    if ((uint32_t)(ruy0 + e) < rowLimit) *(v2f*)(dst + e * P.UPC) = v;
+                    if ((uint32_t)(ruy0 + e) < rowLimit) {
+                        if constexpr (UB) ((uint32_t*)sU)[((ruy0 + e) * P.UPC + rux) >> 1] = colok ? Pack16<bf16_t>::pack(v.x, v.y) : 0u;   // P.UPC: bf16 pitch
+                        else *(v2f*)(dst + e * P.UPC) = v;
+                    }
                 }
                 if (MODE == 1) {
                     codes = colok ? codes : 0u;                  // padding columns of the tile carry no sample
@@ -991,7 +1025,91 @@ __global__ void __launch_bounds__(NT, 4) flr_rb_kernel(FlrRbParams P) {
 
     T* yb = (T*)p.y + n * p.ys[0] + c * p.ys[1];
     float ysum_local = 0.f;
-    if (SD == 2) {
+    if constexpr (UB) {
+        // ---- 4m. 2-D down-FIR (DOWN == 2, 12x12) on the matrix pipe.  out[oy][ox] = sum_ky sum_kx U[2 oy + ky][2 ox + kx] F[ky][kx].  For a row
+        //      offset a, the product  A_a [16 rows m][32 columns k]  x  B [32 columns k][16],  A_a[m][k] = U[2 (oy_b + m) + a][16 cb + k]  (one
+        //      ds_read_b128 per lane; rows 2 x pitch apart, the pitch is 8 mod 16 elements so that the sixteen lanes the LDS serves together
+        //      hit different banks),  B[k][n] = F[ky(n)][k - 2 (n & 7)]  (banded: eight output columns need 26 <= 32 tile columns), carries
+        //      TWO tap rows: columns n < 8 hold tap row a (the product belongs to output row m), columns n >= 8 tap row a + 2 (the same tile
+        //      rows seen from output row m - 1).  a = 0, 1, 4, 5, 8, 9 covers the twelve tap rows with six operand reads per block; each is
+        //      used twice, for the bf16 HI and LO parts of the taps (hi + lo carries 16 mantissa bits; products and sums are fp32): twelve
+        //      v_mfma_f32_16x16x32_bf16 per block of 15 output rows x 8 columns (row 15 of the operand only feeds row 14's second half).
+        //      out[m][j] = C[m][j] + C[m + 1][8 + j]: a row rotation by 8 lanes, for the accumulator quad boundary one ds_bpermute.
+        //      The twelve B operands are the same for every block: 48 VGPRs per lane, read once per tile from the zero-padded table.
+        //      35 % of the multiplies are on taps: 1.7 cycles of the matrix pipe per output against >= 4.5 of packed fp32 FMAs. ----
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), m = lane & 15, g = lane >> 4;
+        flr_bf16x8 B[12];                                                    // [2 t + part], a_t = 4 (t >> 1) + (t & 1)
+        const int j = m & 7;
+        const bool hiHalf = m >= 8, odd = j & 1;
+        {
+            const int cpy = (j & 1) ^ 1;                                     // even columns: the copy shifted by two elements
+            const u32x2* zp = (const u32x2*)(sFdP + cpy * 48 + ((8 * g - 2 * j + 14 + 2 * cpy) >> 1));
+#pragma unroll
+            for (int t = 0; t < 6; t++) {
+                const int ky = 4 * (t >> 1) + (t & 1);                       // (+ 2 in the lanes n >= 8)
+                const u32x2* zk = zp + (ky + (hiHalf ? 2 : 0)) * 48;
+#pragma unroll
+                for (int part = 0; part < 2; part++) {
+                    const u32x2 w0 = zk[part * 12], w1 = zk[part * 12 + 1];
+                    u32x4 w; w.x = w0.x; w.y = w0.y; w.z = w1.x; w.w = w1.y;
+                    B[2 * t + part] = __builtin_bit_cast(flr_bf16x8, w);
+                }
+            }
+        }
+        const __bf16* sUb = (const __bf16*)sU;
+        const int nblk = (P.skip & 8) ? 0 : P.RB * P.CB;
+        // The operand reads of a block and its MFMAs would alternate in lock step across the sixteen waves of a CU (every wave waits on the LDS
+        // queue, then every wave is on the matrix pipe): the six operand registers are a ring instead -- A[t] is re-loaded three steps after
+        // its use, with row offset a_(t+3) of this block or a_(t-3) of the wave's next block
+        const int laneOfs = (2 * m) * P.UPC + 8 * g;
+        auto blockPtr = [&](int blk) { const int rb = blk / P.CB, cb = blk - rb * P.CB; return sUb + (30 * rb) * P.UPC + 16 * cb + laneOfs; };
+        flr_bf16x8 A[6];
+        if (wave < nblk) {
+            const __bf16* ap = blockPtr(wave);
+#pragma unroll
+            for (int t = 0; t < 3; t++) A[t] = *(const flr_bf16x8*)(ap + (4 * (t >> 1) + (t & 1)) * P.UPC);
+        }
+        for (int blk = wave; blk < nblk; blk += NT / 64) {
+            const int rb = blk / P.CB, cb = blk - rb * P.CB;
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};      // two chains
+            const __bf16* ap = blockPtr(blk);
+            const __bf16* apn = blockPtr(blk + NT / 64 < nblk ? blk + NT / 64 : blk);     // (the last block re-reads itself: harmless)
+#pragma unroll
+            for (int t = 0; t < 6; t++) {
+                if (P.skip & 1024) break;
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[t], B[2 * t], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[t], B[2 * t + 1], acc1, 0, 0, 0);
+                const int tn = t < 3 ? t + 3 : t - 3;
+                A[tn] = *(const flr_bf16x8*)((t < 3 ? ap : apn) + (4 * (tn >> 1) + (tn & 1)) * P.UPC);
+            }
+            // lane (n = m, g) holds column n of operand rows 4 g .. 4 g + 3 (c[0 .. 3]).  Output row r, column j: C[r][j] + C[r + 1][8 + j].
+            // Lanes n < 8 produce rows 4 g and 4 g + 1, lanes n >= 8 rows 4 g + 2 and 4 g - 1 (the latter across the quad boundary)
+            float c[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) c[i] = acc0[i] + acc1[i];
+            const float x1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(c[1]), 0x128, 0xF, 0xF, true));    // row_ror:8
+            const float x2 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(c[2]), 0x128, 0xF, 0xF, true));
+            const float y3 = __int_as_float(__builtin_amdgcn_ds_bpermute(((lane - 24) & 63) << 2, __float_as_int(c[3])));     // c[3] of lane (n - 8, g - 1)
+            const float v0 = hiHalf ? c[3] + x2 : c[0] + x1;
+            const float v1 = hiHalf ? c[0] + y3 : c[1] + x2;
+            const int r0 = hiHalf ? 4 * g + 2 : 4 * g, r1 = hiHalf ? 4 * g - 1 : 4 * g + 1;
+            // a lane pair (columns j, j ^ 1) exchanges once so that every lane stores one dword: the even lane its first row, the odd lane its second
+            const float pv0 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v0), 0xB1, 0xF, 0xF, true));       // quad_perm [1,0,3,2]
+            const float pv1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v1), 0xB1, 0xF, 0xF, true));
+            const int rl = odd ? r1 : r0;                                    // 0 .. 14, or -1 (no such row: lanes n >= 8 of the first quad)
+            const int row = 15 * rb + rl, col = 8 * cb + (j & ~1);
+            const float a = odd ? pv1 : v0, b = odd ? v1 : pv0;
+            const int oy = oy0 + row, ox = ox0 + col;
+            if (rl >= 0 && row < p.TOH && oy < p.YH && col < p.TOW && ox < p.YW && !(P.skip & 512)) {
+                T* dst = yb + oy * p.ys[2] + ox * p.ys[3];
+                if (P.sdw && ox + 1 < p.YW) { *(uint32_t*)dst = Pack16<T>::pack(a, b); ysum_local += a + b; }
+                else {
+                    Elem<T>::store(dst, a); ysum_local += a;
+                    if (ox + 1 < p.YW) { Elem<T>::store(dst + p.ys[3], b); ysum_local += b; }
+                }
+            }
+        }
+    } else if (SD == 2) {
         // ---- 4. 2-D down-FIR (DOWN == 2, 12x12): TWO adjacent output columns per lane (floats 4c .. 4c + 13 of an up-resolution
         //      row: three b128 reads and one b64, lanes 16 bytes apart), strip of R4 rows, sliding window over tap rows.  The phase
         //      is bound by LDS bandwidth, not by its FMAs (PMC: LDS busy 100 %, one column per lane: 108 b64 row reads for 288
@@ -1135,11 +1253,11 @@ __global__ void __launch_bounds__(NT, 4) flr_rb_kernel(FlrRbParams P) {
 
 // host side: tile geometry + launch of the register-blocked kernel; returns false when the configuration is not one of its
 // instantiations (the caller then uses filtered_lrelu_kernel).
-template <class T, int UP, int DOWN, int SU, int SD, int NT>
+template <class T, int UP, int DOWN, int SU, int SD, int NT, int UB = 0>
 static bool flr_rb_launch(FlrParams p, hipStream_t st, int* status) {
     constexpr int FU = 6 * UP, FD = 6 * DOWN, RN = 4, R4 = 4;
     constexpr int RD = DOWN == 2 ? 8 : 4;
-    constexpr int ROUT = SD == 2 ? R4 : RD;                   // TOH is a multiple of this
+    constexpr int ROUT = UB ? 1 : SD == 2 ? R4 : RD;          // TOH is a multiple of this (UB: any height; its decimation works in 15-row blocks)
     const int maxW = (SD == 2) ? 64 : (DOWN == 2 ? 64 : 32);
     int nTx = (p.YW + maxW - 1) / maxW;
     int TOW = (p.YW + nTx - 1) / nTx;
@@ -1149,7 +1267,7 @@ static bool flr_rb_launch(FlrParams p, hipStream_t st, int* status) {
     // height that needs no more tile rows than it (second pass): 86 rows are 2 x 48, not 3 x 32 or 3 x 40 -- less halo, no ragged last
     // tile, fewer workgroups (gradient kernels of the SG3-T 512 layers 26.3 -> 24.9 ms in all; forward kernels, whose height used to be
     // tied to one lane per (strip, column) of the decimation, 13.8 -> 13.6)
-    int strips = 16;
+    int strips = UB ? 64 : 16;
     if (strips < 1) strips = 1;
     int needStrips = (p.YH + ROUT - 1) / ROUT;
     if (strips > needStrips) strips = needStrips;
@@ -1165,6 +1283,19 @@ static bool flr_rb_launch(FlrParams p, hipStream_t st, int* status) {
         p.TOW = TOW; p.TOH = TOH;
         p.TUW = (TOW - 1) * DOWN + FD; p.TUH = (TOH - 1) * DOWN + FD;
         P.UPC = (p.TUW + 3) & ~3;
+        P.VW = P.UPC;
+        P.CB = P.RB = 0;
+        int szUb = 0;
+        if (UB) {
+            // bf16 tile read by the matrix pipe in blocks of 15 output rows x 8 output columns (16 operand rows, 32 tile columns each): the pitch
+            // covers the last block's columns and is 8 mod 16 elements (the 16 lanes a ds_read_b128 serves together then hit different banks);
+            // rows are allocated (not written) for a ragged last row block
+            P.CB = (TOW + 7) / 8; P.RB = (TOH + 14) / 15;
+            const int need = p.TUW > 16 * P.CB + 16 ? p.TUW : 16 * P.CB + 16;
+            static const int pm = []() { const char* e = getenv("AGF_FLR_UB_PITCH"); return e ? atoi(e) : 8; }();
+            P.UPC = pm == 8 ? (need - 8 + 15) / 16 * 16 + 8 : (need - 16 + 63) / 64 * 64 + 16;
+            szUb = (((30 * P.RB + 10) * P.UPC + 1) / 2 + 3) & ~3;
+        }
         int szX, szH = 0;
         if (SU == 1) {
             P.TVWa = (p.TUW + UP - 1 + 7) & ~7;
@@ -1193,14 +1324,15 @@ static bool flr_rb_launch(FlrParams p, hipStream_t st, int* status) {
             P.TXHb = 32 * P.NRB + 5;                             // spread over all banks
             szX = (P.TXHb * P.XPb + 1) / 2;
         }
-        const int szU = p.TUH * P.UPC;
+        int szU = UB ? szUb : p.TUH * P.UPC;
         const int szV = SD == 1 ? TOH * P.UPC : 0;
         // layout after the filters: [sU][R2]; separable up: sX overlays sU (dead before sU is written), R2 = max(sH, sV);
         // 2-D up: R2 = max(sX, sV) (sV is written after sX is dead)
         int szR2;
         P.ofsU = 0;
         if (SU == 1) {
-            if (szX > szU) { if (strips > 1) continue; return false; }
+            if (UB) { if (szX > szU) szU = (szX + 3) & ~3; }       // (the fp32 input tile may be the larger of the two that share the region)
+            else if (szX > szU) { if (strips > 1) continue; return false; }
             P.ofsX = 0; P.ofsH = szU; szR2 = szH > szV ? szH : szV; P.ofsV = szU;
         } else {
             P.ofsX = szU; P.ofsH = 0; szR2 = szX > szV ? szX : szV; P.ofsV = szU;
@@ -1208,9 +1340,10 @@ static bool flr_rb_launch(FlrParams p, hipStream_t st, int* status) {
         P.nDw = (p.TUW + 15 + 15) / 16 + 2;
         const int szS = p.signMode == 2 ? p.TUH * P.nDw : 0;
         P.ofsS = szU + szR2;
-        const size_t fl = (size_t)(SU == 1 ? FU : FU * FU + FLR_NFP) + (size_t)(SD == 1 ? FD : FD * FD) + szU + szR2 + szS;
+        const size_t fl = (size_t)(SU == 1 ? FU : FU * FU + FLR_NFP) + (size_t)(SD == 1 ? FD : FD * FD) + (UB ? FLR_NFDP : 0) + szU + szR2 + szS;
         lds = fl * sizeof(float);
-        if (lds <= 78 * 1024) {                                  // two workgroups per CU
+        static const int ubKb = []() { const char* e = getenv("AGF_FLR_UB_LDS_KB"); return e ? atoi(e) : 78; }();   // (tuning knob of the UB kernels)
+        if (lds <= (size_t)(UB ? ubKb : 78) * 1024) {            // two workgroups per CU
             if (balanced) break;
             const int tilesY = (needStrips + strips - 1) / strips;
             strips = (needStrips + tilesY - 1) / tilesY + 1;          // (+ 1: the loop's decrement)
@@ -1227,7 +1360,7 @@ static bool flr_rb_launch(FlrParams p, hipStream_t st, int* status) {
     if (blocks >= (1ll << 31)) { *status = AGF_EINVAL; agf_set_error("filtered_lrelu: x is too large"); return true; }
     P.b = p;
     P.mG = flr_magic(SU == 1 ? P.TVWa >> 3 : 1); P.mTUW = flr_magic(p.TUW); P.mMW = flr_magic(P.MW ? P.MW : 1);
-    P.mQ4 = flr_magic(P.UPC >> 2); P.mTOW = flr_magic(p.TOW); P.mXP = flr_magic(P.XP);
+    P.mQ4 = flr_magic(P.VW >> 2); P.mTOW = flr_magic(p.TOW); P.mXP = flr_magic(P.XP);
     P.mHW = flr_magic(p.TOW >> 1); P.mDw = flr_magic(P.nDw); P.mHU = flr_magic(p.TUW >> 1); P.mWpr = flr_magic(P.XPb ? P.XPb >> 1 : 1);
     P.sdw = sizeof(T) == 2 && p.ys[3] == 1 && !(p.ys[2] & 1) && !(p.ys[1] & 1) && !(p.ys[0] & 1) && !((uintptr_t)p.y & 3);
     P.NW = (P.XP >> 1) + 1; P.dRy = NT / P.NW; P.dW = NT - P.dRy * P.NW; P.mNW = flr_magic(P.NW);
@@ -1239,7 +1372,10 @@ static bool flr_rb_launch(FlrParams p, hipStream_t st, int* status) {
 #else
     P.skip = 0;
 #endif
-    auto kern = flr_rb_kernel<T, UP, DOWN, SU, SD, RN, R4, NT>;
+    { static const bool dbg = getenv("AGF_FLR_DEBUG") != nullptr;
+      if (dbg) fprintf(stderr, "flr_rb UB=%d up%d down%d su%d sd%d Y %dx%d tile %dx%d tiles %dx%d TU %dx%d pitch %d TXH %d XP %d HP %d CB %d RB %d lds %zu blocks %lld\n", UB, UP, DOWN, SU, SD,
+                       p.YH, p.YW, p.TOH, p.TOW, p.tilesY, p.tilesX, p.TUH, p.TUW, P.UPC, p.TXH, P.XP, P.HP, P.CB, P.RB, lds, (long long)blocks); }
+    auto kern = flr_rb_kernel<T, UP, DOWN, SU, SD, RN, R4, NT, UB>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { agf_set_error("filtered_lrelu: cannot reserve LDS: %s", hipGetErrorString(e)); *status = AGF_ELAUNCH; return true; }
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NT), lds, st, P);
@@ -1253,6 +1389,14 @@ static bool flr_rb_dispatch_nt(const FlrParams& p, hipStream_t st, int* status) 
     const int up = p.up, down = p.down;
     if (p.fuw != 6 * up || p.fdw != 6 * down) return false;
     if ((su == 2 && p.fuh != p.fuw) || (sd == 2 && p.fdh != p.fdw)) return false;
+    if constexpr (std::is_same<T, bf16_t>::value) {
+        // bf16 forward pass of the radial layers: bf16 activated tile, decimation on the matrix pipe (AGF_FLR_MFMA_DOWN=0: the fp32 / VALU kernel, for A/B runs)
+        static const bool mfmaDown = []() { const char* e = getenv("AGF_FLR_MFMA_DOWN"); return !(e && e[0] == '0'); }();
+        if (mfmaDown && down == 2 && su == 1 && sd == 2 && (up == 2 || up == 4)) {
+            if (up == 2) return flr_rb_launch<T, 2, 2, 1, 2, NT, 1>(p, st, status);
+            return flr_rb_launch<T, 4, 2, 1, 2, NT, 1>(p, st, status);
+        }
+    }
     if (up == 2 && down == 2 && su == 1 && sd == 2) return flr_rb_launch<T, 2, 2, 1, 2, NT>(p, st, status);
     if (up == 4 && down == 2 && su == 1 && sd == 2) return flr_rb_launch<T, 4, 2, 1, 2, NT>(p, st, status);
     if (up == 2 && down == 2 && su == 1 && sd == 1) return flr_rb_launch<T, 2, 2, 1, 1, NT>(p, st, status);
