@@ -21,9 +21,9 @@ _DTYPES = {torch.float32: AGF_F32, torch.float16: AGF_F16, torch.bfloat16: AGF_B
 
 EXPORTS = ['agf_abi_version', 'agf_last_error', 'agf_device_info', 'agf_set_deterministic', 'agf_get_deterministic', 'agf_memset_node', 'agf_upfirdn2d', 'agf_upfirdn2d_fold_border', 'agf_bias_act',
            'agf_filtered_lrelu', 'agf_filtered_lrelu_act', 'agf_conv2d_fwd', 'agf_conv2d_fwd_post', 'agf_conv2d_fwd_pool', 'agf_conv2d_fwd_mask', 'agf_conv2d_fwd_bits', 'agf_conv2d_fwd_maskbits', 'agf_conv2d_maskbits_covers', 'agf_conv2d_s2_fwd', 'agf_conv2d_s2_dgrad', 'agf_conv2d_wgrad', 'agf_conv2d_wgrad_ws', 'agf_conv2d_wgrad_workspace_bytes',
-           'agf_act_bwd_reduce', 'agf_act_bwd_reduce_pooled', 'agf_act_bwd_reduce_pooled_mask', 'agf_pool2x2', 'agf_act_bwd_reduce_scaled', 'agf_scale_dot', 'agf_sum_squares', 'agf_demod_grad_finish', 'agf_planar_to_cl_pad', 'agf_planar_to_cl_pad_scaled', 'agf_cl_to_planar_crop_scaled', 'agf_cl_to_planar_crop', 'agf_cl_pad', 'agf_prep_weights', 'agf_prep_weights_multi', 'agf_prep_weights_blocks',
+           'agf_act_bwd_reduce', 'agf_act_bwd_reduce_pooled', 'agf_act_bwd_reduce_pooled_mask', 'agf_pool2x2', 'agf_act_bwd_reduce_scaled', 'agf_scale_dot', 'agf_sum_squares', 'agf_demod_grad_finish', 'agf_planar_to_cl_pad', 'agf_planar_to_cl_pad_scaled', 'agf_cl_to_planar_crop_scaled', 'agf_cl_to_planar_crop', 'agf_cl_pad', 'agf_prep_weights', 'agf_prep_weights_pad', 'agf_prep_weights_multi', 'agf_prep_weights_blocks',
            'agf_modulate_weights', 'agf_conv2d_fwd_wimg', 'agf_conv2d_fwd_wimg_covers',
-           'agf_wsq', 'agf_style_demod_fwd', 'agf_style_demod_fwd_ld', 'agf_style_demod_bwd', 'agf_diffaug_sum', 'agf_diffaug_apply', 'agf_color_affine', 'agf_affine_resample', 'agf_ada_pad_up2', 'agf_ada_warp_resample', 'agf_ada_plan', 'agf_upblur_border', 'agf_upblur_border_scaled', 'agf_upfirdn2d_chscale', 'agf_map_layer_fwd', 'agf_map_layer_bwd', 'agf_torgb_covers', 'agf_torgb_fwd', 'agf_torgb_bwd_workspace_floats', 'agf_torgb_bwd', 'agf_image_resample_rows', 'agf_image_finish']
+           'agf_wsq', 'agf_style_demod_fwd', 'agf_style_demod_fwd_ld', 'agf_style_demod_fwd_ex', 'agf_style_demod_bwd', 'agf_style_demod_bwd_ex', 'agf_ema_gain', 'agf_diffaug_sum', 'agf_diffaug_apply', 'agf_color_affine', 'agf_affine_resample', 'agf_ada_pad_up2', 'agf_ada_warp_resample', 'agf_ada_plan', 'agf_upblur_border', 'agf_upblur_border_scaled', 'agf_upfirdn2d_chscale', 'agf_map_layer_fwd', 'agf_map_layer_bwd', 'agf_torgb_covers', 'agf_torgb_fwd', 'agf_torgb_bwd_workspace_floats', 'agf_torgb_bwd', 'agf_image_resample_rows', 'agf_image_finish']
 
 _lib = None
 _i32x4 = ctypes.c_int32 * 4
@@ -117,6 +117,14 @@ def lib():
         L.agf_cl_to_planar_crop_scaled.argtypes = [_vp, _vp, _vp, ctypes.c_int] + [ctypes.c_int32] * 6 + [_vp]
         L.agf_prep_weights.restype = ctypes.c_int
         L.agf_prep_weights.argtypes = [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, _vp]
+        L.agf_prep_weights_pad.restype = ctypes.c_int
+        L.agf_prep_weights_pad.argtypes = [_vp, _vp, _vp, ctypes.c_int] + [ctypes.c_int32] * 5 + [ctypes.c_float, _vp]
+        L.agf_style_demod_fwd_ex.restype = ctypes.c_int
+        L.agf_style_demod_fwd_ex.argtypes = [_vp, ctypes.c_int64] + [_vp] * 5 + [ctypes.c_int32] * 5 + [ctypes.c_float] * 3 + [_vp]
+        L.agf_style_demod_bwd_ex.restype = ctypes.c_int
+        L.agf_style_demod_bwd_ex.argtypes = [_vp] * 9 + [ctypes.c_int32] * 6 + [ctypes.c_float, ctypes.c_int32, _vp]
+        L.agf_ema_gain.restype = ctypes.c_int
+        L.agf_ema_gain.argtypes = [_vp, ctypes.c_int32, ctypes.c_int64, ctypes.c_float, _vp, _vp, _vp]
         L.agf_sum_squares.restype = ctypes.c_int
         L.agf_sum_squares.argtypes = [_vp, _vp, ctypes.c_int32, ctypes.c_int, ctypes.c_int64, _vp]
         L.agf_cl_pad.restype = ctypes.c_int
@@ -180,7 +188,7 @@ def lib():
         L.agf_get_deterministic.restype = ctypes.c_int
         L.agf_memset_node.restype = ctypes.c_int
         L.agf_memset_node.argtypes = [_vp, ctypes.c_int, ctypes.c_int64, _vp]
-        if L.agf_abi_version() != 23:
+        if L.agf_abi_version() != 24:
             raise AgfError('libagf_ops.so ABI version mismatch')
         _lib = L
     return _lib

@@ -1356,6 +1356,12 @@ static bool flr_rb_launch(FlrParams p, hipStream_t st, int* status) {
     static_assert(((SU == 1 ? FU : FU * FU) + (SD == 1 ? FD : FD * FD)) % 4 == 0, "filter block alignment");
     p.tilesX = (p.YW + p.TOW - 1) / p.TOW; p.tilesY = (p.YH + p.TOH - 1) / p.TOH;
     if (p.signMode == 1 && (p.TOW * DOWN) % 4 != 0) return false;
+    if (UB) {
+        // blocks of 15 x 8 outputs over eight waves: below 80 % of the slots used (84 x 84 maps as 2 x 2 tiles of 3 x 6 blocks: 18 of 24) the
+        // vector decimation is as fast or faster (measured per layer of the SG3-T 512 generator, profiles/r05_flrelu_ub.txt)
+        const int nblk = P.RB * P.CB, slots = (nblk + NT / 64 - 1) / (NT / 64) * (NT / 64);
+        if (nblk * 5 < slots * 4) return false;
+    }
     const int64_t blocks = (int64_t)p.tilesX * p.tilesY * p.N * p.C;
     if (blocks >= (1ll << 31)) { *status = AGF_EINVAL; agf_set_error("filtered_lrelu: x is too large"); return true; }
     P.b = p;
@@ -1392,9 +1398,11 @@ static bool flr_rb_dispatch_nt(const FlrParams& p, hipStream_t st, int* status) 
     if constexpr (std::is_same<T, bf16_t>::value) {
         // bf16 forward pass of the radial layers: bf16 activated tile, decimation on the matrix pipe (AGF_FLR_MFMA_DOWN=0: the fp32 / VALU kernel, for A/B runs)
         static const bool mfmaDown = []() { const char* e = getenv("AGF_FLR_MFMA_DOWN"); return !(e && e[0] == '0'); }();
-        if (mfmaDown && down == 2 && su == 1 && sd == 2 && (up == 2 || up == 4)) {
-            if (up == 2) return flr_rb_launch<T, 2, 2, 1, 2, NT, 1>(p, st, status);
-            return flr_rb_launch<T, 4, 2, 1, 2, NT, 1>(p, st, status);
+        if (mfmaDown && down == 2 && su == 1 && sd == 2 && (up == 2 || up == 4) && p.YW >= 48) {
+            bool done;
+            if (up == 2) done = flr_rb_launch<T, 2, 2, 1, 2, NT, 1>(p, st, status);
+            else done = flr_rb_launch<T, 4, 2, 1, 2, NT, 1>(p, st, status);
+            if (done) return true;           // (false: the tile's blocks would leave the eight waves badly balanced -- the vector kernel below takes it)
         }
     }
     if (up == 2 && down == 2 && su == 1 && sd == 2) return flr_rb_launch<T, 2, 2, 1, 2, NT>(p, st, status);

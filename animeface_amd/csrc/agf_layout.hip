@@ -303,37 +303,41 @@ struct PrepDesc {            // = AgfPrepDesc (include/agf_ops.h)
     int32_t block_start, reserved;
 };
 
+// CoutP >= Cout, CinP >= Cin: the OUTPUT tensors are [CoutP][kh][kw][CinP] / [CinP][kh][kw][CoutP] with zeros in the padding (channel counts
+// rounded up to a 16-byte vector for the MFMA kernels: the StyleGAN3-T generator has 362 / 242 / 161 / 108-channel layers); tiles cover the
+// padded extents
 template <class T>
 static __device__ __forceinline__ void prep_tile(const float* __restrict__ w, T* __restrict__ wq, T* __restrict__ wft,
-                                                 int Cout, int Cin, int kk, float coef, int tile, float* sm) {
-    const int tilesCi = (Cin + 31) >> 5;
+                                                 int Cout, int Cin, int kk, float coef, int tile, float* sm, int CoutP, int CinP) {
+    const int tilesCi = (CinP + 31) >> 5;
     const int co0 = (tile / tilesCi) * 32, ci0 = (tile % tilesCi) * 32;
-    const int nco = min(32, Cout - co0), nci = min(32, Cin - ci0);
+    const int nco = min(32, CoutP - co0), nci = min(32, CinP - ci0);
+    const int vci = min(nci, Cin - ci0);                                             // valid input channels of the tile (<= 0: none)
     const int rowLen = nci * kk, pitch = 32 * kk + 1 - ((32 * kk) & 1);             // odd pitch
     for (int e = threadIdx.x; e < nco * rowLen; e += 256) {
         const int co = e / rowLen, r = e - co * rowLen;
-        sm[co * pitch + r] = w[((int64_t)(co0 + co) * Cin + ci0) * kk + r] * coef;
+        sm[co * pitch + r] = (co0 + co < Cout && r < vci * kk) ? w[((int64_t)(co0 + co) * Cin + ci0) * kk + r] * coef : 0.f;
     }
     __syncthreads();
     if (wq) {
         for (int e = threadIdx.x; e < nco * kk * nci; e += 256) {                   // (co, tap, ci): ci fastest
             const int ci = e % nci, t2 = e / nci, tap = t2 % kk, co = t2 / kk;
-            Elem<T>::store(wq + ((int64_t)(co0 + co) * kk + tap) * Cin + ci0 + ci, sm[co * pitch + ci * kk + tap]);
+            Elem<T>::store(wq + ((int64_t)(co0 + co) * kk + tap) * CinP + ci0 + ci, sm[co * pitch + ci * kk + tap]);
         }
     }
     if (wft) {
         for (int e = threadIdx.x; e < nci * kk * nco; e += 256) {                   // (ci, flipped tap, co): co fastest
             const int co = e % nco, t2 = e / nco, tap = t2 % kk, ci = t2 / kk;
-            Elem<T>::store(wft + ((int64_t)(ci0 + ci) * kk + (kk - 1 - tap)) * Cout + co0 + co, sm[co * pitch + ci * kk + tap]);
+            Elem<T>::store(wft + ((int64_t)(ci0 + ci) * kk + (kk - 1 - tap)) * CoutP + co0 + co, sm[co * pitch + ci * kk + tap]);
         }
     }
 }
 
 template <class T>
 __global__ void __launch_bounds__(256) prep_weights_kernel(const float* __restrict__ w, T* __restrict__ wq, T* __restrict__ wft,
-                                                           int Cout, int Cin, int kk, float coef) {
+                                                           int Cout, int Cin, int kk, float coef, int CoutP, int CinP) {
     extern __shared__ float prep_sm[];
-    prep_tile<T>(w, wq, wft, Cout, Cin, kk, coef, blockIdx.x, prep_sm);
+    prep_tile<T>(w, wq, wft, Cout, Cin, kk, coef, blockIdx.x, prep_sm, CoutP, CinP);
 }
 
 template <class T>      // any kernel size: one element per thread, scattered stores
@@ -359,11 +363,23 @@ __global__ void __launch_bounds__(256) prep_weights_multi_kernel(const PrepDesc*
         if (descs[mid].block_start <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
     }
     const PrepDesc d = descs[lo];
-    prep_tile<T>(d.w, (T*)d.wq, (T*)d.wft, d.Cout, d.Cin, d.ksize * d.ksize, d.coef, blockIdx.x - d.block_start, prep_sm);
+    const int CinP = d.reserved ? (d.reserved & 0xFFFF) : d.Cin, CoutP = d.reserved ? ((d.reserved >> 16) & 0xFFFF) : d.Cout;      // (padded extents)
+    prep_tile<T>(d.w, (T*)d.wq, (T*)d.wft, d.Cout, d.Cin, d.ksize * d.ksize, d.coef, blockIdx.x - d.block_start, prep_sm, CoutP, CinP);
 }
 
+static int prep_weights_impl(const float* w, void* wq, void* wft, int dtype, int32_t Cout, int32_t Cin, int32_t ksize, int32_t CoutP, int32_t CinP,
+                             float coef, void* stream);
 extern "C" int agf_prep_weights(const float* w, void* wq, void* wft, int dtype, int32_t Cout, int32_t Cin, int32_t ksize,
                                 float coef, void* stream) {
+    return prep_weights_impl(w, wq, wft, dtype, Cout, Cin, ksize, Cout, Cin, coef, stream);
+}
+extern "C" int agf_prep_weights_pad(const float* w, void* wq, void* wft, int dtype, int32_t Cout, int32_t Cin, int32_t ksize,
+                                    int32_t CoutP, int32_t CinP, float coef, void* stream) {
+    AGF_CHECK(CoutP >= Cout && CinP >= Cin && CoutP < 65536 && CinP < 65536 && ksize <= 3, "prep_weights_pad: padded extents must cover the tensor (kernel sizes 1 ... 3)");
+    return prep_weights_impl(w, wq, wft, dtype, Cout, Cin, ksize, CoutP, CinP, coef, stream);
+}
+static int prep_weights_impl(const float* w, void* wq, void* wft, int dtype, int32_t Cout, int32_t Cin, int32_t ksize, int32_t CoutP, int32_t CinP,
+                             float coef, void* stream) {
     AGF_CHECK(w && (wq || wft), "prep_weights: null pointer");
     AGF_CHECK(dtype == AGF_F32 || dtype == AGF_F16 || dtype == AGF_BF16, "prep_weights: dtype must be float16, bfloat16 or float32");
     AGF_CHECK(Cout >= 1 && Cin >= 1 && ksize >= 1, "prep_weights: bad shape");
@@ -378,11 +394,11 @@ extern "C" int agf_prep_weights(const float* w, void* wq, void* wft, int dtype, 
         AGF_LAUNCH_CHECK();
         return AGF_OK;
     }
-    const unsigned blocks = (unsigned)(((Cout + 31) / 32) * ((Cin + 31) / 32));
+    const unsigned blocks = (unsigned)(((CoutP + 31) / 32) * ((CinP + 31) / 32));
     const size_t lds = (size_t)32 * (32 * kk + 1) * sizeof(float);
-    if (dtype == AGF_F32) hipLaunchKernelGGL((prep_weights_kernel<float>), dim3(blocks), dim3(256), lds, st, w, (float*)wq, (float*)wft, Cout, Cin, kk, coef);
-    else if (dtype == AGF_F16) hipLaunchKernelGGL((prep_weights_kernel<f16_t>), dim3(blocks), dim3(256), lds, st, w, (f16_t*)wq, (f16_t*)wft, Cout, Cin, kk, coef);
-    else hipLaunchKernelGGL((prep_weights_kernel<bf16_t>), dim3(blocks), dim3(256), lds, st, w, (bf16_t*)wq, (bf16_t*)wft, Cout, Cin, kk, coef);
+    if (dtype == AGF_F32) hipLaunchKernelGGL((prep_weights_kernel<float>), dim3(blocks), dim3(256), lds, st, w, (float*)wq, (float*)wft, Cout, Cin, kk, coef, CoutP, CinP);
+    else if (dtype == AGF_F16) hipLaunchKernelGGL((prep_weights_kernel<f16_t>), dim3(blocks), dim3(256), lds, st, w, (f16_t*)wq, (f16_t*)wft, Cout, Cin, kk, coef, CoutP, CinP);
+    else hipLaunchKernelGGL((prep_weights_kernel<bf16_t>), dim3(blocks), dim3(256), lds, st, w, (bf16_t*)wq, (bf16_t*)wft, Cout, Cin, kk, coef, CoutP, CinP);
     AGF_LAUNCH_CHECK();
     return AGF_OK;
 }

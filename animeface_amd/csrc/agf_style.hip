@@ -27,23 +27,37 @@ __global__ void __launch_bounds__(256) wsq_kernel(const float* __restrict__ w, f
 // forward: block = 64 output channels x 4 batch rows; SL wave-sized slices split the ci sum (16 slices = 1024 threads: the sum is a
 // chain of Cin/SL dependent-latency steps per thread -- with 4 slices a 512-channel layer took 28 us).  Dynamic LDS: s^2 [4][Cin].
 #define STYLE_SL 16
+// Extended form (agf_style_demod_fwd_ex, the StyleGAN3 layers): s = s_raw + s_add; a second copy of s times a DEVICE scalar (*gain: the
+// layer's input-magnitude normalisation) with rows CinP floats apart, zero in the padding; d rows CoutP floats apart, 1 in the padding; d may be
+// null (no demodulation: the RGB layer) -- then only the s outputs are written.
 __global__ void __launch_bounds__(64 * STYLE_SL) style_demod_fwd_kernel(const float* __restrict__ s_raw, const float* __restrict__ wsq_t,
                                                               float* __restrict__ s, float* __restrict__ d,
-                                                              int B, int Cin, int Cout, float c2, float eps, int64_t ldRaw) {
+                                                              int B, int Cin, int Cout, float c2, float eps, int64_t ldRaw,
+                                                              float s_add, const float* __restrict__ gain, float* __restrict__ s_scaled, int CinP, int CoutP) {
     extern __shared__ float smem[];
     float* s2 = smem;                                    // [4][Cin]
     __shared__ float red[STYLE_SL][4][64];
     const int tid = threadIdx.x, col = tid & 63, slice = tid >> 6;
     const int co = blockIdx.x * 64 + col, b0 = blockIdx.y * 4;
+    const float gv = gain ? *gain : 1.f;
     for (int idx = tid; idx < 4 * Cin; idx += 64 * STYLE_SL) {
         const int bt = idx / Cin, ci = idx - bt * Cin, b = b0 + bt;
         float v = 0.f;
         if (b < B) {
-            v = s_raw[(int64_t)b * ldRaw + ci] + 1.f;
-            if (blockIdx.x == 0) s[(int64_t)b * Cin + ci] = v;
+            v = s_raw[(int64_t)b * ldRaw + ci] + s_add;
+            if (blockIdx.x == 0) {
+                s[(int64_t)b * Cin + ci] = v;
+                if (s_scaled) s_scaled[(int64_t)b * CinP + ci] = v * gv;
+            }
         }
         s2[idx] = v * v;
     }
+    if (s_scaled && blockIdx.x == 0)
+        for (int idx = tid; idx < 4 * (CinP - Cin); idx += 64 * STYLE_SL) {
+            const int bt = idx / (CinP - Cin), ci = Cin + idx - bt * (CinP - Cin), b = b0 + bt;
+            if (b < B) s_scaled[(int64_t)b * CinP + ci] = 0.f;
+        }
+    if (!d) return;
     __syncthreads();
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     if (co < Cout) {
@@ -64,8 +78,12 @@ __global__ void __launch_bounds__(64 * STYLE_SL) style_demod_fwd_kernel(const fl
             float sum = 0.f;
 #pragma unroll
             for (int k = 0; k < STYLE_SL; k++) sum += red[k][bt][col];
-            if (b < B) d[(int64_t)b * Cout + co] = rsqrtf(c2 * sum + eps);
+            if (b < B) d[(int64_t)b * CoutP + co] = rsqrtf(c2 * sum + eps);
         }
+    }
+    if (slice == 0 && co >= Cout && co < CoutP) {
+#pragma unroll
+        for (int bt = 0; bt < 4; bt++) if (b0 + bt < B) d[(int64_t)(b0 + bt) * CoutP + co] = 1.f;
     }
 }
 
@@ -74,7 +92,10 @@ __global__ void __launch_bounds__(64 * STYLE_SL) style_demod_fwd_kernel(const fl
 __global__ void __launch_bounds__(64 * STYLE_SL) style_demod_bwd_ds_kernel(const float* __restrict__ s, const float* __restrict__ d,
                                                                  const float* __restrict__ dd, const float* __restrict__ ds,
                                                                  const float* __restrict__ wsq, float* __restrict__ ds_raw,
-                                                                 int B, int Cin, int Cout, float c2) {
+                                                                 int B, int Cin, int Cout, float c2, int ldD, int ldDs, const float* __restrict__ gain, int mode) {
+    // (ldD: row pitch of d and dd; ldDs: row pitch of ds, which is the gradient of s * *gain when gain is given; dd may be null: no demodulation.
+    //  mode bit 0: ds holds sum_hw (x s_in) t, the gradient of s_in is that over s_in (0 where s_in = 0) -- times *gain: ds / s;
+    //  mode bit 1: dd holds sum_hw (dy d)(d conv), the gradient of d is that over d^2)
     extern __shared__ float smem[];
     float* g = smem;                                     // [4][Cout]
     __shared__ float red[STYLE_SL][4][64];
@@ -83,12 +104,13 @@ __global__ void __launch_bounds__(64 * STYLE_SL) style_demod_bwd_ds_kernel(const
     for (int idx = tid; idx < 4 * Cout; idx += 64 * STYLE_SL) {
         const int bt = idx / Cout, co = idx - bt * Cout, b = b0 + bt;
         float v = 0.f;
-        if (b < B) { const float dv = d[(int64_t)b * Cout + co]; v = -0.5f * c2 * dv * dv * dv * dd[(int64_t)b * Cout + co]; }
+        if (b < B && dd) { const float dv = d[(int64_t)b * ldD + co]; v = -0.5f * c2 * dv * ((mode & 2) ? 1.f : dv * dv) * dd[(int64_t)b * ldD + co]; }
         g[idx] = v;
     }
     __syncthreads();
+    const float gv = gain ? *gain : 1.f;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    if (ci < Cin) {
+    if (ci < Cin && dd) {
 #pragma unroll 8
         for (int co = slice; co < Cout; co += STYLE_SL) {
             const float wv = wsq[(int64_t)co * Cin + ci];
@@ -108,7 +130,12 @@ __global__ void __launch_bounds__(64 * STYLE_SL) style_demod_bwd_ds_kernel(const
                 float sum = 0.f;
 #pragma unroll
                 for (int k = 0; k < STYLE_SL; k++) sum += red[k][bt][col];
-                ds_raw[o] = (ds ? ds[o] : 0.f) + 2.f * s[o] * sum;
+                float dsv = 0.f;
+                if (ds) {
+                    dsv = ds[(int64_t)b * ldDs + ci];
+                    dsv = (mode & 1) ? (s[o] != 0.f && gv != 0.f ? dsv / s[o] : 0.f) : dsv * gv;
+                }
+                ds_raw[o] = dsv + 2.f * s[o] * sum;
             }
         }
     }
@@ -117,7 +144,7 @@ __global__ void __launch_bounds__(64 * STYLE_SL) style_demod_bwd_ds_kernel(const
 // backward, weight part:  dw[co,ci,t] = 2 W[co,ci,t] * sum_b g[b,co] s[b,ci]^2.   Block = 16 co x 64 ci, batch in chunks of 64.
 __global__ void __launch_bounds__(256) style_demod_bwd_dw_kernel(const float* __restrict__ s, const float* __restrict__ d,
                                                                  const float* __restrict__ dd, const float* __restrict__ w,
-                                                                 float* __restrict__ dw, int B, int Cin, int Cout, int taps, float c2) {
+                                                                 float* __restrict__ dw, int B, int Cin, int Cout, int taps, float c2, int ldD, int mode) {
     __shared__ float gs[64][16];
     __shared__ float s2[64][64];
     const int tid = threadIdx.x, col = tid & 63, sub = tid >> 6;
@@ -128,7 +155,7 @@ __global__ void __launch_bounds__(256) style_demod_bwd_dw_kernel(const float* __
         for (int idx = tid; idx < 64 * 16; idx += 256) {
             const int bl = idx >> 4, c = idx & 15, b = bb + bl, co = co0 + c;
             float v = 0.f;
-            if (b < B && co < Cout) { const float dv = d[(int64_t)b * Cout + co]; v = -0.5f * c2 * dv * dv * dv * dd[(int64_t)b * Cout + co]; }
+            if (b < B && co < Cout) { const float dv = d[(int64_t)b * ldD + co]; v = -0.5f * c2 * dv * ((mode & 2) ? 1.f : dv * dv) * dd[(int64_t)b * ldD + co]; }
             gs[bl][c] = v;
         }
         for (int idx = tid; idx < 64 * 64; idx += 256) {
@@ -180,7 +207,22 @@ extern "C" int agf_style_demod_fwd_ld(const float* s_raw, int64_t s_raw_stride, 
     AGF_CHECK(B >= 1 && Cin >= 1 && Cout >= 1, "style_demod_fwd: empty tensor");
     AGF_CHECK((size_t)4 * Cin * sizeof(float) <= 48 * 1024, "style_demod_fwd: Cin = %d is too large", Cin);
     hipLaunchKernelGGL(style_demod_fwd_kernel, dim3((unsigned)agf_ceil_div(Cout, 64), (unsigned)agf_ceil_div(B, 4)), dim3(64 * STYLE_SL),
-                       (size_t)4 * Cin * sizeof(float), (hipStream_t)stream, s_raw, wsq_t, s, d, B, Cin, Cout, c2, eps, s_raw_stride);
+                       (size_t)4 * Cin * sizeof(float), (hipStream_t)stream, s_raw, wsq_t, s, d, B, Cin, Cout, c2, eps, s_raw_stride,
+                       1.f, (const float*)nullptr, (float*)nullptr, Cin, Cout);
+    AGF_LAUNCH_CHECK();
+    return AGF_OK;
+}
+
+extern "C" int agf_style_demod_fwd_ex(const float* s_raw, int64_t s_raw_stride, const float* wsq_t, const float* gain, float* s, float* s_scaled, float* d,
+                                      int32_t B, int32_t Cin, int32_t Cout, int32_t CinP, int32_t CoutP, float s_add, float c2, float eps, void* stream) {
+    AGF_CHECK(s_raw && s, "style_demod_fwd_ex: null pointer");
+    AGF_CHECK(!d || wsq_t, "style_demod_fwd_ex: d needs wsq_t");
+    AGF_CHECK(s_raw_stride >= Cin && CinP >= Cin && CoutP >= Cout, "style_demod_fwd_ex: row strides below the channel counts");
+    AGF_CHECK(B >= 1 && Cin >= 1 && Cout >= 1, "style_demod_fwd_ex: empty tensor");
+    AGF_CHECK((size_t)4 * Cin * sizeof(float) <= 48 * 1024, "style_demod_fwd_ex: Cin = %d is too large", Cin);
+    hipLaunchKernelGGL(style_demod_fwd_kernel, dim3((unsigned)(d ? agf_ceil_div(CoutP, 64) : 1), (unsigned)agf_ceil_div(B, 4)), dim3(64 * STYLE_SL),
+                       (size_t)4 * Cin * sizeof(float), (hipStream_t)stream, s_raw, wsq_t, s, d, B, Cin, Cout, c2, eps, s_raw_stride,
+                       s_add, gain, s_scaled, CinP, CoutP);
     AGF_LAUNCH_CHECK();
     return AGF_OK;
 }
@@ -193,10 +235,61 @@ extern "C" int agf_style_demod_bwd(const float* s, const float* d, const float* 
     AGF_CHECK(!dw || w, "style_demod_bwd: dw needs w");
     if (ds_raw)
         hipLaunchKernelGGL(style_demod_bwd_ds_kernel, dim3((unsigned)agf_ceil_div(Cin, 64), (unsigned)agf_ceil_div(B, 4)), dim3(64 * STYLE_SL),
-                           (size_t)4 * Cout * sizeof(float), (hipStream_t)stream, s, d, dd, ds, wsq, ds_raw, B, Cin, Cout, c2);
+                           (size_t)4 * Cout * sizeof(float), (hipStream_t)stream, s, d, dd, ds, wsq, ds_raw, B, Cin, Cout, c2, Cout, Cin, (const float*)nullptr, 0);
     if (dw)
         hipLaunchKernelGGL(style_demod_bwd_dw_kernel, dim3((unsigned)agf_ceil_div(Cin, 64), (unsigned)agf_ceil_div(Cout, 16)), dim3(256),
-                           0, (hipStream_t)stream, s, d, dd, w, dw, B, Cin, Cout, taps, c2);
+                           0, (hipStream_t)stream, s, d, dd, w, dw, B, Cin, Cout, taps, c2, Cout, 0);
+    AGF_LAUNCH_CHECK();
+    return AGF_OK;
+}
+
+extern "C" int agf_style_demod_bwd_ex(const float* s, const float* d, const float* dd, const float* ds, const float* wsq, const float* w, const float* gain,
+                                      float* ds_raw, float* dw, int32_t B, int32_t Cin, int32_t Cout, int32_t ld_d, int32_t ld_ds, int32_t taps, float c2,
+                                      int32_t mode, void* stream) {
+    AGF_CHECK(s && (ds_raw || dw), "style_demod_bwd_ex: null pointer");
+    AGF_CHECK(!dd || (d && wsq), "style_demod_bwd_ex: dd needs d and wsq");
+    AGF_CHECK(!dw || (w && dd), "style_demod_bwd_ex: dw needs w and dd");
+    AGF_CHECK(B >= 1 && Cin >= 1 && Cout >= 1 && taps >= 1 && ld_d >= Cout && ld_ds >= Cin, "style_demod_bwd_ex: bad shape");
+    AGF_CHECK((size_t)4 * Cout * sizeof(float) <= 48 * 1024, "style_demod_bwd_ex: Cout = %d is too large", Cout);
+    if (ds_raw)
+        hipLaunchKernelGGL(style_demod_bwd_ds_kernel, dim3((unsigned)agf_ceil_div(Cin, 64), (unsigned)agf_ceil_div(B, 4)), dim3(64 * STYLE_SL),
+                           (size_t)4 * Cout * sizeof(float), (hipStream_t)stream, s, d, dd, ds, wsq, ds_raw, B, Cin, Cout, c2, ld_d, ld_ds, gain, mode);
+    if (dw)
+        hipLaunchKernelGGL(style_demod_bwd_dw_kernel, dim3((unsigned)agf_ceil_div(Cin, 64), (unsigned)agf_ceil_div(Cout, 16)), dim3(256),
+                           0, (hipStream_t)stream, s, d, dd, w, dw, B, Cin, Cout, taps, c2, ld_d, mode);
+    AGF_LAUNCH_CHECK();
+    return AGF_OK;
+}
+
+// ---- input-magnitude EMA of a StyleGAN3 layer (reference implementations/StyleGAN3/model.py:174-178): from the partial sums of
+//      agf_sum_squares,  stats = sum(slots) / numel;  ema <- stats + decay * (ema - stats)  (= torch's stats.lerp_(ema, decay));
+//      gain = rsqrt(ema).  One launch instead of sum, div, lerp_, copy_, rsqrt. ----
+__global__ void __launch_bounds__(256) ema_gain_kernel(const float* __restrict__ slots, int nslots, float inv_numel, float decay, float* __restrict__ ema,
+                                                       float* __restrict__ gain, int update) {
+    __shared__ float red[4];
+    float v = 0.f;
+    if (update) for (int i = threadIdx.x; i < nslots; i += 256) v += slots[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float e = *ema;
+        if (update) {
+            const float stats = (red[0] + red[1] + red[2] + red[3]) * inv_numel;
+            // torch's lerp (ATen/native/Lerp.h): weight < 0.5 ? a + w (b - a) : b - (b - a) (1 - w), a = stats, b = ema, w = decay
+            const float diff = e - stats;
+            e = decay < 0.5f ? stats + decay * diff : e - diff * (1.f - decay);
+            *ema = e;
+        }
+        *gain = rsqrtf(e);
+    }
+}
+
+extern "C" int agf_ema_gain(const float* slots, int32_t nslots, int64_t numel, float decay, float* ema, float* gain, void* stream) {
+    AGF_CHECK(ema && gain, "ema_gain: null pointer");
+    AGF_CHECK(!slots || (nslots >= 1 && numel >= 1), "ema_gain: empty statistic");
+    hipLaunchKernelGGL(ema_gain_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, slots, nslots, slots ? 1.f / (float)numel : 0.f, decay, ema, gain, slots ? 1 : 0);
     AGF_LAUNCH_CHECK();
     return AGF_OK;
 }

@@ -141,17 +141,23 @@ def _empty_ohwi(cout, cin, k, dtype, device):
     return torch.empty((cout, k, k, cin), dtype=dtype, device=device).permute(0, 3, 1, 2)
 
 
-def prep_weights_raw(w, coef, dtype, want_q=True, want_ft=False):
+def prep_weights_raw(w, coef, dtype, want_q=True, want_ft=False, pad=None):
     """One ``agf_prep_weights`` launch: (w * coef) in ``dtype`` as OHWI (``wq``) and / or as the flipped, channel-swapped OHWI
-    weights of the data-gradient convolution (``wft``, logical shape [Cin,Cout,k,k]).  No autograd."""
+    weights of the data-gradient convolution (``wft``, logical shape [Cin,Cout,k,k]).  ``pad`` = (CoutP, CinP): zero-padded to those
+    channel counts (``agf_prep_weights_pad``).  No autograd."""
     Cout, Cin, k, _ = w.shape
     w = w.detach()
     if w.dtype != torch.float32 or not w.is_contiguous():
         w = w.float().contiguous()
-    wq = _empty_ohwi(Cout, Cin, k, dtype, w.device) if want_q else None
-    wft = _empty_ohwi(Cin, Cout, k, dtype, w.device) if want_ft else None
-    rc = _lib.lib().agf_prep_weights(_lib.ptr(w), _lib.ptr(wq), _lib.ptr(wft), _lib._DTYPES[dtype], Cout, Cin, k, float(coef),
-                                     _lib.stream_ptr(w))
+    CoutP, CinP = pad if pad is not None else (Cout, Cin)
+    wq = _empty_ohwi(CoutP, CinP, k, dtype, w.device) if want_q else None
+    wft = _empty_ohwi(CinP, CoutP, k, dtype, w.device) if want_ft else None
+    if pad is not None and (CoutP, CinP) != (Cout, Cin):
+        rc = _lib.lib().agf_prep_weights_pad(_lib.ptr(w), _lib.ptr(wq), _lib.ptr(wft), _lib._DTYPES[dtype], Cout, Cin, k, CoutP, CinP, float(coef),
+                                             _lib.stream_ptr(w))
+    else:
+        rc = _lib.lib().agf_prep_weights(_lib.ptr(w), _lib.ptr(wq), _lib.ptr(wft), _lib._DTYPES[dtype], Cout, Cin, k, float(coef),
+                                         _lib.stream_ptr(w))
     _lib.check(rc, 'prep_weights')
     return wq, wft
 
@@ -661,7 +667,7 @@ def scale_dot_raw(x, t, s, want_dx=True):
 
 
 class _Prepared:
-    __slots__ = ('ref', 'coef', 'wq', 'wq_ft')
+    __slots__ = ('ref', 'coef', 'wq', 'wq_ft', 'pad')
 
 
 _prep_cache = {}
@@ -708,9 +714,9 @@ class PrepPlan:
         self.requests = {}             # id(weight) -> (weight, coef, dtype)
         self.entries = None
 
-    def note(self, weight, coef, dtype):
+    def note(self, weight, coef, dtype, pad=None):
         if self.entries is None and id(weight) in self.ids and weight.dim() == 4 and weight.shape[2] == weight.shape[3] <= 3:
-            self.requests.setdefault(id(weight), (weight, coef, dtype))
+            self.requests.setdefault(id(weight), (weight, coef, dtype, pad))
 
     def build(self):
         """End of the recorded iteration: allocate the persistent buffers and upload the descriptor table (not inside a graph capture:
@@ -733,15 +739,16 @@ class PrepPlan:
                                                   ('coef', '<f4'), ('block_start', '<i4'), ('reserved', '<i4')]))
         assert desc.dtype.itemsize == 48
         self.entries, blocks = [], 0
-        for i, (w, coef, dtype) in enumerate(reqs):
+        for i, (w, coef, dtype, pad) in enumerate(reqs):
             Cout, Cin, k, _ = w.shape
-            wq, wft = _empty_ohwi(Cout, Cin, k, dtype, w.device), _empty_ohwi(Cin, Cout, k, dtype, w.device)
-            desc[i] = (w.data_ptr(), wq.data_ptr(), wft.data_ptr(), Cout, Cin, k, coef, blocks, 0)
-            blocks += int(L.agf_prep_weights_blocks(Cout, Cin))
-            self.entries.append((w, float(coef), wq, wft))
-        self.blocks, self.kmax = blocks, max(int(w.shape[2]) for w, _, _ in reqs)
+            CoutP, CinP = pad if pad is not None else (Cout, Cin)                # (zero-padded operand tensors: AgfPrepDesc.reserved)
+            wq, wft = _empty_ohwi(CoutP, CinP, k, dtype, w.device), _empty_ohwi(CinP, CoutP, k, dtype, w.device)
+            desc[i] = (w.data_ptr(), wq.data_ptr(), wft.data_ptr(), Cout, Cin, k, coef, blocks, (CinP | (CoutP << 16)) if (CoutP, CinP) != (Cout, Cin) else 0)
+            blocks += int(L.agf_prep_weights_blocks(CoutP, CinP))
+            self.entries.append((w, float(coef), wq, wft, pad))
+        self.blocks, self.kmax = blocks, max(int(r[0].shape[2]) for r in reqs)
         self.table = torch.from_numpy(desc.view(np.uint8).copy()).to(reqs[0][0].device)
-        self.ptrs = [w.data_ptr() for w, _, _ in reqs]
+        self.ptrs = [r[0].data_ptr() for r in reqs]
         self.requests = {}
 
     def run(self):
@@ -749,7 +756,7 @@ class PrepPlan:
         import weakref
         if not self.entries:                        # still recording (first iteration), or nothing to batch
             return
-        if any(w.data_ptr() != p for (w, _, _, _), p in zip(self.entries, self.ptrs)):     # a parameter was re-allocated (load_state_dict
+        if any(e[0].data_ptr() != p for e, p in zip(self.entries, self.ptrs)):     # a parameter was re-allocated (load_state_dict
             self.entries, self.requests = None, {}                                         # copies in place; .to() / .data = ... do not):
             return                                                                         # record again during this iteration
         w0 = self.entries[0][0]
@@ -762,9 +769,9 @@ class PrepPlan:
         """Put the (already refreshed) buffers into the prepared-weight cache of the enclosing ``cached_weights()`` scope, no launch."""
         import weakref
         if self.entries and _prep_cache_on:
-            for w, coef, wq, wft in self.entries:
+            for w, coef, wq, wft, pad in self.entries:
                 ent = _Prepared()
-                ent.ref, ent.coef, ent.wq, ent.wq_ft = weakref.ref(w), coef, wq, wft
+                ent.ref, ent.coef, ent.wq, ent.wq_ft, ent.pad = weakref.ref(w), coef, wq, wft, pad
                 _prep_cache[(id(w), self.dtype)] = ent
 
 
@@ -786,26 +793,28 @@ class recording_plans:
         _prep_plans = self.prev
 
 
-def prepared_weights(weight, coef, dtype, need_ft=False):
+def prepared_weights(weight, coef, dtype, need_ft=False, pad=None):
     import weakref
     cacheable = _prep_cache_on and isinstance(weight, torch.nn.Parameter)
+    if pad is not None and tuple(pad) == (weight.shape[0], weight.shape[1]):
+        pad = None
     ent = None
     if cacheable:
         ent = _prep_cache.get((id(weight), dtype))
-        if ent is not None and (ent.ref() is not weight or ent.coef != coef):
+        if ent is not None and (ent.ref() is not weight or ent.coef != coef or ent.pad != pad):
             ent = None
         if ent is None:
             for plan in _prep_plans:
-                plan.note(weight, float(coef), dtype)
+                plan.note(weight, float(coef), dtype, pad)
     if ent is None:
         ent = _Prepared()
-        ent.coef, ent.wq_ft = coef, None
+        ent.coef, ent.wq_ft, ent.pad = coef, None, pad
         ent.ref = weakref.ref(weight) if cacheable else None
-        ent.wq, ent.wq_ft = prep_weights_raw(weight, coef, dtype, True, need_ft)
+        ent.wq, ent.wq_ft = prep_weights_raw(weight, coef, dtype, True, need_ft, pad)
         if cacheable:
             _prep_cache[(id(weight), dtype)] = ent
     if need_ft and ent.wq_ft is None:
-        ent.wq_ft = prep_weights_raw(weight, coef, dtype, False, True)[1]
+        ent.wq_ft = prep_weights_raw(weight, coef, dtype, False, True, pad)[1]
     return ent
 
 

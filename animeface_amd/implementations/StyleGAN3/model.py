@@ -139,6 +139,116 @@ class _ModConvPlanar(torch.autograd.Function):
         return dx, dw, ds, dd, None
 
 
+FUSED_SCALARS = True   # the per-layer scalars of the generator -- style affines (ONE GEMM for every layer), demodulation, the input-magnitude EMA and
+#                        its gain -- on agf_style_demod_fwd_ex / agf_ema_gain, conv weights through the prepared-weight cache (agf_prep_weights_pad):
+#                        ~25 small ATen launches per layer and pass become 3-4 (tools/aten_sites_sg3.py; tests compare both ways)
+
+
+class _ModConvStyled(torch.autograd.Function):
+    """``_ModConvPlanar`` with its scalars inside:  s = s_raw (the layer's column block of the batched affine GEMM),  s_in = s * gain (gain =
+    rsqrt of the input-magnitude EMA, a device scalar),  d = rsqrt(coef^2 (s^2 @ wsq^T) + 1e-8) (reference model.py:46-58), both written with
+    the channel padding the MFMA kernels want (``agf_style_demod_fwd_ex``);  y = d * conv(x * s_in, W * coef)  with the weights taken from
+    the prepared-weight cache (one ``agf_prep_weights_multi`` launch per network and iteration, zero-padded: ``agf_prep_weights_pad``).
+    Backward: the conv's three launches and two ``scale_dot`` sums as in ``_ModConvPlanar``, then ``agf_style_demod_bwd_ex`` turns the sums
+    into the gradients of s_raw and (through wsq) of W.  First order only."""
+
+    @staticmethod
+    def forward(ctx, x, weight, s_raw, gain, coef, demod, extra):
+        from ... import _lib
+        from ..StyleGAN2.conv import conv2d_fwd_raw, prepared_weights, _wsq_pair
+        cout, cin, k = weight.shape[0], weight.shape[1], weight.shape[2]
+        cin_p, cout_p = layout.padded_channels(cin, x.dtype), layout.padded_channels(cout, x.dtype)
+        B = x.shape[0]
+        if not (s_raw.dtype == torch.float32 and s_raw.dim() == 2 and s_raw.stride(1) == 1):
+            s_raw = s_raw.float().contiguous()
+        s = torch.empty((B, cin), dtype=torch.float32, device=x.device)
+        s_p = torch.empty((B, cin_p), dtype=torch.float32, device=x.device)
+        d_p = torch.empty((B, cout_p), dtype=torch.float32, device=x.device) if demod else None
+        wsq, wsq_t = _wsq_pair(weight) if demod else (None, None)
+        rc = _lib.lib().agf_style_demod_fwd_ex(_lib.ptr(s_raw), s_raw.stride(0), _lib.ptr(wsq_t), _lib.ptr(gain), _lib.ptr(s), _lib.ptr(s_p), _lib.ptr(d_p),
+                                               B, cin, cout, cin_p, cout_p, 0.0, float(coef * coef), 1e-8, _lib.stream_ptr(x))
+        _lib.check(rc, 'style_demod_fwd_ex')
+        pad = (cout_p, cin_p)
+        prep = prepared_weights(weight, coef, x.dtype, need_ft=False, pad=pad)
+        xs = layout._to_cl_raw(x, extra, cin_p, scale=s_p)
+        y_cl = conv2d_fwd_raw(xs, prep.wq, in_scale=None, out_scale=d_p, prepared=True)
+        ctx.save_for_backward(xs, weight, s, s_p, d_p, y_cl if demod else None, gain, wsq)
+        ctx.dims = (cin, cout, k, extra, float(coef), pad)
+        return layout._to_planar_raw(y_cl, 0, cout)
+
+    @staticmethod
+    def backward(ctx, dy):
+        from ... import _lib
+        from ..StyleGAN2.conv import conv2d_fwd_raw, conv2d_wgrad_raw, scale_dot_raw, prepared_weights
+        if torch.is_grad_enabled():
+            raise RuntimeError('the fused StyleGAN3 modulated conv is first-order only (set model.FUSED_SCALARS = False)')
+        xs, weight, s, s_p, d_p, y_cl, gain, wsq = ctx.saved_tensors
+        cin, cout, k, extra, coef, pad = ctx.dims
+        cout_p, cin_p = pad
+        B = xs.shape[0]
+        need_x, need_w, need_s = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        dx = dw = ds_raw = None
+        g_cl = layout._to_cl_raw(dy.to(xs.dtype), 0, cout_p, scale=d_p)                 # dy * d, channels-last
+        dw_conv = conv2d_wgrad_raw(xs, g_cl, k) if need_w else None                     # w.r.t. the prepared (W * coef, padded) weights
+        sums = dots = None
+        if need_x or need_s:
+            prep = prepared_weights(weight, coef, xs.dtype, need_ft=True, pad=pad)
+            t = conv2d_fwd_raw(g_cl, prep.wq_ft, prepared=True)                          # gradient w.r.t. (x * s_in), channels-last, padded map
+            if need_s:
+                _, sums = scale_dot_raw(xs, t, s_p, want_dx=False)                      # sum_hw (x s_in) t    [B, cin_p]
+            if need_x:
+                dx = layout._to_planar_raw(t, extra, cin, scale=s_p)
+        if d_p is not None and (need_s or need_w):
+            _, dots = scale_dot_raw(g_cl, y_cl, d_p, want_dx=False)                      # sum_hw (dy d)(d conv)   [B, cout_p]
+        wf = weight.detach()
+        wf = wf if wf.dtype == torch.float32 and wf.is_contiguous() else wf.float().contiguous()
+        if need_s:
+            ds_raw = torch.empty_like(s)
+        dw_wsq = torch.empty_like(wf) if (need_w and dots is not None) else None
+        if ds_raw is not None or dw_wsq is not None:
+            rc = _lib.lib().agf_style_demod_bwd_ex(_lib.ptr(s), _lib.ptr(d_p), _lib.ptr(dots), _lib.ptr(sums), _lib.ptr(wsq), _lib.ptr(wf), _lib.ptr(gain),
+                                                   _lib.ptr(ds_raw), _lib.ptr(dw_wsq), B, cin, cout, cout_p, cin_p, k * k, float(coef * coef), 3,
+                                                   _lib.stream_ptr(xs))
+            _lib.check(rc, 'style_demod_bwd_ex')
+        if need_w:
+            dwc = dw_conv[:cout, :cin]
+            dw = dw_wsq.add_(dwc, alpha=coef) if dw_wsq is not None else dwc * coef
+            dw = dw.to(weight.dtype)
+        return dx, dw, ds_raw, None, None, None, None
+
+
+class _BatchedAffine(torch.autograd.Function):
+    """The style affines of EVERY synthesis layer as one GEMM (reference model.py:16-30 ``Linear`` x 15):  out = w @ (A_all * scale)^T + b_all,
+    returned as the layers' column blocks.  ``flat_w`` [sum Cin, style_dim] / ``flat_b`` are the storage the layers' affine parameters live in
+    (``Synthesis._affine_pack``), so nothing is concatenated; the parameters themselves are inputs only so that autograd routes their gradients:
+    slices of ONE  g^T @ w  product."""
+
+    @staticmethod
+    def forward(ctx, w, flat_w, flat_b, alpha, splits, *params):
+        out = torch.addmm(flat_b, w, flat_w.t(), alpha=alpha)
+        ctx.save_for_backward(w, flat_w)
+        ctx.alpha, ctx.splits = alpha, splits
+        outs, o = [], 0
+        for c in splits:
+            outs.append(out[:, o:o + c])
+            o += c
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        w, flat_w = ctx.saved_tensors
+        splits, alpha = ctx.splits, ctx.alpha
+        g = torch.cat([gi.float() if gi is not None else w.new_zeros((w.shape[0], c)) for gi, c in zip(gs, splits)], 1)
+        dw_lat = (g @ flat_w) * alpha if ctx.needs_input_grad[0] else None
+        dA = (g.t() @ w) * alpha
+        db = g.sum(0)
+        dAs, dbs, o = [], [], 0
+        for c in splits:
+            dAs.append(dA[o:o + c]); dbs.append(db[o:o + c])
+            o += c
+        return (dw_lat, None, None, None, None) + tuple(dAs) + tuple(dbs)
+
+
 class ModulatedConv(nn.Module):
     """reference model.py:32-74.  eps 1e-8; ``input_gain`` multiplies the weights AFTER demodulation, i.e. it scales the
     input channels but does not enter d."""
@@ -295,7 +405,34 @@ class StyleLayer(nn.Module):
         self.conv = ModulatedConv(in_channels, out_channels, kernel_size, kernel_size - 1, demod=not is_rgb)
         self.bias = nn.Parameter(torch.zeros(out_channels))
 
-    def forward(self, x, w):
+    def _input_gain(self, x):
+        """rsqrt of the input-magnitude EMA as a device scalar [1]; in training mode the EMA is updated first (reference model.py:174-178):
+        ``agf_sum_squares`` + ``agf_ema_gain``, two launches.  None when the kernels do not take x (the caller then runs the torch ops)."""
+        from ... import _lib
+        from ..StyleGAN2.conv import _zeros_f32
+        if not (self.ema.is_cuda and self.ema.dtype == torch.float32 and x.dtype in (torch.bfloat16, torch.float16, torch.float32) and x.numel() > 0
+                and (x.is_contiguous() or x.is_contiguous(memory_format=torch.channels_last)) and x.data_ptr() % 16 == 0) or _lib.deterministic():
+            return None
+        with torch.no_grad():
+            gain = torch.empty(1, dtype=torch.float32, device=x.device)
+            slots = None
+            if self.training:
+                slots = _zeros_f32((_SUMSQ_SLOTS,), x.device)
+                _lib.check(_lib.lib().agf_sum_squares(_lib.ptr(x), _lib.ptr(slots), _SUMSQ_SLOTS, _lib.dtype_code(x), x.numel(), _lib.stream_ptr(x)), 'sum_squares')
+            _lib.check(_lib.lib().agf_ema_gain(_lib.ptr(slots), _SUMSQ_SLOTS if slots is not None else 0, x.numel(), float(self.ema_decay), _lib.ptr(self.ema),
+                                               _lib.ptr(gain), _lib.stream_ptr(x)), 'ema_gain')
+        return gain
+
+    def forward(self, x, w, s_raw=None):
+        k = self.conv.weight.shape[2]
+        if FUSED_SCALARS and FOLD_SCALES and x.is_cuda and x.dtype in (torch.bfloat16, torch.float32):
+            gain = self._input_gain(x.detach())
+            if gain is not None:
+                if s_raw is None:
+                    s_raw = self.affine(w)
+                x = _ModConvStyled.apply(x, self.conv.weight, s_raw, gain, self.conv.scale, self.conv.demod, self.conv.padding - k // 2)
+                return filtered_lrelu.filtered_lrelu(x, self.up_filter, self.down_filter, self.bias.to(x.dtype), self.up_factor,
+                                                     self.down_factor, self.padding, self.gain, self.negative_slope, self.conv_clamp)
         if self.training:
             # mean(x^2) in fp32 (reference model.py:174-176): one streaming read of the activations (``mean_square``) instead of an fp32
             # copy + square + mean (three passes over a tensor of up to 650 MB)
@@ -303,7 +440,7 @@ class StyleLayer(nn.Module):
                 stats = mean_square(x.detach())
                 self.ema.copy_(stats.lerp_(self.ema, self.ema_decay))
         input_gain = self.ema.rsqrt()
-        s = self.affine(w)
+        s = s_raw if s_raw is not None else self.affine(w)
         x = self.conv(x, s, input_gain)
         return filtered_lrelu.filtered_lrelu(x, self.up_filter, self.down_filter, self.bias.to(x.dtype), self.up_factor,
                                              self.down_factor, self.padding, self.gain, self.negative_slope, self.conv_clamp)
@@ -413,7 +550,51 @@ class Synthesis(nn.Module):
                                        is_rgb=rgb, is_critical_sampled=i >= num_layers - 2))
         self.register_buffer('output_scale', torch.tensor([output_scale]))
 
+    def _affine_pack(self, build=True):
+        """The affine weights / biases of the layers as column blocks of ONE buffer each: the parameters' ``.data`` are re-pointed into it (same
+        Parameters, same ``state_dict``; optimizer, EMA and checkpoint code see ordinary tensors), so the batched affine GEMM needs no
+        concatenation.  Re-built when a parameter was moved (``.to()``) or replaced."""
+        ws = [m.affine.weight for m in self.net]
+        bs = [m.affine.bias for m in self.net]
+        pack = getattr(self, '_pack', None)
+        ok = pack is not None and pack[0].device == ws[0].device and pack[0].dtype == ws[0].dtype
+        if ok:
+            o = 0
+            for p_w, p_b in zip(ws, bs):
+                c = p_w.shape[0]
+                if p_w.data_ptr() != pack[0][o].data_ptr() or p_b.data_ptr() != pack[1][o:].data_ptr():
+                    ok = False
+                    break
+                o += c
+        if not ok and not build:
+            return None
+        if not ok:
+            with torch.no_grad():
+                flat_w = torch.cat([p.data for p in ws], 0).contiguous()
+                flat_b = torch.cat([p.data for p in bs], 0).contiguous()
+                o = 0
+                for p_w, p_b in zip(ws, bs):
+                    c = p_w.shape[0]
+                    p_w.data = flat_w[o:o + c]
+                    p_b.data = flat_b[o:o + c]
+                    o += c
+            pack = (flat_w, flat_b, tuple(int(p.shape[0]) for p in ws))
+            self._pack = pack
+        return pack
+
     def forward(self, w):
+        scale0 = self.net[0].affine.scale
+        pack = None
+        if (FUSED_SCALARS and FOLD_SCALES and w.ndim == 2 and w.is_cuda and w.dtype == torch.float32
+                and all(m.affine.act_name == 'linear' and m.affine.scale == scale0 and m.affine.bias is not None for m in self.net)):
+            pack = self._affine_pack(build=not torch.cuda.is_current_stream_capturing())     # (never re-packed inside a graph capture)
+        if pack is not None:
+            flat_w, flat_b, splits = pack
+            s_raws = _BatchedAffine.apply(w, flat_w, flat_b, scale0, splits, *[m.affine.weight for m in self.net], *[m.affine.bias for m in self.net])
+            x = self.input(w).to(self.compute_dtype)
+            for module, s_raw in zip(self.net, s_raws):
+                x = module(x, w, s_raw)
+            return x.float() * self.output_scale
         if w.ndim == 2:
             w = w.unsqueeze(1).repeat(1, self.num_ws, 1)
         ws = w.unbind(dim=1)

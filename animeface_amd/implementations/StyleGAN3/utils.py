@@ -20,7 +20,7 @@ from ...nnutils.loss import NonSaturatingLoss, r1_regularizer
 from ...thirdparty.diffaugment import DiffAugment
 from ... import distributed as dp
 from .model import Generator, Discriminator
-from ..StyleGAN2.conv import cached_weights, invalidate_cached, PrepPlan, recording_plans
+from ..StyleGAN2.conv import cached_weights, invalidate_cached, PrepPlan, recording_plans, ZeroArena, zero_arena
 
 
 class TrainStep:
@@ -38,6 +38,7 @@ class TrainStep:
         # prepared conv weights (bf16 OHWI copies in both orientations) live for one iteration and are made by one launch per network
         # from the second iteration on, as in StyleGAN2.utils.TrainStep (136 preparation launches per iteration without)
         self._plan_G, self._plan_D = PrepPlan(G.parameters()), PrepPlan(D.parameters())
+        self._arena = ZeroArena()                      # zero-initialised fp32 scratch of the kernels that accumulate atomically: one fill per iteration
 
     def _mbsd_group_size(self):
         from .model import MinibatchStdDev
@@ -54,7 +55,7 @@ class TrainStep:
             opt.zero_grad(set_to_none=True)
 
     def __call__(self, real):
-        with cached_weights(), recording_plans(self._plan_G, self._plan_D):
+        with cached_weights(), recording_plans(self._plan_G, self._plan_D), zero_arena(self._arena, real.device):
             self._plan_G.run()
             self._plan_D.run()
             out = self._iteration(real)

@@ -35,6 +35,11 @@ def update_ema(model: torch.nn.Module, model_ema: torch.nn.Module, decay: float 
     if copy_buffers:
         buffer_ema = dict(model_ema.named_buffers())
         buffer = dict(model.named_buffers())
-        for key in buffer_ema.keys():
-            buffer_ema[key].data.copy_(buffer[key].data)
+        keys = [k for k in buffer_ema.keys() if buffer_ema[k].data_ptr() != buffer[k].data_ptr()]
+        same = [k for k in keys if buffer_ema[k].dtype == buffer[k].dtype and buffer_ema[k].device == buffer[k].device]
+        if same:                                                    # one multi-tensor pass (the StyleGAN3 generator has 48 buffers)
+            torch._foreach_copy_([buffer_ema[k].data for k in same], [buffer[k].data for k in same])
+        for key in keys:
+            if key not in same:
+                buffer_ema[key].data.copy_(buffer[key].data)
     model.train()

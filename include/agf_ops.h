@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define AGF_ABI_VERSION 23
+#define AGF_ABI_VERSION 24
 
 /* element types of activation tensors */
 enum { AGF_F32 = 0, AGF_F16 = 1, AGF_BF16 = 2, AGF_F64 = 3 };
@@ -363,6 +363,13 @@ int agf_cl_pad(const void* x, void* y, int32_t elem_bytes, int32_t N, int32_t H,
  *   (implementations/StyleGAN2/model.py:29-37,105), which the reference multiplies into activations or weights on every call. */
 int agf_prep_weights(const float* w, void* wq, void* wft, int dtype, int32_t Cout, int32_t Cin, int32_t ksize,
                      float coef, void* stream);
+/* the same into zero-padded operand tensors wq [CoutP][kh][kw][CinP], wft [CinP][kh][kw][CoutP] (ABI v24; kernel sizes 1 ... 3): the MFMA
+ * kernels want channel counts that are multiples of a 16-byte vector, the StyleGAN3-T generator has 362 / 242 / 161 / 108-channel layers
+ * (implementations/StyleGAN3/model.py:95-115 get_layer_params) -- replaces weight * scale, F.pad, flip, clone and two agf_prep_weights
+ * launches per layer.  In an AgfPrepDesc the padded extents ride in `reserved` = CinP | CoutP << 16 (0 = not padded), and block_start
+ * counts agf_prep_weights_blocks(CoutP, CinP). */
+int agf_prep_weights_pad(const float* w, void* wq, void* wft, int dtype, int32_t Cout, int32_t Cin, int32_t ksize,
+                         int32_t CoutP, int32_t CinP, float coef, void* stream);
 
 /* agf_prep_weights for a LIST of weight tensors in one launch (ABI v13): `descs_device` is a device array of `count` descriptors sorted by
  * block_start, where block_start[i] = sum of agf_prep_weights_blocks(Cout, Cin) over the tensors before i and total_blocks the sum over
@@ -392,6 +399,23 @@ int agf_style_demod_fwd_ld(const float* s_raw, int64_t s_raw_stride, const float
                            int32_t B, int32_t Cin, int32_t Cout, float c2, float eps, void* stream);
 int agf_style_demod_bwd(const float* s, const float* d, const float* dd, const float* ds, const float* wsq, const float* w,
                         float* ds_raw, float* dw, int32_t B, int32_t Cin, int32_t Cout, int32_t taps, float c2, void* stream);
+/* The same for the StyleGAN3 layers (implementations/StyleGAN3/model.py:32-74 modulated_conv2d, :160-191 SynthesisLayer.forward; ABI v24):
+ *   s = s_raw + s_add  (dense [B][Cin]);   s_scaled (nullable) = s * *gain, rows CinP floats apart, zeros in the padding -- gain is a DEVICE
+ *   scalar (the layer's input-magnitude normalisation rsqrt(ema), nullable = 1);   d (nullable: the RGB layer has no demodulation) rows CoutP
+ *   floats apart, 1 in the padding.  One launch instead of pow, sum, mm, mul, add, rsqrt, mul and two F.pad per layer.
+ *   backward: ds is the gradient of s_scaled (rows ld_ds apart), dd the gradient of d (rows ld_d apart, like d; nullable);
+ *   ds_raw = ds * *gain + 2 s (g @ wsq),  dw as in agf_style_demod_bwd.  mode bit 0: ds holds the conv's sum_hw (x s_scaled) t instead
+ *   (the gradient of s_scaled is that over s_scaled, 0 where it is 0: the kernel divides by s);  mode bit 1: dd holds sum_hw (dy d)(d conv)
+ *   (the gradient of d is that over d^2) -- the two small divisions of the StyleGAN3 conv's backward folded in. */
+int agf_style_demod_fwd_ex(const float* s_raw, int64_t s_raw_stride, const float* wsq_t, const float* gain, float* s, float* s_scaled, float* d,
+                           int32_t B, int32_t Cin, int32_t Cout, int32_t CinP, int32_t CoutP, float s_add, float c2, float eps, void* stream);
+int agf_style_demod_bwd_ex(const float* s, const float* d, const float* dd, const float* ds, const float* wsq, const float* w, const float* gain,
+                           float* ds_raw, float* dw, int32_t B, int32_t Cin, int32_t Cout, int32_t ld_d, int32_t ld_ds, int32_t taps, float c2,
+                           int32_t mode, void* stream);
+/* Input-magnitude EMA of a StyleGAN3 layer (implementations/StyleGAN3/model.py:174-178; ABI v24): with the partial sums of agf_sum_squares,
+ * stats = sum(slots) / numel;  *ema = lerp(stats, *ema, decay);  *gain = rsqrt(*ema)  -- one launch instead of sum, div, lerp_, copy_, rsqrt.
+ * slots null: *gain = rsqrt(*ema) only (evaluation mode). */
+int agf_ema_gain(const float* slots, int32_t nslots, int64_t numel, float decay, float* ema, float* gain, void* stream);
 
 /* DiffAugment 'color' + 'translation' (thirdparty/diffaugment/DiffAugment.py:10-53: rand_brightness, rand_saturation, rand_contrast,
  * rand_translation -- ~20 elementwise / gather torch launches per call) as one reduction and one apply pass.  NCHW, fp32 or bf16.

@@ -280,6 +280,87 @@ def test_modulated_conv_with_folded_scales_matches_the_operand_scaled_path(dtype
         assert a.shape == b.shape and relerr(a, b.detach().float().cpu()) < tol, (a.shape, relerr(a, b.detach().float().cpu()))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype,tol', [(torch.float32, 2e-4), (torch.bfloat16, 3e-2)], ids=['fp32', 'bf16'])
+def test_generator_with_fused_layer_scalars_matches_the_torch_ops(dtype, tol, monkeypatch):
+    """model.FUSED_SCALARS: one GEMM for the style affines of every layer (parameters packed into one buffer), ``agf_style_demod_fwd_ex`` /
+    ``_bwd_ex`` for s, s * gain, d and their gradients, ``agf_ema_gain`` for the input-magnitude EMA, conv weights from the prepared-weight
+    cache (``agf_prep_weights_pad``: ragged channel counts) -- against the same generator on the per-layer torch ops (FUSED_SCALARS = False):
+    image, every layer's EMA buffer after the pass, and the gradient of every parameter; in eval mode too (the EMA stays put)."""
+    from animeface_amd.implementations.StyleGAN3 import model as M
+    from animeface_amd.implementations.StyleGAN2.conv import cached_weights
+    torch.manual_seed(7)
+    kw = dict(image_size=64, latent_dim=24, num_layers=8, map_num_layers=2, channels=20, max_channels=28, style_dim=24, margin_size=6)
+    G = M.Generator(kw['image_size'], kw['latent_dim'], kw['num_layers'], kw['map_num_layers'], kw['channels'], kw['max_channels'],
+                    kw['style_dim'], margin_size=kw['margin_size'], compute_dtype=dtype).to(DEV)
+    with torch.no_grad():
+        for n, p in G.named_parameters():
+            if n.endswith('bias') and 'affine' not in n:
+                p.normal_(0, 0.2)
+    assert any(m.conv.weight.shape[0] % 8 or m.conv.weight.shape[1] % 8 for m in G.synthesis.net), 'the configuration has ragged channel counts'
+    sd0 = {k: v.detach().clone() for k, v in G.state_dict().items()}
+    z = torch.randn(3, 24, device=DEV)
+    gy = torch.randn(3, 3, 64, 64, device=DEV)
+    res = {}
+    for on in (True, False):
+        monkeypatch.setattr(M, 'FUSED_SCALARS', on)
+        G.load_state_dict(sd0)
+        G.train()
+        params = [p for p in G.parameters()]
+        with cached_weights():
+            img = G(z)
+            grads = torch.autograd.grad(img, params, gy, allow_unused=True)
+        emas = [m.ema.detach().clone() for m in G.synthesis.net]
+        G.eval()
+        with torch.no_grad():
+            img_eval = G(z)
+        assert all(torch.equal(m.ema, e) for m, e in zip(G.synthesis.net, emas)), 'eval mode leaves the EMA alone'
+        res[on] = (img.detach(), grads, emas, img_eval)
+    if True:
+        assert getattr(G.synthesis, '_pack', None) is not None, 'the affine parameters were packed'
+        assert set(G.state_dict().keys()) == set(sd0.keys())
+    assert relerr(res[True][0], res[False][0].float().cpu()) < tol
+    assert relerr(res[True][3], res[False][3].float().cpu()) < tol
+    for a, b in zip(res[True][2], res[False][2]):
+        torch.testing.assert_close(a, b, rtol=2e-5 if dtype == torch.float32 else 2e-3, atol=1e-7)
+    names = [n for n, _ in G.named_parameters()]
+    worst = 0.0
+    for n, a, b in zip(names, res[True][1], res[False][1]):
+        assert (a is None) == (b is None), n
+        if a is None:
+            continue
+        r = relerr(a, b.detach().float().cpu())
+        worst = max(worst, r)
+        assert r < (2e-3 if dtype == torch.float32 else 6e-2), (n, r)
+    print(f'fused layer scalars ({dtype}): worst parameter-gradient deviation {worst:.2e} of the largest value')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize('shape,pad', [((20, 12, 3), (24, 16)), ((33, 65, 3), (40, 72)), ((3, 44, 1), (8, 48)), ((16, 16, 3), (16, 16))])
+def test_prep_weights_pad_matches_pad_then_prep(dtype, shape, pad):
+    """agf_prep_weights_pad (zero-padded operand layouts in one launch, singly and through PrepPlan's descriptor table) against F.pad + agf_prep_weights."""
+    import torch.nn.functional as F
+    from animeface_amd.implementations.StyleGAN2 import conv as C
+    torch.manual_seed(3)
+    cout, cin, k = shape
+    w = torch.nn.Parameter(torch.randn(cout, cin, k, k, device=DEV))
+    wp = F.pad(w.detach(), [0, 0, 0, 0, 0, pad[1] - cin, 0, pad[0] - cout])
+    ref_q, ref_ft = C.prep_weights_raw(wp, 0.37, dtype, True, True)
+    got_q, got_ft = C.prep_weights_raw(w, 0.37, dtype, True, True, pad=pad)
+    assert got_q.shape == ref_q.shape and got_ft.shape == ref_ft.shape
+    assert torch.equal(got_q, ref_q) and torch.equal(got_ft, ref_ft)
+    plan = C.PrepPlan([w])
+    with C.cached_weights(), C.recording_plans(plan):
+        C.prepared_weights(w, 0.37, dtype, need_ft=True, pad=pad)
+    plan.build()
+    with C.cached_weights():
+        plan.run()
+        ent = C.prepared_weights(w, 0.37, dtype, need_ft=True, pad=pad)
+        assert plan.entries and ent.wq is plan.entries[0][2], 'served from the plan'
+        assert torch.equal(ent.wq, ref_q) and torch.equal(ent.wq_ft, ref_ft)
+
+
 def test_hip_model_vs_cpu_oracle_on_a_second_configuration():
     """A configuration / seed the fixtures do not contain: HIP fp32 networks against the CPU oracle (oracle/stylegan3.py, itself
     pinned to the reference by tests/test_oracle_sg3.py) on the same state_dict."""
