@@ -2167,9 +2167,24 @@ extern "C" int agf_conv2d_s2_fwd(const void* x, const void* w, void* y, const fl
     return AGF_OK;
 }
 
+static int conv2d_s2_dgrad_impl(const void* dy, const void* wt, void* dz, int dtype,
+                                int32_t N, int32_t Ho, int32_t Wo, int32_t Cout, int32_t Cin, int32_t zH, int32_t zW,
+                                float gain, int flipped, void* stream);
 extern "C" int agf_conv2d_s2_dgrad(const void* dy, const void* wt, void* dz, int dtype,
                                    int32_t N, int32_t Ho, int32_t Wo, int32_t Cout, int32_t Cin, int32_t zH, int32_t zW,
                                    float gain, void* stream) {
+    return conv2d_s2_dgrad_impl(dy, wt, dz, dtype, N, Ho, Wo, Cout, Cin, zH, zW, gain, 0, stream);
+}
+// the same on the weights as agf_prep_weights lays them out for a data gradient (wft: channel axes swapped AND taps flipped): the
+// prepared-weight cache of a training iteration serves the strided layers too
+extern "C" int agf_conv2d_s2_dgrad_ft(const void* dy, const void* wft, void* dz, int dtype,
+                                      int32_t N, int32_t Ho, int32_t Wo, int32_t Cout, int32_t Cin, int32_t zH, int32_t zW,
+                                      float gain, void* stream) {
+    return conv2d_s2_dgrad_impl(dy, wft, dz, dtype, N, Ho, Wo, Cout, Cin, zH, zW, gain, 1, stream);
+}
+static int conv2d_s2_dgrad_impl(const void* dy, const void* wt, void* dz, int dtype,
+                                int32_t N, int32_t Ho, int32_t Wo, int32_t Cout, int32_t Cin, int32_t zH, int32_t zW,
+                                float gain, int flipped, void* stream) {
     AGF_CHECK(dy && wt && dz, "conv2d_s2_dgrad: null pointer");
     AGF_CHECK(dtype == AGF_BF16, "conv2d_s2_dgrad: bf16 only");
     AGF_CHECK(N >= 1 && zH >= 1 && zW >= 1 && Ho >= 1 && Wo >= 1, "conv2d_s2_dgrad: empty tensor");
@@ -2206,7 +2221,7 @@ extern "C" int agf_conv2d_s2_dgrad(const void* dy, const void* wt, void* dz, int
                         const int ky = kys[a], kx = kxs[c];
                         const int ty = tp.HY - (ky >> 1), tx = tp.HX - (kx >> 1);
                         tp.tapX[nt] = (kg * 2 * PL + ty * PWp + tx) * 8;
-                        tp.tapW[nt] = ky * 3 + kx;
+                        tp.tapW[nt] = flipped ? 8 - (ky * 3 + kx) : ky * 3 + kx;
                         tp.tapK[nt] = kg;
                         nt++;
                     }

@@ -350,12 +350,31 @@ def flip_transpose(w):
     return w.flip([2, 3]).transpose(0, 1)
 
 
+def scaled_weight(param, coef):
+    """``param * coef`` (an ordinary autograd product) that remembers where it came from: the any-order differentiable conv Functions below
+    take derived weight tensors, and prepared one launch per call; a tensor made here lets them look its operand layouts up in the
+    prepared-weight cache of the running iteration (``cached_weights`` / ``PrepPlan``) instead.  The tensor's VALUES are what they say."""
+    w = param * coef
+    if isinstance(param, torch.nn.Parameter):
+        w._agf_src = (param, float(coef))
+    return w
+
+
+def _cached_layouts(w, dtype, need_ft=False):
+    """The prepared operand layouts of a ``scaled_weight`` tensor from the cache (None: not such a tensor, or no cache scope is open)."""
+    src = getattr(w, '_agf_src', None)
+    if src is None or not _prep_cache_on or src[0].dim() != 4 or src[0].shape[2] > 3 or src[0].shape[2] != src[0].shape[3]:
+        return None
+    return prepared_weights(src[0], src[1], dtype, need_ft=need_ft)
+
+
 class _ConvFwd(torch.autograd.Function):
     """y[n] = s_out[n,:,None,None] * conv(x[n] * s_in[n,:,None,None], w)   (scales optional)."""
 
     @staticmethod
     def forward(ctx, x, w, s_in, s_out):
-        y = conv2d_fwd_raw(x, w, in_scale=s_in, out_scale=s_out)
+        ent = _cached_layouts(w, x.dtype) if x.dtype in (torch.bfloat16, torch.float32) else None
+        y = conv2d_fwd_raw(x, ent.wq if ent is not None else w, in_scale=s_in, out_scale=s_out, prepared=ent is not None)
         ctx.save_for_backward(x, w, s_in, s_out, y if (s_out is not None) else None)
         return y
 
@@ -365,7 +384,10 @@ class _ConvFwd(torch.autograd.Function):
         dx = dw = ds_in = ds_out = None
         dy = dy.to(x.dtype)
         if ctx.needs_input_grad[0] or (s_in is not None and ctx.needs_input_grad[2]):
-            if s_in is None:
+            ent = _cached_layouts(w, x.dtype, need_ft=True) if (s_in is None and not torch.is_grad_enabled()) else None
+            if ent is not None:
+                dx = conv2d_fwd_raw(dy, ent.wq_ft, in_scale=s_out, prepared=True)           # first-order pass: the cached data-gradient layout
+            elif s_in is None:
                 dx = _ConvFwd.apply(dy, flip_transpose(w), s_out, None)
             else:
                 t = _ConvFwd.apply(dy, flip_transpose(w), s_out, None)           # gradient w.r.t. (x * s_in)
@@ -453,7 +475,8 @@ class _ConvS2Fwd(torch.autograd.Function):
         N, Cin, ZH, ZW = z.shape
         Cout = w.shape[0]
         Ho, Wo = (ZH - 3) // 2 + 1, (ZW - 3) // 2 + 1
-        wq = prep_weights_raw(w, 1.0, z.dtype)[0]
+        ent = _cached_layouts(w, z.dtype)
+        wq = ent.wq if ent is not None else prep_weights_raw(w, 1.0, z.dtype)[0]
         y = torch.empty((N, Cout, Ho, Wo), dtype=z.dtype, device=z.device, memory_format=torch.channels_last)
         timer = KernelTimer.active
         ev0 = timer.start() if timer is not None else None
@@ -487,12 +510,18 @@ class _ConvS2Dgrad(torch.autograd.Function):
         dy = dy.contiguous(memory_format=torch.channels_last)
         N, Cout, Ho, Wo = dy.shape
         Cin = w.shape[1]
-        wt = prep_weights_raw(w.detach().transpose(0, 1).contiguous(), 1.0, dy.dtype)[0]          # [Cin][3][3][Cout], taps not flipped
+        ent = _cached_layouts(w, dy.dtype, need_ft=True)
+        if ent is None:
+            wt = prep_weights_raw(w.detach().transpose(0, 1).contiguous(), 1.0, dy.dtype)[0]      # [Cin][3][3][Cout], taps not flipped
         dz = torch.empty((N, Cin, ZH, ZW), dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last)
         timer = KernelTimer.active
         ev0 = timer.start() if timer is not None else None
-        rc = _lib.lib().agf_conv2d_s2_dgrad(_lib.ptr(dy), _lib.ptr(wt), _lib.ptr(dz), _lib.dtype_code(dy), N, Ho, Wo, Cout, Cin, ZH, ZW, 1.0,
-                                            _lib.stream_ptr(dy))
+        if ent is not None:                                   # the cache's data-gradient layout (taps flipped): agf_conv2d_s2_dgrad_ft
+            rc = _lib.lib().agf_conv2d_s2_dgrad_ft(_lib.ptr(dy), _lib.ptr(ent.wq_ft), _lib.ptr(dz), _lib.dtype_code(dy), N, Ho, Wo, Cout, Cin, ZH, ZW, 1.0,
+                                                   _lib.stream_ptr(dy))
+        else:
+            rc = _lib.lib().agf_conv2d_s2_dgrad(_lib.ptr(dy), _lib.ptr(wt), _lib.ptr(dz), _lib.dtype_code(dy), N, Ho, Wo, Cout, Cin, ZH, ZW, 1.0,
+                                                _lib.stream_ptr(dy))
         if timer is not None:
             timer.stop('conv2d_fwd_kernel', ev0, 2.0 * N * Ho * Wo * Cin * Cout * 9, (N, Cout, Cin, Ho, Wo, 3, False, False, 's2t'))
         _lib.check(rc, 'conv2d_s2_dgrad')

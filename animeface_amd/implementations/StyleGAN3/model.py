@@ -28,7 +28,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ...stylegan3_ops import bias_act, filtered_lrelu, upfirdn2d, layout
-from ..StyleGAN2.conv import conv2d, conv2d_act, conv2d_s2
+from ..StyleGAN2.conv import conv2d, conv2d_act, conv2d_s2, scaled_weight
 
 
 def _cl_pad_raw(x, pad, crop):
@@ -646,7 +646,9 @@ class ConvAct(nn.Module):
     def forward(self, x):
         k = self.weight.shape[2]
         fused = self.act_name in ('lrelu', 'linear')
-        weight = None if (fused and (self.down == 1 or k == 1)) else self.weight * self.scale      # (the fused op folds the scale itself)
+        # (the fused op folds the scale itself; elsewhere the product remembers its parameter: the conv Functions then take its operand layouts
+        #  from the iteration's prepared-weight cache instead of preparing them per call)
+        weight = None if (fused and (self.down == 1 or k == 1)) else scaled_weight(self.weight, self.scale)
         if self.down == 1:
             # MFMA conv ("same" padding) with bias + activation + gain in its epilogue (and the fused backward of that epilogue)
             return conv2d_act(x.contiguous(memory_format=torch.channels_last), self.weight, self.bias, coef=self.scale,

@@ -183,7 +183,10 @@ def _filtered_lrelu_hip(up=1, down=1, padding=0, gain=np.sqrt(2), slope=0.2, cla
                     # no graph is being recorded: run the gradient pass directly and let the kernel accumulate the bias gradient
                     # (sum of dx over n, h, w) while it stores dx -- one pass less over dx
                     dyc = dy if _dense(dy) else dy.contiguous()
-                    ysum = torch.zeros(dy.shape[1], dtype=torch.float32, device=dy.device) if want_b else None
+                    ysum = None
+                    if want_b:
+                        from ..implementations.StyleGAN2.conv import _zeros_f32        # (the iteration's zero arena when one is open: no fill launch)
+                        ysum = _zeros_f32((dy.shape[1],), dy.device)
                     fu2 = fd if fd.ndim == 2 or down > 1 or fd.shape[0] > 1 else fd.square()[None]
                     fd2 = fu if fu.ndim == 2 or up > 1 or fu.shape[0] > 1 else fu.square()[None]
                     dx, _, rc = _native_fused(dyc, fu2, fd2, None, si, down, up, adj[0], adj[1], adj[2], adj[3], ox, oy, adj_gain, slope,

@@ -231,6 +231,11 @@ int agf_conv2d_s2_fwd(const void* x, const void* w, void* y, const float* bias, 
 int agf_conv2d_s2_dgrad(const void* dy, const void* wt, void* dz, int dtype,
                         int32_t N, int32_t Ho, int32_t Wo, int32_t Cout, int32_t Cin, int32_t zH, int32_t zW,
                         float gain, void* stream);
+/* the same reading the weights as agf_prep_weights prepares them for a data gradient (wft [Cin][kh][kw][Cout], taps flipped): what the
+ * prepared-weight cache of a training iteration already holds (ABI v24) */
+int agf_conv2d_s2_dgrad_ft(const void* dy, const void* wft, void* dz, int dtype,
+                        int32_t N, int32_t Ho, int32_t Wo, int32_t Cout, int32_t Cin, int32_t zH, int32_t zW,
+                        float gain, void* stream);
 
 /* Style-modulated layers on the streaming (persistent, direct-to-LDS) kernel: the modulation `weight * style` of the reference
  * (implementations/StyleGAN2/model.py:115) is folded into ONE weight tensor per image -- only for the few-channel high-resolution
