@@ -165,10 +165,20 @@ def generator(sd, cfg, z, truncation_psi=1., training=True, collect=None):
     return image, dict(w_avg=w_avg, ema=emas)
 
 
-def conv_act(sd, prefix, x, k, down=1, act='linear', gain=1., act_gain=None):
+RESBLOCK_SUM_IN_SKIP_CONV = True     # which tensors the product stores in bf16 (``bf16_storage`` only; the fp32 arithmetic is the reference's either way)
+
+
+def conv_act(sd, prefix, x, k, down=1, act='linear', gain=1., act_gain=None, store=True):
     """model.py:389-417: conv2d_resample(down) + bias_act; act_gain defaults to the activation's own gain."""
     w = sd[prefix + '.weight']
-    w = q(w * (gain / math.sqrt(w[0].numel())))                # (bf16 storage: the prepared weights; the FIR output and the conv output are stored too)
+    if act_gain is None:
+        act_gain = math.sqrt(2) if act == 'lrelu' else 1.
+    if not store and act == 'linear' and _S2._BF16_STORAGE:
+        # (bf16 storage, the ResBlock's skip branch: the product folds the branch gain into the prepared weights -- same real arithmetic)
+        w = q(w * (gain / math.sqrt(w[0].numel()) * act_gain))
+        act_gain = 1.
+    else:
+        w = q(w * (gain / math.sqrt(w[0].numel())))            # (bf16 storage: the prepared weights; the FIR output and the conv output are stored too)
     f = sd.get(prefix + '.down_filter')
     pad = k // 2
     if down == 1:
@@ -180,13 +190,12 @@ def conv_act(sd, prefix, x, k, down=1, act='linear', gain=1., act_gain=None):
             x = F.conv2d(q(U.upfirdn2d(x, f, down=down, padding=[p0, p1, p0, p1])), w)
         else:                                                   # conv2d_resample.py:100-103
             x = F.conv2d(q(U.upfirdn2d(x, f, padding=[p0, p1, p0, p1])), w, stride=down)
-    if act_gain is None:
-        act_gain = math.sqrt(2) if act == 'lrelu' else 1.
     b = sd.get(prefix + '.bias')
     if _S2._BF16_STORAGE and not (down == 1 and act in ('lrelu', 'linear')) and not (down > 1 and k == 1 and act in ('lrelu', 'linear')):
         x = q(x)                                                # a separate bias_act launch reads the stored conv output (bias in bf16)
         b = q(b) if b is not None else None
-    return q(B.bias_act(x, b, act=act, gain=act_gain))
+    y = B.bias_act(x, b, act=act, gain=act_gain)
+    return q(y) if store else y
 
 
 def minibatch_stddev(x, group_size, num_channels=1):
@@ -207,7 +216,8 @@ def discriminator(sd, cfg, x, collect=None):
         pre = f'resblocks.{i}'
         t = conv_act(sd, pre + '.conv1', x, 3, act='lrelu')
         t = conv_act(sd, pre + '.conv2', t, 3, down=2, act='lrelu', act_gain=math.sqrt(0.5))
-        x = q(t + conv_act(sd, pre + '.skip', x, 1, down=2, act='linear', act_gain=math.sqrt(0.5)))
+        # (bf16 storage: the product's skip conv takes t as its residual operand and stores the SUM -- the skip branch itself is never stored)
+        x = q(t + conv_act(sd, pre + '.skip', x, 1, down=2, act='linear', act_gain=math.sqrt(0.5), store=not RESBLOCK_SUM_IN_SKIP_CONV))
         if collect is not None:
             collect.append(x.detach())
     x = minibatch_stddev(x, cfg.mbsd_group_size, cfg.mbsd_channels)

@@ -39,6 +39,9 @@ class Rec(TorchDispatchMode):
             return out
         fr = [f for f in traceback.extract_stack() if 'animeface_amd' in f.filename]
         site = f'{fr[-1].filename.split("animeface_amd/")[-1]}:{fr[-1].lineno} {fr[-1].name}' if fr else 'outside the package'
+        node = torch._C._current_autograd_node() if hasattr(torch._C, '_current_autograd_node') else None
+        if node is not None and fr and 'backward(' in (fr[-1].line or ''):
+            site += f'  <- {node.name()}'
         o = out[0] if isinstance(out, (tuple, list)) and out else out
         n = o.numel() if isinstance(o, torch.Tensor) else 0
         cnt[site] += 1; els[site] += n; names[site][name] += 1
