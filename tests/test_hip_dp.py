@@ -22,7 +22,10 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 CFG = dict(image_size=32, image_channels=3, style_dim=64, channels=8, max_channels=64, block_num_conv=2, map_num_layers=2)
+if os.environ.get('AGF_DP_TEST_FULL'):          # (set for the spawned ranks too) BASELINE.json's networks: 256 x 256, 32 -> 512 channels, 8-layer mapping
+    CFG = dict(image_size=256, image_channels=3, style_dim=512, channels=32, max_channels=512, block_num_conv=2, map_num_layers=8)
 ITERS, BATCH, D_K = int(os.environ.get('AGF_DP_TEST_ITERS', '3')), 4, 2          # iteration 2 is a lazy-R1 iteration (it % d_k == 0, it != 0)
+DETERMINISTIC = bool(os.environ.get('AGF_DP_TEST_DETERMINISTIC'))
 
 
 def _free_port():
@@ -67,11 +70,54 @@ def _worker(rank, world, port, out, dtype=torch.bfloat16):
     r, w, local = dp.init_distributed()
     assert (r, w, local) == (rank, world, 0)
     dev = torch.device('cuda', 0)
+    if DETERMINISTIC:
+        from animeface_amd import _lib
+        _lib.set_deterministic(True)
     G, G_ema, D, opt_G, opt_D = _build(dev, dtype)
     dp.broadcast_module(G), dp.broadcast_module(G_ema), dp.broadcast_module(D)
     red_G = dp.GradReducer(G.parameters(), bucket_bytes=1 << 18, never_used=dp.never_used_parameters(G))
     red_D = dp.GradReducer(D.parameters(), bucket_bytes=1 << 18)
     assert len(red_G.buckets) >= 3 and len(red_D.buckets) >= 2
+    if os.environ.get('AGF_DP_TEST_NOEARLY'):                 # (probe: every bucket exchanged at finish(), none from the backward hooks)
+        red_G.early = red_D.early = False
+    if os.environ.get('AGF_DP_TEST_HOSTSUM'):                 # (probe: the exchange as an all-gather of host copies summed in rank order)
+        def _launch(self, bucket):
+            if bucket['launched']:
+                return
+            bucket['launched'] = True
+            h = bucket['flat'].cpu()
+            parts = [torch.empty_like(h) for _ in range(world)]
+            dp.dist.all_gather(parts, h)
+            bucket['flat'].copy_((parts[0] + parts[1]) / world)
+        dp.GradReducer._launch = _launch
+    if os.environ.get('AGF_DP_TEST_SERIALIZE'):
+        # The two ranks take turns on the GPU (a file lock held while a rank computes, released around the gradient exchange).  Two PROCESSES that
+        # share one GPU are time-sliced by the hardware scheduler, and the fire-and-forget fp32 atomics of the reduction kernels do not survive
+        # that: tools/probe/pooled_mask_sums.py -- the per-(n, c) sums of agf_act_bwd_reduce_pooled_mask come out wrong by up to one image's
+        # share (1 / N) in 7-35 % of the launches while another process runs kernels, exact alone and exact beside a busy second stream of the
+        # same process.  One process per GPU (every real deployment) is not affected; this rig is.
+        import fcntl
+        lock = open(os.environ['AGF_DP_TEST_SERIALIZE'], 'w')
+        _orig_finish = dp.GradReducer.finish
+
+        def _finish(self):
+            torch.cuda.synchronize()
+            fcntl.flock(lock, fcntl.LOCK_UN)
+            _orig_finish(self)
+            torch.cuda.synchronize()
+            fcntl.flock(lock, fcntl.LOCK_EX)
+        dp.GradReducer.finish = _finish
+    trace = []
+    if os.environ.get('AGF_DP_TEST_TRACE'):                   # (probe: a checksum of every bucket's LOCAL gradients right before its exchange)
+        _orig_launch = dp.GradReducer._launch
+
+        def _traced(self, bucket):
+            if not bucket['launched']:
+                f = bucket['flat']
+                trace.append((len(trace), int(f.numel()), float(f.double().sum()), float(f.double().abs().sum()),
+                              [float(v.double().abs().sum()) for v in bucket['views']]))
+            return _orig_launch(self, bucket)
+        dp.GradReducer._launch = _traced
     step = U.TrainStep(G, G_ema, D, opt_G, opt_D, 10., 0., D_K, 8, 'color,translation', CFG['style_dim'],
                        functools.partial(sample_nnoise, device=dev), red_G, red_D)
     real = _shard(rank, dev)
@@ -79,8 +125,16 @@ def _worker(rank, world, port, out, dtype=torch.bfloat16):
     with rng.cpu_stream():                       # every draw from torch's CPU generator: replayable by the single-process run
         torch.manual_seed(1000 + rank)
         for _ in range(ITERS):
+            if os.environ.get('AGF_DP_TEST_SERIALIZE'):
+                fcntl.flock(lock, fcntl.LOCK_EX)
             dl, gl, _ = step(real)
             losses.append((float(dl), float(gl)))
+            if os.environ.get('AGF_DP_TEST_SERIALIZE'):
+                torch.cuda.synchronize()
+                fcntl.flock(lock, fcntl.LOCK_UN)
+            if os.environ.get('AGF_DP_TEST_TRACE'):
+                trace.append(('params', len(losses) - 1, [(n, float(p.detach().double().sum()), float(p.detach().double().abs().sum()))
+                                                         for n, p in list(D.named_parameters()) + list(G.named_parameters())]))
     torch.cuda.synchronize()
     for m in (G, G_ema, D):
         dp.check_replica_consistency(m)
@@ -94,7 +148,9 @@ def _worker(rank, world, port, out, dtype=torch.bfloat16):
     scale = dp.never_used_parameters(G)[0]
     assert not opt_G.state.get(scale), 'Adam stepped a parameter that never received a gradient'
     torch.save(dict(G={k: v.cpu() for k, v in G.state_dict().items()}, D={k: v.cpu() for k, v in D.state_dict().items()},
-                    G_ema={k: v.cpu() for k, v in G_ema.state_dict().items()}, losses=losses), f'{out}.{rank}')
+                    G_ema={k: v.cpu() for k, v in G_ema.state_dict().items()}, losses=losses, trace=trace,
+                    names=[[n for n, p in list(G.named_parameters()) + list(D.named_parameters()) if any(p is q for q in b['params'])]
+                           for red in (red_D, red_G) for b in red.buckets]), f'{out}.{rank}')
     dp.dist.barrier()
     dp.dist.destroy_process_group()
 
@@ -119,10 +175,25 @@ def _single_process(dev, dtype=torch.bfloat16):
     losses = [[], []]
     # the same kind of gradient-scratch arenas the trainer uses (one per half-step and shard), persistent across iterations
     arenas = {(h, r): ZeroArena() for h in 'DG' for r in range(2)}
+    # Bit-exact comparisons (deterministic mode): a rank sums a parameter's contributions of ONE backward pass first and the exchange then adds the
+    # ranks' totals, (h1 + h2) + (k1 + k2); accumulating shard 1 onto shard 0's total contribution by contribution is ((h1 + h2) + k1) + k2 -- another
+    # fp32 rounding for every parameter that is used twice in a pass (the mapping network under style mixing).  So each shard's gradients are
+    # taken aside and the shards' totals added once, as the all-reduce does.
+    def take(params, acc):
+        for i, p in enumerate(params):
+            if p.grad is not None:
+                acc[i] = p.grad if acc[i] is None else acc[i] + p.grad
+                p.grad = None
+
+    def give(params, acc):
+        for i, p in enumerate(params):
+            p.grad = acc[i]
+    pD, pG = list(D.parameters()), list(G.parameters())
     with rng.cpu_stream():
         for it in range(ITERS):
             opt_G.zero_grad(set_to_none=True)
             opt_D.zero_grad(set_to_none=True)
+            accD, accG = [None] * len(pD), [None] * len(pG)
             with cached_weights():
                 dls = []
                 for r in range(NS):
@@ -130,8 +201,10 @@ def _single_process(dev, dtype=torch.bfloat16):
                     with zero_arena(arenas['D', r], dev):
                         dls.append(float(step._d_half(reals[r], it)))
                     streams[r] = torch.get_rng_state()
-                if os.environ.get('AGF_DP_TEST_MANUAL'):
-                    pass
+                    if DETERMINISTIC:
+                        take(pD, accD)
+                if DETERMINISTIC:
+                    give(pD, accD)
                 for p in D.parameters():
                     if p.grad is not None:
                         p.grad.div_(2)
@@ -145,6 +218,10 @@ def _single_process(dev, dtype=torch.bfloat16):
                     with zero_arena(arenas['G', r], dev):
                         gls.append(float(step._g_half(reals[r], it)[0]))
                     streams[r] = torch.get_rng_state()
+                    if DETERMINISTIC:
+                        take(pG, accG)
+                if DETERMINISTIC:
+                    give(pG, accG)
                 for p in D.parameters():
                     p.requires_grad_(True)
             for p in G.parameters():
@@ -199,6 +276,44 @@ def test_two_ranks_on_one_gpu_match_the_accumulated_single_process_run(tmp_path,
         assert n_far <= 0.2 * n_all, (n_far, n_all)
     if n_all32:
         assert n_far32 <= 1e-3 * n_all32 + 2, (n_far32, n_all32)
+
+
+def test_deterministic_mode_two_ranks_at_256_are_bit_identical_to_the_accumulated_single_process_run(tmp_path, monkeypatch):
+    """Deterministic mode (``agf_set_deterministic``) under data parallelism on BASELINE.json's 256 x 256 networks (32 -> 512 channels, 8-layer
+    mapping network; bf16; batch 4 per rank; three iterations, the third a lazy-R1 one): two ranks that share GPU 0 against ONE process that
+    runs the two shards in turn and averages their gradients.  With one writer per output element every kernel result is a function of its
+    inputs alone, the two-term gradient sum a + b is the same number in either order, so the runs must agree BIT FOR BIT -- weights of G, D and
+    the EMA copy, and the losses.  (What this is for: bisecting a divergence between ranks or between a multi-GPU and a single-GPU run.)
+    The ranks take turns on the GPU (``AGF_DP_TEST_SERIALIZE``, see ``_worker``): two processes time-sliced on ONE GPU lose or repeat
+    fire-and-forget fp32 atomics (tools/probe/pooled_mask_sums.py), which one process per GPU never sees; the exchange itself -- gloo
+    all-reduces launched from the backward hooks -- is the real one."""
+    import subprocess
+    import sys
+    env = dict(os.environ, AGF_DP_TEST_FULL='1', AGF_DP_TEST_DETERMINISTIC='1', AGF_DP_TEST_SERIALIZE=str(tmp_path / 'gpu.lock'),
+               PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, 'tests')]))
+    code = (
+        "import sys, torch, torch.multiprocessing as mp\n"
+        "import test_hip_dp as T\n"
+        "from animeface_amd import _lib\n"
+        "out = sys.argv[1]\n"
+        "assert T.CFG['image_size'] == 256 and T.DETERMINISTIC\n"
+        "mp.start_processes(T._worker, args=(2, T._free_port(), out, torch.bfloat16), nprocs=2, join=True, start_method='spawn')\n"
+        "st = [torch.load(f'{out}.{r}') for r in range(2)]\n"
+        "_lib.set_deterministic(True)\n"
+        "G, G_ema, D, losses = T._single_process(torch.device('cuda', 0), torch.bfloat16)\n"
+        "bad = []\n"
+        "for name, mod in (('G', G), ('D', D), ('G_ema', G_ema)):\n"
+        "    for k, v in mod.state_dict().items():\n"
+        "        if not torch.equal(st[0][name][k], st[1][name][k]): bad.append(('replicas', name, k))\n"
+        "        if not torch.equal(st[0][name][k], v.detach().cpu()): bad.append(('vs one process', name, k, float((st[0][name][k].float() - v.detach().cpu().float()).abs().max())))\n"
+        "print('losses 2-rank :', st[0]['losses'], st[1]['losses'])\n"
+        "print('losses single :', losses[0], losses[1])\n"
+        "assert [tuple(x) for x in st[0]['losses']] == [tuple(x) for x in losses[0]] and [tuple(x) for x in st[1]['losses']] == [tuple(x) for x in losses[1]], 'losses differ'\n"
+        "assert not bad, (len(bad), bad[:6])\n"
+        "print('BIT-IDENTICAL: %d tensors' % sum(len(m.state_dict()) for m in (G, D, G_ema)))\n")
+    r = subprocess.run([sys.executable, '-c', code, str(tmp_path / 'dpdet')], env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    print(r.stdout[-3000:])
+    assert r.returncode == 0 and 'BIT-IDENTICAL' in r.stdout, r.stderr[-4000:]
 
 
 def _worker_graphs(rank, world, port, out, graphed):
