@@ -1292,8 +1292,7 @@ static bool flr_rb_launch(FlrParams p, hipStream_t st, int* status) {
             // rows are allocated (not written) for a ragged last row block
             P.CB = (TOW + 7) / 8; P.RB = (TOH + 14) / 15;
             const int need = p.TUW > 16 * P.CB + 16 ? p.TUW : 16 * P.CB + 16;
-            static const int pm = []() { const char* e = getenv("AGF_FLR_UB_PITCH"); return e ? atoi(e) : 8; }();
-            P.UPC = pm == 8 ? (need - 8 + 15) / 16 * 16 + 8 : (need - 16 + 63) / 64 * 64 + 16;
+            P.UPC = (need - 8 + 15) / 16 * 16 + 8;            // (16 mod 64 measured slower: two-way conflicts inside the lane groups, gpurun_out/r05k)
             szUb = (((30 * P.RB + 10) * P.UPC + 1) / 2 + 3) & ~3;
         }
         int szX, szH = 0;
@@ -1342,8 +1341,7 @@ static bool flr_rb_launch(FlrParams p, hipStream_t st, int* status) {
         P.ofsS = szU + szR2;
         const size_t fl = (size_t)(SU == 1 ? FU : FU * FU + FLR_NFP) + (size_t)(SD == 1 ? FD : FD * FD) + (UB ? FLR_NFDP : 0) + szU + szR2 + szS;
         lds = fl * sizeof(float);
-        static const int ubKb = []() { const char* e = getenv("AGF_FLR_UB_LDS_KB"); return e ? atoi(e) : 78; }();   // (tuning knob of the UB kernels)
-        if (lds <= (size_t)(UB ? ubKb : 78) * 1024) {            // two workgroups per CU
+        if (lds <= 78 * 1024) {                                  // two workgroups per CU (UB: 52 KB = three per CU and 150 KB = one were measured slower)
             if (balanced) break;
             const int tilesY = (needStrips + strips - 1) / strips;
             strips = (needStrips + tilesY - 1) / tilesY + 1;          // (+ 1: the loop's decrement)
@@ -1378,9 +1376,6 @@ static bool flr_rb_launch(FlrParams p, hipStream_t st, int* status) {
 #else
     P.skip = 0;
 #endif
-    { static const bool dbg = getenv("AGF_FLR_DEBUG") != nullptr;
-      if (dbg) fprintf(stderr, "flr_rb UB=%d up%d down%d su%d sd%d Y %dx%d tile %dx%d tiles %dx%d TU %dx%d pitch %d TXH %d XP %d HP %d CB %d RB %d lds %zu blocks %lld\n", UB, UP, DOWN, SU, SD,
-                       p.YH, p.YW, p.TOH, p.TOW, p.tilesY, p.tilesX, p.TUH, p.TUW, P.UPC, p.TXH, P.XP, P.HP, P.CB, P.RB, lds, (long long)blocks); }
     auto kern = flr_rb_kernel<T, UP, DOWN, SU, SD, RN, R4, NT, UB>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { agf_set_error("filtered_lrelu: cannot reserve LDS: %s", hipGetErrorString(e)); *status = AGF_ELAUNCH; return true; }
@@ -1396,9 +1391,8 @@ static bool flr_rb_dispatch_nt(const FlrParams& p, hipStream_t st, int* status) 
     if (p.fuw != 6 * up || p.fdw != 6 * down) return false;
     if ((su == 2 && p.fuh != p.fuw) || (sd == 2 && p.fdh != p.fdw)) return false;
     if constexpr (std::is_same<T, bf16_t>::value) {
-        // bf16 forward pass of the radial layers: bf16 activated tile, decimation on the matrix pipe (AGF_FLR_MFMA_DOWN=0: the fp32 / VALU kernel, for A/B runs)
-        static const bool mfmaDown = []() { const char* e = getenv("AGF_FLR_MFMA_DOWN"); return !(e && e[0] == '0'); }();
-        if (mfmaDown && down == 2 && su == 1 && sd == 2 && (up == 2 || up == 4) && p.YW >= 48) {
+        // bf16 forward pass of the radial layers: bf16 activated tile, decimation on the matrix pipe
+        if (down == 2 && su == 1 && sd == 2 && (up == 2 || up == 4) && p.YW >= 48) {
             bool done;
             if (up == 2) done = flr_rb_launch<T, 2, 2, 1, 2, NT, 1>(p, st, status);
             else done = flr_rb_launch<T, 4, 2, 1, 2, NT, 1>(p, st, status);

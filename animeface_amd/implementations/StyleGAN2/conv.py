@@ -1154,7 +1154,12 @@ def torgb(x, weight, bias, s_raw, pre, coef):
 POOL_KERNEL = True     # agf_pool2x2 for the DBlock's AvgPool2d(2) (False: the [1,1] box FIR of upfirdn2d; tests compare the two)
 FUSE_POOL = True       # the DBlock's last conv writes its 2x2 average + sign mask instead of the activation (agf_conv2d_fwd_pool; tests compare both ways)
 POSTSCALE_X = True     # the first modulated conv of a StyleBlock stores its output times the second one's style scale (>= 128 channels), which then
-#                        runs on the unscaled (direct-to-LDS) kernel forward and in its weight gradient (tests compare both ways)
+#                        runs on the unscaled (direct-to-LDS) kernel forward and in its weight gradient (tests compare both ways).
+#                        Assumption: no style scale is EXACTLY 0 -- y and its lrelu sign are recovered from the stored y * s by dividing s back
+#                        out (``_inv_scale``, the kernels' ``ypre`` path), and where s == 0 the element is lost (its gradient contribution
+#                        becomes 0; the unscaled chain would have kept it).  s = affine(w) + 1 with a continuous w: a measure-zero event, and a
+#                        layer whose style IS zero contributes nothing forward either way.  The stored activation also carries one more bf16
+#                        rounding on the backward path; the A/B gradient test (tests/test_hip_conv.py, POSTSCALE_X cases) is the tolerance gate.
 PRESCALE_G = True      # a modulated layer's gradient tensor is stored times its demodulation scale by the pass that makes it (tests compare both ways)
 MASK_BITS = True       # the lrelu mask of the DBlock hand-off travels as one bit per element (agf_conv2d_fwd_bits / _maskbits; tests compare both ways)
 _PREMASK = True        # tests/test_hip_conv.py::test_dblock_linked_backward_matches_unlinked runs the block with the fused hand-offs off
