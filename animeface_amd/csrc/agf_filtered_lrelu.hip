@@ -443,7 +443,11 @@ __global__ void __launch_bounds__(NT, 4) flr_rb_kernel(FlrRbParams P) {
     constexpr int FU = 6 * UP, FD = 6 * DOWN;
     static_assert(SU == 1 || UP == 2, "2-D up filter: factor 2 only");
     static_assert(SD == 1 || DOWN == 2, "2-D down filter: factor 2 only");
-    static_assert(!UB || (SU == 1 && SD == 2 && std::is_same<T, bf16_t>::value), "bf16 tile + matrix-pipe decimation: bf16, separable up, radial down");
+    static_assert(!UB || (std::is_same<T, bf16_t>::value && ((SU == 1 && SD == 2) || (SU == 2 && SD == 1))), "bf16 tile: bf16 tensors; forward of a radial layer or its gradient");
+    // UBM: the forward variant (bf16 tile + matrix-pipe decimation).  UBG: the gradient variant (2-D interpolation on the matrix pipe, P.mf, writing a bf16
+    // tile; separable decimation reading it): half the LDS of the up-resolution tile = twice the tile height -- half the workgroups, less halo, fuller
+    // 32-row operand blocks (the fp32 tile held the x4 layers' gradient kernels to 16 output rows)
+    constexpr bool UBM = UB && SD == 2, UBG = UB && SU == 2;
     extern __shared__ __attribute__((aligned(16))) float flr_smem[];
     const FlrParams& p = P.b;
     constexpr int NFU = SU == 1 ? FU : FU * FU, NFD = SD == 1 ? FD : FD * FD;
@@ -451,7 +455,7 @@ __global__ void __launch_bounds__(NT, 4) flr_rb_kernel(FlrRbParams P) {
     float* sFd = sFu + NFU;
     uint32_t* sFuP = (uint32_t*)(sFd + NFD);                    // 2-D up filter: the taps again as (bf16 hi | bf16 lo << 16), FLR_NFP words
     uint32_t* sFdP = (uint32_t*)(sFd + NFD);                    // UB: FLR_NFDP words
-    float* base = sFd + NFD + (SU == 2 ? FLR_NFP : 0) + (UB ? FLR_NFDP : 0);
+    float* base = sFd + NFD + (SU == 2 ? FLR_NFP : 0) + (UBM ? FLR_NFDP : 0);
     float* sU = base + P.ofsU;
     float* sX = base + P.ofsX;
     float* sH = base + P.ofsH;
@@ -529,7 +533,7 @@ __global__ void __launch_bounds__(NT, 4) flr_rb_kernel(FlrRbParams P) {
     if (SD == 1) { for (int i = tid; i < FD; i += NT) sFd[i] = p.fd[(p.flip ? i : FD - 1 - i) * p.fds0]; }
     else { for (int i = tid; i < FD * FD; i += NT) { int ky = i / FD, kx = i - ky * FD;
             sFd[i] = p.fd[(p.flip ? ky : FD - 1 - ky) * p.fds0 + (p.flip ? kx : FD - 1 - kx) * p.fds1]; } }
-    if constexpr (UB) { for (int i = tid; i < FLR_NFDP; i += NT) sFdP[i] = 0u; }      // (the padded bf16 tap table: entries follow after the barrier)
+    if constexpr (UBM) { for (int i = tid; i < FLR_NFDP; i += NT) sFdP[i] = 0u; }      // (the padded bf16 tap table: entries follow after the barrier)
     }
 
     // ---- 1. input tile + bias (zero outside the image).  Independent loads in flight per lane: with two workgroups per
@@ -594,7 +598,7 @@ __global__ void __launch_bounds__(NT, 4) flr_rb_kernel(FlrRbParams P) {
         }
     }
     __syncthreads();
-    if constexpr (UB) {
+    if constexpr (UBM) {
         // the down filter for the matrix pipe (read in the decimation, three barriers from here): tap row ky as bf16 hi and lo parts (hi + lo
         // carries 16 mantissa bits), zero-padded -- element i of copy c <-> tap i - 2 c - 14 -- so that a lane reads the eight taps of its
         // operand column as two aligned 8-byte words (copy 1 serves the even output columns, whose window starts 4 bytes off).  The table
@@ -645,7 +649,7 @@ __global__ void __launch_bounds__(NT, 4) flr_rb_kernel(FlrRbParams P) {
             }
         }
         __syncthreads();
-        if constexpr (UB) {
+        if constexpr (UBM) {
             // columns between the vertical pass's width and the pitch: zero (operand columns of the last blocks; a tap of 0 times a NaN is a
             // NaN).  (Here, not earlier: the input tile shares this memory and the horizontal pass has just finished with it)
             const int padW = (P.UPC - P.VW) >> 1;
@@ -925,7 +929,10 @@ __global__ void __launch_bounds__(NT, 4) flr_rb_kernel(FlrRbParams P) {
                                 const uint32_t sc = sq[k * P.nDw] >> ssh;
                                 const uint32_t s0 = (uint32_t)__builtin_amdgcn_sbfe((int)sc, 0, 1), z0 = (uint32_t)__builtin_amdgcn_sbfe((int)sc, 1, 1);
                                 const float v = acc[4 * rg + e] * __uint_as_float(((s0 & slopeG) | (~s0 & oneG)) & ~z0);
-                                if (k > 0 || r0 >= 0) up[k * P.UPC] = v;
+                                if (k > 0 || r0 >= 0) {
+                                    if constexpr (UBG) ((__bf16*)sU)[(r0 + k) * P.UPC + rux] = (__bf16)v;
+                                    else up[k * P.UPC] = v;
+                                }
                             }
                     }
                     continue;
@@ -947,7 +954,10 @@ __global__ void __launch_bounds__(NT, 4) flr_rb_kernel(FlrRbParams P) {
                             v = __builtin_amdgcn_fmed3f(v, -clampv, clampv);
                         }
                         if (MODE != 1 && edgeTile) v = (colin && uy0 + ruy < p.UH) ? v : 0.f;       // uniform branch
-                        if (colok && (uint32_t)ruy < (uint32_t)p.TUH) sU[ruy * P.UPC + rux] = v;
+                        if (colok && (uint32_t)ruy < (uint32_t)p.TUH) {
+                            if constexpr (UBG) ((__bf16*)sU)[ruy * P.UPC + rux] = (__bf16)v;
+                            else sU[ruy * P.UPC + rux] = v;
+                        }
                     }
                 }
             }
@@ -1025,7 +1035,7 @@ __global__ void __launch_bounds__(NT, 4) flr_rb_kernel(FlrRbParams P) {
 
     T* yb = (T*)p.y + n * p.ys[0] + c * p.ys[1];
     float ysum_local = 0.f;
-    if constexpr (UB) {
+    if constexpr (UBM) {
         // ---- 4m. 2-D down-FIR (DOWN == 2, 12x12) on the matrix pipe.  out[oy][ox] = sum_ky sum_kx U[2 oy + ky][2 ox + kx] F[ky][kx].  For a row
         //      offset a, the product  A_a [16 rows m][32 columns k]  x  B [32 columns k][16],  A_a[m][k] = U[2 (oy_b + m) + a][16 cb + k]  (one
         //      ds_read_b128 per lane; rows 2 x pitch apart, the pitch is 8 mod 16 elements so that the sixteen lanes the LDS serves together
@@ -1199,13 +1209,16 @@ __global__ void __launch_bounds__(NT, 4) flr_rb_kernel(FlrRbParams P) {
             for (int it = tid; it < items; it += NT) {
                 const int strip = (int)FLR_DIV(it, halfU, P.mHU), c2 = it - strip * halfU;
                 const float* src = sU + (strip * RD * DOWN) * P.UPC + 2 * c2;
+                const uint32_t* srcb = (const uint32_t*)sU + (((strip * RD * DOWN) * P.UPC + 2 * c2) >> 1);       // UBG: the tile is bf16, a column pair = one dword
                 v2f acc[RD];
 #pragma unroll
                 for (int o = 0; o < RD; o++) acc[o] = (v2f)(0.f);
                 constexpr int NROWS = DOWN * (RD - 1) + FD;
 #pragma unroll
                 for (int r = 0; r < NROWS; r++) {
-                    const v2f u = *(const v2f*)(src + r * P.UPC);
+                    v2f u;
+                    if constexpr (UBG) { const uint32_t w = srcb[(r * P.UPC) >> 1]; u = (v2f){__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)}; }
+                    else u = *(const v2f*)(src + r * P.UPC);
 #pragma unroll
                     for (int o = 0; o < RD; o++) {
                         const int k = r - DOWN * o;
@@ -1257,7 +1270,8 @@ template <class T, int UP, int DOWN, int SU, int SD, int NT, int UB = 0>
 static bool flr_rb_launch(FlrParams p, hipStream_t st, int* status) {
     constexpr int FU = 6 * UP, FD = 6 * DOWN, RN = 4, R4 = 4;
     constexpr int RD = DOWN == 2 ? 8 : 4;
-    constexpr int ROUT = UB ? 1 : SD == 2 ? R4 : RD;          // TOH is a multiple of this (UB: any height; its decimation works in 15-row blocks)
+    constexpr bool UBM = UB && SD == 2;
+    constexpr int ROUT = UBM ? 1 : SD == 2 ? R4 : RD;         // TOH is a multiple of this (UBM: any height; its decimation works in 15-row blocks)
     const int maxW = (SD == 2) ? 64 : (DOWN == 2 ? 64 : 32);
     int nTx = (p.YW + maxW - 1) / maxW;
     int TOW = (p.YW + nTx - 1) / nTx;
@@ -1267,7 +1281,7 @@ static bool flr_rb_launch(FlrParams p, hipStream_t st, int* status) {
     // height that needs no more tile rows than it (second pass): 86 rows are 2 x 48, not 3 x 32 or 3 x 40 -- less halo, no ragged last
     // tile, fewer workgroups (gradient kernels of the SG3-T 512 layers 26.3 -> 24.9 ms in all; forward kernels, whose height used to be
     // tied to one lane per (strip, column) of the decimation, 13.8 -> 13.6)
-    int strips = UB ? 64 : 16;
+    int strips = UBM ? 64 : 16;
     if (strips < 1) strips = 1;
     int needStrips = (p.YH + ROUT - 1) / ROUT;
     if (strips > needStrips) strips = needStrips;
@@ -1277,6 +1291,7 @@ static bool flr_rb_launch(FlrParams p, hipStream_t st, int* status) {
     // 2-D up filter on the matrix pipe: bf16 samples that need no bias and read their signs (= the gradient pass), rows that start on dwords
     const bool mfOk = std::is_same<T, bf16_t>::value && SU == 2 && !p.b && p.signMode == 2 && p.xs[3] == 1 && !(p.xs[2] & 1) && !(p.xs[1] & 1) && !(p.xs[0] & 1)
                       && !(p.XW & 1) && !((uintptr_t)p.x & 3) && (int64_t)p.XH * p.xs[2] < (1ll << 31);
+    if (UB && !UBM && !mfOk) return false;                  // the gradient variant's bf16 tile is written by the matrix-pipe interpolation only
     for (;; strips--) {
         if (strips < 1) return false;
         const int TOH = strips * ROUT;
@@ -1286,7 +1301,7 @@ static bool flr_rb_launch(FlrParams p, hipStream_t st, int* status) {
         P.VW = P.UPC;
         P.CB = P.RB = 0;
         int szUb = 0;
-        if (UB) {
+        if (UBM) {
             // bf16 tile read by the matrix pipe in blocks of 15 output rows x 8 output columns (16 operand rows, 32 tile columns each): the pitch
             // covers the last block's columns and is 8 mod 16 elements (the 16 lanes a ds_read_b128 serves together then hit different banks);
             // rows are allocated (not written) for a ragged last row block
@@ -1323,14 +1338,14 @@ static bool flr_rb_launch(FlrParams p, hipStream_t st, int* status) {
             P.TXHb = 32 * P.NRB + 5;                             // spread over all banks
             szX = (P.TXHb * P.XPb + 1) / 2;
         }
-        int szU = UB ? szUb : p.TUH * P.UPC;
+        int szU = UBM ? szUb : UB ? ((p.TUH * P.UPC + 1) / 2 + 3) & ~3 : p.TUH * P.UPC;      // (UB, gradient variant: the same tile in bf16)
         const int szV = SD == 1 ? TOH * P.UPC : 0;
         // layout after the filters: [sU][R2]; separable up: sX overlays sU (dead before sU is written), R2 = max(sH, sV);
         // 2-D up: R2 = max(sX, sV) (sV is written after sX is dead)
         int szR2;
         P.ofsU = 0;
         if (SU == 1) {
-            if (UB) { if (szX > szU) szU = (szX + 3) & ~3; }       // (the fp32 input tile may be the larger of the two that share the region)
+            if (UBM) { if (szX > szU) szU = (szX + 3) & ~3; }       // (the fp32 input tile may be the larger of the two that share the region)
             else if (szX > szU) { if (strips > 1) continue; return false; }
             P.ofsX = 0; P.ofsH = szU; szR2 = szH > szV ? szH : szV; P.ofsV = szU;
         } else {
@@ -1339,7 +1354,7 @@ static bool flr_rb_launch(FlrParams p, hipStream_t st, int* status) {
         P.nDw = (p.TUW + 15 + 15) / 16 + 2;
         const int szS = p.signMode == 2 ? p.TUH * P.nDw : 0;
         P.ofsS = szU + szR2;
-        const size_t fl = (size_t)(SU == 1 ? FU : FU * FU + FLR_NFP) + (size_t)(SD == 1 ? FD : FD * FD) + (UB ? FLR_NFDP : 0) + szU + szR2 + szS;
+        const size_t fl = (size_t)(SU == 1 ? FU : FU * FU + FLR_NFP) + (size_t)(SD == 1 ? FD : FD * FD) + (UBM ? FLR_NFDP : 0) + szU + szR2 + szS;
         lds = fl * sizeof(float);
         if (lds <= 78 * 1024) {                                  // two workgroups per CU (UB: 52 KB = three per CU and 150 KB = one were measured slower)
             if (balanced) break;
@@ -1354,7 +1369,7 @@ static bool flr_rb_launch(FlrParams p, hipStream_t st, int* status) {
     static_assert(((SU == 1 ? FU : FU * FU) + (SD == 1 ? FD : FD * FD)) % 4 == 0, "filter block alignment");
     p.tilesX = (p.YW + p.TOW - 1) / p.TOW; p.tilesY = (p.YH + p.TOH - 1) / p.TOH;
     if (p.signMode == 1 && (p.TOW * DOWN) % 4 != 0) return false;
-    if (UB) {
+    if (UBM) {
         // blocks of 15 x 8 outputs over eight waves: below 80 % of the slots used (84 x 84 maps as 2 x 2 tiles of 3 x 6 blocks: 18 of 24) the
         // vector decimation is as fast or faster (measured per layer of the SG3-T 512 generator, profiles/r05_flrelu_ub.txt)
         const int nblk = P.RB * P.CB, slots = (nblk + NT / 64 - 1) / (NT / 64) * (NT / 64);
@@ -1402,6 +1417,13 @@ static bool flr_rb_dispatch_nt(const FlrParams& p, hipStream_t st, int* status) 
     if (up == 2 && down == 2 && su == 1 && sd == 2) return flr_rb_launch<T, 2, 2, 1, 2, NT>(p, st, status);
     if (up == 4 && down == 2 && su == 1 && sd == 2) return flr_rb_launch<T, 4, 2, 1, 2, NT>(p, st, status);
     if (up == 2 && down == 2 && su == 1 && sd == 1) return flr_rb_launch<T, 2, 2, 1, 1, NT>(p, st, status);
+    if constexpr (std::is_same<T, bf16_t>::value) {
+        // gradient pass of a radial layer (bf16, no bias, signs read): the up-resolution tile in bf16
+        if (su == 2 && sd == 1 && up == 2 && (down == 2 || down == 4)) {
+            const bool done = down == 2 ? flr_rb_launch<T, 2, 2, 2, 1, NT, 1>(p, st, status) : flr_rb_launch<T, 2, 4, 2, 1, NT, 1>(p, st, status);
+            if (done) return true;
+        }
+    }
     if (up == 2 && down == 2 && su == 2 && sd == 1) return flr_rb_launch<T, 2, 2, 2, 1, NT>(p, st, status);
     if (up == 2 && down == 4 && su == 2 && sd == 1) return flr_rb_launch<T, 2, 4, 2, 1, NT>(p, st, status);
     return false;
