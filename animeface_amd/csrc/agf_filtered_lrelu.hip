@@ -443,11 +443,12 @@ __global__ void __launch_bounds__(NT, 4) flr_rb_kernel(FlrRbParams P) {
     constexpr int FU = 6 * UP, FD = 6 * DOWN;
     static_assert(SU == 1 || UP == 2, "2-D up filter: factor 2 only");
     static_assert(SD == 1 || DOWN == 2, "2-D down filter: factor 2 only");
-    static_assert(!UB || (std::is_same<T, bf16_t>::value && ((SU == 1 && SD == 2) || (SU == 2 && SD == 1))), "bf16 tile: bf16 tensors; forward of a radial layer or its gradient");
+    static_assert(!UB || std::is_same<T, bf16_t>::value, "bf16 tile: bf16 tensors");
     // UBM: the forward variant (bf16 tile + matrix-pipe decimation).  UBG: the gradient variant (2-D interpolation on the matrix pipe, P.mf, writing a bf16
     // tile; separable decimation reading it): half the LDS of the up-resolution tile = twice the tile height -- half the workgroups, less halo, fuller
     // 32-row operand blocks (the fp32 tile held the x4 layers' gradient kernels to 16 output rows)
-    constexpr bool UBM = UB && SD == 2, UBG = UB && SU == 2;
+    // UB with both filters separable (layers 12 / 13 and their gradients): the vertical interpolation writes the bf16 tile, the separable decimation reads it.
+    constexpr bool UBM = UB && SD == 2, UBG = UB && SU == 2, UBR = UB && SD == 1;       // UBR: the decimation reads a bf16 tile
     extern __shared__ __attribute__((aligned(16))) float flr_smem[];
     const FlrParams& p = P.b;
     constexpr int NFU = SU == 1 ? FU : FU * FU, NFD = SD == 1 ? FD : FD * FD;
@@ -1217,7 +1218,7 @@ __global__ void __launch_bounds__(NT, 4) flr_rb_kernel(FlrRbParams P) {
 #pragma unroll
                 for (int r = 0; r < NROWS; r++) {
                     v2f u;
-                    if constexpr (UBG) { const uint32_t w = srcb[(r * P.UPC) >> 1]; u = (v2f){__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)}; }
+                    if constexpr (UBR) { const uint32_t w = srcb[(r * P.UPC) >> 1]; u = (v2f){__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)}; }
                     else u = *(const v2f*)(src + r * P.UPC);
 #pragma unroll
                     for (int o = 0; o < RD; o++) {
@@ -1291,7 +1292,7 @@ static bool flr_rb_launch(FlrParams p, hipStream_t st, int* status) {
     // 2-D up filter on the matrix pipe: bf16 samples that need no bias and read their signs (= the gradient pass), rows that start on dwords
     const bool mfOk = std::is_same<T, bf16_t>::value && SU == 2 && !p.b && p.signMode == 2 && p.xs[3] == 1 && !(p.xs[2] & 1) && !(p.xs[1] & 1) && !(p.xs[0] & 1)
                       && !(p.XW & 1) && !((uintptr_t)p.x & 3) && (int64_t)p.XH * p.xs[2] < (1ll << 31);
-    if (UB && !UBM && !mfOk) return false;                  // the gradient variant's bf16 tile is written by the matrix-pipe interpolation only
+    if (UB && SU == 2 && !mfOk) return false;               // the gradient variant's bf16 tile is written by the matrix-pipe interpolation only
     for (;; strips--) {
         if (strips < 1) return false;
         const int TOH = strips * ROUT;
@@ -1345,7 +1346,7 @@ static bool flr_rb_launch(FlrParams p, hipStream_t st, int* status) {
         int szR2;
         P.ofsU = 0;
         if (SU == 1) {
-            if (UBM) { if (szX > szU) szU = (szX + 3) & ~3; }       // (the fp32 input tile may be the larger of the two that share the region)
+            if (UB) { if (szX > szU) szU = (szX + 3) & ~3; }       // (the fp32 input tile may be the larger of the two that share the region)
             else if (szX > szU) { if (strips > 1) continue; return false; }
             P.ofsX = 0; P.ofsH = szU; szR2 = szH > szV ? szH : szV; P.ofsV = szU;
         } else {
@@ -1356,7 +1357,9 @@ static bool flr_rb_launch(FlrParams p, hipStream_t st, int* status) {
         P.ofsS = szU + szR2;
         const size_t fl = (size_t)(SU == 1 ? FU : FU * FU + FLR_NFP) + (size_t)(SD == 1 ? FD : FD * FD) + (UBM ? FLR_NFDP : 0) + szU + szR2 + szS;
         lds = fl * sizeof(float);
-        if (lds <= 78 * 1024) {                                  // two workgroups per CU (UB: 52 KB = three per CU and 150 KB = one were measured slower)
+        // two workgroups per CU (UB forward of the radial layers: 52 KB = three per CU and 150 KB = one were measured slower); the separable / separable
+        // UB kernel has 72 registers: three workgroups per CU at 52 KB (layers 12 / 13 forward + gradient 4.57 -> 4.46 ms; 104 KB: 6.8)
+        if (lds <= (size_t)((UB && SU == 1 && SD == 1) ? 52 : 78) * 1024) {
             if (balanced) break;
             const int tilesY = (needStrips + strips - 1) / strips;
             strips = (needStrips + tilesY - 1) / tilesY + 1;          // (+ 1: the loop's decrement)
@@ -1413,6 +1416,10 @@ static bool flr_rb_dispatch_nt(const FlrParams& p, hipStream_t st, int* status) 
             else done = flr_rb_launch<T, 4, 2, 1, 2, NT, 1>(p, st, status);
             if (done) return true;           // (false: the tile's blocks would leave the eight waves badly balanced -- the vector kernel below takes it)
         }
+    }
+    if constexpr (std::is_same<T, bf16_t>::value) {
+        // both filters separable (the critically sampled layers 12 / 13, forward and gradient): bf16 tile between the two
+        if (up == 2 && down == 2 && su == 1 && sd == 1 && flr_rb_launch<T, 2, 2, 1, 1, NT, 1>(p, st, status)) return true;
     }
     if (up == 2 && down == 2 && su == 1 && sd == 2) return flr_rb_launch<T, 2, 2, 1, 2, NT>(p, st, status);
     if (up == 4 && down == 2 && su == 1 && sd == 2) return flr_rb_launch<T, 4, 2, 1, 2, NT>(p, st, status);
