@@ -20,9 +20,9 @@ struct LayoutParams {
 // consecutive channels of one pixel)
 // PAIR (16-bit elements, W even): the planar side moves as aligned dwords = two pixels of one channel.  With one 2-byte element per lane a
 // wave-level load carries 128 bytes and the address unit, not HBM, set the pace (2.2 TB/s on the 534 x 534 StyleGAN3 layers).
-template <class U, int CT, int SC = 0, bool PAIR = false>            // U = uint16_t (bf16 / fp16) or uint32_t (fp32)
+template <class U, int CT, int SC = 0, bool PAIR = false, int PT_ = 64>            // U = uint16_t (bf16 / fp16) or uint32_t (fp32)
 __global__ void __launch_bounds__(256) planar_to_cl_pad_kernel(LayoutParams p) {
-    constexpr int PT = 64;
+    constexpr int PT = PT_;
     constexpr int VEC = 16 / (int)sizeof(U);                   // channels per 16-byte vector
     constexpr int LP = PT + 2;                                  // LDS pitch (elements): +2 spreads the transposed reads
     __shared__ U tile[CT * LP];
@@ -96,9 +96,9 @@ __global__ void __launch_bounds__(256) planar_to_cl_pad_kernel(LayoutParams p) {
 }
 
 // SC as above: the planar result times scale[n, c] (agf_cl_to_planar_crop_scaled: dx = t * s of a modulated conv's input gradient)
-template <class U, int CT, bool PAIR = false, int SC = 0>
+template <class U, int CT, bool PAIR = false, int SC = 0, int PT_ = 64>
 __global__ void __launch_bounds__(256) cl_to_planar_crop_kernel(LayoutParams p) {
-    constexpr int PT = 64;
+    constexpr int PT = PT_;
     constexpr int VEC = 16 / (int)sizeof(U);
     constexpr int LP = PT + 2;
     __shared__ U tile[CT * LP];
@@ -112,14 +112,29 @@ __global__ void __launch_bounds__(256) cl_to_planar_crop_kernel(LayoutParams p) 
     const int tid = threadIdx.x;
     const U* xrow = (const U*)p.x + ((int64_t)(n * Hp + yi + p.pad) * Wp + p.pad) * p.Cp;
     constexpr int GROUPS = CT / VEC;
-    for (int i = tid; i < PT * GROUPS; i += 256) {
-        const int px = i / GROUPS, g = i - px * GROUPS;
-        const int xi = x0 + px, cc = c0 + g * VEC;
-        U v[VEC];
-        if (xi < p.W && cc < p.Cp) *(uint4*)v = *(const uint4*)(xrow + (int64_t)xi * p.Cp + cc);
-        else { for (int e = 0; e < VEC; e++) v[e] = 0; }
+    {
+        // every 16-byte load of the lane is issued before the first LDS write (as a rolled load -> write loop the block had ONE load in flight per
+        // lane and the pass sat at 3.0 TB/s whatever the shape: 13 registers, latency-bound)
+        constexpr int NV = (PT * GROUPS + 255) / 256;
+        u32x4 vv[NV];
 #pragma unroll
-        for (int e = 0; e < VEC; e++) tile[(g * VEC + e) * LP + px] = v[e];
+        for (int k = 0; k < NV; k++) {
+            const int i = tid + k * 256;
+            const int px = i / GROUPS, g = i - px * GROUPS;
+            const int xi = x0 + px, cc = c0 + g * VEC;
+            vv[k] = (u32x4){0u, 0u, 0u, 0u};
+            if (i < PT * GROUPS && xi < p.W && cc < p.Cp) vv[k] = *(const u32x4*)(xrow + (int64_t)xi * p.Cp + cc);
+        }
+#pragma unroll
+        for (int k = 0; k < NV; k++) {
+            const int i = tid + k * 256;
+            if (i >= PT * GROUPS) continue;
+            const int px = i / GROUPS, g = i - px * GROUPS;
+            U v[VEC];
+            *(u32x4*)v = vv[k];
+#pragma unroll
+            for (int e = 0; e < VEC; e++) tile[(g * VEC + e) * LP + px] = v[e];
+        }
     }
     __syncthreads();
     U* yb = (U*)p.y + ((int64_t)n * p.C * p.H + yi) * p.W;
@@ -153,6 +168,23 @@ __global__ void __launch_bounds__(256) cl_to_planar_crop_kernel(LayoutParams p) 
     }
 }
 
+// Channel tile of the 16-bit dword (PAIR) kernels.  A tile that is mostly padding still costs its workgroup the full load -> LDS -> store
+// latency chain: 72 channels in tiles of 64 were two workgroups per pixel tile, the second one-eighth full (3.1 TB/s on the 532 x 532 layer);
+// 32 channels half a tile.  The tile is the smallest of {32, 48, 56, 64, 80} that holds the tensor in one piece, else 64.
+static int layout_pick_ct(int Cp) {
+    if (Cp <= 32) return 32;
+    if (Cp <= 48) return 48;
+    if (Cp <= 56) return 56;
+    if (Cp <= 64) return 64;
+    if (Cp <= 80) return 80;
+    return 64;          // (several tiles: 56 for 112 / 168 channels wastes nothing and was measured 7-9 % SLOWER than 64, gpurun r05: tools/bench_layout.py)
+}
+#define LAYOUT_CT_SWITCH(CT, CALL)                                                      \
+    switch (CT) {                                                                      \
+        case 32: CALL(32) break; case 48: CALL(48) break; case 56: CALL(56) break;     \
+        case 80: CALL(80) break; default: CALL(64) break;                              \
+    }
+
 static int layout_common(LayoutParams& p, const void* x, void* y, int dtype, int N, int C, int H, int W, int pad, int Cp, const char* name) {
     AGF_CHECK(x && y, "layout: null pointer");
     AGF_CHECK(dtype == AGF_F32 || dtype == AGF_F16 || dtype == AGF_BF16, "layout: dtype must be float16, bfloat16 or float32");
@@ -173,8 +205,8 @@ static int planar_to_cl_pad_impl(const void* x, void* y, const float* scale, int
     AGF_CHECK(((uintptr_t)y % 16) == 0, "planar_to_cl_pad: y must be 16-byte aligned");
     AGF_CHECK(!scale || dtype != AGF_F16, "planar_to_cl_pad_scaled: bf16 or f32");
     p.scale = scale;
-    const int CT = dtype == AGF_F32 ? 32 : 64;
     const bool pair = dtype != AGF_F32 && (W % 2) == 0 && ((uintptr_t)x % 4) == 0;
+    const int CT = dtype == AGF_F32 ? 32 : pair ? layout_pick_ct(Cp) : 64;
     p.xshift = pair ? (pad & 1) : 0;
     p.tilesW = (W + 2 * pad + p.xshift + 63) / 64; p.tilesC = (Cp + CT - 1) / CT;
     const int64_t gx = (int64_t)p.tilesW * p.tilesC * (H + 2 * pad);
@@ -185,8 +217,11 @@ static int planar_to_cl_pad_impl(const void* x, void* y, const float* scale, int
         if (scale) hipLaunchKernelGGL((planar_to_cl_pad_kernel<uint32_t, 32, 2>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((planar_to_cl_pad_kernel<uint32_t, 32>), grid, dim3(256), 0, st, p);
     } else if (pair) {
-        if (scale) hipLaunchKernelGGL((planar_to_cl_pad_kernel<uint16_t, 64, 1, true>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((planar_to_cl_pad_kernel<uint16_t, 64, 0, true>), grid, dim3(256), 0, st, p);
+#define P2C_S(ct) hipLaunchKernelGGL((planar_to_cl_pad_kernel<uint16_t, ct, 1, true>), grid, dim3(256), 0, st, p);
+#define P2C_N(ct) hipLaunchKernelGGL((planar_to_cl_pad_kernel<uint16_t, ct, 0, true>), grid, dim3(256), 0, st, p);
+        if (scale) { LAYOUT_CT_SWITCH(CT, P2C_S) } else { LAYOUT_CT_SWITCH(CT, P2C_N) }
+#undef P2C_S
+#undef P2C_N
     } else {
         if (scale) hipLaunchKernelGGL((planar_to_cl_pad_kernel<uint16_t, 64, 1>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((planar_to_cl_pad_kernel<uint16_t, 64>), grid, dim3(256), 0, st, p);
@@ -214,19 +249,22 @@ static int cl_to_planar_crop_impl(const void* x, void* y, const float* scale, in
     AGF_CHECK(((uintptr_t)x % 16) == 0, "cl_to_planar_crop: x must be 16-byte aligned");
     AGF_CHECK(!scale || dtype != AGF_F16, "cl_to_planar_crop_scaled: bf16 or f32");
     p.scale = scale;
-    const int CT = dtype == AGF_F32 ? 32 : 64;
+    const bool pair = (W % 2) == 0 && ((uintptr_t)y % 4) == 0;
+    const int CT = dtype == AGF_F32 ? 32 : pair ? layout_pick_ct((C + 7) / 8 * 8) : 64;
     p.tilesW = (W + 63) / 64; p.tilesC = (C + CT - 1) / CT;
     const int64_t gx = (int64_t)p.tilesW * p.tilesC * H;
     AGF_CHECK(gx < (1ll << 31) && N < 65536, "cl_to_planar_crop: tensor too large");
     dim3 grid((unsigned)gx, (unsigned)N);
     hipStream_t st = (hipStream_t)stream;
-    const bool pair = (W % 2) == 0 && ((uintptr_t)y % 4) == 0;
     if (dtype == AGF_F32) {
         if (scale) hipLaunchKernelGGL((cl_to_planar_crop_kernel<uint32_t, 32, false, 2>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((cl_to_planar_crop_kernel<uint32_t, 32>), grid, dim3(256), 0, st, p);
     } else if (pair) {
-        if (scale) hipLaunchKernelGGL((cl_to_planar_crop_kernel<uint16_t, 64, true, 1>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((cl_to_planar_crop_kernel<uint16_t, 64, true>), grid, dim3(256), 0, st, p);
+#define C2P_S(ct) hipLaunchKernelGGL((cl_to_planar_crop_kernel<uint16_t, ct, true, 1>), grid, dim3(256), 0, st, p);
+#define C2P_N(ct) hipLaunchKernelGGL((cl_to_planar_crop_kernel<uint16_t, ct, true>), grid, dim3(256), 0, st, p);
+        if (scale) { LAYOUT_CT_SWITCH(CT, C2P_S) } else { LAYOUT_CT_SWITCH(CT, C2P_N) }
+#undef C2P_S
+#undef C2P_N
     } else {
         if (scale) hipLaunchKernelGGL((cl_to_planar_crop_kernel<uint16_t, 64, false, 1>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((cl_to_planar_crop_kernel<uint16_t, 64>), grid, dim3(256), 0, st, p);
