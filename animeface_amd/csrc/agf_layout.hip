@@ -179,6 +179,9 @@ static int layout_pick_ct(int Cp) {
     if (Cp <= 80) return 80;
     return 64;          // (several tiles: 56 for 112 / 168 channels wastes nothing and was measured 7-9 % SLOWER than 64, gpurun r05: tools/bench_layout.py)
 }
+#ifndef LAYOUT_PT
+#define LAYOUT_PT 64            // pixels per tile of the 16-bit dword (PAIR) kernels
+#endif
 #define LAYOUT_CT_SWITCH(CT, CALL)                                                      \
     switch (CT) {                                                                      \
         case 32: CALL(32) break; case 48: CALL(48) break; case 56: CALL(56) break;     \
@@ -208,7 +211,8 @@ static int planar_to_cl_pad_impl(const void* x, void* y, const float* scale, int
     const bool pair = dtype != AGF_F32 && (W % 2) == 0 && ((uintptr_t)x % 4) == 0;
     const int CT = dtype == AGF_F32 ? 32 : pair ? layout_pick_ct(Cp) : 64;
     p.xshift = pair ? (pad & 1) : 0;
-    p.tilesW = (W + 2 * pad + p.xshift + 63) / 64; p.tilesC = (Cp + CT - 1) / CT;
+    const int PT = pair ? LAYOUT_PT : 64;
+    p.tilesW = (W + 2 * pad + p.xshift + PT - 1) / PT; p.tilesC = (Cp + CT - 1) / CT;
     const int64_t gx = (int64_t)p.tilesW * p.tilesC * (H + 2 * pad);
     AGF_CHECK(gx < (1ll << 31) && N < 65536, "planar_to_cl_pad: tensor too large");
     dim3 grid((unsigned)gx, (unsigned)N);
@@ -217,8 +221,8 @@ static int planar_to_cl_pad_impl(const void* x, void* y, const float* scale, int
         if (scale) hipLaunchKernelGGL((planar_to_cl_pad_kernel<uint32_t, 32, 2>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((planar_to_cl_pad_kernel<uint32_t, 32>), grid, dim3(256), 0, st, p);
     } else if (pair) {
-#define P2C_S(ct) hipLaunchKernelGGL((planar_to_cl_pad_kernel<uint16_t, ct, 1, true>), grid, dim3(256), 0, st, p);
-#define P2C_N(ct) hipLaunchKernelGGL((planar_to_cl_pad_kernel<uint16_t, ct, 0, true>), grid, dim3(256), 0, st, p);
+#define P2C_S(ct) hipLaunchKernelGGL((planar_to_cl_pad_kernel<uint16_t, ct, 1, true, LAYOUT_PT>), grid, dim3(256), 0, st, p);
+#define P2C_N(ct) hipLaunchKernelGGL((planar_to_cl_pad_kernel<uint16_t, ct, 0, true, LAYOUT_PT>), grid, dim3(256), 0, st, p);
         if (scale) { LAYOUT_CT_SWITCH(CT, P2C_S) } else { LAYOUT_CT_SWITCH(CT, P2C_N) }
 #undef P2C_S
 #undef P2C_N
@@ -251,7 +255,8 @@ static int cl_to_planar_crop_impl(const void* x, void* y, const float* scale, in
     p.scale = scale;
     const bool pair = (W % 2) == 0 && ((uintptr_t)y % 4) == 0;
     const int CT = dtype == AGF_F32 ? 32 : pair ? layout_pick_ct((C + 7) / 8 * 8) : 64;
-    p.tilesW = (W + 63) / 64; p.tilesC = (C + CT - 1) / CT;
+    const int PT = (pair && dtype != AGF_F32) ? LAYOUT_PT : 64;
+    p.tilesW = (W + PT - 1) / PT; p.tilesC = (C + CT - 1) / CT;
     const int64_t gx = (int64_t)p.tilesW * p.tilesC * H;
     AGF_CHECK(gx < (1ll << 31) && N < 65536, "cl_to_planar_crop: tensor too large");
     dim3 grid((unsigned)gx, (unsigned)N);
@@ -260,8 +265,8 @@ static int cl_to_planar_crop_impl(const void* x, void* y, const float* scale, in
         if (scale) hipLaunchKernelGGL((cl_to_planar_crop_kernel<uint32_t, 32, false, 2>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((cl_to_planar_crop_kernel<uint32_t, 32>), grid, dim3(256), 0, st, p);
     } else if (pair) {
-#define C2P_S(ct) hipLaunchKernelGGL((cl_to_planar_crop_kernel<uint16_t, ct, true, 1>), grid, dim3(256), 0, st, p);
-#define C2P_N(ct) hipLaunchKernelGGL((cl_to_planar_crop_kernel<uint16_t, ct, true>), grid, dim3(256), 0, st, p);
+#define C2P_S(ct) hipLaunchKernelGGL((cl_to_planar_crop_kernel<uint16_t, ct, true, 1, LAYOUT_PT>), grid, dim3(256), 0, st, p);
+#define C2P_N(ct) hipLaunchKernelGGL((cl_to_planar_crop_kernel<uint16_t, ct, true, 0, LAYOUT_PT>), grid, dim3(256), 0, st, p);
         if (scale) { LAYOUT_CT_SWITCH(CT, C2P_S) } else { LAYOUT_CT_SWITCH(CT, C2P_N) }
 #undef C2P_S
 #undef C2P_N
