@@ -1856,7 +1856,10 @@ static int launch_fwd(const ConvParams& p, hipStream_t st) {
     constexpr int dl = 1;
     if (dl && KS == 3 && MT == 2 && !p.in_scale && !p.flat && !p.mask_y) {        // (a bf16 mask: the generic 8-wave kernel below; the networks pass bits)
         const bool plain = KS == 3 && !p.mask_bits && !p.res_pooled && !p.residual && p.vecStore == 2;
-        const int rc = p.Cout <= 64 ? (plain ? launch_fwd_dl<KS, 2, 4, 612, 1, 4, false, true>(p, st) : launch_fwd_dl<KS, 2, 4, 612, 1, 4>(p, st))
+#ifndef AGF_DL_CO64_MAX
+#define AGF_DL_CO64_MAX 64      // (probe: the 4-wave 64-channel tile, two blocks per CU, for wider layers too)
+#endif
+        const int rc = p.Cout <= AGF_DL_CO64_MAX ? (plain ? launch_fwd_dl<KS, 2, 4, 612, 1, 4, false, true>(p, st) : launch_fwd_dl<KS, 2, 4, 612, 1, 4>(p, st))
                                     : (plain ? launch_fwd_dl<KS, 2, 4, 612, 2, 4, false, true>(p, st) : launch_fwd_dl<KS, 2, 4, 612, 2, 4>(p, st));
         if (rc != AGF_ENOKERNEL) return rc;
     }

@@ -579,9 +579,9 @@ def conv2d(x, w, s_in=None, s_out=None):
 # fused epilogue:  y = lrelu( s_out * conv(x * s_in, w) + bias + noise )   in ONE launch, with a fused backward
 
 def _inv_scale(s):
-    """1 / s with 0 where s is 0 (the reciprocal of a style scale folded into a stored activation)."""
-    s = s.float()
-    return torch.where(s != 0, 1.0 / s, torch.zeros_like(s))
+    """1 / s with 0 where s is 0 (the reciprocal of a style scale folded into a stored activation).  Two launches (reciprocal, nan_to_num: 1 / 0 = inf -> 0)
+    instead of the five of ``where(s != 0, 1 / s, 0)``: the call sits in six backward nodes of a StyleGAN2 iteration."""
+    return torch.nan_to_num(torch.reciprocal(s.float()), nan=0.0, posinf=0.0, neginf=0.0)
 
 
 def act_bwd_reduce_raw(dy, y, noise, alpha, want_sums, g_scale=None):
