@@ -123,7 +123,11 @@ __global__ void __launch_bounds__(256) cl_to_planar_crop_kernel(LayoutParams p) 
             const int px = i / GROUPS, g = i - px * GROUPS;
             const int xi = x0 + px, cc = c0 + g * VEC;
             vv[k] = (u32x4){0u, 0u, 0u, 0u};
+#ifdef LAYOUT_NT_LOAD
+            if (i < PT * GROUPS && xi < p.W && cc < p.Cp) vv[k] = __builtin_nontemporal_load((const u32x4*)(xrow + (int64_t)xi * p.Cp + cc));
+#else
             if (i < PT * GROUPS && xi < p.W && cc < p.Cp) vv[k] = *(const u32x4*)(xrow + (int64_t)xi * p.Cp + cc);
+#endif
         }
 #pragma unroll
         for (int k = 0; k < NV; k++) {
@@ -151,7 +155,11 @@ __global__ void __launch_bounds__(256) cl_to_planar_crop_kernel(LayoutParams p) 
                     Pack16<bf16_t>::unpack(w, lo, hi);
                     w = Pack16<bf16_t>::pack(lo * sc, hi * sc);
                 }
+#ifdef LAYOUT_NT_STORE
+                __builtin_nontemporal_store(w, (uint32_t*)(yb + (int64_t)cc * p.H * p.W + xi));
+#else
                 *(uint32_t*)(yb + (int64_t)cc * p.H * p.W + xi) = w;
+#endif
             }
         }
         return;
@@ -181,6 +189,9 @@ static int layout_pick_ct(int Cp) {
 }
 #ifndef LAYOUT_PT
 #define LAYOUT_PT 64            // pixels per tile of the 16-bit dword (PAIR) kernels
+#endif
+#ifndef LAYOUT_PT_C2P
+#define LAYOUT_PT_C2P LAYOUT_PT   // ... of cl_to_planar_crop (its planar STORES are the slow side: 128-byte runs per channel row at 64 pixels)
 #endif
 #define LAYOUT_CT_SWITCH(CT, CALL)                                                      \
     switch (CT) {                                                                      \
@@ -255,7 +266,7 @@ static int cl_to_planar_crop_impl(const void* x, void* y, const float* scale, in
     p.scale = scale;
     const bool pair = (W % 2) == 0 && ((uintptr_t)y % 4) == 0;
     const int CT = dtype == AGF_F32 ? 32 : pair ? layout_pick_ct((C + 7) / 8 * 8) : 64;
-    const int PT = (pair && dtype != AGF_F32) ? LAYOUT_PT : 64;
+    const int PT = (pair && dtype != AGF_F32) ? LAYOUT_PT_C2P : 64;
     p.tilesW = (W + PT - 1) / PT; p.tilesC = (C + CT - 1) / CT;
     const int64_t gx = (int64_t)p.tilesW * p.tilesC * H;
     AGF_CHECK(gx < (1ll << 31) && N < 65536, "cl_to_planar_crop: tensor too large");
@@ -265,8 +276,8 @@ static int cl_to_planar_crop_impl(const void* x, void* y, const float* scale, in
         if (scale) hipLaunchKernelGGL((cl_to_planar_crop_kernel<uint32_t, 32, false, 2>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((cl_to_planar_crop_kernel<uint32_t, 32>), grid, dim3(256), 0, st, p);
     } else if (pair) {
-#define C2P_S(ct) hipLaunchKernelGGL((cl_to_planar_crop_kernel<uint16_t, ct, true, 1, LAYOUT_PT>), grid, dim3(256), 0, st, p);
-#define C2P_N(ct) hipLaunchKernelGGL((cl_to_planar_crop_kernel<uint16_t, ct, true, 0, LAYOUT_PT>), grid, dim3(256), 0, st, p);
+#define C2P_S(ct) hipLaunchKernelGGL((cl_to_planar_crop_kernel<uint16_t, ct, true, 1, LAYOUT_PT_C2P>), grid, dim3(256), 0, st, p);
+#define C2P_N(ct) hipLaunchKernelGGL((cl_to_planar_crop_kernel<uint16_t, ct, true, 0, LAYOUT_PT_C2P>), grid, dim3(256), 0, st, p);
         if (scale) { LAYOUT_CT_SWITCH(CT, C2P_S) } else { LAYOUT_CT_SWITCH(CT, C2P_N) }
 #undef C2P_S
 #undef C2P_N
