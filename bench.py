@@ -384,7 +384,7 @@ def main():
     # the worst case "G+D+R1 step" literally names: the R1 penalty on EVERY iteration; a few extra steps after the
     # timed window, forced onto the lazy-R1 branch, rank-local timing is enough for this side figure
     step = eager_step if not use_graphs else step
-    r1_ms, timer_r1 = None, None
+    r1_ms, timer_r1, r1_clocks = None, None, None
     if not args.no_r1_every_step:
         step = eager_step
         saved = step.batches_done
@@ -395,12 +395,14 @@ def main():
         step(real)
         C.KernelTimer.active = None
         barrier()
+        smi_r1 = SmiSampler(delay=0.05) if rank == 0 else None       # clock / power of this leg too (it is not the regime of the timed window)
         t1 = time.perf_counter()
         for _ in range(n_r1):
             step.batches_done = 16
             step(real)
         barrier()
         r1_ms = (time.perf_counter() - t1) / n_r1 * 1e3
+        r1_clocks = smi_r1.result() if smi_r1 is not None else None
         step.batches_done = saved
 
     # BASELINE.json configs[2] literally reads "StyleGAN2 256x256 + ADA + R1": the same iteration with the adaptive augmentation pipe
@@ -488,6 +490,7 @@ def main():
             out['deterministic'] = True
         if r1_ms is not None:
             out['r1_every_step'] = {'value': round(args.batch * world / (r1_ms * 1e-3), 2), 'unit': 'img/s', 'ms_per_step': round(r1_ms, 3),
+                                    'execution': 'eager launches (no graph, hence no pace choice)', 'clocks': r1_clocks,
                                     'note': 'the lazy-R1 iteration (penalty replaces the GAN loss) on every step: 4 steps after the timed window'}
         if ada_out is not None:
             out['ada_variant'] = ada_out
