@@ -535,6 +535,10 @@ __global__ void __launch_bounds__(64 * NWM * NWN, OCC) conv2d_fwd_kernel(ConvPar
     constexpr int TAPS = KS * KS;
     constexpr int HALO = KS / 2;
     constexpr int BM = 32 * NWM * MT;
+#ifndef AGF_FRAG_AHEAD
+#define AGF_FRAG_AHEAD 1
+#endif
+    constexpr bool FRAG_AHEAD = AGF_FRAG_AHEAD != 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* sW = (bf16_t*)smem_raw;                                  // [TAPS][BM][PITCH]
     bf16_t* sX = sW + TAPS * BM * PITCH;                             // [P][PITCH]
@@ -544,9 +548,12 @@ __global__ void __launch_bounds__(64 * NWM * NWN, OCC) conv2d_fwd_kernel(ConvPar
     const int xcd = b & 7, slot = b >> 3;
     // xcdBand: XCD x owns the contiguous band of pixel tiles [x * xcdBand, (x+1) * xcdBand) -- tiles that share halo rows run on
     // the same XCD at about the same time, so its L2 serves the halo re-reads; 0 = tiles interleaved over the XCDs
-    const int pixTile = p.xcdBand ? xcd * p.xcdBand + slot / p.tilesCo : (slot / p.tilesCo) * 8 + xcd;
-    const int coTile = slot % p.tilesCo;
-    if (pixTile >= p.pixTiles || (p.xcdBand && slot / p.tilesCo >= p.xcdBand)) return;
+    // coXcd (small maps, more weight bytes than activation bytes): XCD x owns the co tiles == x (mod 8) of EVERY pixel tile, so its L2 keeps one
+    // eighth of the weights and serves them to all of its blocks (pixel tiles over the XCDs: every L2 streams all of the weights)
+    const int coPer = p.tilesCo >> 3;
+    const int pixTile = p.coXcd ? slot / coPer : p.xcdBand ? xcd * p.xcdBand + slot / p.tilesCo : (slot / p.tilesCo) * 8 + xcd;
+    const int coTile = p.coXcd ? xcd + 8 * (slot % coPer) : slot % p.tilesCo;
+    if (pixTile >= p.pixTiles || (!p.coXcd && p.xcdBand && slot / p.tilesCo >= p.xcdBand)) return;
     // rectangular tiling: (TI images) x TH x TW pixels.  Flat tiling (maps whose width is not a multiple of the tile: StyleGAN3's
     // 38 / 54 / 66 / 86-wide maps waste up to half of a rectangular tile): 128*NWN consecutive pixels of one image in row-major
     // order; the patch is then the rows they touch plus halo, TW = W and TH = the most rows a tile can span.
@@ -678,13 +685,67 @@ __global__ void __launch_bounds__(64 * NWM * NWN, OCC) conv2d_fwd_kernel(ConvPar
         }
     };
 
-    const int nChunks = (p.Cin + KC - 1) / KC;
-    load_chunk(0);
-    store_chunk();
-    __syncthreads();
-    for (int ch = 0; ch < nChunks; ch++) {
-        if (ch + 1 < nChunks) load_chunk((ch + 1) * KC);
+    int chBeg = 0, nChunks = (p.Cin + KC - 1) / KC;
+    if (p.splitK > 1) {                                   // this block's slice of the chunks (the host made every slice non-empty)
+        const int per = (nChunks + p.splitK - 1) / p.splitK;
+        chBeg = (int)blockIdx.y * per;
+        nChunks = chBeg + per < nChunks ? chBeg + per : nChunks;
+    }
+    auto contract = [&]() {
         // ---- contraction over taps and the chunk's two 16-channel k-steps ----
+        if constexpr (MT == 1 && FRAG_AHEAD) {
+            // Fragment reads run AHEAD of the matrix instructions that use them.  Written the plain way (below) the compiler emits
+            // ds_read, s_waitcnt lgkmcnt(0), v_mfma per instruction, reusing one fragment register: every MFMA waits out an LDS round
+            // trip (the 64 x 64 tile, one wave per SIMD: 1.4 us per chunk for 0.24 us of matrix work).  NJ == 1: a ring of 4 k-steps;
+            // NJ >= 2: A one step ahead, each B register refilled for the next step right after its MFMA issues.
+            constexpr int STEPS = TAPS * (KC / 16);
+            auto ldA = [&](int st) { const int tap = st / (KC / 16), ks = st % (KC / 16);
+                                     return *(const bf16x8*)(sW + tap * BM * PITCH + aBase[0] + ks * 16); };
+            auto ldB = [&](int st, int j) { const int tap = st / (KC / 16), ks = st % (KC / 16);
+                                            return *(const bf16x8*)(sX + ((tap / KS) * PW + (tap % KS)) * PITCH + bBase[j] + ks * 16); };
+            if constexpr (NJ == 1) {
+                constexpr int R = STEPS < 4 ? STEPS : 4;
+                bf16x8 a[R], b[R];
+#pragma unroll
+                for (int st = 0; st < R - 1; st++) { a[st] = ldA(st); b[st] = ldB(st, 0); }
+#pragma unroll
+                for (int st = 0; st < STEPS; st++) {
+                    if (st + R - 1 < STEPS) { a[(st + R - 1) % R] = ldA(st + R - 1); b[(st + R - 1) % R] = ldB(st + R - 1, 0); }
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[st % R], b[st % R], acc[0][0], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 * (R - 1), 0);
+#pragma unroll
+                for (int st = 0; st < STEPS; st++) {
+                    if (st + R - 1 < STEPS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                }
+            } else {
+                bf16x8 a[2], b[NJ];
+                a[0] = ldA(0);
+#pragma unroll
+                for (int j = 0; j < NJ; j++) b[j] = ldB(0, j);
+#pragma unroll
+                for (int st = 0; st < STEPS; st++) {
+                    if (st + 1 < STEPS) a[(st + 1) & 1] = ldA(st + 1);
+#pragma unroll
+                    for (int j = 0; j < NJ; j++) {
+                        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[st & 1], b[j], acc[0][j], 0, 0, 0);
+                        if (st + 1 < STEPS) b[j] = ldB(st + 1, j);
+                    }
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, 1 + NJ, 0);
+#pragma unroll
+                for (int st = 0; st < STEPS; st++) {
+                    if (st + 1 < STEPS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+                    for (int j = 0; j < NJ; j++) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        if (st + 1 < STEPS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int kh = 0; kh < KS; kh++) {
 #pragma unroll
@@ -707,6 +768,13 @@ __global__ void __launch_bounds__(64 * NWM * NWN, OCC) conv2d_fwd_kernel(ConvPar
                 }
             }
         }
+    };
+    load_chunk(chBeg * KC);
+    store_chunk();
+    __syncthreads();
+    for (int ch = chBeg; ch < nChunks; ch++) {
+        if (ch + 1 < nChunks) load_chunk((ch + 1) * KC);
+        contract();
         if (ch + 1 < nChunks) {
             __syncthreads();                              // every wave is done reading this chunk
             store_chunk();
@@ -714,7 +782,61 @@ __global__ void __launch_bounds__(64 * NWM * NWN, OCC) conv2d_fwd_kernel(ConvPar
         }
     }
 
-    if (POOL || p.vecStore == 2) conv_epilogue_pl<MT, NJ, POOL, false, MT == 2 ? 0 : 1>(p, acc, smem_raw, wave, lane, wm, wn, n0, h0, w0, flatP0, co0, NWN, NWM * NWN, pixTile & 255);
+    if (p.splitK > 1) {
+        // ---- channel slices of one tile meet here: every slice parks its accumulators (register layout, 16 bytes per lane and store:
+        //      fully coalesced; write-through (sc1) stores, so no L2 write-back is needed to publish them -- plain stores + an agent-scope
+        //      release per block measured 1.5-2x slower for the whole launch), the last one to arrive adds all of them IN SLICE ORDER (its
+        //      own included, from memory: the sum does not depend on which slice came last) and carries on into the epilogue. ----
+        constexpr int NV = MT * NJ * 4;
+        const int tileId = pixTile * p.tilesCo + coTile;
+        f32x4* slab = (f32x4*)p.splitWs + (size_t)tileId * p.splitK * (NV * NTHR);
+        f32x4* mine = slab + (size_t)blockIdx.y * (NV * NTHR);
+        const __amdgpu_buffer_rsrc_t mRes = __builtin_amdgcn_make_buffer_rsrc((void*)mine, 0, NV * NTHR * 16, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < MT; i++)
+#pragma unroll
+            for (int j = 0; j < NJ; j++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const f32x4 v = f32x4{acc[i][j][4 * r], acc[i][j][4 * r + 1], acc[i][j][4 * r + 2], acc[i][j][4 * r + 3]};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), mRes, (((i * NJ + j) * 4 + r) * NTHR + tid) * 16, 0, 16 /* sc1 */);
+                }
+        // publish: every wave drains its write-through stores, then the ticket; the last arriver's agent-scope acquire drops its CU's L1
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                  // (also: every wave is done with sW / sX)
+        unsigned* flag = (unsigned*)smem_raw;
+        if (tid == 0) {
+            const unsigned old = __hip_atomic_fetch_add(p.splitCnt + tileId, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == (unsigned)p.splitK - 1) {
+                __hip_atomic_store(p.splitCnt + tileId, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            *flag = old;
+        }
+        __syncthreads();
+        const unsigned arrived = *flag;
+        __syncthreads();                                  // (the epilogue reuses the LDS)
+        if (arrived != (unsigned)p.splitK - 1) return;
+#pragma unroll
+        for (int i = 0; i < MT; i++)
+#pragma unroll
+            for (int j = 0; j < NJ; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+        for (int s = 0; s < p.splitK; s++) {
+            const f32x4* src = slab + (size_t)s * (NV * NTHR);
+#pragma unroll
+            for (int i = 0; i < MT; i++)
+#pragma unroll
+                for (int j = 0; j < NJ; j++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const f32x4 v = src[((i * NJ + j) * 4 + r) * NTHR + tid];
+                        acc[i][j][4 * r] += v.x; acc[i][j][4 * r + 1] += v.y; acc[i][j][4 * r + 2] += v.z; acc[i][j][4 * r + 3] += v.w;
+                    }
+        }
+    }
+    if (POOL || p.vecStore == 2) conv_epilogue_pl<MT, NJ, POOL, false, (MT == 2 && NJ == 4) ? 0 : 1>(p, acc, smem_raw, wave, lane, wm, wn, n0, h0, w0, flatP0, co0, NWN, NWM * NWN, pixTile & 255);
     else conv_epilogue<MT, NJ>(p, acc, smem_raw, wave, lane, wm, wn, n0, h0, w0, flatP0, co0, NWN, NWM * NWN, pixTile & 255);
 }
 
@@ -751,9 +873,12 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_dl_kernel(ConvPa
     const int xcd = b & 7, slot = b >> 3;
     // xcdBand: XCD x owns the contiguous band of pixel tiles [x * xcdBand, (x+1) * xcdBand) -- tiles that share halo rows run on
     // the same XCD at about the same time, so its L2 serves the halo re-reads; 0 = tiles interleaved over the XCDs
-    const int pixTile = p.xcdBand ? xcd * p.xcdBand + slot / p.tilesCo : (slot / p.tilesCo) * 8 + xcd;
-    const int coTile = slot % p.tilesCo;
-    if (pixTile >= p.pixTiles || (p.xcdBand && slot / p.tilesCo >= p.xcdBand)) return;
+    // coXcd (small maps, more weight bytes than activation bytes): XCD x owns the co tiles == x (mod 8) of EVERY pixel tile, so its L2 keeps one
+    // eighth of the weights and serves them to all of its blocks (pixel tiles over the XCDs: every L2 streams all of the weights)
+    const int coPer = p.tilesCo >> 3;
+    const int pixTile = p.coXcd ? slot / coPer : p.xcdBand ? xcd * p.xcdBand + slot / p.tilesCo : (slot / p.tilesCo) * 8 + xcd;
+    const int coTile = p.coXcd ? xcd + 8 * (slot % coPer) : slot % p.tilesCo;
+    if (pixTile >= p.pixTiles || (!p.coXcd && p.xcdBand && slot / p.tilesCo >= p.xcdBand)) return;
     int tq = pixTile;
     const int tw = tq % p.tilesW; tq /= p.tilesW;
     const int th = tq % p.tilesH;
@@ -959,9 +1084,12 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_taps_kernel(TapP
 
     const int b = blockIdx.x;
     const int xcd = b & 7, slot = b >> 3;
-    const int pixTile = p.xcdBand ? xcd * p.xcdBand + slot / p.tilesCo : (slot / p.tilesCo) * 8 + xcd;
-    const int coTile = slot % p.tilesCo;
-    if (pixTile >= p.pixTiles || (p.xcdBand && slot / p.tilesCo >= p.xcdBand)) return;
+    // coXcd (small maps, more weight bytes than activation bytes): XCD x owns the co tiles == x (mod 8) of EVERY pixel tile, so its L2 keeps one
+    // eighth of the weights and serves them to all of its blocks (pixel tiles over the XCDs: every L2 streams all of the weights)
+    const int coPer = p.tilesCo >> 3;
+    const int pixTile = p.coXcd ? slot / coPer : p.xcdBand ? xcd * p.xcdBand + slot / p.tilesCo : (slot / p.tilesCo) * 8 + xcd;
+    const int coTile = p.coXcd ? xcd + 8 * (slot % coPer) : slot % p.tilesCo;
+    if (pixTile >= p.pixTiles || (!p.coXcd && p.xcdBand && slot / p.tilesCo >= p.xcdBand)) return;
     int tq = pixTile;
     const int tw = tq % p.tilesW; tq /= p.tilesW;
     const int th = tq % p.tilesH;
@@ -1778,8 +1906,9 @@ static int launch_fwd_v(const ConvParams& p0, hipStream_t st) {
     if (P > PMAX) { agf_set_error("conv2d_fwd: internal patch %d exceeds %d", P, PMAX); return AGF_ENOKERNEL; }
     size_t lds = (size_t)(TAPS * BM + P) * PITCH * sizeof(bf16_t);
     if (lds > 160 * 1024) { agf_set_error("conv2d_fwd: tile needs %zu bytes of LDS", lds); return AGF_ENOKERNEL; }
-    const int slots = ((p.pixTiles + 7) / 8) * p.tilesCo;
-    dim3 grid((unsigned)(slots * 8)), block(64 * NWM * NWN);
+    p.coXcd = ((p.tilesCo % 8) == 0 && p.H * p.W <= 64 && (int64_t)p.N * p.H * p.W < (int64_t)KS * KS * p.Cout) ? 1 : 0;
+    const int slots = p.coXcd ? p.pixTiles * (p.tilesCo / 8) : ((p.pixTiles + 7) / 8) * p.tilesCo;
+    dim3 grid((unsigned)(slots * 8), (unsigned)(p.splitK > 1 ? p.splitK : 1)), block(64 * NWM * NWN);
     hipError_t e = hipFuncSetAttribute((const void*)conv2d_fwd_kernel<KS, MT, SC, KC, NWN, PMAX, NWM, NJ, OCC, POOL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { agf_set_error("conv2d_fwd: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e)); return AGF_ELAUNCH; }
     hipLaunchKernelGGL((conv2d_fwd_kernel<KS, MT, SC, KC, NWN, PMAX, NWM, NJ, OCC, POOL>), grid, block, lds, st, p);
@@ -1867,6 +1996,21 @@ static int launch_fwd(const ConvParams& p, hipStream_t st) {
     if (MT == 2 && p.Cout <= 64) return p.in_scale ? launch_fwd_v<KS, 2, true, 16, 4, 612, 1>(p, st) : launch_fwd_v<KS, 2, false, 16, 4, 612, 1>(p, st);
     if (MT == 2) return p.in_scale ? launch_fwd_v<KS, 2, true, 16, 4, 612>(p, st) : launch_fwd_v<KS, 2, false, 16, 4, 612>(p, st);
     return p.in_scale ? launch_fwd_v<KS, 1, true, 32, 2, (KS == 3 ? 576 : 256)>(p, st) : launch_fwd_v<KS, 1, false, 32, 2, (KS == 3 ? 576 : 256)>(p, st);
+}
+
+// scratch of the channel-sliced small-map launches: [g_split_tiles] arrival counters (zero between launches) + accumulator slabs
+static float* g_split_ws = nullptr;
+static unsigned* g_split_cnt = nullptr;
+static int64_t g_split_ws_bytes = 0;
+static const int g_split_tiles = 16384;
+
+extern "C" int agf_conv2d_set_split_workspace(void* ws, int64_t bytes) {
+    if (!ws || bytes < (int64_t)g_split_tiles * 4 + (1 << 20)) { g_split_ws = nullptr; g_split_cnt = nullptr; g_split_ws_bytes = 0; return AGF_OK; }
+    AGF_CHECK(((uintptr_t)ws % 256) == 0, "conv2d_set_split_workspace: the buffer must be 256-byte aligned");
+    g_split_cnt = (unsigned*)ws;
+    g_split_ws = (float*)((char*)ws + (size_t)g_split_tiles * 4);
+    g_split_ws_bytes = bytes - (int64_t)g_split_tiles * 4;
+    return AGF_OK;
 }
 
 static int conv2d_fwd_impl(const void* x, const void* w, void* y,
@@ -1991,6 +2135,10 @@ static int conv2d_fwd_impl(const void* x, const void* w, void* y,
     if (AGF_SMALL_MODE >= 2 && narrowOK && smallTile && H * W == 16 && (int64_t)N * H * W >= 1024) narrow = true;
     if (smallTile && !narrow) blockPix = 64;
     p.narrow = narrow ? 1 : 0;
+    // 4x4 maps of the 512-channel blocks at batch <= 64 (and 8x8 at batch <= 16): at most 128 tiles of 64 x 64 -- half of the CUs, one
+    // block each.  The input channels are cut into 2-4 slices over blockIdx.y (conv2d_fwd_kernel, splitK): 27 -> 18 us for 512 -> 512
+    // at batch 64.  (More tiles than that: no gain measured; 128 x 128 tiles with slices: slower -- profiles/r05_small_map_conv.txt)
+    const bool sliced = g_split_ws && smallTile && !narrow && Cout >= 128 && Cin >= 128 && !pool_mask;
     p.TW = pow2_ceil(W) < 32 ? pow2_ceil(W) : 32;
     int th = pow2_ceil(H);
     p.TH = th < blockPix / p.TW ? th : blockPix / p.TW;
@@ -2019,6 +2167,15 @@ static int conv2d_fwd_impl(const void* x, const void* w, void* y,
         }
     }
     p.tilesCo = (Cout + 64 * MT - 1) / (64 * MT);
+    p.splitK = 1;
+    if (sliced && !p.flat && p.TI * p.TH * p.TW == 64) {
+        const int tiles = p.pixTiles * ((Cout + 63) / 64), nCh = (Cin + 31) / 32;
+        int S = 1;
+        while (S < 4 && tiles * S * 2 <= 512 && nCh / (S * 2) >= 2) S *= 2;
+        while (S > 1 && (S - 1) * ((nCh + S - 1) / S) >= nCh) S >>= 1;                       // no empty slice
+        if (tiles > 128 || tiles > g_split_tiles || (int64_t)tiles * S * (64 * 64 * 4) > g_split_ws_bytes) S = 1;
+        p.splitK = S; p.splitWs = g_split_ws; p.splitCnt = g_split_cnt;
+    }
     { constexpr int band = 1;
       p.xcdBand = (band && p.pixTiles >= 64) ? (p.pixTiles + 7) / 8 : 0; }
     p.twShift = 0; while ((1 << p.twShift) < p.TW) p.twShift++;

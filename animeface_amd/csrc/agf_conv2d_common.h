@@ -68,8 +68,12 @@ struct ConvParams {
     int flat, flatTiles;      // flat tiling: a tile = 256 consecutive pixels (row-major) of one image; flatTiles = tiles per image
     uint32_t mW;              // magic multiplier for division by W (flat tiling)
     int xcdBand;              // pixel tiles per XCD (contiguous bands), 0 = interleaved
+    int coXcd;                // conv2d_fwd_kernel: co tiles (not pixel tiles) spread over the XCDs
     int narrow;               // 32 co x 256 px tiling of the small maps (launch_fwd)
     int yMul, yOffH, yOffW, yH, yW;   // conv_epilogue: strided store into a [N, yH, yW, Cout] tensor (yMul = 0: the ordinary [N, H, W, Cout])
+    int splitK;               // conv2d_fwd_kernel on the 4x4 / 8x8 maps: blockIdx.y = slice of the input-channel chunks; > 1: partial tiles go to
+    float* splitWs;           //   splitWs [tile][slice][register][thread] (fp32, the accumulator layout as it is), the LAST slice of a tile to arrive
+    unsigned* splitCnt;       //   (splitCnt [tile], self-resetting) adds them in slice order and runs the epilogue
 };
 
 // persistent multi-stage direct-to-LDS kernel (agf_conv2d_pipe.hip); AGF_ENOKERNEL = shape not covered, use the other kernels

@@ -193,6 +193,7 @@ def conv2d_fwd_raw(x, w, in_scale=None, out_scale=None, bias=None, noise=None, r
         residual = residual.to(x.dtype).contiguous(memory_format=torch.channels_last)
     timer = KernelTimer.active
     ev0 = timer.start() if timer is not None else None
+    _lib.ensure_split_workspace(x.device)
     L = _lib.lib()
     if post_scale is not None:
         assert mask_y is None and res_pooled is None

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define AGF_ABI_VERSION 24
+#define AGF_ABI_VERSION 25
 
 /* element types of activation tensors */
 enum { AGF_F32 = 0, AGF_F16 = 1, AGF_BF16 = 2, AGF_F64 = 3 };
@@ -236,6 +236,16 @@ int agf_conv2d_s2_dgrad(const void* dy, const void* wt, void* dz, int dtype,
 int agf_conv2d_s2_dgrad_ft(const void* dy, const void* wft, void* dz, int dtype,
                         int32_t N, int32_t Ho, int32_t Wo, int32_t Cout, int32_t Cin, int32_t zH, int32_t zW,
                         float gain, void* stream);
+
+/* Scratch for the 3x3 launches on 4x4 / 8x8 maps with >= 128 channels each way and at most 128 output tiles of 64 x 64 (the 512-channel
+ * blocks of StyleGAN2 at the bottom of both networks at batch <= 64, reference implementations/StyleGAN2/model.py:291-301, 369-380): such a
+ * launch fills half of the chip at most, so its input channels are cut into 2-4 slices that run as separate workgroups; each slice parks its
+ * fp32 accumulator tile in this buffer and the last slice of a tile to arrive adds them in slice order (the result does not depend on the
+ * arrival order: bit-reproducible) and runs the epilogue.
+ * ws: device memory, 256-byte aligned, the first 64 KB ZERO (arrival counters, left zero by every launch), owned by the caller for as long
+ * as launches may run; bytes >= 64 KB + 1 MB (8 MB + 64 KB covers every shape that is sliced).  null / too small: those launches run
+ * unsliced.  One buffer per process (one process per GPU); launches that use it must not overlap on different streams.  (ABI v25) */
+int agf_conv2d_set_split_workspace(void* ws, int64_t bytes);
 
 /* Style-modulated layers on the streaming (persistent, direct-to-LDS) kernel: the modulation `weight * style` of the reference
  * (implementations/StyleGAN2/model.py:115) is folded into ONE weight tensor per image -- only for the few-channel high-resolution

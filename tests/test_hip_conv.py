@@ -50,6 +50,10 @@ FWD_CASES = [
     (40, 64, 64, 5, 7, 3, None, '64-pixel tiles, ragged 5x7 map'),
     (48, 72, 136, 32, 64, 3, None, 'direct-to-LDS 8-wave (>= 384 tiles of 128 co x 512 px), Cin % 16 == 8, partial co tile'),
     (86, 40, 56, 48, 40, 3, None, '64 co on >= 512 tiles, ragged map, channel tails'),
+    (64, 512, 512, 4, 4, 3, None, '64-pixel tiles, four channel slices (4x4 maps at batch 64)'),
+    (40, 520, 136, 4, 4, 3, None, '64-pixel tiles, channel slices: 17 chunks, partial co tile'),
+    (9, 128, 128, 8, 8, 3, None, '64-pixel tiles (8x8 maps), odd batch, two channel slices'),
+    (128, 512, 512, 8, 8, 3, None, '8x8 maps at batch 128 (256-pixel tiles, unsliced)'),
 ]
 
 
@@ -330,7 +334,7 @@ def test_style_demod_vs_composite(shape):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('shape', [(4, 64, 64, 64, 64, None), (48, 128, 136, 32, 64, None), (16, 64, 64, 128, 128, None), (5, 512, 512, 8, 8, None),
+@pytest.mark.parametrize('shape', [(4, 64, 64, 64, 64, None), (48, 128, 136, 32, 64, None), (16, 64, 64, 128, 128, None), (5, 512, 512, 8, 8, None), (16, 512, 512, 8, 8, None),
                                    (2, 72, 40, 19, 38, None), (8, 64, 32, 256, 256, None), (8, 32, 32, 256, 256, None), (8, 32, 64, 256, 256, None),
                                    (5, 64, 40, 250, 250, None), (16, 128, 64, 128, 128, None), (4, 64, 64, 256, 256, None)])
 @pytest.mark.parametrize('mode', ['mask', 'pooled', 'both'])
@@ -761,6 +765,8 @@ def _bits_reference(y):
     (16, 64, 32, 128, 128),     # 32-channel tile: words leave in pixel pairs
     (16, 512, 512, 16, 16),     # 64 co x 256 px generic tile (MT = 1, NJ = 4)
     (32, 512, 512, 8, 8),       # 64-pixel tiles (NJ = 1)
+    (64, 512, 512, 4, 4),       # the same with channel slices (<= 128 tiles)
+    (16, 512, 512, 8, 8),       # channel slices on 8x8 maps
     (4, 128, 96, 40, 56),       # ragged map, Cout = 3 words
 ])
 def test_sign_bits_of_the_forward_launch_and_the_masked_data_gradient_equal_the_bf16_mask_path(N, Cin, Cout, H, W):
@@ -823,3 +829,16 @@ def test_dblock_backward_with_the_mask_as_bits_is_bit_identical(monkeypatch):
         assert torch.equal(outs[0][0], outs[1][0])
         for a, b in zip(outs[0][1], outs[1][1]):
             assert rel(a, b) < 1e-5, (a.shape, rel(a, b))      # (bias sums: fp32 atomics in another order)
+
+
+@pytest.mark.gpu
+def test_channel_sliced_small_map_launch_is_run_to_run_bit_identical():
+    """The slices of a tile are added in slice order by whichever slice arrives last (conv2d_fwd_kernel, splitK): the output must not
+    depend on the arrival order, and the arrival counters must be back at zero for the next launch."""
+    from animeface_amd.implementations.StyleGAN2 import conv as C
+    x, w, g = make(64, 512, 512, 4, 4, 3, seed=5)
+    s_in = (torch.rand(64, 512, generator=g) + 0.5).to(DEV)
+    wq = C.prep_weights_raw(w.float(), 1.0, torch.bfloat16)[0]
+    y0 = C.conv2d_fwd_raw(x, wq, in_scale=s_in, prepared=True)
+    for _ in range(20):
+        assert torch.equal(C.conv2d_fwd_raw(x, wq, in_scale=s_in, prepared=True), y0)
