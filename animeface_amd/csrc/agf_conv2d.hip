@@ -20,6 +20,7 @@
 // Fused on load : per-(n,ci) input scale (the style modulation), fp32 multiply, rounded once to bf16.
 // Fused on store: per-(n,co) output scale (demodulation), bias[co], noise[n,h,w], residual, leaky ReLU, gain.
 #include "agf_conv2d_common.h"
+#include <type_traits>
 
 // ---- epilogue shared by conv2d_fwd_kernel and conv2d_fwd_dl_kernel.  A lane holds, per accumulator tile, ONE pixel (column) x 4
 //      groups of 4 consecutive channels: written
@@ -1200,30 +1201,43 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_taps_kernel(TapP
     issue_range(0, 0, 0, NP);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int ch = 0; ch < nChunks; ch++) {
+    // One chunk: ntaps k-steps on the current buffer, the next chunk's DMA pieces between the taps' MFMA groups (nine taps: spread over the
+    // first eight; eight: over the first five; fewer: after the first).  NT (0 = run-time tap count) and MORE are compile-time for the common
+    // cases, so that the body is one straight-line block: the fragments of tap t + 1 are requested before the MFMAs of tap t (written with
+    // run-time conditions inside, every join made the compiler drain the LDS queue and every tap paid an LDS round trip).
+    auto chunk = [&](auto NTC, auto MOREC, int ch) {
+        constexpr int NT = decltype(NTC)::value;
+        constexpr bool more = decltype(MOREC)::value;
         const int cur = ch & 1;
-        const bool more = ch + 1 < nChunks;
         const bf16_t* cW = sW + cur * WBUF;
         const bf16_t* cX = sX + cur * XBUF;
+        bf16x8 af[2][MT], bfr[2][NJ];
+        {
+            const int tx = tp.tapX[0];
+#pragma unroll
+            for (int i = 0; i < MT; i++) af[0][i] = *(const bf16x8*)(cW + aBase[i]);
+#pragma unroll
+            for (int j = 0; j < NJ; j++) bfr[0][j] = *(const bf16x8*)(cX + bBase[j] + tx);
+        }
 #pragma unroll
         for (int t = 0; t < MAXT; t++) {
-            if (t < ntaps) {
-                bf16x8 af[MT], bfr[NJ];
-                const int tx = tp.tapX[t];
+            if (NT ? t < NT : t < ntaps) {
+                if (t + 1 < MAXT && (NT ? t + 1 < NT : t + 1 < ntaps)) {
+                    const int tx = tp.tapX[t + 1 < MAXT ? t + 1 : 0];
 #pragma unroll
-                for (int i = 0; i < MT; i++) af[i] = *(const bf16x8*)(cW + t * BM * KC + aBase[i]);
+                    for (int i = 0; i < MT; i++) af[(t + 1) & 1][i] = *(const bf16x8*)(cW + (t + 1) * BM * KC + aBase[i]);
 #pragma unroll
-                for (int j = 0; j < NJ; j++) bfr[j] = *(const bf16x8*)(cX + bBase[j] + tx);
+                    for (int j = 0; j < NJ; j++) bfr[(t + 1) & 1][j] = *(const bf16x8*)(cX + bBase[j] + tx);
+                }
 #pragma unroll
                 for (int i = 0; i < MT; i++)
 #pragma unroll
                     for (int j = 0; j < NJ; j++)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t & 1][i], bfr[t & 1][j], acc[i][j], 0, 0, 0);
             }
-            // the next chunk's DMA pieces between the taps' MFMA groups (nine taps: spread over the first eight; fewer: after the first)
             if (more) {
-                if (ntaps == MAXT) { if (t < MAXT - 1) issue_range((ch + 1) * KCH, cur ^ 1, t * NP / (MAXT - 1), (t + 1) * NP / (MAXT - 1)); }
-                else if (ntaps == 8) { if (t < 5) issue_range((ch + 1) * KCH, cur ^ 1, t * NP / 5, (t + 1) * NP / 5); }
+                if (NT ? NT == MAXT : ntaps == MAXT) { if (t < MAXT - 1) issue_range((ch + 1) * KCH, cur ^ 1, t * NP / (MAXT - 1), (t + 1) * NP / (MAXT - 1)); }
+                else if (NT ? NT == 8 : ntaps == 8) { if (t < 5) issue_range((ch + 1) * KCH, cur ^ 1, t * NP / 5, (t + 1) * NP / 5); }
                 else if (t == 0) issue_range((ch + 1) * KCH, cur ^ 1, 0, NP);
             }
         }
@@ -1231,7 +1245,15 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 2) conv2d_fwd_taps_kernel(TapP
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
-    }
+    };
+    constexpr std::integral_constant<int, 0> NT0{};
+    constexpr std::integral_constant<int, 8> NT8{};
+    constexpr std::integral_constant<int, MAXT> NT9{};
+    constexpr std::true_type MORE{};
+    constexpr std::false_type LAST{};
+    if (ntaps == MAXT)   { for (int ch = 0; ch + 1 < nChunks; ch++) chunk(NT9, MORE, ch); chunk(NT9, LAST, nChunks - 1); }
+    else if (ntaps == 8) { for (int ch = 0; ch + 1 < nChunks; ch++) chunk(NT8, MORE, ch); chunk(NT8, LAST, nChunks - 1); }
+    else                 { for (int ch = 0; ch + 1 < nChunks; ch++) chunk(NT0, MORE, ch); chunk(NT0, LAST, nChunks - 1); }
     conv_epilogue<MT, NJ>(p, acc, smem_raw, wave, lane, wm, wn, n0, h0, w0, 0, co0, NWN, NWM * NWN, pixTile & 255);
 }
 

@@ -23,10 +23,13 @@ ap.add_argument('--steps', type=int, default=8)
 ap.add_argument('--warmup', type=int, default=2)
 ap.add_argument('--fp32', action='store_true')
 ap.add_argument('--no-sumsq', action='store_true', help="model.SUM_SQUARES_KERNEL off: the layers' input statistic through ATen's vector_norm (same-box A/B)")
+ap.add_argument('--s2-min', type=int, default=None, help='model.S2_MIN_CHANNELS (same-box A/B of the strided 3x3 kernel against conv + decimation)')
 ap.add_argument('--eager', action='store_true', help='launch every kernel from the host instead of replaying the recorded iteration (HIP graphs)')
 a = ap.parse_args()
 if a.no_sumsq:
     M.SUM_SQUARES_KERNEL = False
+if a.s2_min is not None:
+    M.S2_MIN_CHANNELS = a.s2_min
 dev = torch.device('cuda')
 dt = torch.float32 if a.fp32 else torch.bfloat16
 torch.manual_seed(0)
