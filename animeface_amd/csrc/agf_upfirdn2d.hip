@@ -34,6 +34,7 @@ struct UpfirdnParams {
     int tileInW, tileInH;
     int cg_shift;                // nhwc_vec: log2(C / VEC) or -1
     const float* chscale;        // nhwc_rows only: [N][C] fp32 or null -- the stored result is multiplied by chscale[n, c] (agf_upfirdn2d_chscale)
+    const void* addend;          // nhwc_rows, 4 x 4 up-sampling only: a tensor like y, or null -- the stored result is FIR(x) + addend (agf_upfirdn2d_add)
 };
 
 #define MAX_FILTER_TAPS 1024     // up to 32x32 (reference limit: 32x32 in the small kernels)
@@ -186,7 +187,7 @@ template <class T> struct RawUnpack<T, 8> {
 // decimation 651 MB (10 input rows per 8 new ones); with four strips 572 / 554 MB (PMC) -- and the launches take 221 instead of 204 us and
 // 135 instead of 128: a quarter of the lanes, each a serial load -> FMA -> store chain per strip, keep fewer loads in flight than the
 // re-read costs.  The kernels move 6.0-6.4 TB/s with one strip per lane, which is what this memory system delivers to any kernel.
-template <class T, int VEC, int UP, int DN, int FW, int FH, int ROWS, int K00, int PD = 2, bool CHS = false, int STRIPS = 1>
+template <class T, int VEC, int UP, int DN, int FW, int FH, int ROWS, int K00, int PD = 2, bool CHS = false, int STRIPS = 1, bool ADD = false>
 __global__ void __launch_bounds__(256, ROWS_WAVES) upfirdn2d_nhwc_rows(UpfirdnParams p) {
     // K00 = (floor(mid0/UP)+1)*UP - mid0 - 1 for the strip's first row: identical for every strip because ROWS*DN is a
     // multiple of UP, so the host passes it as a template argument and every (input row t, output row r) tap index
@@ -309,6 +310,21 @@ __global__ void __launch_bounds__(256, ROWS_WAVES) upfirdn2d_nhwc_rows(UpfirdnPa
             for (int r = 0; r < ROWS; r++) acc[r][i] *= s;
         }
     }
+    if constexpr (ADD) {
+        // the other branch's gradient, added where this one is produced (the residual block of StyleGAN3's discriminator: the data gradient
+        // of the first conv + the adjoint of the skip branch's decimation; an instantiation of its own, as the channel scale above)
+        const char* abn = (const char*)p.addend + (int64_t)n * p.OH * ((int64_t)p.OW * p.C) * (int64_t)sizeof(T);
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) {
+            const int oy = oy0 + r;
+            if (oy < p.OH) {
+                float a[VEC];
+                VecIO<T, VEC>::load((const T*)(abn + (int64_t)oy * p.OW * p.C * (int64_t)sizeof(T) + yo), a);
+#pragma unroll
+                for (int i = 0; i < VEC; i++) acc[r][i] += a[i];
+            }
+        }
+    }
 #pragma unroll
     for (int r = 0; r < ROWS; r++) {
         const int oy = oy0 + r;
@@ -323,6 +339,17 @@ static bool launch_rows(const UpfirdnParams& p, dim3 g, hipStream_t st) {
     const int mid0 = UP - 1 - p.pady0;
     const int k00 = (agf_floor_div(mid0, UP) + 1) * UP - mid0 - 1;
     static_assert((ROWS * DN) % UP == 0, "strip height must preserve the row phase");
+    if (p.addend) {
+        // the adding variant exists for the adjoint of the 4 x 4 decimation only
+        if constexpr (UP == 2 && DN == 1 && FW == 4 && STRIPS == 1) {
+            if (p.chscale) return false;
+            if (k00 == 0) hipLaunchKernelGGL((upfirdn2d_nhwc_rows<T, VEC, UP, DN, FW, FH, ROWS, 0, PD, false, 1, true>), g, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((upfirdn2d_nhwc_rows<T, VEC, UP, DN, FW, FH, ROWS, 1, PD, false, 1, true>), g, dim3(256), 0, st, p);
+            return true;
+        } else {
+            return false;
+        }
+    }
     if (p.chscale) {
         // the channel-scaled variant exists for the generator's fused upsample + blur only (6 x 6 composite, up 2)
         if constexpr (UP == 2 && DN == 1 && FW == 6) {
@@ -737,7 +764,7 @@ static bool launch_nhwc(const UpfirdnParams& p, hipStream_t st) {
     if (p.upx == ux && p.upy == uy && p.downx == dx && p.downy == dy && p.fw == w && p.fh == h && ux == uy && dx == dy && w == h) { \
         constexpr int ROWS = rows;                                                                        \
         const int64_t wgs = agf_ceil_div((int64_t)p.OW * CG, 256) * agf_ceil_div(p.OH, ROWS * strips) * p.N;   \
-        if (strips > 1 && !p.chscale && wgs >= 1024) {                                                    \
+        if (strips > 1 && !p.chscale && !p.addend && wgs >= 1024) {                                       \
             dim3 gs((unsigned)agf_ceil_div((int64_t)p.OW * CG, 256), (unsigned)agf_ceil_div(p.OH, ROWS * strips), (unsigned)p.N);   \
             return launch_rows<T, VEC, ux, dx, w, h, ROWS, NHWC_STRIP_PD, strips>(pp, gs, st);            \
         }                                                                                                 \
@@ -753,7 +780,7 @@ static bool launch_nhwc(const UpfirdnParams& p, hipStream_t st) {
     NHWC_CASE(2, 2, 1, 1, 6, 6, 8, 1)   // fused Upsample2x -> Blur2d of the StyleGAN2 generator (composite [1,5,10,10,5,1] filter)
     NHWC_CASE(1, 1, 2, 2, 6, 6, 4, 1)   // its adjoint (4 shared rows per strip: carrying them spills)
 #undef NHWC_CASE
-    if (p.chscale) return false;                      // only the row-marching specialisations carry the channel scale
+    if (p.chscale || p.addend) return false;          // only the row-marching specialisations carry the channel scale / the addend
     hipLaunchKernelGGL((upfirdn2d_nhwc_vec<T, VEC, 0, 0, 0, 0, 0, 0>), g, b, 0, st, pp);
     return true;
 }
@@ -768,6 +795,7 @@ static int launch_typed(UpfirdnParams& p, bool dense_nchw, bool dense_nhwc, int 
         if (ok) return AGF_OK;
     }
     if (p.chscale) { agf_set_error("upfirdn2d_chscale: served by the channels-last row kernels only"); return AGF_ENOKERNEL; }
+    if (p.addend) { agf_set_error("upfirdn2d_add: served by the channels-last 4 x 4 up-sampling kernel only"); return AGF_ENOKERNEL; }
     if (dense_nchw && sizeof(T) <= 4 && p.OW >= 64) {
         constexpr bool planar_on = true;
         if constexpr (sizeof(T) <= 4) { if (planar_on && launch_planar_vec_cases<T>(p, st)) return AGF_OK; }
@@ -908,7 +936,7 @@ static int upfirdn2d_impl(const void* x, const float* f, void* y, int dtype,
                           const int32_t f_size[2], const int64_t f_stride[2],
                           const int32_t out_size[4], const int64_t out_stride[4],
                           int upx, int upy, int downx, int downy, int padx0, int pady0,
-                          int flip, float gain, int edge_mode, void* stream, const float* chscale) {
+                          int flip, float gain, int edge_mode, void* stream, const float* chscale, const void* addend = nullptr) {
     // validation mirrors upfirdn2d.cpp:13-34
     AGF_CHECK(x && f && y, "upfirdn2d: null pointer");
     AGF_CHECK(dtype >= AGF_F32 && dtype <= AGF_F64, "upfirdn2d: unsupported dtype %d", dtype);
@@ -934,7 +962,7 @@ static int upfirdn2d_impl(const void* x, const float* f, void* y, int dtype,
     p.upx = upx; p.upy = upy; p.downx = downx; p.downy = downy; p.padx0 = padx0; p.pady0 = pady0;
     p.flip = flip ? 1 : 0; p.clamp_edge = edge_mode == AGF_EDGE_CLAMP; p.gain = gain;
     p.tilesX = p.tilesY = p.tileInW = p.tileInH = 0; p.cg_shift = -1;
-    p.chscale = chscale;
+    p.chscale = chscale; p.addend = addend;
 
     auto dense = [](const int32_t* sz, const int64_t* st, bool nhwc) {
         int64_t N = sz[0], C = sz[1], H = sz[2], W = sz[3];
@@ -978,6 +1006,17 @@ extern "C" int agf_upfirdn2d_chscale(const void* x, const float* f, void* y, con
                           flip, gain, edge_mode, stream, chscale);
 }
 
+extern "C" int agf_upfirdn2d_add(const void* x, const float* f, void* y, const void* addend, int dtype,
+                                 const int32_t in_size[4], const int64_t in_stride[4],
+                                 const int32_t f_size[2], const int64_t f_stride[2],
+                                 const int32_t out_size[4], const int64_t out_stride[4],
+                                 int upx, int upy, int downx, int downy, int padx0, int pady0,
+                                 int flip, float gain, int edge_mode, void* stream) {
+    AGF_CHECK(addend, "upfirdn2d_add: null addend");
+    return upfirdn2d_impl(x, f, y, dtype, in_size, in_stride, f_size, f_stride, out_size, out_stride, upx, upy, downx, downy, padx0, pady0,
+                          flip, gain, edge_mode, stream, nullptr, addend);
+}
+
 extern "C" int agf_upfirdn2d_fold_border(const void* x, const float* f, void* y, int dtype,
                                          const int32_t in_size[4], const int64_t in_stride[4],
                                          const int32_t f_size[2], const int64_t f_stride[2],
@@ -997,6 +1036,7 @@ extern "C" int agf_upfirdn2d_fold_border(const void* x, const float* f, void* y,
     p.upx = upx; p.upy = upy; p.downx = downx; p.downy = downy; p.padx0 = padx0; p.pady0 = pady0;
     p.flip = flip ? 1 : 0; p.clamp_edge = 0; p.gain = gain;
     p.tilesX = p.tilesY = p.tileInW = p.tileInH = 0; p.cg_shift = -1;
+    p.chscale = nullptr; p.addend = nullptr;
     const int per = 2 * p.OW + 2 * (p.OH > 2 ? p.OH - 2 : 0);
     int64_t total = (int64_t)p.N * p.C * per;
     int64_t blocks = agf_ceil_div(total, 256);

@@ -643,7 +643,7 @@ class ConvAct(nn.Module):
         else:
             self.down_filter = None
 
-    def forward(self, x, residual=None):
+    def forward(self, x, residual=None, grad_link=None):
         """``residual`` (only for a bias-free linear 1x1 + down layer on the fused op: the ResBlock's skip branch): the result is
         conv(x) * act_gain + residual out of ONE launch -- the gain folded into the weight coefficient, the sum formed on the fp32
         accumulators (``RES_FUSED``)."""
@@ -662,7 +662,10 @@ class ConvAct(nn.Module):
             # conv2d_resample's "1x1 + down" order (conv2d_resample.py:88-91): FIR-downsample first, then the 1x1 conv on MFMA
             f = self.down_filter
             p0, p1 = (f.shape[-1] - self.down + 1) // 2, (f.shape[-1] - self.down) // 2
-            x = upfirdn2d.upfirdn2d(x, f, down=self.down, padding=[p0, p1, p0, p1])
+            if grad_link is not None:
+                x = _SkipDown.apply(x, f, p0, p1, grad_link)              # (``RES_GRAD_LINK``)
+            else:
+                x = upfirdn2d.upfirdn2d(x, f, down=self.down, padding=[p0, p1, p0, p1])
             if residual is not None:
                 assert self.act_name == 'linear' and self.bias is None
                 return conv2d_act(x.contiguous(memory_format=torch.channels_last), self.weight, None, coef=self.scale * self.act_gain,
@@ -705,6 +708,71 @@ def fir_strided_conv3x3(x, weight, f):
     return upfirdn2d.upfirdn2d(x, f, down=2, padding=0)
 
 
+RES_GRAD_LINK = True   # ResBlock, first-order backward: the gradient of the block input is (data gradient of conv1) + (adjoint of the skip branch's
+#                        decimation); the second term is produced by an up-sampling FIR pass, which takes the first as its addend
+#                        (``agf_upfirdn2d_add``) -- 14 bf16 ``add`` passes over the block inputs less per iteration.  Double-backward passes (R1)
+#                        keep the two differentiable ops and autograd's own sum.
+
+
+class _GradLink:
+    """One per ResBlock call: carries the skip branch's half-resolution gradient from ``_SkipDown.backward`` (which runs first: its node is
+    younger than conv1's) to ``_JoinGrad.backward``.  If the order were ever the other way round (``joined`` already set), the skip branch
+    falls back to returning its own gradient and autograd adds the two."""
+    __slots__ = ('half', 'joined')
+
+    def __init__(self):
+        self.half = None
+        self.joined = False
+
+
+class _SkipDown(torch.autograd.Function):
+    """``upfirdn2d(x, f, down=2, padding=[p0, p1, p0, p1])`` (4 x 4 ``f``) whose first-order backward hands dy to the link instead of
+    launching the adjoint."""
+
+    @staticmethod
+    def forward(ctx, x, f, p0, p1, link):
+        ctx.save_for_backward(f)
+        ctx.geom = (x.shape[2], x.shape[3], p0, p1)
+        ctx.link = link
+        return upfirdn2d._launch(x, f, 1, 1, 2, 2, p0, p1, p0, p1, False, 1.0, 'zero')
+
+    @staticmethod
+    def backward(ctx, dy):
+        f, = ctx.saved_tensors
+        in_h, in_w, p0, p1 = ctx.geom
+        tw = f.shape[-1]
+        adj = [tw - p0 - 1, in_w - dy.shape[3] * 2 + p0, tw - p0 - 1, in_h - dy.shape[2] * 2 + p0]      # (upfirdn2d.py's adjoint padding, up = 1)
+        link = ctx.link
+        if torch.is_grad_enabled() or link.joined:
+            return upfirdn2d.upfirdn2d(dy, f, up=2, padding=adj, flip_filter=True), None, None, None, None
+        link.half = (dy, f, adj)
+        return None, None, None, None, None
+
+
+class _JoinGrad(torch.autograd.Function):
+    """Identity on the way to conv1; its backward adds the skip branch's gradient to conv1's data gradient inside the FIR pass that produces it."""
+
+    @staticmethod
+    def forward(ctx, x, link):
+        ctx.link = link
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        link = ctx.link
+        link.joined = True
+        if link.half is None:
+            return g, None
+        dy, f, adj = link.half
+        link.half = None
+        gc = g.contiguous(memory_format=torch.channels_last)
+        dyc = dy.contiguous(memory_format=torch.channels_last)
+        out = upfirdn2d._launch_add(dyc, f, gc, 2, 2, 1, 1, adj[0], adj[1], adj[2], adj[3], True, 1.0)
+        if out is None:
+            out = upfirdn2d._launch(dyc, f, 2, 2, 1, 1, adj[0], adj[1], adj[2], adj[3], True, 1.0, 'zero') + g
+        return out, None
+
+
 class ResBlock(nn.Module):
     def __init__(self, in_channels, out_channels, filter_size=4, act_name='lrelu', gain=1.) -> None:
         super().__init__()
@@ -713,10 +781,17 @@ class ResBlock(nn.Module):
         self.skip = ConvAct(in_channels, out_channels, 1, False, 2, filter_size, 'linear', gain, 0.5 ** 0.5)
 
     def forward(self, x):
-        t = self.conv2(self.conv1(x))
-        if RES_FUSED and x.is_cuda and x.dtype == torch.bfloat16 and self.skip.bias is None and self.skip.act_name == 'linear' \
-                and self.skip.weight.shape[0] % 8 == 0 and self.skip.weight.shape[1] % 8 == 0:
-            return self.skip(x, residual=t)
+        fused = RES_FUSED and x.is_cuda and x.dtype == torch.bfloat16 and self.skip.bias is None and self.skip.act_name == 'linear' \
+            and self.skip.weight.shape[0] % 8 == 0 and self.skip.weight.shape[1] % 8 == 0
+        link = None
+        if fused and RES_GRAD_LINK and torch.is_grad_enabled() and x.requires_grad and self.skip.down == 2 and self.skip.weight.shape[2] == 1 \
+                and self.skip.down_filter.shape[-1] == 4 and x.shape[1] % 8 == 0:
+            link = _GradLink()
+            t = self.conv2(self.conv1(_JoinGrad.apply(x, link)))
+        else:
+            t = self.conv2(self.conv1(x))
+        if fused:
+            return self.skip(x, residual=t, grad_link=link)
         return t + self.skip(x)
 
 

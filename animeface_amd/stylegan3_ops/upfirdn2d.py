@@ -95,6 +95,27 @@ def _launch(x, f2d, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, ga
     return y
 
 
+def _launch_add(x, f2d, addend, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain):
+    """``_launch`` (zero edges) + ``addend`` in the same pass (``agf_upfirdn2d_add``); None where the adding kernel does not take the call."""
+    N, C, H, W = x.shape
+    fh, fw = f2d.shape
+    ow = (W * upx + padx0 + padx1 - fw + downx) // downx
+    oh = (H * upy + pady0 + pady1 - fh + downy) // downy
+    if not (x.is_cuda and x.dtype in (torch.bfloat16, torch.float32) and (upx, upy, downx, downy, fh, fw) == (2, 2, 1, 1, 4, 4)
+            and C % (8 if x.dtype == torch.bfloat16 else 4) == 0 and x.is_contiguous(memory_format=torch.channels_last)
+            and tuple(addend.shape) == (N, C, oh, ow) and addend.dtype == x.dtype and addend.is_contiguous(memory_format=torch.channels_last)):
+        return None
+    y = torch.empty((N, C, oh, ow), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    rc = _lib.lib().agf_upfirdn2d_add(
+        _lib.ptr(x), _lib.ptr(f2d), _lib.ptr(y), _lib.ptr(addend), _lib.dtype_code(x),
+        _lib.sizes4(x), _lib.strides4(x), _lib._i32x2(fh, fw), _lib._i64x2(*f2d.stride()),
+        _lib.sizes4(y), _lib.strides4(y), upx, upy, downx, downy, padx0, pady0, int(bool(flip)), float(gain), _lib.EDGE_ZERO, _lib.stream_ptr(x))
+    if rc == _lib.AGF_ENOKERNEL:
+        return None
+    _lib.check(rc, 'upfirdn2d_add')
+    return y
+
+
 def _fold_edges(g, rx, ry):
     """Adjoint of replicate padding: fold the rx / ry border columns / rows into the edge pixels."""
     if ry and g.shape[2] - 2 * ry == 1:

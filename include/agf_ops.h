@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define AGF_ABI_VERSION 25
+#define AGF_ABI_VERSION 26
 
 /* element types of activation tensors */
 enum { AGF_F32 = 0, AGF_F16 = 1, AGF_BF16 = 2, AGF_F64 = 3 };
@@ -533,6 +533,17 @@ int agf_upfirdn2d_chscale(const void* x, const float* f, void* y, const float* c
                           int upx, int upy, int downx, int downy, int padx0, int pady0,
                           int flip, float gain, int edge_mode, void* stream);
 int agf_upblur_border_scaled(const void* x, void* y, const float* scale, int dtype, int32_t N, int32_t C, int32_t H, int32_t W, void* stream);
+
+/* agf_upfirdn2d with  y = FIR(x) + addend  (addend: a dense tensor like y; ABI v26).  Served by the channels-last row kernel of the 4 x 4
+ * x2 up-sampling only (AGF_ENOKERNEL otherwise): the adjoint of the 4-tap decimation in front of the skip conv of StyleGAN3's residual
+ * block (reference implementations/StyleGAN3/model.py:419-436: out = conv2(conv1(x)) + skip(x)) -- the gradient of x is the data gradient of
+ * conv1 plus that adjoint, and the sum is formed where the second term is produced instead of in a pass of its own. */
+int agf_upfirdn2d_add(const void* x, const float* f, void* y, const void* addend, int dtype,
+                      const int32_t in_size[4], const int64_t in_stride[4],
+                      const int32_t f_size[2], const int64_t f_stride[2],
+                      const int32_t out_size[4], const int64_t out_stride[4],
+                      int upx, int upy, int downx, int downy, int padx0, int pady0,
+                      int flip, float gain, int edge_mode, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * GPU-side input transform (new: the reference runs torchvision / Pillow transforms in DataLoader worker processes,

@@ -400,6 +400,33 @@ def test_resblock_sum_inside_the_skip_conv_is_as_close_to_fp32_as_the_separate_a
         assert relerr(a, b.cpu()) < 2e-2
 
 
+@pytest.mark.gpu
+def test_resblock_input_gradient_summed_inside_the_fir_pass(monkeypatch):
+    """model.RES_GRAD_LINK: the gradient of a residual block's input = conv1's data gradient + the adjoint of the skip branch's decimation, with
+    the sum formed by the FIR pass (agf_upfirdn2d_add) instead of autograd's bf16 add -- against the unlinked run of the same bf16
+    discriminator (one rounding less: within bf16 noise), for the input and every parameter; and a double-backward (R1-style) pass, which must
+    not use the link at all: the same launches with and without."""
+    from animeface_amd.implementations.StyleGAN3 import model as M
+    torch.manual_seed(3)
+    D = M.Discriminator(64, 3, 16, 64, compute_dtype=torch.bfloat16).to(DEV)
+    x = (torch.rand(6, 3, 64, 64, device=DEV) * 2 - 1)
+    params = [p for p in D.parameters()]
+    first, second = {}, {}
+    for on in (True, False):
+        monkeypatch.setattr(M, 'RES_GRAD_LINK', on)
+        xin = x.clone().requires_grad_(True)
+        out = D(xin)
+        first[on] = [g.float() for g in torch.autograd.grad(out.float().square().sum(), [xin] + params)]
+        xin = x.clone().requires_grad_(True)
+        g, = torch.autograd.grad(D(xin).float().sum(), xin, create_graph=True)
+        second[on] = [t.float() for t in torch.autograd.grad(g.square().sum(), params, allow_unused=True) if t is not None]
+    for a, b in zip(first[True], first[False]):
+        assert float((a - b).abs().mean()) <= 1.5e-2 * float(b.abs().mean()) + 1e-6
+    assert len(second[True]) == len(second[False]) > 0
+    for a, b in zip(second[True], second[False]):        # (the same launches; the weight gradients' fp32 atomics are not bit-reproducible run to run)
+        assert float((a - b).abs().mean()) <= 1e-3 * float(b.abs().mean()) + 1e-9
+
+
 def test_hip_model_vs_cpu_oracle_on_a_second_configuration():
     """A configuration / seed the fixtures do not contain: HIP fp32 networks against the CPU oracle (oracle/stylegan3.py, itself
     pinned to the reference by tests/test_oracle_sg3.py) on the same state_dict."""
