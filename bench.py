@@ -113,7 +113,7 @@ def upfirdn2d_roofline(dev, batch=64, reps=20):
                              'achieved': round(nbytes / sec / 1e9, 1), 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': round(nbytes / sec / HBM_PEAK, 4)})
         del x128, x256
     return {'bound': 'hbm', 'rows': rows, 'target': 'north_star: >= 0.60 on upfirdn2d at 256x256',
-            'traffic': 'PMC passes (FETCH_SIZE x2 + WRITE_SIZE): profiles/r04b_upfirdn_hbm_pmc.txt'}
+            'traffic': 'PMC passes (FETCH_SIZE x2 + WRITE_SIZE): profiles/r05_upfirdn_hbm_pmc.txt'}
 
 
 def measured_traffic():
