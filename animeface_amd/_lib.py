@@ -216,6 +216,8 @@ def ensure_split_workspace(device):
         return
     buf = _split_ws.get(idx)
     if buf is None:
+        if torch.cuda.is_current_stream_capturing():
+            return                              # (no allocation inside a recording: those launches run unsliced until an eager launch has set the buffer up)
         buf = _split_ws[idx] = torch.zeros(SPLIT_WS_BYTES, dtype=torch.uint8, device=device)
     check(lib().agf_conv2d_set_split_workspace(_vp(buf.data_ptr()), SPLIT_WS_BYTES), 'conv2d_set_split_workspace')
     _split_ws_dev = idx

@@ -1,11 +1,11 @@
 #!/bin/bash
 # Kernel trace of graph-replayed StyleGAN3-T iterations (adversarial loss only), cut at the once-per-iteration sine kernel of the Fourier-feature
 # input, averaged over the last full iterations and grouped by family (cf. tools/iter_breakdown.sh for StyleGAN2).
-#   bash tools/iter_breakdown_sg3.sh OUT.txt [image size] [batch]
+#   bash tools/iter_breakdown_sg3.sh OUT.txt [image size] [batch] [extra bench_sg3.py arguments]
 out=${1:-gpurun_out/iter_breakdown_sg3.txt}; size=${2:-512}; batch=${3:-16}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p $(dirname $out)
-rm -rf /tmp/itb3; rocprofv3 --kernel-trace --output-format csv -d /tmp/itb3 -o g -- python tools/bench_sg3.py --image-size $size --batch $batch --steps 12 --warmup 2 > /tmp/itb3_bench.log 2>&1
+rm -rf /tmp/itb3; rocprofv3 --kernel-trace --output-format csv -d /tmp/itb3 -o g -- python tools/bench_sg3.py --image-size $size --batch $batch --steps 12 --warmup 2 "${@:4}" > /tmp/itb3_bench.log 2>&1
 tail -1 /tmp/itb3_bench.log | cut -c1-260 > $out
 python - >> $out <<'PY'
 import csv, glob, collections, re
