@@ -901,10 +901,12 @@ __global__ void __launch_bounds__(NT, 4) flr_rb_kernel(FlrRbParams P) {
                 const __bf16* ap = sXb + (32 * rb + l31) * P.XPb + 8 * cb + 8 * lhi;
 #pragma unroll
                 for (int jy = 0; jy < 6; jy++) {
+                    if (P.skip & 2048) break;                       // (profiling builds: the block loop without its reads and MFMAs)
                     const flr_bf16x8 A = *(const flr_bf16x8*)(ap + jy * P.XPb);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B[2 * jy], acc, 0, 0, 0);
                     accl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B[2 * jy + 1], accl, 0, 0, 0);
                 }
+                if (P.skip & 4096) continue;                        // (profiling builds: without the sign / gain / store part of a block)
 #pragma unroll
                 for (int e = 0; e < 16; e++) acc[e] += accl[e];
                 // lane: output column rux, output rows 2 (32 rb + m) + a - dy for m = 8 rg + 4 lhi + e  (acc[4 rg + e])
