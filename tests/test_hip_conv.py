@@ -842,3 +842,26 @@ def test_channel_sliced_small_map_launch_is_run_to_run_bit_identical():
     y0 = C.conv2d_fwd_raw(x, wq, in_scale=s_in, prepared=True)
     for _ in range(20):
         assert torch.equal(C.conv2d_fwd_raw(x, wq, in_scale=s_in, prepared=True), y0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('seed', range(12))
+def test_small_map_launches_random_shapes_vs_aten(seed):
+    """4x4 ... 8x8 maps with >= 128 channels each way: the 64-pixel tiles, with and without input-channel slices (<= 128 tiles: sliced), co tiles
+    over the XCDs or not, ragged maps, channel tails, odd batches, with and without a style scale -- against ATen, three launches each (the
+    in-launch combine of the slices must give the same bits every time)."""
+    from animeface_amd.implementations.StyleGAN2.conv import conv2d_fwd_raw, ACT_LRELU
+    g = torch.Generator(device='cpu').manual_seed(1000 + seed)
+    H = int(torch.randint(4, 9, (1,), generator=g)); W = int(torch.randint(4, 9, (1,), generator=g))
+    N = int(torch.randint(8, 131, (1,), generator=g))
+    Cin = 8 * int(torch.randint(16, 66, (1,), generator=g)); Cout = 8 * int(torch.randint(16, 66, (1,), generator=g))
+    scaled = bool(seed & 1)
+    x = torch.randn(N, Cin, H, W, generator=g).to(torch.bfloat16).to(DEV).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).to(torch.bfloat16).to(DEV)
+    s_in = (torch.rand(N, Cin, generator=g) + 0.5).to(DEV) if scaled else None
+    bias = torch.randn(Cout, generator=g).to(DEV)
+    ys = [conv2d_fwd_raw(x, w, in_scale=s_in, bias=bias, act=ACT_LRELU, alpha=0.2, gain=1.0) for _ in range(3)]
+    assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2]), (N, Cin, Cout, H, W)
+    xf = x.float() * (s_in[:, :, None, None] if scaled else 1.0)
+    ref = F.leaky_relu(F.conv2d(xf, w.float(), padding=1) + bias[None, :, None, None], 0.2)
+    assert rel(ys[0], ref) < (1.2e-2 if scaled else 6e-3), (N, Cin, Cout, H, W)
