@@ -823,8 +823,21 @@ class recording_plans:
         _prep_plans = self.prev
 
 
+def padded_weight(param, mult=8):
+    """``param`` with its input-channel axis zero-padded to a multiple of ``mult`` (an ordinary autograd op) that remembers where it came from:
+    ``prepared_weights`` then takes the operand layouts of the PADDED tensor from the parameter's entry in the iteration's prepared-weight cache
+    (``agf_prep_weights_pad`` inside the ``PrepPlan`` launch) instead of preparing the derived tensor per call."""
+    w = _pad_channels(param, mult, 1)
+    if w is not param and isinstance(param, torch.nn.Parameter):
+        w._agf_pad_src = (param, (w.shape[0], w.shape[1]))
+    return w
+
+
 def prepared_weights(weight, coef, dtype, need_ft=False, pad=None):
     import weakref
+    src = getattr(weight, '_agf_pad_src', None)
+    if src is not None and pad is None and _prep_cache_on:
+        return prepared_weights(src[0], coef, dtype, need_ft=need_ft, pad=src[1])
     cacheable = _prep_cache_on and isinstance(weight, torch.nn.Parameter)
     if pad is not None and tuple(pad) == (weight.shape[0], weight.shape[1]):
         pad = None
@@ -1460,7 +1473,7 @@ def conv2d_act(x, weight, bias=None, s_in=None, s_out=None, noise=None, alpha=0.
                 x = layout.planar_to_channels_last(x, 0, (Cin + 7) // 8 * 8)
             else:
                 x = _pad_channels(x, 8, 1).contiguous(memory_format=torch.channels_last)
-            weight = _pad_channels(weight, 8, 1)
+            weight = padded_weight(weight, 8)
             s_in = _pad_channels(s_in, 8, 1) if s_in is not None else None
             pre_link = None                           # the link describes the UNPADDED input tensor
             if skip_pool is not None:                 # (not a case the networks produce: pool the unpadded tensor separately)
@@ -1472,7 +1485,7 @@ def conv2d_act(x, weight, bias=None, s_in=None, s_out=None, noise=None, alpha=0.
                                 ACT_LRELU if act == 'lrelu' else ACT_LINEAR, alpha, gain, pre_link, post_link, skip_pool, post_scale, out_pool, skip_link)
     assert out_pool is None, 'out_pool is a feature of the fused path'
     x_in = x
-    out = conv2d(x, weight * coef if coef != 1.0 else weight, s_in, s_out)
+    out = conv2d(x, scaled_weight(weight, coef) if coef != 1.0 else weight, s_in, s_out)      # (tagged: the layouts come from the iteration's cache)
     if noise is not None:
         out = out + noise.to(out.dtype)
     if residual is not None:
